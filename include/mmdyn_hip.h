@@ -1,0 +1,207 @@
+/*
+ * mmdyn_hip.h -- C ABI of libmmdyn_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * cnn-mvae / cnn-vae training and inference hot path of SAIC-MONTREAL/multimodal-dynamics.
+ *
+ * The reference has no native boundary: the path sits behind torch.nn modules
+ * (mmdyn/pytorch/models/vae.py) and torch.nn.functional losses (mmdyn/pytorch/problems/problems.py).
+ * Every entry point below replaces the stock ATen op(s) named in its comment (reference file:line),
+ * and is what a maintainer would bind with ctypes from those modules.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to fp32 unless stated; no allocation, no ownership transfer;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work (graph-capturable);
+ *   - return value: 0 = ok, MMDYN_ERR_* (<0) = argument error detected on the host before launch,
+ *     >0 = hipError_t of the launch;
+ *   - activations between layers are kept channels-last: a [rows][C] matrix whose row index is
+ *     (sample, y, x); the reference's NCHW tensors appear only at the image input / logits output;
+ *   - "groups": a batch of G*Bg samples made of G independent sub-batches (one per modality-subset
+ *     pass of _evaluate_mvae, problems.py:473-546); train-mode BatchNorm statistics are per group.
+ */
+#ifndef MMDYN_HIP_H
+#define MMDYN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMDYN_OK 0
+#define MMDYN_ERR_SHAPE (-1)   /* dimension not supported by the kernel (see each function) */
+#define MMDYN_ERR_NULL (-2)    /* required pointer is null */
+#define MMDYN_ERR_RANGE (-3)   /* tensor too large for 32-bit element offsets */
+
+#define MMDYN_ACT_NONE 0
+#define MMDYN_ACT_SWISH 1      /* x * sigmoid(x), vae.py:331-334 */
+#define MMDYN_ACT_RELU 2
+
+/* implicit-GEMM modes (k = 4 everywhere, as in vae.py:198-206, 268-277) */
+#define MMDYN_DENSE 0          /* plain rows x Cin matrix (nn.Linear, and the col-matrix GEMMs) */
+#define MMDYN_CONV 1           /* gather form: out(r,c) <- in(r*s+o+kh, c*s+o+kw), 16 taps */
+#define MMDYN_TCONV_S2P1 2     /* transposed k4 s2 p1, four output-parity classes of 4 taps each */
+
+const char* mmdyn_version(void);
+
+/* ---- MFMA implicit GEMM, "NT" form ---------------------------------------------------------
+ * C[row][n] = act( sum_{tap,ci} A_tap[row][ci] * Bp[widx(tap)][n][ci] + bias[n] )
+ * Replaces: nn.Conv2d forward (vae.py:200,203,206), nn.ConvTranspose2d forward (vae.py:271,274),
+ * their input-gradient kernels, and nn.Linear forward / input-gradient (vae.py:211,215,216,264).
+ *   A      : NHWC activations [G*Bg][Hi][Wi][Cin]
+ *   Bp     : packed weights [taps][N][Cin] (see mmdyn_pack_conv_weight)
+ *   C      : NHWC output [G*Bg][Ho][Wo] rows of stride ldc (>= N); pre-activation (+bias)
+ *   C_act  : optional second output = act(C) (null: none)
+ *   stats  : optional per-tile BatchNorm partial sums [G][T][2][N], T = mmdyn_igemm_stat_tiles(...)
+ *   splitk : >1 only for DENSE: partial products go to `ws` ([splitk][rows][N]) and
+ *            mmdyn_splitk_reduce finishes (bias/act/second output are applied there).
+ * Requirements: Cin % 32 == 0, N % 32 == 0.  v_mfma_f32_32x32x2_f32, fp32 in / fp32 accumulate. */
+int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
+                   float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
+                   int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
+                   void* stream);
+int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Ho, int Wo, int N);
+int mmdyn_splitk_reduce(const float* ws, const float* bias, float* C, float* C_act, int splitk,
+                        int rows, int N, int act, void* stream);
+
+/* ---- MFMA weight gradient, "TN" form -------------------------------------------------------
+ * partial[chunk][tap][cd][cg] = sum_{rows in chunk} D[row][cd] * G_tap[row][cg]
+ * Replaces the weight-gradient kernels of Conv2d / ConvTranspose2d / Linear.
+ *   D  : dense rows [Bt*Hr*Wr][Cd];  Gt : gathered operand, NHWC [Bt][Hi][Wi][Cg]
+ *   mode DENSE: one tap, Gt rows == D rows.  mode CONV: 16 taps, pixel (r*s+o+kh, c*s+o+kw).
+ * mmdyn_wgrad_reduce sums the chunks and writes the reference's canonical layout:
+ *   perm 0: canon[cd][cg][tap] (conv [Cout][Cin][4][4] / convT [Cin][Cout][4][4]; Linear [out][in])
+ *   perm 1: linear with permuted columns, cg = hw*256+c -> canon[cd][c*25+hw]  (Encoder fc_net.0)
+ *   perm 2: linear with permuted rows,    cd = hw*256+c -> canon[c*25+hw][cg]  (Decoder upsample.0)
+ *   cg_canon <= Cg drops zero-padded gathered columns (the 48 -> 64 padded first/last layers).
+ * Requirements: Cd % 32 == 0, Cg % 32 == 0. */
+int mmdyn_wgrad_tn(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr, int Wr,
+                   int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks, void* stream);
+/* recommended `chunks` (a multiple of 4) for mmdyn_wgrad_tn; partial must hold chunks*taps*Cd*Cg floats */
+int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg);
+int mmdyn_wgrad_reduce(const float* partial, float* canon, int chunks, int taps, int Cd, int Cg,
+                       int cg_canon, int perm, float beta, void* stream);
+
+/* ---- weight packing (canonical reference layout -> GEMM operand layout) --------------------- */
+/* Wc[d0][d1][16] -> P[tap][d0][d1] (swap=0) or P[tap][d1][d0] (swap=1) */
+int mmdyn_pack_conv_weight(const float* Wc, float* P, int d0, int d1, int swap, void* stream);
+/* generic 2-D repack: out[r][c] (rows_out x cols_out, zero padded) = in[...] with
+ * mode 0: copy/pad in[r][c] (in is rows_in x cols_in)
+ * mode 1: transpose  out[r][c] = in[c][r]
+ * mode 2: column permute out[r][hw*256+ch] = in[r][ch*25+hw]
+ * mode 3: row permute    out[hw*256+ch][c] = in[ch*25+hw][c]
+ * mode 4: transpose of mode 2: out[hw*256+ch][c] = in[c][ch*25+hw]
+ * mode 5: transpose of mode 3: out[r][hw*256+ch] = in[ch*25+hw][r] */
+int mmdyn_repack2d(const float* in, float* out, int rows_in, int cols_in, int rows_out, int cols_out,
+                   int mode, void* stream);
+
+/* ---- first / last layer helpers (3-channel NCHW side) --------------------------------------- */
+/* col[(b*Ho+ho)*Wo+wo][ci*16+kh*4+kw] = x[b][ci][2ho-1+kh][2wo-1+kw], columns 48..63 zero.
+ * x: NCHW [Bt][3][H][W]; col: [Bt*(H/2)*(W/2)][64].  Lowers nn.Conv2d(3,32,4,2,1) (vae.py:198) and the
+ * backward of nn.ConvTranspose2d(32,3,4,2,1) (vae.py:277) onto the MFMA GEMMs above. */
+int mmdyn_im2col_nchw3(const float* x, float* col, int Bt, int H, int W, void* stream);
+/* transposed-conv scatter as a gather: out(ho,wo,c) = sum_{kh,kw} col[(hi,wi)][...], hi=(ho+p-kh)/s.
+ *   tap_major=1: col column = tap*C + c (NHWC out, [Bt][Ho][Wo][C]);
+ *   tap_major=0: col column = c*16 + tap and the output is NCHW [Bt][C][Ho][Wo] (logits). */
+int mmdyn_col2im_k4(const float* col, float* out, int Bt, int Hi, int Wi, int Ho, int Wo, int C,
+                    int ldcol, int stride, int pad, int tap_major, void* stream);
+
+/* ---- train-mode BatchNorm2d + Swish, channels-last, per group (vae.py:201-208, 269-276) ----- */
+/* column sums of y and y*y over row chunks -> partial[G][T][2][C], T = mmdyn_colstats_tiles(rows_per_group) */
+int mmdyn_colstats(const float* y, float* partial, int G, int rows_per_group, int C, void* stream);
+int mmdyn_colstats_tiles(int rows_per_group);
+/* partial -> mean/rstd [G][C]; running stats EMA (momentum 0.1, unbiased var) applied for the groups in
+ * order, `repeat` times each (the reference re-runs identical encoder trunks: SURVEY.md 3.2);
+ * num_batches_tracked (int64) += G*repeat.  running_* may be null. */
+int mmdyn_bn_finalize(const float* partial, float* mean, float* rstd, float* running_mean,
+                      float* running_var, int64_t* num_batches_tracked, double* scratch /* [G][2][C] */,
+                      int G, int T, int C, int rows_per_group, float eps, float momentum, int repeat,
+                      void* stream);
+/* a = swish(gamma*(y-mean)*rstd + beta) */
+int mmdyn_bn_swish_fwd(const float* y, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, float* a, int G, int rows_per_group, int C, void* stream);
+/* backward, two launches: reduce -> sums[G][2][C] (+ dgamma/dbeta accumulated), then apply -> dy */
+int mmdyn_bn_swish_bwd_reduce(const float* da, const float* y, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, float* partial, int G,
+                              int rows_per_group, int C, void* stream);
+int mmdyn_bn_bwd_finalize(const float* partial, float* sums, float* dgamma, float* dbeta,
+                          double* scratch /* [G][2][C] */, int G, int T, int C, float beta_acc,
+                          void* stream);
+int mmdyn_bn_swish_bwd_apply(const float* da, const float* y, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, const float* sums, float* dy, int G,
+                             int rows_per_group, int C, void* stream);
+
+/* ---- element-wise ---------------------------------------------------------------------------- */
+int mmdyn_act_fwd(const float* u, float* h, int64_t n, int act, void* stream);
+/* du = dh * act'(u) */
+int mmdyn_act_bwd(const float* dh, const float* u, float* du, int64_t n, int act, void* stream);
+/* nn.Dropout(p) with injected keep-masks (vae.py:213): out[p][b][:] = h[b][:] * mask[p][b][:] / (1-p_drop)
+ * for P passes sharing one trunk output h[B][H];  backward sums the P masked gradients. */
+int mmdyn_dropout_expand(const float* h, const uint8_t* masks, float* out, int P, int B, int H,
+                         float p_drop, void* stream);
+int mmdyn_dropout_reduce(const float* dout, const uint8_t* masks, float* dh, int P, int B, int H,
+                         float p_drop, void* stream);
+/* keep-masks from a counter-based generator (throughput runs; parity runs inject masks) */
+int mmdyn_random_masks(uint8_t* masks, int64_t n, float p_drop, uint64_t seed, uint64_t offset, void* stream);
+int mmdyn_random_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* out[c] (+)= sum_r x[r][c]   (bias gradients) */
+int mmdyn_colsum(const float* x, float* out, int rows, int C, int perm, float beta, void* stream);
+/* sum of P row blocks: out[b][:] = sum_p x[p][b][:] */
+int mmdyn_sum_blocks(const float* x, float* out, int P, int64_t n, void* stream);
+/* tiny Linear layers of the 7-DoF pose MLP (K or N == 7; vae.py:117-123): y = x W^T + b */
+int mmdyn_linear_small_fwd(const float* x, const float* W, const float* b, float* y, int rows, int K,
+                           int N, int act, void* stream);
+int mmdyn_linear_small_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW,
+                           float* db, int rows, int K, int N, float beta, void* stream);
+
+/* ---- product of experts + reparametrisation + KL (vae.py:311-318, 52-61; problems.py:429) --- */
+#define MMDYN_MAX_PASSES 8
+#define MMDYN_MAX_EXPERTS 4
+typedef struct {
+  const float* mu[MMDYN_MAX_EXPERTS];   /* expert means (visual, tactile, pose, spare); null = absent */
+  const float* lv[MMDYN_MAX_EXPERTS];   /* expert log-variances */
+  float* dmu[MMDYN_MAX_EXPERTS];        /* backward outputs (same shapes/strides) */
+  float* dlv[MMDYN_MAX_EXPERTS];
+  int ld[MMDYN_MAX_EXPERTS];            /* row stride of the expert tensors (heads are stored fused: [rows][2L]) */
+} mmdyn_pass_experts;
+/* P passes of [B][L].  with_prior=1 adds the universal N(0,1) expert first (vae.py:139, 321-328).
+ * Outputs mu/logvar [P][B][L]; optional z = eps*exp(logvar/2)+mu; optional kl_sum[p] (double)
+ * += -0.5*sum(1+lv-mu^2-e^lv).  eps added twice to each variance, as the reference does. */
+int mmdyn_poe_fwd(const mmdyn_pass_experts* passes, const float* eps_noise, float* mu, float* logvar,
+                  float* z, double* kl_sum, int with_prior, int P, int B, int L, void* stream);
+/* upstream gradients: dz [P][B][L] (through z), g_mu / g_lv [P][B][L] (directly on the fused mu/logvar),
+ * any may be null; kl_scale = kl_weight / B adds the KL term's gradient. */
+int mmdyn_poe_bwd(const mmdyn_pass_experts* passes, const float* eps_noise, const float* mu,
+                  const float* logvar, const float* dz, const float* g_mu, const float* g_lv, float kl_scale,
+                  int with_prior, int P, int B, int L, void* stream);
+/* single-expert path (VAE, vae.py:81-88): reparametrisation and/or KL on mu/lv rows of stride ld */
+int mmdyn_reparam_fwd(const float* mu, const float* lv, const float* eps_noise, float* z, double* kl_sum,
+                      int B, int L, int ld, void* stream);
+int mmdyn_reparam_bwd(const float* mu, const float* lv, const float* eps_noise, const float* dz,
+                      float kl_scale, float* dmu, float* dlv, int B, int L, int ld, void* stream);
+
+/* ---- ELBO reconstruction terms (problems.py:433-449) ----------------------------------------- */
+/* sum over all elements of BCE-with-logits(x, t) added to *loss_sum (double); optional dlogit =
+ * (sigmoid(x) - t) * grad_scale.  With `mask` (broadcast over channels: [B][1][H][W]) both logits and
+ * targets are multiplied by it first (problems.py:445-447). */
+int mmdyn_bce_logits(const float* logits, const float* target, const float* mask, float* dlogit,
+                     double* loss_sum, int64_t n, int chw, int hw, float grad_scale, void* stream);
+/* sum (r-t)^2 added to *loss_sum; dr = 2 (r-t) grad_scale */
+int mmdyn_mse(const float* r, const float* t, float* dr, double* loss_sum, int64_t n, float grad_scale,
+              void* stream);
+/* loss[0] = (sum_p bce[p] + pose_multiplier * mse[p] + kl_weight * kl[p]) / B; partial[p] likewise */
+int mmdyn_elbo_assemble(const double* bce, const double* mse, const double* kl, float* loss, float* partials,
+                        int P, int B, float kl_weight, float pose_multiplier, void* stream);
+
+/* ---- Adam (torch.optim.Adam defaults, problems.py:137-138) ----------------------------------- */
+/* state: 3 doubles {step count, step size, sqrt(bias_correction2)}, advanced on the device by this call
+ * (graph-replay safe); p/g/m/v: flat fp32 buffers of n elements; g is multiplied by grad_scale first */
+int mmdyn_adam_step(float* p, const float* g, float* m, float* v, double* state, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* ---- misc ------------------------------------------------------------------------------------- */
+int mmdyn_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, void* stream);
+int mmdyn_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,282 @@
+// Train-mode BatchNorm2d (+ fused Swish) on channels-last [rows][C] activations, statistics per group.
+// Replaces nn.BatchNorm2d + Swish forward/backward of the reference
+// (/root/reference/mmdyn/pytorch/models/vae.py:201-208, 269-276, 331-334): batch mean / biased variance
+// over (B, H, W), eps 1e-5, affine, running estimates with momentum 0.1 and the unbiased variance.
+// All kernels are HBM-bound: 16-byte lane accesses along the channel axis, column sums by
+// per-thread accumulation + one LDS pass, per-tile partials (no atomics, deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int TILE_ROWS = 512;
+
+struct StatFwd {
+  __device__ __forceinline__ void operator()(float y, int, int, float& a, float& b) const {
+    a = y;
+    b = y * y;
+  }
+};
+
+struct BnParams {
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* beta;
+};
+
+// column sums of two per-element quantities over a tile of rows -> partial[g][t][2][C]
+// MODE 0: (y, y^2).  MODE 1: (du, du * xhat) with du = da * swish'(gamma*xhat+beta).
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ y,
+                                                        const float* __restrict__ da, BnParams bp,
+                                                        float* __restrict__ partial, int rows_per_group,
+                                                        int C, int T) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  const int g = blockIdx.y, t = blockIdx.x;
+  const int CV = C >> 2;        // float4 columns (8..64)
+  const int RL = 256 / CV;      // row lanes
+  const int rl = tid / CV, cv = tid - rl * CV;
+  const int r_begin = t * TILE_ROWS;
+  const int r_end = min(rows_per_group, r_begin + TILE_ROWS);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 mean4, rstd4, gam4, bet4;
+  if (MODE == 1 && rl < RL) {
+    mean4 = *reinterpret_cast<const f32x4*>(bp.mean + (size_t)g * C + cv * 4);
+    rstd4 = *reinterpret_cast<const f32x4*>(bp.rstd + (size_t)g * C + cv * 4);
+    gam4 = *reinterpret_cast<const f32x4*>(bp.gamma + cv * 4);
+    bet4 = *reinterpret_cast<const f32x4*>(bp.beta + cv * 4);
+  }
+  if (rl < RL) {
+    const size_t base = (size_t)g * rows_per_group;
+    for (int r = r_begin + rl; r < r_end; r += RL) {
+      const size_t off = (base + r) * C + cv * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
+      if (MODE == 0) {
+        s0 += v;
+        s1 += v * v;
+      } else {
+        f32x4 d = *reinterpret_cast<const f32x4*>(da + off);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float xh = (v[k] - mean4[k]) * rstd4[k];
+          float u = gam4[k] * xh + bet4[k];
+          float du = d[k] * swish_gradf_(u);
+          s0[k] += du;
+          s1[k] += du * xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[tid * 8 + k] = s0[k];
+    red[tid * 8 + 4 + k] = s1[k];
+  }
+  __syncthreads();
+  if (tid < C) {
+    const int cv2 = tid >> 2, k = tid & 3;
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < RL; ++l) {
+      a += red[(l * CV + cv2) * 8 + k];
+      b += red[(l * CV + cv2) * 8 + 4 + k];
+    }
+    const size_t o = ((size_t)(g * T + t) * 2) * C + tid;
+    partial[o] = a;
+    partial[o + C] = b;
+  }
+}
+
+// sums over the T tile partials of one group, 32 channels per block: out[g][2][C] (double accumulate)
+__global__ __launch_bounds__(256) void tile_sum_kernel(const float* __restrict__ partial,
+                                                       double* __restrict__ out, int T, int C) {
+  __shared__ double red[2][8][32];
+  const int g = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31), tl = threadIdx.x >> 5;
+  double a = 0.0, b = 0.0;
+  for (int t = tl; t < T; t += 8) {
+    const size_t o = ((size_t)(g * T + t) * 2) * C + c;
+    a += (double)partial[o];
+    b += (double)partial[o + C];
+  }
+  red[0][tl][threadIdx.x & 31] = a;
+  red[1][tl][threadIdx.x & 31] = b;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5, cc = threadIdx.x & 31;
+    double s = 0.0;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) s += red[which][l][cc];
+    out[((size_t)g * 2 + which) * C + blockIdx.x * 32 + cc] = s;
+  }
+}
+
+__global__ void bn_stats_finish_kernel(const double* __restrict__ sums, float* __restrict__ mean,
+                                       float* __restrict__ rstd, float* __restrict__ running_mean,
+                                       float* __restrict__ running_var, int64_t* __restrict__ nbt, int G,
+                                       int C, int n, float eps, float momentum, int repeat) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float rm = running_mean ? running_mean[c] : 0.f;
+  float rv = running_var ? running_var[c] : 0.f;
+  for (int g = 0; g < G; ++g) {
+    double m = sums[((size_t)g * 2 + 0) * C + c] / n;
+    double var = sums[((size_t)g * 2 + 1) * C + c] / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[(size_t)g * C + c] = (float)m;
+    rstd[(size_t)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    float unb = (float)(var * ((double)n / (double)(n > 1 ? n - 1 : 1)));
+    for (int k = 0; k < repeat; ++k) {
+      rm = (1.f - momentum) * rm + momentum * (float)m;
+      rv = (1.f - momentum) * rv + momentum * unb;
+    }
+  }
+  if (running_mean) running_mean[c] = rm;
+  if (running_var) running_var[c] = rv;
+  if (nbt && c == 0) *nbt += (int64_t)G * repeat;
+}
+
+__global__ void bn_swish_fwd_kernel(const float* __restrict__ y, BnParams bp, float* __restrict__ a,
+                                    int64_t total4, int rows_per_group, int C) {
+  const int CV = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const int64_t row = i / CV;
+    const int g = (int)(row / rows_per_group);
+    f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+    f32x4 m = *reinterpret_cast<const f32x4*>(bp.mean + (size_t)g * C + cv * 4);
+    f32x4 r = *reinterpret_cast<const f32x4*>(bp.rstd + (size_t)g * C + cv * 4);
+    f32x4 ga = *reinterpret_cast<const f32x4*>(bp.gamma + cv * 4);
+    f32x4 be = *reinterpret_cast<const f32x4*>(bp.beta + cv * 4);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = swishf_(ga[k] * ((v[k] - m[k]) * r[k]) + be[k]);
+    reinterpret_cast<f32x4*>(a)[i] = o;
+  }
+}
+
+__global__ void bn_bwd_param_kernel(const double* __restrict__ sums, float* __restrict__ sums_f,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int C,
+                                    float beta_acc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sb = 0.0, sg = 0.0;
+  for (int g = 0; g < G; ++g) {
+    double a = sums[((size_t)g * 2 + 0) * C + c], b = sums[((size_t)g * 2 + 1) * C + c];
+    sums_f[((size_t)g * 2 + 0) * C + c] = (float)a;
+    sums_f[((size_t)g * 2 + 1) * C + c] = (float)b;
+    sb += a;
+    sg += b;
+  }
+  if (dbeta) dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)sb;
+  if (dgamma) dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)sg;
+}
+
+__global__ void bn_swish_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ y,
+                                          BnParams bp, const float* __restrict__ sums,
+                                          float* __restrict__ dy, int64_t total4, int rows_per_group, int C) {
+  const int CV = C >> 2;
+  const float inv_n = 1.f / (float)rows_per_group;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const int64_t row = i / CV;
+    const int g = (int)(row / rows_per_group);
+    f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+    f32x4 d = reinterpret_cast<const f32x4*>(da)[i];
+    f32x4 m = *reinterpret_cast<const f32x4*>(bp.mean + (size_t)g * C + cv * 4);
+    f32x4 r = *reinterpret_cast<const f32x4*>(bp.rstd + (size_t)g * C + cv * 4);
+    f32x4 ga = *reinterpret_cast<const f32x4*>(bp.gamma + cv * 4);
+    f32x4 be = *reinterpret_cast<const f32x4*>(bp.beta + cv * 4);
+    f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + ((size_t)g * 2 + 0) * C + cv * 4);
+    f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + ((size_t)g * 2 + 1) * C + cv * 4);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float xh = (v[k] - m[k]) * r[k];
+      float u = ga[k] * xh + be[k];
+      float du = d[k] * swish_gradf_(u);
+      o[k] = ga[k] * r[k] * (du - s0[k] * inv_n - xh * (s1[k] * inv_n));
+    }
+    reinterpret_cast<f32x4*>(dy)[i] = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int mmdyn_colstats_tiles(int rows_per_group) { return ceil_div(rows_per_group, TILE_ROWS); }
+
+static bool bn_shape_ok(int G, int rows_per_group, int C) {
+  return G > 0 && rows_per_group > 0 && C >= 32 && C <= 256 && (C % 32) == 0 && (256 % (C / 4)) == 0 &&
+         true;
+}
+
+extern "C" int mmdyn_colstats(const float* y, float* partial, int G, int rows_per_group, int C, void* stream) {
+  if (!y || !partial) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
+  const int T = ceil_div(rows_per_group, TILE_ROWS);
+  BnParams bp{};
+  hipLaunchKernelGGL(colreduce_kernel<0>, dim3(T, G), dim3(256), 0, (hipStream_t)stream, y, nullptr, bp,
+                     partial, rows_per_group, C, T);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bn_finalize(const float* partial, float* mean, float* rstd, float* running_mean,
+                                 float* running_var, int64_t* nbt, double* g_sums, int G, int T, int C,
+                                 int rows_per_group, float eps, float momentum, int repeat, void* stream) {
+  if (!partial || !mean || !rstd || !g_sums) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, rows_per_group, C) || T <= 0) return MMDYN_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(tile_sum_kernel, dim3(C / 32, G), dim3(256), 0, st, partial, g_sums, T, C);
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, g_sums, mean, rstd,
+                     running_mean, running_var, nbt, G, C, rows_per_group, eps, momentum, repeat);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bn_swish_fwd(const float* y, const float* mean, const float* rstd, const float* gamma,
+                                  const float* beta, float* a, int G, int rows_per_group, int C,
+                                  void* stream) {
+  if (!y || !mean || !rstd || !gamma || !beta || !a) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
+  BnParams bp{mean, rstd, gamma, beta};
+  int64_t total4 = (int64_t)G * rows_per_group * (C / 4);
+  hipLaunchKernelGGL(bn_swish_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, bp, a,
+                     total4, rows_per_group, C);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bn_swish_bwd_reduce(const float* da, const float* y, const float* mean,
+                                         const float* rstd, const float* gamma, const float* beta,
+                                         float* partial, int G, int rows_per_group, int C, void* stream) {
+  if (!da || !y || !mean || !rstd || !gamma || !beta || !partial) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
+  const int T = ceil_div(rows_per_group, TILE_ROWS);
+  BnParams bp{mean, rstd, gamma, beta};
+  hipLaunchKernelGGL(colreduce_kernel<1>, dim3(T, G), dim3(256), 0, (hipStream_t)stream, y, da, bp, partial,
+                     rows_per_group, C, T);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bn_bwd_finalize(const float* partial, float* sums, float* dgamma, float* dbeta,
+                                     double* g_sums, int G, int T, int C, float beta_acc, void* stream) {
+  if (!partial || !sums || !g_sums) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, 1, C) || T <= 0) return MMDYN_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(tile_sum_kernel, dim3(C / 32, G), dim3(256), 0, st, partial, g_sums, T, C);
+  hipLaunchKernelGGL(bn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, g_sums, sums, dgamma,
+                     dbeta, G, C, beta_acc);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bn_swish_bwd_apply(const float* da, const float* y, const float* mean,
+                                        const float* rstd, const float* gamma, const float* beta,
+                                        const float* sums, float* dy, int G, int rows_per_group, int C,
+                                        void* stream) {
+  if (!da || !y || !mean || !rstd || !gamma || !beta || !sums || !dy) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
+  BnParams bp{mean, rstd, gamma, beta};
+  int64_t total4 = (int64_t)G * rows_per_group * (C / 4);
+  hipLaunchKernelGGL(bn_swish_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, da,
+                     y, bp, sums, dy, total4, rows_per_group, C);
+  MMDYN_LAUNCH_CHECK();
+}

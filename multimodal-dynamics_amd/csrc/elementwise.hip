@@ -1,0 +1,331 @@
+// Element-wise / small-reduction kernels of the cnn-mvae step: activations of the FC layers, dropout with
+// injected keep-masks (vae.py:213), bias gradients, the tiny 7-DoF pose Linear layers (vae.py:117-123),
+// counter-based random draws for throughput runs, and Adam (problems.py:137-138).
+// HBM-bound: 16-byte lane accesses, grid-stride loops capped at 2048 blocks.
+#include "common.h"
+
+namespace {
+
+__global__ void act_fwd_kernel(const float* __restrict__ u, float* __restrict__ h, int64_t n, int act) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 v = reinterpret_cast<const f32x4*>(u)[i], o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = apply_act(v[k], act);
+    reinterpret_cast<f32x4*>(h)[i] = o;
+  }
+  for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    h[i] = apply_act(u[i], act);
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ u,
+                               float* __restrict__ du, int64_t n, int act) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 v = reinterpret_cast<const f32x4*>(u)[i], d = reinterpret_cast<const f32x4*>(dh)[i], o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = d[k] * act_grad(v[k], act);
+    reinterpret_cast<f32x4*>(du)[i] = o;
+  }
+  for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    du[i] = dh[i] * act_grad(u[i], act);
+}
+
+__global__ void dropout_expand_kernel(const float* __restrict__ h, const uint8_t* __restrict__ masks,
+                                      float* __restrict__ out, int P, int64_t bh, float scale) {
+  const int64_t total = (int64_t)P * bh;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = i % bh;
+    // same association as the reference: x * (mask / (1-p))
+    out[i] = h[j] * ((float)masks[i] * scale);
+  }
+}
+
+__global__ void dropout_reduce_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ masks,
+                                      float* __restrict__ dh, int P, int64_t bh, float scale) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < bh;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += dout[(int64_t)p * bh + j] * ((float)masks[(int64_t)p * bh + j] * scale);
+    dh[j] = s;
+  }
+}
+
+// Philox-4x32-10 counter-based generator (Salmon et al., SC'11): stateless, so a draw is a pure function
+// of (seed, offset, element index) and a captured graph replays with a device-side offset bump.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0;
+  c[1] = n1;
+  c[2] = n2;
+  c[3] = n3;
+}
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0];
+  out[1] = c[1];
+  out[2] = c[2];
+  out[3] = c[3];
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__global__ void random_masks_kernel(uint8_t* __restrict__ masks, int64_t n, float p_drop, uint64_t seed,
+                                    uint64_t offset) {
+  const int64_t n4 = (n + 3) >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4(seed, offset + (uint64_t)i, r);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int64_t j = i * 4 + k;
+      if (j < n) masks[j] = (u01(r[k]) >= p_drop) ? 1 : 0;
+    }
+  }
+}
+
+__global__ void random_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+  const int64_t n4 = (n + 3) >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4(seed, offset + (uint64_t)i, r);
+    float z[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {  // Box-Muller on two pairs
+      float rad = sqrtf(-2.0f * __logf(u01(r[2 * k])));
+      float ang = 6.28318530717958647692f * u01(r[2 * k + 1]);
+      z[2 * k] = rad * __cosf(ang);
+      z[2 * k + 1] = rad * __sinf(ang);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int64_t j = i * 4 + k;
+      if (j < n) out[j] = z[k];
+    }
+  }
+}
+
+// out[c] (+)= sum_r x[r][c]; 32 channels per block, 8 row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                     int rows, int C, int perm, float beta) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float s = 0.f;
+  if (c < C)
+    for (int r = rl; r < rows; r += 8) s += x[(size_t)r * C + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (threadIdx.x < 32 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) t += red[l][cl];
+    int o = c;
+    if (perm == 2) {
+      int hw = c / 256, ch = c - hw * 256;
+      o = ch * 25 + hw;
+    }
+    out[o] = (beta != 0.f ? beta * out[o] : 0.f) + t;
+  }
+}
+
+__global__ void sum_blocks_kernel(const float* __restrict__ x, float* __restrict__ out, int P, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += x[(int64_t)p * n + i];
+    out[i] = s;
+  }
+}
+
+__global__ void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                        const float* __restrict__ b, float* __restrict__ y, int rows, int K,
+                                        int N, int act) {
+  const int64_t total = (int64_t)rows * N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N), r = (int)(i / N);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s = fmaf(x[(size_t)r * K + k], W[(size_t)n * K + k], s);
+    if (b) s += b[n];
+    y[i] = apply_act(s, act);
+  }
+}
+__global__ void linear_small_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                       float* __restrict__ dx, int rows, int K, int N) {
+  const int64_t total = (int64_t)rows * K;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K), r = (int)(i / K);
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = fmaf(dy[(size_t)r * N + n], W[(size_t)n * K + k], s);
+    dx[i] = s;
+  }
+}
+// one wavefront per weight element: lanes stride over rows, then a 64-lane shuffle reduction
+__global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __restrict__ dy,
+                                                              const float* __restrict__ x,
+                                                              float* __restrict__ dW, float* __restrict__ db,
+                                                              int rows, int K, int N, float beta) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t total = (int64_t)N * (K + 1);  // column K = bias
+  for (int64_t i = wave; i < total; i += nwaves) {
+    const int k = (int)(i % (K + 1)), n = (int)(i / (K + 1));
+    float s = 0.f;
+    for (int r = lane; r < rows; r += 64) {
+      float g = dy[(size_t)r * N + n];
+      s += (k < K) ? g * x[(size_t)r * K + k] : g;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      if (k < K) {
+        float* o = dW + (size_t)n * K + k;
+        *o = (beta != 0.f ? beta * *o : 0.f) + s;
+      } else if (db) {
+        db[n] = (beta != 0.f ? beta * db[n] : 0.f) + s;
+      }
+    }
+  }
+}
+
+__global__ void adam_tick_kernel(double* __restrict__ state, float lr, float beta1, float beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double t = state[0] + 1.0;
+    state[0] = t;
+    state[1] = (double)lr / (1.0 - pow((double)beta1, t));  // step size
+    state[2] = sqrt(1.0 - pow((double)beta2, t));           // sqrt(bias_correction2)
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, const double* __restrict__ state, int64_t n, float beta1,
+                            float beta2, float eps, float grad_scale) {
+  const float step_size = (float)state[1], bc2s = (float)state[2];
+  const int64_t n4 = n >> 2;
+  auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+    gg *= grad_scale;
+    mm = mm + (gg - mm) * (1.f - beta1);
+    vv = vv * beta2 + (1.f - beta2) * gg * gg;
+    float denom = sqrtf(vv) / bc2s + eps;
+    pp = pp - step_size * (mm / denom);
+  };
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float a = pp[k], b = mm[k], c = vv[k];
+      upd(a, gg[k], b, c);
+      pp[k] = a;
+      mm[k] = b;
+      vv[k] = c;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    upd(p[i], g[i], m[i], v[i]);
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int mmdyn_act_fwd(const float* u, float* h, int64_t n, int act, void* stream) {
+  if (!u || !h) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, u, h, n, act);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_act_bwd(const float* dh, const float* u, float* du, int64_t n, int act, void* stream) {
+  if (!dh || !u || !du) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, dh, u, du, n, act);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_dropout_expand(const float* h, const uint8_t* masks, float* out, int P, int B, int H,
+                                    float p_drop, void* stream) {
+  if (!h || !masks || !out) return MMDYN_ERR_NULL;
+  if (p_drop < 0.f || p_drop >= 1.f) return MMDYN_ERR_SHAPE;
+  int64_t bh = (int64_t)B * H;
+  hipLaunchKernelGGL(dropout_expand_kernel, dim3(ew_grid(P * bh)), dim3(256), 0, ST, h, masks, out, P, bh,
+                     1.0f / (1.0f - p_drop));
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_dropout_reduce(const float* dout, const uint8_t* masks, float* dh, int P, int B, int H,
+                                    float p_drop, void* stream) {
+  if (!dout || !masks || !dh) return MMDYN_ERR_NULL;
+  if (p_drop < 0.f || p_drop >= 1.f) return MMDYN_ERR_SHAPE;
+  int64_t bh = (int64_t)B * H;
+  hipLaunchKernelGGL(dropout_reduce_kernel, dim3(ew_grid(bh)), dim3(256), 0, ST, dout, masks, dh, P, bh,
+                     1.0f / (1.0f - p_drop));
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_random_masks(uint8_t* masks, int64_t n, float p_drop, uint64_t seed, uint64_t offset,
+                                  void* stream) {
+  if (!masks) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(random_masks_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, masks, n, p_drop, seed,
+                     offset);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_random_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  if (!out) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(random_normal_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, out, n, seed, offset);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_colsum(const float* x, float* out, int rows, int C, int perm, float beta, void* stream) {
+  if (!x || !out) return MMDYN_ERR_NULL;
+  if (perm == 2 && C != 6400) return MMDYN_ERR_SHAPE;
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, ST, x, out, rows, C, perm, beta);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_sum_blocks(const float* x, float* out, int P, int64_t n, void* stream) {
+  if (!x || !out) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(sum_blocks_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, x, out, P, n);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_linear_small_fwd(const float* x, const float* W, const float* b, float* y, int rows,
+                                      int K, int N, int act, void* stream) {
+  if (!x || !W || !y) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(linear_small_fwd_kernel, dim3(ew_grid((int64_t)rows * N)), dim3(256), 0, ST, x, W, b, y,
+                     rows, K, N, act);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_linear_small_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW,
+                                      float* db, int rows, int K, int N, float beta, void* stream) {
+  if (!dy || !x || !W || !dW) return MMDYN_ERR_NULL;
+  if (dx)
+    hipLaunchKernelGGL(linear_small_dx_kernel, dim3(ew_grid((int64_t)rows * K)), dim3(256), 0, ST, dy, W, dx,
+                       rows, K, N);
+  hipLaunchKernelGGL(linear_small_dw_kernel, dim3(ew_grid((int64_t)N * (K + 1) * 64)), dim3(256), 0, ST, dy,
+                     x, dW, db, rows, K, N, beta);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_adam_step(float* p, const float* g, float* m, float* v, double* state, int64_t n,
+                               float lr, float beta1, float beta2, float eps, float grad_scale,
+                               void* stream) {
+  if (!p || !g || !m || !v || !state) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, ST, state, lr, beta1, beta2);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, p, g, m, v, state, n, beta1,
+                     beta2, eps, grad_scale);
+  MMDYN_LAUNCH_CHECK();
+}

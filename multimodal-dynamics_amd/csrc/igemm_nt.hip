@@ -1,0 +1,392 @@
+// MFMA implicit GEMM, NT form, fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32, gfx950).
+//
+//   C[row][n] = sum_{tap, ci} A_tap[row][ci] * Bp[widx(tap)][n][ci]
+//
+// Replaces the ATen kernels behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear forward and
+// input-gradient on the reference path (/root/reference/mmdyn/pytorch/models/vae.py:198-216, 264-277).
+//
+// Layout and tiling (designed for CDNA4, not a port of a warp-32 tiling):
+//   * activations are channels-last, so one GEMM row of one tap is a contiguous run of Cin floats:
+//     every global load is a full 16-byte lane access inside a 128-byte segment;
+//   * block tile BM x BN x 32, 256 threads = 4 wavefronts of 64, each wave owns (WM/32) x (WN/32)
+//     32x32 MFMA tiles (16 accumulator VGPRs each);
+//   * both operand tiles live in LDS as [row][36] (row padded by one 16-byte slot): the fragment
+//     read is one conflict-free ds_read_b128 per 4 MFMAs.  The K order inside a group of 8 is
+//     permuted (lane half h consumes k = 8q + 4h + j for MFMA j) -- legal because A and B use the
+//     same permutation;
+//   * register-staged prefetch: the global loads of K-step s+1 are issued before the MFMAs of step s;
+//   * epilogue: optional bias, optional second (activated) output, optional per-tile BatchNorm
+//     partial sums (column sums of the tile and of its squares), deterministic (no atomics).
+#include "common.h"
+
+namespace {
+
+struct IgemmGeom {
+  int mode;            // MMDYN_DENSE / MMDYN_CONV / MMDYN_TCONV_S2P1
+  int G, Bg;           // groups, samples per group
+  int Hr, Wr;          // row grid per sample (rows per sample = Hr*Wr)
+  int Hi, Wi, Cin;     // gathered operand
+  int Ho, Wo, N, ldc;  // output pixel grid, channels, row stride
+  int rs, ro;          // input base of a row: y0 = r*rs + ro
+  int os;              // output pixel of a row: (r*os + ph, c*os + pw)
+  int ntaps, nclasses, splitk;
+  int act, has_bias, want_stats, want_act_out;
+  int rows_total;      // G*Bg*Hr*Wr (split-K workspace stride)
+  int tiles_per_group; // ceil(Bg*Hr*Wr / BM)
+};
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__ A,
+                                                       const float* __restrict__ Bp,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ C, float* __restrict__ C_act,
+                                                       float* __restrict__ stats, float* __restrict__ ws,
+                                                       const IgemmGeom g) {
+  constexpr int MT = WM / 32, NT = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int WAVES_M = BM / WM;
+  static_assert(WAVES_N * WAVES_M == 4, "4 waves per block");
+  constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);            // [BM][36]
+  float* Bs = As + BM * LDS_LD;                          // [BN][36]
+  int* rowinfo = reinterpret_cast<int*>(Bs + BN * LDS_LD);  // [BM][4]: b, y0, x0, out offset (-1: none)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int HWr = g.Hr * g.Wr;
+  const int Mg = g.Bg * HWr;
+  const int grp = blockIdx.x / g.tiles_per_group, tile = blockIdx.x - grp * g.tiles_per_group;
+  const int cls = blockIdx.z % g.nclasses, split = blockIdx.z / g.nclasses;
+  const int n0 = blockIdx.y * BN;
+  const int ph = cls >> 1, pw = cls & 1;
+
+  for (int r = tid; r < BM; r += 256) {
+    int ml = tile * BM + r;
+    int ib = -1, y0 = 0, x0 = 0, ooff = -1;
+    if (ml < Mg) {
+      int s = ml / HWr;
+      int p = ml - s * HWr;
+      int rr = p / g.Wr;
+      int cc = p - rr * g.Wr;
+      ib = grp * g.Bg + s;
+      y0 = rr * g.rs + g.ro;
+      x0 = cc * g.rs + g.ro;
+      int oy = rr * g.os + ph, ox = cc * g.os + pw;
+      ooff = ((ib * g.Ho + oy) * g.Wo + ox) * g.ldc;
+    }
+    rowinfo[r * 4 + 0] = ib;
+    rowinfo[r * 4 + 1] = y0;
+    rowinfo[r * 4 + 2] = x0;
+    rowinfo[r * 4 + 3] = ooff;
+  }
+  __syncthreads();
+
+  const int lrow = tid >> 3, gran = tid & 7;
+  int rb[A_LOADS], ry[A_LOADS], rx[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    int r = lrow + 32 * i;
+    rb[i] = rowinfo[r * 4 + 0];
+    ry[i] = rowinfo[r * 4 + 1];
+    rx[i] = rowinfo[r * 4 + 2];
+  }
+
+  const int cin_steps = g.Cin / BK;
+  const int total_steps = g.ntaps * cin_steps;
+  const int per_split = (total_steps + g.splitk - 1) / g.splitk;
+  const int s_begin = split * per_split;
+  const int s_end = min(total_steps, s_begin + per_split);
+
+  f32x4 ra[A_LOADS], rbv[B_LOADS];
+  auto gload = [&](int s) {
+    int t = s / cin_steps;
+    int c0 = (s - t * cin_steps) * BK + gran * 4;
+    int dh = 0, dw = 0, wi = 0;
+    if (g.mode == MMDYN_CONV) {
+      dh = t >> 2;
+      dw = t & 3;
+      wi = t;
+    } else if (g.mode == MMDYN_TCONV_S2P1) {
+      int th = t >> 1, tw = t & 1;
+      dh = ph - th;
+      dw = pw - tw;
+      wi = (1 - ph + 2 * th) * 4 + (1 - pw + 2 * tw);
+    }
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      int y = ry[i] + dh, x = rx[i] + dw;
+      bool ok = (rb[i] >= 0) && ((unsigned)y < (unsigned)g.Hi) && ((unsigned)x < (unsigned)g.Wi);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const float* p = A + ((size_t)((rb[i] * g.Hi + y) * g.Wi + x)) * g.Cin + c0;
+        v = *reinterpret_cast<const f32x4*>(p);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j) {
+      int n = n0 + lrow + 32 * j;
+      const float* p = Bp + ((size_t)wi * g.N + n) * g.Cin + c0;
+      rbv[j] = *reinterpret_cast<const f32x4*>(p);
+    }
+  };
+  auto lds_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i)
+      *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * LDS_LD + gran * 4]) = ra[i];
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j)
+      *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * j) * LDS_LD + gran * 4]) = rbv[j];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+  const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
+  if (s_begin < s_end) {
+    gload(s_begin);
+    lds_store();
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+      const bool more = (s + 1 < s_end);
+      if (more) gload(s + 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 af[MT], bf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          af[mt] = *reinterpret_cast<const f32x4*>(&As[(wm * WM + mt * 32) * LDS_LD + frag_off + q * 8]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bf[nt] = *reinterpret_cast<const f32x4*>(&Bs[(wn * WN + nt * 32) * LDS_LD + frag_off + q * 8]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        lds_store();
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  const int h = lane >> 5, cl = lane & 31;
+  float colsum[NT], colsq[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) colsum[nt] = colsq[nt] = 0.f;
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = wm * WM + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int ooff = rowinfo[r * 4 + 3];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + wn * WN + nt * 32 + cl;
+        float v = acc[mt][nt][e];
+        colsum[nt] += v;
+        colsq[nt] += v * v;
+        if (ooff >= 0) {
+          if (g.splitk > 1) {
+            const int grow = grp * Mg + tile * BM + r;  // dense row id (DENSE mode only)
+            ws[((size_t)split * g.rows_total + grow) * g.N + col] = v;
+          } else {
+            if (g.has_bias) v += bias[col];
+            C[(size_t)ooff + col] = v;
+            if (g.want_act_out) C_act[(size_t)ooff + col] = apply_act(v, g.act);
+          }
+        }
+      }
+    }
+  }
+
+  if (g.want_stats) {
+    // rows beyond the group are zero-filled operands -> contribute exactly 0
+    __syncthreads();
+    float* red = As;  // [WAVES_M][2][BN]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float s = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
+      float q = colsq[nt] + __shfl_xor(colsq[nt], 32, 64);
+      if (h == 0) {
+        red[(wm * 2 + 0) * BN + wn * WN + nt * 32 + cl] = s;
+        red[(wm * 2 + 1) * BN + wn * WN + nt * 32 + cl] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) {
+        s += red[(w * 2 + 0) * BN + tid];
+        q += red[(w * 2 + 1) * BN + tid];
+      }
+      const int T = g.nclasses * g.tiles_per_group;
+      const size_t base = ((size_t)(grp * T + cls * g.tiles_per_group + tile) * 2) * g.N + n0 + tid;
+      stats[base] = s;
+      stats[base + g.N] = q;
+    }
+  }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                     float* __restrict__ C, float* __restrict__ C_act, int splitk,
+                                     int64_t total, int N, int act) {
+  const int64_t nvec = total / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 s = reinterpret_cast<const f32x4*>(ws)[i];
+    for (int k = 1; k < splitk; ++k) {
+      f32x4 t = reinterpret_cast<const f32x4*>(ws + (size_t)k * total)[i];
+      s += t;
+    }
+    if (bias) {
+      int c = (int)((i * 4) % N);
+      s += *reinterpret_cast<const f32x4*>(bias + c);
+    }
+    reinterpret_cast<f32x4*>(C)[i] = s;
+    if (C_act) {
+      f32x4 a;
+      a[0] = apply_act(s[0], act);
+      a[1] = apply_act(s[1], act);
+      a[2] = apply_act(s[2], act);
+      a[3] = apply_act(s[3], act);
+      reinterpret_cast<f32x4*>(C_act)[i] = a;
+    }
+  }
+}
+
+// tile choice shared by the launcher and mmdyn_igemm_stat_tiles: the largest tile that still gives
+// >= 2 blocks per CU (256 CUs), otherwise the smallest one that divides N.
+static void pick_tile(int N, int rows_per_group, int G, int ncls, int splitk, int* bm, int* bn) {
+  static const int cand[][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 32}, {128, 32}};
+  int best = -1;
+  for (int i = 0; i < 6; ++i) {
+    int m = cand[i][0], n = cand[i][1];
+    if (N % n) continue;
+    if (n == 32 && N % 64 == 0) continue;  // 32-wide tiles only for N == 32 (mod 64)
+    long blocks = (long)G * ceil_div(rows_per_group, m) * (N / n) * ncls * splitk;
+    best = i;
+    if (blocks >= 512) break;
+  }
+  *bm = cand[best][0];
+  *bn = cand[best][1];
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats,
+                  float* ws, IgemmGeom g, hipStream_t st) {
+  g.tiles_per_group = ceil_div(g.Bg * g.Hr * g.Wr, BM);
+  dim3 grid(g.G * g.tiles_per_group, g.N / BN, g.nclasses * g.splitk);
+  size_t smem = (size_t)(BM + BN) * LDS_LD * sizeof(float) + (size_t)BM * 4 * sizeof(int);
+  hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN>), grid, dim3(256), smem, st, A, Bp, bias, C, C_act,
+                     stats, ws, g);
+  MMDYN_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Ho, int Wo, int N) {
+  int Hr = Ho, Wr = Wo, ncls = 1;
+  if (mode == MMDYN_TCONV_S2P1) {
+    Hr = Hi;
+    Wr = Wi;
+    ncls = 4;
+  }
+  int bm, bn;
+  pick_tile(N, Bg * Hr * Wr, G, ncls, 1, &bm, &bn);
+  return ncls * ceil_div(Bg * Hr * Wr, bm);
+}
+
+extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
+                              float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
+                              int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
+                              void* stream) {
+  if (!A || !Bp || !C) return MMDYN_ERR_NULL;
+  if (Cin <= 0 || N <= 0 || Cin % 32 || N % 32 || G <= 0 || Bg <= 0 || ldc < N) return MMDYN_ERR_SHAPE;
+  if (splitk < 1) splitk = 1;
+  if (splitk > 1 && (mode != MMDYN_DENSE || !ws || stats)) return MMDYN_ERR_SHAPE;
+  IgemmGeom g{};
+  g.mode = mode;
+  g.G = G;
+  g.Bg = Bg;
+  g.Hi = Hi;
+  g.Wi = Wi;
+  g.Cin = Cin;
+  g.Ho = Ho;
+  g.Wo = Wo;
+  g.N = N;
+  g.ldc = ldc;
+  g.act = act;
+  g.has_bias = bias != nullptr;
+  g.want_stats = stats != nullptr;
+  g.want_act_out = C_act != nullptr;
+  g.splitk = splitk;
+  g.nclasses = 1;
+  g.os = 1;
+  if (mode == MMDYN_DENSE) {
+    if (Hi != Ho || Wi != Wo) return MMDYN_ERR_SHAPE;
+    g.Hr = Ho;
+    g.Wr = Wo;
+    g.rs = 1;
+    g.ro = 0;
+    g.ntaps = 1;
+  } else if (mode == MMDYN_CONV) {
+    g.Hr = Ho;
+    g.Wr = Wo;
+    g.rs = stride;
+    g.ro = offset;
+    g.ntaps = 16;
+  } else if (mode == MMDYN_TCONV_S2P1) {
+    if (Ho != 2 * Hi || Wo != 2 * Wi) return MMDYN_ERR_SHAPE;
+    g.Hr = Hi;
+    g.Wr = Wi;
+    g.rs = 1;
+    g.ro = 0;
+    g.os = 2;
+    g.ntaps = 4;
+    g.nclasses = 4;
+  } else {
+    return MMDYN_ERR_SHAPE;
+  }
+  const int64_t rows = (int64_t)G * Bg * g.Hr * g.Wr;
+  if ((int64_t)G * Bg * Hi * Wi * Cin >= (1LL << 31) || (int64_t)G * Bg * Ho * Wo * ldc >= (1LL << 31))
+    return MMDYN_ERR_RANGE;
+  g.rows_total = (int)rows;
+  hipStream_t st = (hipStream_t)stream;
+  int bm, bn;
+  pick_tile(N, Bg * g.Hr * g.Wr, G, g.nclasses, splitk, &bm, &bn);
+  if (bn == 128 && bm == 128) return launch<128, 128, 64, 64>(A, Bp, bias, C, C_act, stats, ws, g, st);
+  if (bn == 128 && bm == 64) return launch<64, 128, 32, 64>(A, Bp, bias, C, C_act, stats, ws, g, st);
+  if (bn == 64 && bm == 128) return launch<128, 64, 64, 32>(A, Bp, bias, C, C_act, stats, ws, g, st);
+  if (bn == 64 && bm == 64) return launch<64, 64, 32, 32>(A, Bp, bias, C, C_act, stats, ws, g, st);
+  if (bn == 32 && bm == 256) return launch<256, 32, 64, 32>(A, Bp, bias, C, C_act, stats, ws, g, st);
+  return launch<128, 32, 32, 32>(A, Bp, bias, C, C_act, stats, ws, g, st);
+}
+
+extern "C" int mmdyn_splitk_reduce(const float* ws, const float* bias, float* C, float* C_act, int splitk,
+                                   int rows, int N, int act, void* stream) {
+  if (!ws || !C) return MMDYN_ERR_NULL;
+  if (N % 4) return MMDYN_ERR_SHAPE;
+  int64_t total = (int64_t)rows * N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream, ws,
+                     bias, C, C_act, splitk, total, N, act);
+  MMDYN_LAUNCH_CHECK();
+}

@@ -1,0 +1,315 @@
+// Latent-space and loss kernels of the cnn-mvae step:
+//   - product of experts + reparametrisation + KL, all P modality-subset passes in one launch
+//     (/root/reference/mmdyn/pytorch/models/vae.py:311-318, 52-61; problems.py:429);
+//   - BCE-with-logits / MSE reconstruction sums with their gradients in the same pass
+//     (problems.py:433-449), 64-lane shuffle reduction -> one double atomic per block;
+//   - the final (sum recon + kl_weight * KL) / B assembly (problems.py:458).
+#include "common.h"
+
+namespace {
+
+struct PoeArgs {
+  mmdyn_pass_experts pass[MMDYN_MAX_PASSES];
+};
+
+constexpr float POE_EPS = 1e-8f;
+
+__global__ __launch_bounds__(256) void poe_fwd_kernel(PoeArgs args, const float* __restrict__ eps_noise,
+                                                      float* __restrict__ mu_out, float* __restrict__ lv_out,
+                                                      float* __restrict__ z_out, double* __restrict__ kl_sum,
+                                                      int with_prior, int B, int L) {
+  const int p = blockIdx.y;
+  const mmdyn_pass_experts& e = args.pass[p];
+  const int64_t n = (int64_t)B * L;
+  double kl = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L), l = (int)(i - (int64_t)b * L);
+    // universal prior expert N(0, 1) first, then the present modalities in the reference's order
+    float var0 = 1.f + POE_EPS;
+    float sumT = with_prior ? 1.f / (var0 + POE_EPS) : 0.f, sumMuT = 0.f;
+#pragma unroll
+    for (int m = 0; m < MMDYN_MAX_EXPERTS; ++m) {
+      if (e.mu[m]) {
+        float mu_m = e.mu[m][(size_t)b * e.ld[m] + l];
+        float lv_m = e.lv[m][(size_t)b * e.ld[m] + l];
+        float var = expf(lv_m) + POE_EPS;
+        float Tm = 1.f / (var + POE_EPS);
+        sumT += Tm;
+        sumMuT += mu_m * Tm;
+      }
+    }
+    float pd_mu = sumMuT / sumT;
+    float pd_var = 1.f / sumT;
+    float pd_lv = logf(pd_var + POE_EPS);
+    const size_t o = (size_t)p * n + i;
+    mu_out[o] = pd_mu;
+    lv_out[o] = pd_lv;
+    if (z_out) z_out[o] = eps_noise[o] * expf(0.5f * pd_lv) + pd_mu;
+    kl += (double)(1.f + pd_lv - pd_mu * pd_mu - expf(pd_lv));
+  }
+  if (kl_sum) {
+    kl = wave_sum_d(kl);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kl;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&kl_sum[p], -0.5 * (red[0] + red[1] + red[2] + red[3]));
+  }
+}
+
+__global__ __launch_bounds__(256) void poe_bwd_kernel(PoeArgs args, const float* __restrict__ eps_noise,
+                                                      const float* __restrict__ mu_pd,
+                                                      const float* __restrict__ lv_pd,
+                                                      const float* __restrict__ dz,
+                                                      const float* __restrict__ g_mu,
+                                                      const float* __restrict__ g_lv, float kl_scale,
+                                                      int with_prior, int B, int L) {
+  const int p = blockIdx.y;
+  const mmdyn_pass_experts& e = args.pass[p];
+  const int64_t n = (int64_t)B * L;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L), l = (int)(i - (int64_t)b * L);
+    const size_t o = (size_t)p * n + i;
+    const float mu = mu_pd[o], lv = lv_pd[o], g = dz ? dz[o] : 0.f;
+    // z = eps * exp(lv/2) + mu ;  KL = -0.5 * sum(1 + lv - mu^2 - exp(lv))
+    float dmu_pd = g + kl_scale * mu;
+    float dlv_pd = -0.5f * kl_scale * (1.f - expf(lv));
+    if (dz) dlv_pd += g * eps_noise[o] * 0.5f * expf(0.5f * lv);
+    if (g_mu) dmu_pd += g_mu[o];
+    if (g_lv) dlv_pd += g_lv[o];
+    float Tm[MMDYN_MAX_EXPERTS], mum[MMDYN_MAX_EXPERTS], ex[MMDYN_MAX_EXPERTS];
+    float var0 = 1.f + POE_EPS;
+    float S = with_prior ? 1.f / (var0 + POE_EPS) : 0.f, N = 0.f;
+#pragma unroll
+    for (int m = 0; m < MMDYN_MAX_EXPERTS; ++m) {
+      Tm[m] = 0.f;
+      mum[m] = 0.f;
+      ex[m] = 0.f;
+      if (e.mu[m]) {
+        mum[m] = e.mu[m][(size_t)b * e.ld[m] + l];
+        ex[m] = expf(e.lv[m][(size_t)b * e.ld[m] + l]);
+        Tm[m] = 1.f / (ex[m] + POE_EPS + POE_EPS);
+        S += Tm[m];
+        N += mum[m] * Tm[m];
+      }
+    }
+    const float pd_var = 1.f / S;
+    const float dvar = dlv_pd / (pd_var + POE_EPS);
+    const float invS2 = pd_var * pd_var;
+    const float dS = -dvar * invS2 - dmu_pd * N * invS2;
+    const float dN = dmu_pd * pd_var;
+#pragma unroll
+    for (int m = 0; m < MMDYN_MAX_EXPERTS; ++m) {
+      if (e.mu[m]) {
+        const float dT = dS + dN * mum[m];
+        e.dmu[m][(size_t)b * e.ld[m] + l] = dN * Tm[m];
+        e.dlv[m][(size_t)b * e.ld[m] + l] = -dT * Tm[m] * Tm[m] * ex[m];
+      }
+    }
+  }
+}
+
+// z = eps * exp(lv/2) + mu and/or KL(mu, lv); mu/lv rows of stride ld (vae.py:57-59, problems.py:406)
+__global__ __launch_bounds__(256) void reparam_fwd_kernel(const float* __restrict__ mu,
+                                                          const float* __restrict__ lv,
+                                                          const float* __restrict__ eps_noise,
+                                                          float* __restrict__ z, double* __restrict__ kl_sum,
+                                                          int B, int L, int ld) {
+  const int64_t n = (int64_t)B * L;
+  double kl = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L), l = (int)(i - (int64_t)b * L);
+    const float m = mu[(size_t)b * ld + l], v = lv[(size_t)b * ld + l];
+    if (z) z[i] = eps_noise[i] * expf(0.5f * v) + m;
+    kl += (double)(1.f + v - m * m - expf(v));
+  }
+  if (kl_sum) {
+    kl = wave_sum_d(kl);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kl;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(kl_sum, -0.5 * (red[0] + red[1] + red[2] + red[3]));
+  }
+}
+
+__global__ void reparam_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                   const float* __restrict__ eps_noise, const float* __restrict__ dz,
+                                   float kl_scale, float* __restrict__ dmu, float* __restrict__ dlv, int B,
+                                   int L, int ld) {
+  const int64_t n = (int64_t)B * L;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L), l = (int)(i - (int64_t)b * L);
+    const float m = mu[(size_t)b * ld + l], v = lv[(size_t)b * ld + l];
+    const float g = dz ? dz[i] : 0.f;
+    float gm = g + kl_scale * m;
+    float gv = -0.5f * kl_scale * (1.f - expf(v));
+    if (dz) gv += g * eps_noise[i] * 0.5f * expf(0.5f * v);
+    dmu[(size_t)b * ld + l] = gm;
+    dlv[(size_t)b * ld + l] = gv;
+  }
+}
+
+__device__ __forceinline__ void block_atomic_add(double v, double* dst) {
+  v = wave_sum_d(v);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dst, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ logits,
+                                                         const float* __restrict__ target,
+                                                         const float* __restrict__ mask,
+                                                         float* __restrict__ dlogit, double* __restrict__ loss,
+                                                         int64_t n, int chw, int hw, float grad_scale) {
+  double acc = 0.0;
+  const int64_t n4 = n >> 2;  // n is a multiple of 4 for image tensors (checked by the caller)
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 x = reinterpret_cast<const f32x4*>(logits)[i], t = reinterpret_cast<const f32x4*>(target)[i];
+    f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+    if (mask) {
+      const int64_t e0 = i * 4;
+      const int64_t b = e0 / chw;
+      const int pix = (int)((e0 - b * chw) % hw);
+      mk = *reinterpret_cast<const f32x4*>(mask + b * hw + pix);
+    }
+    f32x4 d;
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xm = x[k] * mk[k], tm = t[k] * mk[k];
+      // max(x,0) - x*t + log(1 + exp(-|x|))
+      part += fmaxf(xm, 0.f) - xm * tm + log1pf(expf(-fabsf(xm)));
+      d[k] = mk[k] * (1.f / (1.f + expf(-xm)) - tm) * grad_scale;
+    }
+    acc += (double)part;
+    if (dlogit) reinterpret_cast<f32x4*>(dlogit)[i] = d;
+  }
+  block_atomic_add(acc, loss);
+}
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ r, const float* __restrict__ t,
+                                                  float* __restrict__ dr, double* __restrict__ loss, int64_t n,
+                                                  float grad_scale) {
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = r[i] - t[i];
+    acc += (double)(d * d);
+    if (dr) dr[i] = 2.f * d * grad_scale;
+  }
+  block_atomic_add(acc, loss);
+}
+
+__global__ void elbo_assemble_kernel(const double* __restrict__ bce, const double* __restrict__ mse,
+                                     const double* __restrict__ kl, float* __restrict__ loss,
+                                     float* __restrict__ partials, int P, int B, float kl_weight,
+                                     float pose_multiplier) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double tot = 0.0;
+    for (int p = 0; p < P; ++p) {
+      double v = ((bce ? bce[p] : 0.0) + (double)pose_multiplier * (mse ? mse[p] : 0.0) +
+                  (double)kl_weight * (kl ? kl[p] : 0.0)) /
+                 (double)B;
+      if (partials) partials[p] = (float)v;
+      tot += v;
+    }
+    loss[0] = (float)tot;
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+static int copy_passes(const mmdyn_pass_experts* passes, int P, PoeArgs* out) {
+  if (!passes) return MMDYN_ERR_NULL;
+  if (P < 1 || P > MMDYN_MAX_PASSES) return MMDYN_ERR_SHAPE;
+  for (int p = 0; p < P; ++p) out->pass[p] = passes[p];
+  return 0;
+}
+
+extern "C" int mmdyn_poe_fwd(const mmdyn_pass_experts* passes, const float* eps_noise, float* mu,
+                             float* logvar, float* z, double* kl_sum, int with_prior, int P, int B, int L,
+                             void* stream) {
+  if (!mu || !logvar || (z && !eps_noise)) return MMDYN_ERR_NULL;
+  PoeArgs a{};
+  if (int e = copy_passes(passes, P, &a)) return e;
+  for (int p = 0; p < P; ++p)
+    for (int m = 0; m < MMDYN_MAX_EXPERTS; ++m)
+      if ((a.pass[p].mu[m] != nullptr) != (a.pass[p].lv[m] != nullptr)) return MMDYN_ERR_NULL;
+  int gx = ew_grid((int64_t)B * L);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(poe_fwd_kernel, dim3(gx, P), dim3(256), 0, ST, a, eps_noise, mu, logvar, z, kl_sum,
+                     with_prior, B, L);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_poe_bwd(const mmdyn_pass_experts* passes, const float* eps_noise, const float* mu,
+                             const float* logvar, const float* dz, const float* g_mu, const float* g_lv,
+                             float kl_scale, int with_prior, int P, int B, int L, void* stream) {
+  if (!mu || !logvar || (dz && !eps_noise)) return MMDYN_ERR_NULL;
+  PoeArgs a{};
+  if (int e = copy_passes(passes, P, &a)) return e;
+  for (int p = 0; p < P; ++p)
+    for (int m = 0; m < MMDYN_MAX_EXPERTS; ++m)
+      if (a.pass[p].mu[m] && (!a.pass[p].lv[m] || !a.pass[p].dmu[m] || !a.pass[p].dlv[m])) return MMDYN_ERR_NULL;
+  int gx = ew_grid((int64_t)B * L);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(poe_bwd_kernel, dim3(gx, P), dim3(256), 0, ST, a, eps_noise, mu, logvar, dz, g_mu, g_lv,
+                     kl_scale, with_prior, B, L);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_reparam_fwd(const float* mu, const float* lv, const float* eps_noise, float* z,
+                                 double* kl_sum, int B, int L, int ld, void* stream) {
+  if (!mu || !lv || (z && !eps_noise)) return MMDYN_ERR_NULL;
+  if (ld < L) return MMDYN_ERR_SHAPE;
+  int gx = ew_grid((int64_t)B * L);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(gx), dim3(256), 0, ST, mu, lv, eps_noise, z, kl_sum, B, L, ld);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_reparam_bwd(const float* mu, const float* lv, const float* eps_noise, const float* dz,
+                                 float kl_scale, float* dmu, float* dlv, int B, int L, int ld, void* stream) {
+  if (!mu || !lv || !dmu || !dlv || (dz && !eps_noise)) return MMDYN_ERR_NULL;
+  if (ld < L) return MMDYN_ERR_SHAPE;
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(ew_grid((int64_t)B * L)), dim3(256), 0, ST, mu, lv, eps_noise,
+                     dz, kl_scale, dmu, dlv, B, L, ld);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bce_logits(const float* logits, const float* target, const float* mask, float* dlogit,
+                                double* loss_sum, int64_t n, int chw, int hw, float grad_scale,
+                                void* stream) {
+  if (!logits || !target || !loss_sum) return MMDYN_ERR_NULL;
+  if (n % 4 || (mask && (hw % 4 || chw % hw))) return MMDYN_ERR_SHAPE;
+  int g = ew_grid(n / 4);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(g), dim3(256), 0, ST, logits, target, mask, dlogit, loss_sum, n,
+                     chw, hw, grad_scale);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_mse(const float* r, const float* t, float* dr, double* loss_sum, int64_t n,
+                         float grad_scale, void* stream) {
+  if (!r || !t || !loss_sum) return MMDYN_ERR_NULL;
+  int g = ew_grid(n);
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(mse_kernel, dim3(g), dim3(256), 0, ST, r, t, dr, loss_sum, n, grad_scale);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_elbo_assemble(const double* bce, const double* mse, const double* kl, float* loss,
+                                   float* partials, int P, int B, float kl_weight, float pose_multiplier,
+                                   void* stream) {
+  if (!loss) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(elbo_assemble_kernel, dim3(1), dim3(64), 0, ST, bce, mse, kl, loss, partials, P, B,
+                     kl_weight, pose_multiplier);
+  MMDYN_LAUNCH_CHECK();
+}

@@ -1,0 +1,209 @@
+// Weight packing and the 3-channel (NCHW) side of the first / last layer.
+//   - canonical reference weight layouts (vae.py:198-206, 268-277: Conv2d [Cout][Cin][4][4],
+//     ConvTranspose2d [Cin][Cout][4][4], Linear [out][in]) -> [tap][n][k] GEMM operands;
+//   - im2col of the 3-channel NCHW image (input of Conv2d(3,32,4,2,1), vae.py:198; logit gradient of
+//     ConvTranspose2d(32,3,4,2,1), vae.py:277);
+//   - col2im (transposed-conv scatter written as a gather, so it is deterministic and atomic-free).
+// All HBM-bound, fully coalesced on the write side.
+#include "common.h"
+
+namespace {
+
+__global__ void pack_conv_weight_kernel(const float* __restrict__ Wc, float* __restrict__ P, int d0, int d1,
+                                        int swap) {
+  const int64_t total = (int64_t)16 * d0 * d1;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    // i indexes P[tap][x][y]
+    int nx = swap ? d1 : d0, ny = swap ? d0 : d1;
+    int y = (int)(i % ny);
+    int64_t t = i / ny;
+    int x = (int)(t % nx);
+    int tap = (int)(t / nx);
+    int a = swap ? y : x, b = swap ? x : y;  // canonical indices (d0, d1)
+    P[i] = Wc[((int64_t)a * d1 + b) * 16 + tap];
+  }
+}
+
+__global__ void repack2d_kernel(const float* __restrict__ in, float* __restrict__ out, int rows_in,
+                                int cols_in, int rows_out, int cols_out, int mode) {
+  const int64_t total = (int64_t)rows_out * cols_out;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % cols_out), r = (int)(i / cols_out);
+    int ri, ci;
+    switch (mode) {
+      case 0: ri = r; ci = c; break;
+      case 1: ri = c; ci = r; break;
+      case 2: { int hw = c / 256, ch = c - hw * 256; ri = r; ci = ch * 25 + hw; } break;
+      case 3: { int hw = r / 256, ch = r - hw * 256; ri = ch * 25 + hw; ci = c; } break;
+      case 4: { int hw = r / 256, ch = r - hw * 256; ri = c; ci = ch * 25 + hw; } break;
+      default: { int hw = c / 256, ch = c - hw * 256; ri = ch * 25 + hw; ci = r; } break;
+    }
+    float v = 0.f;
+    if (ri < rows_in && ci < cols_in) v = in[(int64_t)ri * cols_in + ci];
+    out[i] = v;
+  }
+}
+
+// one thread per (output pixel, ci*4+kh): writes one float4 = the 4 kw taps; 16 threads cover a 64-float row
+__global__ void im2col_nchw3_kernel(const float* __restrict__ x, float* __restrict__ col, int Bt, int H,
+                                    int W) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)Bt * Ho * Wo * 16;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int q = (int)(i & 15);
+    int64_t pix = i >> 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < 12) {
+      int ci = q >> 2, kh = q & 3;
+      int wo = (int)(pix % Wo);
+      int64_t t = pix / Wo;
+      int ho = (int)(t % Ho);
+      int b = (int)(t / Ho);
+      int y = 2 * ho - 1 + kh;
+      if ((unsigned)y < (unsigned)H) {
+        const float* row = x + (((int64_t)b * 3 + ci) * H + y) * W;
+        int x0 = 2 * wo - 1;
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+          int xx = x0 + kw;
+          if ((unsigned)xx < (unsigned)W) v[kw] = row[xx];
+        }
+      }
+    }
+    reinterpret_cast<f32x4*>(col)[i] = v;
+  }
+}
+
+// out(b, ho, wo, c) = sum over taps with (ho + p - kh) % s == 0: col[(b, hi, wi)][tap, c]
+template <bool TAP_MAJOR>
+__global__ void col2im_k4_kernel(const float* __restrict__ col, float* __restrict__ out, int Bt, int Hi,
+                                 int Wi, int Ho, int Wo, int C, int ldcol, int s, int p) {
+  const int64_t total = (int64_t)Bt * Ho * Wo * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int b, c, ho, wo;
+    if (TAP_MAJOR) {  // NHWC output
+      c = (int)(i % C);
+      int64_t t = i / C;
+      wo = (int)(t % Wo);
+      t /= Wo;
+      ho = (int)(t % Ho);
+      b = (int)(t / Ho);
+    } else {          // NCHW output
+      wo = (int)(i % Wo);
+      int64_t t = i / Wo;
+      ho = (int)(t % Ho);
+      t /= Ho;
+      c = (int)(t % C);
+      b = (int)(t / C);
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+      int ty = ho + p - kh;
+      if (ty < 0 || (ty % s) != 0) continue;
+      int hi = ty / s;
+      if (hi >= Hi) continue;
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw) {
+        int tx = wo + p - kw;
+        if (tx < 0 || (tx % s) != 0) continue;
+        int wi = tx / s;
+        if (wi >= Wi) continue;
+        int tap = kh * 4 + kw;
+        int64_t row = ((int64_t)b * Hi + hi) * Wi + wi;
+        int cc = TAP_MAJOR ? (tap * C + c) : (c * 16 + tap);
+        acc += col[row * ldcol + cc];
+      }
+    }
+    out[i] = acc;
+  }
+}
+
+// [B][C][HW] <-> [B][HW][C]; small tensors only (3-channel images), simple gather
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C,
+                                    int HW) {
+  const int64_t total = (int64_t)B * C * HW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    int64_t t = i / C;
+    int p = (int)(t % HW);
+    int b = (int)(t / HW);
+    out[i] = in[((int64_t)b * C + c) * HW + p];
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C,
+                                    int HW) {
+  const int64_t total = (int64_t)B * C * HW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int p = (int)(i % HW);
+    int64_t t = i / HW;
+    int c = (int)(t % C);
+    int b = (int)(t / C);
+    out[i] = in[((int64_t)b * HW + p) * C + c];
+  }
+}
+
+}  // namespace
+
+extern "C" const char* mmdyn_version(void) { return "mmdyn_hip 0.1 (gfx950)"; }
+
+extern "C" int mmdyn_pack_conv_weight(const float* Wc, float* P, int d0, int d1, int swap, void* stream) {
+  if (!Wc || !P) return MMDYN_ERR_NULL;
+  if (d0 <= 0 || d1 <= 0) return MMDYN_ERR_SHAPE;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(ew_grid((int64_t)16 * d0 * d1)), dim3(256), 0,
+                     (hipStream_t)stream, Wc, P, d0, d1, swap);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_repack2d(const float* in, float* out, int rows_in, int cols_in, int rows_out,
+                              int cols_out, int mode, void* stream) {
+  if (!in || !out) return MMDYN_ERR_NULL;
+  if (mode < 0 || mode > 5 || rows_out <= 0 || cols_out <= 0) return MMDYN_ERR_SHAPE;
+  hipLaunchKernelGGL(repack2d_kernel, dim3(ew_grid((int64_t)rows_out * cols_out)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, rows_in, cols_in, rows_out, cols_out, mode);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_im2col_nchw3(const float* x, float* col, int Bt, int H, int W, void* stream) {
+  if (!x || !col) return MMDYN_ERR_NULL;
+  if (H % 2 || W % 2 || Bt <= 0) return MMDYN_ERR_SHAPE;
+  int64_t total = (int64_t)Bt * (H / 2) * (W / 2) * 16;
+  hipLaunchKernelGGL(im2col_nchw3_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, col,
+                     Bt, H, W);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_col2im_k4(const float* col, float* out, int Bt, int Hi, int Wi, int Ho, int Wo, int C,
+                               int ldcol, int stride, int pad, int tap_major, void* stream) {
+  if (!col || !out) return MMDYN_ERR_NULL;
+  if (stride < 1 || Ho != (Hi - 1) * stride - 2 * pad + 4 || Wo != (Wi - 1) * stride - 2 * pad + 4 ||
+      ldcol < 16 * C)
+    return MMDYN_ERR_SHAPE;
+  int64_t total = (int64_t)Bt * Ho * Wo * C;
+  if (tap_major)
+    hipLaunchKernelGGL(col2im_k4_kernel<true>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, col,
+                       out, Bt, Hi, Wi, Ho, Wo, C, ldcol, stride, pad);
+  else
+    hipLaunchKernelGGL(col2im_k4_kernel<false>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       col, out, Bt, Hi, Wi, Ho, Wo, C, ldcol, stride, pad);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, void* stream) {
+  if (!in || !out) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((int64_t)B * C * HW)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, B, C, HW);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, void* stream) {
+  if (!in || !out) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid((int64_t)B * C * HW)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, B, C, HW);
+  MMDYN_LAUNCH_CHECK();
+}

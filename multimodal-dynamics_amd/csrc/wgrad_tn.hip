@@ -1,0 +1,265 @@
+// MFMA weight-gradient GEMM, TN form (reduction over rows), fp32 (v_mfma_f32_32x32x2_f32, gfx950).
+//
+//   partial[chunk][tap][cd][cg] = sum_{row in chunk} D[row][cd] * G_tap[row][cg]
+//
+// Replaces the ATen weight-gradient kernels of nn.Conv2d / nn.ConvTranspose2d / nn.Linear used by
+// loss.backward() on the reference path (/root/reference/mmdyn/pytorch/problems/problems.py:153).
+//
+// D is the "dense" operand (one contiguous row per GEMM row), G the "gathered" one (for the 16 taps of
+// a k=4 convolution the row's pixel is shifted by (kh, kw); out-of-image rows read as zero).  For a
+// Conv2d, D = dY and G = X; for a ConvTranspose2d, D = X and G = dY -- in both cases the reference's
+// canonical weight layout is [cd][cg][kh][kw], which mmdyn_wgrad_reduce produces.
+//
+// Both tiles sit in LDS row-major ([32 rows][channels]); the MFMA A operand A[i][k] is read as
+// Ds[k][cd0+i] and the B operand B[k][j] as Gs[k][cg0+j]: consecutive lanes read consecutive floats,
+// conflict-free ds_read_b32.  The row reduction is split over `chunks` blocks (deterministic partial
+// slabs, no atomics); a second kernel sums the slabs and scatters into the canonical layout.
+#include "common.h"
+
+namespace {
+
+struct WgradGeom {
+  int mode;  // MMDYN_DENSE or MMDYN_CONV
+  int rows;  // Bt*Hr*Wr
+  int Hr, Wr, Cd;
+  int Hi, Wi, Cg;
+  int rs, ro;
+  int ntaps, chunks, rows_per_chunk;
+};
+
+constexpr int RK = 32;  // rows per K-step
+
+// WK = number of waves that split the rows of one K-step between them (small channel tiles cannot
+// occupy four waves with distinct 32x32 outputs); each of them owns its own partial slab.
+template <int BD, int BG, int WD, int WG, int WK>
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__ D,
+                                                       const float* __restrict__ Gt,
+                                                       float* __restrict__ partial, const WgradGeom g) {
+  constexpr int DT = WD / 32, GT = WG / 32;
+  constexpr int WAVES_G = BG / WG;
+  constexpr int WAVES_DG = (BD / WD) * WAVES_G;
+  static_assert(WAVES_DG * WK == 4, "4 waves per block");
+  constexpr int KPW = (RK / 2) / WK;
+  constexpr int DV = BD / 4, GV = BG / 4;            // float4 per tile row
+  constexpr int D_LOADS = (RK * DV) / 256, G_LOADS = (RK * GV) / 256;
+  static_assert(D_LOADS >= 1 && G_LOADS >= 1, "tile too small for 256 threads");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Ds = reinterpret_cast<float*>(smem);  // [RK][BD]
+  float* Gs = Ds + RK * BD;                    // [RK][BG]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / WAVES_DG, wdg = wave % WAVES_DG;
+  const int wd = wdg / WAVES_G, wg = wdg % WAVES_G;
+  const int tiles_g = g.Cg / BG;
+  const int td = blockIdx.x / tiles_g, tg = blockIdx.x - td * tiles_g;
+  const int cd0 = td * BD, cg0 = tg * BG;
+  const int tap = blockIdx.y, chunk = blockIdx.z;
+  const int dh = (g.mode == MMDYN_CONV) ? (tap >> 2) : 0;
+  const int dw = (g.mode == MMDYN_CONV) ? (tap & 3) : 0;
+  const int HWr = g.Hr * g.Wr;
+
+  const int row_begin = chunk * g.rows_per_chunk;
+  const int row_end = min(g.rows, row_begin + g.rows_per_chunk);
+
+  f32x4 rd[D_LOADS], rg[G_LOADS];
+  auto gload = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < D_LOADS; ++i) {
+      int idx = tid + 256 * i;
+      int r = idx / DV, v = idx - r * DV;
+      int row = r0 + r;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (row < row_end) val = *reinterpret_cast<const f32x4*>(D + (size_t)row * g.Cd + cd0 + v * 4);
+      rd[i] = val;
+    }
+#pragma unroll
+    for (int i = 0; i < G_LOADS; ++i) {
+      int idx = tid + 256 * i;
+      int r = idx / GV, v = idx - r * GV;
+      int row = r0 + r;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (row < row_end) {
+        size_t pix;
+        bool ok = true;
+        if (g.mode == MMDYN_CONV) {
+          int b = row / HWr;
+          int p = row - b * HWr;
+          int rr = p / g.Wr;
+          int cc = p - rr * g.Wr;
+          int y = rr * g.rs + g.ro + dh, x = cc * g.rs + g.ro + dw;
+          ok = ((unsigned)y < (unsigned)g.Hi) && ((unsigned)x < (unsigned)g.Wi);
+          pix = (size_t)((b * g.Hi + y) * g.Wi + x);
+        } else {
+          pix = (size_t)row;
+        }
+        if (ok) val = *reinterpret_cast<const f32x4*>(Gt + pix * g.Cg + cg0 + v * 4);
+      }
+      rg[i] = val;
+    }
+  };
+  auto lds_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < D_LOADS; ++i) {
+      int idx = tid + 256 * i;
+      reinterpret_cast<f32x4*>(Ds)[idx] = rd[i];
+    }
+#pragma unroll
+    for (int i = 0; i < G_LOADS; ++i) {
+      int idx = tid + 256 * i;
+      reinterpret_cast<f32x4*>(Gs)[idx] = rg[i];
+    }
+  };
+
+  f32x16 acc[DT][GT];
+#pragma unroll
+  for (int a = 0; a < DT; ++a)
+#pragma unroll
+    for (int b = 0; b < GT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int h = lane >> 5, cl = lane & 31;
+  if (row_begin < row_end) {
+    gload(row_begin);
+    lds_store();
+    __syncthreads();
+    for (int r0 = row_begin; r0 < row_end; r0 += RK) {
+      const bool more = (r0 + RK < row_end);
+      if (more) gload(r0 + RK);
+#pragma unroll
+      for (int kk = wk * KPW; kk < (wk + 1) * KPW; ++kk) {
+        float af[DT], bf[GT];
+#pragma unroll
+        for (int a = 0; a < DT; ++a) af[a] = Ds[(2 * kk + h) * BD + wd * WD + a * 32 + cl];
+#pragma unroll
+        for (int b = 0; b < GT; ++b) bf[b] = Gs[(2 * kk + h) * BG + wg * WG + b * 32 + cl];
+#pragma unroll
+        for (int a = 0; a < DT; ++a)
+#pragma unroll
+          for (int b = 0; b < GT; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        lds_store();
+        __syncthreads();
+      }
+    }
+  }
+
+  float* out = partial + ((size_t)((chunk * WK + wk) * g.ntaps + tap) * g.Cd) * g.Cg;
+#pragma unroll
+  for (int a = 0; a < DT; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int cd = cd0 + wd * WD + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+#pragma unroll
+      for (int b = 0; b < GT; ++b) {
+        const int cg = cg0 + wg * WG + b * 32 + cl;
+        out[(size_t)cd * g.Cg + cg] = acc[a][b][e];
+      }
+    }
+}
+
+// canon (+)= sum_chunks partial, scattered into the reference layout
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ canon, int chunks,
+                                    int taps, int Cd, int Cg, int cg_canon, int perm, float beta) {
+  const int64_t slab = (int64_t)taps * Cd * Cg;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < slab;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int cg = (int)(i % Cg);
+    int64_t t = i / Cg;
+    int cd = (int)(t % Cd);
+    int tap = (int)(t / Cd);
+    if (cg >= cg_canon) continue;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * slab + i];
+    int64_t o;
+    if (perm == 0) {
+      o = ((int64_t)cd * cg_canon + cg) * taps + tap;
+    } else if (perm == 1) {  // cg = hw*256 + ch  -> column ch*25 + hw
+      int hw = cg / 256, ch = cg - hw * 256;
+      o = (int64_t)cd * cg_canon + ch * 25 + hw;
+    } else {                 // cd = hw*256 + ch  -> row ch*25 + hw
+      int hw = cd / 256, ch = cd - hw * 256;
+      o = (int64_t)(ch * 25 + hw) * cg_canon + cg;
+    }
+    canon[o] = (beta != 0.f) ? (beta * canon[o] + s) : s;
+  }
+}
+
+template <int BD, int BG, int WD, int WG, int WK>
+static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, hipStream_t st) {
+  const int zblocks = g.chunks / WK;  // chunks % 4 == 0 is checked by the caller
+  int rpc = ceil_div(g.rows, zblocks);
+  g.rows_per_chunk = ceil_div(rpc, RK) * RK;
+  dim3 grid((g.Cd / BD) * (g.Cg / BG), g.ntaps, zblocks);
+  size_t smem = (size_t)RK * (BD + BG) * sizeof(float);
+  hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  MMDYN_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+extern "C" int mmdyn_wgrad_tn(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr,
+                              int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
+                              void* stream) {
+  if (!D || !Gt || !partial) return MMDYN_ERR_NULL;
+  if (Cd % 32 || Cg % 32 || Cd <= 0 || Cg <= 0 || chunks < 4 || chunks % 4) return MMDYN_ERR_SHAPE;
+  if (mode != MMDYN_DENSE && mode != MMDYN_CONV) return MMDYN_ERR_SHAPE;
+  WgradGeom g{};
+  g.mode = mode;
+  const int64_t rows = (int64_t)Bt * Hr * Wr;
+  if (rows * Cd >= (1LL << 31) || (int64_t)Bt * Hi * Wi * Cg >= (1LL << 31)) return MMDYN_ERR_RANGE;
+  g.rows = (int)rows;
+  g.Hr = Hr;
+  g.Wr = Wr;
+  g.Cd = Cd;
+  g.Hi = Hi;
+  g.Wi = Wi;
+  g.Cg = Cg;
+  g.rs = stride;
+  g.ro = offset;
+  g.ntaps = (mode == MMDYN_CONV) ? 16 : 1;
+  g.chunks = chunks;
+  hipStream_t st = (hipStream_t)stream;
+  const bool d64 = (Cd % 64 == 0), g64 = (Cg % 64 == 0);
+  if (Cd % 128 == 0 && Cg % 128 == 0) return launch<128, 128, 64, 64, 1>(D, Gt, partial, g, st);
+  if (d64 && g64) return launch<64, 64, 32, 32, 1>(D, Gt, partial, g, st);
+  if (d64) return launch<64, 32, 32, 32, 2>(D, Gt, partial, g, st);
+  if (g64) return launch<32, 64, 32, 32, 2>(D, Gt, partial, g, st);
+  return launch<32, 32, 32, 32, 4>(D, Gt, partial, g, st);
+}
+
+// recommended number of partial slabs: ~1024 blocks in flight, at least 128 rows per block
+extern "C" int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg) {
+  if (Cd % 32 || Cg % 32 || rows <= 0) return MMDYN_ERR_SHAPE;
+  int bd, bg, wk;
+  if (Cd % 128 == 0 && Cg % 128 == 0) { bd = 128; bg = 128; wk = 1; }
+  else if (Cd % 64 == 0 && Cg % 64 == 0) { bd = 64; bg = 64; wk = 1; }
+  else if (Cd % 64 == 0) { bd = 64; bg = 32; wk = 2; }
+  else if (Cg % 64 == 0) { bd = 32; bg = 64; wk = 2; }
+  else { bd = 32; bg = 32; wk = 4; }
+  const int taps = (mode == MMDYN_CONV) ? 16 : 1;
+  const long tiles = (long)(Cd / bd) * (Cg / bg) * taps;
+  long z = 1024 / tiles;
+  const long zmax = rows / 128;
+  if (z > zmax) z = zmax;
+  if (z < 1) z = 1;
+  long chunks = z * wk;
+  chunks = (chunks + 3) / 4 * 4;
+  return (int)chunks;
+}
+
+extern "C" int mmdyn_wgrad_reduce(const float* partial, float* canon, int chunks, int taps, int Cd, int Cg,
+                                  int cg_canon, int perm, float beta, void* stream) {
+  if (!partial || !canon) return MMDYN_ERR_NULL;
+  if (cg_canon > Cg || cg_canon <= 0) return MMDYN_ERR_SHAPE;
+  if (perm == 1 && (Cg % 256 || Cg / 256 != 25)) return MMDYN_ERR_SHAPE;
+  if (perm == 2 && (Cd % 256 || Cd / 256 != 25)) return MMDYN_ERR_SHAPE;
+  int64_t slab = (int64_t)taps * Cd * Cg;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(slab)), dim3(256), 0, (hipStream_t)stream, partial,
+                     canon, chunks, taps, Cd, Cg, cg_canon, perm, beta);
+  MMDYN_LAUNCH_CHECK();
+}

@@ -1,0 +1,100 @@
+"""ctypes binding of libmmdyn_hip.so (include/mmdyn_hip.h).
+
+The HIP library IS the product's compute path: there is no CPU or PyTorch fallback.  If the shared
+object is missing or a symbol is absent the import fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmdyn_hip.so")
+
+_P, _I, _L, _F, _Q = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
+
+
+class PassExperts(ctypes.Structure):
+    """mmdyn_pass_experts (include/mmdyn_hip.h)."""
+    _fields_ = [("mu", _P * 4), ("lv", _P * 4), ("dmu", _P * 4), ("dlv", _P * 4), ("ld", _I * 4)]
+
+
+MAX_PASSES = 8
+MAX_EXPERTS = 4
+
+# name -> argument type codes, in header order: p pointer, i int, l int64, f float, Q uint64
+_SIGNATURES = {
+    "mmdyn_igemm_nt": "ppppppp" + "iiiiiiiiiiiiii" + "p",
+    "mmdyn_igemm_stat_tiles": "iiiiiiii",
+    "mmdyn_splitk_reduce": "pppp" + "iiii" + "p",
+    "mmdyn_wgrad_tn": "ppp" + "iiiiiiiiiiii" + "p",
+    "mmdyn_wgrad_chunks": "iiii",
+    "mmdyn_wgrad_reduce": "pp" + "iiiiii" + "f" + "p",
+    "mmdyn_pack_conv_weight": "pp" + "iii" + "p",
+    "mmdyn_repack2d": "pp" + "iiiii" + "p",
+    "mmdyn_im2col_nchw3": "pp" + "iii" + "p",
+    "mmdyn_col2im_k4": "pp" + "iiiiiiiiii" + "p",
+    "mmdyn_colstats": "pp" + "iii" + "p",
+    "mmdyn_colstats_tiles": "i",
+    "mmdyn_bn_finalize": "ppppppp" + "iiii" + "ff" + "i" + "p",
+    "mmdyn_bn_swish_fwd": "pppppp" + "iii" + "p",
+    "mmdyn_bn_swish_bwd_reduce": "ppppppp" + "iii" + "p",
+    "mmdyn_bn_bwd_finalize": "ppppp" + "iii" + "f" + "p",
+    "mmdyn_bn_swish_bwd_apply": "pppppppp" + "iii" + "p",
+    "mmdyn_act_fwd": "pp" + "l" + "i" + "p",
+    "mmdyn_act_bwd": "ppp" + "l" + "i" + "p",
+    "mmdyn_dropout_expand": "ppp" + "iii" + "f" + "p",
+    "mmdyn_dropout_reduce": "ppp" + "iii" + "f" + "p",
+    "mmdyn_random_masks": "p" + "l" + "f" + "QQ" + "p",
+    "mmdyn_random_normal": "p" + "l" + "QQ" + "p",
+    "mmdyn_colsum": "pp" + "iii" + "f" + "p",
+    "mmdyn_sum_blocks": "pp" + "i" + "l" + "p",
+    "mmdyn_linear_small_fwd": "pppp" + "iiii" + "p",
+    "mmdyn_linear_small_bwd": "pppppp" + "iii" + "f" + "p",
+    "mmdyn_poe_fwd": "pppppp" + "iiii" + "p",
+    "mmdyn_poe_bwd": "ppppppp" + "f" + "iiii" + "p",
+    "mmdyn_reparam_fwd": "ppppp" + "iii" + "p",
+    "mmdyn_reparam_bwd": "pppp" + "f" + "pp" + "iii" + "p",
+    "mmdyn_bce_logits": "ppppp" + "l" + "ii" + "f" + "p",
+    "mmdyn_mse": "pppp" + "l" + "f" + "p",
+    "mmdyn_elbo_assemble": "ppppp" + "ii" + "ff" + "p",
+    "mmdyn_adam_step": "ppppp" + "l" + "fffff" + "p",
+    "mmdyn_nchw_to_nhwc": "pp" + "iii" + "p",
+    "mmdyn_nhwc_to_nchw": "pp" + "iii" + "p",
+}
+_CODES = {"p": _P, "i": _I, "l": _L, "f": _F, "Q": _Q}
+
+EXPORTS = ["mmdyn_version"] + list(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load the library once; raises OSError / AttributeError if it (or a symbol) is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(
+            f"{LIB_PATH} not found: build it with `make -C multimodal-dynamics_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()').  There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.mmdyn_version.restype = ctypes.c_char_p
+    lib.mmdyn_version.argtypes = []
+    for name, sig in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = _I
+        fn.argtypes = [_CODES[c] for c in sig]
+    _lib = lib
+    return lib
+
+
+class MmdynError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "MMDYN_ERR_SHAPE (unsupported dimensions)", -2: "MMDYN_ERR_NULL (null pointer)",
+        -3: "MMDYN_ERR_RANGE (tensor too large for 32-bit offsets)"}
+
+
+def check(rc, name):
+    if rc != 0:
+        raise MmdynError(f"{name} failed: {_ERR.get(rc, 'hipError_t %d' % rc)}")

@@ -1,0 +1,376 @@
+"""Layer stacks of the cnn VAE / MVAE as explicit forward / backward kernel sequences.
+
+This is the host-side schedule of the hot path: which ``mmdyn_*`` kernel runs on which buffer.  The
+arithmetic itself is entirely in libmmdyn_hip.so (see :mod:`mmdyn_hip.ops`); torch supplies device
+memory (``torch.empty``) only.
+
+Layout: activations between layers are channels-last matrices ``[rows][C]`` with rows ordered
+(sample, y, x).  A batch may consist of ``G`` groups of ``Bg`` samples (one group per modality-subset
+pass of the reference's ``_evaluate_mvae``); train-mode BatchNorm statistics are per group, which makes
+the grouped batch numerically identical to ``G`` separate reference forward calls.
+
+Reference structure restated here (file:line relative to /root/reference/mmdyn/pytorch/models/vae.py):
+  image encoder  :197-216, 224-242      image decoder  :263-279, 285-301
+  pose MLPs      :117-123, 14-19        the flatten order c*25+hw of :227/:295 is absorbed into the
+  packed FC weights (hw*256+c), so no activation is ever transposed.
+"""
+import torch
+
+from . import ops
+from .ops import ACT_NONE, ACT_SWISH, ACT_RELU, DENSE, CONV, TCONV_S2P1
+from .models.shapes import BN_EPS, BN_MOMENTUM, FEAT
+
+
+def _new(like, *shape, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+# ------------------------------------------------------------------------------------------------
+# primitive helpers
+# ------------------------------------------------------------------------------------------------
+def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False):
+    """C = A[rows][K] . Bp[N][K]^T (+bias) on the MFMA GEMM; picks split-K for short, wide-K problems.
+    Returns (pre_activation, activated or None)."""
+    C = _new(A, rows, N)
+    Ca = _new(A, rows, N) if want_act else None
+    tiles = _cdiv(rows, 64) * _cdiv(N, 128)
+    steps = K // 32
+    splitk = 1
+    if tiles < 256 and steps >= 8:
+        splitk = max(1, min(steps // 4, _cdiv(512, tiles)))
+    if splitk > 1:
+        ws = _new(A, splitk, rows, N)
+        ops.B.igemm_nt(A, Bp, None, C, None, None, ws, DENSE, 1, rows, 1, 1, K, 1, 1, N, N, 1, 0, ACT_NONE, splitk)
+        ops.B.splitk_reduce(ws, bias, C, Ca, splitk, rows, N, act)
+    else:
+        ops.B.igemm_nt(A, Bp, bias, C, Ca, None, None, DENSE, 1, rows, 1, 1, K, 1, 1, N, N, 1, 0, act, 1)
+    return C, Ca
+
+
+def conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride=1, offset=0, stats=False):
+    """Implicit-GEMM conv / transposed conv on NHWC rows; optional per-tile BatchNorm partial sums."""
+    Bt = G * Bg
+    y = _new(x, Bt * Ho * Ho, N)
+    st, T = None, 0
+    if stats:
+        T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Ho, Ho, N)
+        st = _new(x, G, T, 2, N)
+    ops.B.igemm_nt(x, Wp, None, y, None, st, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset,
+                   ACT_NONE, 1)
+    return y, st, T
+
+
+class BNState:
+    """Handles of one BatchNorm2d: affine parameters + running buffers (may be None to skip updates)."""
+    __slots__ = ("gamma", "beta", "rm", "rv", "nbt")
+
+    def __init__(self, gamma, beta, rm=None, rv=None, nbt=None):
+        self.gamma, self.beta, self.rm, self.rv, self.nbt = gamma, beta, rm, rv, nbt
+
+
+def bn_swish_from_partials(y, partial, T, bn, G, rows_per_group, C, repeat=1):
+    mean, rstd = _new(y, G, C), _new(y, G, C)
+    scratch = _new(y, G, 2, C, dtype=torch.float64)
+    ops.B.bn_finalize(partial, mean, rstd, bn.rm, bn.rv, bn.nbt, scratch, G, T, C, rows_per_group, BN_EPS,
+                      BN_MOMENTUM, repeat)
+    a = torch.empty_like(y)
+    ops.B.bn_swish_fwd(y, mean, rstd, bn.gamma, bn.beta, a, G, rows_per_group, C)
+    return a, mean, rstd
+
+
+def bn_swish_backward(da, y, mean, rstd, bn, dgamma, dbeta, G, rows_per_group, C):
+    T = ops.B.colstats_tiles(rows_per_group)
+    partial = _new(y, G, T, 2, C)
+    sums = _new(y, G, 2, C)
+    scratch = _new(y, G, 2, C, dtype=torch.float64)
+    ops.B.bn_swish_bwd_reduce(da, y, mean, rstd, bn.gamma, bn.beta, partial, G, rows_per_group, C)
+    ops.B.bn_bwd_finalize(partial, sums, dgamma, dbeta, scratch, G, T, C, 0.0)
+    dy = torch.empty_like(y)
+    ops.B.bn_swish_bwd_apply(da, y, mean, rstd, bn.gamma, bn.beta, sums, dy, G, rows_per_group, C)
+    return dy
+
+
+def wgrad(D, Gt, canon, mode, Bt, Hr, Cd, Hi, Cg, stride=1, offset=0, cg_canon=None, perm=0):
+    """canon[cd][cg][taps] = sum_rows D[row][cd] * G_tap[row][cg]  (reference weight-gradient layout)."""
+    rows = Bt * Hr * Hr
+    taps = 16 if mode == CONV else 1
+    chunks = ops.B.wgrad_chunks(mode, rows, Cd, Cg)
+    partial = _new(D, chunks, taps, Cd, Cg)
+    ops.B.wgrad_tn(D, Gt, partial, mode, Bt, Hr, Hr, Cd, Hi, Hi, Cg, stride, offset, chunks)
+    ops.B.wgrad_reduce(partial, canon, chunks, taps, Cd, Cg, Cg if cg_canon is None else cg_canon, perm, 0.0)
+
+
+def pack_conv(W, swap):
+    d0, d1 = W.shape[0], W.shape[1]
+    P = _new(W, 16, d1 if swap else d0, d0 if swap else d1)
+    ops.B.pack_conv_weight(W, P, d0, d1, swap)
+    return P
+
+
+def repack(W, rows_in, cols_in, rows_out, cols_out, mode):
+    out = _new(W, rows_out, cols_out)
+    ops.B.repack2d(W, out, rows_in, cols_in, rows_out, cols_out, mode)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# generic Linear (MFMA when both dims are multiples of 32, the small kernel for the 7-wide pose ends)
+# ------------------------------------------------------------------------------------------------
+def linear_forward(x, W, b, act=ACT_NONE):
+    """y = act(x W^T + b).  Returns (pre_activation or None, y)."""
+    rows, K = x.shape
+    N = W.shape[0]
+    if K % 32 == 0 and N % 32 == 0:
+        if act == ACT_NONE:
+            u, _ = dense(x, W, b, rows, K, N)
+            return None, u
+        u, y = dense(x, W, b, rows, K, N, act, want_act=True)
+        return u, y
+    y = _new(x, rows, N)
+    ops.B.linear_small_fwd(x, W, b, y, rows, K, N, act)
+    return None, y
+
+
+def linear_backward(dy, x, W, gW, gb, need_dx=True):
+    """Gradients of y = x W^T + b given dy (already through the activation).  Returns dx or None."""
+    rows, K = x.shape
+    N = W.shape[0]
+    if K % 32 == 0 and N % 32 == 0:
+        wgrad(dy, x, gW, DENSE, rows, 1, N, 1, K)
+        if gb is not None:
+            ops.B.colsum(dy, gb, rows, N, 0, 0.0)
+        if not need_dx:
+            return None
+        Wt = repack(W, N, K, K, N, 1)
+        dx, _ = dense(dy, Wt, None, rows, N, K)
+        return dx
+    dx = _new(x, rows, K) if need_dx else None
+    ops.B.linear_small_bwd(dy, x, W, dx, gW, gb, rows, K, N, 0.0)
+    return dx
+
+
+def act_backward(dh, u, act):
+    du = torch.empty_like(u)
+    ops.B.act_bwd(dh, u, du, act)
+    return du
+
+
+# ------------------------------------------------------------------------------------------------
+# image encoder trunk: conv_net + fc_net (up to, not including, the dropout)
+# ------------------------------------------------------------------------------------------------
+ENC_KEYS = ["conv_net.0.weight", "conv_net.2.weight", "conv_net.3.weight", "conv_net.3.bias",
+            "conv_net.5.weight", "conv_net.6.weight", "conv_net.6.bias", "conv_net.8.weight",
+            "conv_net.9.weight", "conv_net.9.bias", "fc_net.0.weight", "fc_net.0.bias"]
+ENC_BN = ["conv_net.3", "conv_net.6", "conv_net.9"]
+
+
+def _bn_of(P, buf, pre):
+    b = buf or {}
+    return BNState(P[pre + ".weight"], P[pre + ".bias"], b.get(pre + ".running_mean"),
+                   b.get(pre + ".running_var"), b.get(pre + ".num_batches_tracked"))
+
+
+def encoder_trunk_forward(P, buf, x, G=1, repeat=1):
+    """x: NCHW [Bt,3,64,64] -> h = Swish(fc(conv stack)) [Bt,512]; returns (h, ctx).
+    ``repeat``: how many reference forward calls this one stands for (running-stat EMA updates)."""
+    Bt = x.shape[0]
+    Bg = Bt // G
+    c = {"Bt": Bt, "G": G, "Bg": Bg}
+    W1p = repack(P["conv_net.0.weight"], 32, 48, 32, 64, 0)                   # [32][64], cols 48.. zero
+    col1 = _new(x, Bt * 1024, 64)
+    ops.B.im2col_nchw3(x, col1, Bt, 64, 64)
+    u1, a1 = _new(x, Bt * 1024, 32), _new(x, Bt * 1024, 32)
+    ops.B.igemm_nt(col1, W1p, None, u1, a1, None, None, DENSE, 1, Bt * 1024, 1, 1, 64, 1, 1, 32, 32, 1, 0,
+                   ACT_SWISH, 1)
+    bn2, bn3, bn4 = (_bn_of(P, buf, k) for k in ENC_BN)
+    y2, st, T = conv_like(a1, pack_conv(P["conv_net.2.weight"], False), CONV, G, Bg, 32, 32, 16, 64, 2, -1, True)
+    a2, m2, r2 = bn_swish_from_partials(y2, st, T, bn2, G, Bg * 256, 64, repeat)
+    y3, st, T = conv_like(a2, pack_conv(P["conv_net.5.weight"], False), CONV, G, Bg, 16, 64, 8, 128, 2, -1, True)
+    a3, m3, r3 = bn_swish_from_partials(y3, st, T, bn3, G, Bg * 64, 128, repeat)
+    y4, st, T = conv_like(a3, pack_conv(P["conv_net.8.weight"], False), CONV, G, Bg, 8, 128, 5, 256, 1, 0, True)
+    a4, m4, r4 = bn_swish_from_partials(y4, st, T, bn4, G, Bg * 25, 256, repeat)
+    Wf = repack(P["fc_net.0.weight"], 512, FEAT, 512, FEAT, 2)               # columns -> hw*256+c
+    u5, h = dense(a4, Wf, P["fc_net.0.bias"], Bt, FEAT, 512, ACT_SWISH, want_act=True)
+    c.update(col1=col1, u1=u1, a1=a1, y2=y2, a2=a2, m2=m2, r2=r2, y3=y3, a3=a3, m3=m3, r3=r3, y4=y4, a4=a4,
+             m4=m4, r4=r4, u5=u5, bn=(bn2, bn3, bn4))
+    return h, c
+
+
+def encoder_trunk_backward(P, c, dh, grads):
+    """dh: [Bt,512]; writes every weight gradient of the trunk into ``grads[key]`` (canonical layout)."""
+    Bt, G, Bg = c["Bt"], c["G"], c["Bg"]
+    bn2, bn3, bn4 = c["bn"]
+    du5 = act_backward(dh, c["u5"], ACT_SWISH)
+    wgrad(du5, c["a4"], grads["fc_net.0.weight"], DENSE, Bt, 1, 512, 1, FEAT, perm=1)
+    ops.B.colsum(du5, grads["fc_net.0.bias"], Bt, 512, 0, 0.0)
+    WfT = repack(P["fc_net.0.weight"], 512, FEAT, FEAT, 512, 4)             # [hw*256+c][512]
+    da4, _ = dense(du5, WfT, None, Bt, 512, FEAT)
+    dy4 = bn_swish_backward(da4, c["y4"], c["m4"], c["r4"], bn4, grads["conv_net.9.weight"],
+                            grads["conv_net.9.bias"], G, Bg * 25, 256)
+    wgrad(dy4, c["a3"], grads["conv_net.8.weight"], CONV, Bt, 5, 256, 8, 128, 1, 0)
+    W4s = pack_conv(P["conv_net.8.weight"], True)                            # [16][128 ci][256 co]
+    col, _ = dense(dy4, W4s, None, Bt * 25, 256, 2048)
+    da3 = _new(dh, Bt * 64, 128)
+    ops.B.col2im_k4(col, da3, Bt, 5, 5, 8, 8, 128, 2048, 1, 0, True)
+    dy3 = bn_swish_backward(da3, c["y3"], c["m3"], c["r3"], bn3, grads["conv_net.6.weight"],
+                            grads["conv_net.6.bias"], G, Bg * 64, 128)
+    wgrad(dy3, c["a2"], grads["conv_net.5.weight"], CONV, Bt, 8, 128, 16, 64, 2, -1)
+    da2, _, _ = conv_like(dy3, pack_conv(P["conv_net.5.weight"], True), TCONV_S2P1, 1, Bt, 8, 128, 16, 64)
+    dy2 = bn_swish_backward(da2, c["y2"], c["m2"], c["r2"], bn2, grads["conv_net.3.weight"],
+                            grads["conv_net.3.bias"], G, Bg * 256, 64)
+    wgrad(dy2, c["a1"], grads["conv_net.2.weight"], CONV, Bt, 16, 64, 32, 32, 2, -1)
+    da1, _, _ = conv_like(dy2, pack_conv(P["conv_net.2.weight"], True), TCONV_S2P1, 1, Bt, 16, 64, 32, 32)
+    du1 = act_backward(da1, c["u1"], ACT_SWISH)
+    wgrad(du1, c["col1"], grads["conv_net.0.weight"], DENSE, Bt * 1024, 1, 32, 1, 64, cg_canon=48)
+
+
+# ------------------------------------------------------------------------------------------------
+# image decoder: upsample FC + hallucinate stack -> logits (NCHW)
+# ------------------------------------------------------------------------------------------------
+DEC_KEYS = ["upsample.0.weight", "upsample.0.bias", "hallucinate.0.weight", "hallucinate.1.weight",
+            "hallucinate.1.bias", "hallucinate.3.weight", "hallucinate.4.weight", "hallucinate.4.bias",
+            "hallucinate.6.weight", "hallucinate.7.weight", "hallucinate.7.bias", "hallucinate.9.weight"]
+DEC_BN = ["hallucinate.1", "hallucinate.4", "hallucinate.7"]
+
+
+def decoder_forward(P, buf, z, G=1, repeat=1, logits=True):
+    """z: [Bt, L] -> logits NCHW [Bt,3,64,64]; returns (logits, ctx).  ``logits=False`` stops after the last
+    BatchNorm (used only to reproduce the running statistics of the reference's unused decoder passes)."""
+    Bt, L = z.shape
+    Bg = Bt // G
+    c = {"Bt": Bt, "G": G, "Bg": Bg, "L": L, "z": z}
+    Wu = repack(P["upsample.0.weight"], FEAT, L, FEAT, L, 3)                  # rows -> hw*256+c
+    bu = repack(P["upsample.0.bias"], FEAT, 1, FEAT, 1, 3).view(FEAT)
+    u0, h0 = dense(z, Wu, bu, Bt, L, FEAT, ACT_SWISH, want_act=True)
+    bn1, bn2, bn3 = (_bn_of(P, buf, k) for k in DEC_BN)
+    W1s = pack_conv(P["hallucinate.0.weight"], True)                          # [16][128 co][256 ci]
+    col, _ = dense(h0, W1s, None, Bt * 25, 256, 2048)
+    y1 = _new(z, Bt * 64, 128)
+    ops.B.col2im_k4(col, y1, Bt, 5, 5, 8, 8, 128, 2048, 1, 0, True)
+    T = ops.B.colstats_tiles(Bg * 64)
+    st = _new(z, G, T, 2, 128)
+    ops.B.colstats(y1, st, G, Bg * 64, 128)
+    a1, m1, r1 = bn_swish_from_partials(y1, st, T, bn1, G, Bg * 64, 128, repeat)
+    y2, st, T = conv_like(a1, pack_conv(P["hallucinate.3.weight"], True), TCONV_S2P1, G, Bg, 8, 128, 16, 64,
+                          stats=True)
+    a2, m2, r2 = bn_swish_from_partials(y2, st, T, bn2, G, Bg * 256, 64, repeat)
+    y3, st, T = conv_like(a2, pack_conv(P["hallucinate.6.weight"], True), TCONV_S2P1, G, Bg, 16, 64, 32, 32,
+                          stats=True)
+    a3, m3, r3 = bn_swish_from_partials(y3, st, T, bn3, G, Bg * 1024, 32, repeat)
+    out = None
+    if logits:
+        W4T = repack(P["hallucinate.9.weight"], 32, 48, 64, 32, 1)            # [co*16+tap (pad 64)][ci]
+        col4, _ = dense(a3, W4T, None, Bt * 1024, 32, 64)
+        out = _new(z, Bt, 3, 64, 64)
+        ops.B.col2im_k4(col4, out, Bt, 32, 32, 64, 64, 3, 64, 2, 1, False)
+    c.update(u0=u0, h0=h0, y1=y1, a1=a1, m1=m1, r1=r1, y2=y2, a2=a2, m2=m2, r2=r2, y3=y3, a3=a3, m3=m3, r3=r3,
+             bn=(bn1, bn2, bn3))
+    return out, c
+
+
+def decoder_backward(P, c, dlogits, grads, need_dz=True):
+    """dlogits: NCHW [Bt,3,64,64] -> dz [Bt, L]; weight gradients into ``grads``."""
+    Bt, G, Bg, L = c["Bt"], c["G"], c["Bg"], c["L"]
+    bn1, bn2, bn3 = c["bn"]
+    dcol4 = _new(dlogits, Bt * 1024, 64)
+    ops.B.im2col_nchw3(dlogits, dcol4, Bt, 64, 64)
+    wgrad(c["a3"], dcol4, grads["hallucinate.9.weight"], DENSE, Bt * 1024, 1, 32, 1, 64, cg_canon=48)
+    W4p = repack(P["hallucinate.9.weight"], 32, 48, 32, 64, 0)
+    da3, _ = dense(dcol4, W4p, None, Bt * 1024, 64, 32)
+    dy3 = bn_swish_backward(da3, c["y3"], c["m3"], c["r3"], bn3, grads["hallucinate.7.weight"],
+                            grads["hallucinate.7.bias"], G, Bg * 1024, 32)
+    wgrad(c["a2"], dy3, grads["hallucinate.6.weight"], CONV, Bt, 16, 64, 32, 32, 2, -1)
+    da2, _, _ = conv_like(dy3, pack_conv(P["hallucinate.6.weight"], False), CONV, 1, Bt, 32, 32, 16, 64, 2, -1)
+    dy2 = bn_swish_backward(da2, c["y2"], c["m2"], c["r2"], bn2, grads["hallucinate.4.weight"],
+                            grads["hallucinate.4.bias"], G, Bg * 256, 64)
+    wgrad(c["a1"], dy2, grads["hallucinate.3.weight"], CONV, Bt, 8, 128, 16, 64, 2, -1)
+    da1, _, _ = conv_like(dy2, pack_conv(P["hallucinate.3.weight"], False), CONV, 1, Bt, 16, 64, 8, 128, 2, -1)
+    dy1 = bn_swish_backward(da1, c["y1"], c["m1"], c["r1"], bn1, grads["hallucinate.1.weight"],
+                            grads["hallucinate.1.bias"], G, Bg * 64, 128)
+    wgrad(c["h0"], dy1, grads["hallucinate.0.weight"], CONV, Bt, 5, 256, 8, 128, 1, 0)
+    dh0, _, _ = conv_like(dy1, pack_conv(P["hallucinate.0.weight"], False), CONV, 1, Bt, 8, 128, 5, 256, 1, 0)
+    du0 = act_backward(dh0, c["u0"], ACT_SWISH)
+    wgrad(du0, c["z"], grads["upsample.0.weight"], DENSE, Bt, 1, FEAT, 1, L, perm=2)
+    ops.B.colsum(du0, grads["upsample.0.bias"], Bt, FEAT, 2, 0.0)
+    if not need_dz:
+        return None
+    WuT = repack(P["upsample.0.weight"], FEAT, L, L, FEAT, 5)                # [L][hw*256+c]
+    dz, _ = dense(du0, WuT, None, Bt, FEAT, L)
+    return dz
+
+
+# ------------------------------------------------------------------------------------------------
+# fused heads (linear_means | linear_log_var) and the pose MLPs
+# ------------------------------------------------------------------------------------------------
+def heads_forward(P, hd):
+    """hd: [rows, 512] -> out [rows, 2L]: columns [0,L) = means, [L,2L) = log-variances."""
+    Wm, Wl = P["linear_means.weight"], P["linear_log_var.weight"]
+    L, K = Wm.shape
+    Wh = _new(hd, 2 * L, K)
+    ops.B.repack2d(Wm, Wh[:L], L, K, L, K, 0)
+    ops.B.repack2d(Wl, Wh[L:], L, K, L, K, 0)
+    bh = _new(hd, 2 * L)
+    ops.B.repack2d(P["linear_means.bias"], bh[:L], L, 1, L, 1, 0)
+    ops.B.repack2d(P["linear_log_var.bias"], bh[L:], L, 1, L, 1, 0)
+    out, _ = dense(hd, Wh, bh, hd.shape[0], K, 2 * L)
+    return out, {"hd": hd, "Wh": Wh, "L": L, "K": K}
+
+
+def heads_backward(c, dout, grads, need_dx=True):
+    hd, Wh, L, K = c["hd"], c["Wh"], c["L"], c["K"]
+    rows = hd.shape[0]
+    gW, gb = _new(hd, 2 * L, K), _new(hd, 2 * L)
+    wgrad(dout, hd, gW, DENSE, rows, 1, 2 * L, 1, K)
+    ops.B.colsum(dout, gb, rows, 2 * L, 0, 0.0)
+    ops.B.repack2d(gW[:L], grads["linear_means.weight"], L, K, L, K, 0)
+    ops.B.repack2d(gW[L:], grads["linear_log_var.weight"], L, K, L, K, 0)
+    ops.B.repack2d(gb[:L], grads["linear_means.bias"], L, 1, L, 1, 0)
+    ops.B.repack2d(gb[L:], grads["linear_log_var.bias"], L, 1, L, 1, 0)
+    if not need_dx:
+        return None
+    WhT = repack(Wh, 2 * L, K, K, 2 * L, 1)
+    dx, _ = dense(dout, WhT, None, rows, 2 * L, K)
+    return dx
+
+
+HEAD_KEYS = ["linear_means.weight", "linear_means.bias", "linear_log_var.weight", "linear_log_var.bias"]
+POSE_ENC_KEYS = ["fc_net.0.weight", "fc_net.0.bias", "fc_net.2.weight", "fc_net.2.bias"]
+POSE_DEC_KEYS = ["deconv_net.0.weight", "deconv_net.0.bias", "deconv_net.2.weight", "deconv_net.2.bias",
+                 "deconv_net.4.weight", "deconv_net.4.bias"]
+
+
+def pose_encoder_trunk_forward(P, pose):
+    """Linear(7,512) ReLU Linear(512,512) (Identity): vae.py:218-222 with layer_sizes [512,512]."""
+    _, h1 = linear_forward(pose, P["fc_net.0.weight"], P["fc_net.0.bias"], ACT_RELU)
+    _, h2 = linear_forward(h1, P["fc_net.2.weight"], P["fc_net.2.bias"], ACT_NONE)
+    return h2, {"x": pose, "h1": h1}
+
+
+def pose_encoder_trunk_backward(P, c, dh2, grads):
+    dh1 = linear_backward(dh2, c["h1"], P["fc_net.2.weight"], grads["fc_net.2.weight"], grads["fc_net.2.bias"])
+    du1 = act_backward(dh1, c["h1"], ACT_RELU)       # ReLU: sign of the output equals sign of the input
+    linear_backward(du1, c["x"], P["fc_net.0.weight"], grads["fc_net.0.weight"], grads["fc_net.0.bias"],
+                    need_dx=False)
+
+
+def pose_decoder_forward(P, z):
+    """Linear(L,512) ReLU Linear(512,512) ReLU Linear(512,7): vae.py:281-283."""
+    _, h1 = linear_forward(z, P["deconv_net.0.weight"], P["deconv_net.0.bias"], ACT_RELU)
+    _, h2 = linear_forward(h1, P["deconv_net.2.weight"], P["deconv_net.2.bias"], ACT_RELU)
+    _, out = linear_forward(h2, P["deconv_net.4.weight"], P["deconv_net.4.bias"], ACT_NONE)
+    return out, {"z": z, "h1": h1, "h2": h2}
+
+
+def pose_decoder_backward(P, c, dout, grads, need_dz=True):
+    dh2 = linear_backward(dout, c["h2"], P["deconv_net.4.weight"], grads["deconv_net.4.weight"],
+                          grads["deconv_net.4.bias"])
+    du2 = act_backward(dh2, c["h2"], ACT_RELU)
+    dh1 = linear_backward(du2, c["h1"], P["deconv_net.2.weight"], grads["deconv_net.2.weight"],
+                          grads["deconv_net.2.bias"])
+    du1 = act_backward(dh1, c["h1"], ACT_RELU)
+    return linear_backward(du1, c["z"], P["deconv_net.0.weight"], grads["deconv_net.0.weight"],
+                           grads["deconv_net.0.bias"], need_dx=need_dz)

@@ -1,0 +1,236 @@
+"""Tensor-level wrappers over the C ABI (include/mmdyn_hip.h).
+
+Every method of :class:`HipBackend` maps 1:1 onto one ``mmdyn_*`` entry point: it validates device /
+dtype / contiguity, passes raw device pointers and launches on torch's *current* HIP stream.  PyTorch is
+used only for memory, streams and autograd plumbing -- all arithmetic of the hot path happens in
+libmmdyn_hip.so.  There is no CPU / ATen fallback: a CPU tensor raises.
+
+``B`` is the active backend.  The test-suite may swap in an emulation object (tests/emu_backend.py) to
+exercise the host-side orchestration on a machine without a GPU; nothing in the product does.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import PassExperts, MAX_PASSES, MAX_EXPERTS, check
+
+ACT_NONE, ACT_SWISH, ACT_RELU = 0, 1, 2
+DENSE, CONV, TCONV_S2P1 = 0, 1, 2
+
+
+def _ptr(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("mmdyn_hip: the HIP path needs GPU tensors (got a CPU tensor); there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"mmdyn_hip: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("mmdyn_hip: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self._l = None
+
+    @property
+    def lib(self):
+        if self._l is None:
+            self._l = _lib.load()
+        return self._l
+
+    # ---- host-only helpers (no GPU needed) ----
+    def igemm_stat_tiles(self, mode, G, Bg, Hi, Wi, Ho, Wo, N):
+        return self.lib.mmdyn_igemm_stat_tiles(mode, G, Bg, Hi, Wi, Ho, Wo, N)
+
+    def colstats_tiles(self, rows_per_group):
+        return self.lib.mmdyn_colstats_tiles(rows_per_group)
+
+    def wgrad_chunks(self, mode, rows, Cd, Cg):
+        r = self.lib.mmdyn_wgrad_chunks(mode, rows, Cd, Cg)
+        if r < 0:
+            check(r, "mmdyn_wgrad_chunks")
+        return r
+
+    # ---- GEMMs ----
+    def igemm_nt(self, A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride,
+                 offset, act, splitk):
+        check(self.lib.mmdyn_igemm_nt(_ptr(A), _ptr(Bp), _ptr(bias), _ptr(C), _ptr(C_act), _ptr(stats), _ptr(ws),
+                                      mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk,
+                                      _stream()), "mmdyn_igemm_nt")
+
+    def splitk_reduce(self, ws, bias, C, C_act, splitk, rows, N, act):
+        check(self.lib.mmdyn_splitk_reduce(_ptr(ws), _ptr(bias), _ptr(C), _ptr(C_act), splitk, rows, N, act,
+                                           _stream()), "mmdyn_splitk_reduce")
+
+    def wgrad_tn(self, D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks):
+        check(self.lib.mmdyn_wgrad_tn(_ptr(D), _ptr(Gt), _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride,
+                                      offset, chunks, _stream()), "mmdyn_wgrad_tn")
+
+    def wgrad_reduce(self, partial, canon, chunks, taps, Cd, Cg, cg_canon, perm, beta):
+        check(self.lib.mmdyn_wgrad_reduce(_ptr(partial), _ptr(canon), chunks, taps, Cd, Cg, cg_canon, perm,
+                                          float(beta), _stream()), "mmdyn_wgrad_reduce")
+
+    # ---- packing / layout ----
+    def pack_conv_weight(self, Wc, P, d0, d1, swap):
+        check(self.lib.mmdyn_pack_conv_weight(_ptr(Wc), _ptr(P), d0, d1, int(swap), _stream()),
+              "mmdyn_pack_conv_weight")
+
+    def repack2d(self, src, dst, rows_in, cols_in, rows_out, cols_out, mode):
+        check(self.lib.mmdyn_repack2d(_ptr(src), _ptr(dst), rows_in, cols_in, rows_out, cols_out, mode, _stream()),
+              "mmdyn_repack2d")
+
+    def im2col_nchw3(self, x, col, Bt, H, W):
+        check(self.lib.mmdyn_im2col_nchw3(_ptr(x), _ptr(col), Bt, H, W, _stream()), "mmdyn_im2col_nchw3")
+
+    def col2im_k4(self, col, out, Bt, Hi, Wi, Ho, Wo, C, ldcol, stride, pad, tap_major):
+        check(self.lib.mmdyn_col2im_k4(_ptr(col), _ptr(out), Bt, Hi, Wi, Ho, Wo, C, ldcol, stride, pad,
+                                       int(tap_major), _stream()), "mmdyn_col2im_k4")
+
+    def nchw_to_nhwc(self, src, dst, B, C, HW):
+        check(self.lib.mmdyn_nchw_to_nhwc(_ptr(src), _ptr(dst), B, C, HW, _stream()), "mmdyn_nchw_to_nhwc")
+
+    def nhwc_to_nchw(self, src, dst, B, C, HW):
+        check(self.lib.mmdyn_nhwc_to_nchw(_ptr(src), _ptr(dst), B, C, HW, _stream()), "mmdyn_nhwc_to_nchw")
+
+    # ---- BatchNorm + Swish ----
+    def colstats(self, y, partial, G, rows_per_group, C):
+        check(self.lib.mmdyn_colstats(_ptr(y), _ptr(partial), G, rows_per_group, C, _stream()), "mmdyn_colstats")
+
+    def bn_finalize(self, partial, mean, rstd, running_mean, running_var, nbt, scratch, G, T, C, rows_per_group,
+                    eps, momentum, repeat):
+        check(self.lib.mmdyn_bn_finalize(_ptr(partial), _ptr(mean), _ptr(rstd), _ptr(running_mean),
+                                         _ptr(running_var), _ptr(nbt, torch.int64), _ptr(scratch, torch.float64),
+                                         G, T, C, rows_per_group, eps, momentum, repeat, _stream()),
+              "mmdyn_bn_finalize")
+
+    def bn_swish_fwd(self, y, mean, rstd, gamma, beta, a, G, rows_per_group, C):
+        check(self.lib.mmdyn_bn_swish_fwd(_ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(a), G,
+                                          rows_per_group, C, _stream()), "mmdyn_bn_swish_fwd")
+
+    def bn_swish_bwd_reduce(self, da, y, mean, rstd, gamma, beta, partial, G, rows_per_group, C):
+        check(self.lib.mmdyn_bn_swish_bwd_reduce(_ptr(da), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                                                 _ptr(beta), _ptr(partial), G, rows_per_group, C, _stream()),
+              "mmdyn_bn_swish_bwd_reduce")
+
+    def bn_bwd_finalize(self, partial, sums, dgamma, dbeta, scratch, G, T, C, beta_acc):
+        check(self.lib.mmdyn_bn_bwd_finalize(_ptr(partial), _ptr(sums), _ptr(dgamma), _ptr(dbeta),
+                                             _ptr(scratch, torch.float64), G, T, C, float(beta_acc), _stream()),
+              "mmdyn_bn_bwd_finalize")
+
+    def bn_swish_bwd_apply(self, da, y, mean, rstd, gamma, beta, sums, dy, G, rows_per_group, C):
+        check(self.lib.mmdyn_bn_swish_bwd_apply(_ptr(da), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+                                                _ptr(sums), _ptr(dy), G, rows_per_group, C, _stream()),
+              "mmdyn_bn_swish_bwd_apply")
+
+    # ---- element-wise ----
+    def act_fwd(self, u, h, act):
+        check(self.lib.mmdyn_act_fwd(_ptr(u), _ptr(h), u.numel(), act, _stream()), "mmdyn_act_fwd")
+
+    def act_bwd(self, dh, u, du, act):
+        check(self.lib.mmdyn_act_bwd(_ptr(dh), _ptr(u), _ptr(du), u.numel(), act, _stream()), "mmdyn_act_bwd")
+
+    def dropout_expand(self, h, masks, out, P, B, H, p_drop):
+        check(self.lib.mmdyn_dropout_expand(_ptr(h), _ptr(masks, torch.uint8), _ptr(out), P, B, H, p_drop,
+                                            _stream()), "mmdyn_dropout_expand")
+
+    def dropout_reduce(self, dout, masks, dh, P, B, H, p_drop):
+        check(self.lib.mmdyn_dropout_reduce(_ptr(dout), _ptr(masks, torch.uint8), _ptr(dh), P, B, H, p_drop,
+                                            _stream()), "mmdyn_dropout_reduce")
+
+    def random_masks(self, masks, p_drop, seed, offset):
+        check(self.lib.mmdyn_random_masks(_ptr(masks, torch.uint8), masks.numel(), p_drop, seed, offset, _stream()),
+              "mmdyn_random_masks")
+
+    def random_normal(self, out, seed, offset):
+        check(self.lib.mmdyn_random_normal(_ptr(out), out.numel(), seed, offset, _stream()), "mmdyn_random_normal")
+
+    def colsum(self, x, out, rows, C, perm, beta):
+        check(self.lib.mmdyn_colsum(_ptr(x), _ptr(out), rows, C, perm, float(beta), _stream()), "mmdyn_colsum")
+
+    def sum_blocks(self, x, out, P, n):
+        check(self.lib.mmdyn_sum_blocks(_ptr(x), _ptr(out), P, n, _stream()), "mmdyn_sum_blocks")
+
+    def linear_small_fwd(self, x, W, b, y, rows, K, N, act):
+        check(self.lib.mmdyn_linear_small_fwd(_ptr(x), _ptr(W), _ptr(b), _ptr(y), rows, K, N, act, _stream()),
+              "mmdyn_linear_small_fwd")
+
+    def linear_small_bwd(self, dy, x, W, dx, dW, db, rows, K, N, beta):
+        check(self.lib.mmdyn_linear_small_bwd(_ptr(dy), _ptr(x), _ptr(W), _ptr(dx), _ptr(dW), _ptr(db), rows, K, N,
+                                              float(beta), _stream()), "mmdyn_linear_small_bwd")
+
+    # ---- latent / loss ----
+    @staticmethod
+    def _passes(passes):
+        """passes: list of dicts {'mu': [t|None]*n, 'lv': [...], 'dmu': [...], 'dlv': [...], 'ld': [int]*n}, n<=4;
+        tensors may be views (row stride ld) into the fused heads output, so raw data_ptr is used."""
+        arr = (PassExperts * MAX_PASSES)()
+        for i, p in enumerate(passes):
+            for m in range(len(p["ld"])):
+                for key in ("mu", "lv", "dmu", "dlv"):
+                    t = p.get(key, [None] * MAX_EXPERTS)[m]
+                    if t is not None:
+                        if not t.is_cuda or t.dtype != torch.float32 or t.stride(-1) != 1:
+                            raise ValueError("mmdyn_hip: expert tensors must be fp32 GPU tensors with unit inner stride")
+                        getattr(arr[i], key)[m] = t.data_ptr()
+                arr[i].ld[m] = int(p["ld"][m])
+        return arr
+
+    def poe_fwd(self, passes, eps_noise, mu, logvar, z, kl_sum, with_prior, P, B, L):
+        arr = self._passes(passes)
+        check(self.lib.mmdyn_poe_fwd(ctypes.cast(arr, ctypes.c_void_p), _ptr(eps_noise), _ptr(mu), _ptr(logvar),
+                                     _ptr(z), _ptr(kl_sum, torch.float64), int(with_prior), P, B, L, _stream()),
+              "mmdyn_poe_fwd")
+
+    def poe_bwd(self, passes, eps_noise, mu, logvar, dz, g_mu, g_lv, kl_scale, with_prior, P, B, L):
+        arr = self._passes(passes)
+        check(self.lib.mmdyn_poe_bwd(ctypes.cast(arr, ctypes.c_void_p), _ptr(eps_noise), _ptr(mu), _ptr(logvar),
+                                     _ptr(dz), _ptr(g_mu), _ptr(g_lv), float(kl_scale), int(with_prior), P, B, L,
+                                     _stream()), "mmdyn_poe_bwd")
+
+    def reparam_fwd(self, mu, lv, eps_noise, z, kl_sum, B, L, ld):
+        """mu/lv may be column views (row stride ld) of the fused heads output."""
+        check(self.lib.mmdyn_reparam_fwd(mu.data_ptr(), lv.data_ptr(), _ptr(eps_noise), _ptr(z),
+                                         None if kl_sum is None else kl_sum.data_ptr(), B, L, ld, _stream()),
+              "mmdyn_reparam_fwd")
+
+    def reparam_bwd(self, mu, lv, eps_noise, dz, kl_scale, dmu, dlv, B, L, ld):
+        check(self.lib.mmdyn_reparam_bwd(mu.data_ptr(), lv.data_ptr(), _ptr(eps_noise), _ptr(dz), float(kl_scale),
+                                         dmu.data_ptr(), dlv.data_ptr(), B, L, ld, _stream()), "mmdyn_reparam_bwd")
+
+    def bce_logits(self, logits, target, mask, dlogit, loss_sum, n, chw, hw, grad_scale):
+        check(self.lib.mmdyn_bce_logits(_ptr(logits), _ptr(target), _ptr(mask), _ptr(dlogit),
+                                        loss_sum.data_ptr(), n, chw, hw, float(grad_scale), _stream()),
+              "mmdyn_bce_logits")
+
+    def mse(self, r, t, dr, loss_sum, n, grad_scale):
+        check(self.lib.mmdyn_mse(_ptr(r), _ptr(t), _ptr(dr), loss_sum.data_ptr(), n, float(grad_scale), _stream()),
+              "mmdyn_mse")
+
+    def elbo_assemble(self, bce, mse, kl, loss, partials, P, B, kl_weight, pose_multiplier):
+        check(self.lib.mmdyn_elbo_assemble(_ptr(bce, torch.float64), _ptr(mse, torch.float64),
+                                           _ptr(kl, torch.float64), _ptr(loss), _ptr(partials), P, B,
+                                           float(kl_weight), float(pose_multiplier), _stream()),
+              "mmdyn_elbo_assemble")
+
+    def adam_step(self, p, g, m, v, state, lr, beta1, beta2, eps, grad_scale):
+        check(self.lib.mmdyn_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(state, torch.float64), p.numel(),
+                                       lr, beta1, beta2, eps, grad_scale, _stream()), "mmdyn_adam_step")
+
+
+B = HipBackend()
+
+
+def set_backend(b):
+    """Test hook only (tests/emu_backend.py): swap the object that executes the ops."""
+    global B
+    old, B = B, b
+    return old
