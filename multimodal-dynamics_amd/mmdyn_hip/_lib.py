@@ -25,7 +25,7 @@ _SIGNATURES = {
     "mmdyn_igemm_nt": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_stat_tiles": "iiiiiiii",
     "mmdyn_splitk_reduce": "pppp" + "iiii" + "p",
-    "mmdyn_wgrad_tn": "ppp" + "iiiiiiiiiiii" + "p",
+    "mmdyn_wgrad_tn": "ppp" + "iiiiiiiiiii" + "p",
     "mmdyn_wgrad_chunks": "iiii",
     "mmdyn_wgrad_reduce": "pp" + "iiiiii" + "f" + "p",
     "mmdyn_pack_conv_weight": "pp" + "iii" + "p",

@@ -1,0 +1,309 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point of libmmdyn_hip.so is run on the GPU and
+compared with the CPU contract emulation (tests/emu_backend.py) / the oracle on identical seeded inputs.
+fp32 MFMA is an exact fp32 fma chain, so tolerances only cover summation-order differences."""
+import math
+
+import pytest
+import torch
+
+from mmdyn_hip import ops
+from mmdyn_hip.ops import DENSE, CONV, TCONV_S2P1
+from emu_backend import EmuBackend
+
+pytestmark = pytest.mark.gpu
+
+HIP = ops.HipBackend()
+EMU = EmuBackend()
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def both(name, args, outs, post=None, tol=2e-5):
+    """Call HIP.<name> on GPU copies and EMU.<name> on CPU copies of `args`; compare the tensors named in
+    `outs` (indices into args)."""
+    gpu_args = [a.to(DEV) if torch.is_tensor(a) else a for a in args]
+    cpu_args = [a.clone() if torch.is_tensor(a) else a for a in args]
+    getattr(HIP, name)(*gpu_args)
+    torch.cuda.synchronize()
+    getattr(EMU, name)(*cpu_args)
+    for i in outs:
+        g, c = gpu_args[i].cpu(), cpu_args[i]
+        if post:
+            g, c = post(i, g), post(i, c)
+        assert torch.isfinite(g).all(), (name, i)
+        assert rel(g, c) <= tol, (name, i, rel(g, c))
+    return gpu_args, cpu_args
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+IGEMM_CASES = [
+    # mode, G, Bg, Hi, Cin, Ho, N, stride, offset
+    (DENSE, 1, 256, 1, 64, 1, 32, 1, 0),
+    (DENSE, 1, 100, 1, 256, 1, 2048, 1, 0),
+    (DENSE, 1, 37, 1, 512, 1, 512, 1, 0),
+    (DENSE, 2, 50, 1, 32, 1, 64, 1, 0),
+    (CONV, 1, 4, 32, 32, 16, 64, 2, -1),
+    (CONV, 2, 3, 16, 64, 8, 128, 2, -1),
+    (CONV, 1, 5, 8, 128, 5, 256, 1, 0),
+    (CONV, 1, 3, 32, 32, 16, 64, 2, -1),
+    (TCONV_S2P1, 1, 4, 8, 128, 16, 64, 1, 0),
+    (TCONV_S2P1, 2, 3, 16, 64, 32, 32, 1, 0),
+    (TCONV_S2P1, 1, 2, 16, 64, 32, 32, 1, 0),
+    (CONV, 4, 64, 8, 128, 5, 256, 1, 0),       # 4 groups, rows not a tile multiple (64*25 = 1600)
+]
+
+
+@pytest.mark.parametrize("case", IGEMM_CASES)
+def test_igemm_nt(case):
+    mode, G, Bg, Hi, Cin, Ho, N, stride, offset = case
+    Bt = G * Bg
+    taps = 16 if mode != DENSE else 1
+    A = rnd(Bt * Hi * Hi, Cin, seed=1)
+    Bp = rnd(taps, N, Cin, seed=2, scale=0.2)
+    bias = rnd(N, seed=3)
+    C = torch.zeros(Bt * Ho * Ho, N)
+    Ca = torch.zeros(Bt * Ho * Ho, N)
+    T = HIP.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Ho, Ho, N)
+    stats = torch.zeros(G, T, 2, N)
+    post = lambda i, t: t.sum(1) if i == 5 else t
+    # plain output + stats, no bias
+    both("igemm_nt", [A, Bp, None, C, None, stats, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1],
+         [3, 5], post)
+    # bias + swish second output
+    both("igemm_nt", [A, Bp, bias, C, Ca, None, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 1, 1],
+         [3, 4])
+
+
+@pytest.mark.parametrize("rows,K,N,splitk", [(256, 6400, 512, 25), (64, 512, 256, 3), (1024, 6400, 256, 8), (5, 64, 32, 2)])
+def test_igemm_splitk(rows, K, N, splitk):
+    A, Bp, bias = rnd(rows, K, seed=4), rnd(N, K, seed=5, scale=0.1), rnd(N, seed=6)
+    ws = torch.zeros(splitk, rows, N)
+    C, Ca = torch.zeros(rows, N), torch.zeros(rows, N)
+    ga, ca = both("igemm_nt", [A, Bp, None, C, None, None, ws, DENSE, 1, rows, 1, 1, K, 1, 1, N, N, 1, 0, 0, splitk],
+                  [6], lambda i, t: t.sum(0))
+    HIP.splitk_reduce(ga[6], bias.to(DEV), ga[3], Ca.to(DEV), splitk, rows, N, 1)
+    ref = A @ Bp.t() + bias
+    assert rel(ga[3], ref) < 2e-5
+
+
+WGRAD_CASES = [
+    # mode, Bt, Hr, Cd, Hi, Cg, stride, offset, cg_canon, perm
+    (DENSE, 300, 1, 512, 1, 512, 1, 0, None, 0),
+    (DENSE, 4 * 1024, 1, 32, 1, 64, 1, 0, 48, 0),
+    (DENSE, 64, 1, 512, 1, 6400, 1, 0, None, 1),
+    (DENSE, 64, 1, 6400, 1, 256, 1, 0, None, 2),
+    (CONV, 3, 16, 64, 32, 32, 2, -1, None, 0),
+    (CONV, 3, 8, 128, 16, 64, 2, -1, None, 0),
+    (CONV, 5, 5, 256, 8, 128, 1, 0, None, 0),
+    (CONV, 2, 16, 64, 32, 32, 2, -1, None, 0),
+    (CONV, 3, 8, 128, 16, 64, 2, -1, None, 0),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad(case):
+    mode, Bt, Hr, Cd, Hi, Cg, stride, offset, cgc, perm = case
+    rows = Bt * Hr * Hr
+    taps = 16 if mode == CONV else 1
+    D = rnd(rows, Cd, seed=7)
+    Gt = rnd(Bt * Hi * Hi, Cg, seed=8)
+    chunks = HIP.wgrad_chunks(mode, rows, Cd, Cg)
+    assert chunks % 4 == 0
+    partial = torch.zeros(chunks, taps, Cd, Cg)
+    ga, ca = both("wgrad_tn", [D, Gt, partial, mode, Bt, Hr, Hr, Cd, Hi, Hi, Cg, stride, offset, chunks], [2],
+                  lambda i, t: t.sum(0), tol=5e-5)
+    cgc = Cg if cgc is None else cgc
+    canon_g = torch.zeros(Cd * cgc * taps, device=DEV)
+    canon_c = torch.zeros(Cd * cgc * taps)
+    HIP.wgrad_reduce(ga[2], canon_g, chunks, taps, Cd, Cg, cgc, perm, 0.0)
+    EMU.wgrad_reduce(ca[2], canon_c, chunks, taps, Cd, Cg, cgc, perm, 0.0)
+    assert rel(canon_g, canon_c) < 5e-5
+    # accumulate form
+    HIP.wgrad_reduce(ga[2], canon_g, chunks, taps, Cd, Cg, cgc, perm, 1.0)
+    assert rel(canon_g, 2 * canon_c) < 5e-5
+
+
+def test_pack_and_layout_kernels():
+    W = rnd(64, 32, 4, 4, seed=9)
+    for swap in (0, 1):
+        both("pack_conv_weight", [W, torch.zeros(16 * 64 * 32), 64, 32, swap], [1], tol=0)
+    for mode, ri, ci, ro, co in [(0, 32, 48, 32, 64), (1, 32, 48, 64, 32), (2, 8, 6400, 8, 6400), (3, 6400, 8, 6400, 8),
+                                 (4, 8, 6400, 6400, 8), (5, 6400, 8, 8, 6400), (3, 6400, 1, 6400, 1)]:
+        both("repack2d", [rnd(ri, ci, seed=10), torch.zeros(ro * co), ri, ci, ro, co, mode], [1], tol=0)
+    x = rnd(3, 3, 64, 64, seed=11)
+    both("im2col_nchw3", [x, torch.zeros(3 * 1024 * 64), 3, 64, 64], [1], tol=0)
+    both("col2im_k4", [rnd(3 * 25, 2048, seed=12), torch.zeros(3 * 64 * 128), 3, 5, 5, 8, 8, 128, 2048, 1, 0, 1], [1])
+    both("col2im_k4", [rnd(2 * 1024, 64, seed=13), torch.zeros(2 * 3 * 64 * 64), 2, 32, 32, 64, 64, 3, 64, 2, 1, 0], [1])
+    both("nchw_to_nhwc", [x, torch.zeros(x.numel()), 3, 3, 4096], [1], tol=0)
+    both("nhwc_to_nchw", [x, torch.zeros(x.numel()), 3, 3, 4096], [1], tol=0)
+
+
+@pytest.mark.parametrize("G,rpg,C", [(1, 1600, 256), (4, 700, 128), (2, 5000, 64), (3, 4096, 32), (1, 100, 256)])
+def test_batchnorm_kernels(G, rpg, C):
+    y = rnd(G * rpg, C, seed=14) * 2 + 0.3
+    da = rnd(G * rpg, C, seed=15)
+    gamma, beta = rnd(C, seed=16) + 1.5, rnd(C, seed=17)
+    T = HIP.colstats_tiles(rpg)
+    partial = torch.zeros(G, T, 2, C)
+    ga, ca = both("colstats", [y, partial, G, rpg, C], [1], lambda i, t: t.sum(1))
+    mean, rstd = torch.zeros(G, C), torch.zeros(G, C)
+    rm, rv, nbt = rnd(C, seed=18), rnd(C, seed=19).abs() + 0.5, torch.zeros((), dtype=torch.long)
+    scratch = torch.zeros(G, 2, C, dtype=torch.float64)
+    args = [partial, mean, rstd, rm, rv, nbt, scratch, G, T, C, rpg, 1e-5, 0.1, 2]
+    g_args = [a.to(DEV) if torch.is_tensor(a) else a for a in args]
+    g_args[0] = ga[1]
+    HIP.bn_finalize(*g_args)
+    c_args = [a.clone() if torch.is_tensor(a) else a for a in args]
+    c_args[0] = ca[1]
+    EMU.bn_finalize(*c_args)
+    for i in (1, 2, 3, 4):
+        assert rel(g_args[i], c_args[i]) < 1e-5, i
+    assert int(g_args[5].cpu()) == 2 * G == int(c_args[5])
+    mean, rstd = c_args[1], c_args[2]
+    a = torch.zeros(G * rpg, C)
+    both("bn_swish_fwd", [y, mean, rstd, gamma, beta, a, G, rpg, C], [5])
+    ga, ca = both("bn_swish_bwd_reduce", [da, y, mean, rstd, gamma, beta, partial, G, rpg, C], [6],
+                  lambda i, t: t.sum(1), tol=1e-4)
+    sums, dg, db = torch.zeros(G, 2, C), torch.zeros(C), torch.zeros(C)
+    g2 = [ga[6], sums.to(DEV), dg.to(DEV), db.to(DEV), scratch.to(DEV), G, T, C, 0.0]
+    HIP.bn_bwd_finalize(*g2)
+    c2 = [ca[6], sums, dg, db, scratch, G, T, C, 0.0]
+    EMU.bn_bwd_finalize(*c2)
+    for i in (1, 2, 3):
+        assert rel(g2[i], c2[i]) < 1e-4, i
+    both("bn_swish_bwd_apply", [da, y, mean, rstd, gamma, beta, sums, torch.zeros(G * rpg, C), G, rpg, C], [7], tol=1e-4)
+
+
+def test_elementwise_kernels():
+    u, dh = rnd(1000, 513, seed=20) * 4, rnd(1000, 513, seed=21)
+    for act in (0, 1, 2):
+        both("act_fwd", [u, torch.zeros_like(u), act], [1])
+        both("act_bwd", [dh, u, torch.zeros_like(u), act], [2])
+    h = rnd(8, 512, seed=22)
+    masks = (torch.rand(4, 8, 512) > 0.1).to(torch.uint8)
+    both("dropout_expand", [h, masks, torch.zeros(4, 8, 512), 4, 8, 512, 0.1], [2])
+    both("dropout_reduce", [rnd(4, 8, 512, seed=23), masks, torch.zeros(8, 512), 4, 8, 512, 0.1], [2])
+    both("colsum", [rnd(300, 512, seed=24), torch.zeros(512), 300, 512, 0, 0.0], [1])
+    both("colsum", [rnd(64, 6400, seed=25), torch.zeros(6400), 64, 6400, 2, 0.0], [1])
+    both("sum_blocks", [rnd(4, 999, seed=26), torch.zeros(999), 4, 999], [1])
+    for rows, K, N, act in [(33, 7, 512, 2), (33, 512, 7, 0)]:
+        x, W, b = rnd(rows, K, seed=27), rnd(N, K, seed=28), rnd(N, seed=29)
+        both("linear_small_fwd", [x, W, b, torch.zeros(rows, N), rows, K, N, act], [3])
+        both("linear_small_bwd", [rnd(rows, N, seed=30), x, W, torch.zeros(rows, K), torch.zeros(N, K), torch.zeros(N),
+                                  rows, K, N, 0.0], [3, 4, 5])
+
+
+def test_adam_matches_torch():
+    n = 100003
+    p0, g = rnd(n, seed=31), rnd(n, seed=32) * 0.01
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    state = torch.zeros(3, dtype=torch.float64, device=DEV)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    for step in range(3):
+        HIP.adam_step(p, (g * (step + 1)).to(DEV), m, v, state, 1e-3, 0.9, 0.999, 1e-8, 1.0)
+        ref.grad = g * (step + 1)
+        opt.step()
+    assert float(state[0].cpu()) == 3.0
+    torch.testing.assert_close(p.cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_latent_and_loss_kernels():
+    B, L, P = 5, 256, 3
+    heads = [rnd(B, 2 * L, seed=40 + i) for i in range(3)]
+    dheads_g = [torch.zeros(B, 2 * L, device=DEV) for _ in range(3)]
+    dheads_c = [torch.zeros(B, 2 * L) for _ in range(3)]
+    eps = torch.randn(P, B, L, generator=torch.Generator().manual_seed(5))
+    subsets = [(1, 1, 0), (0, 1, 1), (1, 1, 1)]
+
+    def passes(hs, ds):
+        out = []
+        for s in subsets:
+            out.append({"mu": [hs[m][:, :L] if s[m] else None for m in range(3)],
+                        "lv": [hs[m][:, L:] if s[m] else None for m in range(3)],
+                        "dmu": [ds[m][:, :L] if s[m] else None for m in range(3)],
+                        "dlv": [ds[m][:, L:] if s[m] else None for m in range(3)], "ld": [2 * L] * 3})
+        return out
+
+    hg = [h.to(DEV) for h in heads]
+    mu_g, lv_g, z_g = (torch.zeros(P, B, L, device=DEV) for _ in range(3))
+    kl_g = torch.zeros(P, dtype=torch.float64, device=DEV)
+    HIP.poe_fwd(passes(hg, dheads_g), eps.to(DEV), mu_g, lv_g, z_g, kl_g, 1, P, B, L)
+    mu_c, lv_c, z_c = (torch.zeros(P, B, L) for _ in range(3))
+    kl_c = torch.zeros(P, dtype=torch.float64)
+    EMU.poe_fwd(passes(heads, dheads_c), eps, mu_c, lv_c, z_c, kl_c, 1, P, B, L)
+    for a, b in ((mu_g, mu_c), (lv_g, lv_c), (z_g, z_c), (kl_g, kl_c)):
+        assert rel(a, b) < 1e-5
+    dz = torch.randn(P, B, L, generator=torch.Generator().manual_seed(6))
+    # each pass writes its own gradient rows; run pass by pass so shared expert buffers are compared per pass
+    for p in range(P):
+        for d in dheads_g + dheads_c:
+            d.zero_()
+        HIP.poe_bwd(passes(hg, dheads_g)[p:p + 1], eps[p:p + 1].to(DEV), mu_g[p:p + 1].contiguous(),
+                    lv_g[p:p + 1].contiguous(), dz[p:p + 1].to(DEV), None, None, 0.02 / B, 1, 1, B, L)
+        EMU.poe_bwd(passes(heads, dheads_c)[p:p + 1], eps[p:p + 1], mu_c[p:p + 1], lv_c[p:p + 1], dz[p:p + 1], None, None,
+                    0.02 / B, 1, 1, B, L)
+        for m in range(3):
+            if subsets[p][m]:
+                assert rel(dheads_g[m], dheads_c[m]) < 1e-4, (p, m)
+    # single-expert reparametrisation + KL
+    z1g, kl1g = torch.zeros(B, L, device=DEV), torch.zeros(1, dtype=torch.float64, device=DEV)
+    HIP.reparam_fwd(hg[0][:, :L], hg[0][:, L:], eps[0].to(DEV), z1g, kl1g, B, L, 2 * L)
+    z1c, kl1c = torch.zeros(B, L), torch.zeros(1, dtype=torch.float64)
+    EMU.reparam_fwd(heads[0][:, :L], heads[0][:, L:], eps[0], z1c, kl1c, B, L, 2 * L)
+    assert rel(z1g, z1c) < 1e-5 and rel(kl1g, kl1c) < 1e-6
+    HIP.reparam_bwd(hg[0][:, :L], hg[0][:, L:], eps[0].to(DEV), dz[0].to(DEV), 0.3, dheads_g[0][:, :L], dheads_g[0][:, L:],
+                    B, L, 2 * L)
+    EMU.reparam_bwd(heads[0][:, :L], heads[0][:, L:], eps[0], dz[0], 0.3, dheads_c[0][:, :L], dheads_c[0][:, L:], B, L, 2 * L)
+    assert rel(dheads_g[0], dheads_c[0]) < 1e-5
+    # reconstruction terms
+    n = 3 * 3 * 64 * 64
+    logits, target = rnd(3, 3, 64, 64, seed=50) * 6, torch.rand(3, 3, 64, 64)
+    mask = (torch.rand(3, 1, 64, 64) > 0.5).float()
+    for mk in (None, mask):
+        lg, lc = torch.zeros(1, dtype=torch.float64, device=DEV), torch.zeros(1, dtype=torch.float64)
+        dg, dc = torch.zeros(n, device=DEV), torch.zeros(n)
+        HIP.bce_logits(logits.to(DEV), target.to(DEV), None if mk is None else mk.to(DEV), dg, lg, n, 3 * 4096, 4096, 0.25)
+        EMU.bce_logits(logits, target, mk, dc, lc, n, 3 * 4096, 4096, 0.25)
+        assert rel(lg, lc) < 1e-6 and rel(dg, dc) < 1e-5
+    r, t = rnd(9, 7, seed=51), rnd(9, 7, seed=52)
+    lg, lc = torch.zeros(1, dtype=torch.float64, device=DEV), torch.zeros(1, dtype=torch.float64)
+    dg, dc = torch.zeros(63, device=DEV), torch.zeros(63)
+    HIP.mse(r.to(DEV), t.to(DEV), dg, lg, 63, 0.5)
+    EMU.mse(r, t, dc, lc, 63, 0.5)
+    assert rel(lg, lc) < 1e-6 and rel(dg, dc) < 1e-6
+    acc = torch.tensor([[1.0, 2.0, 3.0], [0.5, 0.0, 0.25], [7.0, 8.0, 9.0]], dtype=torch.float64)
+    loss_g, part_g = torch.zeros(1, device=DEV), torch.zeros(3, device=DEV)
+    HIP.elbo_assemble(acc[0].to(DEV), acc[1].to(DEV), acc[2].to(DEV), loss_g, part_g, 3, 4, 0.02, 1000.0)
+    want = (acc[0] + 1000.0 * acc[1] + 0.02 * acc[2]) / 4
+    assert rel(part_g, want) < 1e-6 and abs(float(loss_g.cpu()) - float(want.sum())) < 1e-3
+
+
+def test_random_kernels_statistics():
+    n = 1 << 20
+    m = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    HIP.random_masks(m, 0.1, 1234, 0)
+    keep = float(m.float().mean().cpu())
+    assert abs(keep - 0.9) < 3e-3
+    z = torch.zeros(n, device=DEV)
+    HIP.random_normal(z, 99, 0)
+    assert abs(float(z.mean().cpu())) < 5e-3 and abs(float(z.std().cpu()) - 1.0) < 5e-3
+    z2 = torch.zeros(n, device=DEV)
+    HIP.random_normal(z2, 99, n // 4)
+    assert not torch.equal(z, z2)
+    HIP.random_normal(z2, 99, 0)
+    assert torch.equal(z, z2)
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HIP.act_fwd(torch.zeros(8), torch.zeros(8), 1)
