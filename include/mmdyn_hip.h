@@ -144,6 +144,8 @@ int mmdyn_random_masks(uint8_t* masks, int64_t n, float p_drop, uint64_t seed, u
 int mmdyn_random_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 /* out[c] (+)= sum_r x[r][c]   (bias gradients) */
 int mmdyn_colsum(const float* x, float* out, int rows, int C, int perm, float beta, void* stream);
+/* out = x * s[0], s in device memory (chain rule through a scalar loss term without a host sync) */
+int mmdyn_scale_dev(const float* x, const float* s, float* out, int64_t n, void* stream);
 /* sum of P row blocks: out[b][:] = sum_p x[p][b][:] */
 int mmdyn_sum_blocks(const float* x, float* out, int P, int64_t n, void* stream);
 /* tiny Linear layers of the 7-DoF pose MLP (K or N == 7; vae.py:117-123): y = x W^T + b */
@@ -161,6 +163,8 @@ typedef struct {
   float* dmu[MMDYN_MAX_EXPERTS];        /* backward outputs (same shapes/strides) */
   float* dlv[MMDYN_MAX_EXPERTS];
   int ld[MMDYN_MAX_EXPERTS];            /* row stride of the expert tensors (heads are stored fused: [rows][2L]) */
+  const float* dz[3];                   /* backward only: up to three [B][L] latent gradients of this pass (one per
+                                           decoder that consumed z), summed by the kernel; null = none */
 } mmdyn_pass_experts;
 /* P passes of [B][L].  with_prior=1 adds the universal N(0,1) expert first (vae.py:139, 321-328).
  * Outputs mu/logvar [P][B][L]; optional z = eps*exp(logvar/2)+mu; optional kl_sum[p] (double)

@@ -206,6 +206,15 @@ __global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __res
   }
 }
 
+// out = x * s[0] with the scale read from device memory (autograd's upstream scalar gradient: no host sync)
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                 float* __restrict__ out, int64_t n) {
+  const float k = s[0];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = x[i] * k;
+}
+
 __global__ void adam_tick_kernel(double* __restrict__ state, float lr, float beta1, float beta2) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double t = state[0] + 1.0;
@@ -318,6 +327,11 @@ extern "C" int mmdyn_linear_small_bwd(const float* dy, const float* x, const flo
                        rows, K, N);
   hipLaunchKernelGGL(linear_small_dw_kernel, dim3(ew_grid((int64_t)N * (K + 1) * 64)), dim3(256), 0, ST, dy,
                      x, dW, db, rows, K, N, beta);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_scale_dev(const float* x, const float* s, float* out, int64_t n, void* stream) {
+  if (!x || !s || !out) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, x, s, out, n);
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_adam_step(float* p, const float* g, float* m, float* v, double* state, int64_t n,

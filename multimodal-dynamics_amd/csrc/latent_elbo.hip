@@ -71,11 +71,19 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(PoeArgs args, const float*
        i += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / L), l = (int)(i - (int64_t)b * L);
     const size_t o = (size_t)p * n + i;
-    const float mu = mu_pd[o], lv = lv_pd[o], g = dz ? dz[o] : 0.f;
+    const float mu = mu_pd[o], lv = lv_pd[o];
+    float g = dz ? dz[o] : 0.f;
+    bool any_dz = dz != nullptr;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (e.dz[k]) {
+        g += e.dz[k][i];
+        any_dz = true;
+      }
     // z = eps * exp(lv/2) + mu ;  KL = -0.5 * sum(1 + lv - mu^2 - exp(lv))
     float dmu_pd = g + kl_scale * mu;
     float dlv_pd = -0.5f * kl_scale * (1.f - expf(lv));
-    if (dz) dlv_pd += g * eps_noise[o] * 0.5f * expf(0.5f * lv);
+    if (any_dz) dlv_pd += g * eps_noise[o] * 0.5f * expf(0.5f * lv);
     if (g_mu) dmu_pd += g_mu[o];
     if (g_lv) dlv_pd += g_lv[o];
     float Tm[MMDYN_MAX_EXPERTS], mum[MMDYN_MAX_EXPERTS], ex[MMDYN_MAX_EXPERTS];
@@ -255,9 +263,12 @@ extern "C" int mmdyn_poe_bwd(const mmdyn_pass_experts* passes, const float* eps_
   if (!mu || !logvar || (dz && !eps_noise)) return MMDYN_ERR_NULL;
   PoeArgs a{};
   if (int e = copy_passes(passes, P, &a)) return e;
-  for (int p = 0; p < P; ++p)
+  for (int p = 0; p < P; ++p) {
     for (int m = 0; m < MMDYN_MAX_EXPERTS; ++m)
       if (a.pass[p].mu[m] && (!a.pass[p].lv[m] || !a.pass[p].dmu[m] || !a.pass[p].dlv[m])) return MMDYN_ERR_NULL;
+    for (int k = 0; k < 3; ++k)
+      if (a.pass[p].dz[k] && !eps_noise) return MMDYN_ERR_NULL;
+  }
   int gx = ew_grid((int64_t)B * L);
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(poe_bwd_kernel, dim3(gx, P), dim3(256), 0, ST, a, eps_noise, mu, logvar, dz, g_mu, g_lv,

@@ -14,7 +14,7 @@ _P, _I, _L, _F, _Q = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_flo
 
 class PassExperts(ctypes.Structure):
     """mmdyn_pass_experts (include/mmdyn_hip.h)."""
-    _fields_ = [("mu", _P * 4), ("lv", _P * 4), ("dmu", _P * 4), ("dlv", _P * 4), ("ld", _I * 4)]
+    _fields_ = [("mu", _P * 4), ("lv", _P * 4), ("dmu", _P * 4), ("dlv", _P * 4), ("ld", _I * 4), ("dz", _P * 3)]
 
 
 MAX_PASSES = 8
@@ -46,6 +46,7 @@ _SIGNATURES = {
     "mmdyn_random_masks": "p" + "l" + "f" + "QQ" + "p",
     "mmdyn_random_normal": "p" + "l" + "QQ" + "p",
     "mmdyn_colsum": "pp" + "iii" + "f" + "p",
+    "mmdyn_scale_dev": "ppp" + "l" + "p",
     "mmdyn_sum_blocks": "pp" + "i" + "l" + "p",
     "mmdyn_linear_small_fwd": "pppp" + "iiii" + "p",
     "mmdyn_linear_small_bwd": "pppppp" + "iii" + "f" + "p",

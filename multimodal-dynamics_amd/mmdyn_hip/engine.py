@@ -1,0 +1,299 @@
+"""Hand-scheduled cnn-mvae training / evaluation step (the throughput path).
+
+Computes exactly what the reference's ``Reconstruction._evaluate_mvae`` + ``loss.backward()`` +
+``Adam.step()`` compute (/root/reference/mmdyn/pytorch/problems/problems.py:473-546, 148-156) -- the sum
+over the 3 (or 7, with pose) modality-subset ELBOs and its gradient -- but restructured for the GPU:
+
+  * each image-encoder trunk runs ONCE per step (its 4 reference runs are bit-identical up to the
+    dropout mask); only dropout -> heads is evaluated per pass, batched as 4B rows;
+  * the 4 live passes of each image decoder are one batch of 4 groups with per-group BatchNorm
+    statistics; decoder outputs the reference computes and discards ("dead" passes) are not computed;
+  * PoE + reparametrisation + KL of all passes is one kernel; BCE/MSE produce their gradients in the
+    same pass; the backward is an explicit reverse schedule writing straight into one flat gradient
+    buffer, which is what RCCL all-reduces (three buckets, overlapped with the remaining backward)
+    before the fused Adam kernel.
+
+Loss value, every partial ELBO and every parameter gradient equal the reference's up to fp32
+summation order (tests/test_engine_*.py).  BatchNorm running statistics: encoder buffers receive the same
+4 EMA updates as in the reference; decoder buffers receive the live passes' updates only (the
+reference also folds in the discarded passes) unless ``exact_running_stats=True``.
+"""
+import torch
+
+from . import layers, ops
+from .models.shapes import DROPOUT_P
+
+SUBSETS_POSE = [(1, 1, 0), (1, 0, 0), (0, 1, 0), (1, 1, 1), (1, 0, 1), (0, 1, 1), (0, 0, 1)]
+SUBSETS_NOPOSE = SUBSETS_POSE[:3]
+
+_PREFIX_ORDER = ["pose_decoder", "visual_decoder", "tactile_decoder",         # bucket 0: ready first
+                 "heads", "pose_encoder",                                    # bucket 1
+                 "visual_encoder", "tactile_encoder"]                        # bucket 2: ready last
+
+
+def _align4(n):
+    return (n + 3) // 4 * 4
+
+
+class FlatParams:
+    """All parameters (and their gradients) as views into two flat fp32 buffers, ordered by the time their
+    gradient becomes available in the backward schedule (so contiguous slices are all-reduce buckets)."""
+
+    def __init__(self, model):
+        named = dict(model.named_parameters())
+        heads = [k for k in named if ".linear_" in k]
+        groups = {p: [] for p in _PREFIX_ORDER}
+        for k in named:
+            if k in heads:
+                groups["heads"].append(k)
+            else:
+                groups[k.split(".", 1)[0]].append(k)
+        self.order, self.offsets, self.bucket_bounds = [], {}, []
+        off = 0
+        marks = {"tactile_decoder": None, "pose_encoder": None, "tactile_encoder": None}
+        for g in _PREFIX_ORDER:
+            for k in groups[g]:
+                self.order.append(k)
+                self.offsets[k] = off
+                off = _align4(off + named[k].numel())
+            if g in marks:
+                self.bucket_bounds.append(off)
+        self.total = off
+        dev = next(model.parameters()).device
+        self.flat = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        self.P, self.G = {}, {}
+        for k in self.order:
+            p = named[k]
+            o, n = self.offsets[k], p.numel()
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+            self.P[k], self.G[k] = p.data, p.grad
+        self.model = model
+
+    def still_attached(self):
+        named = dict(self.model.named_parameters())
+        k = self.order[0]
+        return named[k].data_ptr() == self.P[k].data_ptr()
+
+    def sub(self, prefix, which="P"):
+        src = self.P if which == "P" else self.G
+        return {k[len(prefix) + 1:]: v for k, v in src.items() if k.startswith(prefix + ".")}
+
+
+class MVAEStep:
+    """Fused train / eval step for an :class:`mmdyn_hip.models.MVAE` on one GPU (one rank)."""
+
+    def __init__(self, model, lr=1e-3, pose_multiplier=1000.0, betas=(0.9, 0.999), eps=1e-8, noise=None,
+                 process_group=None, world_size=1):
+        self.model = model
+        self.use_pose = bool(model._use_pose)
+        self.L = model.latent_size
+        self.subsets = SUBSETS_POSE if self.use_pose else SUBSETS_NOPOSE
+        self.P = len(self.subsets)
+        self.pass_v = [i for i, s in enumerate(self.subsets) if s[0]]
+        self.pass_t = [i for i, s in enumerate(self.subsets) if s[1]]
+        self.pass_p = [i for i, s in enumerate(self.subsets) if s[2]]
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.pose_multiplier = float(pose_multiplier)
+        self.noise = noise
+        self.pg, self.world = process_group, world_size
+        self.params = FlatParams(model)
+        dev = self.params.flat.device
+        self.adam_m = torch.zeros_like(self.params.flat)
+        self.adam_v = torch.zeros_like(self.params.flat)
+        self.adam_state = torch.zeros(3, dtype=torch.float64, device=dev)
+        self.acc = torch.zeros(3, 8, dtype=torch.float64, device=dev)          # bce / mse / kl per pass
+        self.loss = torch.zeros(1, device=dev)
+        self.partials = torch.zeros(8, device=dev)
+        self.last = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _noise(self):
+        from .models.vae import NoiseSource
+        if self.noise is None:
+            self.noise = getattr(self.model, "noise", None) or NoiseSource(0)
+        return self.noise
+
+    def _draw(self, B, dev):
+        """eps [P][B][L] and the dropout keep-masks of the visual / tactile passes, consumed from the noise
+        source in the reference's call order (visual encoder, tactile encoder, then the latent draw)."""
+        n = self._noise()
+        eps, mv, mt = [], [], []
+        for a, b, _ in self.subsets:
+            if a:
+                mv.append(n.keep_mask((B, 512), dev))
+            if b:
+                mt.append(n.keep_mask((B, 512), dev))
+            eps.append(n.eps((B, self.L), dev))
+        return torch.stack(eps), torch.stack(mv), torch.stack(mt)
+
+    def _buffers(self, prefix):
+        mod = getattr(self.model, prefix)
+        return mod.bn_buffers()
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, inputs, targets, kl_weight, train=True):
+        """Runs the forward schedule and the loss; with train=True also fills the loss gradients needed by
+        :meth:`backward`.  Returns the device scalar loss (fp32)."""
+        if not self.params.still_attached():
+            raise RuntimeError("model parameters were re-allocated (e.g. .to()/.cuda() after MVAEStep was built); "
+                               "construct MVAEStep after moving the model")
+        v, t = inputs[0].contiguous(), inputs[1].contiguous()
+        B, dev, L, P = v.shape[0], v.device, self.L, self.P
+        FP = self.params
+        eps, mv, mt = self._draw(B, dev)
+        nv, nt, npp = len(self.pass_v), len(self.pass_t), len(self.pass_p)
+        c = {"B": B, "eps": eps, "mv": mv, "mt": mt}
+
+        # 1. encoder trunks, once per modality (running statistics: nv identical EMA updates, as in the reference)
+        hv, c["ev"] = layers.encoder_trunk_forward(FP.sub("visual_encoder"), self._buffers("visual_encoder"), v, 1, nv)
+        ht, c["et"] = layers.encoder_trunk_forward(FP.sub("tactile_encoder"), self._buffers("tactile_encoder"), t, 1, nt)
+        # 2. per-pass dropout, batched
+        hdv = torch.empty(nv * B, 512, device=dev)
+        hdt = torch.empty(nt * B, 512, device=dev)
+        ops.B.dropout_expand(hv, mv, hdv, nv, B, 512, DROPOUT_P)
+        ops.B.dropout_expand(ht, mt, hdt, nt, B, 512, DROPOUT_P)
+        # 3. heads (means | log_var fused), all passes of a modality in one GEMM
+        ov, c["hv"] = layers.heads_forward(FP.sub("visual_encoder"), hdv)
+        ot, c["ht"] = layers.heads_forward(FP.sub("tactile_encoder"), hdt)
+        op = None
+        if self.use_pose:
+            pose_rep = inputs[2].contiguous().repeat(npp, 1)                  # same pose rows for each pass
+            hp, c["ep"] = layers.pose_encoder_trunk_forward(FP.sub("pose_encoder"), pose_rep)
+            op, c["hp"] = layers.heads_forward(FP.sub("pose_encoder"), hp)
+        c["ov"], c["ot"], c["op"] = ov, ot, op
+        # 4. product of experts + reparametrisation + KL for every pass
+        mu = torch.empty(P, B, L, device=dev)
+        lv = torch.empty(P, B, L, device=dev)
+        z = torch.empty(P, B, L, device=dev)
+        self.acc.zero_()
+        ops.B.poe_fwd(self._passes(c, B, None), eps, mu, lv, z, self.acc[2], True, P, B, L)
+        c["mu"], c["lv"] = mu, lv
+        # 5. decoders on their live passes (groups)
+        zv = torch.cat([z[p] for p in self.pass_v])
+        zt = torch.cat([z[p] for p in self.pass_t])
+        lg_v, c["dv"] = layers.decoder_forward(FP.sub("visual_decoder"), self._buffers("visual_decoder"), zv, nv)
+        lg_t, c["dt"] = layers.decoder_forward(FP.sub("tactile_decoder"), self._buffers("tactile_decoder"), zt, nt)
+        pr = None
+        if self.use_pose:
+            zp = torch.cat([z[p] for p in self.pass_p])
+            pr, c["dp"] = layers.pose_decoder_forward(FP.sub("pose_decoder"), zp)
+        # 6. reconstruction terms (+ their gradients when training)
+        n_img = B * 3 * 64 * 64
+        tv, tt = targets[0].contiguous(), targets[1].contiguous()
+        dl_v = torch.empty_like(lg_v) if train else None
+        dl_t = torch.empty_like(lg_t) if train else None
+        inv_b = 1.0 / B
+        for g, p in enumerate(self.pass_v):
+            ops.B.bce_logits(lg_v[g * B:(g + 1) * B], tv, None, None if dl_v is None else dl_v[g * B:(g + 1) * B],
+                             self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, inv_b)
+        for g, p in enumerate(self.pass_t):
+            ops.B.bce_logits(lg_t[g * B:(g + 1) * B], tt, None, None if dl_t is None else dl_t[g * B:(g + 1) * B],
+                             self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, inv_b)
+        dpr = None
+        if self.use_pose:
+            tp = targets[2].contiguous()
+            dpr = torch.empty_like(pr) if train else None
+            for g, p in enumerate(self.pass_p):
+                ops.B.mse(pr[g * B:(g + 1) * B], tp, None if dpr is None else dpr[g * B:(g + 1) * B],
+                          self.acc[1, p:p + 1], B * 7, self.pose_multiplier * inv_b)
+        ops.B.elbo_assemble(self.acc[0], self.acc[1], self.acc[2], self.loss, self.partials, P, B, kl_weight,
+                            self.pose_multiplier)
+        c.update(dl_v=dl_v, dl_t=dl_t, dpr=dpr, kl_weight=kl_weight)
+        self.ctx = c
+        joint = self.subsets.index((1, 1, 1)) if self.use_pose else 0
+        gv, gt = self.pass_v.index(joint), self.pass_t.index(joint)
+        self.last = {"recon_x": [lg_v[gv * B:(gv + 1) * B], lg_t[gt * B:(gt + 1) * B]] +
+                     ([pr[self.pass_p.index(joint) * B:(self.pass_p.index(joint) + 1) * B]] if self.use_pose else []),
+                     "means": mu[P - 1], "log_var": lv[P - 1],
+                     "logits_v": lg_v, "logits_t": lg_t, "pose_recon": pr}
+        return self.loss
+
+    def _passes(self, c, B, dheads, dz_blocks=None):
+        """Per-pass expert descriptors: row block of each modality's fused heads output."""
+        L = self.L
+        out = []
+        for p, (a, b, cc) in enumerate(self.subsets):
+            hs, ds = [None] * 3, [None] * 3
+            for m, (flag, plist, key) in enumerate(((a, self.pass_v, "ov"), (b, self.pass_t, "ot"), (cc, self.pass_p, "op"))):
+                if flag:
+                    g = plist.index(p)
+                    hs[m] = c[key][g * B:(g + 1) * B]
+                    if dheads is not None:
+                        ds[m] = dheads[m][g * B:(g + 1) * B]
+            d = {"mu": [None if h is None else h[:, :L] for h in hs], "lv": [None if h is None else h[:, L:] for h in hs],
+                 "dmu": [None if x is None else x[:, :L] for x in ds], "dlv": [None if x is None else x[:, L:] for x in ds],
+                 "ld": [2 * L] * 3}
+            if dz_blocks is not None:
+                d["dz"] = dz_blocks[p]
+            out.append(d)
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def backward(self):
+        """Reverse schedule; fills the flat gradient buffer.  Returns async all-reduce handles (if any)."""
+        c, FP, B, L, P = self.ctx, self.params, self.ctx["B"], self.L, self.P
+        handles = []
+        dzp = None
+        if self.use_pose:
+            dzp = layers.pose_decoder_backward(FP.sub("pose_decoder"), c["dp"], c["dpr"], FP.sub("pose_decoder", "G"))
+        dzv = layers.decoder_backward(FP.sub("visual_decoder"), c["dv"], c["dl_v"], FP.sub("visual_decoder", "G"))
+        dzt = layers.decoder_backward(FP.sub("tactile_decoder"), c["dt"], c["dl_t"], FP.sub("tactile_decoder", "G"))
+        handles += self._reduce_bucket(0)
+        # latent gradient sources per pass (summed inside the PoE backward kernel)
+        blocks = [[None, None, None] for _ in range(P)]
+        for g, p in enumerate(self.pass_v):
+            blocks[p][0] = dzv[g * B:(g + 1) * B]
+        for g, p in enumerate(self.pass_t):
+            blocks[p][1] = dzt[g * B:(g + 1) * B]
+        if self.use_pose:
+            for g, p in enumerate(self.pass_p):
+                blocks[p][2] = dzp[g * B:(g + 1) * B]
+        dov, dot = torch.empty_like(c["ov"]), torch.empty_like(c["ot"])
+        dop = torch.empty_like(c["op"]) if self.use_pose else None
+        ops.B.poe_bwd(self._passes(c, B, [dov, dot, dop], blocks), c["eps"], c["mu"], c["lv"], None, None, None,
+                      c["kl_weight"] / B, True, P, B, L)
+        dhdv = layers.heads_backward(c["hv"], dov, FP.sub("visual_encoder", "G"))
+        dhdt = layers.heads_backward(c["ht"], dot, FP.sub("tactile_encoder", "G"))
+        if self.use_pose:
+            dhp = layers.heads_backward(c["hp"], dop, FP.sub("pose_encoder", "G"))
+            layers.pose_encoder_trunk_backward(FP.sub("pose_encoder"), c["ep"], dhp, FP.sub("pose_encoder", "G"))
+        handles += self._reduce_bucket(1)
+        dhv, dht = torch.empty(B, 512, device=dov.device), torch.empty(B, 512, device=dov.device)
+        ops.B.dropout_reduce(dhdv, c["mv"], dhv, len(self.pass_v), B, 512, DROPOUT_P)
+        ops.B.dropout_reduce(dhdt, c["mt"], dht, len(self.pass_t), B, 512, DROPOUT_P)
+        layers.encoder_trunk_backward(FP.sub("visual_encoder"), c["ev"], dhv, FP.sub("visual_encoder", "G"))
+        layers.encoder_trunk_backward(FP.sub("tactile_encoder"), c["et"], dht, FP.sub("tactile_encoder", "G"))
+        handles += self._reduce_bucket(2)
+        self.ctx = None
+        return handles
+
+    def _reduce_bucket(self, i):
+        if self.world <= 1:
+            return []
+        import torch.distributed as dist
+        lo = 0 if i == 0 else self.params.bucket_bounds[i - 1]
+        hi = self.params.bucket_bounds[i]
+        return [dist.all_reduce(self.params.grad[lo:hi], group=self.pg, async_op=True)]
+
+    def optimizer_step(self, handles=()):
+        for h in handles:
+            h.wait()
+        ops.B.adam_step(self.params.flat, self.params.grad, self.adam_m, self.adam_v, self.adam_state, self.lr,
+                        self.betas[0], self.betas[1], self.eps, 1.0 / self.world)
+
+    def train_step(self, inputs, targets, kl_weight):
+        """zero_grad -> forward -> backward -> (all-reduce) -> Adam, as problems.py:150-155.  Gradients are
+        overwritten, not accumulated, so no zero_grad pass is needed."""
+        loss = self.forward(inputs, targets, kl_weight, train=True)
+        handles = self.backward()
+        self.optimizer_step(handles)
+        return loss
+
+    @torch.no_grad()
+    def eval_step(self, inputs, targets, kl_weight):
+        loss = self.forward(inputs, targets, kl_weight, train=False)
+        self.ctx = None
+        return loss

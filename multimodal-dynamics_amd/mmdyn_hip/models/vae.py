@@ -1,0 +1,382 @@
+"""VAE / MVAE modules with the reference's public surface, computed by the HIP kernel library.
+
+Drop-in for /root/reference/mmdyn/pytorch/models/vae.py: same class names, constructor keyword
+arguments, ``forward`` / ``inference`` signatures and return tuples, same ``state_dict`` keys and tensor
+layouts, so checkpoints written by either implementation load into the other.
+The sub-modules only *hold* parameters under the reference's names; all arithmetic is issued by
+``Encoder.forward`` / ``Decoder.forward`` / ``MVAE.forward`` as fused kernel sequences
+(:mod:`mmdyn_hip.layers`), never by ``torch.nn.functional``.
+
+Randomness: the reference draws the reparametrisation noise with ``torch.randn`` on the CPU and the
+dropout masks on the device, both unseeded (vae.py:58, 213).  Here both come from ``model.noise`` (a
+:class:`NoiseSource`): by default a counter-based on-device Philox stream, or injected tensors for
+parity runs.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import config, ops
+from . import functional as Fn
+from .. import layers
+from .shapes import FEAT, HID, DROPOUT_P
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter holders (named and shaped like the reference's nn layers)
+# ------------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError(f"{type(self).__name__} only holds parameters; the enclosing Encoder/Decoder "
+                           "issues the fused HIP kernels")
+
+
+class Conv2dParams(_Holder):
+    """weight [Cout, Cin, k, k] (transposed=False) or [Cin, Cout, k, k] (transposed=True), no bias."""
+
+    def __init__(self, cin, cout, k, stride, pad, transposed=False):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.pad, self.transposed = cin, cout, k, stride, pad, transposed
+        shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        self.weight = nn.Parameter(torch.empty(shape))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def extra_repr(self):
+        kind = "ConvTranspose2d" if self.transposed else "Conv2d"
+        return f"{kind}({self.cin}, {self.cout}, kernel_size={self.k}, stride={self.stride}, padding={self.pad}, bias=False)"
+
+
+class BatchNorm2dParams(_Holder):
+    def __init__(self, c):
+        super().__init__()
+        self.num_features = c
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def extra_repr(self):
+        return f"BatchNorm2d({self.num_features}, eps=1e-05, momentum=0.1, train-mode batch statistics)"
+
+
+class LinearParams(_Holder):
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.in_features, self.out_features = fin, fout
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.empty(fout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(fin)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return f"Linear(in_features={self.in_features}, out_features={self.out_features}, bias=True)"
+
+
+class Swish(nn.Module):
+    """x * sigmoid(x) (vae.py:331-334).  Inside Encoder/Decoder it is fused into the neighbouring kernels;
+    called on its own it runs the element-wise kernel."""
+
+    def forward(self, x):
+        return Fn.SwishFn.apply(x)
+
+
+class _Marker(_Holder):
+    """Parameter-free placeholder keeping the reference's Sequential indices (ReLU / Identity / Dropout)."""
+
+    def __init__(self, text):
+        super().__init__()
+        self.text = text
+
+    def extra_repr(self):
+        return self.text
+
+
+def mlp(sizes, activation="ReLU", output_activation="Identity"):
+    """Holder Sequential with the reference's indexing: Linear at even positions (vae.py:14-19)."""
+    mods = []
+    for j in range(len(sizes) - 1):
+        mods += [LinearParams(sizes[j], sizes[j + 1]), _Marker(activation if j < len(sizes) - 2 else output_activation)]
+    return nn.Sequential(*mods)
+
+
+# ------------------------------------------------------------------------------------------------
+# noise sources
+# ------------------------------------------------------------------------------------------------
+class NoiseSource:
+    """On-device Philox stream (mmdyn_random_normal / mmdyn_random_masks)."""
+
+    def __init__(self, seed=0):
+        self.seed, self.offset = int(seed), 0
+
+    def eps(self, shape, device):
+        out = torch.empty(shape, device=device, dtype=torch.float32)
+        ops.B.random_normal(out, self.seed, self.offset)
+        self.offset += (out.numel() + 3) // 4
+        return out
+
+    def keep_mask(self, shape, device):
+        out = torch.empty(shape, device=device, dtype=torch.uint8)
+        ops.B.random_masks(out, DROPOUT_P, self.seed ^ 0x5DEECE66D, self.offset)
+        self.offset += (out.numel() + 3) // 4
+        return out
+
+
+class InjectedNoise:
+    """Replays given tensors in call order (parity tests: the same draws the oracle consumes)."""
+
+    def __init__(self, eps_list, mask_list):
+        self._eps, self._masks = list(eps_list), list(mask_list)
+
+    def eps(self, shape, device):
+        e = self._eps.pop(0)
+        assert tuple(e.shape) == tuple(shape), (e.shape, shape)
+        return e.to(device=device, dtype=torch.float32).contiguous()
+
+    def keep_mask(self, shape, device):
+        m = self._masks.pop(0)
+        assert tuple(m.shape) == tuple(shape), (m.shape, shape)
+        return m.to(device=device, dtype=torch.uint8).contiguous()
+
+
+def _noise_of(module):
+    n = getattr(module, "noise", None)
+    if n is None:
+        n = module.noise = NoiseSource(0)
+    return n
+
+
+# ------------------------------------------------------------------------------------------------
+# reference-shaped modules
+# ------------------------------------------------------------------------------------------------
+class Autoencoder(nn.Module):
+    """Base class (vae.py:26-67)."""
+
+    def __init__(self, input_dim=784, encoder_hid=[256, 256], latent_size=8, decoder_hid=[256, 256],
+                 condition_dim=None, architecture='mlp', conditional=False, categorical_conditions=False):
+        super().__init__()
+        assert type(encoder_hid) == list
+        assert type(latent_size) == int
+        assert type(decoder_hid) == list
+        assert architecture in config.ARCHITECTURES
+        self.latent_size = latent_size
+        self.input_dim = input_dim
+        self.condition_dim = condition_dim
+        self.architecture = architecture
+        self.conditional = conditional
+        self.categorical_conditions = categorical_conditions
+        self.noise = None
+
+    def reparametrize(self, means, log_var):
+        eps = _noise_of(self).eps((means.size(0), self.latent_size), means.device)
+        return Fn.ReparamFn.apply(means, log_var, eps)
+
+    def forward(self, x):
+        raise NotImplementedError
+
+    def inference(self, n=1):
+        raise NotImplementedError
+
+
+def _check_supported(architecture, conditional):
+    if conditional:
+        raise NotImplementedError("mmdyn_hip: --conditional (shock-conditioned) models are not built yet "
+                                  "(SURVEY.md section 8f, rank 4)")
+
+
+class Encoder(nn.Module):
+    """vae.py:179-242.  cnn: conv_net/fc_net/linear_means/linear_log_var; mlp: fc_net + the two heads."""
+
+    def __init__(self, input_dim=784, layer_sizes=[256, 256], latent_size=8, architecture='mlp', conditional=False,
+                 categorical_conditions=False, condition_dim=None, **kwargs):
+        super().__init__()
+        self.architecture = architecture
+        self.conditional = conditional
+        self.categorical_conditions = categorical_conditions
+        self.condition_dim = condition_dim
+        self.latent_size = latent_size
+        if categorical_conditions:
+            assert condition_dim is not None, "Num conditions is not specified for categorical conditions."
+        _check_supported(architecture, conditional)
+        if architecture == 'cnn':
+            self.conv_net = nn.Sequential(
+                Conv2dParams(3, 32, 4, 2, 1), Swish(),
+                Conv2dParams(32, 64, 4, 2, 1), BatchNorm2dParams(64), Swish(),
+                Conv2dParams(64, 128, 4, 2, 1), BatchNorm2dParams(128), Swish(),
+                Conv2dParams(128, 256, 4, 1, 0), BatchNorm2dParams(256), Swish())
+            self.fc_net = nn.Sequential(LinearParams(FEAT, HID), Swish(), _Marker("Dropout(p=0.1)"))
+            self.linear_means = LinearParams(HID, latent_size)
+            self.linear_log_var = LinearParams(HID, latent_size)
+        else:
+            layer_sizes = [input_dim] + layer_sizes
+            if not (len(layer_sizes) == 3 and layer_sizes[1] % 32 == 0 and layer_sizes[2] % 32 == 0):
+                raise NotImplementedError("mmdyn_hip: the mlp Encoder is built for the MVAE pose branch "
+                                          "(two hidden layers, widths multiple of 32)")
+            self.fc_net = mlp(layer_sizes)
+            self.linear_means = LinearParams(layer_sizes[-1], latent_size)
+            self.linear_log_var = LinearParams(layer_sizes[-1], latent_size)
+        self.noise = None
+
+    def bn_buffers(self):
+        return {f"conv_net.{i}.{n}": getattr(self.conv_net[i], n) for i in (3, 6, 9)
+                for n in ("running_mean", "running_var", "num_batches_tracked")}
+
+    def _check_mode(self):
+        if not self.training:
+            raise NotImplementedError("mmdyn_hip: eval-mode (running-statistics BatchNorm, no dropout) is not "
+                                      "built; the reference keeps the model in train mode everywhere "
+                                      "(problems.py:145,174)")
+
+    def trunk(self, x):
+        """Everything before the dropout: [B,512] features."""
+        self._check_mode()
+        if self.architecture == 'cnn':
+            sd = dict(self.named_parameters())
+            return Fn.ImageEncoderTrunkFn.apply(x, self, *[sd[k] for k in layers.ENC_KEYS])
+        sd = dict(self.named_parameters())
+        return Fn.PoseEncoderTrunkFn.apply(x, *[sd[k] for k in layers.POSE_ENC_KEYS])
+
+    def heads(self, h):
+        out = Fn.HeadsFn.apply(h, self.linear_means.weight, self.linear_means.bias, self.linear_log_var.weight,
+                               self.linear_log_var.bias)
+        return out
+
+    def forward_fused(self, x, noise):
+        """Returns the fused heads output [B, 2L] (means | log_vars)."""
+        h = self.trunk(x)
+        if self.architecture == 'cnn':
+            h = Fn.DropoutFn.apply(h, noise.keep_mask(tuple(h.shape), h.device))
+        return self.heads(h)
+
+    def forward(self, x, c=None):
+        out = self.forward_fused(x, _noise_of(self))
+        L = self.latent_size
+        return out[:, :L], out[:, L:]
+
+
+class Decoder(nn.Module):
+    """vae.py:245-301.  cnn: upsample + hallucinate (returns LOGITS, no sigmoid); mlp: deconv_net."""
+
+    def __init__(self, output_dim=784, layer_sizes=[256, 256], latent_size=2, architecture='mlp', conditional=False,
+                 categorical_conditions=False, condition_dim=None, **kwargs):
+        super().__init__()
+        self.architecture = architecture
+        self.conditional = conditional
+        self.categorical_conditions = categorical_conditions
+        self.condition_dim = condition_dim
+        if categorical_conditions:
+            assert condition_dim is not None, "Num conditions is not specified for categorical conditions."
+        _check_supported(architecture, conditional)
+        if architecture == 'cnn':
+            if latent_size % 32:
+                raise NotImplementedError("mmdyn_hip: latent_size must be a multiple of 32 (MFMA K-step)")
+            self.upsample = nn.Sequential(LinearParams(latent_size, FEAT), Swish())
+            self.hallucinate = nn.Sequential(
+                Conv2dParams(256, 128, 4, 1, 0, True), BatchNorm2dParams(128), Swish(),
+                Conv2dParams(128, 64, 4, 2, 1, True), BatchNorm2dParams(64), Swish(),
+                Conv2dParams(64, 32, 4, 2, 1, True), BatchNorm2dParams(32), Swish(),
+                Conv2dParams(32, 3, 4, 2, 1, True))
+        else:
+            layer_sizes = [latent_size] + layer_sizes + [output_dim]
+            if len(layer_sizes) != 4:
+                raise NotImplementedError("mmdyn_hip: the mlp Decoder is built for the MVAE pose branch")
+            self.deconv_net = mlp(layer_sizes)
+
+    def bn_buffers(self):
+        return {f"hallucinate.{i}.{n}": getattr(self.hallucinate[i], n) for i in (1, 4, 7)
+                for n in ("running_mean", "running_var", "num_batches_tracked")}
+
+    def forward(self, z, c=None):
+        if not self.training:
+            raise NotImplementedError("mmdyn_hip: eval-mode BatchNorm is not built (the reference never leaves "
+                                      "train mode: problems.py:145,174)")
+        sd = dict(self.named_parameters())
+        if self.architecture == 'cnn':
+            return Fn.ImageDecoderFn.apply(z, self, *[sd[k] for k in layers.DEC_KEYS])
+        return Fn.PoseDecoderFn.apply(z, *[sd[k] for k in layers.POSE_DEC_KEYS])
+
+
+class ProductOfExperts(nn.Module):
+    """Product of independent Gaussian experts (vae.py:304-318): mu, logvar are [M, B, D]."""
+
+    def forward(self, mu, logvar, eps=1e-8):
+        if eps != 1e-8:
+            raise NotImplementedError("mmdyn_hip: the PoE kernel has the reference's eps=1e-8 built in")
+        return Fn.ProductOfExpertsFn.apply(mu, logvar)
+
+
+def prior_expert(size, device=torch.device('cpu')):
+    """Universal N(0, 1) prior expert (vae.py:321-328): zero mean, zero log-variance."""
+    return torch.zeros(size, device=device), torch.zeros(size, device=device)
+
+
+class VAE(Autoencoder):
+    """Single-modality VAE (vae.py:70-98)."""
+
+    def __init__(self, use_pose=False, **kwargs):
+        super().__init__(**kwargs)
+        if kwargs.get('architecture', 'mlp') != 'cnn':
+            raise NotImplementedError("mmdyn_hip: mlp-vae is outside the cnn hot path (SURVEY.md section 8a)")
+        self.encoder = Encoder(**kwargs)
+        self.decoder = Decoder(**kwargs)
+
+    def forward(self, x, c=None):
+        noise = _noise_of(self)
+        out = self.encoder.forward_fused(x, noise)
+        L = self.latent_size
+        means, log_var = out[:, :L], out[:, L:]
+        eps = noise.eps((x.size(0), L), x.device)
+        z = Fn.ReparamFn.apply(means, log_var, eps)
+        return self.decoder(z, c), means, log_var
+
+    def inference(self, n=1, c=None):
+        dev = next(self.parameters()).device
+        z = _noise_of(self).eps((n, self.latent_size), dev)
+        return self.decoder(z, c)
+
+
+class MVAE(Autoencoder):
+    """Multimodal VAE with a product-of-experts posterior (vae.py:101-176)."""
+
+    def __init__(self, use_pose=False, **kwargs):
+        super().__init__(**kwargs)
+        assert kwargs['architecture'] != 'mlp', "MVAE is not implemented with MLP"
+        self._use_pose = use_pose
+        self.visual_encoder = Encoder(**kwargs)
+        self.visual_decoder = Decoder(**kwargs)
+        self.tactile_encoder = Encoder(**kwargs)
+        self.tactile_decoder = Decoder(**kwargs)
+        if self._use_pose:
+            self.pose_encoder = Encoder(input_dim=7, layer_sizes=[512, 512], latent_size=kwargs["latent_size"],
+                                        condition_dim=0, architecture="mlp")
+            self.pose_decoder = Decoder(output_dim=7, layer_sizes=[512, 512], latent_size=kwargs["latent_size"],
+                                        condition_dim=0, architecture="mlp")
+        self.experts = ProductOfExperts()
+
+    def forward(self, x, pose=None, condition=None):
+        assert isinstance(x, list) or isinstance(x, tuple)
+        visual, tactile = x
+        ref = visual if visual is not None else (tactile if tactile is not None else pose)
+        batch_size = ref.size(0)
+        noise = _noise_of(self)
+        L = self.latent_size
+        heads = [None, None, None]
+        if visual is not None:
+            heads[0] = self.visual_encoder.forward_fused(visual, noise)
+        if tactile is not None:
+            heads[1] = self.tactile_encoder.forward_fused(tactile, noise)
+        if pose is not None and self._use_pose:
+            heads[2] = self.pose_encoder.forward_fused(pose, noise)
+        eps = noise.eps((batch_size, L), ref.device)
+        means, log_var, z = Fn.PoEReparamFn.apply(eps, L, *heads)
+        visual_recon = self.visual_decoder(z, c=condition)
+        tactile_recon = self.tactile_decoder(z, c=condition)
+        pose_recon = self.pose_decoder(z, c=condition) if self._use_pose else None
+        return visual_recon, tactile_recon, pose_recon, means, log_var
+
+    def inference(self, n=1, c=None):
+        dev = next(self.parameters()).device
+        z = _noise_of(self).eps((n, self.latent_size), dev)
+        return self.visual_decoder(z, c), self.tactile_decoder(z, c)

@@ -156,6 +156,9 @@ class HipBackend:
     def colsum(self, x, out, rows, C, perm, beta):
         check(self.lib.mmdyn_colsum(_ptr(x), _ptr(out), rows, C, perm, float(beta), _stream()), "mmdyn_colsum")
 
+    def scale_dev(self, x, s, out):
+        check(self.lib.mmdyn_scale_dev(_ptr(x), _ptr(s), _ptr(out), x.numel(), _stream()), "mmdyn_scale_dev")
+
     def sum_blocks(self, x, out, P, n):
         check(self.lib.mmdyn_sum_blocks(_ptr(x), _ptr(out), P, n, _stream()), "mmdyn_sum_blocks")
 
@@ -182,6 +185,9 @@ class HipBackend:
                             raise ValueError("mmdyn_hip: expert tensors must be fp32 GPU tensors with unit inner stride")
                         getattr(arr[i], key)[m] = t.data_ptr()
                 arr[i].ld[m] = int(p["ld"][m])
+            for k, t in enumerate(p.get("dz", [])):
+                if t is not None:
+                    arr[i].dz[k] = _ptr(t)
         return arr
 
     def poe_fwd(self, passes, eps_noise, mu, logvar, z, kl_sum, with_prior, P, B, L):

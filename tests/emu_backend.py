@@ -266,6 +266,9 @@ class EmuBackend:
             s = s.reshape(25, 256).t().reshape(-1)
         out.reshape(-1).copy_(beta * out.reshape(-1) + s if beta else s)
 
+    def scale_dev(self, x, s, out):
+        out.reshape(-1).copy_(x.reshape(-1) * s.reshape(-1)[0])
+
     def sum_blocks(self, x, out, P, n):
         out.reshape(-1).copy_(x.reshape(P, n).sum(0))
 
@@ -320,15 +323,26 @@ class EmuBackend:
                 kl_sum[i] += (-0.5 * (1 + plv - pm * pm - plv.exp()).double().sum())
 
     def poe_bwd(self, passes, eps_noise, mu, logvar, dz, g_mu, g_lv, kl_scale, with_prior, P, B, L):
+        with torch.enable_grad():
+            self._poe_bwd(passes, eps_noise, mu, logvar, dz, g_mu, g_lv, kl_scale, with_prior, P, B, L)
+
+    def _poe_bwd(self, passes, eps_noise, mu, logvar, dz, g_mu, g_lv, kl_scale, with_prior, P, B, L):
         for i, p in enumerate(passes):
             idx = [m for m in range(len(p["ld"])) if p["mu"][m] is not None]
             mus = [p["mu"][m][:, :L].detach().clone().requires_grad_(True) for m in idx]
             lvs = [p["lv"][m][:, :L].detach().clone().requires_grad_(True) for m in idx]
             pm, plv = self._poe_math(mus, lvs, with_prior, B, L)
             obj = kl_scale * (-0.5 * (1 + plv - pm * pm - plv.exp()).sum())
+            gz = torch.zeros(B, L)
+            has = False
             if dz is not None:
+                gz, has = gz + dz.reshape(P, B, L)[i], True
+            for t in p.get("dz", []):
+                if t is not None:
+                    gz, has = gz + t.reshape(B, L), True
+            if has:
                 zz = eps_noise.reshape(P, B, L)[i] * torch.exp(0.5 * plv) + pm
-                obj = obj + (zz * dz.reshape(P, B, L)[i]).sum()
+                obj = obj + (zz * gz).sum()
             if g_mu is not None:
                 obj = obj + (pm * g_mu.reshape(P, B, L)[i]).sum()
             if g_lv is not None:

@@ -1,0 +1,221 @@
+"""Drop-in module API + problem layer + fused engine, host logic on CPU (kernels emulated by
+tests/emu_backend.py), checked against the golden vectors produced by the reference."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mmdyn_hip import ops
+from mmdyn_hip.engine import MVAEStep
+from mmdyn_hip.models import setup_model, InjectedNoise, ProductOfExperts
+from mmdyn_hip.models.shapes import state_dict_shapes
+from mmdyn_hip.problems.problems import SeqModeling, DynModeling, SyntheticVisuoTactile
+from mmdyn_hip.utils.seeded_init import seeded_state_dict, seeded_batch, seeded_noise
+from emu_backend import EmuBackend
+from test_oracle_golden import summarize, close_summary, close_params, load
+
+MODEL_KW = dict(condition_dim=0, input_dim=4096, architecture="cnn", conditional=False, categorical_conditions=False,
+                latent_size=256)
+
+
+@pytest.fixture(autouse=True)
+def emu():
+    old = ops.set_backend(EmuBackend())
+    yield
+    ops.set_backend(old)
+
+
+def build(name, cross, use_pose=None, device="cpu"):
+    kw = dict(MODEL_KW)
+    if use_pose is not None:
+        kw["use_pose"] = use_pose
+    m = setup_model(name, cross_modal=cross, **kw)
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 0))
+    return m.to(device).train()
+
+
+def args(**over):
+    d = dict(problem_type="seq_modeling", model_name="cnn-mvae", input_type="visuotactile", use_pose=True, lr=1e-3,
+             dataset_path="", batchsize=4, criterion="crossentropy", optimizer="Adam", num_epochs=1, mask_loss=False,
+             vis_pose=False, pose_multiplier=1000.0, save_name="t", no_cuda=False, kl_weight=1.0, latent_size=256,
+             annealing_epochs=50, conditional=False)
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+def check_forward_subsets(golden_dir, device):
+    g = load(golden_dir, "mvae_forward_B3.npz")
+    B = int(g["batch"])
+    m = build("cnn-mvae", True, True, device)
+    v, t, p = (torch.tensor(g[f"in{i}"]).to(device) for i in range(3))
+    eps, masks = seeded_noise(B, 256, 8, 8, 99)
+    m.noise = InjectedNoise(eps, masks)
+    with torch.no_grad():
+        for i, (a, b, c) in enumerate(g["subsets"]):
+            vr, tr, pr, mu, lv = m([v if a else None, t if b else None], pose=p if c else None)
+            np.testing.assert_allclose(mu.cpu().numpy(), g[f"s{i}/means"], rtol=1e-4, atol=3e-5)
+            np.testing.assert_allclose(lv.cpu().numpy(), g[f"s{i}/log_var"], rtol=1e-4, atol=3e-5)
+            np.testing.assert_allclose(pr.cpu().numpy(), g[f"s{i}/pose"], rtol=1e-4, atol=3e-5)
+            close_summary(summarize(vr.cpu(), 256), g[f"s{i}/visual"], 3e-5, f"s{i} visual")
+            close_summary(summarize(tr.cpu(), 256), g[f"s{i}/tactile"], 3e-5, f"s{i} tactile")
+        vr, tr = m.inference(n=B)
+        close_summary(summarize(vr.cpu(), 256), g["inference/visual"], 3e-5, "inference")
+    sd = m.state_dict()
+    for k in sd:
+        if "running" in k or "num_batches" in k:
+            np.testing.assert_allclose(sd[k].double().cpu().numpy(), g["buffer/" + k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+def check_reference_schedule_step(golden_dir, device, fname, use_pose):
+    """fused=False: seven model() calls + autograd, as the reference does."""
+    g = load(golden_dir, fname)
+    B = int(g["batch"])
+    prob = SeqModeling(args(use_pose=use_pose, no_cuda=(device == "cpu")), log_dir="/tmp/mmdyn_test_logs", fused=False)
+    m = prob.model
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 0))
+    inputs, targets = seeded_batch(B, 1234, with_pose=use_pose)
+    n_pass, n_mask = (7, 8) if use_pose else (3, 4)
+    eps, masks = seeded_noise(B, 256, n_pass * int(g["n_steps"]), n_mask * int(g["n_steps"]), 4321)
+    m.noise = InjectedNoise(eps, masks)
+    prob._kl_weight = float(g["kl_weight"])
+    x = {"model_input": [inputs[0].to(device), inputs[1].to(device)], "input_object_pose": [inputs[2].to(device)] if use_pose else None, "shock": None}
+    t = {"target_output": [targets[0].to(device), targets[1].to(device)], "target_object_pose": [targets[2].to(device)] if use_pose else None, "loss_mask": None}
+    prob._optimizer.zero_grad()
+    outputs, loss = prob._evaluate_model(x, t)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss_step0"]), rel=1e-4)
+    pm = outputs["perf_measure"]
+    np.testing.assert_allclose([pm["visual"], pm["tactile"]], g["perf_measure"][:2], rtol=1e-4)
+    np.testing.assert_allclose(outputs["means"].detach().cpu().numpy(), g["means"], rtol=1e-4, atol=3e-5)
+    for k, p_ in m.named_parameters():
+        close_summary(summarize(p_.grad.cpu()), g["grad/" + k], 1e-3, "grad " + k)
+    prob._optimizer.step()
+    for k, p_ in m.named_parameters():
+        close_params(summarize(p_.detach().cpu()), g["param_step0/" + k], 1e-3, 1, "param " + k)
+    sd = m.state_dict()
+    for k in sd:
+        if "running" in k or "num_batches" in k:
+            np.testing.assert_allclose(sd[k].double().cpu().numpy(), g["buffer_step0/" + k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+def check_fused_engine(golden_dir, device, fname, use_pose):
+    g = load(golden_dir, fname)
+    B, n_steps = int(g["batch"]), int(g["n_steps"])
+    m = build("cnn-mvae", True, use_pose, device)
+    inputs, targets = seeded_batch(B, 1234, with_pose=use_pose)
+    inputs, targets = [x.to(device) for x in inputs], [x.to(device) for x in targets]
+    n_pass, n_mask = (7, 8) if use_pose else (3, 4)
+    eps, masks = seeded_noise(B, 256, n_pass * n_steps, n_mask * n_steps, 4321)
+    step = MVAEStep(m, lr=float(g["lr"]), pose_multiplier=float(g["pose_multiplier"]), noise=InjectedNoise(eps, masks))
+    for s in range(n_steps):
+        loss = step.forward(inputs, targets, float(g["kl_weight"]), train=True)
+        assert float(loss) == pytest.approx(float(g[f"loss_step{s}"]), rel=1e-4), s
+        if s == 0:
+            np.testing.assert_allclose(step.partials[:n_pass].cpu().numpy(), g["loss_partials"], rtol=1e-4)
+            np.testing.assert_allclose(step.last["means"].cpu().numpy(), g["means"], rtol=1e-4, atol=3e-5)
+            np.testing.assert_allclose(step.last["log_var"].cpu().numpy(), g["log_var"], rtol=1e-4, atol=3e-5)
+            close_summary(summarize(step.last["recon_x"][0].cpu(), 256), g["recon0"], 3e-5, "recon0")
+            if use_pose:
+                np.testing.assert_allclose(step.last["recon_x"][2].cpu().numpy(), g["recon2"], rtol=1e-4, atol=3e-5)
+        handles = step.backward()
+        if s == 0:
+            for k, p_ in m.named_parameters():
+                close_summary(summarize(p_.grad.cpu()), g["grad/" + k], 1e-3, "grad " + k)
+        step.optimizer_step(handles)
+        if s in (0, n_steps - 1):
+            for k, p_ in m.named_parameters():
+                close_params(summarize(p_.detach().cpu()), g[f"param_step{s}/" + k], float(g["lr"]), s + 1, f"param {k}")
+    # encoder running statistics follow the reference exactly (4 identical EMA updates per step)
+    sd = m.state_dict()
+    for k in sd:
+        if "encoder" in k and ("running" in k or "num_batches" in k):
+            np.testing.assert_allclose(sd[k].double().cpu().numpy(), g[f"buffer_step{n_steps - 1}/" + k], rtol=2e-5,
+                                       atol=2e-3 if n_steps > 1 else 2e-6, err_msg=k)
+
+
+def test_mvae_forward_subsets(golden_dir):
+    check_forward_subsets(golden_dir, "cpu")
+
+
+@pytest.mark.parametrize("fname,use_pose", [("mvae_pose_B4.npz", True), ("mvae_nopose_B4.npz", False)])
+def test_reference_schedule_step(golden_dir, fname, use_pose):
+    check_reference_schedule_step(golden_dir, "cpu", fname, use_pose)
+
+
+@pytest.mark.parametrize("fname,use_pose", [("mvae_pose_B4.npz", True), ("mvae_nopose_B4.npz", False)])
+def test_fused_engine_matches_reference(golden_dir, fname, use_pose):
+    check_fused_engine(golden_dir, "cpu", fname, use_pose)
+
+
+def check_vae_config1(golden_dir, device):
+    g = load(golden_dir, "vae_visual_B16.npz")
+    prob = SeqModeling(args(model_name="cnn-vae", input_type="visual", use_pose=False, no_cuda=(device == "cpu")),
+                       log_dir="/tmp/mmdyn_test_logs", fused=False)
+    m = prob.model
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 0))
+    eps, masks = seeded_noise(16, 256, 2, 2, 31)
+    m.noise = InjectedNoise(eps, masks)
+    prob._kl_weight = float(g["kl_weight"])
+    x, y = torch.tensor(g["x"]).to(device), torch.tensor(g["y"]).to(device)
+    for s in range(2):
+        prob._optimizer.zero_grad()
+        out, loss = prob._evaluate_model({"model_input": x, "shock": None}, {"target_output": y, "loss_mask": None})
+        loss.backward()
+        assert float(loss.detach()) == pytest.approx(float(g[f"loss_step{s}"]), rel=1e-4)
+        if s == 0:
+            assert out["perf_measure"]["visual"] == pytest.approx(float(g["perf_measure"]), rel=1e-4)
+            for k, p_ in m.named_parameters():
+                close_summary(summarize(p_.grad.cpu()), g["grad/" + k], 1e-3, "grad " + k)
+        prob._optimizer.step()
+
+
+def test_vae_config1(golden_dir):
+    check_vae_config1(golden_dir, "cpu")
+
+
+def test_product_of_experts_module(golden_dir):
+    g = load(golden_dir, "small_ops.npz")
+    mu = torch.tensor(g["poe/mu"], requires_grad=True)
+    lv = torch.tensor(g["poe/logvar"], requires_grad=True)
+    pm, plv = ProductOfExperts()(mu, lv)
+    np.testing.assert_allclose(pm.detach().numpy(), g["poe/out_mu"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(plv.detach().numpy(), g["poe/out_logvar"], rtol=1e-5, atol=1e-5)
+    (pm.sum() + plv.sum()).backward()
+    assert torch.isfinite(mu.grad).all() and torch.isfinite(lv.grad).all()
+
+
+def test_parse_input_and_training_loop(golden_dir, tmp_path):
+    g = load(golden_dir, "small_ops.npz")
+    data = [torch.tensor(g[f"parse/data{i}"]) for i in range(5)]
+    target = [torch.tensor(g[f"parse/target{i}"]) for i in range(4)]
+    for cls, tag in ((SeqModeling, "seq"), (DynModeling, "dyn")):
+        for it in ("visual", "tactile", "visuotactile"):
+            p = cls.__new__(cls)
+            p._seq_length, p._device, p.parameters = int(g["parse/seq_length"]), torch.device("cpu"), {"input_type": it}
+            x, t = p.parse_input([d.clone() for d in data], [d.clone() for d in target])
+            mi, to = x["model_input"], t["target_output"]
+            if not isinstance(mi, list):
+                mi, to = [mi], [to]
+            pre = f"parse/{tag}/{it}/"
+            for j in range(len(mi)):
+                np.testing.assert_array_equal(mi[j].numpy(), g[pre + f"model_input{j}"])
+                np.testing.assert_array_equal(to[j].numpy(), g[pre + f"target_output{j}"])
+            np.testing.assert_array_equal(t["target_object_pose"][0].numpy(), g[pre + "target_pose"])
+            np.testing.assert_array_equal(x["shock"].numpy(), g[pre + "shock"])
+    # KL annealing + one tiny epoch through the fused engine, checkpoint format
+    prob = SeqModeling(args(num_epochs=1, no_cuda=True), log_dir=str(tmp_path), fused=True,
+                       train_loader=SyntheticVisuoTactile(2, 2), test_loader=SyntheticVisuoTactile(1, 2, seed=7))
+    sched = []
+    for e in range(60):
+        prob._anneal_KL(e)
+        sched.append(prob._kl_weight)
+    np.testing.assert_allclose(sched, g["anneal/kl"])
+    prob.train()
+    ck = [f for f in os.listdir(prob.checkpoint_dir) if f.endswith(".ckpt")]
+    assert ck == ["epoch_0.ckpt"]
+    state = torch.load(os.path.join(prob.checkpoint_dir, ck[0]), weights_only=False)
+    assert set(state) == {"model", "loss", "epoch"}
+    assert list(state["model"].keys()) == list(state_dict_shapes("cnn-mvae", use_pose=True).keys())
+    assert os.path.exists(os.path.join(str(tmp_path), "results.pkl"))
