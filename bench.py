@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- cnn-mvae visuotactile+pose training throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimiser step of the cnn-mvae seq_modeling problem on one synthetic batch that is already
+resident in HBM: the 7 modality-subset ELBO passes, backward and Adam (problems.py:148-156, 473-546), fp32,
+64x64 visual + tactile + 7-DoF pose, 256 samples per GPU (weak scaling: pure data parallel, gradients
+all-reduced over RCCL).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-dynamics_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = fp32 vector peak
+ALGO_GFLOP_PER_SAMPLE = 2.024      # distinct contractions of one train step
+KL_WEIGHT = 1.0 / 50               # epoch 0 of the reference's annealing schedule (problems.py:212-216)
+
+
+def host_cpu_share():
+    """CPU threads this process may really use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    found = False
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n, found = min(n, max(1, int(float(quota) / float(period) + 0.5))), True
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n, found = min(n, max(1, int(q / per + 0.5))), True
+    except (OSError, ValueError):
+        pass
+    if not found:
+        n = min(n, 16)          # a one-GPU box's documented CPU share
+    return max(1, n)
+
+
+def cpu_baseline(batch, threads):
+    """The CPU oracle (a port of the reference path executing the reference's own schedule: 8 encoder + 14
+    decoder forwards, autograd backward, Adam) timed on this box's host cores.  Bounded: a probe step at bs=32
+    decides whether the full bs=256 step fits the ~30 s budget; otherwise a bs=64 sample is timed."""
+    from oracle import mvae_oracle as O
+    from mmdyn_hip.models.shapes import state_dict_shapes
+    from mmdyn_hip.utils.seeded_init import seeded_state_dict, seeded_batch, seeded_noise
+    torch.set_num_threads(threads)
+
+    def run(bs, steps):
+        prm, buf = O.split_state(seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True), 0))
+        inputs, targets = seeded_batch(bs, 1234)
+        eps, masks = seeded_noise(bs, 256, 7, 8, 4321)
+        opt = O.Adam([prm[k] for k in prm], lr=1e-3)
+        times, loss = [], None
+        for s in range(steps):
+            t0 = time.perf_counter()
+            opt.zero_grad()
+            _, loss, _ = O.evaluate_mvae(prm, inputs, targets, eps, masks, KL_WEIGHT, 1000.0, True, buf)
+            loss.backward()
+            opt.step()
+            times.append(time.perf_counter() - t0)
+            print(f"[cpu_baseline] bs={bs} step {s}: {times[-1]:.2f} s ({threads} threads)", file=sys.stderr, flush=True)
+        return times, float(loss.detach())
+
+    probe, _ = run(32, 2)
+    est_full = probe[-1] * (batch / 32.0)
+    bs = batch if est_full * 3 <= 45.0 else 64
+    times, loss = run(bs, 3)
+    best = min(times[1:])
+    return {"value": bs / best, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"2 timed steps (+1 warm-up) of the cnn-mvae+pose train step at bs={bs}, min; {best:.2f} s/step",
+            "loss": loss}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a HIP graph")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        pg = dist.group.WORLD
+
+    from mmdyn_hip.engine import MVAEStep
+    from mmdyn_hip.models import setup_model, NoiseSource
+    from mmdyn_hip.profiling import profile_step
+    from mmdyn_hip.utils.seeded_init import seeded_batch
+
+    torch.manual_seed(0)
+    model = setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=4096, architecture="cnn",
+                        conditional=False, categorical_conditions=False, latent_size=256, use_pose=True).to(dev).train()
+    step = MVAEStep(model, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), process_group=pg,
+                    world_size=world)
+    inputs, targets = seeded_batch(args.batch, 1234 + rank)
+    inputs, targets = [x.to(dev) for x in inputs], [x.to(dev) for x in targets]
+
+    def one_step():
+        return step.train_step(inputs, targets, KL_WEIGHT)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss)
+
+    # per-kernel timing of one extra (untimed) step, HIP events on the launch stream
+    kern = profile_step(one_step)
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    global_batch = args.batch * world
+    sps = global_batch * args.steps / elapsed
+    ig = kern.get("igemm_nt", {"ms": 0.0, "flops": 0.0, "calls": 0})
+    wg = kern.get("wgrad_tn", {"ms": 0.0, "flops": 0.0, "calls": 0})
+    dom = ig if ig["ms"] >= wg["ms"] else wg
+    dom_name = "igemm_nt_kernel" if dom is ig else "wgrad_tn_kernel"
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    total_ms = sum(d["ms"] for d in kern.values())
+    out = {
+        "metric": "visuotactile samples/sec (train) + ELBO vs CPU ref, cnn-mvae 64x64 bs256 @1/2/4/8 GPU",
+        "value": sps, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cnn-mvae visuotactile+pose 64x64, bs=256 per GPU, fp32, seq_modeling train step "
+                               "(7 subset ELBOs + backward + Adam), BASELINE configs[1]",
+                   "global_batch": global_batch, "parallelism": f"dp{world}", "bn": "local",
+                   "final_loss": final_loss},
+        "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "launches_per_step": dom["calls"], "avg_launch_ms": dom["ms"] / max(dom["calls"], 1),
+                     "kernel_share_of_step": dom["ms"] / total_ms if total_ms else None,
+                     "step_algorithmic_tflops": sps / world * ALGO_GFLOP_PER_SAMPLE * 1e9 / 1e12,
+                     "step_frac_of_peak": sps / world * ALGO_GFLOP_PER_SAMPLE * 1e9 / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+    }
+    if args.breakdown:
+        for k, d in sorted(kern.items(), key=lambda kv: -kv[1]["ms"]):
+            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 and d["flops"] else 0.0
+            gb = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+            print(f"{k:24s} calls {d['calls']:4d}  {d['ms']:8.3f} ms  {tf:7.2f} TFLOP/s  {gb:8.1f} GB/s(args)", file=sys.stderr)
+        print(f"sum of kernel time {total_ms:.3f} ms vs step {1e3 * elapsed / args.steps:.3f} ms", file=sys.stderr)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.batch, host_cpu_share())
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

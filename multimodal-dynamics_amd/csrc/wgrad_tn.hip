@@ -162,30 +162,52 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
     }
 }
 
-// canon (+)= sum_chunks partial, scattered into the reference layout
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ canon, int chunks,
-                                    int taps, int Cd, int Cg, int cg_canon, int perm, float beta) {
+// canon (+)= sum_chunks partial, scattered into the reference layout.
+// 256 threads = 32 element lanes x 8 chunk lanes: the chunk sum is split 8 ways (short dependent chains even
+// for 128+ slabs) and finished through LDS; slab reads stay 128-byte coalesced.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                           float* __restrict__ canon, int chunks, int taps,
+                                                           int Cd, int Cg, int cg_canon, int perm, float beta) {
+  __shared__ float red[8][33];
   const int64_t slab = (int64_t)taps * Cd * Cg;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < slab;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    int cg = (int)(i % Cg);
-    int64_t t = i / Cg;
-    int cd = (int)(t % Cd);
-    int tap = (int)(t / Cd);
-    if (cg >= cg_canon) continue;
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * slab + i];
-    int64_t o;
-    if (perm == 0) {
-      o = ((int64_t)cd * cg_canon + cg) * taps + tap;
-    } else if (perm == 1) {  // cg = hw*256 + ch  -> column ch*25 + hw
-      int hw = cg / 256, ch = cg - hw * 256;
-      o = (int64_t)cd * cg_canon + ch * 25 + hw;
-    } else {                 // cd = hw*256 + ch  -> row ch*25 + hw
-      int hw = cd / 256, ch = cd - hw * 256;
-      o = (int64_t)(ch * 25 + hw) * cg_canon + cg;
+  const int il = threadIdx.x & 31, cl = threadIdx.x >> 5;
+  const int64_t ntiles = (slab + 31) / 32;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t i = tile * 32 + il;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < slab) {
+      int c = cl;
+      for (; c + 8 < chunks; c += 16) {
+        s0 += partial[(size_t)c * slab + i];
+        s1 += partial[(size_t)(c + 8) * slab + i];
+      }
+      if (c < chunks) s0 += partial[(size_t)c * slab + i];
     }
-    canon[o] = (beta != 0.f) ? (beta * canon[o] + s) : s;
+    red[cl][il] = s0 + s1;
+    __syncthreads();
+    if (cl == 0 && i < slab) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += red[k][il];
+      int cg = (int)(i % Cg);
+      int64_t t = i / Cg;
+      int cd = (int)(t % Cd);
+      int tap = (int)(t / Cd);
+      if (cg < cg_canon) {
+        int64_t o;
+        if (perm == 0) {
+          o = ((int64_t)cd * cg_canon + cg) * taps + tap;
+        } else if (perm == 1) {  // cg = hw*256 + ch  -> column ch*25 + hw
+          int hw = cg / 256, ch = cg - hw * 256;
+          o = (int64_t)cd * cg_canon + ch * 25 + hw;
+        } else {                 // cd = hw*256 + ch  -> row ch*25 + hw
+          int hw = cd / 256, ch = cd - hw * 256;
+          o = (int64_t)(ch * 25 + hw) * cg_canon + cg;
+        }
+        canon[o] = (beta != 0.f) ? (beta * canon[o] + s) : s;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -259,7 +281,9 @@ extern "C" int mmdyn_wgrad_reduce(const float* partial, float* canon, int chunks
   if (perm == 1 && (Cg % 256 || Cg / 256 != 25)) return MMDYN_ERR_SHAPE;
   if (perm == 2 && (Cd % 256 || Cd / 256 != 25)) return MMDYN_ERR_SHAPE;
   int64_t slab = (int64_t)taps * Cd * Cg;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(slab)), dim3(256), 0, (hipStream_t)stream, partial,
-                     canon, chunks, taps, Cd, Cg, cg_canon, perm, beta);
+  int64_t ntiles = (slab + 31) / 32;
+  int grid = (int)(ntiles < 8192 ? ntiles : 8192);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partial, canon, chunks,
+                     taps, Cd, Cg, cg_canon, perm, beta);
   MMDYN_LAUNCH_CHECK();
 }

@@ -1,0 +1,78 @@
+"""Per-kernel timing with HIP events on the launch stream (bench.py's ``roofline`` object).
+
+``TimedBackend`` wraps the active backend: every kernel-launching call is bracketed by two events recorded
+on torch's current stream -- the stream the C ABI launches on -- and tagged with its algorithmic FLOPs /
+bytes, so achieved rates are measured live rather than taken from a trace."""
+import collections
+
+import torch
+
+from . import ops
+
+HOST_ONLY = {"igemm_stat_tiles", "colstats_tiles", "wgrad_chunks"}
+
+
+def _flops(name, a):
+    if name == "igemm_nt":
+        (mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) = a[7:16]
+        if mode == ops.DENSE:
+            return 2.0 * G * Bg * Ho * Wo * N * Cin
+        if mode == ops.CONV:
+            return 2.0 * G * Bg * Ho * Wo * N * 16 * Cin
+        return 2.0 * G * Bg * Ho * Wo * N * 4 * Cin
+    if name == "wgrad_tn":
+        (mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg) = a[3:11]
+        return 2.0 * Bt * Hr * Wr * Cd * Cg * (16 if mode == ops.CONV else 1)
+    return 0.0
+
+
+def _bytes(a):
+    n = 0
+    for t in a:
+        if torch.is_tensor(t):
+            n += t.numel() * t.element_size()
+    return n
+
+
+class TimedBackend:
+    name = "hip"
+
+    def __init__(self, inner):
+        self._inner = inner
+        self.records = []
+
+    def __getattr__(self, attr):
+        fn = getattr(self._inner, attr)
+        if attr in HOST_ONLY or not callable(fn):
+            return fn
+
+        def wrapped(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a, **k)
+            e.record()
+            self.records.append((attr, _flops(attr, a), _bytes(a), s, e))
+            return r
+        return wrapped
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = collections.OrderedDict()
+        for name, fl, by, s, e in self.records:
+            d = agg.setdefault(name, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["calls"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["bytes"] += by
+        return agg
+
+
+def profile_step(fn):
+    """Run ``fn()`` once with every kernel call timed; returns {kernel: {calls, ms, flops, bytes}}."""
+    timed = TimedBackend(ops.B)
+    old = ops.set_backend(timed)
+    try:
+        fn()
+    finally:
+        ops.set_backend(old)
+    return timed.summary()
