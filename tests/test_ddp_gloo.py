@@ -1,0 +1,85 @@
+"""Data-parallel path with world_size 2 on gloo/CPU (kernels emulated): the flat-gradient all-reduce buckets of
+engine.MVAEStep must reproduce 'average of the per-shard gradients, then one Adam step' (local BatchNorm)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "multimodal-dynamics_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mmdyn_hip import ops
+    from mmdyn_hip.engine import MVAEStep
+    from mmdyn_hip.models import InjectedNoise
+    from mmdyn_hip.utils.seeded_init import seeded_batch, seeded_noise
+    from emu_backend import EmuBackend
+    import test_model_emu as T
+    ops.set_backend(EmuBackend())
+    B = 2
+    inputs, targets = seeded_batch(B * world, 1234)
+    sl = slice(rank * B, (rank + 1) * B)
+    eps, masks = seeded_noise(B, 256, 7, 8, 100 + rank)
+    m = T.build("cnn-mvae", True, True, "cpu")
+    step = MVAEStep(m, noise=InjectedNoise(eps, masks), process_group=dist.group.WORLD, world_size=world)
+    loss = step.train_step([x[sl] for x in inputs], [x[sl] for x in targets], 0.02)
+    torch.save({"flat": step.params.flat.clone(), "order": step.params.order, "offsets": step.params.offsets,
+                "loss": float(loss)}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_step_matches_averaged_gradients(tmp_path):
+    world = 2
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
+    torch.testing.assert_close(r0["flat"], r1["flat"], rtol=0, atol=0)       # replicas stay identical
+
+    from oracle import mvae_oracle as O
+    from mmdyn_hip.models.shapes import state_dict_shapes
+    from mmdyn_hip.utils.seeded_init import seeded_state_dict, seeded_batch, seeded_noise
+    sd = seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True), 0)
+    inputs, targets = seeded_batch(4, 1234)
+    grads, losses = [], []
+    for rank in range(world):
+        prm, buf = O.split_state(sd)
+        sl = slice(rank * 2, (rank + 1) * 2)
+        eps, masks = seeded_noise(2, 256, 7, 8, 100 + rank)
+        _, loss, _ = O.evaluate_mvae(prm, [x[sl] for x in inputs], [x[sl] for x in targets], eps, masks, 0.02, 1000.0, True, buf)
+        loss.backward()
+        grads.append({k: v.grad for k, v in prm.items()})
+        losses.append(float(loss.detach()))
+    assert r0["loss"] == pytest.approx(losses[0], rel=1e-4) and r1["loss"] == pytest.approx(losses[1], rel=1e-4)
+    prm, _ = O.split_state(sd)
+    names = list(prm)
+    for k in names:
+        prm[k].grad = 0.5 * (grads[0][k] + grads[1][k])
+    O.Adam([prm[k] for k in names], lr=1e-3).step()
+    for k in names:
+        o = r0["offsets"][k]
+        got = r0["flat"][o:o + prm[k].numel()].view_as(prm[k])
+        err = (got - prm[k].detach()).abs()
+        # first Adam step moves every element by ~lr*sign(g): allow sign flips only where the gradient is at noise level
+        assert float((err > 1e-5).float().mean()) < 0.02, (k, float(err.max()))
+        assert float(err.max()) <= 2.1e-3, k
