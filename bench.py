@@ -184,6 +184,11 @@ def main():
             gb = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
             print(f"{k:24s} calls {d['calls']:4d}  {d['ms']:8.3f} ms  {tf:7.2f} TFLOP/s  {gb:8.1f} GB/s(args)", file=sys.stderr)
         print(f"sum of kernel time {total_ms:.3f} ms vs step {1e3 * elapsed / args.steps:.3f} ms", file=sys.stderr)
+        print("per-shape MFMA launches: name, (mode,G,Bg,Hi,Wi,Cin,Ho,Wo,N,ldc,stride,offset,act,splitk) | "
+              "(mode,Bt,Hr,Wr,Cd,Hi,Wi,Cg,stride,offset,chunks)", file=sys.stderr)
+        for k, d in sorted(profile_step.by_shape.items(), key=lambda kv: -kv[1]["ms"]):
+            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+            print(f"  {k[0]:9s} {str(k[1:]):70s} x{d['calls']:2d} {d['ms']:7.3f} ms {tf:6.1f} TF/s", file=sys.stderr)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.batch, host_cpu_share())
     print(json.dumps(out))

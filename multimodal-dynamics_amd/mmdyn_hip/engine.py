@@ -82,11 +82,38 @@ class FlatParams:
         return {k[len(prefix) + 1:]: v for k, v in src.items() if k.startswith(prefix + ".")}
 
 
+class _Lanes:
+    """Two side streams for the independent visual / tactile halves of the schedule (HIP streams on the GPU,
+    no-ops on the CPU emulation).  Every fork starts from the main stream's current point and every join
+    returns to it, so buffers handed between lanes are ordered by events, never by luck."""
+
+    def __init__(self, device, enabled=True):
+        self.on = enabled and device.type == "cuda"
+        if self.on:
+            self.side = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+
+    def fork(self):
+        if self.on:
+            ev = torch.cuda.current_stream().record_event()
+            for s in self.side:
+                s.wait_event(ev)
+
+    def lane(self, i):
+        import contextlib
+        return torch.cuda.stream(self.side[i]) if self.on else contextlib.nullcontext()
+
+    def join(self):
+        if self.on:
+            main = torch.cuda.current_stream()
+            for s in self.side:
+                main.wait_event(s.record_event())
+
+
 class MVAEStep:
     """Fused train / eval step for an :class:`mmdyn_hip.models.MVAE` on one GPU (one rank)."""
 
     def __init__(self, model, lr=1e-3, pose_multiplier=1000.0, betas=(0.9, 0.999), eps=1e-8, noise=None,
-                 process_group=None, world_size=1):
+                 process_group=None, world_size=1, two_lanes=True):
         self.model = model
         self.use_pose = bool(model._use_pose)
         self.L = model.latent_size
@@ -108,6 +135,7 @@ class MVAEStep:
         self.loss = torch.zeros(1, device=dev)
         self.partials = torch.zeros(8, device=dev)
         self.last = {}
+        self.lanes = _Lanes(dev, two_lanes)
 
     # ------------------------------------------------------------------------------------------
     def _noise(self):
@@ -148,21 +176,25 @@ class MVAEStep:
         c = {"B": B, "eps": eps, "mv": mv, "mt": mt}
 
         # 1. encoder trunks, once per modality (running statistics: nv identical EMA updates, as in the reference)
-        hv, c["ev"] = layers.encoder_trunk_forward(FP.sub("visual_encoder"), self._buffers("visual_encoder"), v, 1, nv)
-        ht, c["et"] = layers.encoder_trunk_forward(FP.sub("tactile_encoder"), self._buffers("tactile_encoder"), t, 1, nt)
-        # 2. per-pass dropout, batched
-        hdv = torch.empty(nv * B, 512, device=dev)
-        hdt = torch.empty(nt * B, 512, device=dev)
-        ops.B.dropout_expand(hv, mv, hdv, nv, B, 512, DROPOUT_P)
-        ops.B.dropout_expand(ht, mt, hdt, nt, B, 512, DROPOUT_P)
-        # 3. heads (means | log_var fused), all passes of a modality in one GEMM
-        ov, c["hv"] = layers.heads_forward(FP.sub("visual_encoder"), hdv)
-        ot, c["ht"] = layers.heads_forward(FP.sub("tactile_encoder"), hdt)
+        # 2. per-pass dropout, batched;  3. heads (means | log_var fused), all passes of a modality in one GEMM
+        LN = self.lanes
+        LN.fork()
+        with LN.lane(0):
+            hv, c["ev"] = layers.encoder_trunk_forward(FP.sub("visual_encoder"), self._buffers("visual_encoder"), v, 1, nv)
+            hdv = torch.empty(nv * B, 512, device=dev)
+            ops.B.dropout_expand(hv, mv, hdv, nv, B, 512, DROPOUT_P)
+            ov, c["hv"] = layers.heads_forward(FP.sub("visual_encoder"), hdv)
+        with LN.lane(1):
+            ht, c["et"] = layers.encoder_trunk_forward(FP.sub("tactile_encoder"), self._buffers("tactile_encoder"), t, 1, nt)
+            hdt = torch.empty(nt * B, 512, device=dev)
+            ops.B.dropout_expand(ht, mt, hdt, nt, B, 512, DROPOUT_P)
+            ot, c["ht"] = layers.heads_forward(FP.sub("tactile_encoder"), hdt)
         op = None
         if self.use_pose:
             pose_rep = inputs[2].contiguous().repeat(npp, 1)                  # same pose rows for each pass
             hp, c["ep"] = layers.pose_encoder_trunk_forward(FP.sub("pose_encoder"), pose_rep)
             op, c["hp"] = layers.heads_forward(FP.sub("pose_encoder"), hp)
+        LN.join()
         c["ov"], c["ot"], c["op"] = ov, ot, op
         # 4. product of experts + reparametrisation + KL for every pass
         mu = torch.empty(P, B, L, device=dev)
@@ -172,26 +204,29 @@ class MVAEStep:
         ops.B.poe_fwd(self._passes(c, B, None), eps, mu, lv, z, self.acc[2], True, P, B, L)
         c["mu"], c["lv"] = mu, lv
         # 5. decoders on their live passes (groups)
-        zv = torch.cat([z[p] for p in self.pass_v])
-        zt = torch.cat([z[p] for p in self.pass_t])
-        lg_v, c["dv"] = layers.decoder_forward(FP.sub("visual_decoder"), self._buffers("visual_decoder"), zv, nv)
-        lg_t, c["dt"] = layers.decoder_forward(FP.sub("tactile_decoder"), self._buffers("tactile_decoder"), zt, nt)
+        # 6. reconstruction terms (+ their gradients when training) follow each decoder on its lane
+        n_img = B * 3 * 64 * 64
+        tv, tt = targets[0].contiguous(), targets[1].contiguous()
+        inv_b = 1.0 / B
+        LN.fork()
+        with LN.lane(0):
+            zv = torch.cat([z[p] for p in self.pass_v])
+            lg_v, c["dv"] = layers.decoder_forward(FP.sub("visual_decoder"), self._buffers("visual_decoder"), zv, nv)
+            dl_v = torch.empty_like(lg_v) if train else None
+            for g, p in enumerate(self.pass_v):
+                ops.B.bce_logits(lg_v[g * B:(g + 1) * B], tv, None, None if dl_v is None else dl_v[g * B:(g + 1) * B],
+                                 self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, inv_b)
+        with LN.lane(1):
+            zt = torch.cat([z[p] for p in self.pass_t])
+            lg_t, c["dt"] = layers.decoder_forward(FP.sub("tactile_decoder"), self._buffers("tactile_decoder"), zt, nt)
+            dl_t = torch.empty_like(lg_t) if train else None
+            for g, p in enumerate(self.pass_t):
+                ops.B.bce_logits(lg_t[g * B:(g + 1) * B], tt, None, None if dl_t is None else dl_t[g * B:(g + 1) * B],
+                                 self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, inv_b)
         pr = None
         if self.use_pose:
             zp = torch.cat([z[p] for p in self.pass_p])
             pr, c["dp"] = layers.pose_decoder_forward(FP.sub("pose_decoder"), zp)
-        # 6. reconstruction terms (+ their gradients when training)
-        n_img = B * 3 * 64 * 64
-        tv, tt = targets[0].contiguous(), targets[1].contiguous()
-        dl_v = torch.empty_like(lg_v) if train else None
-        dl_t = torch.empty_like(lg_t) if train else None
-        inv_b = 1.0 / B
-        for g, p in enumerate(self.pass_v):
-            ops.B.bce_logits(lg_v[g * B:(g + 1) * B], tv, None, None if dl_v is None else dl_v[g * B:(g + 1) * B],
-                             self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, inv_b)
-        for g, p in enumerate(self.pass_t):
-            ops.B.bce_logits(lg_t[g * B:(g + 1) * B], tt, None, None if dl_t is None else dl_t[g * B:(g + 1) * B],
-                             self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, inv_b)
         dpr = None
         if self.use_pose:
             tp = targets[2].contiguous()
@@ -199,6 +234,7 @@ class MVAEStep:
             for g, p in enumerate(self.pass_p):
                 ops.B.mse(pr[g * B:(g + 1) * B], tp, None if dpr is None else dpr[g * B:(g + 1) * B],
                           self.acc[1, p:p + 1], B * 7, self.pose_multiplier * inv_b)
+        LN.join()
         ops.B.elbo_assemble(self.acc[0], self.acc[1], self.acc[2], self.loss, self.partials, P, B, kl_weight,
                             self.pose_multiplier)
         c.update(dl_v=dl_v, dl_t=dl_t, dpr=dpr, kl_weight=kl_weight)
@@ -239,8 +275,13 @@ class MVAEStep:
         dzp = None
         if self.use_pose:
             dzp = layers.pose_decoder_backward(FP.sub("pose_decoder"), c["dp"], c["dpr"], FP.sub("pose_decoder", "G"))
-        dzv = layers.decoder_backward(FP.sub("visual_decoder"), c["dv"], c["dl_v"], FP.sub("visual_decoder", "G"))
-        dzt = layers.decoder_backward(FP.sub("tactile_decoder"), c["dt"], c["dl_t"], FP.sub("tactile_decoder", "G"))
+        LN = self.lanes
+        LN.fork()
+        with LN.lane(0):
+            dzv = layers.decoder_backward(FP.sub("visual_decoder"), c["dv"], c["dl_v"], FP.sub("visual_decoder", "G"))
+        with LN.lane(1):
+            dzt = layers.decoder_backward(FP.sub("tactile_decoder"), c["dt"], c["dl_t"], FP.sub("tactile_decoder", "G"))
+        LN.join()
         handles += self._reduce_bucket(0)
         # latent gradient sources per pass (summed inside the PoE backward kernel)
         blocks = [[None, None, None] for _ in range(P)]
@@ -255,17 +296,22 @@ class MVAEStep:
         dop = torch.empty_like(c["op"]) if self.use_pose else None
         ops.B.poe_bwd(self._passes(c, B, [dov, dot, dop], blocks), c["eps"], c["mu"], c["lv"], None, None, None,
                       c["kl_weight"] / B, True, P, B, L)
-        dhdv = layers.heads_backward(c["hv"], dov, FP.sub("visual_encoder", "G"))
-        dhdt = layers.heads_backward(c["ht"], dot, FP.sub("tactile_encoder", "G"))
+        LN.fork()
+        with LN.lane(0):
+            dhdv = layers.heads_backward(c["hv"], dov, FP.sub("visual_encoder", "G"))
+            dhv = torch.empty(B, 512, device=dov.device)
+            ops.B.dropout_reduce(dhdv, c["mv"], dhv, len(self.pass_v), B, 512, DROPOUT_P)
+            layers.encoder_trunk_backward(FP.sub("visual_encoder"), c["ev"], dhv, FP.sub("visual_encoder", "G"))
+        with LN.lane(1):
+            dhdt = layers.heads_backward(c["ht"], dot, FP.sub("tactile_encoder", "G"))
+            dht = torch.empty(B, 512, device=dov.device)
+            ops.B.dropout_reduce(dhdt, c["mt"], dht, len(self.pass_t), B, 512, DROPOUT_P)
+            layers.encoder_trunk_backward(FP.sub("tactile_encoder"), c["et"], dht, FP.sub("tactile_encoder", "G"))
         if self.use_pose:
             dhp = layers.heads_backward(c["hp"], dop, FP.sub("pose_encoder", "G"))
             layers.pose_encoder_trunk_backward(FP.sub("pose_encoder"), c["ep"], dhp, FP.sub("pose_encoder", "G"))
+        LN.join()
         handles += self._reduce_bucket(1)
-        dhv, dht = torch.empty(B, 512, device=dov.device), torch.empty(B, 512, device=dov.device)
-        ops.B.dropout_reduce(dhdv, c["mv"], dhv, len(self.pass_v), B, 512, DROPOUT_P)
-        ops.B.dropout_reduce(dhdt, c["mt"], dht, len(self.pass_t), B, 512, DROPOUT_P)
-        layers.encoder_trunk_backward(FP.sub("visual_encoder"), c["ev"], dhv, FP.sub("visual_encoder", "G"))
-        layers.encoder_trunk_backward(FP.sub("tactile_encoder"), c["et"], dht, FP.sub("tactile_encoder", "G"))
         handles += self._reduce_bucket(2)
         self.ctx = None
         return handles

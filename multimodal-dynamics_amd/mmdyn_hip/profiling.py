@@ -51,14 +51,21 @@ class TimedBackend:
             s.record()
             r = fn(*a, **k)
             e.record()
-            self.records.append((attr, _flops(attr, a), _bytes(a), s, e))
+            sig = tuple(x for x in a if isinstance(x, (int, bool))) if attr in ("igemm_nt", "wgrad_tn") else ()
+            self.records.append((attr, _flops(attr, a), _bytes(a), s, e, sig))
             return r
         return wrapped
 
     def summary(self):
         torch.cuda.synchronize()
         agg = collections.OrderedDict()
-        for name, fl, by, s, e in self.records:
+        self.by_shape = collections.OrderedDict()
+        for name, fl, by, s, e, sig in self.records:
+            if sig:
+                d2 = self.by_shape.setdefault((name,) + sig, {"calls": 0, "ms": 0.0, "flops": 0.0})
+                d2["calls"] += 1
+                d2["ms"] += s.elapsed_time(e)
+                d2["flops"] += fl
             d = agg.setdefault(name, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["calls"] += 1
             d["ms"] += s.elapsed_time(e)
@@ -75,4 +82,6 @@ def profile_step(fn):
         fn()
     finally:
         ops.set_backend(old)
-    return timed.summary()
+    out = timed.summary()
+    profile_step.by_shape = timed.by_shape
+    return out
