@@ -122,8 +122,13 @@ def main():
     inputs, targets = seeded_batch(args.batch, 1234 + rank)
     inputs, targets = [x.to(dev) for x in inputs], [x.to(dev) for x in targets]
 
-    def one_step():
+    def eager_step():
         return step.train_step(inputs, targets, KL_WEIGHT)
+
+    def one_step():
+        if args.no_graph:
+            return step.train_step(inputs, targets, KL_WEIGHT)
+        return step.train_step_graphed(inputs, targets, KL_WEIGHT)
 
     for _ in range(args.warmup):
         one_step()
@@ -146,7 +151,7 @@ def main():
     final_loss = float(loss)
 
     # per-kernel timing of one extra (untimed) step, HIP events on the launch stream
-    kern = profile_step(one_step)
+    kern = profile_step(eager_step)
     if world > 1:
         dist.barrier()
     if rank != 0:
@@ -170,6 +175,7 @@ def main():
         "config": {"workload": "cnn-mvae visuotactile+pose 64x64, bs=256 per GPU, fp32, seq_modeling train step "
                                "(7 subset ELBOs + backward + Adam), BASELINE configs[1]",
                    "global_batch": global_batch, "parallelism": f"dp{world}", "bn": "local",
+                   "launch": "eager" if args.no_graph else "hip_graph",
                    "final_loss": final_loss},
         "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,

@@ -139,9 +139,14 @@ int mmdyn_dropout_expand(const float* h, const uint8_t* masks, float* out, int P
                          float p_drop, void* stream);
 int mmdyn_dropout_reduce(const float* dout, const uint8_t* masks, float* dh, int P, int B, int H,
                          float p_drop, void* stream);
-/* keep-masks from a counter-based generator (throughput runs; parity runs inject masks) */
-int mmdyn_random_masks(uint8_t* masks, int64_t n, float p_drop, uint64_t seed, uint64_t offset, void* stream);
-int mmdyn_random_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* keep-masks / N(0,1) draws from a counter-based Philox-4x32-10 stream (throughput runs; parity runs inject
+ * tensors).  The stream position is offset + *offset_dev (offset_dev may be null): keeping the running position
+ * in device memory and bumping it with mmdyn_counter_add makes a captured HIP graph draw fresh numbers on replay. */
+int mmdyn_random_masks(uint8_t* masks, int64_t n, float p_drop, uint64_t seed, uint64_t offset,
+                       const uint64_t* offset_dev, void* stream);
+int mmdyn_random_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                        void* stream);
+int mmdyn_counter_add(uint64_t* counter, uint64_t inc, void* stream);
 /* out[c] (+)= sum_r x[r][c]   (bias gradients) */
 int mmdyn_colsum(const float* x, float* out, int rows, int C, int perm, float beta, void* stream);
 /* out = x * s[0], s in device memory (chain rule through a scalar loss term without a host sync) */

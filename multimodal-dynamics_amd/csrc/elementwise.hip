@@ -85,7 +85,8 @@ __device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 __global__ void random_masks_kernel(uint8_t* __restrict__ masks, int64_t n, float p_drop, uint64_t seed,
-                                    uint64_t offset) {
+                                    uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+  if (offset_dev) offset += offset_dev[0];
   const int64_t n4 = (n + 3) >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -99,7 +100,9 @@ __global__ void random_masks_kernel(uint8_t* __restrict__ masks, int64_t n, floa
   }
 }
 
-__global__ void random_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+__global__ void random_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset,
+                                     const uint64_t* __restrict__ offset_dev) {
+  if (offset_dev) offset += offset_dev[0];
   const int64_t n4 = (n + 3) >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -119,6 +122,10 @@ __global__ void random_normal_kernel(float* __restrict__ out, int64_t n, uint64_
       if (j < n) out[j] = z[k];
     }
   }
+}
+
+__global__ void counter_add_kernel(uint64_t* __restrict__ c, uint64_t inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += inc;
 }
 
 // out[c] (+)= sum_r x[r][c]; 32 channels per block, 8 row lanes
@@ -290,15 +297,22 @@ extern "C" int mmdyn_dropout_reduce(const float* dout, const uint8_t* masks, flo
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_random_masks(uint8_t* masks, int64_t n, float p_drop, uint64_t seed, uint64_t offset,
-                                  void* stream) {
+                                  const uint64_t* offset_dev, void* stream) {
   if (!masks) return MMDYN_ERR_NULL;
   hipLaunchKernelGGL(random_masks_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, masks, n, p_drop, seed,
-                     offset);
+                     offset, offset_dev);
   MMDYN_LAUNCH_CHECK();
 }
-extern "C" int mmdyn_random_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+extern "C" int mmdyn_random_normal(float* out, int64_t n, uint64_t seed, uint64_t offset,
+                                   const uint64_t* offset_dev, void* stream) {
   if (!out) return MMDYN_ERR_NULL;
-  hipLaunchKernelGGL(random_normal_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, out, n, seed, offset);
+  hipLaunchKernelGGL(random_normal_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, out, n, seed, offset,
+                     offset_dev);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_counter_add(uint64_t* counter, uint64_t inc, void* stream) {
+  if (!counter) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, ST, counter, inc);
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_colsum(const float* x, float* out, int rows, int C, int perm, float beta, void* stream) {

@@ -43,8 +43,9 @@ _SIGNATURES = {
     "mmdyn_act_bwd": "ppp" + "l" + "i" + "p",
     "mmdyn_dropout_expand": "ppp" + "iii" + "f" + "p",
     "mmdyn_dropout_reduce": "ppp" + "iii" + "f" + "p",
-    "mmdyn_random_masks": "p" + "l" + "f" + "QQ" + "p",
-    "mmdyn_random_normal": "p" + "l" + "QQ" + "p",
+    "mmdyn_random_masks": "p" + "l" + "f" + "QQ" + "pp",
+    "mmdyn_random_normal": "p" + "l" + "QQ" + "pp",
+    "mmdyn_counter_add": "p" + "Q" + "p",
     "mmdyn_colsum": "pp" + "iii" + "f" + "p",
     "mmdyn_scale_dev": "ppp" + "l" + "p",
     "mmdyn_sum_blocks": "pp" + "i" + "l" + "p",

@@ -136,6 +136,8 @@ class MVAEStep:
         self.partials = torch.zeros(8, device=dev)
         self.last = {}
         self.lanes = _Lanes(dev, two_lanes)
+        self._capturing = False
+        self._graph = None
 
     # ------------------------------------------------------------------------------------------
     def _noise(self):
@@ -155,6 +157,7 @@ class MVAEStep:
             if b:
                 mt.append(n.keep_mask((B, 512), dev))
             eps.append(n.eps((B, self.L), dev))
+        n.commit()
         return torch.stack(eps), torch.stack(mv), torch.stack(mt)
 
     def _buffers(self, prefix):
@@ -317,7 +320,7 @@ class MVAEStep:
         return handles
 
     def _reduce_bucket(self, i):
-        if self.world <= 1:
+        if self.world <= 1 or self._capturing:
             return []
         import torch.distributed as dist
         lo = 0 if i == 0 else self.params.bucket_bounds[i - 1]
@@ -337,6 +340,48 @@ class MVAEStep:
         handles = self.backward()
         self.optimizer_step(handles)
         return loss
+
+    # ------------------------------------------------------------------------------------------
+    def train_step_graphed(self, inputs, targets, kl_weight):
+        """Same as :meth:`train_step`, replayed from a HIP graph: the ~330 kernel launches of a step (both lanes)
+        are captured once per (batch shape, kl_weight) and re-issued with one graph launch, which removes the host
+        launch path from the critical path.  Inputs are copied into the graph's static buffers; random draws
+        advance through a device-side counter, Adam's step count lives on the device, so replays are real steps.
+        With more than one rank the gradient all-reduce and Adam run after the graph (one bucket)."""
+        key = (tuple(tuple(x.shape) for x in inputs), float(kl_weight))
+        if self._graph is None or self._graph[0] != key:
+            self._static_in = [x.clone() for x in inputs]
+            self._static_tg = [x.clone() for x in targets]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                      # warm-up outside capture (allocator, lazy init)
+                self.train_step(self._static_in, self._static_tg, kl_weight)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            self._capturing = True
+            try:
+                with torch.cuda.graph(g):
+                    self.forward(self._static_in, self._static_tg, kl_weight, train=True)
+                    self.backward()
+                    if self.world <= 1:
+                        self.optimizer_step(())
+            finally:
+                self._capturing = False
+            self._graph = (key, g)
+            # the warm-up above WAS this call's optimiser step (the capture itself executes nothing)
+            return self.loss
+        for dst, src in zip(self._static_in, inputs):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        for dst, src in zip(self._static_tg, targets):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        self._graph[1].replay()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.params.grad, group=self.pg)
+            self.optimizer_step(())
+        return self.loss
 
     @torch.no_grad()
     def eval_step(self, inputs, targets, kl_weight):

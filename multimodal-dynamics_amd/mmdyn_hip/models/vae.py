@@ -106,22 +106,37 @@ def mlp(sizes, activation="ReLU", output_activation="Identity"):
 # noise sources
 # ------------------------------------------------------------------------------------------------
 class NoiseSource:
-    """On-device Philox stream (mmdyn_random_normal / mmdyn_random_masks)."""
+    """On-device Philox stream (mmdyn_random_normal / mmdyn_random_masks).
+
+    The stream position is ``offset`` (host, advanced per draw) + ``base`` (a device counter).  Eager code only
+    moves ``offset``.  A captured HIP graph bakes its host offsets in; :meth:`commit` then enqueues a device-side
+    bump of ``base`` by everything drawn since the last commit, so every replay draws fresh numbers."""
 
     def __init__(self, seed=0):
-        self.seed, self.offset = int(seed), 0
+        self.seed, self.offset, self.base, self._mark = int(seed), 0, None, 0
+
+    def _base(self, device):
+        if self.base is None or self.base.device != device:
+            self.base = torch.zeros(1, dtype=torch.int64, device=device)
+        return self.base
 
     def eps(self, shape, device):
         out = torch.empty(shape, device=device, dtype=torch.float32)
-        ops.B.random_normal(out, self.seed, self.offset)
+        ops.B.random_normal(out, self.seed, self.offset, self._base(device))
         self.offset += (out.numel() + 3) // 4
         return out
 
     def keep_mask(self, shape, device):
         out = torch.empty(shape, device=device, dtype=torch.uint8)
-        ops.B.random_masks(out, DROPOUT_P, self.seed ^ 0x5DEECE66D, self.offset)
+        ops.B.random_masks(out, DROPOUT_P, self.seed ^ 0x5DEECE66D, self.offset, self._base(device))
         self.offset += (out.numel() + 3) // 4
         return out
+
+    def commit(self):
+        """Move the draws made since the previous commit from the host offset into the device counter."""
+        if self.base is not None and self.offset > self._mark:
+            ops.B.counter_add(self.base, self.offset - self._mark)
+            self.offset = self._mark
 
 
 class InjectedNoise:
@@ -139,6 +154,9 @@ class InjectedNoise:
         m = self._masks.pop(0)
         assert tuple(m.shape) == tuple(shape), (m.shape, shape)
         return m.to(device=device, dtype=torch.uint8).contiguous()
+
+    def commit(self):
+        pass
 
 
 def _noise_of(module):

@@ -146,12 +146,16 @@ class HipBackend:
         check(self.lib.mmdyn_dropout_reduce(_ptr(dout), _ptr(masks, torch.uint8), _ptr(dh), P, B, H, p_drop,
                                             _stream()), "mmdyn_dropout_reduce")
 
-    def random_masks(self, masks, p_drop, seed, offset):
-        check(self.lib.mmdyn_random_masks(_ptr(masks, torch.uint8), masks.numel(), p_drop, seed, offset, _stream()),
-              "mmdyn_random_masks")
+    def random_masks(self, masks, p_drop, seed, offset, offset_dev=None):
+        check(self.lib.mmdyn_random_masks(_ptr(masks, torch.uint8), masks.numel(), p_drop, seed, offset,
+                                          _ptr(offset_dev, torch.int64), _stream()), "mmdyn_random_masks")
 
-    def random_normal(self, out, seed, offset):
-        check(self.lib.mmdyn_random_normal(_ptr(out), out.numel(), seed, offset, _stream()), "mmdyn_random_normal")
+    def random_normal(self, out, seed, offset, offset_dev=None):
+        check(self.lib.mmdyn_random_normal(_ptr(out), out.numel(), seed, offset, _ptr(offset_dev, torch.int64),
+                                           _stream()), "mmdyn_random_normal")
+
+    def counter_add(self, counter, inc):
+        check(self.lib.mmdyn_counter_add(_ptr(counter, torch.int64), inc, _stream()), "mmdyn_counter_add")
 
     def colsum(self, x, out, rows, C, perm, beta):
         check(self.lib.mmdyn_colsum(_ptr(x), _ptr(out), rows, C, perm, float(beta), _stream()), "mmdyn_colsum")

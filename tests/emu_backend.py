@@ -252,11 +252,16 @@ class EmuBackend:
     def dropout_reduce(self, dout, masks, dh, P, B, H, p):
         dh.reshape(B, H).copy_((dout.reshape(P, B, H) * (masks.reshape(P, B, H).float() / (1 - p))).sum(0))
 
-    def random_masks(self, masks, p, seed, offset):
+    def counter_add(self, counter, inc):
+        counter += inc
+
+    def random_masks(self, masks, p, seed, offset, offset_dev=None):
+        offset += 0 if offset_dev is None else int(offset_dev)
         g = torch.Generator().manual_seed(seed + offset)
         masks.copy_((torch.rand(masks.shape, generator=g) >= p).to(torch.uint8))
 
-    def random_normal(self, out, seed, offset):
+    def random_normal(self, out, seed, offset, offset_dev=None):
+        offset += 0 if offset_dev is None else int(offset_dev)
         g = torch.Generator().manual_seed(seed + offset)
         out.copy_(torch.randn(out.shape, generator=g))
 
