@@ -35,10 +35,18 @@ struct IgemmGeom {
   int tiles_per_group; // ceil(Bg*Hr*Wr / BM)
 };
 
-constexpr int BK = 32;
-constexpr int LDS_LD = 36;
+#ifndef IG_BK
+#define IG_BK 32
+#endif
+#ifndef IG_DBUF
+#define IG_DBUF 0
+#endif
+constexpr int BK = IG_BK;           // K-step (channels of one tap per stage)
+constexpr int LDS_LD = BK + 4;      // row stride: one 16-byte pad slot keeps ds_read_b128 conflict-free
+constexpr int GRANS = BK / 4;       // 16-byte granules per tile row
+constexpr int ROWS_PER_PASS = 256 / GRANS;
 
-template <int BM, int BN, int WM, int WN>
+template <int MODE, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__ A,
                                                        const float* __restrict__ Bp,
                                                        const float* __restrict__ bias,
@@ -49,12 +57,15 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
   static_assert(WAVES_N * WAVES_M == 4, "4 waves per block");
-  constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
+  constexpr int A_LOADS = BM / ROWS_PER_PASS, B_LOADS = BN / ROWS_PER_PASS;
+  static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile smaller than one load pass");
+  constexpr int STAGE = (BM + BN) * LDS_LD;
+  constexpr int NSTAGE = IG_DBUF ? 2 : 1;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* As = reinterpret_cast<float*>(smem);            // [BM][36]
-  float* Bs = As + BM * LDS_LD;                          // [BN][36]
-  int* rowinfo = reinterpret_cast<int*>(Bs + BN * LDS_LD);  // [BM][4]: b, y0, x0, out offset (-1: none)
+  float* As = reinterpret_cast<float*>(smem);            // stage s: [BM][LDS_LD] then [BN][LDS_LD]
+  float* Bs = As + BM * LDS_LD;
+  int* rowinfo = reinterpret_cast<int*>(As + NSTAGE * STAGE);  // [BM][4]: b, y0, x0, out offset (-1: none)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -86,11 +97,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   }
   __syncthreads();
 
-  const int lrow = tid >> 3, gran = tid & 7;
+  const int lrow = tid / GRANS, gran = tid % GRANS;
   int rb[A_LOADS], ry[A_LOADS], rx[A_LOADS];
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) {
-    int r = lrow + 32 * i;
+    int r = lrow + ROWS_PER_PASS * i;
     rb[i] = rowinfo[r * 4 + 0];
     ry[i] = rowinfo[r * 4 + 1];
     rx[i] = rowinfo[r * 4 + 2];
@@ -102,46 +113,62 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   const int s_begin = split * per_split;
   const int s_end = min(total_steps, s_begin + per_split);
 
+  // Branch-free operand fetch: an out-of-image (or out-of-range) row reads a valid dummy address and is zeroed by
+  // a select, so one K-step is a single basic block and the scheduler can slot the address arithmetic and the
+  // global loads between the 64-cycle MFMAs instead of in front of them.
   f32x4 ra[A_LOADS], rbv[B_LOADS];
-  auto gload = [&](int s) {
-    int t = s / cin_steps;
-    int c0 = (s - t * cin_steps) * BK + gran * 4;
+  unsigned okmask = 0;
+  int tap = s_begin / cin_steps;            // running (tap, channel-step) position of the NEXT fetch
+  int cstep = s_begin - tap * cin_steps;
+  auto gload = [&]() {
+    const int c0 = cstep * BK + gran * 4;
     int dh = 0, dw = 0, wi = 0;
-    if (g.mode == MMDYN_CONV) {
-      dh = t >> 2;
-      dw = t & 3;
-      wi = t;
-    } else if (g.mode == MMDYN_TCONV_S2P1) {
-      int th = t >> 1, tw = t & 1;
+    if (MODE == MMDYN_CONV) {
+      dh = tap >> 2;
+      dw = tap & 3;
+      wi = tap;
+    } else if (MODE == MMDYN_TCONV_S2P1) {
+      const int th = tap >> 1, tw = tap & 1;
       dh = ph - th;
       dw = pw - tw;
       wi = (1 - ph + 2 * th) * 4 + (1 - pw + 2 * tw);
     }
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-      int y = ry[i] + dh, x = rx[i] + dw;
-      bool ok = (rb[i] >= 0) && ((unsigned)y < (unsigned)g.Hi) && ((unsigned)x < (unsigned)g.Wi);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const float* p = A + ((size_t)((rb[i] * g.Hi + y) * g.Wi + x)) * g.Cin + c0;
-        v = *reinterpret_cast<const f32x4*>(p);
-      }
-      ra[i] = v;
+      const int y = ry[i] + dh, x = rx[i] + dw;
+      const bool ok = (rb[i] >= 0) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
+      const int pix = ok ? (rb[i] * g.Hi + y) * g.Wi + x : 0;
+      ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)pix * g.Cin + c0);
+      okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));   // consumed only when the tile is stored
     }
 #pragma unroll
     for (int j = 0; j < B_LOADS; ++j) {
-      int n = n0 + lrow + 32 * j;
-      const float* p = Bp + ((size_t)wi * g.N + n) * g.Cin + c0;
-      rbv[j] = *reinterpret_cast<const f32x4*>(p);
+      const int n = n0 + lrow + ROWS_PER_PASS * j;
+      rbv[j] = *reinterpret_cast<const f32x4*>(Bp + ((size_t)wi * g.N + n) * g.Cin + c0);
     }
+    // advance; the fetch issued during the last K-step is a harmless repeat of a valid tile (keeps the loop
+    // body free of branches)
+    const bool last = (tap * cin_steps + cstep + 1 >= s_end);
+    const bool wrap = (cstep + 1 == cin_steps);
+    const int ncstep = wrap ? 0 : cstep + 1;
+    const int ntap = tap + (wrap ? 1 : 0);
+    cstep = last ? cstep : ncstep;
+    tap = last ? tap : ntap;
   };
-  auto lds_store = [&]() {
+  auto lds_store = [&](int stage) {
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i)
-      *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * LDS_LD + gran * 4]) = ra[i];
+    for (int i = 0; i < A_LOADS; ++i) {
+      const bool ok = (okmask >> i) & 1u;
+      f32x4 v;
+      v[0] = ok ? ra[i][0] : 0.f;
+      v[1] = ok ? ra[i][1] : 0.f;
+      v[2] = ok ? ra[i][2] : 0.f;
+      v[3] = ok ? ra[i][3] : 0.f;
+      *reinterpret_cast<f32x4*>(&As[stage * STAGE + (lrow + ROWS_PER_PASS * i) * LDS_LD + gran * 4]) = v;
+    }
 #pragma unroll
     for (int j = 0; j < B_LOADS; ++j)
-      *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * j) * LDS_LD + gran * 4]) = rbv[j];
+      *reinterpret_cast<f32x4*>(&Bs[stage * STAGE + (lrow + ROWS_PER_PASS * j) * LDS_LD + gran * 4]) = rbv[j];
   };
 
   f32x16 acc[MT][NT];
@@ -154,21 +181,24 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
 
   const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
   if (s_begin < s_end) {
-    gload(s_begin);
-    lds_store();
+    gload();
+    lds_store(0);
     __syncthreads();
+    int cur = 0;
     for (int s = s_begin; s < s_end; ++s) {
-      const bool more = (s + 1 < s_end);
-      if (more) gload(s + 1);
+      gload();
+      __builtin_amdgcn_sched_barrier(0);   // keep the fetch of step s+1 in front of the MFMAs of step s
+      const float* Ac = As + cur * STAGE;
+      const float* Bc = Bs + cur * STAGE;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < BK / 8; ++q) {
         f32x4 af[MT], bf[NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          af[mt] = *reinterpret_cast<const f32x4*>(&As[(wm * WM + mt * 32) * LDS_LD + frag_off + q * 8]);
+          af[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * WM + mt * 32) * LDS_LD + frag_off + q * 8]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          bf[nt] = *reinterpret_cast<const f32x4*>(&Bs[(wn * WN + nt * 32) * LDS_LD + frag_off + q * 8]);
+          bf[nt] = *reinterpret_cast<const f32x4*>(&Bc[(wn * WN + nt * 32) * LDS_LD + frag_off + q * 8]);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -177,9 +207,14 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
             for (int nt = 0; nt < NT; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
       }
-      __syncthreads();
-      if (more) {
-        lds_store();
+      if (IG_DBUF) {
+        // two LDS stages: the next tile goes to the other stage, one barrier per K-step
+        lds_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+      } else {
+        __syncthreads();
+        lds_store(0);
         __syncthreads();
       }
     }
@@ -290,15 +325,23 @@ static void pick_tile(int N, int rows_per_group, int G, int ncls, int splitk, in
   *bn = cand[best][1];
 }
 
+template <int MODE, int BM, int BN, int WM, int WN>
+static int launch_m(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats,
+                    float* ws, IgemmGeom g, hipStream_t st) {
+  g.tiles_per_group = ceil_div(g.Bg * g.Hr * g.Wr, BM);
+  dim3 grid(g.G * g.tiles_per_group, g.N / BN, g.nclasses * g.splitk);
+  size_t smem = (size_t)(IG_DBUF ? 2 : 1) * (BM + BN) * LDS_LD * sizeof(float) + (size_t)BM * 4 * sizeof(int);
+  hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN>), grid, dim3(256), smem, st, A, Bp, bias, C, C_act,
+                     stats, ws, g);
+  MMDYN_LAUNCH_CHECK();
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats,
                   float* ws, IgemmGeom g, hipStream_t st) {
-  g.tiles_per_group = ceil_div(g.Bg * g.Hr * g.Wr, BM);
-  dim3 grid(g.G * g.tiles_per_group, g.N / BN, g.nclasses * g.splitk);
-  size_t smem = (size_t)(BM + BN) * LDS_LD * sizeof(float) + (size_t)BM * 4 * sizeof(int);
-  hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN>), grid, dim3(256), smem, st, A, Bp, bias, C, C_act,
-                     stats, ws, g);
-  MMDYN_LAUNCH_CHECK();
+  if (g.mode == MMDYN_DENSE) return launch_m<MMDYN_DENSE, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
+  if (g.mode == MMDYN_CONV) return launch_m<MMDYN_CONV, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
+  return launch_m<MMDYN_TCONV_S2P1, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
 }
 
 }  // namespace
@@ -320,7 +363,7 @@ extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias
                               int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
                               void* stream) {
   if (!A || !Bp || !C) return MMDYN_ERR_NULL;
-  if (Cin <= 0 || N <= 0 || Cin % 32 || N % 32 || G <= 0 || Bg <= 0 || ldc < N) return MMDYN_ERR_SHAPE;
+  if (Cin <= 0 || N <= 0 || Cin % BK || N % 32 || G <= 0 || Bg <= 0 || ldc < N) return MMDYN_ERR_SHAPE;
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && (mode != MMDYN_DENSE || !ws || stats)) return MMDYN_ERR_SHAPE;
   IgemmGeom g{};

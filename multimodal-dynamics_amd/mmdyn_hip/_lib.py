@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmdyn_hip.so")
+LIB_PATH = os.environ.get("MMDYN_HIP_LIB") or os.path.join(_HERE, "libmmdyn_hip.so")   # override: kernel experiments
 
 _P, _I, _L, _F, _Q = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
 
