@@ -151,7 +151,10 @@ def main():
     final_loss = float(loss)
 
     # per-kernel timing of one extra (untimed) step, HIP events on the launch stream
+    # (one lane, eager launches: per-kernel durations are then not inflated by the other lane's kernels)
+    lanes_on, step.lanes.on = step.lanes.on, False
     kern = profile_step(eager_step)
+    step.lanes.on = lanes_on
     if world > 1:
         dist.barrier()
     if rank != 0:

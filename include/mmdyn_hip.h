@@ -39,6 +39,10 @@ extern "C" {
 #define MMDYN_DENSE 0          /* plain rows x Cin matrix (nn.Linear, and the col-matrix GEMMs) */
 #define MMDYN_CONV 1           /* gather form: out(r,c) <- in(r*s+o+kh, c*s+o+kw), 16 taps */
 #define MMDYN_TCONV_S2P1 2     /* transposed k4 s2 p1, four output-parity classes of 4 taps each */
+#define MMDYN_IM2COL3 3        /* k4 s2 p1 window of an NCHW 3-channel tensor gathered on the fly: virtual Cin = 64
+                                  (k = ci*16 + kh*4 + kw, 48 real + 16 zero); rows = output pixels.  Lowers
+                                  nn.Conv2d(3,32,4,2,1) (vae.py:198) and the backward of nn.ConvTranspose2d(32,3,4,2,1)
+                                  (vae.py:277) onto the MFMA GEMMs without materialising an im2col matrix */
 
 const char* mmdyn_version(void);
 
@@ -103,6 +107,10 @@ int mmdyn_im2col_nchw3(const float* x, float* col, int Bt, int H, int W, void* s
  *   tap_major=0: col column = c*16 + tap and the output is NCHW [Bt][C][Ho][Wo] (logits). */
 int mmdyn_col2im_k4(const float* col, float* out, int Bt, int Hi, int Wi, int Ho, int Wo, int C,
                     int ldcol, int stride, int pad, int tap_major, void* stream);
+
+/* nn.ConvTranspose2d(32, 3, 4, 2, 1) forward (vae.py:277) as a direct LDS-tiled VALU kernel: a is NHWC
+ * [Bt][Hi][Wi][32], w the reference's [32][3][4][4], out NCHW logits [Bt][3][2Hi][2Wi]; Hi, Wi % 16 == 0. */
+int mmdyn_tconv_out3_fwd(const float* a, const float* w, float* out, int Bt, int Hi, int Wi, void* stream);
 
 /* ---- train-mode BatchNorm2d + Swish, channels-last, per group (vae.py:201-208, 269-276) ----- */
 /* column sums of y and y*y over row chunks -> partial[G][T][2][C], T = mmdyn_colstats_tiles(rows_per_group) */

@@ -133,13 +133,33 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       dw = pw - tw;
       wi = (1 - ph + 2 * th) * 4 + (1 - pw + 2 * tw);
     }
+    if (MODE == MMDYN_IM2COL3) {
+      // A is the reference's NCHW 3-channel image; virtual K index k = ci*16 + kh*4 + kw (48 real + 16 zero):
+      // this granule holds the 4 kw taps of (ci, kh) for the row's output pixel (k4 s2 p1 window)
+      const int ci = c0 >> 4, kh = (c0 >> 2) & 3;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        const int y = 2 * ry[i] - 1 + kh, x0 = 2 * rx[i] - 1;
+        const bool okr = (rb[i] >= 0) & (ci < 3) & ((unsigned)y < (unsigned)g.Hi);
+        const int base = okr ? ((rb[i] * 3 + ci) * g.Hi + y) * g.Wi : 0;
+        unsigned m = 0;
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+          const int xx = x0 + kw;
+          const bool ok = okr & ((unsigned)xx < (unsigned)g.Wi);
+          ra[i][kw] = A[(size_t)base + (ok ? xx : 0)];
+          m |= ok ? (1u << kw) : 0u;
+        }
+        okmask = (okmask & ~(0xFu << (4 * i))) | (m << (4 * i));
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const int y = ry[i] + dh, x = rx[i] + dw;
       const bool ok = (rb[i] >= 0) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
       const int pix = ok ? (rb[i] * g.Hi + y) * g.Wi + x : 0;
       ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)pix * g.Cin + c0);
-      okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));   // consumed only when the tile is stored
+      okmask = ok ? (okmask | (0xFu << (4 * i))) : (okmask & ~(0xFu << (4 * i)));   // consumed at lds_store
     }
 #pragma unroll
     for (int j = 0; j < B_LOADS; ++j) {
@@ -158,12 +178,12 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   auto lds_store = [&](int stage) {
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-      const bool ok = (okmask >> i) & 1u;
+      const unsigned m = okmask >> (4 * i);
       f32x4 v;
-      v[0] = ok ? ra[i][0] : 0.f;
-      v[1] = ok ? ra[i][1] : 0.f;
-      v[2] = ok ? ra[i][2] : 0.f;
-      v[3] = ok ? ra[i][3] : 0.f;
+      v[0] = (m & 1u) ? ra[i][0] : 0.f;
+      v[1] = (m & 2u) ? ra[i][1] : 0.f;
+      v[2] = (m & 4u) ? ra[i][2] : 0.f;
+      v[3] = (m & 8u) ? ra[i][3] : 0.f;
       *reinterpret_cast<f32x4*>(&As[stage * STAGE + (lrow + ROWS_PER_PASS * i) * LDS_LD + gran * 4]) = v;
     }
 #pragma unroll
@@ -341,6 +361,7 @@ static int launch(const float* A, const float* Bp, const float* bias, float* C, 
                   float* ws, IgemmGeom g, hipStream_t st) {
   if (g.mode == MMDYN_DENSE) return launch_m<MMDYN_DENSE, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
   if (g.mode == MMDYN_CONV) return launch_m<MMDYN_CONV, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
+  if (g.mode == MMDYN_IM2COL3) return launch_m<MMDYN_IM2COL3, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
   return launch_m<MMDYN_TCONV_S2P1, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
 }
 
@@ -397,6 +418,13 @@ extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias
     g.rs = stride;
     g.ro = offset;
     g.ntaps = 16;
+  } else if (mode == MMDYN_IM2COL3) {
+    if (Hi != 2 * Ho || Wi != 2 * Wo || Cin != 64 || splitk != 1) return MMDYN_ERR_SHAPE;
+    g.Hr = Ho;
+    g.Wr = Wo;
+    g.rs = 1;
+    g.ro = 0;
+    g.ntaps = 1;
   } else if (mode == MMDYN_TCONV_S2P1) {
     if (Ho != 2 * Hi || Wo != 2 * Wi) return MMDYN_ERR_SHAPE;
     g.Hr = Hi;
@@ -410,7 +438,8 @@ extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias
     return MMDYN_ERR_SHAPE;
   }
   const int64_t rows = (int64_t)G * Bg * g.Hr * g.Wr;
-  if ((int64_t)G * Bg * Hi * Wi * Cin >= (1LL << 31) || (int64_t)G * Bg * Ho * Wo * ldc >= (1LL << 31))
+  if ((int64_t)G * Bg * Hi * Wi * (mode == MMDYN_IM2COL3 ? 3 : Cin) >= (1LL << 31) ||
+      (int64_t)G * Bg * Ho * Wo * ldc >= (1LL << 31))
     return MMDYN_ERR_RANGE;
   g.rows_total = (int)rows;
   hipStream_t st = (hipStream_t)stream;

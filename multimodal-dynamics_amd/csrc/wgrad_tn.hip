@@ -62,52 +62,80 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
   const int row_begin = chunk * g.rows_per_chunk;
   const int row_end = min(g.rows, row_begin + g.rows_per_chunk);
 
+  // Branch-free fetch (same idea as igemm_nt): rows past the chunk or outside the image read a valid dummy
+  // address and are zeroed when the tile is written to LDS; pixel decode uses a float reciprocal (rows < 2^23).
+  const float inv_hw = 1.0f / (float)HWr, inv_w = 1.0f / (float)g.Wr;
+  auto fdiv = [](int n, int d, float inv, int& q, int& r) {
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { q -= 1; r += d; }
+    if (r >= d) { q += 1; r -= d; }
+  };
   f32x4 rd[D_LOADS], rg[G_LOADS];
+  unsigned okd = 0, okg = 0;   // okg: 4 bits per load (per-element validity in the im2col mode)
   auto gload = [&](int r0) {
 #pragma unroll
     for (int i = 0; i < D_LOADS; ++i) {
-      int idx = tid + 256 * i;
-      int r = idx / DV, v = idx - r * DV;
-      int row = r0 + r;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (row < row_end) val = *reinterpret_cast<const f32x4*>(D + (size_t)row * g.Cd + cd0 + v * 4);
-      rd[i] = val;
+      const int idx = tid + 256 * i;
+      const int r = idx / DV, v = idx - r * DV;
+      const int row = r0 + r;
+      const bool ok = row < row_end;
+      rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
+      okd = ok ? (okd | (1u << i)) : (okd & ~(1u << i));
     }
 #pragma unroll
     for (int i = 0; i < G_LOADS; ++i) {
-      int idx = tid + 256 * i;
-      int r = idx / GV, v = idx - r * GV;
-      int row = r0 + r;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (row < row_end) {
-        size_t pix;
-        bool ok = true;
-        if (g.mode == MMDYN_CONV) {
-          int b = row / HWr;
-          int p = row - b * HWr;
-          int rr = p / g.Wr;
-          int cc = p - rr * g.Wr;
-          int y = rr * g.rs + g.ro + dh, x = cc * g.rs + g.ro + dw;
-          ok = ((unsigned)y < (unsigned)g.Hi) && ((unsigned)x < (unsigned)g.Wi);
-          pix = (size_t)((b * g.Hi + y) * g.Wi + x);
-        } else {
-          pix = (size_t)row;
+      const int idx = tid + 256 * i;
+      const int r = idx / GV, v = idx - r * GV;
+      const int row = r0 + r;
+      bool ok = row < row_end;
+      int pix = row;
+      if (g.mode == MMDYN_IM2COL3) {
+        // G row = im2col of the NCHW 3-channel tensor: columns ci*16 + kh*4 + kw (48 real + 16 zero)
+        int bb, p, rr, cc;
+        fdiv(row, HWr, inv_hw, bb, p);
+        fdiv(p, g.Wr, inv_w, rr, cc);
+        const int k0 = cg0 + v * 4, ci = k0 >> 4, kh = (k0 >> 2) & 3;
+        const int y = 2 * rr - 1 + kh, x0 = 2 * cc - 1;
+        const bool okr = ok & (ci < 3) & ((unsigned)y < (unsigned)g.Hi);
+        const int base = okr ? ((bb * 3 + ci) * g.Hi + y) * g.Wi : 0;
+        unsigned m = 0;
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+          const int xx = x0 + kw;
+          const bool okk = okr & ((unsigned)xx < (unsigned)g.Wi);
+          rg[i][kw] = Gt[(size_t)base + (okk ? xx : 0)];
+          m |= okk ? (1u << kw) : 0u;
         }
-        if (ok) val = *reinterpret_cast<const f32x4*>(Gt + pix * g.Cg + cg0 + v * 4);
+        okg = (okg & ~(0xFu << (4 * i))) | (m << (4 * i));
+        continue;
       }
-      rg[i] = val;
+      if (g.mode == MMDYN_CONV) {
+        int bb, p, rr, cc;
+        fdiv(row, HWr, inv_hw, bb, p);
+        fdiv(p, g.Wr, inv_w, rr, cc);
+        const int y = rr * g.rs + g.ro + dh, x = cc * g.rs + g.ro + dw;
+        ok = ok & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
+        pix = (bb * g.Hi + y) * g.Wi + x;
+      }
+      rg[i] = *reinterpret_cast<const f32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
+      okg = ok ? (okg | (0xFu << (4 * i))) : (okg & ~(0xFu << (4 * i)));
     }
   };
   auto lds_store = [&]() {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < D_LOADS; ++i) {
-      int idx = tid + 256 * i;
-      reinterpret_cast<f32x4*>(Ds)[idx] = rd[i];
-    }
+    for (int i = 0; i < D_LOADS; ++i)
+      reinterpret_cast<f32x4*>(Ds)[tid + 256 * i] = ((okd >> i) & 1u) ? rd[i] : zero;
 #pragma unroll
     for (int i = 0; i < G_LOADS; ++i) {
-      int idx = tid + 256 * i;
-      reinterpret_cast<f32x4*>(Gs)[idx] = rg[i];
+      const unsigned m = okg >> (4 * i);
+      f32x4 v;
+      v[0] = (m & 1u) ? rg[i][0] : 0.f;
+      v[1] = (m & 2u) ? rg[i][1] : 0.f;
+      v[2] = (m & 4u) ? rg[i][2] : 0.f;
+      v[3] = (m & 8u) ? rg[i][3] : 0.f;
+      reinterpret_cast<f32x4*>(Gs)[tid + 256 * i] = v;
     }
   };
 
@@ -125,8 +153,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
     lds_store();
     __syncthreads();
     for (int r0 = row_begin; r0 < row_end; r0 += RK) {
-      const bool more = (r0 + RK < row_end);
-      if (more) gload(r0 + RK);
+      gload(r0 + RK);                      // past the chunk end every row is masked: a harmless dummy fetch
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kk = wk * KPW; kk < (wk + 1) * KPW; ++kk) {
         float af[DT], bf[GT];
@@ -141,10 +169,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
       }
       __syncthreads();
-      if (more) {
-        lds_store();
-        __syncthreads();
-      }
+      lds_store();
+      __syncthreads();
     }
   }
 
@@ -229,11 +255,13 @@ extern "C" int mmdyn_wgrad_tn(const float* D, const float* Gt, float* partial, i
                               void* stream) {
   if (!D || !Gt || !partial) return MMDYN_ERR_NULL;
   if (Cd % 32 || Cg % 32 || Cd <= 0 || Cg <= 0 || chunks < 4 || chunks % 4) return MMDYN_ERR_SHAPE;
-  if (mode != MMDYN_DENSE && mode != MMDYN_CONV) return MMDYN_ERR_SHAPE;
+  if (mode != MMDYN_DENSE && mode != MMDYN_CONV && mode != MMDYN_IM2COL3) return MMDYN_ERR_SHAPE;
+  if (mode == MMDYN_IM2COL3 && (Cg != 64 || Hi != 2 * Hr || Wi != 2 * Wr)) return MMDYN_ERR_SHAPE;
   WgradGeom g{};
   g.mode = mode;
   const int64_t rows = (int64_t)Bt * Hr * Wr;
-  if (rows * Cd >= (1LL << 31) || (int64_t)Bt * Hi * Wi * Cg >= (1LL << 31)) return MMDYN_ERR_RANGE;
+  if (rows * Cd >= (1LL << 31) || (int64_t)Bt * Hi * Wi * (mode == MMDYN_IM2COL3 ? 3 : Cg) >= (1LL << 31))
+    return MMDYN_ERR_RANGE;
   g.rows = (int)rows;
   g.Hr = Hr;
   g.Wr = Wr;

@@ -17,7 +17,7 @@ Reference structure restated here (file:line relative to /root/reference/mmdyn/p
 import torch
 
 from . import ops
-from .ops import ACT_NONE, ACT_SWISH, ACT_RELU, DENSE, CONV, TCONV_S2P1
+from .ops import ACT_NONE, ACT_SWISH, ACT_RELU, DENSE, CONV, TCONV_S2P1, IM2COL3
 from .models.shapes import BN_EPS, BN_MOMENTUM, FEAT
 
 
@@ -181,10 +181,9 @@ def encoder_trunk_forward(P, buf, x, G=1, repeat=1):
     Bg = Bt // G
     c = {"Bt": Bt, "G": G, "Bg": Bg}
     W1p = repack(P["conv_net.0.weight"], 32, 48, 32, 64, 0)                   # [32][64], cols 48.. zero
-    col1 = _new(x, Bt * 1024, 64)
-    ops.B.im2col_nchw3(x, col1, Bt, 64, 64)
     u1, a1 = _new(x, Bt * 1024, 32), _new(x, Bt * 1024, 32)
-    ops.B.igemm_nt(col1, W1p, None, u1, a1, None, None, DENSE, 1, Bt * 1024, 1, 1, 64, 1, 1, 32, 32, 1, 0,
+    # first layer: the k4 s2 p1 window of the NCHW image is gathered on the fly (no im2col matrix in HBM)
+    ops.B.igemm_nt(x, W1p, None, u1, a1, None, None, IM2COL3, 1, Bt, 64, 64, 64, 32, 32, 32, 32, 1, 0,
                    ACT_SWISH, 1)
     bn2, bn3, bn4 = (_bn_of(P, buf, k) for k in ENC_BN)
     y2, st, T = conv_like(a1, pack_conv(P["conv_net.2.weight"], False), CONV, G, Bg, 32, 32, 16, 64, 2, -1, True)
@@ -195,7 +194,7 @@ def encoder_trunk_forward(P, buf, x, G=1, repeat=1):
     a4, m4, r4 = bn_swish_from_partials(y4, st, T, bn4, G, Bg * 25, 256, repeat)
     Wf = repack(P["fc_net.0.weight"], 512, FEAT, 512, FEAT, 2)               # columns -> hw*256+c
     u5, h = dense(a4, Wf, P["fc_net.0.bias"], Bt, FEAT, 512, ACT_SWISH, want_act=True)
-    c.update(col1=col1, u1=u1, a1=a1, y2=y2, a2=a2, m2=m2, r2=r2, y3=y3, a3=a3, m3=m3, r3=r3, y4=y4, a4=a4,
+    c.update(x=x, u1=u1, a1=a1, y2=y2, a2=a2, m2=m2, r2=r2, y3=y3, a3=a3, m3=m3, r3=r3, y4=y4, a4=a4,
              m4=m4, r4=r4, u5=u5, bn=(bn2, bn3, bn4))
     return h, c
 
@@ -225,7 +224,7 @@ def encoder_trunk_backward(P, c, dh, grads):
     wgrad(dy2, c["a1"], grads["conv_net.2.weight"], CONV, Bt, 16, 64, 32, 32, 2, -1)
     da1, _, _ = conv_like(dy2, pack_conv(P["conv_net.2.weight"], True), TCONV_S2P1, 1, Bt, 16, 64, 32, 32)
     du1 = act_backward(da1, c["u1"], ACT_SWISH)
-    wgrad(du1, c["col1"], grads["conv_net.0.weight"], DENSE, Bt * 1024, 1, 32, 1, 64, cg_canon=48)
+    wgrad(du1, c["x"], grads["conv_net.0.weight"], IM2COL3, Bt, 32, 32, 64, 64, cg_canon=48)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -263,10 +262,8 @@ def decoder_forward(P, buf, z, G=1, repeat=1, logits=True):
     a3, m3, r3 = bn_swish_from_partials(y3, st, T, bn3, G, Bg * 1024, 32, repeat)
     out = None
     if logits:
-        W4T = repack(P["hallucinate.9.weight"], 32, 48, 64, 32, 1)            # [co*16+tap (pad 64)][ci]
-        col4, _ = dense(a3, W4T, None, Bt * 1024, 32, 64)
         out = _new(z, Bt, 3, 64, 64)
-        ops.B.col2im_k4(col4, out, Bt, 32, 32, 64, 64, 3, 64, 2, 1, False)
+        ops.B.tconv_out3_fwd(a3, P["hallucinate.9.weight"], out, Bt, 32, 32)   # direct kernel, canonical weights
     c.update(u0=u0, h0=h0, y1=y1, a1=a1, m1=m1, r1=r1, y2=y2, a2=a2, m2=m2, r2=r2, y3=y3, a3=a3, m3=m3, r3=r3,
              bn=(bn1, bn2, bn3))
     return out, c
@@ -276,11 +273,12 @@ def decoder_backward(P, c, dlogits, grads, need_dz=True):
     """dlogits: NCHW [Bt,3,64,64] -> dz [Bt, L]; weight gradients into ``grads``."""
     Bt, G, Bg, L = c["Bt"], c["G"], c["Bg"], c["L"]
     bn1, bn2, bn3 = c["bn"]
-    dcol4 = _new(dlogits, Bt * 1024, 64)
-    ops.B.im2col_nchw3(dlogits, dcol4, Bt, 64, 64)
-    wgrad(c["a3"], dcol4, grads["hallucinate.9.weight"], DENSE, Bt * 1024, 1, 32, 1, 64, cg_canon=48)
+    # last layer backward: both GEMMs gather the k4 s2 p1 window of the NCHW logit gradient on the fly
+    wgrad(c["a3"], dlogits, grads["hallucinate.9.weight"], IM2COL3, Bt, 32, 32, 64, 64, cg_canon=48)
     W4p = repack(P["hallucinate.9.weight"], 32, 48, 32, 64, 0)
-    da3, _ = dense(dcol4, W4p, None, Bt * 1024, 64, 32)
+    da3 = _new(dlogits, Bt * 1024, 32)
+    ops.B.igemm_nt(dlogits, W4p, None, da3, None, None, None, IM2COL3, 1, Bt, 64, 64, 64, 32, 32, 32, 32, 1, 0,
+                   ACT_NONE, 1)
     dy3 = bn_swish_backward(da3, c["y3"], c["m3"], c["r3"], bn3, grads["hallucinate.7.weight"],
                             grads["hallucinate.7.bias"], G, Bg * 1024, 32)
     wgrad(c["a2"], dy3, grads["hallucinate.6.weight"], CONV, Bt, 16, 64, 32, 32, 2, -1)

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import PassExperts, MAX_PASSES, MAX_EXPERTS, check
 
 ACT_NONE, ACT_SWISH, ACT_RELU = 0, 1, 2
-DENSE, CONV, TCONV_S2P1 = 0, 1, 2
+DENSE, CONV, TCONV_S2P1, IM2COL3 = 0, 1, 2, 3
 
 
 def _ptr(t, dtype=torch.float32):
@@ -94,6 +94,9 @@ class HipBackend:
     def col2im_k4(self, col, out, Bt, Hi, Wi, Ho, Wo, C, ldcol, stride, pad, tap_major):
         check(self.lib.mmdyn_col2im_k4(_ptr(col), _ptr(out), Bt, Hi, Wi, Ho, Wo, C, ldcol, stride, pad,
                                        int(tap_major), _stream()), "mmdyn_col2im_k4")
+
+    def tconv_out3_fwd(self, a, w, out, Bt, Hi, Wi):
+        check(self.lib.mmdyn_tconv_out3_fwd(_ptr(a), _ptr(w), _ptr(out), Bt, Hi, Wi, _stream()), "mmdyn_tconv_out3_fwd")
 
     def nchw_to_nhwc(self, src, dst, B, C, HW):
         check(self.lib.mmdyn_nchw_to_nhwc(_ptr(src), _ptr(dst), B, C, HW, _stream()), "mmdyn_nchw_to_nhwc")

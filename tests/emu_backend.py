@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from mmdyn_hip import _lib
 
-DENSE, CONV, TCONV = 0, 1, 2
+DENSE, CONV, TCONV, IM2COL3 = 0, 1, 2, 3
 
 
 def _act(x, act):
@@ -61,13 +61,24 @@ class EmuBackend:
         xs = torch.arange(Wr) * stride + offset + kw + pad
         return Xp[:, ys][:, :, xs].reshape(Bt * Hr * Wr, C)
 
+    @staticmethod
+    def _unfold3(x, Bt, H, W):
+        cols = F.unfold(x.reshape(Bt, 3, H, W), kernel_size=4, stride=2, padding=1)      # [Bt][48][Ho*Wo]
+        out = torch.zeros(Bt * (H // 2) * (W // 2), 64)
+        out[:, :48] = cols.permute(0, 2, 1).reshape(-1, 48)
+        return out
+
     def igemm_nt(self, A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset,
                  act, splitk):
         self.calls.append("igemm_nt")
         assert Cin % 32 == 0 and N % 32 == 0 and ldc == N
         Bt = G * Bg
-        A = A.reshape(-1)[: Bt * Hi * Wi * Cin]
         Bp = Bp.reshape(-1, N, Cin)
+        if mode == IM2COL3:
+            assert Cin == 64
+            A = self._unfold3(A, Bt, Hi, Wi)
+            mode, Hi, Wi = DENSE, Ho, Wo
+        A = A.reshape(-1)[: Bt * Hi * Wi * Cin]
         if mode == DENSE:
             out = A.reshape(Bt * Hi * Wi, Cin) @ Bp[0].t()
             out = out.reshape(Bt, Ho, Wo, N)
@@ -122,7 +133,9 @@ class EmuBackend:
         taps = 16 if mode == CONV else 1
         p = partial.reshape(chunks, taps, Cd, Cg)
         for t in range(taps):
-            if mode == CONV:
+            if mode == IM2COL3:
+                g = self._unfold3(Gt, Bt, Hi, Wi)
+            elif mode == CONV:
                 g = self._gather(Gt.reshape(-1)[: Bt * Hi * Wi * Cg], Bt, Hi, Wi, Cg, Hr, Wr, stride, offset, t >> 2, t & 3)
             else:
                 g = Gt.reshape(-1)[: rows * Cg].reshape(rows, Cg)
@@ -181,6 +194,10 @@ class EmuBackend:
         if tap_major:
             img = img.permute(0, 2, 3, 1)
         out.reshape(-1).copy_(img.reshape(-1))
+
+    def tconv_out3_fwd(self, a, w, out, Bt, Hi, Wi):
+        x = a.reshape(Bt, Hi, Wi, 32).permute(0, 3, 1, 2)
+        out.reshape(-1).copy_(F.conv_transpose2d(x, w.reshape(32, 3, 4, 4), stride=2, padding=1).reshape(-1))
 
     def nchw_to_nhwc(self, src, dst, B, C, HW):
         dst.reshape(-1).copy_(src.reshape(B, C, HW).permute(0, 2, 1).reshape(-1))

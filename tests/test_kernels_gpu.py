@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from mmdyn_hip import ops
-from mmdyn_hip.ops import DENSE, CONV, TCONV_S2P1
+from mmdyn_hip.ops import DENSE, CONV, TCONV_S2P1, IM2COL3
 from emu_backend import EmuBackend
 
 pytestmark = pytest.mark.gpu
@@ -307,3 +307,22 @@ def test_random_kernels_statistics():
 def test_cpu_tensor_is_rejected_loudly():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         HIP.act_fwd(torch.zeros(8), torch.zeros(8), 1)
+
+
+@pytest.mark.parametrize("Bt", [1, 5])
+def test_tconv_out3_direct(Bt):
+    a = rnd(Bt * 32 * 32, 32, seed=60)
+    w = rnd(32, 3, 4, 4, seed=61)
+    both("tconv_out3_fwd", [a, w, torch.zeros(Bt, 3, 64, 64), Bt, 32, 32], [2])
+
+
+@pytest.mark.parametrize("Bt", [2, 7])
+def test_im2col_on_the_fly_modes(Bt):
+    x = rnd(Bt, 3, 64, 64, seed=70)
+    Bp = rnd(1, 32, 64, seed=71, scale=0.2)
+    C, Ca = torch.zeros(Bt * 1024, 32), torch.zeros(Bt * 1024, 32)
+    both("igemm_nt", [x, Bp, None, C, Ca, None, None, IM2COL3, 1, Bt, 64, 64, 64, 32, 32, 32, 32, 1, 0, 1, 1], [3, 4])
+    D = rnd(Bt * 1024, 32, seed=72)
+    chunks = HIP.wgrad_chunks(IM2COL3, Bt * 1024, 32, 64)
+    partial = torch.zeros(chunks, 1, 32, 64)
+    both("wgrad_tn", [D, x, partial, IM2COL3, Bt, 32, 32, 32, 64, 64, 64, 1, 0, chunks], [2], lambda i, t: t.sum(0), tol=5e-5)
