@@ -76,6 +76,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   const int n0 = blockIdx.y * BN;
   const int ph = cls >> 1, pw = cls & 1;
 
+#ifdef IG_STAGGER
+  if (blockIdx.x & 1) __builtin_amdgcn_s_sleep(IG_STAGGER);   // experiment: de-phase co-resident blocks
+#endif
   for (int r = tid; r < BM; r += 256) {
     int ml = tile * BM + r;
     int ib = -1, y0 = 0, x0 = 0, ooff = -1;
@@ -206,7 +209,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
     __syncthreads();
     int cur = 0;
     for (int s = s_begin; s < s_end; ++s) {
+#if !defined(IG_ABL) || IG_ABL < 1
       gload();
+#endif
       __builtin_amdgcn_sched_barrier(0);   // keep the fetch of step s+1 in front of the MFMAs of step s
       const float* Ac = As + cur * STAGE;
       const float* Bc = Bs + cur * STAGE;
@@ -233,9 +238,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
         __syncthreads();
         cur ^= 1;
       } else {
+#if !defined(IG_ABL) || IG_ABL < 2
         __syncthreads();
         lds_store(0);
         __syncthreads();
+#endif
       }
     }
   }
