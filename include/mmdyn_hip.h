@@ -44,6 +44,10 @@ extern "C" {
                                   nn.Conv2d(3,32,4,2,1) (vae.py:198) and the backward of nn.ConvTranspose2d(32,3,4,2,1)
                                   (vae.py:277) onto the MFMA GEMMs without materialising an im2col matrix */
 
+#define MMDYN_TCONV_S1P0 4      /* transposed k4 s1 p0 (Ho = Hi+3): rows ordered (output pixel, sample) inside a group so
+                                  every tile covers one output pixel and only its 1..16 valid taps are multiplied --
+                                  exactly the useful MACs, no zero padding, no column matrix */
+
 const char* mmdyn_version(void);
 
 /* ---- MFMA implicit GEMM, "NT" form ---------------------------------------------------------

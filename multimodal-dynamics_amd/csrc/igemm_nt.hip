@@ -32,7 +32,8 @@ struct IgemmGeom {
   int ntaps, nclasses, splitk;
   int act, has_bias, want_stats, want_act_out;
   int rows_total;      // G*Bg*Hr*Wr (split-K workspace stride)
-  int tiles_per_group; // ceil(Bg*Hr*Wr / BM)
+  int tiles_per_group; // ceil(Bg*Hr*Wr / BM); TCONV_S1P0: Ho*Wo*ceil(Bg/BM) (tiles never straddle an output pixel)
+  int tiles_per_pixel; // TCONV_S1P0 only: ceil(Bg/BM)
 };
 
 #ifndef IG_BK
@@ -79,10 +80,35 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
 #ifdef IG_STAGGER
   if (blockIdx.x & 1) __builtin_amdgcn_s_sleep(IG_STAGGER);   // experiment: de-phase co-resident blocks
 #endif
+  // TCONV_S1P0: rows are ordered (output pixel, sample) so that a tile sees ONE output pixel and multiplies only
+  // the kernel taps that reach the input for it (1..16 of them for k4 s1 p0).  To balance the blocks, each block
+  // walks the FOUR pixels {(h,w),(h+4,w),(h,w+4),(h+4,w+4)} of the 8x8 output: their valid-tap counts always sum
+  // to (1+4)*(1+4) = 25, so every block does identical work.
+  constexpr int NSUB = (MODE == MMDYN_TCONV_S1P0) ? 4 : 1;
+  for (int sub = 0; sub < NSUB; ++sub) {
+  int px_y = 0, px_x = 0, kh0 = 0, kw0 = 0, nkh = 4, nkw = 4;
+  if (MODE == MMDYN_TCONV_S1P0) {
+    const int quad = tile / g.tiles_per_pixel;
+    px_y = (quad >> 2) + 4 * (sub >> 1);
+    px_x = (quad & 3) + 4 * (sub & 1);
+    kh0 = max(0, px_y - (g.Hi - 1));
+    kw0 = max(0, px_x - (g.Wi - 1));
+    nkh = min(3, px_y) - kh0 + 1;
+    nkw = min(3, px_x) - kw0 + 1;
+    if (sub > 0) __syncthreads();      // previous sub-tile's epilogue still reads rowinfo / stats scratch
+  }
   for (int r = tid; r < BM; r += 256) {
     int ml = tile * BM + r;
     int ib = -1, y0 = 0, x0 = 0, ooff = -1;
-    if (ml < Mg) {
+    if (MODE == MMDYN_TCONV_S1P0) {
+      const int sidx = (tile % g.tiles_per_pixel) * BM + r;
+      if (sidx < g.Bg) {
+        ib = grp * g.Bg + sidx;
+        y0 = px_y;
+        x0 = px_x;
+        ooff = ((ib * g.Ho + px_y) * g.Wo + px_x) * g.ldc;
+      }
+    } else if (ml < Mg) {
       int s = ml / HWr;
       int p = ml - s * HWr;
       int rr = p / g.Wr;
@@ -111,7 +137,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   }
 
   const int cin_steps = g.Cin / BK;
-  const int total_steps = g.ntaps * cin_steps;
+  const int total_steps = (MODE == MMDYN_TCONV_S1P0 ? nkh * nkw : g.ntaps) * cin_steps;
   const int per_split = (total_steps + g.splitk - 1) / g.splitk;
   const int s_begin = split * per_split;
   const int s_end = min(total_steps, s_begin + per_split);
@@ -135,6 +161,12 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       dh = ph - th;
       dw = pw - tw;
       wi = (1 - ph + 2 * th) * 4 + (1 - pw + 2 * tw);
+    } else if (MODE == MMDYN_TCONV_S1P0) {
+      const int a = tap / nkw;
+      const int kh = kh0 + a, kw = kw0 + (tap - a * nkw);
+      dh = -kh;
+      dw = -kw;
+      wi = kh * 4 + kw;
     }
     if (MODE == MMDYN_IM2COL3) {
       // A is the reference's NCHW 3-channel image; virtual K index k = ci*16 + kh*4 + kw (48 real + 16 zero):
@@ -300,12 +332,17 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
         s += red[(w * 2 + 0) * BN + tid];
         q += red[(w * 2 + 1) * BN + tid];
       }
-      const int T = g.nclasses * g.tiles_per_group;
-      const size_t base = ((size_t)(grp * T + cls * g.tiles_per_group + tile) * 2) * g.N + n0 + tid;
+      int T = g.nclasses * g.tiles_per_group, slot = cls * g.tiles_per_group + tile;
+      if (MODE == MMDYN_TCONV_S1P0) {     // one slot per (output pixel, sample chunk)
+        T = g.Ho * g.Wo * g.tiles_per_pixel;
+        slot = (px_y * g.Wo + px_x) * g.tiles_per_pixel + tile % g.tiles_per_pixel;
+      }
+      const size_t base = ((size_t)(grp * T + slot) * 2) * g.N + n0 + tid;
       stats[base] = s;
       stats[base + g.N] = q;
     }
   }
+  }  // sub-tile loop
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
@@ -337,6 +374,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
 
 // tile choice shared by the launcher and mmdyn_igemm_stat_tiles: the largest tile that still gives
 // >= 2 blocks per CU (256 CUs), otherwise the smallest one that divides N.
+// (rows_per_group, G) describe the row segments a tile may not straddle: groups, or (group, output pixel) pairs
 static void pick_tile(int N, int rows_per_group, int G, int ncls, int splitk, int* bm, int* bn) {
   static const int cand[][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 32}, {128, 32}};
   int best = -1;
@@ -356,6 +394,10 @@ template <int MODE, int BM, int BN, int WM, int WN>
 static int launch_m(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats,
                     float* ws, IgemmGeom g, hipStream_t st) {
   g.tiles_per_group = ceil_div(g.Bg * g.Hr * g.Wr, BM);
+  if (MODE == MMDYN_TCONV_S1P0) {
+    g.tiles_per_pixel = ceil_div(g.Bg, BM);
+    g.tiles_per_group = 16 * g.tiles_per_pixel;       // 16 pixel quads per group, 4 pixels walked per block
+  }
   dim3 grid(g.G * g.tiles_per_group, g.N / BN, g.nclasses * g.splitk);
   size_t smem = (size_t)(IG_DBUF ? 2 : 1) * (BM + BN) * LDS_LD * sizeof(float) + (size_t)BM * 4 * sizeof(int);
   hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN>), grid, dim3(256), smem, st, A, Bp, bias, C, C_act,
@@ -369,12 +411,18 @@ static int launch(const float* A, const float* Bp, const float* bias, float* C, 
   if (g.mode == MMDYN_DENSE) return launch_m<MMDYN_DENSE, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
   if (g.mode == MMDYN_CONV) return launch_m<MMDYN_CONV, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
   if (g.mode == MMDYN_IM2COL3) return launch_m<MMDYN_IM2COL3, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
+  if (g.mode == MMDYN_TCONV_S1P0) return launch_m<MMDYN_TCONV_S1P0, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
   return launch_m<MMDYN_TCONV_S2P1, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
 }
 
 }  // namespace
 
 extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Ho, int Wo, int N) {
+  if (mode == MMDYN_TCONV_S1P0) {
+    int bm, bn;
+    pick_tile(N, Bg, G * 16, 1, 1, &bm, &bn);
+    return Ho * Wo * ceil_div(Bg, bm);
+  }
   int Hr = Ho, Wr = Wo, ncls = 1;
   if (mode == MMDYN_TCONV_S2P1) {
     Hr = Hi;
@@ -432,6 +480,13 @@ extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias
     g.rs = 1;
     g.ro = 0;
     g.ntaps = 1;
+  } else if (mode == MMDYN_TCONV_S1P0) {
+    if (Ho != Hi + 3 || Wo != Wi + 3 || Ho != 8 || Wo != 8 || splitk != 1) return MMDYN_ERR_SHAPE;
+    g.Hr = Ho;
+    g.Wr = Wo;
+    g.rs = 1;
+    g.ro = 0;
+    g.ntaps = 16;
   } else if (mode == MMDYN_TCONV_S2P1) {
     if (Ho != 2 * Hi || Wo != 2 * Wi) return MMDYN_ERR_SHAPE;
     g.Hr = Hi;
@@ -451,7 +506,10 @@ extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias
   g.rows_total = (int)rows;
   hipStream_t st = (hipStream_t)stream;
   int bm, bn;
-  pick_tile(N, Bg * g.Hr * g.Wr, G, g.nclasses, splitk, &bm, &bn);
+  if (mode == MMDYN_TCONV_S1P0)
+    pick_tile(N, Bg, G * 16, 1, 1, &bm, &bn);
+  else
+    pick_tile(N, Bg * g.Hr * g.Wr, G, g.nclasses, splitk, &bm, &bn);
   if (bn == 128 && bm == 128) return launch<128, 128, 64, 64>(A, Bp, bias, C, C_act, stats, ws, g, st);
   if (bn == 128 && bm == 64) return launch<64, 128, 32, 64>(A, Bp, bias, C, C_act, stats, ws, g, st);
   if (bn == 64 && bm == 128) return launch<128, 64, 64, 32>(A, Bp, bias, C, C_act, stats, ws, g, st);

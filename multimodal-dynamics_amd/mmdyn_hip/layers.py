@@ -17,7 +17,7 @@ Reference structure restated here (file:line relative to /root/reference/mmdyn/p
 import torch
 
 from . import ops
-from .ops import ACT_NONE, ACT_SWISH, ACT_RELU, DENSE, CONV, TCONV_S2P1, IM2COL3
+from .ops import ACT_NONE, ACT_SWISH, ACT_RELU, DENSE, CONV, TCONV_S2P1, IM2COL3, TCONV_S1P0
 from .models.shapes import BN_EPS, BN_MOMENTUM, FEAT
 
 
@@ -61,6 +61,24 @@ def conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride=1, offset=0, stats=Fals
         st = _new(x, G, T, 2, N)
     ops.B.igemm_nt(x, Wp, None, y, None, st, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset,
                    ACT_NONE, 1)
+    return y, st, T
+
+
+def tconv_s1p0(x, Wsp, G, Bg, Cin, N, stats=False):
+    """k4 s1 p0 transposed conv 5x5 -> 8x8 on NHWC rows, swap-packed weights [16][N][Cin].
+    Large batches: the tap-skipping implicit GEMM (exactly the useful MACs, balanced pixel quads).  Small ones
+    (too few blocks to fill 256 CUs): dense GEMM to a [rows][16*N] column matrix + col2im gather."""
+    Bt = G * Bg
+    if G * 16 * _cdiv(Bg, 64) * (N // 64) >= 512:
+        return conv_like(x, Wsp, TCONV_S1P0, G, Bg, 5, Cin, 8, N, stats=stats)
+    col, _ = dense(x, Wsp, None, Bt * 25, Cin, 16 * N)
+    y = _new(x, Bt * 64, N)
+    ops.B.col2im_k4(col, y, Bt, 5, 5, 8, 8, N, 16 * N, 1, 0, True)
+    st, T = None, 0
+    if stats:
+        T = ops.B.colstats_tiles(Bg * 64)
+        st = _new(x, G, T, 2, N)
+        ops.B.colstats(y, st, G, Bg * 64, N)
     return y, st, T
 
 
@@ -212,9 +230,7 @@ def encoder_trunk_backward(P, c, dh, grads):
                             grads["conv_net.9.bias"], G, Bg * 25, 256)
     wgrad(dy4, c["a3"], grads["conv_net.8.weight"], CONV, Bt, 5, 256, 8, 128, 1, 0)
     W4s = pack_conv(P["conv_net.8.weight"], True)                            # [16][128 ci][256 co]
-    col, _ = dense(dy4, W4s, None, Bt * 25, 256, 2048)
-    da3 = _new(dh, Bt * 64, 128)
-    ops.B.col2im_k4(col, da3, Bt, 5, 5, 8, 8, 128, 2048, 1, 0, True)
+    da3 = tconv_s1p0(dy4, W4s, 1, Bt, 256, 128)[0]
     dy3 = bn_swish_backward(da3, c["y3"], c["m3"], c["r3"], bn3, grads["conv_net.6.weight"],
                             grads["conv_net.6.bias"], G, Bg * 64, 128)
     wgrad(dy3, c["a2"], grads["conv_net.5.weight"], CONV, Bt, 8, 128, 16, 64, 2, -1)
@@ -247,12 +263,7 @@ def decoder_forward(P, buf, z, G=1, repeat=1, logits=True):
     u0, h0 = dense(z, Wu, bu, Bt, L, FEAT, ACT_SWISH, want_act=True)
     bn1, bn2, bn3 = (_bn_of(P, buf, k) for k in DEC_BN)
     W1s = pack_conv(P["hallucinate.0.weight"], True)                          # [16][128 co][256 ci]
-    col, _ = dense(h0, W1s, None, Bt * 25, 256, 2048)
-    y1 = _new(z, Bt * 64, 128)
-    ops.B.col2im_k4(col, y1, Bt, 5, 5, 8, 8, 128, 2048, 1, 0, True)
-    T = ops.B.colstats_tiles(Bg * 64)
-    st = _new(z, G, T, 2, 128)
-    ops.B.colstats(y1, st, G, Bg * 64, 128)
+    y1, st, T = tconv_s1p0(h0, W1s, G, Bg, 256, 128, stats=True)
     a1, m1, r1 = bn_swish_from_partials(y1, st, T, bn1, G, Bg * 64, 128, repeat)
     y2, st, T = conv_like(a1, pack_conv(P["hallucinate.3.weight"], True), TCONV_S2P1, G, Bg, 8, 128, 16, 64,
                           stats=True)

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import PassExperts, MAX_PASSES, MAX_EXPERTS, check
 
 ACT_NONE, ACT_SWISH, ACT_RELU = 0, 1, 2
-DENSE, CONV, TCONV_S2P1, IM2COL3 = 0, 1, 2, 3
+DENSE, CONV, TCONV_S2P1, IM2COL3, TCONV_S1P0 = 0, 1, 2, 3, 4
 
 
 def _ptr(t, dtype=torch.float32):

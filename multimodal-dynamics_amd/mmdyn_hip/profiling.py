@@ -19,6 +19,10 @@ def _flops(name, a):
             return 2.0 * G * Bg * Ho * Wo * N * Cin
         if mode == ops.CONV:
             return 2.0 * G * Bg * Ho * Wo * N * 16 * Cin
+        if mode == ops.TCONV_S1P0:
+            return 2.0 * G * Bg * Hi * Wi * N * 16 * Cin
+        if mode == ops.IM2COL3:
+            return 2.0 * G * Bg * Ho * Wo * N * 48
         return 2.0 * G * Bg * Ho * Wo * N * 4 * Cin
     if name == "wgrad_tn":
         (mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg) = a[3:11]

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from mmdyn_hip import _lib
 
-DENSE, CONV, TCONV, IM2COL3 = 0, 1, 2, 3
+DENSE, CONV, TCONV, IM2COL3, TCONV_S1P0 = 0, 1, 2, 3, 4
 
 
 def _act(x, act):
@@ -86,6 +86,12 @@ class EmuBackend:
             out = torch.zeros(Bt * Ho * Wo, N)
             for t in range(16):
                 out += self._gather(A, Bt, Hi, Wi, Cin, Ho, Wo, stride, offset, t >> 2, t & 3) @ Bp[t].t()
+            out = out.reshape(Bt, Ho, Wo, N)
+        elif mode == TCONV_S1P0:
+            assert Ho == Hi + 3
+            out = torch.zeros(Bt * Ho * Wo, N)
+            for t in range(16):
+                out += self._gather(A, Bt, Hi, Wi, Cin, Ho, Wo, 1, 0, -(t >> 2), -(t & 3)) @ Bp[t].t()
             out = out.reshape(Bt, Ho, Wo, N)
         else:
             assert Ho == 2 * Hi and Wo == 2 * Wi

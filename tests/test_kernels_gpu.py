@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from mmdyn_hip import ops
-from mmdyn_hip.ops import DENSE, CONV, TCONV_S2P1, IM2COL3
+from mmdyn_hip.ops import DENSE, CONV, TCONV_S2P1, IM2COL3, TCONV_S1P0
 from emu_backend import EmuBackend
 
 pytestmark = pytest.mark.gpu
@@ -58,6 +58,9 @@ IGEMM_CASES = [
     (TCONV_S2P1, 2, 3, 16, 64, 32, 32, 1, 0),
     (TCONV_S2P1, 1, 2, 16, 64, 32, 32, 1, 0),
     (CONV, 4, 64, 8, 128, 5, 256, 1, 0),       # 4 groups, rows not a tile multiple (64*25 = 1600)
+    (TCONV_S1P0, 1, 5, 5, 256, 8, 128, 1, 0),
+    (TCONV_S1P0, 4, 70, 5, 256, 8, 128, 1, 0),  # 4 groups, samples per group not a tile multiple
+    (TCONV_S1P0, 1, 256, 5, 256, 8, 128, 1, 0),
 ]
 
 
