@@ -101,6 +101,20 @@ int mmdyn_pack_conv_weight(const float* Wc, float* P, int d0, int d1, int swap, 
 int mmdyn_repack2d(const float* in, float* out, int rows_in, int cols_in, int rows_out, int cols_out,
                    int mode, void* stream);
 
+/* mmdyn_repack2d writing a rows_out x cols_out block into a wider matrix (row stride ld_out >= cols_out) */
+int mmdyn_repack2d_ld(const float* in, float* out, int rows_in, int cols_in, int rows_out, int cols_out,
+                      int ld_out, int mode, void* stream);
+/* A whole step's weight repacks in one launch.  `plan_dev` is a DEVICE array of n entries (built once: the
+ * parameter storage of a training run does not move).  kind 0..5 = mmdyn_repack2d modes with an output leading
+ * dimension ld_out (>= cols_out); kind 100 / 101 = mmdyn_pack_conv_weight with swap 0 / 1 (rows_in = d0,
+ * cols_in = d1). */
+typedef struct {
+  const float* src;
+  float* dst;
+  int kind, rows_in, cols_in, rows_out, cols_out, ld_out;
+} mmdyn_pack_entry;
+int mmdyn_pack_plan(const mmdyn_pack_entry* plan_dev, int n, void* stream);
+
 /* ---- first / last layer helpers (3-channel NCHW side) --------------------------------------- */
 /* col[(b*Ho+ho)*Wo+wo][ci*16+kh*4+kw] = x[b][ci][2ho-1+kh][2wo-1+kw], columns 48..63 zero.
  * x: NCHW [Bt][3][H][W]; col: [Bt*(H/2)*(W/2)][64].  Lowers nn.Conv2d(3,32,4,2,1) (vae.py:198) and the

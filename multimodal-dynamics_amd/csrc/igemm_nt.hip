@@ -244,7 +244,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
 #if !defined(IG_ABL) || IG_ABL < 1
       gload();
 #endif
+#ifndef IG_SGB
       __builtin_amdgcn_sched_barrier(0);   // keep the fetch of step s+1 in front of the MFMAs of step s
+#endif
       const float* Ac = As + cur * STAGE;
       const float* Bc = Bs + cur * STAGE;
 #pragma unroll
@@ -264,6 +266,15 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
             for (int nt = 0; nt < NT; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
       }
+#ifdef IG_SGB
+      // experiment: ask the scheduler to weave the fetch (VALU address math + VMEM) between the MFMAs
+#pragma unroll
+      for (int i = 0; i < A_LOADS + B_LOADS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (MT * NT * 4 * (BK / 8)) / (A_LOADS + B_LOADS) / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, IG_SGB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+#endif
       if (IG_DBUF) {
         // two LDS stages: the next tile goes to the other stage, one barrier per K-step
         lds_store(cur ^ 1);

@@ -46,6 +46,55 @@ __global__ void repack2d_kernel(const float* __restrict__ in, float* __restrict_
   }
 }
 
+// All weight repacks of a step in ONE launch: blockIdx.y = plan entry, grid-stride over its output elements.
+__device__ __forceinline__ float repack_fetch(const float* __restrict__ in, int rows_in, int cols_in, int r, int c,
+                                              int mode) {
+  int ri, ci;
+  switch (mode) {
+    case 0: ri = r; ci = c; break;
+    case 1: ri = c; ci = r; break;
+    case 2: { int hw = c / 256, ch = c - hw * 256; ri = r; ci = ch * 25 + hw; } break;
+    case 3: { int hw = r / 256, ch = r - hw * 256; ri = ch * 25 + hw; ci = c; } break;
+    case 4: { int hw = r / 256, ch = r - hw * 256; ri = c; ci = ch * 25 + hw; } break;
+    default: { int hw = c / 256, ch = c - hw * 256; ri = ch * 25 + hw; ci = r; } break;
+  }
+  return (ri < rows_in && ci < cols_in) ? in[(int64_t)ri * cols_in + ci] : 0.f;
+}
+
+__global__ void repack2d_ld_kernel(const float* __restrict__ in, float* __restrict__ out, int rows_in, int cols_in,
+                                   int rows_out, int cols_out, int ld_out, int mode) {
+  const int64_t total = (int64_t)rows_out * cols_out;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % cols_out), r = (int)(i / cols_out);
+    out[(int64_t)r * ld_out + c] = repack_fetch(in, rows_in, cols_in, r, c, mode);
+  }
+}
+
+__global__ void pack_plan_kernel(const mmdyn_pack_entry* __restrict__ plan) {
+  const mmdyn_pack_entry e = plan[blockIdx.y];
+  const float* __restrict__ src = e.src;
+  float* __restrict__ dst = e.dst;
+  if (e.kind >= 100) {                       // conv weight: Wc[d0][d1][16] -> P[tap][x][y]
+    const int swap = e.kind - 100, d0 = e.rows_in, d1 = e.cols_in;
+    const int nx = swap ? d1 : d0, ny = swap ? d0 : d1;
+    const int64_t total = (int64_t)16 * d0 * d1;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      int y = (int)(i % ny);
+      int64_t t = i / ny;
+      int x = (int)(t % nx);
+      int tap = (int)(t / nx);
+      int a = swap ? y : x, b = swap ? x : y;
+      dst[i] = src[((int64_t)a * d1 + b) * 16 + tap];
+    }
+  } else {                                   // 2-D repack with output leading dimension
+    const int64_t total = (int64_t)e.rows_out * e.cols_out;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      int c = (int)(i % e.cols_out), r = (int)(i / e.cols_out);
+      dst[(int64_t)r * e.ld_out + c] = repack_fetch(src, e.rows_in, e.cols_in, r, c, e.kind);
+    }
+  }
+}
+
 // one thread per (output pixel, ci*4+kh): writes one float4 = the 4 kw taps; 16 threads cover a 64-float row
 __global__ void im2col_nchw3_kernel(const float* __restrict__ x, float* __restrict__ col, int Bt, int H,
                                     int W) {
@@ -167,6 +216,22 @@ extern "C" int mmdyn_repack2d(const float* in, float* out, int rows_in, int cols
   if (mode < 0 || mode > 5 || rows_out <= 0 || cols_out <= 0) return MMDYN_ERR_SHAPE;
   hipLaunchKernelGGL(repack2d_kernel, dim3(ew_grid((int64_t)rows_out * cols_out)), dim3(256), 0,
                      (hipStream_t)stream, in, out, rows_in, cols_in, rows_out, cols_out, mode);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_repack2d_ld(const float* in, float* out, int rows_in, int cols_in, int rows_out, int cols_out,
+                                 int ld_out, int mode, void* stream) {
+  if (!in || !out) return MMDYN_ERR_NULL;
+  if (mode < 0 || mode > 5 || rows_out <= 0 || cols_out <= 0 || ld_out < cols_out) return MMDYN_ERR_SHAPE;
+  hipLaunchKernelGGL(repack2d_ld_kernel, dim3(ew_grid((int64_t)rows_out * cols_out)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, rows_in, cols_in, rows_out, cols_out, ld_out, mode);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_pack_plan(const mmdyn_pack_entry* plan_dev, int n, void* stream) {
+  if (!plan_dev) return MMDYN_ERR_NULL;
+  if (n <= 0 || n > 65535) return MMDYN_ERR_SHAPE;
+  hipLaunchKernelGGL(pack_plan_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, plan_dev);
   MMDYN_LAUNCH_CHECK();
 }
 

@@ -17,6 +17,12 @@ class PassExperts(ctypes.Structure):
     _fields_ = [("mu", _P * 4), ("lv", _P * 4), ("dmu", _P * 4), ("dlv", _P * 4), ("ld", _I * 4), ("dz", _P * 3)]
 
 
+class PackEntry(ctypes.Structure):
+    """mmdyn_pack_entry (include/mmdyn_hip.h)."""
+    _fields_ = [("src", _P), ("dst", _P), ("kind", _I), ("rows_in", _I), ("cols_in", _I), ("rows_out", _I),
+                ("cols_out", _I), ("ld_out", _I)]
+
+
 MAX_PASSES = 8
 MAX_EXPERTS = 4
 
@@ -30,6 +36,8 @@ _SIGNATURES = {
     "mmdyn_wgrad_reduce": "pp" + "iiiiii" + "f" + "p",
     "mmdyn_pack_conv_weight": "pp" + "iii" + "p",
     "mmdyn_repack2d": "pp" + "iiiii" + "p",
+    "mmdyn_repack2d_ld": "pp" + "iiiiii" + "p",
+    "mmdyn_pack_plan": "p" + "i" + "p",
     "mmdyn_im2col_nchw3": "pp" + "iii" + "p",
     "mmdyn_col2im_k4": "pp" + "iiiiiiiiii" + "p",
     "mmdyn_tconv_out3_fwd": "ppp" + "iii" + "p",

@@ -136,6 +136,20 @@ class MVAEStep:
         self.partials = torch.zeros(8, device=dev)
         self.last = {}
         self.lanes = _Lanes(dev, two_lanes)
+        # every weight repack of a step (conv tap-major packs, FC permutations / transposes, fused heads) as ONE
+        # kernel launch over a device-resident plan; the emulation backend packs per stack instead
+        self.plan = None
+        if ops.B.name == "hip":
+            FP = self.params
+            specs = {"ev": layers.encoder_pack_specs(FP.sub("visual_encoder")),
+                     "et": layers.encoder_pack_specs(FP.sub("tactile_encoder")),
+                     "hv": layers.heads_pack_specs(FP.sub("visual_encoder")),
+                     "ht": layers.heads_pack_specs(FP.sub("tactile_encoder")),
+                     "dv": layers.decoder_pack_specs(FP.sub("visual_decoder")),
+                     "dt": layers.decoder_pack_specs(FP.sub("tactile_decoder"))}
+            if self.use_pose:
+                specs["hp"] = layers.heads_pack_specs(FP.sub("pose_encoder"))
+            self.plan = layers.PackPlan(specs)
         self._capturing = False
         self._graph = None
 
@@ -176,6 +190,10 @@ class MVAEStep:
         FP = self.params
         eps, mv, mt = self._draw(B, dev)
         nv, nt, npp = len(self.pass_v), len(self.pass_t), len(self.pass_p)
+        pk = {}
+        if self.plan is not None:
+            self.plan.run()
+            pk = self.plan.packed
         c = {"B": B, "eps": eps, "mv": mv, "mt": mt}
 
         # 1. encoder trunks, once per modality (running statistics: nv identical EMA updates, as in the reference)
@@ -183,20 +201,22 @@ class MVAEStep:
         LN = self.lanes
         LN.fork()
         with LN.lane(0):
-            hv, c["ev"] = layers.encoder_trunk_forward(FP.sub("visual_encoder"), self._buffers("visual_encoder"), v, 1, nv)
+            hv, c["ev"] = layers.encoder_trunk_forward(FP.sub("visual_encoder"), self._buffers("visual_encoder"), v, 1, nv,
+                                                       pk.get("ev"))
             hdv = torch.empty(nv * B, 512, device=dev)
             ops.B.dropout_expand(hv, mv, hdv, nv, B, 512, DROPOUT_P)
-            ov, c["hv"] = layers.heads_forward(FP.sub("visual_encoder"), hdv)
+            ov, c["hv"] = layers.heads_forward(FP.sub("visual_encoder"), hdv, pk.get("hv"))
         with LN.lane(1):
-            ht, c["et"] = layers.encoder_trunk_forward(FP.sub("tactile_encoder"), self._buffers("tactile_encoder"), t, 1, nt)
+            ht, c["et"] = layers.encoder_trunk_forward(FP.sub("tactile_encoder"), self._buffers("tactile_encoder"), t, 1, nt,
+                                                       pk.get("et"))
             hdt = torch.empty(nt * B, 512, device=dev)
             ops.B.dropout_expand(ht, mt, hdt, nt, B, 512, DROPOUT_P)
-            ot, c["ht"] = layers.heads_forward(FP.sub("tactile_encoder"), hdt)
+            ot, c["ht"] = layers.heads_forward(FP.sub("tactile_encoder"), hdt, pk.get("ht"))
         op = None
         if self.use_pose:
             pose_rep = inputs[2].contiguous().repeat(npp, 1)                  # same pose rows for each pass
             hp, c["ep"] = layers.pose_encoder_trunk_forward(FP.sub("pose_encoder"), pose_rep)
-            op, c["hp"] = layers.heads_forward(FP.sub("pose_encoder"), hp)
+            op, c["hp"] = layers.heads_forward(FP.sub("pose_encoder"), hp, pk.get("hp"))
         LN.join()
         c["ov"], c["ot"], c["op"] = ov, ot, op
         # 4. product of experts + reparametrisation + KL for every pass
@@ -214,14 +234,16 @@ class MVAEStep:
         LN.fork()
         with LN.lane(0):
             zv = torch.cat([z[p] for p in self.pass_v])
-            lg_v, c["dv"] = layers.decoder_forward(FP.sub("visual_decoder"), self._buffers("visual_decoder"), zv, nv)
+            lg_v, c["dv"] = layers.decoder_forward(FP.sub("visual_decoder"), self._buffers("visual_decoder"), zv, nv,
+                                                   packed=pk.get("dv"))
             dl_v = torch.empty_like(lg_v) if train else None
             for g, p in enumerate(self.pass_v):
                 ops.B.bce_logits(lg_v[g * B:(g + 1) * B], tv, None, None if dl_v is None else dl_v[g * B:(g + 1) * B],
                                  self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, inv_b)
         with LN.lane(1):
             zt = torch.cat([z[p] for p in self.pass_t])
-            lg_t, c["dt"] = layers.decoder_forward(FP.sub("tactile_decoder"), self._buffers("tactile_decoder"), zt, nt)
+            lg_t, c["dt"] = layers.decoder_forward(FP.sub("tactile_decoder"), self._buffers("tactile_decoder"), zt, nt,
+                                                   packed=pk.get("dt"))
             dl_t = torch.empty_like(lg_t) if train else None
             for g, p in enumerate(self.pass_t):
                 ops.B.bce_logits(lg_t[g * B:(g + 1) * B], tt, None, None if dl_t is None else dl_t[g * B:(g + 1) * B],

@@ -136,6 +136,108 @@ def repack(W, rows_in, cols_in, rows_out, cols_out, mode):
 
 
 # ------------------------------------------------------------------------------------------------
+# weight packing: specs -> packed GEMM operands, either one kernel per entry or one launch for a whole plan
+# ------------------------------------------------------------------------------------------------
+K_KEEP, K_SWAP = 100, 101      # mmdyn_pack_entry.kind for conv weights; 0..5 = mmdyn_repack2d modes
+
+
+def _spec(name, src, kind, rin, cin, rout, cout, shape, part=None):
+    """part = (row_offset, col_offset, ld_out) when this entry fills a sub-block of the packed tensor `name`."""
+    return dict(name=name, src=src, kind=kind, rin=rin, cin=cin, rout=rout, cout=cout, shape=tuple(shape), part=part)
+
+
+def encoder_pack_specs(P):
+    c = lambda k, kind, d0, d1: _spec(k[0], P[k[1]], kind, d0, d1, 0, 0, (16, d1, d0) if kind == K_SWAP else (16, d0, d1))
+    return [_spec("W1p", P["conv_net.0.weight"], 0, 32, 48, 32, 64, (32, 64)),
+            c(("W2k", "conv_net.2.weight"), K_KEEP, 64, 32), c(("W3k", "conv_net.5.weight"), K_KEEP, 128, 64),
+            c(("W4k", "conv_net.8.weight"), K_KEEP, 256, 128),
+            _spec("Wf", P["fc_net.0.weight"], 2, 512, FEAT, 512, FEAT, (512, FEAT)),
+            _spec("WfT", P["fc_net.0.weight"], 4, 512, FEAT, FEAT, 512, (FEAT, 512)),
+            c(("W4s", "conv_net.8.weight"), K_SWAP, 256, 128), c(("W3s", "conv_net.5.weight"), K_SWAP, 128, 64),
+            c(("W2s", "conv_net.2.weight"), K_SWAP, 64, 32)]
+
+
+def decoder_pack_specs(P):
+    L = P["upsample.0.weight"].shape[1]
+    c = lambda k, kind, d0, d1: _spec(k[0], P[k[1]], kind, d0, d1, 0, 0, (16, d1, d0) if kind == K_SWAP else (16, d0, d1))
+    return [_spec("Wu", P["upsample.0.weight"], 3, FEAT, L, FEAT, L, (FEAT, L)),
+            _spec("bu", P["upsample.0.bias"], 3, FEAT, 1, FEAT, 1, (FEAT,)),
+            c(("W1s", "hallucinate.0.weight"), K_SWAP, 256, 128), c(("W2s", "hallucinate.3.weight"), K_SWAP, 128, 64),
+            c(("W3s", "hallucinate.6.weight"), K_SWAP, 64, 32),
+            _spec("W4p", P["hallucinate.9.weight"], 0, 32, 48, 32, 64, (32, 64)),
+            c(("W3k", "hallucinate.6.weight"), K_KEEP, 64, 32), c(("W2k", "hallucinate.3.weight"), K_KEEP, 128, 64),
+            c(("W1k", "hallucinate.0.weight"), K_KEEP, 256, 128),
+            _spec("WuT", P["upsample.0.weight"], 5, FEAT, L, L, FEAT, (L, FEAT))]
+
+
+def heads_pack_specs(P):
+    Wm, Wl = P["linear_means.weight"], P["linear_log_var.weight"]
+    L, K = Wm.shape
+    return [_spec("Wh", Wm, 0, L, K, L, K, (2 * L, K), (0, 0, K)), _spec("Wh", Wl, 0, L, K, L, K, (2 * L, K), (L, 0, K)),
+            _spec("bh", P["linear_means.bias"], 0, L, 1, L, 1, (2 * L,), (0, 0, 1)),
+            _spec("bh", P["linear_log_var.bias"], 0, L, 1, L, 1, (2 * L,), (L, 0, 1)),
+            _spec("WhT", Wm, 1, L, K, K, L, (K, 2 * L), (0, 0, 2 * L)), _spec("WhT", Wl, 1, L, K, K, L, (K, 2 * L), (0, L, 2 * L))]
+
+
+def _alloc_packed(specs, like):
+    out = {}
+    for s in specs:
+        if s["name"] not in out:
+            out[s["name"]] = torch.zeros(s["shape"], device=like.device, dtype=torch.float32)
+    return out
+
+
+def pack_now(specs):
+    """One kernel per entry (module-API path)."""
+    out = _alloc_packed(specs, specs[0]["src"])
+    for s in specs:
+        dst = out[s["name"]]
+        if s["kind"] >= K_KEEP:
+            ops.B.pack_conv_weight(s["src"], dst, s["rin"], s["cin"], s["kind"] - K_KEEP)
+        elif s["part"] is None:
+            ops.B.repack2d(s["src"], dst, s["rin"], s["cin"], s["rout"], s["cout"], s["kind"])
+        else:
+            r0, c0, ld = s["part"]
+            corner = dst.view(-1)[r0 * ld + c0:]
+            ops.B.repack2d_ld(s["src"], corner, s["rin"], s["cin"], s["rout"], s["cout"], ld, s["kind"])
+    return out
+
+
+class PackPlan:
+    """All repacks of the given spec lists as ONE kernel launch (mmdyn_pack_plan).  Source and destination
+    storage must not move afterwards (the fused engine's flat parameter buffer and these outputs never do)."""
+
+    def __init__(self, named_specs):
+        import ctypes
+        from ._lib import PackEntry
+        self.packed, entries = {}, []
+        for key, specs in named_specs.items():
+            outs = _alloc_packed(specs, specs[0]["src"])
+            self.packed[key] = outs
+            for s in specs:
+                dst = outs[s["name"]]
+                e = PackEntry()
+                e.src = s["src"].data_ptr()
+                e.kind, e.rows_in, e.cols_in = s["kind"], s["rin"], s["cin"]
+                if s["kind"] >= K_KEEP:
+                    e.dst, e.rows_out, e.cols_out, e.ld_out = dst.data_ptr(), 0, 0, 0
+                else:
+                    r0, c0, ld = s["part"] if s["part"] is not None else (0, 0, s["cout"])
+                    e.dst = dst.data_ptr() + 4 * (r0 * ld + c0)
+                    e.rows_out, e.cols_out, e.ld_out = s["rout"], s["cout"], ld
+                entries.append(e)
+        self.n = len(entries)
+        arr = (PackEntry * self.n)(*entries)
+        raw = bytes(memoryview(arr))
+        dev = next(iter(next(iter(self.packed.values())).values())).device
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self._ptrs = [(e.src, e.dst) for e in entries]
+
+    def run(self):
+        ops.B.pack_plan(self.table, self.n)
+
+
+# ------------------------------------------------------------------------------------------------
 # generic Linear (MFMA when both dims are multiples of 32, the small kernel for the 7-wide pose ends)
 # ------------------------------------------------------------------------------------------------
 def linear_forward(x, W, b, act=ACT_NONE):
@@ -192,26 +294,27 @@ def _bn_of(P, buf, pre):
                    b.get(pre + ".running_var"), b.get(pre + ".num_batches_tracked"))
 
 
-def encoder_trunk_forward(P, buf, x, G=1, repeat=1):
+def encoder_trunk_forward(P, buf, x, G=1, repeat=1, packed=None):
     """x: NCHW [Bt,3,64,64] -> h = Swish(fc(conv stack)) [Bt,512]; returns (h, ctx).
-    ``repeat``: how many reference forward calls this one stands for (running-stat EMA updates)."""
+    ``repeat``: how many reference forward calls this one stands for (running-stat EMA updates).
+    ``packed``: pre-packed weights (PackPlan); packed here, one kernel each, when absent."""
     Bt = x.shape[0]
     Bg = Bt // G
-    c = {"Bt": Bt, "G": G, "Bg": Bg}
-    W1p = repack(P["conv_net.0.weight"], 32, 48, 32, 64, 0)                   # [32][64], cols 48.. zero
+    pk = packed if packed is not None else pack_now(encoder_pack_specs(P))
+    c = {"Bt": Bt, "G": G, "Bg": Bg, "pk": pk}
+    W1p = pk["W1p"]                                                          # [32][64], cols 48.. zero
     u1, a1 = _new(x, Bt * 1024, 32), _new(x, Bt * 1024, 32)
     # first layer: the k4 s2 p1 window of the NCHW image is gathered on the fly (no im2col matrix in HBM)
     ops.B.igemm_nt(x, W1p, None, u1, a1, None, None, IM2COL3, 1, Bt, 64, 64, 64, 32, 32, 32, 32, 1, 0,
                    ACT_SWISH, 1)
     bn2, bn3, bn4 = (_bn_of(P, buf, k) for k in ENC_BN)
-    y2, st, T = conv_like(a1, pack_conv(P["conv_net.2.weight"], False), CONV, G, Bg, 32, 32, 16, 64, 2, -1, True)
+    y2, st, T = conv_like(a1, pk["W2k"], CONV, G, Bg, 32, 32, 16, 64, 2, -1, True)
     a2, m2, r2 = bn_swish_from_partials(y2, st, T, bn2, G, Bg * 256, 64, repeat)
-    y3, st, T = conv_like(a2, pack_conv(P["conv_net.5.weight"], False), CONV, G, Bg, 16, 64, 8, 128, 2, -1, True)
+    y3, st, T = conv_like(a2, pk["W3k"], CONV, G, Bg, 16, 64, 8, 128, 2, -1, True)
     a3, m3, r3 = bn_swish_from_partials(y3, st, T, bn3, G, Bg * 64, 128, repeat)
-    y4, st, T = conv_like(a3, pack_conv(P["conv_net.8.weight"], False), CONV, G, Bg, 8, 128, 5, 256, 1, 0, True)
+    y4, st, T = conv_like(a3, pk["W4k"], CONV, G, Bg, 8, 128, 5, 256, 1, 0, True)
     a4, m4, r4 = bn_swish_from_partials(y4, st, T, bn4, G, Bg * 25, 256, repeat)
-    Wf = repack(P["fc_net.0.weight"], 512, FEAT, 512, FEAT, 2)               # columns -> hw*256+c
-    u5, h = dense(a4, Wf, P["fc_net.0.bias"], Bt, FEAT, 512, ACT_SWISH, want_act=True)
+    u5, h = dense(a4, pk["Wf"], P["fc_net.0.bias"], Bt, FEAT, 512, ACT_SWISH, want_act=True)   # columns hw*256+c
     c.update(x=x, u1=u1, a1=a1, y2=y2, a2=a2, m2=m2, r2=r2, y3=y3, a3=a3, m3=m3, r3=r3, y4=y4, a4=a4,
              m4=m4, r4=r4, u5=u5, bn=(bn2, bn3, bn4))
     return h, c
@@ -219,26 +322,24 @@ def encoder_trunk_forward(P, buf, x, G=1, repeat=1):
 
 def encoder_trunk_backward(P, c, dh, grads):
     """dh: [Bt,512]; writes every weight gradient of the trunk into ``grads[key]`` (canonical layout)."""
-    Bt, G, Bg = c["Bt"], c["G"], c["Bg"]
+    Bt, G, Bg, pk = c["Bt"], c["G"], c["Bg"], c["pk"]
     bn2, bn3, bn4 = c["bn"]
     du5 = act_backward(dh, c["u5"], ACT_SWISH)
     wgrad(du5, c["a4"], grads["fc_net.0.weight"], DENSE, Bt, 1, 512, 1, FEAT, perm=1)
     ops.B.colsum(du5, grads["fc_net.0.bias"], Bt, 512, 0, 0.0)
-    WfT = repack(P["fc_net.0.weight"], 512, FEAT, FEAT, 512, 4)             # [hw*256+c][512]
-    da4, _ = dense(du5, WfT, None, Bt, 512, FEAT)
+    da4, _ = dense(du5, pk["WfT"], None, Bt, 512, FEAT)                      # WfT: [hw*256+c][512]
     dy4 = bn_swish_backward(da4, c["y4"], c["m4"], c["r4"], bn4, grads["conv_net.9.weight"],
                             grads["conv_net.9.bias"], G, Bg * 25, 256)
     wgrad(dy4, c["a3"], grads["conv_net.8.weight"], CONV, Bt, 5, 256, 8, 128, 1, 0)
-    W4s = pack_conv(P["conv_net.8.weight"], True)                            # [16][128 ci][256 co]
-    da3 = tconv_s1p0(dy4, W4s, 1, Bt, 256, 128)[0]
+    da3 = tconv_s1p0(dy4, pk["W4s"], 1, Bt, 256, 128)[0]                     # W4s: [16][128 ci][256 co]
     dy3 = bn_swish_backward(da3, c["y3"], c["m3"], c["r3"], bn3, grads["conv_net.6.weight"],
                             grads["conv_net.6.bias"], G, Bg * 64, 128)
     wgrad(dy3, c["a2"], grads["conv_net.5.weight"], CONV, Bt, 8, 128, 16, 64, 2, -1)
-    da2, _, _ = conv_like(dy3, pack_conv(P["conv_net.5.weight"], True), TCONV_S2P1, 1, Bt, 8, 128, 16, 64)
+    da2, _, _ = conv_like(dy3, pk["W3s"], TCONV_S2P1, 1, Bt, 8, 128, 16, 64)
     dy2 = bn_swish_backward(da2, c["y2"], c["m2"], c["r2"], bn2, grads["conv_net.3.weight"],
                             grads["conv_net.3.bias"], G, Bg * 256, 64)
     wgrad(dy2, c["a1"], grads["conv_net.2.weight"], CONV, Bt, 16, 64, 32, 32, 2, -1)
-    da1, _, _ = conv_like(dy2, pack_conv(P["conv_net.2.weight"], True), TCONV_S2P1, 1, Bt, 16, 64, 32, 32)
+    da1, _, _ = conv_like(dy2, pk["W2s"], TCONV_S2P1, 1, Bt, 16, 64, 32, 32)
     du1 = act_backward(da1, c["u1"], ACT_SWISH)
     wgrad(du1, c["x"], grads["conv_net.0.weight"], IM2COL3, Bt, 32, 32, 64, 64, cg_canon=48)
 
@@ -252,24 +353,20 @@ DEC_KEYS = ["upsample.0.weight", "upsample.0.bias", "hallucinate.0.weight", "hal
 DEC_BN = ["hallucinate.1", "hallucinate.4", "hallucinate.7"]
 
 
-def decoder_forward(P, buf, z, G=1, repeat=1, logits=True):
+def decoder_forward(P, buf, z, G=1, repeat=1, logits=True, packed=None):
     """z: [Bt, L] -> logits NCHW [Bt,3,64,64]; returns (logits, ctx).  ``logits=False`` stops after the last
     BatchNorm (used only to reproduce the running statistics of the reference's unused decoder passes)."""
     Bt, L = z.shape
     Bg = Bt // G
-    c = {"Bt": Bt, "G": G, "Bg": Bg, "L": L, "z": z}
-    Wu = repack(P["upsample.0.weight"], FEAT, L, FEAT, L, 3)                  # rows -> hw*256+c
-    bu = repack(P["upsample.0.bias"], FEAT, 1, FEAT, 1, 3).view(FEAT)
-    u0, h0 = dense(z, Wu, bu, Bt, L, FEAT, ACT_SWISH, want_act=True)
+    pk = packed if packed is not None else pack_now(decoder_pack_specs(P))
+    c = {"Bt": Bt, "G": G, "Bg": Bg, "L": L, "z": z, "pk": pk}
+    u0, h0 = dense(z, pk["Wu"], pk["bu"], Bt, L, FEAT, ACT_SWISH, want_act=True)      # rows -> hw*256+c
     bn1, bn2, bn3 = (_bn_of(P, buf, k) for k in DEC_BN)
-    W1s = pack_conv(P["hallucinate.0.weight"], True)                          # [16][128 co][256 ci]
-    y1, st, T = tconv_s1p0(h0, W1s, G, Bg, 256, 128, stats=True)
+    y1, st, T = tconv_s1p0(h0, pk["W1s"], G, Bg, 256, 128, stats=True)        # W1s: [16][128 co][256 ci]
     a1, m1, r1 = bn_swish_from_partials(y1, st, T, bn1, G, Bg * 64, 128, repeat)
-    y2, st, T = conv_like(a1, pack_conv(P["hallucinate.3.weight"], True), TCONV_S2P1, G, Bg, 8, 128, 16, 64,
-                          stats=True)
+    y2, st, T = conv_like(a1, pk["W2s"], TCONV_S2P1, G, Bg, 8, 128, 16, 64, stats=True)
     a2, m2, r2 = bn_swish_from_partials(y2, st, T, bn2, G, Bg * 256, 64, repeat)
-    y3, st, T = conv_like(a2, pack_conv(P["hallucinate.6.weight"], True), TCONV_S2P1, G, Bg, 16, 64, 32, 32,
-                          stats=True)
+    y3, st, T = conv_like(a2, pk["W3s"], TCONV_S2P1, G, Bg, 16, 64, 32, 32, stats=True)
     a3, m3, r3 = bn_swish_from_partials(y3, st, T, bn3, G, Bg * 1024, 32, repeat)
     out = None
     if logits:
@@ -282,55 +379,47 @@ def decoder_forward(P, buf, z, G=1, repeat=1, logits=True):
 
 def decoder_backward(P, c, dlogits, grads, need_dz=True):
     """dlogits: NCHW [Bt,3,64,64] -> dz [Bt, L]; weight gradients into ``grads``."""
-    Bt, G, Bg, L = c["Bt"], c["G"], c["Bg"], c["L"]
+    Bt, G, Bg, L, pk = c["Bt"], c["G"], c["Bg"], c["L"], c["pk"]
     bn1, bn2, bn3 = c["bn"]
     # last layer backward: both GEMMs gather the k4 s2 p1 window of the NCHW logit gradient on the fly
     wgrad(c["a3"], dlogits, grads["hallucinate.9.weight"], IM2COL3, Bt, 32, 32, 64, 64, cg_canon=48)
-    W4p = repack(P["hallucinate.9.weight"], 32, 48, 32, 64, 0)
     da3 = _new(dlogits, Bt * 1024, 32)
-    ops.B.igemm_nt(dlogits, W4p, None, da3, None, None, None, IM2COL3, 1, Bt, 64, 64, 64, 32, 32, 32, 32, 1, 0,
+    ops.B.igemm_nt(dlogits, pk["W4p"], None, da3, None, None, None, IM2COL3, 1, Bt, 64, 64, 64, 32, 32, 32, 32, 1, 0,
                    ACT_NONE, 1)
     dy3 = bn_swish_backward(da3, c["y3"], c["m3"], c["r3"], bn3, grads["hallucinate.7.weight"],
                             grads["hallucinate.7.bias"], G, Bg * 1024, 32)
     wgrad(c["a2"], dy3, grads["hallucinate.6.weight"], CONV, Bt, 16, 64, 32, 32, 2, -1)
-    da2, _, _ = conv_like(dy3, pack_conv(P["hallucinate.6.weight"], False), CONV, 1, Bt, 32, 32, 16, 64, 2, -1)
+    da2, _, _ = conv_like(dy3, pk["W3k"], CONV, 1, Bt, 32, 32, 16, 64, 2, -1)
     dy2 = bn_swish_backward(da2, c["y2"], c["m2"], c["r2"], bn2, grads["hallucinate.4.weight"],
                             grads["hallucinate.4.bias"], G, Bg * 256, 64)
     wgrad(c["a1"], dy2, grads["hallucinate.3.weight"], CONV, Bt, 8, 128, 16, 64, 2, -1)
-    da1, _, _ = conv_like(dy2, pack_conv(P["hallucinate.3.weight"], False), CONV, 1, Bt, 16, 64, 8, 128, 2, -1)
+    da1, _, _ = conv_like(dy2, pk["W2k"], CONV, 1, Bt, 16, 64, 8, 128, 2, -1)
     dy1 = bn_swish_backward(da1, c["y1"], c["m1"], c["r1"], bn1, grads["hallucinate.1.weight"],
                             grads["hallucinate.1.bias"], G, Bg * 64, 128)
     wgrad(c["h0"], dy1, grads["hallucinate.0.weight"], CONV, Bt, 5, 256, 8, 128, 1, 0)
-    dh0, _, _ = conv_like(dy1, pack_conv(P["hallucinate.0.weight"], False), CONV, 1, Bt, 8, 128, 5, 256, 1, 0)
+    dh0, _, _ = conv_like(dy1, pk["W1k"], CONV, 1, Bt, 8, 128, 5, 256, 1, 0)
     du0 = act_backward(dh0, c["u0"], ACT_SWISH)
     wgrad(du0, c["z"], grads["upsample.0.weight"], DENSE, Bt, 1, FEAT, 1, L, perm=2)
     ops.B.colsum(du0, grads["upsample.0.bias"], Bt, FEAT, 2, 0.0)
     if not need_dz:
         return None
-    WuT = repack(P["upsample.0.weight"], FEAT, L, L, FEAT, 5)                # [L][hw*256+c]
-    dz, _ = dense(du0, WuT, None, Bt, FEAT, L)
+    dz, _ = dense(du0, pk["WuT"], None, Bt, FEAT, L)                         # WuT: [L][hw*256+c]
     return dz
 
 
 # ------------------------------------------------------------------------------------------------
 # fused heads (linear_means | linear_log_var) and the pose MLPs
 # ------------------------------------------------------------------------------------------------
-def heads_forward(P, hd):
+def heads_forward(P, hd, packed=None):
     """hd: [rows, 512] -> out [rows, 2L]: columns [0,L) = means, [L,2L) = log-variances."""
-    Wm, Wl = P["linear_means.weight"], P["linear_log_var.weight"]
-    L, K = Wm.shape
-    Wh = _new(hd, 2 * L, K)
-    ops.B.repack2d(Wm, Wh[:L], L, K, L, K, 0)
-    ops.B.repack2d(Wl, Wh[L:], L, K, L, K, 0)
-    bh = _new(hd, 2 * L)
-    ops.B.repack2d(P["linear_means.bias"], bh[:L], L, 1, L, 1, 0)
-    ops.B.repack2d(P["linear_log_var.bias"], bh[L:], L, 1, L, 1, 0)
-    out, _ = dense(hd, Wh, bh, hd.shape[0], K, 2 * L)
-    return out, {"hd": hd, "Wh": Wh, "L": L, "K": K}
+    L, K = P["linear_means.weight"].shape
+    pk = packed if packed is not None else pack_now(heads_pack_specs(P))
+    out, _ = dense(hd, pk["Wh"], pk["bh"], hd.shape[0], K, 2 * L)
+    return out, {"hd": hd, "pk": pk, "L": L, "K": K}
 
 
 def heads_backward(c, dout, grads, need_dx=True):
-    hd, Wh, L, K = c["hd"], c["Wh"], c["L"], c["K"]
+    hd, L, K = c["hd"], c["L"], c["K"]
     rows = hd.shape[0]
     gW, gb = _new(hd, 2 * L, K), _new(hd, 2 * L)
     wgrad(dout, hd, gW, DENSE, rows, 1, 2 * L, 1, K)
@@ -341,8 +430,7 @@ def heads_backward(c, dout, grads, need_dx=True):
     ops.B.repack2d(gb[L:], grads["linear_log_var.bias"], L, 1, L, 1, 0)
     if not need_dx:
         return None
-    WhT = repack(Wh, 2 * L, K, K, 2 * L, 1)
-    dx, _ = dense(dout, WhT, None, rows, 2 * L, K)
+    dx, _ = dense(dout, c["pk"]["WhT"], None, rows, 2 * L, K)
     return dx
 
 

@@ -88,6 +88,15 @@ class HipBackend:
         check(self.lib.mmdyn_repack2d(_ptr(src), _ptr(dst), rows_in, cols_in, rows_out, cols_out, mode, _stream()),
               "mmdyn_repack2d")
 
+    def repack2d_ld(self, src, dst, rows_in, cols_in, rows_out, cols_out, ld_out, mode):
+        """dst: any fp32 view whose first element is the block's top-left corner (row stride ld_out)."""
+        check(self.lib.mmdyn_repack2d_ld(_ptr(src), dst.data_ptr(), rows_in, cols_in, rows_out, cols_out, ld_out, mode,
+                                         _stream()), "mmdyn_repack2d_ld")
+
+    def pack_plan(self, plan_dev, n):
+        """plan_dev: uint8 device tensor holding n mmdyn_pack_entry structs (see layers.PackPlan)."""
+        check(self.lib.mmdyn_pack_plan(_ptr(plan_dev, torch.uint8), n, _stream()), "mmdyn_pack_plan")
+
     def im2col_nchw3(self, x, col, Bt, H, W):
         check(self.lib.mmdyn_im2col_nchw3(_ptr(x), _ptr(col), Bt, H, W, _stream()), "mmdyn_im2col_nchw3")
 

@@ -184,6 +184,17 @@ class EmuBackend:
         out[: m.shape[0], : m.shape[1]] = m
         dst.reshape(-1).copy_(out.reshape(-1))
 
+    def repack2d_ld(self, src, dst, rows_in, cols_in, rows_out, cols_out, ld_out, mode):
+        tmp = torch.zeros(rows_out, cols_out)
+        self.repack2d(src, tmp, rows_in, cols_in, rows_out, cols_out, mode)
+        flat = dst.reshape(-1) if dst.is_contiguous() else None
+        base = dst.storage_offset()
+        buf = torch.as_strided(dst, (rows_out, cols_out), (ld_out, 1), base)
+        buf.copy_(tmp)
+
+    def pack_plan(self, table, n):
+        raise NotImplementedError("the emulation runs pack specs one by one (layers.pack_now)")
+
     def im2col_nchw3(self, x, col, Bt, H, W):
         cols = F.unfold(x.reshape(Bt, 3, H, W), kernel_size=4, stride=2, padding=1)      # [Bt][48][Ho*Wo]
         out = torch.zeros(Bt * (H // 2) * (W // 2), 64)
