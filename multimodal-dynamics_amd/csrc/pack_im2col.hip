@@ -231,7 +231,7 @@ extern "C" int mmdyn_repack2d_ld(const float* in, float* out, int rows_in, int c
 extern "C" int mmdyn_pack_plan(const mmdyn_pack_entry* plan_dev, int n, void* stream) {
   if (!plan_dev) return MMDYN_ERR_NULL;
   if (n <= 0 || n > 65535) return MMDYN_ERR_SHAPE;
-  hipLaunchKernelGGL(pack_plan_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, plan_dev);
+  hipLaunchKernelGGL(pack_plan_kernel, dim3(512, n), dim3(256), 0, (hipStream_t)stream, plan_dev);
   MMDYN_LAUNCH_CHECK();
 }
 

@@ -200,18 +200,18 @@ class MVAEStep:
         # 2. per-pass dropout, batched;  3. heads (means | log_var fused), all passes of a modality in one GEMM
         LN = self.lanes
         LN.fork()
-        with LN.lane(0):
-            hv, c["ev"] = layers.encoder_trunk_forward(FP.sub("visual_encoder"), self._buffers("visual_encoder"), v, 1, nv,
-                                                       pk.get("ev"))
-            hdv = torch.empty(nv * B, 512, device=dev)
-            ops.B.dropout_expand(hv, mv, hdv, nv, B, 512, DROPOUT_P)
-            ov, c["hv"] = layers.heads_forward(FP.sub("visual_encoder"), hdv, pk.get("hv"))
-        with LN.lane(1):
-            ht, c["et"] = layers.encoder_trunk_forward(FP.sub("tactile_encoder"), self._buffers("tactile_encoder"), t, 1, nt,
-                                                       pk.get("et"))
-            hdt = torch.empty(nt * B, 512, device=dev)
-            ops.B.dropout_expand(ht, mt, hdt, nt, B, 512, DROPOUT_P)
-            ot, c["ht"] = layers.heads_forward(FP.sub("tactile_encoder"), hdt, pk.get("ht"))
+
+        def enc_job(prefix, x, masks, n, ek, hk):
+            h, ce = yield from layers.encoder_trunk_forward_steps(FP.sub(prefix), self._buffers(prefix), x, 1, n, pk.get(ek))
+            hd = torch.empty(n * B, 512, device=dev)
+            ops.B.dropout_expand(h, masks, hd, n, B, 512, DROPOUT_P)
+            out, ch = layers.heads_forward(FP.sub(prefix), hd, pk.get(hk))
+            return ce, out, ch
+
+        # the two modality lanes are enqueued layer by layer in alternation (layers.interleave)
+        (c["ev"], ov, c["hv"]), (c["et"], ot, c["ht"]) = layers.interleave([
+            (lambda: LN.lane(0), enc_job("visual_encoder", v, mv, nv, "ev", "hv")),
+            (lambda: LN.lane(1), enc_job("tactile_encoder", t, mt, nt, "et", "ht"))])
         op = None
         if self.use_pose:
             pose_rep = inputs[2].contiguous().repeat(npp, 1)                  # same pose rows for each pass
@@ -232,22 +232,20 @@ class MVAEStep:
         tv, tt = targets[0].contiguous(), targets[1].contiguous()
         inv_b = 1.0 / B
         LN.fork()
-        with LN.lane(0):
-            zv = torch.cat([z[p] for p in self.pass_v])
-            lg_v, c["dv"] = layers.decoder_forward(FP.sub("visual_decoder"), self._buffers("visual_decoder"), zv, nv,
-                                                   packed=pk.get("dv"))
-            dl_v = torch.empty_like(lg_v) if train else None
-            for g, p in enumerate(self.pass_v):
-                ops.B.bce_logits(lg_v[g * B:(g + 1) * B], tv, None, None if dl_v is None else dl_v[g * B:(g + 1) * B],
+
+        def dec_job(prefix, plist, tgt, dk):
+            zz = torch.cat([z[p] for p in plist])
+            lg, cd = yield from layers.decoder_forward_steps(FP.sub(prefix), self._buffers(prefix), zz, len(plist),
+                                                             packed=pk.get(dk))
+            dl = torch.empty_like(lg) if train else None
+            for g, p in enumerate(plist):
+                ops.B.bce_logits(lg[g * B:(g + 1) * B], tgt, None, None if dl is None else dl[g * B:(g + 1) * B],
                                  self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, inv_b)
-        with LN.lane(1):
-            zt = torch.cat([z[p] for p in self.pass_t])
-            lg_t, c["dt"] = layers.decoder_forward(FP.sub("tactile_decoder"), self._buffers("tactile_decoder"), zt, nt,
-                                                   packed=pk.get("dt"))
-            dl_t = torch.empty_like(lg_t) if train else None
-            for g, p in enumerate(self.pass_t):
-                ops.B.bce_logits(lg_t[g * B:(g + 1) * B], tt, None, None if dl_t is None else dl_t[g * B:(g + 1) * B],
-                                 self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, inv_b)
+            return lg, cd, dl
+
+        (lg_v, c["dv"], dl_v), (lg_t, c["dt"], dl_t) = layers.interleave([
+            (lambda: LN.lane(0), dec_job("visual_decoder", self.pass_v, tv, "dv")),
+            (lambda: LN.lane(1), dec_job("tactile_decoder", self.pass_t, tt, "dt"))])
         pr = None
         if self.use_pose:
             zp = torch.cat([z[p] for p in self.pass_p])
@@ -302,10 +300,11 @@ class MVAEStep:
             dzp = layers.pose_decoder_backward(FP.sub("pose_decoder"), c["dp"], c["dpr"], FP.sub("pose_decoder", "G"))
         LN = self.lanes
         LN.fork()
-        with LN.lane(0):
-            dzv = layers.decoder_backward(FP.sub("visual_decoder"), c["dv"], c["dl_v"], FP.sub("visual_decoder", "G"))
-        with LN.lane(1):
-            dzt = layers.decoder_backward(FP.sub("tactile_decoder"), c["dt"], c["dl_t"], FP.sub("tactile_decoder", "G"))
+        dzv, dzt = layers.interleave([
+            (lambda: LN.lane(0), layers.decoder_backward_steps(FP.sub("visual_decoder"), c["dv"], c["dl_v"],
+                                                               FP.sub("visual_decoder", "G"))),
+            (lambda: LN.lane(1), layers.decoder_backward_steps(FP.sub("tactile_decoder"), c["dt"], c["dl_t"],
+                                                               FP.sub("tactile_decoder", "G")))])
         LN.join()
         handles += self._reduce_bucket(0)
         # latent gradient sources per pass (summed inside the PoE backward kernel)
@@ -322,16 +321,17 @@ class MVAEStep:
         ops.B.poe_bwd(self._passes(c, B, [dov, dot, dop], blocks), c["eps"], c["mu"], c["lv"], None, None, None,
                       c["kl_weight"] / B, True, P, B, L)
         LN.fork()
-        with LN.lane(0):
-            dhdv = layers.heads_backward(c["hv"], dov, FP.sub("visual_encoder", "G"))
-            dhv = torch.empty(B, 512, device=dov.device)
-            ops.B.dropout_reduce(dhdv, c["mv"], dhv, len(self.pass_v), B, 512, DROPOUT_P)
-            layers.encoder_trunk_backward(FP.sub("visual_encoder"), c["ev"], dhv, FP.sub("visual_encoder", "G"))
-        with LN.lane(1):
-            dhdt = layers.heads_backward(c["ht"], dot, FP.sub("tactile_encoder", "G"))
-            dht = torch.empty(B, 512, device=dov.device)
-            ops.B.dropout_reduce(dhdt, c["mt"], dht, len(self.pass_t), B, 512, DROPOUT_P)
-            layers.encoder_trunk_backward(FP.sub("tactile_encoder"), c["et"], dht, FP.sub("tactile_encoder", "G"))
+
+        def enc_bwd_job(prefix, hk, ek, dout, masks, n):
+            dhd = layers.heads_backward(c[hk], dout, FP.sub(prefix, "G"))
+            dh = torch.empty(B, 512, device=dout.device)
+            ops.B.dropout_reduce(dhd, masks, dh, n, B, 512, DROPOUT_P)
+            yield
+            yield from layers.encoder_trunk_backward_steps(FP.sub(prefix), c[ek], dh, FP.sub(prefix, "G"))
+
+        layers.interleave([
+            (lambda: LN.lane(0), enc_bwd_job("visual_encoder", "hv", "ev", dov, c["mv"], len(self.pass_v))),
+            (lambda: LN.lane(1), enc_bwd_job("tactile_encoder", "ht", "et", dot, c["mt"], len(self.pass_t)))])
         if self.use_pose:
             dhp = layers.heads_backward(c["hp"], dop, FP.sub("pose_encoder", "G"))
             layers.pose_encoder_trunk_backward(FP.sub("pose_encoder"), c["ep"], dhp, FP.sub("pose_encoder", "G"))

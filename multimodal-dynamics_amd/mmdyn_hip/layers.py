@@ -294,8 +294,41 @@ def _bn_of(P, buf, pre):
                    b.get(pre + ".running_var"), b.get(pre + ".num_batches_tracked"))
 
 
-def encoder_trunk_forward(P, buf, x, G=1, repeat=1, packed=None):
-    """x: NCHW [Bt,3,64,64] -> h = Swish(fc(conv stack)) [Bt,512]; returns (h, ctx).
+def run(gen):
+    """Drive a stack generator to completion and return its result."""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        return e.value
+
+
+def interleave(jobs):
+    """jobs: list of (stream_context_factory, generator).  Advances the generators round-robin, one layer at a
+    time, each under its own stream context, so that the kernels of independent stacks are *enqueued* alternately
+    (host launches -- and the node order of a captured HIP graph -- then feed both lanes evenly instead of one
+    stack after the other).  Returns the generators' results in order."""
+    results = [None] * len(jobs)
+    live = list(range(len(jobs)))
+    while live:
+        for i in list(live):
+            ctx, gen = jobs[i]
+            with ctx():
+                try:
+                    next(gen)
+                except StopIteration as e:
+                    results[i] = e.value
+                    live.remove(i)
+    return results
+
+
+def encoder_trunk_forward(*a, **k):
+    return run(encoder_trunk_forward_steps(*a, **k))
+
+
+def encoder_trunk_forward_steps(P, buf, x, G=1, repeat=1, packed=None):
+    """x: NCHW [Bt,3,64,64] -> h = Swish(fc(conv stack)) [Bt,512]; returns (h, ctx).  Generator: yields after
+    every layer (see :func:`interleave`).
     ``repeat``: how many reference forward calls this one stands for (running-stat EMA updates).
     ``packed``: pre-packed weights (PackPlan); packed here, one kernel each, when absent."""
     Bt = x.shape[0]
@@ -307,20 +340,28 @@ def encoder_trunk_forward(P, buf, x, G=1, repeat=1, packed=None):
     # first layer: the k4 s2 p1 window of the NCHW image is gathered on the fly (no im2col matrix in HBM)
     ops.B.igemm_nt(x, W1p, None, u1, a1, None, None, IM2COL3, 1, Bt, 64, 64, 64, 32, 32, 32, 32, 1, 0,
                    ACT_SWISH, 1)
+    yield
     bn2, bn3, bn4 = (_bn_of(P, buf, k) for k in ENC_BN)
     y2, st, T = conv_like(a1, pk["W2k"], CONV, G, Bg, 32, 32, 16, 64, 2, -1, True)
     a2, m2, r2 = bn_swish_from_partials(y2, st, T, bn2, G, Bg * 256, 64, repeat)
+    yield
     y3, st, T = conv_like(a2, pk["W3k"], CONV, G, Bg, 16, 64, 8, 128, 2, -1, True)
     a3, m3, r3 = bn_swish_from_partials(y3, st, T, bn3, G, Bg * 64, 128, repeat)
+    yield
     y4, st, T = conv_like(a3, pk["W4k"], CONV, G, Bg, 8, 128, 5, 256, 1, 0, True)
     a4, m4, r4 = bn_swish_from_partials(y4, st, T, bn4, G, Bg * 25, 256, repeat)
+    yield
     u5, h = dense(a4, pk["Wf"], P["fc_net.0.bias"], Bt, FEAT, 512, ACT_SWISH, want_act=True)   # columns hw*256+c
     c.update(x=x, u1=u1, a1=a1, y2=y2, a2=a2, m2=m2, r2=r2, y3=y3, a3=a3, m3=m3, r3=r3, y4=y4, a4=a4,
              m4=m4, r4=r4, u5=u5, bn=(bn2, bn3, bn4))
     return h, c
 
 
-def encoder_trunk_backward(P, c, dh, grads):
+def encoder_trunk_backward(*a, **k):
+    return run(encoder_trunk_backward_steps(*a, **k))
+
+
+def encoder_trunk_backward_steps(P, c, dh, grads):
     """dh: [Bt,512]; writes every weight gradient of the trunk into ``grads[key]`` (canonical layout)."""
     Bt, G, Bg, pk = c["Bt"], c["G"], c["Bg"], c["pk"]
     bn2, bn3, bn4 = c["bn"]
@@ -328,18 +369,22 @@ def encoder_trunk_backward(P, c, dh, grads):
     wgrad(du5, c["a4"], grads["fc_net.0.weight"], DENSE, Bt, 1, 512, 1, FEAT, perm=1)
     ops.B.colsum(du5, grads["fc_net.0.bias"], Bt, 512, 0, 0.0)
     da4, _ = dense(du5, pk["WfT"], None, Bt, 512, FEAT)                      # WfT: [hw*256+c][512]
+    yield
     dy4 = bn_swish_backward(da4, c["y4"], c["m4"], c["r4"], bn4, grads["conv_net.9.weight"],
                             grads["conv_net.9.bias"], G, Bg * 25, 256)
     wgrad(dy4, c["a3"], grads["conv_net.8.weight"], CONV, Bt, 5, 256, 8, 128, 1, 0)
     da3 = tconv_s1p0(dy4, pk["W4s"], 1, Bt, 256, 128)[0]                     # W4s: [16][128 ci][256 co]
+    yield
     dy3 = bn_swish_backward(da3, c["y3"], c["m3"], c["r3"], bn3, grads["conv_net.6.weight"],
                             grads["conv_net.6.bias"], G, Bg * 64, 128)
     wgrad(dy3, c["a2"], grads["conv_net.5.weight"], CONV, Bt, 8, 128, 16, 64, 2, -1)
     da2, _, _ = conv_like(dy3, pk["W3s"], TCONV_S2P1, 1, Bt, 8, 128, 16, 64)
+    yield
     dy2 = bn_swish_backward(da2, c["y2"], c["m2"], c["r2"], bn2, grads["conv_net.3.weight"],
                             grads["conv_net.3.bias"], G, Bg * 256, 64)
     wgrad(dy2, c["a1"], grads["conv_net.2.weight"], CONV, Bt, 16, 64, 32, 32, 2, -1)
     da1, _, _ = conv_like(dy2, pk["W2s"], TCONV_S2P1, 1, Bt, 16, 64, 32, 32)
+    yield
     du1 = act_backward(da1, c["u1"], ACT_SWISH)
     wgrad(du1, c["x"], grads["conv_net.0.weight"], IM2COL3, Bt, 32, 32, 64, 64, cg_canon=48)
 
@@ -353,7 +398,11 @@ DEC_KEYS = ["upsample.0.weight", "upsample.0.bias", "hallucinate.0.weight", "hal
 DEC_BN = ["hallucinate.1", "hallucinate.4", "hallucinate.7"]
 
 
-def decoder_forward(P, buf, z, G=1, repeat=1, logits=True, packed=None):
+def decoder_forward(*a, **k):
+    return run(decoder_forward_steps(*a, **k))
+
+
+def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None):
     """z: [Bt, L] -> logits NCHW [Bt,3,64,64]; returns (logits, ctx).  ``logits=False`` stops after the last
     BatchNorm (used only to reproduce the running statistics of the reference's unused decoder passes)."""
     Bt, L = z.shape
@@ -361,13 +410,17 @@ def decoder_forward(P, buf, z, G=1, repeat=1, logits=True, packed=None):
     pk = packed if packed is not None else pack_now(decoder_pack_specs(P))
     c = {"Bt": Bt, "G": G, "Bg": Bg, "L": L, "z": z, "pk": pk}
     u0, h0 = dense(z, pk["Wu"], pk["bu"], Bt, L, FEAT, ACT_SWISH, want_act=True)      # rows -> hw*256+c
+    yield
     bn1, bn2, bn3 = (_bn_of(P, buf, k) for k in DEC_BN)
     y1, st, T = tconv_s1p0(h0, pk["W1s"], G, Bg, 256, 128, stats=True)        # W1s: [16][128 co][256 ci]
     a1, m1, r1 = bn_swish_from_partials(y1, st, T, bn1, G, Bg * 64, 128, repeat)
+    yield
     y2, st, T = conv_like(a1, pk["W2s"], TCONV_S2P1, G, Bg, 8, 128, 16, 64, stats=True)
     a2, m2, r2 = bn_swish_from_partials(y2, st, T, bn2, G, Bg * 256, 64, repeat)
+    yield
     y3, st, T = conv_like(a2, pk["W3s"], TCONV_S2P1, G, Bg, 16, 64, 32, 32, stats=True)
     a3, m3, r3 = bn_swish_from_partials(y3, st, T, bn3, G, Bg * 1024, 32, repeat)
+    yield
     out = None
     if logits:
         out = _new(z, Bt, 3, 64, 64)
@@ -377,7 +430,11 @@ def decoder_forward(P, buf, z, G=1, repeat=1, logits=True, packed=None):
     return out, c
 
 
-def decoder_backward(P, c, dlogits, grads, need_dz=True):
+def decoder_backward(*a, **k):
+    return run(decoder_backward_steps(*a, **k))
+
+
+def decoder_backward_steps(P, c, dlogits, grads, need_dz=True):
     """dlogits: NCHW [Bt,3,64,64] -> dz [Bt, L]; weight gradients into ``grads``."""
     Bt, G, Bg, L, pk = c["Bt"], c["G"], c["Bg"], c["L"], c["pk"]
     bn1, bn2, bn3 = c["bn"]
@@ -386,18 +443,22 @@ def decoder_backward(P, c, dlogits, grads, need_dz=True):
     da3 = _new(dlogits, Bt * 1024, 32)
     ops.B.igemm_nt(dlogits, pk["W4p"], None, da3, None, None, None, IM2COL3, 1, Bt, 64, 64, 64, 32, 32, 32, 32, 1, 0,
                    ACT_NONE, 1)
+    yield
     dy3 = bn_swish_backward(da3, c["y3"], c["m3"], c["r3"], bn3, grads["hallucinate.7.weight"],
                             grads["hallucinate.7.bias"], G, Bg * 1024, 32)
     wgrad(c["a2"], dy3, grads["hallucinate.6.weight"], CONV, Bt, 16, 64, 32, 32, 2, -1)
     da2, _, _ = conv_like(dy3, pk["W3k"], CONV, 1, Bt, 32, 32, 16, 64, 2, -1)
+    yield
     dy2 = bn_swish_backward(da2, c["y2"], c["m2"], c["r2"], bn2, grads["hallucinate.4.weight"],
                             grads["hallucinate.4.bias"], G, Bg * 256, 64)
     wgrad(c["a1"], dy2, grads["hallucinate.3.weight"], CONV, Bt, 8, 128, 16, 64, 2, -1)
     da1, _, _ = conv_like(dy2, pk["W2k"], CONV, 1, Bt, 16, 64, 8, 128, 2, -1)
+    yield
     dy1 = bn_swish_backward(da1, c["y1"], c["m1"], c["r1"], bn1, grads["hallucinate.1.weight"],
                             grads["hallucinate.1.bias"], G, Bg * 64, 128)
     wgrad(c["h0"], dy1, grads["hallucinate.0.weight"], CONV, Bt, 5, 256, 8, 128, 1, 0)
     dh0, _, _ = conv_like(dy1, pk["W1k"], CONV, 1, Bt, 8, 128, 5, 256, 1, 0)
+    yield
     du0 = act_backward(dh0, c["u0"], ACT_SWISH)
     wgrad(du0, c["z"], grads["upsample.0.weight"], DENSE, Bt, 1, FEAT, 1, L, perm=2)
     ops.B.colsum(du0, grads["upsample.0.bias"], Bt, FEAT, 2, 0.0)
