@@ -161,18 +161,25 @@ class MVAEStep:
         return self.noise
 
     def _draw(self, B, dev):
-        """eps [P][B][L] and the dropout keep-masks of the visual / tactile passes, consumed from the noise
-        source in the reference's call order (visual encoder, tactile encoder, then the latent draw)."""
+        """eps [P][B][L] and the dropout keep-masks of the visual / tactile passes.  An injected noise source is
+        consumed in the reference's call order (per pass: visual mask, tactile mask, latent draw); the on-device
+        Philox source draws each block with one launch."""
         n = self._noise()
-        eps, mv, mt = [], [], []
-        for a, b, _ in self.subsets:
-            if a:
-                mv.append(n.keep_mask((B, 512), dev))
-            if b:
-                mt.append(n.keep_mask((B, 512), dev))
-            eps.append(n.eps((B, self.L), dev))
+        nv, nt = len(self.pass_v), len(self.pass_t)
+        if hasattr(n, "_eps"):                       # InjectedNoise: keep the reference's interleaved order
+            eps, mv, mt = [], [], []
+            for a, b, _ in self.subsets:
+                if a:
+                    mv.append(n.keep_mask((B, 512), dev))
+                if b:
+                    mt.append(n.keep_mask((B, 512), dev))
+                eps.append(n.eps((B, self.L), dev))
+            return torch.stack(eps), torch.stack(mv), torch.stack(mt)
+        mv = n.mask_block(nv, B, 512, dev)
+        mt = n.mask_block(nt, B, 512, dev)
+        eps = n.eps_block(self.P, B, self.L, dev)
         n.commit()
-        return torch.stack(eps), torch.stack(mv), torch.stack(mt)
+        return eps, mv, mt
 
     def _buffers(self, prefix):
         mod = getattr(self.model, prefix)
@@ -188,17 +195,20 @@ class MVAEStep:
         v, t = inputs[0].contiguous(), inputs[1].contiguous()
         B, dev, L, P = v.shape[0], v.device, self.L, self.P
         FP = self.params
-        eps, mv, mt = self._draw(B, dev)
         nv, nt, npp = len(self.pass_v), len(self.pass_t), len(self.pass_p)
         pk = {}
+        LN = self.lanes
+        LN.fork()
         if self.plan is not None:
-            self.plan.run()
+            with LN.lane(1):                      # weight repack overlaps the noise draws of the main stream
+                self.plan.run()
             pk = self.plan.packed
+        eps, mv, mt = self._draw(B, dev)
+        LN.join()
         c = {"B": B, "eps": eps, "mv": mv, "mt": mt}
 
         # 1. encoder trunks, once per modality (running statistics: nv identical EMA updates, as in the reference)
         # 2. per-pass dropout, batched;  3. heads (means | log_var fused), all passes of a modality in one GEMM
-        LN = self.lanes
         LN.fork()
 
         def enc_job(prefix, x, masks, n, ek, hk):

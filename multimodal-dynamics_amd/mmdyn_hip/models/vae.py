@@ -132,6 +132,13 @@ class NoiseSource:
         self.offset += (out.numel() + 3) // 4
         return out
 
+    def eps_block(self, n, B, L, device):
+        """n independent [B, L] draws as one [n, B, L] tensor, one launch."""
+        return self.eps((n, B, L), device)
+
+    def mask_block(self, n, B, H, device):
+        return self.keep_mask((n, B, H), device)
+
     def commit(self):
         """Move the draws made since the previous commit from the host offset into the device counter."""
         if self.base is not None and self.offset > self._mark:
@@ -154,6 +161,12 @@ class InjectedNoise:
         m = self._masks.pop(0)
         assert tuple(m.shape) == tuple(shape), (m.shape, shape)
         return m.to(device=device, dtype=torch.uint8).contiguous()
+
+    def eps_block(self, n, B, L, device):
+        return torch.stack([self.eps((B, L), device) for _ in range(n)])
+
+    def mask_block(self, n, B, H, device):
+        return torch.stack([self.keep_mask((B, H), device) for _ in range(n)])
 
     def commit(self):
         pass
