@@ -18,6 +18,8 @@
 //   * epilogue: optional bias, optional second (activated) output, optional per-tile BatchNorm
 //     partial sums (column sums of the tile and of its squares), deterministic (no atomics).
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -399,6 +401,13 @@ static void pick_tile(int N, int rows_per_group, int G, int ncls, int splitk, in
   }
   *bm = cand[best][0];
   *bn = cand[best][1];
+  if (const char* ov = getenv("MMDYN_IGEMM_TILE")) {   // kernel experiments only
+    int a = 0, b = 0;
+    if (sscanf(ov, "%d,%d", &a, &b) == 2 && N % b == 0) {
+      *bm = a;
+      *bn = b;
+    }
+  }
 }
 
 template <int MODE, int BM, int BN, int WM, int WN>
