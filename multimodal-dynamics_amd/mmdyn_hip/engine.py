@@ -186,98 +186,172 @@ class MVAEStep:
         return mod.bn_buffers()
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, inputs, targets, kl_weight, train=True):
-        """Runs the forward schedule and the loss; with train=True also fills the loss gradients needed by
-        :meth:`backward`.  Returns the device scalar loss (fp32)."""
+    # The step is cut into PHASES.  A phase issues kernels on whatever stream is current; "steps" phases are
+    # generators yielding after every layer so that two of them can be enqueued in alternation
+    # (layers.interleave).  forward()/backward() run them eagerly over the lanes; train_step_graphed() captures
+    # each phase into its own HIP graph and replays the visual / tactile phases concurrently on two streams.
+    # ------------------------------------------------------------------------------------------
+    _MOD = {"v": ("visual_encoder", "visual_decoder", 0), "t": ("tactile_encoder", "tactile_decoder", 1)}
+
+    def _begin(self, inputs, targets, kl_weight, train):
         if not self.params.still_attached():
             raise RuntimeError("model parameters were re-allocated (e.g. .to()/.cuda() after MVAEStep was built); "
                                "construct MVAEStep after moving the model")
-        v, t = inputs[0].contiguous(), inputs[1].contiguous()
-        B, dev, L, P = v.shape[0], v.device, self.L, self.P
-        FP = self.params
-        nv, nt, npp = len(self.pass_v), len(self.pass_t), len(self.pass_p)
-        pk = {}
-        LN = self.lanes
+        v = inputs[0].contiguous()
+        self.ctx = {"B": v.shape[0], "dev": v.device, "x": {"v": v, "t": inputs[1].contiguous()},
+                    "tg": {"v": targets[0].contiguous(), "t": targets[1].contiguous()},
+                    "pose": inputs[2].contiguous() if self.use_pose else None,
+                    "pose_tg": targets[2].contiguous() if self.use_pose else None,
+                    "kl_weight": float(kl_weight), "train": train, "pk": {}}
+
+    def _passes_of(self, m):
+        return self.pass_v if m == "v" else self.pass_t
+
+    def _ph_pre(self):
+        """Weight repack (one launch, side lane) overlapped with the noise draws."""
+        c, LN = self.ctx, self.lanes
         LN.fork()
         if self.plan is not None:
-            with LN.lane(1):                      # weight repack overlaps the noise draws of the main stream
+            with LN.lane(1):
                 self.plan.run()
-            pk = self.plan.packed
-        eps, mv, mt = self._draw(B, dev)
+            c["pk"] = self.plan.packed
+        c["eps"], mv, mt = self._draw(c["B"], c["dev"])
+        c["mask"] = {"v": mv, "t": mt}
         LN.join()
-        c = {"B": B, "eps": eps, "mv": mv, "mt": mt}
-
-        # 1. encoder trunks, once per modality (running statistics: nv identical EMA updates, as in the reference)
-        # 2. per-pass dropout, batched;  3. heads (means | log_var fused), all passes of a modality in one GEMM
-        LN.fork()
-
-        def enc_job(prefix, x, masks, n, ek, hk):
-            h, ce = yield from layers.encoder_trunk_forward_steps(FP.sub(prefix), self._buffers(prefix), x, 1, n, pk.get(ek))
-            hd = torch.empty(n * B, 512, device=dev)
-            ops.B.dropout_expand(h, masks, hd, n, B, 512, DROPOUT_P)
-            out, ch = layers.heads_forward(FP.sub(prefix), hd, pk.get(hk))
-            return ce, out, ch
-
-        # the two modality lanes are enqueued layer by layer in alternation (layers.interleave)
-        (c["ev"], ov, c["hv"]), (c["et"], ot, c["ht"]) = layers.interleave([
-            (lambda: LN.lane(0), enc_job("visual_encoder", v, mv, nv, "ev", "hv")),
-            (lambda: LN.lane(1), enc_job("tactile_encoder", t, mt, nt, "et", "ht"))])
-        op = None
-        if self.use_pose:
-            pose_rep = inputs[2].contiguous().repeat(npp, 1)                  # same pose rows for each pass
-            hp, c["ep"] = layers.pose_encoder_trunk_forward(FP.sub("pose_encoder"), pose_rep)
-            op, c["hp"] = layers.heads_forward(FP.sub("pose_encoder"), hp, pk.get("hp"))
-        LN.join()
-        c["ov"], c["ot"], c["op"] = ov, ot, op
-        # 4. product of experts + reparametrisation + KL for every pass
-        mu = torch.empty(P, B, L, device=dev)
-        lv = torch.empty(P, B, L, device=dev)
-        z = torch.empty(P, B, L, device=dev)
         self.acc.zero_()
-        ops.B.poe_fwd(self._passes(c, B, None), eps, mu, lv, z, self.acc[2], True, P, B, L)
-        c["mu"], c["lv"] = mu, lv
-        # 5. decoders on their live passes (groups)
-        # 6. reconstruction terms (+ their gradients when training) follow each decoder on its lane
+
+    def _ph_enc_steps(self, m):
+        """Encoder trunk once per modality; per-pass dropout batched; fused heads for all passes of the modality."""
+        c, FP, B = self.ctx, self.params, self.ctx["B"]
+        enc = self._MOD[m][0]
+        n = len(self._passes_of(m))
+        h, c["e" + m] = yield from layers.encoder_trunk_forward_steps(FP.sub(enc), self._buffers(enc), c["x"][m], 1, n,
+                                                                     c["pk"].get("e" + m))
+        hd = torch.empty(n * B, 512, device=c["dev"])
+        ops.B.dropout_expand(h, c["mask"][m], hd, n, B, 512, DROPOUT_P)
+        c["o" + m], c["h" + m] = layers.heads_forward(FP.sub(enc), hd, c["pk"].get("h" + m))
+
+    def _ph_pose_enc(self):
+        c, FP = self.ctx, self.params
+        c["op"] = None
+        if self.use_pose:
+            pose_rep = c["pose"].repeat(len(self.pass_p), 1)                  # same pose rows for each pass
+            hp, c["ep"] = layers.pose_encoder_trunk_forward(FP.sub("pose_encoder"), pose_rep)
+            c["op"], c["hp"] = layers.heads_forward(FP.sub("pose_encoder"), hp, c["pk"].get("hp"))
+
+    def _ph_poe(self):
+        """Product of experts + reparametrisation + KL for every pass, one launch."""
+        c, B, L, P, dev = self.ctx, self.ctx["B"], self.L, self.P, self.ctx["dev"]
+        c["mu"], c["lv"], c["z"] = (torch.empty(P, B, L, device=dev) for _ in range(3))
+        ops.B.poe_fwd(self._passes(c, B, None), c["eps"], c["mu"], c["lv"], c["z"], self.acc[2], True, P, B, L)
+
+    def _ph_dec_fwd_steps(self, m):
+        """Image decoder on its live passes (groups) followed by the BCE sums (+ logit gradients when training)."""
+        c, FP, B = self.ctx, self.params, self.ctx["B"]
+        dec, plist = self._MOD[m][1], self._passes_of(m)
+        zz = torch.cat([c["z"][p] for p in plist])
+        lg, c["d" + m] = yield from layers.decoder_forward_steps(FP.sub(dec), self._buffers(dec), zz, len(plist),
+                                                                 packed=c["pk"].get("d" + m))
+        dl = torch.empty_like(lg) if c["train"] else None
         n_img = B * 3 * 64 * 64
-        tv, tt = targets[0].contiguous(), targets[1].contiguous()
-        inv_b = 1.0 / B
-        LN.fork()
+        for g, p in enumerate(plist):
+            ops.B.bce_logits(lg[g * B:(g + 1) * B], c["tg"][m], None, None if dl is None else dl[g * B:(g + 1) * B],
+                             self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, 1.0 / B)
+        c["lg" + m], c["dl" + m] = lg, dl
 
-        def dec_job(prefix, plist, tgt, dk):
-            zz = torch.cat([z[p] for p in plist])
-            lg, cd = yield from layers.decoder_forward_steps(FP.sub(prefix), self._buffers(prefix), zz, len(plist),
-                                                             packed=pk.get(dk))
-            dl = torch.empty_like(lg) if train else None
-            for g, p in enumerate(plist):
-                ops.B.bce_logits(lg[g * B:(g + 1) * B], tgt, None, None if dl is None else dl[g * B:(g + 1) * B],
-                                 self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, inv_b)
-            return lg, cd, dl
-
-        (lg_v, c["dv"], dl_v), (lg_t, c["dt"], dl_t) = layers.interleave([
-            (lambda: LN.lane(0), dec_job("visual_decoder", self.pass_v, tv, "dv")),
-            (lambda: LN.lane(1), dec_job("tactile_decoder", self.pass_t, tt, "dt"))])
-        pr = None
+    def _ph_pose_dec_fwd(self):
+        c, FP, B = self.ctx, self.params, self.ctx["B"]
+        c["pr"], c["dpr"] = None, None
         if self.use_pose:
-            zp = torch.cat([z[p] for p in self.pass_p])
+            zp = torch.cat([c["z"][p] for p in self.pass_p])
             pr, c["dp"] = layers.pose_decoder_forward(FP.sub("pose_decoder"), zp)
-        dpr = None
-        if self.use_pose:
-            tp = targets[2].contiguous()
-            dpr = torch.empty_like(pr) if train else None
+            dpr = torch.empty_like(pr) if c["train"] else None
             for g, p in enumerate(self.pass_p):
-                ops.B.mse(pr[g * B:(g + 1) * B], tp, None if dpr is None else dpr[g * B:(g + 1) * B],
-                          self.acc[1, p:p + 1], B * 7, self.pose_multiplier * inv_b)
-        LN.join()
-        ops.B.elbo_assemble(self.acc[0], self.acc[1], self.acc[2], self.loss, self.partials, P, B, kl_weight,
-                            self.pose_multiplier)
-        c.update(dl_v=dl_v, dl_t=dl_t, dpr=dpr, kl_weight=kl_weight)
-        self.ctx = c
+                ops.B.mse(pr[g * B:(g + 1) * B], c["pose_tg"], None if dpr is None else dpr[g * B:(g + 1) * B],
+                          self.acc[1, p:p + 1], B * 7, self.pose_multiplier / B)
+            c["pr"], c["dpr"] = pr, dpr
+
+    def _ph_assemble(self):
+        c = self.ctx
+        ops.B.elbo_assemble(self.acc[0], self.acc[1], self.acc[2], self.loss, self.partials, self.P, c["B"],
+                            c["kl_weight"], self.pose_multiplier)
+
+    def _ph_dec_bwd_steps(self, m):
+        c, FP = self.ctx, self.params
+        dec = self._MOD[m][1]
+        c["dz" + m] = yield from layers.decoder_backward_steps(FP.sub(dec), c["d" + m], c["dl" + m], FP.sub(dec, "G"))
+
+    def _ph_pose_dec_bwd(self):
+        c, FP = self.ctx, self.params
+        c["dzp"] = None
+        if self.use_pose:
+            c["dzp"] = layers.pose_decoder_backward(FP.sub("pose_decoder"), c["dp"], c["dpr"], FP.sub("pose_decoder", "G"))
+
+    def _ph_poe_bwd(self):
+        """Latent gradients of every pass (summed over the decoders that consumed z) through PoE / KL."""
+        c, B, L, P = self.ctx, self.ctx["B"], self.L, self.P
+        blocks = [[None, None, None] for _ in range(P)]
+        for g, p in enumerate(self.pass_v):
+            blocks[p][0] = c["dzv"][g * B:(g + 1) * B]
+        for g, p in enumerate(self.pass_t):
+            blocks[p][1] = c["dzt"][g * B:(g + 1) * B]
+        if self.use_pose:
+            for g, p in enumerate(self.pass_p):
+                blocks[p][2] = c["dzp"][g * B:(g + 1) * B]
+        c["dov"], c["dot"] = torch.empty_like(c["ov"]), torch.empty_like(c["ot"])
+        c["dop"] = torch.empty_like(c["op"]) if self.use_pose else None
+        ops.B.poe_bwd(self._passes(c, B, [c["dov"], c["dot"], c["dop"]], blocks), c["eps"], c["mu"], c["lv"], None, None,
+                      None, c["kl_weight"] / B, True, P, B, L)
+
+    def _ph_enc_bwd_steps(self, m):
+        c, FP, B = self.ctx, self.params, self.ctx["B"]
+        enc = self._MOD[m][0]
+        dhd = layers.heads_backward(c["h" + m], c["do" + m], FP.sub(enc, "G"))
+        dh = torch.empty(B, 512, device=c["dev"])
+        ops.B.dropout_reduce(dhd, c["mask"][m], dh, len(self._passes_of(m)), B, 512, DROPOUT_P)
+        yield
+        yield from layers.encoder_trunk_backward_steps(FP.sub(enc), c["e" + m], dh, FP.sub(enc, "G"))
+
+    def _ph_pose_enc_bwd(self):
+        c, FP = self.ctx, self.params
+        if self.use_pose:
+            dhp = layers.heads_backward(c["hp"], c["dop"], FP.sub("pose_encoder", "G"))
+            layers.pose_encoder_trunk_backward(FP.sub("pose_encoder"), c["ep"], dhp, FP.sub("pose_encoder", "G"))
+
+    def _publish(self):
+        c, B, P = self.ctx, self.ctx["B"], self.P
         joint = self.subsets.index((1, 1, 1)) if self.use_pose else 0
         gv, gt = self.pass_v.index(joint), self.pass_t.index(joint)
-        self.last = {"recon_x": [lg_v[gv * B:(gv + 1) * B], lg_t[gt * B:(gt + 1) * B]] +
-                     ([pr[self.pass_p.index(joint) * B:(self.pass_p.index(joint) + 1) * B]] if self.use_pose else []),
-                     "means": mu[P - 1], "log_var": lv[P - 1],
-                     "logits_v": lg_v, "logits_t": lg_t, "pose_recon": pr}
+        recon = [c["lgv"][gv * B:(gv + 1) * B], c["lgt"][gt * B:(gt + 1) * B]]
+        if self.use_pose:
+            gp = self.pass_p.index(joint)
+            recon.append(c["pr"][gp * B:(gp + 1) * B])
+        self.last = {"recon_x": recon, "means": c["mu"][P - 1], "log_var": c["lv"][P - 1],
+                     "logits_v": c["lgv"], "logits_t": c["lgt"], "pose_recon": c["pr"]}
+
+    def _two(self, phase):
+        """Run a per-modality steps-phase for both modalities, lane 0 / lane 1, enqueued in alternation."""
+        LN = self.lanes
+        layers.interleave([(lambda: LN.lane(0), phase("v")), (lambda: LN.lane(1), phase("t"))])
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, inputs, targets, kl_weight, train=True):
+        """Runs the forward schedule and the loss; with train=True also fills the loss gradients needed by
+        :meth:`backward`.  Returns the device scalar loss (fp32)."""
+        LN = self.lanes
+        self._begin(inputs, targets, kl_weight, train)
+        self._ph_pre()
+        LN.fork()
+        self._two(self._ph_enc_steps)
+        self._ph_pose_enc()
+        LN.join()
+        self._ph_poe()
+        LN.fork()
+        self._two(self._ph_dec_fwd_steps)
+        self._ph_pose_dec_fwd()
+        LN.join()
+        self._ph_assemble()
+        self._publish()
         return self.loss
 
     def _passes(self, c, B, dheads, dz_blocks=None):
@@ -303,48 +377,17 @@ class MVAEStep:
     # ------------------------------------------------------------------------------------------
     def backward(self):
         """Reverse schedule; fills the flat gradient buffer.  Returns async all-reduce handles (if any)."""
-        c, FP, B, L, P = self.ctx, self.params, self.ctx["B"], self.L, self.P
-        handles = []
-        dzp = None
-        if self.use_pose:
-            dzp = layers.pose_decoder_backward(FP.sub("pose_decoder"), c["dp"], c["dpr"], FP.sub("pose_decoder", "G"))
         LN = self.lanes
+        handles = []
+        self._ph_pose_dec_bwd()
         LN.fork()
-        dzv, dzt = layers.interleave([
-            (lambda: LN.lane(0), layers.decoder_backward_steps(FP.sub("visual_decoder"), c["dv"], c["dl_v"],
-                                                               FP.sub("visual_decoder", "G"))),
-            (lambda: LN.lane(1), layers.decoder_backward_steps(FP.sub("tactile_decoder"), c["dt"], c["dl_t"],
-                                                               FP.sub("tactile_decoder", "G")))])
+        self._two(self._ph_dec_bwd_steps)
         LN.join()
         handles += self._reduce_bucket(0)
-        # latent gradient sources per pass (summed inside the PoE backward kernel)
-        blocks = [[None, None, None] for _ in range(P)]
-        for g, p in enumerate(self.pass_v):
-            blocks[p][0] = dzv[g * B:(g + 1) * B]
-        for g, p in enumerate(self.pass_t):
-            blocks[p][1] = dzt[g * B:(g + 1) * B]
-        if self.use_pose:
-            for g, p in enumerate(self.pass_p):
-                blocks[p][2] = dzp[g * B:(g + 1) * B]
-        dov, dot = torch.empty_like(c["ov"]), torch.empty_like(c["ot"])
-        dop = torch.empty_like(c["op"]) if self.use_pose else None
-        ops.B.poe_bwd(self._passes(c, B, [dov, dot, dop], blocks), c["eps"], c["mu"], c["lv"], None, None, None,
-                      c["kl_weight"] / B, True, P, B, L)
+        self._ph_poe_bwd()
         LN.fork()
-
-        def enc_bwd_job(prefix, hk, ek, dout, masks, n):
-            dhd = layers.heads_backward(c[hk], dout, FP.sub(prefix, "G"))
-            dh = torch.empty(B, 512, device=dout.device)
-            ops.B.dropout_reduce(dhd, masks, dh, n, B, 512, DROPOUT_P)
-            yield
-            yield from layers.encoder_trunk_backward_steps(FP.sub(prefix), c[ek], dh, FP.sub(prefix, "G"))
-
-        layers.interleave([
-            (lambda: LN.lane(0), enc_bwd_job("visual_encoder", "hv", "ev", dov, c["mv"], len(self.pass_v))),
-            (lambda: LN.lane(1), enc_bwd_job("tactile_encoder", "ht", "et", dot, c["mt"], len(self.pass_t)))])
-        if self.use_pose:
-            dhp = layers.heads_backward(c["hp"], dop, FP.sub("pose_encoder", "G"))
-            layers.pose_encoder_trunk_backward(FP.sub("pose_encoder"), c["ep"], dhp, FP.sub("pose_encoder", "G"))
+        self._two(self._ph_enc_bwd_steps)
+        self._ph_pose_enc_bwd()
         LN.join()
         handles += self._reduce_bucket(1)
         handles += self._reduce_bucket(2)
@@ -375,11 +418,14 @@ class MVAEStep:
 
     # ------------------------------------------------------------------------------------------
     def train_step_graphed(self, inputs, targets, kl_weight):
-        """Same as :meth:`train_step`, replayed from a HIP graph: the ~330 kernel launches of a step (both lanes)
-        are captured once per (batch shape, kl_weight) and re-issued with one graph launch, which removes the host
-        launch path from the critical path.  Inputs are copied into the graph's static buffers; random draws
-        advance through a device-side counter, Adam's step count lives on the device, so replays are real steps.
-        With more than one rank the gradient all-reduce and Adam run after the graph (one bucket)."""
+        """Same as :meth:`train_step`, replayed from HIP graphs: the ~300 kernel launches of a step are captured
+        once per (batch shape, kl_weight).  Each phase is its OWN graph: the visual and the tactile phases are
+        linear kernel chains that are launched concurrently on two streams (a single graph with parallel branches
+        was measured to run its branches mostly one after the other), the joint phases run on the caller's stream.
+        Each lane captures into its own memory pool, so concurrently replayed graphs never share scratch memory.
+        Inputs are copied into static buffers; random draws advance through a device-side counter and Adam's step
+        count lives on the device, so every replay is a real optimiser step.  With more than one rank the gradient
+        all-reduce and Adam run after the graphs."""
         key = (tuple(tuple(x.shape) for x in inputs), float(kl_weight))
         if self._graph is None or self._graph[0] != key:
             self._static_in = [x.clone() for x in inputs]
@@ -389,31 +435,78 @@ class MVAEStep:
             with torch.cuda.stream(side):                      # warm-up outside capture (allocator, lazy init)
                 self.train_step(self._static_in, self._static_tg, kl_weight)
             torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            self._capturing = True
-            try:
-                with torch.cuda.graph(g):
-                    self.forward(self._static_in, self._static_tg, kl_weight, train=True)
-                    self.backward()
-                    if self.world <= 1:
-                        self.optimizer_step(())
-            finally:
-                self._capturing = False
-            self._graph = (key, g)
-            # the warm-up above WAS this call's optimiser step (the capture itself executes nothing)
-            return self.loss
-        for dst, src in zip(self._static_in, inputs):
+            self._graph = (key, self._capture(kl_weight))
+            return self.loss             # the warm-up above WAS this call's optimiser step
+        for dst, src in zip(self._static_in + self._static_tg, list(inputs) + list(targets)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
-        for dst, src in zip(self._static_tg, targets):
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src)
-        self._graph[1].replay()
+        self._replay(self._graph[1])
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.params.grad, group=self.pg)
             self.optimizer_step(())
         return self.loss
+
+    def _capture(self, kl_weight):
+        LN = self.lanes
+        run = layers.run
+        stages = [
+            [("main", lambda: self._ph_pre())],
+            [("l0", lambda: run(self._ph_enc_steps("v"))), ("l1", lambda: run(self._ph_enc_steps("t"))),
+             ("main", lambda: self._ph_pose_enc())],
+            [("main", lambda: self._ph_poe())],
+            [("l0", lambda: (run(self._ph_dec_fwd_steps("v")), run(self._ph_dec_bwd_steps("v")))),
+             ("l1", lambda: (run(self._ph_dec_fwd_steps("t")), run(self._ph_dec_bwd_steps("t")))),
+             ("main", lambda: (self._ph_pose_dec_fwd(), self._ph_pose_dec_bwd()))],
+            [("main", lambda: (self._ph_assemble(), self._ph_poe_bwd()))],
+            [("l0", lambda: run(self._ph_enc_bwd_steps("v"))), ("l1", lambda: run(self._ph_enc_bwd_steps("t"))),
+             ("main", lambda: self._ph_pose_enc_bwd())],
+        ]
+        if self.world <= 1:
+            stages.append([("main", lambda: self.optimizer_step(()))])
+        cap_stream = {"main": torch.cuda.Stream(), "l0": LN.side[0], "l1": LN.side[1]}
+        pools = {k: torch.cuda.graph_pool_handle() for k in cap_stream}
+        self._capturing = True
+        lanes_on, LN.on = LN.on, False            # inside a lane graph everything stays on the capture stream ...
+        captured = []
+        try:
+            self._begin(self._static_in, self._static_tg, kl_weight, True)
+            for stage in stages:
+                row = []
+                for lane, fn in stage:
+                    g = torch.cuda.CUDAGraph()
+                    LN.on = lanes_on and lane == "main" and fn is stages[0][0][1]   # ... except the pre-phase fork
+                    with torch.cuda.graph(g, pool=pools[lane], stream=cap_stream[lane]):
+                        fn()
+                    row.append((lane, g))
+                captured.append(row)
+            self._publish()
+        finally:
+            self._capturing = False
+            LN.on = lanes_on
+            self.ctx = None
+        return captured
+
+    def _replay(self, captured):
+        LN = self.lanes
+        main = torch.cuda.current_stream()
+        side = {"l0": LN.side[0], "l1": LN.side[1]}
+        for row in captured:
+            if len(row) == 1:
+                row[0][1].replay()
+                continue
+            ev = main.record_event()
+            for lane, g in row:
+                if lane != "main":
+                    side[lane].wait_event(ev)
+                    with torch.cuda.stream(side[lane]):
+                        g.replay()
+            for lane, g in row:
+                if lane == "main":
+                    g.replay()
+            for lane, g in row:
+                if lane != "main":
+                    main.wait_event(side[lane].record_event())
 
     @torch.no_grad()
     def eval_step(self, inputs, targets, kl_weight):
