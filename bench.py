@@ -27,6 +27,20 @@ ALGO_GFLOP_PER_SAMPLE = 2.024      # distinct contractio
 KL_WEIGHT = 1.0 / 50               # epoch 0 of the reference's annealing schedule (problems.py:212-216)
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled
+    per the gfx950 correction + WRITE_SIZE; profiles/r1/igemm_traffic_pmc.json).  PMC counters cannot be read from
+    inside this process, so the value is the last profiled one, or None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r1", "igemm_traffic_pmc.json")
+    try:
+        d = json.load(open(path))
+        if kernel.startswith(d["kernel"].split(" ")[0]):
+            return d["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def host_cpu_share():
     """CPU threads this process may really use: the cgroup quota if there is one, else the affinity mask."""
     n = len(os.sched_getaffinity(0))
@@ -93,6 +107,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a HIP graph")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--single-lane", action="store_true",
+                    help="no visual/tactile stream overlap: per-kernel durations in a rocprofv3 trace then match "
+                         "the roofline object's live HIP-event measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,7 +135,7 @@ def main():
     model = setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=4096, architecture="cnn",
                         conditional=False, categorical_conditions=False, latent_size=256, use_pose=True).to(dev).train()
     step = MVAEStep(model, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), process_group=pg,
-                    world_size=world)
+                    world_size=world, two_lanes=not args.single_lane)
     inputs, targets = seeded_batch(args.batch, 1234 + rank)
     inputs, targets = [x.to(dev) for x in inputs], [x.to(dev) for x in targets]
 
@@ -181,7 +198,9 @@ def main():
                    "launch": "eager" if args.no_graph else "hip_graph",
                    "final_loss": final_loss},
         "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom_name),
+                     "algorithmic_flops_per_launch": dom["flops"] / max(dom["calls"], 1),
+                     "operand_bytes_per_launch": dom["bytes"] / max(dom["calls"], 1),
                      "launches_per_step": dom["calls"], "avg_launch_ms": dom["ms"] / max(dom["calls"], 1),
                      "kernel_share_of_step": dom["ms"] / total_ms if total_ms else None,
                      "step_algorithmic_tflops": sps / world * ALGO_GFLOP_PER_SAMPLE * 1e9 / 1e12,
