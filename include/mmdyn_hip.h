@@ -173,8 +173,10 @@ int mmdyn_random_masks(uint8_t* masks, int64_t n, float p_drop, uint64_t seed, u
 int mmdyn_random_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                         void* stream);
 int mmdyn_counter_add(uint64_t* counter, uint64_t inc, void* stream);
-/* out[c] (+)= sum_r x[r][c]   (bias gradients) */
-int mmdyn_colsum(const float* x, float* out, int rows, int C, int perm, float beta, void* stream);
+/* out[c] (+)= sum_r x[r][c]   (bias gradients); deterministic two-stage sum, scratch holds
+ * mmdyn_colsum_chunks(rows) * C floats; perm 2 = the upsample-bias permutation hw*256+c -> c*25+hw; C % 4 == 0 */
+int mmdyn_colsum(const float* x, float* out, float* scratch, int rows, int C, int perm, float beta, void* stream);
+int mmdyn_colsum_chunks(int rows);
 /* out = x * s[0], s in device memory (chain rule through a scalar loss term without a host sync) */
 int mmdyn_scale_dev(const float* x, const float* s, float* out, int64_t n, void* stream);
 /* sum of P row blocks: out[b][:] = sum_p x[p][b][:] */

@@ -128,28 +128,52 @@ __global__ void counter_add_kernel(uint64_t* __restrict__ c, uint64_t inc) {
   if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += inc;
 }
 
-// out[c] (+)= sum_r x[r][c]; 32 channels per block, 8 row lanes
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                     int rows, int C, int perm, float beta) {
-  __shared__ float red[8][32];
+// out[c] (+)= sum_r x[r][c], two deterministic stages.  Stage 1: grid (C/128, chunks); a block covers 128 channels
+// (32 float4 columns) x one row chunk with 8 row lanes, 4 rows in flight per thread, LDS finish -> partial[chunk][C].
+// Stage 2 adds the chunks (and applies the upsample-bias row permutation).  C % 4 == 0.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                             int rows, int C, int rows_per_chunk) {
+  __shared__ f32x4 red[8][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  float s = 0.f;
-  if (c < C)
-    for (int r = rl; r < rows; r += 8) s += x[(size_t)r * C + c];
+  const int c4 = blockIdx.x * 32 + cl;                     // float4 column
+  const int CV = C >> 2;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < CV) {
+    for (int r = r0 + rl; r < r1; r += 32) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + 8 * u;
+        v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(rr < r1 ? rr : r) * C + c4 * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + 8 * u < r1) s += v[u];
+    }
+  }
   red[rl][cl] = s;
   __syncthreads();
-  if (threadIdx.x < 32 && c < C) {
-    float t = 0.f;
+  if (rl == 0 && c4 < CV) {
+    f32x4 t = red[0][cl];
 #pragma unroll
-    for (int l = 0; l < 8; ++l) t += red[l][cl];
-    int o = c;
-    if (perm == 2) {
-      int hw = c / 256, ch = c - hw * 256;
-      o = ch * 25 + hw;
-    }
-    out[o] = (beta != 0.f ? beta * out[o] : 0.f) + t;
+    for (int l = 1; l < 8; ++l) t += red[l][cl];
+    *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * C + c4 * 4) = t;
   }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int chunks, int C,
+                                    int perm, float beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t = 0.f;
+  for (int k = 0; k < chunks; ++k) t += partial[(size_t)k * C + c];
+  int o = c;
+  if (perm == 2) {
+    int hw = c / 256, ch = c - hw * 256;
+    o = ch * 25 + hw;
+  }
+  out[o] = (beta != 0.f ? beta * out[o] : 0.f) + t;
 }
 
 __global__ void sum_blocks_kernel(const float* __restrict__ x, float* __restrict__ out, int P, int64_t n) {
@@ -315,10 +339,20 @@ extern "C" int mmdyn_counter_add(uint64_t* counter, uint64_t inc, void* stream) 
   hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, ST, counter, inc);
   MMDYN_LAUNCH_CHECK();
 }
-extern "C" int mmdyn_colsum(const float* x, float* out, int rows, int C, int perm, float beta, void* stream) {
-  if (!x || !out) return MMDYN_ERR_NULL;
-  if (perm == 2 && C != 6400) return MMDYN_ERR_SHAPE;
-  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, ST, x, out, rows, C, perm, beta);
+extern "C" int mmdyn_colsum_chunks(int rows) {
+  int c = rows / 64;
+  return c < 1 ? 1 : (c > 32 ? 32 : c);
+}
+extern "C" int mmdyn_colsum(const float* x, float* out, float* scratch, int rows, int C, int perm, float beta,
+                            void* stream) {
+  if (!x || !out || !scratch) return MMDYN_ERR_NULL;
+  if ((perm == 2 && C != 6400) || C % 4 || rows <= 0) return MMDYN_ERR_SHAPE;
+  const int chunks = mmdyn_colsum_chunks(rows);
+  const int rpc = ceil_div(rows, chunks);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C / 4, 32), chunks), dim3(256), 0, ST, x, scratch, rows, C,
+                     rpc);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, ST, scratch, out, chunks, C, perm,
+                     beta);
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_sum_blocks(const float* x, float* out, int P, int64_t n, void* stream) {

@@ -74,13 +74,23 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int HWr = g.Hr * g.Wr;
   const int Mg = g.Bg * HWr;
-  const int grp = blockIdx.x / g.tiles_per_group, tile = blockIdx.x - grp * g.tiles_per_group;
-  const int cls = blockIdx.z % g.nclasses, split = blockIdx.z / g.nclasses;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware block order (speed only): workgroups are dealt round-robin over the 8 XCDs, each with its own L2.
+  // All blocks that read the same rows of A -- the N-tiles and the output-parity classes of one M-tile -- get
+  // linear ids that are equal modulo 8, i.e. the same XCD, so the tile's activations are fetched into one L2.
+  const int NY = g.N / BN, S = NY * g.nclasses;
+  const int MX = g.G * g.tiles_per_group, MX8 = (MX + 7) >> 3;
+  const int L = blockIdx.x;
+  const int m_lo = L & 7, r8 = L >> 3;
+  const int inner = r8 % S, rest = r8 / S;
+  const int mx = (rest % MX8) * 8 + m_lo, split = rest / MX8;
+  if (mx >= MX) return;
+  const int grp = mx / g.tiles_per_group, tile = mx - grp * g.tiles_per_group;
+  const int cls = inner / NY;
+  const int n0 = (inner - cls * NY) * BN;
   const int ph = cls >> 1, pw = cls & 1;
 
 #ifdef IG_STAGGER
-  if (blockIdx.x & 1) __builtin_amdgcn_s_sleep(IG_STAGGER);   // experiment: de-phase co-resident blocks
+  if (mx & 1) __builtin_amdgcn_s_sleep(IG_STAGGER);   // experiment: de-phase co-resident blocks
 #endif
   // TCONV_S1P0: rows are ordered (output pixel, sample) so that a tile sees ONE output pixel and multiplies only
   // the kernel taps that reach the input for it (1..16 of them for k4 s1 p0).  To balance the blocks, each block
@@ -418,7 +428,8 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
     g.tiles_per_pixel = ceil_div(g.Bg, BM);
     g.tiles_per_group = 16 * g.tiles_per_pixel;       // 16 pixel quads per group, 4 pixels walked per block
   }
-  dim3 grid(g.G * g.tiles_per_group, g.N / BN, g.nclasses * g.splitk);
+  const int mx8 = (g.G * g.tiles_per_group + 7) / 8 * 8;
+  dim3 grid((unsigned)mx8 * (g.N / BN) * g.nclasses * g.splitk);
   size_t smem = (size_t)(IG_DBUF ? 2 : 1) * (BM + BN) * LDS_LD * sizeof(float) + (size_t)BM * 4 * sizeof(int);
   hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN>), grid, dim3(256), smem, st, A, Bp, bias, C, C_act,
                      stats, ws, g);

@@ -55,7 +55,8 @@ _SIGNATURES = {
     "mmdyn_random_masks": "p" + "l" + "f" + "QQ" + "pp",
     "mmdyn_random_normal": "p" + "l" + "QQ" + "pp",
     "mmdyn_counter_add": "p" + "Q" + "p",
-    "mmdyn_colsum": "pp" + "iii" + "f" + "p",
+    "mmdyn_colsum": "ppp" + "iii" + "f" + "p",
+    "mmdyn_colsum_chunks": "i",
     "mmdyn_scale_dev": "ppp" + "l" + "p",
     "mmdyn_sum_blocks": "pp" + "i" + "l" + "p",
     "mmdyn_linear_small_fwd": "pppp" + "iiii" + "p",

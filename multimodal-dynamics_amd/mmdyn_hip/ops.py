@@ -170,7 +170,9 @@ class HipBackend:
         check(self.lib.mmdyn_counter_add(_ptr(counter, torch.int64), inc, _stream()), "mmdyn_counter_add")
 
     def colsum(self, x, out, rows, C, perm, beta):
-        check(self.lib.mmdyn_colsum(_ptr(x), _ptr(out), rows, C, perm, float(beta), _stream()), "mmdyn_colsum")
+        scratch = torch.empty(self.lib.mmdyn_colsum_chunks(rows) * C, device=x.device, dtype=torch.float32)
+        check(self.lib.mmdyn_colsum(_ptr(x), _ptr(out), _ptr(scratch), rows, C, perm, float(beta), _stream()),
+              "mmdyn_colsum")
 
     def scale_dev(self, x, s, out):
         check(self.lib.mmdyn_scale_dev(_ptr(x), _ptr(s), _ptr(out), x.numel(), _stream()), "mmdyn_scale_dev")
