@@ -234,6 +234,11 @@ int mmdyn_elbo_assemble(const double* bce, const double* mse, const double* kl, 
 int mmdyn_adam_step(float* p, const float* g, float* m, float* v, double* state, int64_t n, float lr,
                     float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* torch.optim.SGD with momentum / weight decay as configured by problems.py:132-136 (momentum 0.9, wd 5e-4);
+ * first != 0 on the first step (momentum buffer := gradient, like torch) */
+int mmdyn_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
+                   float weight_decay, float grad_scale, int first, void* stream);
+
 /* ---- misc ------------------------------------------------------------------------------------- */
 int mmdyn_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, void* stream);
 int mmdyn_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, void* stream);

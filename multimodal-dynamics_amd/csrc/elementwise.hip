@@ -288,6 +288,18 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     upd(p[i], g[i], m[i], v[i]);
 }
 
+// torch.optim.SGD(lr, momentum, weight_decay) as the reference configures it (problems.py:132-136: momentum 0.9,
+// weight decay 5e-4, no dampening, no Nesterov).  first != 0: the momentum buffer starts as the gradient.
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, int64_t n,
+                           float lr, float momentum, float weight_decay, float grad_scale, int first) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float d = g[i] * grad_scale + weight_decay * p[i];
+    float b = first ? d : momentum * buf[i] + d;
+    buf[i] = b;
+    p[i] = p[i] - lr * b;
+  }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -380,6 +392,13 @@ extern "C" int mmdyn_linear_small_bwd(const float* dy, const float* x, const flo
 extern "C" int mmdyn_scale_dev(const float* x, const float* s, float* out, int64_t n, void* stream) {
   if (!x || !s || !out) return MMDYN_ERR_NULL;
   hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, x, s, out, n);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
+                              float weight_decay, float grad_scale, int first, void* stream) {
+  if (!p || !g || !momentum_buf) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, p, g, momentum_buf, n, lr, momentum, weight_decay,
+                     grad_scale, first);
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_adam_step(float* p, const float* g, float* m, float* v, double* state, int64_t n,

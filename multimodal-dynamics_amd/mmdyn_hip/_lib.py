@@ -69,6 +69,7 @@ _SIGNATURES = {
     "mmdyn_mse": "pppp" + "l" + "f" + "p",
     "mmdyn_elbo_assemble": "ppppp" + "ii" + "ff" + "p",
     "mmdyn_adam_step": "ppppp" + "l" + "fffff" + "p",
+    "mmdyn_sgd_step": "ppp" + "l" + "ffff" + "i" + "p",
     "mmdyn_nchw_to_nhwc": "pp" + "iii" + "p",
     "mmdyn_nhwc_to_nchw": "pp" + "iii" + "p",
 }

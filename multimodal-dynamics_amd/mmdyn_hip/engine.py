@@ -114,6 +114,9 @@ class MVAEStep:
 
     def __init__(self, model, lr=1e-3, pose_multiplier=1000.0, betas=(0.9, 0.999), eps=1e-8, noise=None,
                  process_group=None, world_size=1, two_lanes=True):
+        if getattr(model, "conditional", False):
+            raise NotImplementedError("mmdyn_hip: the fused step is built for the unconditional cnn-mvae; run conditional "
+                                      "models through the module API (Problem(..., fused=False))")
         self.model = model
         self.use_pose = bool(model._use_pose)
         self.L = model.latent_size

@@ -135,6 +135,29 @@ def repack(W, rows_in, cols_in, rows_out, cols_out, mode):
     return out
 
 
+def _pad32(n):
+    return (n + 31) // 32 * 32
+
+
+def concat_condition(x, cond, width):
+    """[x | cond | 0] as one [rows, width] matrix (width = K padded to the MFMA K-step): the reference's
+    torch.cat((x, c.float()), dim=-1) of the conditional models (vae.py:231-237, 286-291)."""
+    rows, K = x.shape
+    cd = cond.shape[1]
+    out = torch.zeros(rows, width, device=x.device, dtype=torch.float32)
+    ops.B.repack2d_ld(x, out, rows, K, rows, K, width, 0)
+    ops.B.repack2d_ld(cond.to(torch.float32).contiguous(), out.view(-1)[K:], rows, cd, rows, cd, width, 0)
+    return out
+
+
+def crop_columns(x, width_in, cols):
+    """First ``cols`` columns of a [rows, width_in] matrix as a contiguous tensor."""
+    rows = x.numel() // width_in
+    out = _new(x, rows, cols)
+    ops.B.repack2d(x, out, rows, width_in, rows, cols, 0)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # weight packing: specs -> packed GEMM operands, either one kernel per entry or one launch for a whole plan
 # ------------------------------------------------------------------------------------------------
@@ -158,25 +181,29 @@ def encoder_pack_specs(P):
 
 
 def decoder_pack_specs(P):
-    L = P["upsample.0.weight"].shape[1]
+    L = P["upsample.0.weight"].shape[1]          # latent (+ condition_dim)
+    Lp = _pad32(L)
     c = lambda k, kind, d0, d1: _spec(k[0], P[k[1]], kind, d0, d1, 0, 0, (16, d1, d0) if kind == K_SWAP else (16, d0, d1))
-    return [_spec("Wu", P["upsample.0.weight"], 3, FEAT, L, FEAT, L, (FEAT, L)),
+    return [_spec("Wu", P["upsample.0.weight"], 3, FEAT, L, FEAT, Lp, (FEAT, Lp)),
             _spec("bu", P["upsample.0.bias"], 3, FEAT, 1, FEAT, 1, (FEAT,)),
             c(("W1s", "hallucinate.0.weight"), K_SWAP, 256, 128), c(("W2s", "hallucinate.3.weight"), K_SWAP, 128, 64),
             c(("W3s", "hallucinate.6.weight"), K_SWAP, 64, 32),
             _spec("W4p", P["hallucinate.9.weight"], 0, 32, 48, 32, 64, (32, 64)),
             c(("W3k", "hallucinate.6.weight"), K_KEEP, 64, 32), c(("W2k", "hallucinate.3.weight"), K_KEEP, 128, 64),
             c(("W1k", "hallucinate.0.weight"), K_KEEP, 256, 128),
-            _spec("WuT", P["upsample.0.weight"], 5, FEAT, L, L, FEAT, (L, FEAT))]
+            _spec("WuT", P["upsample.0.weight"], 5, FEAT, L, Lp, FEAT, (Lp, FEAT))]
 
 
 def heads_pack_specs(P):
+    """K = 512 (+ condition_dim, zero-padded to a multiple of 32 for the conditional models)."""
     Wm, Wl = P["linear_means.weight"], P["linear_log_var.weight"]
     L, K = Wm.shape
-    return [_spec("Wh", Wm, 0, L, K, L, K, (2 * L, K), (0, 0, K)), _spec("Wh", Wl, 0, L, K, L, K, (2 * L, K), (L, 0, K)),
+    Kp = _pad32(K)
+    return [_spec("Wh", Wm, 0, L, K, L, Kp, (2 * L, Kp), (0, 0, Kp)), _spec("Wh", Wl, 0, L, K, L, Kp, (2 * L, Kp), (L, 0, Kp)),
             _spec("bh", P["linear_means.bias"], 0, L, 1, L, 1, (2 * L,), (0, 0, 1)),
             _spec("bh", P["linear_log_var.bias"], 0, L, 1, L, 1, (2 * L,), (L, 0, 1)),
-            _spec("WhT", Wm, 1, L, K, K, L, (K, 2 * L), (0, 0, 2 * L)), _spec("WhT", Wl, 1, L, K, K, L, (K, 2 * L), (0, L, 2 * L))]
+            _spec("WhT", Wm, 1, L, K, Kp, L, (Kp, 2 * L), (0, 0, 2 * L)),
+            _spec("WhT", Wl, 1, L, K, Kp, L, (Kp, 2 * L), (0, L, 2 * L))]
 
 
 def _alloc_packed(specs, like):
@@ -402,13 +429,17 @@ def decoder_forward(*a, **k):
     return run(decoder_forward_steps(*a, **k))
 
 
-def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None):
+def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, cond=None):
     """z: [Bt, L] -> logits NCHW [Bt,3,64,64]; returns (logits, ctx).  ``logits=False`` stops after the last
     BatchNorm (used only to reproduce the running statistics of the reference's unused decoder passes)."""
-    Bt, L = z.shape
+    Bt, L0 = z.shape
     Bg = Bt // G
     pk = packed if packed is not None else pack_now(decoder_pack_specs(P))
-    c = {"Bt": Bt, "G": G, "Bg": Bg, "L": L, "z": z, "pk": pk}
+    Lc = P["upsample.0.weight"].shape[1]         # latent + condition_dim
+    L = _pad32(Lc)
+    if cond is not None or L != L0:
+        z = concat_condition(z, cond, L)          # [z | c | 0]  (vae.py:286-291)
+    c = {"Bt": Bt, "G": G, "Bg": Bg, "L": L, "L0": L0, "Lc": Lc, "z": z, "pk": pk}
     u0, h0 = dense(z, pk["Wu"], pk["bu"], Bt, L, FEAT, ACT_SWISH, want_act=True)      # rows -> hw*256+c
     yield
     bn1, bn2, bn3 = (_bn_of(P, buf, k) for k in DEC_BN)
@@ -460,39 +491,43 @@ def decoder_backward_steps(P, c, dlogits, grads, need_dz=True):
     dh0, _, _ = conv_like(dy1, pk["W1k"], CONV, 1, Bt, 8, 128, 5, 256, 1, 0)
     yield
     du0 = act_backward(dh0, c["u0"], ACT_SWISH)
-    wgrad(du0, c["z"], grads["upsample.0.weight"], DENSE, Bt, 1, FEAT, 1, L, perm=2)
+    wgrad(du0, c["z"], grads["upsample.0.weight"], DENSE, Bt, 1, FEAT, 1, L, cg_canon=c["Lc"], perm=2)
     ops.B.colsum(du0, grads["upsample.0.bias"], Bt, FEAT, 2, 0.0)
     if not need_dz:
         return None
     dz, _ = dense(du0, pk["WuT"], None, Bt, FEAT, L)                         # WuT: [L][hw*256+c]
-    return dz
+    return dz if L == c["L0"] else crop_columns(dz, L, c["L0"])
 
 
 # ------------------------------------------------------------------------------------------------
 # fused heads (linear_means | linear_log_var) and the pose MLPs
 # ------------------------------------------------------------------------------------------------
-def heads_forward(P, hd, packed=None):
-    """hd: [rows, 512] -> out [rows, 2L]: columns [0,L) = means, [L,2L) = log-variances."""
+def heads_forward(P, hd, packed=None, cond=None):
+    """hd: [rows, 512] (+ cond [rows, cd] for the conditional models) -> out [rows, 2L]: columns [0,L) = means,
+    [L,2L) = log-variances."""
     L, K = P["linear_means.weight"].shape
+    Kp = _pad32(K)
     pk = packed if packed is not None else pack_now(heads_pack_specs(P))
-    out, _ = dense(hd, pk["Wh"], pk["bh"], hd.shape[0], K, 2 * L)
-    return out, {"hd": hd, "pk": pk, "L": L, "K": K}
+    if cond is not None or Kp != hd.shape[1]:
+        hd = concat_condition(hd, cond, Kp)
+    out, _ = dense(hd, pk["Wh"], pk["bh"], hd.shape[0], Kp, 2 * L)
+    return out, {"hd": hd, "pk": pk, "L": L, "K": K, "Kp": Kp}
 
 
 def heads_backward(c, dout, grads, need_dx=True):
-    hd, L, K = c["hd"], c["L"], c["K"]
+    hd, L, K, Kp = c["hd"], c["L"], c["K"], c["Kp"]
     rows = hd.shape[0]
-    gW, gb = _new(hd, 2 * L, K), _new(hd, 2 * L)
-    wgrad(dout, hd, gW, DENSE, rows, 1, 2 * L, 1, K)
+    gW, gb = _new(hd, 2 * L, Kp), _new(hd, 2 * L)
+    wgrad(dout, hd, gW, DENSE, rows, 1, 2 * L, 1, Kp)
     ops.B.colsum(dout, gb, rows, 2 * L, 0, 0.0)
-    ops.B.repack2d(gW[:L], grads["linear_means.weight"], L, K, L, K, 0)
-    ops.B.repack2d(gW[L:], grads["linear_log_var.weight"], L, K, L, K, 0)
+    ops.B.repack2d(gW[:L], grads["linear_means.weight"], L, Kp, L, K, 0)      # drops the zero-padded columns
+    ops.B.repack2d(gW[L:], grads["linear_log_var.weight"], L, Kp, L, K, 0)
     ops.B.repack2d(gb[:L], grads["linear_means.bias"], L, 1, L, 1, 0)
     ops.B.repack2d(gb[L:], grads["linear_log_var.bias"], L, 1, L, 1, 0)
     if not need_dx:
         return None
-    dx, _ = dense(dout, c["pk"]["WhT"], None, rows, 2 * L, K)
-    return dx
+    dx, _ = dense(dout, c["pk"]["WhT"], None, rows, 2 * L, Kp)
+    return dx if Kp == 512 else crop_columns(dx, Kp, 512)
 
 
 HEAD_KEYS = ["linear_means.weight", "linear_means.bias", "linear_log_var.weight", "linear_log_var.bias"]

@@ -39,7 +39,7 @@ def build_parser():
     parser.add_argument('--kl-weight', type=float, default=1.0, help="KL weight (overwritten by the annealing schedule)")
     parser.add_argument('--latent-size', type=int, default=256, help="Latent dimension (default: 256)")
     parser.add_argument('--annealing-epochs', type=int, default=50, help="Number of epochs to anneal KL for (default: 50)")
-    parser.add_argument('--conditional', action='store_true', default=False, help="Conditional VAE (not built yet)")
+    parser.add_argument('--conditional', action='store_true', default=False, help="Conditional VAE (conditioned on the shock force)")
     # this build only
     parser.add_argument('--synthetic-batches', type=int, default=20, help="synthetic batches per epoch")
     parser.add_argument('--synthetic-seq-length', type=int, default=1, help="frames per synthetic sequence")
@@ -52,8 +52,10 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     assert args.problem_type in config.PROBLEM_TYPES, "Invalid problem type."
     L = args.synthetic_seq_length
-    loaders = dict(train_loader=SyntheticVisuoTactile(args.synthetic_batches, args.batchsize, L, seed=1234),
-                   test_loader=SyntheticVisuoTactile(max(1, args.synthetic_batches // 4), args.batchsize, L, seed=4321),
+    shock = 3 if args.conditional else 0
+    loaders = dict(train_loader=SyntheticVisuoTactile(args.synthetic_batches, args.batchsize, L, seed=1234, shock_dim=shock),
+                   test_loader=SyntheticVisuoTactile(max(1, args.synthetic_batches // 4), args.batchsize, L, seed=4321,
+                                                     shock_dim=shock),
                    seq_length=L, fused=not args.reference_schedule)
     problem_args = argparse.Namespace(**{k: v for k, v in vars(args).items()
                                          if not k.startswith('synthetic') and k != 'reference_schedule'})

@@ -44,7 +44,7 @@ class ImageDecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, holder, *params):
         P = _dict(layers.DEC_KEYS, [p.detach() for p in params])
-        out, c = layers.decoder_forward(P, holder.bn_buffers(), z.detach().contiguous(), G=1)
+        out, c = layers.decoder_forward(P, holder.bn_buffers(), z.detach().contiguous(), G=1, cond=holder._cond)
         ctx.P, ctx.c = P, c
         return out
 
@@ -60,9 +60,9 @@ class HeadsFn(torch.autograd.Function):
     """Fused linear_means | linear_log_var: returns [rows, 2L]."""
 
     @staticmethod
-    def forward(ctx, hd, Wm, bm, Wl, bl):
+    def forward(ctx, hd, Wm, bm, Wl, bl, cond=None):
         P = _dict(layers.HEAD_KEYS, [Wm.detach(), bm.detach(), Wl.detach(), bl.detach()])
-        out, c = layers.heads_forward(P, hd.detach().contiguous())
+        out, c = layers.heads_forward(P, hd.detach().contiguous(), cond=cond)
         ctx.P, ctx.c = P, c
         return out
 
@@ -70,7 +70,7 @@ class HeadsFn(torch.autograd.Function):
     def backward(ctx, dout):
         grads = {k: torch.empty_like(ctx.P[k]) for k in layers.HEAD_KEYS}
         dx = layers.heads_backward(ctx.c, dout.contiguous(), grads, need_dx=ctx.needs_input_grad[0])
-        return (dx,) + tuple(grads[k] for k in layers.HEAD_KEYS)
+        return (dx,) + tuple(grads[k] for k in layers.HEAD_KEYS) + (None,)
 
 
 class DropoutFn(torch.autograd.Function):

@@ -211,10 +211,21 @@ class Autoencoder(nn.Module):
         raise NotImplementedError
 
 
-def _check_supported(architecture, conditional):
-    if conditional:
-        raise NotImplementedError("mmdyn_hip: --conditional (shock-conditioned) models are not built yet "
-                                  "(SURVEY.md section 8f, rank 4)")
+def _check_supported(architecture, conditional, categorical_conditions=False):
+    if conditional and categorical_conditions:
+        raise NotImplementedError("mmdyn_hip: categorical (one-hot) conditions are not built; the seq/dyn modeling "
+                                  "problems use real-valued shock conditions (problems.py:675-681)")
+
+
+def _condition(c, conditional):
+    """The reference's treatment of the condition tensor (vae.py:231-237): 1-D -> column, cast to float."""
+    if not conditional:
+        return None
+    if c is None:
+        raise ValueError("conditional model called without a condition")
+    if c.dim() == 1:
+        c = c.unsqueeze(1)
+    return c.to(torch.float32).contiguous()
 
 
 class Encoder(nn.Module):
@@ -230,7 +241,8 @@ class Encoder(nn.Module):
         self.latent_size = latent_size
         if categorical_conditions:
             assert condition_dim is not None, "Num conditions is not specified for categorical conditions."
-        _check_supported(architecture, conditional)
+        _check_supported(architecture, conditional, categorical_conditions)
+        cond_w = (condition_dim or 0) if conditional else 0
         if architecture == 'cnn':
             self.conv_net = nn.Sequential(
                 Conv2dParams(3, 32, 4, 2, 1), Swish(),
@@ -238,8 +250,8 @@ class Encoder(nn.Module):
                 Conv2dParams(64, 128, 4, 2, 1), BatchNorm2dParams(128), Swish(),
                 Conv2dParams(128, 256, 4, 1, 0), BatchNorm2dParams(256), Swish())
             self.fc_net = nn.Sequential(LinearParams(FEAT, HID), Swish(), _Marker("Dropout(p=0.1)"))
-            self.linear_means = LinearParams(HID, latent_size)
-            self.linear_log_var = LinearParams(HID, latent_size)
+            self.linear_means = LinearParams(HID + cond_w, latent_size)
+            self.linear_log_var = LinearParams(HID + cond_w, latent_size)
         else:
             layer_sizes = [input_dim] + layer_sizes
             if not (len(layer_sizes) == 3 and layer_sizes[1] % 32 == 0 and layer_sizes[2] % 32 == 0):
@@ -269,20 +281,20 @@ class Encoder(nn.Module):
         sd = dict(self.named_parameters())
         return Fn.PoseEncoderTrunkFn.apply(x, *[sd[k] for k in layers.POSE_ENC_KEYS])
 
-    def heads(self, h):
+    def heads(self, h, c=None):
         out = Fn.HeadsFn.apply(h, self.linear_means.weight, self.linear_means.bias, self.linear_log_var.weight,
-                               self.linear_log_var.bias)
+                               self.linear_log_var.bias, _condition(c, self.conditional))
         return out
 
-    def forward_fused(self, x, noise):
+    def forward_fused(self, x, noise, c=None):
         """Returns the fused heads output [B, 2L] (means | log_vars)."""
         h = self.trunk(x)
         if self.architecture == 'cnn':
             h = Fn.DropoutFn.apply(h, noise.keep_mask(tuple(h.shape), h.device))
-        return self.heads(h)
+        return self.heads(h, c)
 
     def forward(self, x, c=None):
-        out = self.forward_fused(x, _noise_of(self))
+        out = self.forward_fused(x, _noise_of(self), c)
         L = self.latent_size
         return out[:, :L], out[:, L:]
 
@@ -299,11 +311,13 @@ class Decoder(nn.Module):
         self.condition_dim = condition_dim
         if categorical_conditions:
             assert condition_dim is not None, "Num conditions is not specified for categorical conditions."
-        _check_supported(architecture, conditional)
+        _check_supported(architecture, conditional, categorical_conditions)
+        cond_w = (condition_dim or 0) if conditional else 0
+        self._cond = None
         if architecture == 'cnn':
             if latent_size % 32:
                 raise NotImplementedError("mmdyn_hip: latent_size must be a multiple of 32 (MFMA K-step)")
-            self.upsample = nn.Sequential(LinearParams(latent_size, FEAT), Swish())
+            self.upsample = nn.Sequential(LinearParams(latent_size + cond_w, FEAT), Swish())
             self.hallucinate = nn.Sequential(
                 Conv2dParams(256, 128, 4, 1, 0, True), BatchNorm2dParams(128), Swish(),
                 Conv2dParams(128, 64, 4, 2, 1, True), BatchNorm2dParams(64), Swish(),
@@ -325,7 +339,11 @@ class Decoder(nn.Module):
                                       "train mode: problems.py:145,174)")
         sd = dict(self.named_parameters())
         if self.architecture == 'cnn':
-            return Fn.ImageDecoderFn.apply(z, self, *[sd[k] for k in layers.DEC_KEYS])
+            self._cond = _condition(c, self.conditional)      # read by ImageDecoderFn.forward through `holder`
+            try:
+                return Fn.ImageDecoderFn.apply(z, self, *[sd[k] for k in layers.DEC_KEYS])
+            finally:
+                self._cond = None
         return Fn.PoseDecoderFn.apply(z, *[sd[k] for k in layers.POSE_DEC_KEYS])
 
 
@@ -355,7 +373,7 @@ class VAE(Autoencoder):
 
     def forward(self, x, c=None):
         noise = _noise_of(self)
-        out = self.encoder.forward_fused(x, noise)
+        out = self.encoder.forward_fused(x, noise, c)
         L = self.latent_size
         means, log_var = out[:, :L], out[:, L:]
         eps = noise.eps((x.size(0), L), x.device)
@@ -395,11 +413,11 @@ class MVAE(Autoencoder):
         L = self.latent_size
         heads = [None, None, None]
         if visual is not None:
-            heads[0] = self.visual_encoder.forward_fused(visual, noise)
+            heads[0] = self.visual_encoder.forward_fused(visual, noise, condition)
         if tactile is not None:
-            heads[1] = self.tactile_encoder.forward_fused(tactile, noise)
+            heads[1] = self.tactile_encoder.forward_fused(tactile, noise, condition)
         if pose is not None and self._use_pose:
-            heads[2] = self.pose_encoder.forward_fused(pose, noise)
+            heads[2] = self.pose_encoder.forward_fused(pose, noise, condition)
         eps = noise.eps((batch_size, L), ref.device)
         means, log_var, z = Fn.PoEReparamFn.apply(eps, L, *heads)
         visual_recon = self.visual_decoder(z, c=condition)

@@ -250,6 +250,11 @@ class HipBackend:
                                        lr, beta1, beta2, eps, grad_scale, _stream()), "mmdyn_adam_step")
 
 
+    def sgd_step(self, p, g, buf, lr, momentum, weight_decay, grad_scale, first):
+        check(self.lib.mmdyn_sgd_step(_ptr(p), _ptr(g), _ptr(buf), p.numel(), lr, momentum, weight_decay, grad_scale,
+                                      int(first), _stream()), "mmdyn_sgd_step")
+
+
 B = HipBackend()
 
 

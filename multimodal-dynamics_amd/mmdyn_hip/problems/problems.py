@@ -56,15 +56,36 @@ class FusedAdam(torch.optim.Optimizer):
                                 st["state"], group["lr"], b1, b2, group["eps"], 1.0)
 
 
+class FusedSGD(torch.optim.Optimizer):
+    """torch.optim.SGD(lr, momentum=0.9, weight_decay=5e-4) -- the reference's SGD option (problems.py:132-136) -- on
+    the mmdyn_sgd_step kernel."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.9, weight_decay=5e-4):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                first = not st
+                if first:
+                    st["buf"] = torch.zeros_like(p)
+                ops.B.sgd_step(p.data.view(-1), p.grad.contiguous().view(-1), st["buf"].view(-1), group["lr"],
+                               group["momentum"], group["weight_decay"], 1.0, first)
+
+
 class SyntheticVisuoTactile:
     """Iterable of ``(data_input, data_target)`` in the reference's collated list format
     (datasets.py:395-404): [visual, tactile, pose, available_modals(, shock)] / [visual, tactile, pose, mask],
     frames of ``seq_length`` per sequence folded into the batch dimension.  Values are U[0,1) like
     ``ToTensor`` images and min-max normalised poses (datasets.py:23-31, 407-408)."""
 
-    def __init__(self, n_batches, batchsize, seq_length=1, device="cpu", seed=1234, size=64):
+    def __init__(self, n_batches, batchsize, seq_length=1, device="cpu", seed=1234, size=64, shock_dim=0):
         self.n_batches, self.batchsize, self.seq_length = n_batches, batchsize, seq_length
-        self.device, self.seed, self.size = device, seed, size
+        self.device, self.seed, self.size, self.shock_dim = device, seed, size, shock_dim
 
     def __len__(self):
         return self.n_batches
@@ -78,6 +99,8 @@ class SyntheticVisuoTactile:
                         torch.rand(n, 7, generator=g)]
             d, t = draw(), draw()
             d.append(torch.ones(n, 2))
+            if self.shock_dim:
+                d.append(torch.rand(n, self.shock_dim, generator=g))      # the shock force (datasets.py:395-404)
             t.append(torch.ones(n, 1, self.size, self.size))
             yield [x.to(self.device) for x in d], [x.to(self.device) for x in t]
 
@@ -134,9 +157,10 @@ class Problem:
 
     def set_optimizer(self):
         assert (self.parameters['optimizer'] in config.OPTIMIZERS), "loss name not implemented in Problem"
-        if self.parameters['optimizer'] != 'Adam':
-            raise NotImplementedError("mmdyn_hip: only Adam (the reference default, problems.py:137-138) is built")
-        use_engine = self._fused and 'mvae' in self.parameters['model_name']
+        if self.parameters['optimizer'] == 'SGD':      # reference: momentum 0.9, weight decay 5e-4 (problems.py:132-136)
+            self._optimizer = FusedSGD(self._model.parameters(), lr=self.parameters['lr'], momentum=0.9, weight_decay=5e-4)
+            return
+        use_engine = self._fused and 'mvae' in self.parameters['model_name'] and not self._conditional
         if use_engine:
             self._step = MVAEStep(self._model, lr=self.parameters['lr'], pose_multiplier=self._pose_multiplier)
         else:
@@ -163,7 +187,7 @@ class Problem:
                 outputs, loss = self._evaluate_model(inputs, targets)
                 loss.backward()
                 self._optimizer.step()
-            train_loss += float(loss)
+            train_loss += float(loss.detach()) if torch.is_tensor(loss) else float(loss)
             n += 1
             for k, v in outputs.get('perf_measure', {}).items():
                 perf[k] += v
@@ -366,6 +390,13 @@ class Reconstruction(Problem):
 
 class SeqModeling(Reconstruction):
 
+    def _set_condition_dim(self):
+        """condition_dim = the shock-force dimension of the dataset (problems.py:675-681)."""
+        self._categorical_conditions = False
+        self._condition_dim = int(getattr(self.train_loader, 'shock_dim', 0) or 0)
+        if self._conditional and not self._condition_dim:
+            raise ValueError("--conditional needs a dataset that carries the shock force (data[4])")
+
     def parse_input(self, data, target):
         """First frame of every sequence -> input, dataset's final frame -> target ([::l], problems.py:634-673)."""
         l = self._seq_length
@@ -393,7 +424,10 @@ class SeqModeling(Reconstruction):
             xs, ts = self._fused_io(x, targets)
             return self._evaluate_mvae(x=xs, targets=ts, loss_mask=loss_mask, reduce=reduce, reduction=reduction,
                                        condition=x.get('shock'))
-        recon_x, means, log_var = self._model(x['model_input'])
+        if self._conditional:
+            recon_x, means, log_var = self._model(x['model_input'], x['shock'])
+        else:
+            recon_x, means, log_var = self._model(x['model_input'])
         loss = self._elbo_loss(recon_x, targets['target_output'], means, log_var, loss_mask=loss_mask, reduce=reduce,
                                reduction=reduction)
         with torch.no_grad():

@@ -181,7 +181,8 @@ class EmuBackend:
         else:
             m = s.reshape(256, 25, cols_in).permute(2, 1, 0).reshape(cols_in, rows_in)
         out = torch.zeros(rows_out, cols_out)
-        out[: m.shape[0], : m.shape[1]] = m
+        r, c = min(m.shape[0], rows_out), min(m.shape[1], cols_out)      # zero-pads or crops, like the kernel
+        out[:r, :c] = m[:r, :c]
         dst.reshape(-1).copy_(out.reshape(-1))
 
     def repack2d_ld(self, src, dst, rows_in, cols_in, rows_out, cols_out, ld_out, mode):
@@ -445,3 +446,8 @@ class EmuBackend:
         m.add_((gg - m) * (1 - beta1))
         v.mul_(beta2).add_((1 - beta2) * gg * gg)
         p.sub_(float(state[1]) * (m / (v.sqrt() / float(state[2]) + eps)))
+
+    def sgd_step(self, p, g, buf, lr, momentum, weight_decay, grad_scale, first):
+        d = g * grad_scale + weight_decay * p
+        buf.copy_(d if first else momentum * buf + d)
+        p.sub_(lr * buf)

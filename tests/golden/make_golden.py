@@ -263,6 +263,33 @@ def gen_vae_step(batch, fname):
     print(fname, "loss", float(out["loss_step0"]), float(out["loss_step1"]))
 
 
+def gen_conditional(batch, fname):
+    """--conditional (shock-conditioned) cnn-mvae: vae.py:196, 231-237, 257, 286-291; problems.py:692-695."""
+    kw = dict(MODEL_KW)
+    kw.update(conditional=True, condition_dim=3, use_pose=True)
+    model = M.setup_model("cnn-mvae", cross_modal=True, **kw)
+    model.load_state_dict(seeded_state_dict(model.state_dict(), 0))
+    model.train()
+    inputs, targets = seeded_batch(batch, 321, with_pose=True)
+    g = torch.Generator().manual_seed(9)
+    cond = torch.rand(batch, 3, generator=g)
+    eps, masks = seeded_noise(batch, 256, 7, 8, 77)
+    slf = make_self(model, True, "cnn-mvae", kl_weight=0.02, conditional=True)
+    out = {"batch": batch, "cond": cond.numpy(), "kl_weight": 0.02}
+    with Injector(eps, masks):
+        outputs, loss = slf._evaluate_mvae(x=list(inputs), targets=list(targets), condition=cond)
+        loss.backward()
+    out["loss"] = np.float64(loss.item())
+    out["loss_partials"] = np.array(slf.partials, dtype=np.float64)
+    out["means"] = outputs["means"].detach().numpy()
+    out["recon2"] = outputs["recon_x"][2].detach().numpy()
+    out["recon0"] = summarize(outputs["recon_x"][0], 256)
+    for n, p_ in model.named_parameters():
+        out["grad/" + n] = summarize(p_.grad)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "loss", float(out["loss"]))
+
+
 def gen_small_ops(fname):
     g = torch.Generator().manual_seed(2024)
     out = {}
@@ -336,6 +363,10 @@ def gen_small_ops(fname):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "conditional":
+        gen_conditional(2, "mvae_conditional_B2.npz")
+        sys.exit(0)
+    gen_conditional(2, "mvae_conditional_B2.npz")
     gen_small_ops("small_ops.npz")
     gen_mvae_forward(3, "mvae_forward_B3.npz")
     gen_vae_step(16, "vae_visual_B16.npz")

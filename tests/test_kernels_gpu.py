@@ -329,3 +329,16 @@ def test_im2col_on_the_fly_modes(Bt):
     chunks = HIP.wgrad_chunks(IM2COL3, Bt * 1024, 32, 64)
     partial = torch.zeros(chunks, 1, 32, 64)
     both("wgrad_tn", [D, x, partial, IM2COL3, Bt, 32, 32, 32, 64, 64, 64, 1, 0, chunks], [2], lambda i, t: t.sum(0), tol=5e-5)
+
+
+def test_sgd_matches_torch():
+    n = 50001
+    p0, g = rnd(n, seed=80), rnd(n, seed=81) * 0.1
+    p, buf = p0.clone().to(DEV), torch.zeros(n, device=DEV)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref], lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    for step in range(3):
+        HIP.sgd_step(p, (g * (step + 1)).to(DEV), buf, 1e-2, 0.9, 5e-4, 1.0, step == 0)
+        ref.grad = g * (step + 1)
+        opt.step()
+    torch.testing.assert_close(p.cpu(), ref.detach(), rtol=1e-6, atol=1e-7)

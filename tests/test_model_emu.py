@@ -219,3 +219,55 @@ def test_parse_input_and_training_loop(golden_dir, tmp_path):
     assert set(state) == {"model", "loss", "epoch"}
     assert list(state["model"].keys()) == list(state_dict_shapes("cnn-mvae", use_pose=True).keys())
     assert os.path.exists(os.path.join(str(tmp_path), "results.pkl"))
+
+
+def check_conditional(golden_dir, device):
+    """--conditional cnn-mvae through the module API against vectors from the reference (B=2, condition_dim=3)."""
+    g = load(golden_dir, "mvae_conditional_B2.npz")
+    B = int(g["batch"])
+    kw = dict(MODEL_KW)
+    kw.update(conditional=True, condition_dim=3, use_pose=True)
+    m = setup_model("cnn-mvae", cross_modal=True, **kw)
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 0))
+    m.to(device).train()
+    assert m.visual_encoder.linear_means.weight.shape == (256, 515) and m.visual_decoder.upsample[0].weight.shape == (6400, 259)
+    prob = SeqModeling.__new__(SeqModeling)
+    prob._model, prob._kl_weight, prob._pose_multiplier = m, float(g["kl_weight"]), 1000.0
+    prob.parameters = {"use_pose": True, "model_name": "cnn-mvae", "mask_loss": False, "input_type": "visuotactile"}
+    inputs, targets = seeded_batch(B, 321)
+    eps, masks = seeded_noise(B, 256, 7, 8, 77)
+    m.noise = InjectedNoise(eps, masks)
+    cond = torch.tensor(g["cond"]).to(device)
+    outputs, loss = prob._evaluate_mvae(x=[t.to(device) for t in inputs], targets=[t.to(device) for t in targets], condition=cond)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-4)
+    np.testing.assert_allclose(outputs["means"].detach().cpu().numpy(), g["means"], rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(outputs["recon_x"][2].detach().cpu().numpy(), g["recon2"], rtol=1e-4, atol=3e-5)
+    for k, p_ in m.named_parameters():
+        close_summary(summarize(p_.grad.cpu()), g["grad/" + k], 1e-3, "grad " + k)
+
+
+def test_conditional_mvae(golden_dir):
+    check_conditional(golden_dir, "cpu")
+
+
+def check_conditional_loops(tmp_path, no_cuda):
+    """--conditional through Problem.train(): cnn-mvae (shock-conditioned, module API) and cnn-vae with the SGD option."""
+    for i, over in enumerate((dict(model_name="cnn-mvae"), dict(model_name="cnn-vae", input_type="visual", optimizer="SGD"))):
+        prob = SeqModeling(args(num_epochs=1, no_cuda=no_cuda, conditional=True, batchsize=2, **over),
+                           log_dir=str(tmp_path / str(i)), train_loader=SyntheticVisuoTactile(2, 2, shock_dim=3),
+                           test_loader=SyntheticVisuoTactile(1, 2, seed=7, shock_dim=3))
+        assert prob.condition_dim == 3 and prob._step is None
+        before = {k: v.detach().clone() for k, v in prob.model.state_dict().items()}
+        prob.train()
+        after = prob.model.state_dict()
+        fl = [k for k in before if before[k].dtype.is_floating_point]
+        assert all(not torch.equal(before[k], after[k]) for k in fl)
+        assert all(torch.isfinite(v).all() for v in after.values())
+    with pytest.raises(ValueError):
+        SeqModeling(args(conditional=True, no_cuda=no_cuda), log_dir=str(tmp_path / "x"),
+                    train_loader=SyntheticVisuoTactile(1, 2), test_loader=SyntheticVisuoTactile(1, 2))
+
+
+def test_conditional_training_loops(tmp_path):
+    check_conditional_loops(tmp_path, no_cuda=True)

@@ -34,6 +34,14 @@ def test_vae_config1(golden_dir):
     T.check_vae_config1(golden_dir, DEV)
 
 
+def test_conditional_mvae(golden_dir):
+    T.check_conditional(golden_dir, DEV)
+
+
+def test_conditional_training_loops(tmp_path):
+    T.check_conditional_loops(tmp_path, no_cuda=False)
+
+
 def test_fused_engine_vs_oracle_b32():
     """ELBO (total and each of the 7 partials) within 1e-4 relative of the CPU oracle, gradients within 1e-3
     relative L2 per tensor, loss still within 1e-4 after 3 Adam steps."""

@@ -173,3 +173,24 @@ def test_vae_config1(golden_dir):
         close_params(summarize(prm[k]), g["param_step1/" + k], 1e-3, 2, "param " + k)
     for k in buf:
         np.testing.assert_allclose(buf[k].double().numpy(), g["buffer_step1/" + k], rtol=2e-5, atol=2e-3)
+
+
+def test_mvae_conditional(golden_dir):
+    """--conditional cnn-mvae (condition_dim 3 = the shock force): vae.py:231-237 / 286-291 concatenations."""
+    g = load(golden_dir, "mvae_conditional_B2.npz")
+    B = int(g["batch"])
+    prm, buf = O.split_state(seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True, cond=3), 0))
+    assert prm["visual_encoder.linear_means.weight"].shape == (256, 515)
+    inputs, targets = seeded_batch(B, 321)
+    eps, masks = seeded_noise(B, 256, 7, 8, 77)
+    cond = torch.tensor(g["cond"])
+    outputs, loss, partials = O.evaluate_mvae(prm, inputs, targets, eps, masks, float(g["kl_weight"]), 1000.0, True, buf,
+                                              condition=cond)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=2e-5)
+    np.testing.assert_allclose([float(x) for x in partials], g["loss_partials"], rtol=1e-5)
+    np.testing.assert_allclose(outputs["means"].detach().numpy(), g["means"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(outputs["recon_x"][2].detach().numpy(), g["recon2"], rtol=1e-4, atol=2e-5)
+    close_summary(summarize(outputs["recon_x"][0], 256), g["recon0"], 2e-5, "recon0")
+    for k in prm:
+        close_summary(summarize(prm[k].grad), g["grad/" + k], 2e-4, "grad " + k)
