@@ -66,7 +66,7 @@ int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C,
                    float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
                    int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
                    void* stream);
-int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Ho, int Wo, int N);
+int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
 int mmdyn_splitk_reduce(const float* ws, const float* bias, float* C, float* C_act, int splitk,
                         int rows, int N, int act, void* stream);
 

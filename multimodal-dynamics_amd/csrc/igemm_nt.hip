@@ -395,22 +395,24 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
   }
 }
 
-// tile choice shared by the launcher and mmdyn_igemm_stat_tiles: the largest tile that still gives
-// >= 2 blocks per CU (256 CUs), otherwise the smallest one that divides N.
+// tile choice shared by the launcher and mmdyn_igemm_stat_tiles.  Measured on MI355X over every shape of the
+// bs=256 step (tests/microbench/sweep_tiles.py): the 64x64 tile (more resident blocks per CU to hide the
+// single-stage fetch latency) wins or ties everywhere except long-K problems that still fill the chip with
+// 128x128 tiles; N == 32 (mod 64) takes 128x32.
 // (rows_per_group, G) describe the row segments a tile may not straddle: groups, or (group, output pixel) pairs
-static void pick_tile(int N, int rows_per_group, int G, int ncls, int splitk, int* bm, int* bn) {
-  static const int cand[][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 32}, {128, 32}};
-  int best = -1;
-  for (int i = 0; i < 6; ++i) {
-    int m = cand[i][0], n = cand[i][1];
-    if (N % n) continue;
-    if (n == 32 && N % 64 == 0) continue;  // 32-wide tiles only for N == 32 (mod 64)
-    long blocks = (long)G * ceil_div(rows_per_group, m) * (N / n) * ncls * splitk;
-    best = i;
-    if (blocks >= 512) break;
+static void pick_tile(int N, int rows_per_group, int G, int ncls, int splitk, int ksteps, int* bm, int* bn) {
+  if (N % 64) {
+    *bm = 128;
+    *bn = 32;
+  } else {
+    *bm = 64;
+    *bn = 64;
+    if (N % 128 == 0 && splitk == 1 && ksteps >= 32 &&
+        (long)G * ceil_div(rows_per_group, 128) * (N / 128) * ncls >= 512) {
+      *bm = 128;
+      *bn = 128;
+    }
   }
-  *bm = cand[best][0];
-  *bn = cand[best][1];
   if (const char* ov = getenv("MMDYN_IGEMM_TILE")) {   // kernel experiments only
     int a = 0, b = 0;
     if (sscanf(ov, "%d,%d", &a, &b) == 2 && N % b == 0) {
@@ -448,20 +450,22 @@ static int launch(const float* A, const float* Bp, const float* bias, float* C, 
 
 }  // namespace
 
-extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Ho, int Wo, int N) {
+extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   if (mode == MMDYN_TCONV_S1P0) {
     int bm, bn;
-    pick_tile(N, Bg, G * 16, 1, 1, &bm, &bn);
+    pick_tile(N, Bg, G * 16, 1, 1, 0, &bm, &bn);
     return Ho * Wo * ceil_div(Bg, bm);
   }
-  int Hr = Ho, Wr = Wo, ncls = 1;
+  int Hr = Ho, Wr = Wo, ncls = 1, ntaps = (mode == MMDYN_CONV) ? 16 : 1;
   if (mode == MMDYN_TCONV_S2P1) {
     Hr = Hi;
     Wr = Wi;
     ncls = 4;
+    ntaps = 4;
   }
+  const int ksteps = ntaps * (Cin / BK);
   int bm, bn;
-  pick_tile(N, Bg * Hr * Wr, G, ncls, 1, &bm, &bn);
+  pick_tile(N, Bg * Hr * Wr, G, ncls, 1, ksteps, &bm, &bn);
   return ncls * ceil_div(Bg * Hr * Wr, bm);
 }
 
@@ -538,9 +542,9 @@ extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias
   hipStream_t st = (hipStream_t)stream;
   int bm, bn;
   if (mode == MMDYN_TCONV_S1P0)
-    pick_tile(N, Bg, G * 16, 1, 1, &bm, &bn);
+    pick_tile(N, Bg, G * 16, 1, 1, 0, &bm, &bn);
   else
-    pick_tile(N, Bg * g.Hr * g.Wr, G, g.nclasses, splitk, &bm, &bn);
+    pick_tile(N, Bg * g.Hr * g.Wr, G, g.nclasses, splitk, g.ntaps * (Cin / BK), &bm, &bn);
   if (bn == 128 && bm == 128) return launch<128, 128, 64, 64>(A, Bp, bias, C, C_act, stats, ws, g, st);
   if (bn == 128 && bm == 64) return launch<64, 128, 32, 64>(A, Bp, bias, C, C_act, stats, ws, g, st);
   if (bn == 64 && bm == 128) return launch<128, 64, 64, 32>(A, Bp, bias, C, C_act, stats, ws, g, st);

@@ -29,7 +29,7 @@ MAX_EXPERTS = 4
 # name -> argument type codes, in header order: p pointer, i int, l int64, f float, Q uint64
 _SIGNATURES = {
     "mmdyn_igemm_nt": "ppppppp" + "iiiiiiiiiiiiii" + "p",
-    "mmdyn_igemm_stat_tiles": "iiiiiiii",
+    "mmdyn_igemm_stat_tiles": "iiiiiiiii",
     "mmdyn_splitk_reduce": "pppp" + "iiii" + "p",
     "mmdyn_wgrad_tn": "ppp" + "iiiiiiiiiii" + "p",
     "mmdyn_wgrad_chunks": "iiii",

@@ -37,11 +37,11 @@ def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False):
     Returns (pre_activation, activated or None)."""
     C = _new(A, rows, N)
     Ca = _new(A, rows, N) if want_act else None
-    tiles = _cdiv(rows, 64) * _cdiv(N, 128)
+    # split-K only when the 64x64 tiling leaves most of the 256 CUs idle AND K is long enough to amortise the
+    # partial-sum pass (measured: tests/microbench/sweep_dense.py)
+    tiles = _cdiv(rows, 64) * _cdiv(N, 64)
     steps = K // 32
-    splitk = 1
-    if tiles < 256 and steps >= 8:
-        splitk = max(1, min(steps // 4, _cdiv(512, tiles)))
+    splitk = max(1, min(512 // tiles, steps // 8)) if N % 64 == 0 else 1
     if splitk > 1:
         ws = _new(A, splitk, rows, N)
         ops.B.igemm_nt(A, Bp, None, C, None, None, ws, DENSE, 1, rows, 1, 1, K, 1, 1, N, N, 1, 0, ACT_NONE, splitk)
@@ -57,7 +57,7 @@ def conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride=1, offset=0, stats=Fals
     y = _new(x, Bt * Ho * Ho, N)
     st, T = None, 0
     if stats:
-        T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Ho, Ho, N)
+        T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
         st = _new(x, G, T, 2, N)
     ops.B.igemm_nt(x, Wp, None, y, None, st, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset,
                    ACT_NONE, 1)

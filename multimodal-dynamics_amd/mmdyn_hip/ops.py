@@ -48,8 +48,8 @@ class HipBackend:
         return self._l
 
     # ---- host-only helpers (no GPU needed) ----
-    def igemm_stat_tiles(self, mode, G, Bg, Hi, Wi, Ho, Wo, N):
-        return self.lib.mmdyn_igemm_stat_tiles(mode, G, Bg, Hi, Wi, Ho, Wo, N)
+    def igemm_stat_tiles(self, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N):
+        return self.lib.mmdyn_igemm_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
 
     def colstats_tiles(self, rows_per_group):
         return self.lib.mmdyn_colstats_tiles(rows_per_group)

@@ -56,4 +56,4 @@ def test_argument_errors_are_reported_without_a_gpu():
     # null pointers / bad shapes are rejected on the host before any launch
     assert lib.mmdyn_igemm_nt(None, None, None, None, None, None, None, 0, 1, 1, 1, 1, 32, 1, 1, 32, 32, 1, 0, 0, 1, None) == -2
     assert lib.mmdyn_wgrad_chunks(0, 128, 33, 32) == -1
-    assert lib.mmdyn_igemm_stat_tiles(2, 4, 256, 8, 8, 16, 16, 64) > 0
+    assert lib.mmdyn_igemm_stat_tiles(2, 4, 256, 8, 8, 128, 16, 16, 64) > 0

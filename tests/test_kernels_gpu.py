@@ -74,7 +74,7 @@ def test_igemm_nt(case):
     bias = rnd(N, seed=3)
     C = torch.zeros(Bt * Ho * Ho, N)
     Ca = torch.zeros(Bt * Ho * Ho, N)
-    T = HIP.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Ho, Ho, N)
+    T = HIP.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
     stats = torch.zeros(G, T, 2, N)
     post = lambda i, t: t.sum(1) if i == 5 else t
     # plain output + stats, no bias
