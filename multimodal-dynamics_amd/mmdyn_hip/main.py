@@ -9,7 +9,7 @@ import os
 import pickle
 
 from . import config
-from .problems.problems import Reconstruction, SeqModeling, DynModeling, SyntheticVisuoTactile
+from .problems.problems import Reconstruction, Regression, SeqModeling, DynModeling, SyntheticVisuoTactile
 
 
 def build_parser():
@@ -60,7 +60,7 @@ def main(argv=None):
     problem_args = argparse.Namespace(**{k: v for k, v in vars(args).items()
                                          if not k.startswith('synthetic') and k != 'reference_schedule'})
     if args.problem_type == 'regression':
-        raise NotImplementedError("mmdyn_hip: the regression problem / Regressor baseline is outside the hot path")
+        problem = Regression(problem_args, **loaders)
     elif args.problem_type == 'reconstruction':
         problem = Reconstruction(problem_args, **loaders)
     elif args.problem_type == 'dyn_modeling':

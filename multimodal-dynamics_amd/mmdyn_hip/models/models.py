@@ -1,6 +1,12 @@
 """Model registry: the ``--model-name`` plug-in surface of /root/reference/mmdyn/pytorch/models/models.py:13-25."""
 from .. import config
-from .vae import VAE, MVAE, Swish  # noqa: F401  (Swish re-exported like the reference does)
+from torch import nn
+
+from .. import layers
+from . import functional as Fn
+from .vae import (VAE, MVAE, Swish, Conv2dParams, BatchNorm2dParams, LinearParams, _Marker, _noise_of,  # noqa: F401
+                  _condition)
+from .shapes import FEAT, HID
 
 
 def count_parameters(model):
@@ -9,7 +15,7 @@ def count_parameters(model):
 
 def setup_model(model_name, cross_modal=False, **kwargs):
     """Same dispatch rules and assertions as the reference: 'mvae' needs cross-modal input, 'vae' must not
-    get it.  'regressor' (a different problem type) is not built."""
+    get it; 'regressor' builds the pose-regression baseline."""
     assert (model_name in config.MODELS), "Model is not implement yet"
     if 'mvae' in model_name and cross_modal:
         model = MVAE(**kwargs)
@@ -17,7 +23,44 @@ def setup_model(model_name, cross_modal=False, **kwargs):
         assert not cross_modal, "VAE does not work with cross modal inputs."
         model = VAE(**kwargs)
     elif 'regressor' in model_name:
-        raise NotImplementedError("mmdyn_hip: the Regressor baseline is outside the cnn-mvae hot path")
+        model = Regressor(**kwargs)
     else:
         exit("The model and modality combination is not valid.")
     return model
+
+
+class Regressor(nn.Module):
+    """Pose-regression baseline (models.py:28-77): the image-encoder conv/fc trunk, dropout, then a three-layer
+    ReLU MLP to ``out_dim``; ``conditional`` concatenates the (real-valued) condition to the 512 features.
+    Same state_dict keys as the reference (conv_net.*, fc_net.0.*, out_net.{0,2,4}.*)."""
+
+    def __init__(self, out_dim=7, conditional=False, num_classes=None):
+        super().__init__()
+        self.conditional = conditional
+        self.num_classes = num_classes
+        cnn_features_comp = HID + self.conditional * self.num_classes      # TypeError for None, like the reference
+        self.conv_net = nn.Sequential(
+            Conv2dParams(3, 32, 4, 2, 1), Swish(),
+            Conv2dParams(32, 64, 4, 2, 1), BatchNorm2dParams(64), Swish(),
+            Conv2dParams(64, 128, 4, 2, 1), BatchNorm2dParams(128), Swish(),
+            Conv2dParams(128, 256, 4, 1, 0), BatchNorm2dParams(256), Swish())
+        self.fc_net = nn.Sequential(LinearParams(FEAT, HID), Swish(), _Marker("Dropout(p=0.1)"))
+        self.out_net = nn.Sequential(LinearParams(cnn_features_comp, 256), _Marker("ReLU()"), LinearParams(256, 256),
+                                     _Marker("ReLU()"), LinearParams(256, out_dim))
+        self.noise = None
+
+    def bn_buffers(self):
+        return {f"conv_net.{i}.{n}": getattr(self.conv_net[i], n) for i in (3, 6, 9)
+                for n in ("running_mean", "running_var", "num_batches_tracked")}
+
+    def forward(self, x, c=None):
+        if not self.training:
+            raise NotImplementedError("mmdyn_hip: eval-mode BatchNorm / dropout is not built (the reference trains "
+                                      "and validates in train mode, problems.py:145,174)")
+        sd = dict(self.named_parameters())
+        h = Fn.ImageEncoderTrunkFn.apply(x, self, *[sd[k] for k in layers.ENC_KEYS])
+        h = Fn.DropoutFn.apply(h, _noise_of(self).keep_mask(tuple(h.shape), h.device))
+        if self.conditional:
+            import torch
+            h = torch.cat((h, _condition(c, True)), dim=-1)
+        return Fn.PoseDecoderFn.apply(h, *[sd[f"out_net.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias")])

@@ -85,9 +85,23 @@ def pose_decoder_shapes(pre="pose_decoder", latent=256):
     return d
 
 
+def regressor_shapes(out_dim=7, cond=0):
+    """Regressor baseline (models.py:28-64)."""
+    d = image_encoder_shapes("r")
+    for k in [k for k in d if "linear_" in k]:
+        del d[k]
+    d = OrderedDict((k[2:], v) for k, v in d.items())
+    for i, (fin, fout) in zip((0, 2, 4), ((HID + cond, 256), (256, 256), (256, out_dim))):
+        d[f"out_net.{i}.weight"] = (fout, fin)
+        d[f"out_net.{i}.bias"] = (fout,)
+    return d
+
+
 def state_dict_shapes(model_name, use_pose=False, latent=256, cond=0):
     """``{key: shape}`` in the reference's registration order."""
     d = OrderedDict()
+    if "regressor" in model_name:
+        return regressor_shapes(cond=cond)
     if "mvae" in model_name:
         d.update(image_encoder_shapes("visual_encoder", latent, cond))
         d.update(image_decoder_shapes("visual_decoder", latent, cond))

@@ -283,6 +283,48 @@ class Problem:
         return self._condition_dim
 
 
+class Regression(Problem):
+    """Baseline regressing the object pose from one image modality (problems.py:263-359).  The reference's
+    ``set_model`` passes a ``condition_dim`` keyword its Regressor does not take (problems.py:275 vs
+    models.py:30) and so cannot run as shipped; here the shock dimension goes in as ``num_classes``, the
+    argument the Regressor actually sizes its conditional input with (models.py:37)."""
+
+    def set_model(self):
+        self._categorical_conditions = False
+        self._condition_dim = int(getattr(self.train_loader, 'shock_dim', 0) or 0)
+        if self._conditional and not self._condition_dim:
+            raise ValueError("--conditional needs a dataset that carries the shock force (data[4])")
+        self._model = setup_model(self.parameters['model_name'], out_dim=7, conditional=self._conditional,
+                                  num_classes=self._condition_dim)
+        self._model.to(self._device)
+
+    def set_criterion(self):
+        self._criterion = None                # MSELoss(reduction='sum') == Fn.MSESumFn
+
+    def parse_input(self, data, target):
+        """problems.py:290-316: one image modality in, the target pose (target[2]) out, every l-th frame."""
+        l, dev = self._seq_length, self._device
+        if not isinstance(data, list):
+            mi, to = data.to(dev), target.to(dev)
+        elif len(data) == 1:
+            mi, to = data[0].to(dev), target[0].to(dev)
+        else:
+            i = {'visual': 0, 'tactile': 1}[self.parameters['input_type']]
+            mi, to = data[i][::l].to(dev), target[2][::l].to(dev)
+        shock = data[4][::l].to(dev) if isinstance(data, list) and len(data) > 4 else None
+        return {'model_input': mi, 'shock': shock}, to
+
+    def _evaluate_model(self, inputs, targets, **kwargs):
+        out = self._model(inputs['model_input'], inputs['shock']) if self._conditional \
+            else self._model(inputs['model_input'])
+        out = out.view(targets.size())
+        loss = Fn.MSESumFn.apply(out, targets.contiguous())
+        return {'outputs': out, 'perf_measure': {'pose': float(loss.detach()) / targets.numel()}}, loss
+
+    def _sample(self, n=50):
+        pass
+
+
 class Reconstruction(Problem):
 
     def set_model(self):

@@ -120,6 +120,22 @@ def pose_decoder(z, prm, pre="pose_decoder"):
     return F.linear(h, prm[pre + ".deconv_net.4.weight"], prm[pre + ".deconv_net.4.bias"])
 
 
+def regressor_forward(prm, x, keep_mask, c=None, buffers=None):
+    """Regressor.forward (models.py:66-77): the image-encoder trunk, dropout, optional condition concat, then
+    out_net = Linear(512[+cd],256) ReLU Linear(256,256) ReLU Linear(256,out_dim) (models.py:57-63)."""
+    pp = {"r." + k: v for k, v in prm.items()}
+    bb = {"r." + k: v for k, v in buffers.items()} if buffers is not None else None
+    h = image_encoder_trunk(x, pp, "r", bb)
+    h = h * (keep_mask.to(h.dtype) / (1.0 - DROPOUT_P))
+    if c is not None:
+        if c.dim() == 1:
+            c = c.unsqueeze(1)
+        h = torch.cat((h, c.to(h.dtype)), dim=-1)
+    h = torch.relu(F.linear(h, prm["out_net.0.weight"], prm["out_net.0.bias"]))
+    h = torch.relu(F.linear(h, prm["out_net.2.weight"], prm["out_net.2.bias"]))
+    return F.linear(h, prm["out_net.4.weight"], prm["out_net.4.bias"])
+
+
 def product_of_experts(mu, logvar, eps=POE_EPS):
     """vae.py:311-318.  mu/logvar: [M, B, D]; the variance gets ``eps`` twice."""
     var = torch.exp(logvar) + eps

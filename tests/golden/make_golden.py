@@ -290,6 +290,35 @@ def gen_conditional(batch, fname):
     print(fname, "loss", float(out["loss"]))
 
 
+def gen_regressor(batch, fname):
+    """Regressor baseline (models.py:28-77) with the Regression problem's MSE-sum criterion (problems.py:323-335),
+    plain and shock-conditioned (conditional=True, num_classes=3)."""
+    out = {"batch": batch}
+    g = torch.Generator().manual_seed(808)
+    x = torch.rand(batch, 3, 64, 64, generator=g)
+    pose = torch.rand(batch, 7, generator=g)
+    cond = torch.rand(batch, 3, generator=g)
+    _, masks = seeded_noise(batch, 256, 1, 2, 55)
+    out.update(x=x.numpy(), pose=pose.numpy(), cond=cond.numpy())
+    for tag, kw in (("plain", dict(num_classes=3)), ("cond", dict(conditional=True, num_classes=3))):
+        model = M.Regressor(out_dim=7, **kw)
+        model.load_state_dict(seeded_state_dict(model.state_dict(), 0))
+        model.train()
+        with Injector([], masks[:1] if tag == "plain" else masks[1:]):
+            y = model(x, cond) if tag == "cond" else model(x)
+            loss = torch.nn.MSELoss(reduction='sum')(y.view(pose.size()), pose)
+            loss.backward()
+        out[f"{tag}/out"] = y.detach().numpy()
+        out[f"{tag}/loss"] = np.float64(loss.item())
+        out[f"{tag}/keys"] = np.array(list(model.state_dict().keys()))
+        for n, p_ in model.named_parameters():
+            out[f"{tag}/grad/" + n] = summarize(p_.grad)
+        for n, b in model.named_buffers():
+            out[f"{tag}/buffer/" + n] = b.detach().numpy().astype(np.float64)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "loss", float(out["plain/loss"]), float(out["cond/loss"]))
+
+
 def gen_small_ops(fname):
     g = torch.Generator().manual_seed(2024)
     out = {}
@@ -366,6 +395,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "conditional":
         gen_conditional(2, "mvae_conditional_B2.npz")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "regressor":
+        gen_regressor(4, "regressor_B4.npz")
+        sys.exit(0)
+    gen_regressor(4, "regressor_B4.npz")
     gen_conditional(2, "mvae_conditional_B2.npz")
     gen_small_ops("small_ops.npz")
     gen_mvae_forward(3, "mvae_forward_B3.npz")

@@ -271,3 +271,41 @@ def check_conditional_loops(tmp_path, no_cuda):
 
 def test_conditional_training_loops(tmp_path):
     check_conditional_loops(tmp_path, no_cuda=True)
+
+
+def check_regressor(golden_dir, device, tmp_path):
+    """Regressor baseline through setup_model + the Regression problem against vectors from the reference."""
+    from mmdyn_hip.problems.problems import Regression
+    g = load(golden_dir, "regressor_B4.npz")
+    B = int(g["batch"])
+    _, masks = seeded_noise(B, 256, 1, 2, 55)
+    x, pose, cond = (torch.tensor(g[k]).to(device) for k in ("x", "pose", "cond"))
+    for tag in ("plain", "cond"):
+        m = setup_model("regressor", out_dim=7, conditional=tag == "cond", num_classes=3)
+        assert list(m.state_dict().keys()) == [str(k) for k in g[tag + "/keys"]]
+        m.load_state_dict(seeded_state_dict(m.state_dict(), 0))
+        m.to(device).train()
+        m.noise = InjectedNoise([], [masks[0] if tag == "plain" else masks[1]])
+        prob = Regression.__new__(Regression)
+        prob._model, prob._conditional = m, tag == "cond"
+        out, loss = prob._evaluate_model({"model_input": x, "shock": cond}, pose)
+        loss.backward()
+        assert float(loss.detach()) == pytest.approx(float(g[tag + "/loss"]), rel=1e-4)
+        np.testing.assert_allclose(out["outputs"].detach().cpu().numpy(), g[tag + "/out"], rtol=1e-4, atol=3e-5)
+        for k, p_ in m.named_parameters():
+            close_summary(summarize(p_.grad.cpu()), g[f"{tag}/grad/" + k], 1e-3, "grad " + k)
+        for k, b in m.named_buffers():
+            np.testing.assert_allclose(b.double().cpu().numpy(), g[f"{tag}/buffer/" + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    with pytest.raises(TypeError):
+        setup_model("regressor")             # num_classes=None: the reference raises the same TypeError (models.py:37)
+    # one tiny epoch through Problem.train()
+    prob = Regression(args(problem_type="regression", model_name="regressor", input_type="tactile", num_epochs=1,
+                           no_cuda=device == "cpu", conditional=True, batchsize=2),
+                      log_dir=str(tmp_path), train_loader=SyntheticVisuoTactile(2, 2, shock_dim=3),
+                      test_loader=SyntheticVisuoTactile(1, 2, seed=7, shock_dim=3))
+    prob.train()
+    assert os.path.exists(os.path.join(str(tmp_path), "results.pkl"))
+
+
+def test_regressor(golden_dir, tmp_path):
+    check_regressor(golden_dir, "cpu", tmp_path)

@@ -38,6 +38,10 @@ def test_conditional_mvae(golden_dir):
     T.check_conditional(golden_dir, DEV)
 
 
+def test_regressor(golden_dir, tmp_path):
+    T.check_regressor(golden_dir, DEV, tmp_path)
+
+
 def test_conditional_training_loops(tmp_path):
     T.check_conditional_loops(tmp_path, no_cuda=False)
 

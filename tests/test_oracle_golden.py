@@ -194,3 +194,24 @@ def test_mvae_conditional(golden_dir):
     close_summary(summarize(outputs["recon_x"][0], 256), g["recon0"], 2e-5, "recon0")
     for k in prm:
         close_summary(summarize(prm[k].grad), g["grad/" + k], 2e-4, "grad " + k)
+
+
+@pytest.mark.parametrize("tag", ["plain", "cond"])
+def test_regressor(golden_dir, tag):
+    """Regressor baseline (models.py:28-77) + MSE-sum criterion (problems.py:323-335)."""
+    g = load(golden_dir, "regressor_B4.npz")
+    B = int(g["batch"])
+    shapes = state_dict_shapes("regressor", cond=3 if tag == "cond" else 0)
+    assert list(shapes.keys()) == [str(k) for k in g[tag + "/keys"]]
+    prm, buf = O.split_state(seeded_state_dict(shapes, 0))
+    _, masks = seeded_noise(B, 256, 1, 2, 55)
+    x, pose, cond = (torch.tensor(g[k]) for k in ("x", "pose", "cond"))
+    y = O.regressor_forward(prm, x, masks[0] if tag == "plain" else masks[1], cond if tag == "cond" else None, buf)
+    loss = ((y - pose) ** 2).sum()
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g[tag + "/loss"]), rel=2e-5)
+    np.testing.assert_allclose(y.detach().numpy(), g[tag + "/out"], rtol=1e-4, atol=2e-5)
+    for k in prm:
+        close_summary(summarize(prm[k].grad), g[f"{tag}/grad/" + k], 2e-4, "grad " + k)
+    for k in buf:
+        np.testing.assert_allclose(buf[k].double().numpy(), g[f"{tag}/buffer/" + k], rtol=1e-5, atol=1e-6, err_msg=k)
