@@ -239,6 +239,20 @@ int mmdyn_adam_step(float* p, const float* g, float* m, float* v, double* state,
 int mmdyn_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
                    float weight_decay, float grad_scale, int first, void* stream);
 
+/* ---- image decode in front of the path --------------------------------------------------------
+ * transforms.Resize(input_size) + transforms.ToTensor() of datasets.py:23-31 / 375-385 on frames kept as uint8
+ * HWC in HBM: Pillow's 8-bit anti-aliased bilinear resampler (libImaging/Resample.c: 22-bit fixed-point taps,
+ * horizontal then vertical pass, each rounded to uint8) followed by /255 -> float32 CHW.  Bit-exact.
+ *   mmdyn_resize_ksize : taps per output sample for one axis (host only)
+ *   mmdyn_resize_plan  : bounds[out][2] = (first tap, tap count), coeffs[out][ksize]; returns ksize (host only)
+ *   mmdyn_resize_u8_to_chw_f32 : src uint8 [n][Hin][Win][3]; index (nullable) int32 [n_out] frame gather;
+ *                        dst float32 [n_out][3][Hout][Wout]; xb/xk, yb/yk: the DEVICE copies of the two plans */
+int mmdyn_resize_ksize(int in_size, int out_size);
+int mmdyn_resize_plan(int in_size, int out_size, int* bounds, int* coeffs);
+int mmdyn_resize_u8_to_chw_f32(const uint8_t* src, const int* index, float* dst, int n_out, int Hin, int Win,
+                               int Hout, int Wout, const int* xb, const int* xk, const int* yb, const int* yk,
+                               void* stream);
+
 /* ---- misc ------------------------------------------------------------------------------------- */
 int mmdyn_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, void* stream);
 int mmdyn_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, void* stream);

@@ -70,6 +70,9 @@ _SIGNATURES = {
     "mmdyn_elbo_assemble": "ppppp" + "ii" + "ff" + "p",
     "mmdyn_adam_step": "ppppp" + "l" + "fffff" + "p",
     "mmdyn_sgd_step": "ppp" + "l" + "ffff" + "i" + "p",
+    "mmdyn_resize_ksize": "ii",
+    "mmdyn_resize_plan": "ii" + "pp",
+    "mmdyn_resize_u8_to_chw_f32": "ppp" + "iiiii" + "pppp" + "p",
     "mmdyn_nchw_to_nhwc": "pp" + "iii" + "p",
     "mmdyn_nhwc_to_nchw": "pp" + "iii" + "p",
 }

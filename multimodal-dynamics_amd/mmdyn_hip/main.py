@@ -1,5 +1,8 @@
-"""CLI with the reference's flags and defaults (/root/reference/mmdyn/pytorch/main.py:13-54) plus the synthetic
-data source this build trains on (the on-disk dataset reader is out of scope):
+"""CLI with the reference's flags and defaults (/root/reference/mmdyn/pytorch/main.py:13-54).
+
+With ``--dataset-path`` pointing at a dataset (the PNG/json tree or its compiled pickle) it trains on it like the
+reference, decoding the frames on the GPU (utils/datasets.py).  ``--synthetic-batches N`` (this build only)
+replaces the dataset by N random batches per epoch -- the BASELINE workload:
 
     python -m mmdyn_hip.main --problem-type seq_modeling --input-type visuotactile --model-name cnn-mvae \
         --use-pose --batchsize 256 --num-epochs 2 --synthetic-batches 20
@@ -41,7 +44,8 @@ def build_parser():
     parser.add_argument('--annealing-epochs', type=int, default=50, help="Number of epochs to anneal KL for (default: 50)")
     parser.add_argument('--conditional', action='store_true', default=False, help="Conditional VAE (conditioned on the shock force)")
     # this build only
-    parser.add_argument('--synthetic-batches', type=int, default=20, help="synthetic batches per epoch")
+    parser.add_argument('--synthetic-batches', type=int, default=0,
+                        help="train on this many random batches per epoch instead of --dataset-path")
     parser.add_argument('--synthetic-seq-length', type=int, default=1, help="frames per synthetic sequence")
     parser.add_argument('--reference-schedule', action='store_true', default=False,
                         help="run the reference's 7-forward autograd schedule instead of the fused step")
@@ -53,10 +57,14 @@ def main(argv=None):
     assert args.problem_type in config.PROBLEM_TYPES, "Invalid problem type."
     L = args.synthetic_seq_length
     shock = 3 if args.conditional else 0
-    loaders = dict(train_loader=SyntheticVisuoTactile(args.synthetic_batches, args.batchsize, L, seed=1234, shock_dim=shock),
-                   test_loader=SyntheticVisuoTactile(max(1, args.synthetic_batches // 4), args.batchsize, L, seed=4321,
-                                                     shock_dim=shock),
-                   seq_length=L, fused=not args.reference_schedule)
+    if args.synthetic_batches > 0:
+        loaders = dict(train_loader=SyntheticVisuoTactile(args.synthetic_batches, args.batchsize, L, seed=1234,
+                                                          shock_dim=shock),
+                       test_loader=SyntheticVisuoTactile(max(1, args.synthetic_batches // 4), args.batchsize, L,
+                                                         seed=4321, shock_dim=shock),
+                       seq_length=L, fused=not args.reference_schedule)
+    else:
+        loaders = dict(fused=not args.reference_schedule)      # Problem.set_dataset reads --dataset-path
     problem_args = argparse.Namespace(**{k: v for k, v in vars(args).items()
                                          if not k.startswith('synthetic') and k != 'reference_schedule'})
     if args.problem_type == 'regression':

@@ -255,6 +255,24 @@ class HipBackend:
                                       int(first), _stream()), "mmdyn_sgd_step")
 
 
+    # ---- image decode (uint8 HWC frames in HBM -> float32 CHW) ----
+    def resize_plan(self, in_size, out_size, device):
+        """(bounds int32 [out][2], coeffs int32 [out][ksize]) of Pillow's 8-bit bilinear resampler, on ``device``."""
+        ks = self.lib.mmdyn_resize_ksize(in_size, out_size)
+        check(min(ks, 0), "mmdyn_resize_ksize")
+        bounds = torch.empty(out_size, 2, dtype=torch.int32)
+        coeffs = torch.empty(out_size, ks, dtype=torch.int32)
+        check(min(self.lib.mmdyn_resize_plan(in_size, out_size, bounds.data_ptr(), coeffs.data_ptr()), 0),
+              "mmdyn_resize_plan")
+        return bounds.to(device), coeffs.to(device)
+
+    def resize_u8_to_chw_f32(self, src, index, dst, n_out, Hin, Win, Hout, Wout, xb, xk, yb, yk):
+        I32 = torch.int32
+        check(self.lib.mmdyn_resize_u8_to_chw_f32(_ptr(src, torch.uint8), _ptr(index, I32), _ptr(dst), n_out, Hin, Win,
+                                                  Hout, Wout, _ptr(xb, I32), _ptr(xk, I32), _ptr(yb, I32),
+                                                  _ptr(yk, I32), _stream()), "mmdyn_resize_u8_to_chw_f32")
+
+
 B = HipBackend()
 
 

@@ -128,11 +128,26 @@ class Problem:
             raise RuntimeError("mmdyn_hip needs a ROCm GPU: there is no CPU path (run the reference for --no-cuda)")
         self._device = torch.device('cuda' if use_gpu else 'cpu')
         assert (self.parameters['input_type'] in config.INPUT_TYPES), "Input type is not implemented"
+        if self.train_loader is None and self.parameters.get('dataset_path'):
+            self.set_dataset()
         if log_dir:
             self.load_dir(log_dir)
         else:
             self.set_dir()
         self._set_problem()
+
+    def set_dataset(self):
+        """problems.py:110-125: the on-disk dataset at --dataset-path, decoded on the GPU (utils/datasets.py)."""
+        from ..utils.datasets import dataset_setup
+        self._input_size = (64, 64)
+        self._n_channels = 3
+        self.dataset_dict = dataset_setup(self.parameters['dataset_path'], self.parameters['problem_type'],
+                                          input_size=self._input_size, batchsize=self.parameters['batchsize'],
+                                          shuffle=True, device=self._device)
+        self.train_dataset, self.test_dataset = self.dataset_dict['train_dataset'], self.dataset_dict['test_dataset']
+        self.train_loader, self.test_loader = self.dataset_dict['train_loader'], self.dataset_dict['test_loader']
+        self._seq_length = self.dataset_dict['seq_length']
+        print(len(self.train_dataset), len(self.test_dataset))
 
     def _set_problem(self):
         self.set_model()

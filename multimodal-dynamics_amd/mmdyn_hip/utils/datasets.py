@@ -1,0 +1,330 @@
+"""Visuo-tactile dataset reader -- the step in front of the hot path
+(/root/reference/mmdyn/pytorch/utils/datasets.py).
+
+Same on-disk formats and the same ``dataset_setup`` / ``VisuoTactileDataset`` surface as the reference:
+
+* the PNG/json tree ``<dataset_path>/dataset/**/{visual,tactile,seg}_NNNN.png + data.json`` is compiled once into
+  ``<dataset_path>/compiled_dataset_array.pickle`` = ``{'data': [seq][frame][visual u8 256x256x3, tactile, pose7,
+  avail2(, shock)], 'targets': [seq][frame][final visual, final tactile, final pose7, seg]}`` (datasets.py:159-267);
+* 80/20 split with the reference's ``[frac:-1]`` test slice (datasets.py:99-108).
+
+What differs is where the per-frame work happens.  The reference resizes every frame with PIL and converts it
+to a float tensor on the host, one frame at a time, in the DataLoader (``num_workers=0``).  Here the unique uint8
+frames of a split are uploaded to HBM once (288 GB per GPU: a 10^5-frame split is ~20 GB), and a mini-batch is ONE
+kernel launch (``mmdyn_resize_u8_to_chw_f32``) that gathers the frames by index, resamples them exactly like
+Pillow's 8-bit bilinear filter and writes float32 CHW -- bit-identical to ``Resize(input_size) + ToTensor()``.
+"""
+import copy
+import json
+import os
+import pickle
+import random
+from collections import defaultdict
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+def normalize(x, min, max):
+    return np.nan_to_num((x - min) / (max - min), nan=0.)
+
+
+def resize_output_size(h, w, size):
+    """torchvision ``Resize``: an int scales the short side keeping the aspect ratio, a pair is (h, w)."""
+    if isinstance(size, (tuple, list)):
+        if len(size) == 2:
+            return int(size[0]), int(size[1])
+        size = size[0]
+    short, long_ = (w, h) if w <= h else (h, w)
+    new_short, new_long = int(size), int(size * long_ / short)
+    return (new_long, new_short) if w <= h else (new_short, new_long)
+
+
+class FrameDecoder:
+    """uint8 [n][H][W][3] frames on the device -> float32 [m][3][h][w] (Resize + ToTensor), gathered by index."""
+
+    def __init__(self, Hin, Win, size, device):
+        self.Hin, self.Win = Hin, Win
+        self.Hout, self.Wout = resize_output_size(Hin, Win, size)
+        self.xb, self.xk = ops.B.resize_plan(Win, self.Wout, device)
+        self.yb, self.yk = ops.B.resize_plan(Hin, self.Hout, device)
+
+    def __call__(self, frames, index=None):
+        n = int(index.numel()) if index is not None else frames.shape[0]
+        out = torch.empty(n, 3, self.Hout, self.Wout, dtype=torch.float32, device=frames.device)
+        for lo in range(0, n, 65535):          # grid.y limit of one launch
+            hi = min(n, lo + 65535)
+            idx = index[lo:hi].contiguous() if index is not None else None
+            src = frames if index is not None else frames[lo:hi]
+            ops.B.resize_u8_to_chw_f32(src, idx, out[lo:hi], hi - lo, self.Hin, self.Win, self.Hout, self.Wout,
+                                       self.xb, self.xk, self.yb, self.yk)
+        return out
+
+
+class VisuoTactileDataset:
+    """Dataset manager for visuo-tactile datasets (datasets.py:71-393)."""
+
+    def __init__(self, train=True, transform=None, dataset_path=None, real_dataset=False, train_frac=0.8,
+                 compiled_name='compiled_dataset_array', background_subtraction=False, input_size=64):
+        self._train_frac = train_frac
+        self.transform = transform                  # kept for the signature; the decode is the HIP kernel
+        self.train = train
+        self.targets = None
+        self.seq_length = None                      # like the reference: only known after compiling the tree
+        self.input_size = input_size
+        self._compiled_name = compiled_name
+        self._background_subtraction = background_subtraction
+        self._store = None
+        self.root = os.path.expanduser(dataset_path)
+        self.dataset_path = os.path.join(self.root, self._compiled_name + ".pickle")
+        if not os.path.exists(self.dataset_path):
+            self._generate_object_seq(real_dataset, sv='sv' in dataset_path)
+        with open(self.dataset_path, 'rb') as f:
+            datapoint_dict = pickle.load(f)
+        len_dataset = len(datapoint_dict['targets'])
+        frac_index = int(self._train_frac * len_dataset)
+        if 'classes' in datapoint_dict.keys():
+            self.classes = datapoint_dict['classes']
+        if self.train:
+            self.data = datapoint_dict['data'][0:frac_index]
+            self.targets = datapoint_dict['targets'][0:frac_index]
+        else:
+            self.data = datapoint_dict['data'][frac_index:-1]         # sic (datasets.py:107-108)
+            self.targets = datapoint_dict['targets'][frac_index:-1]
+
+    def __len__(self):
+        return len(self.targets)
+
+    # ---- geometry of one sample -------------------------------------------------------------------
+    @property
+    def frames_per_item(self):
+        return len(self.data[0]) if self._nested(self.data[0]) else 1
+
+    @property
+    def shock_dim(self):
+        first = self.data[0][0] if self._nested(self.data[0]) else self.data[0]
+        return int(len(first[4])) if isinstance(first, (list, tuple)) and len(first) > 4 else 0
+
+    @staticmethod
+    def _nested(item):
+        return isinstance(item, (list, tuple)) and any(isinstance(i, (list, tuple)) for i in item)
+
+    # ---- HBM-resident store -------------------------------------------------------------------------
+    def store(self, device):
+        """Upload once: unique uint8 frames (targets repeat the final frame of a sequence -- the pickle keeps one
+        object, the store keeps one copy) + float side data, and the per-(sample, frame, field) slot tables."""
+        if self._store is not None and self._store["device"] == torch.device(device):
+            return self._store
+        device = torch.device(device)
+        L = self.frames_per_item
+        slots, frames = {}, []
+        tables = {"data": None, "targets": None}
+        floats = {"data": {}, "targets": {}}
+        for name, seqs in (("data", self.data), ("targets", self.targets)):
+            n_fields = len(seqs[0][0]) if self._nested(seqs[0]) else len(seqs[0])
+            table = np.full((len(seqs), L, n_fields), -1, dtype=np.int64)
+            flt = defaultdict(list)
+            for s, seq in enumerate(seqs):
+                fr = seq if self._nested(seq) else [seq]
+                for t, fields in enumerate(fr):
+                    for j, d in enumerate(fields):
+                        d = np.asarray(d)
+                        if d.ndim > 1:
+                            if d.ndim == 2:
+                                d = np.repeat(d[:, :, None], 3, axis=2)
+                            key = id(fields[j])
+                            if key not in slots:
+                                slots[key] = len(frames)
+                                frames.append(np.ascontiguousarray(d, dtype=np.uint8))
+                            table[s, t, j] = slots[key]
+                        else:
+                            flt[j].append(d.astype(np.float32))
+            tables[name] = table
+            for j, rows in flt.items():
+                floats[name][j] = torch.from_numpy(np.stack(rows).reshape(len(seqs), L, -1)).to(device)
+        shapes = {f.shape for f in frames}
+        if len(shapes) != 1:
+            raise ValueError(f"mmdyn_hip: all frames of a split must share one size, got {sorted(shapes)}")
+        H, W, _ = frames[0].shape
+        self._store = {"device": device, "frames": torch.from_numpy(np.stack(frames)).to(device), "tables": tables,
+                       "floats": floats, "decoder": FrameDecoder(H, W, self.input_size, device), "L": L}
+        return self._store
+
+    def batch(self, seq_index, device, fold=True):
+        """Decoded mini-batch for the sequences ``seq_index``: ``(data_fields, target_fields)`` with every field
+        [B*L, ...] (``fold``, what seq_collate_fn produces) or [B, L, ...] (default collate)."""
+        st = self.store(device)
+        L = st["L"]
+        sidx = torch.as_tensor(seq_index, dtype=torch.int64)
+        out = []
+        for name in ("data", "targets"):
+            table = st["tables"][name][sidx.numpy()]                      # [B][L][fields]
+            fields = []
+            for j in range(table.shape[2]):
+                if table[0, 0, j] >= 0:
+                    idx = torch.from_numpy(table[:, :, j].reshape(-1).astype(np.int32)).to(st["device"])
+                    x = st["decoder"](st["frames"], idx)
+                else:
+                    x = st["floats"][name][j][sidx.to(st["device"])].reshape(len(sidx) * L, -1)
+                fields.append(x if fold else x.reshape(len(sidx), L, *x.shape[1:]))
+            out.append(fields)
+        return out[0], out[1]
+
+    def __getitem__(self, index):
+        """One sample, decoded: fields stacked over the frames of the sequence ([L, ...]), like the reference's
+        per-sample transform (datasets.py:113-157).  The loaders below do not go through this."""
+        dev = self._store["device"] if self._store is not None else \
+            torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        d, t = self.batch([index], dev, fold=True)
+        if not self._nested(self.data[index]):
+            d, t = [x[0] for x in d], [x[0] for x in t]
+        return d, t
+
+    # ---- compile the PNG / json tree -------------------------------------------------------------------
+    def _generate_object_seq(self, real_dataset=False, sv=False):
+        """Compile ``<root>/dataset/**`` into the pickle the reference writes (datasets.py:159-267, simulated
+        branch; PIL only).  The real-robot branch needs OpenCV colour masking (datasets.py:268-316, 352-361) and
+        is not part of this build.  Frames are matched to sequences the way the reference does it: all paths
+        sorted globally and cut into runs of ``seq_length`` = frames / data.json files."""
+        if real_dataset:
+            raise NotImplementedError("mmdyn_hip: compiling the real-robot dataset needs OpenCV; compile it with the "
+                                      "reference and point --dataset-path at the resulting pickle")
+        root = Path(self.root).joinpath("dataset")
+        lists = {k: sorted(root.glob(f'**/{k}_*.png')) for k in ("visual", "tactile", "seg")}
+        metas = []
+        for p in sorted(root.glob('**/data.json')):
+            with open(str(p)) as f:
+                metas.append(json.load(f))
+        if not metas:
+            raise FileNotFoundError(f"mmdyn_hip: no compiled pickle and no dataset/**/data.json under {self.root}")
+        L = self.seq_length = int(len(lists["visual"]) / len(metas))
+        print("Visual images: {}, Tactile images: {}, Sequences: {}, Sequence length: {}".format(
+            len(lists["visual"]), len(lists["tactile"]), len(metas), L))
+        finals = {k: sorted(root.glob(f'**/{k}_' + str(L - 1).zfill(4) + '.png')) for k in lists}
+
+        # min-max ranges over the whole tree; quaternion components keep the fixed range [-1, 1]
+        poses = np.concatenate([np.concatenate((m['position'], m['orientation']), axis=1) for m in metas], axis=0)
+        shocks = np.concatenate([np.array(m['shock']) if 'shock' in m else np.zeros(1) for m in metas], axis=0)
+        pose_lo, pose_hi = np.min(poses, axis=0), np.max(poses, axis=0)
+        shock_lo, shock_hi = np.min(shocks, axis=0), np.max(shocks, axis=0)
+        pose_lo[3:], pose_hi[3:] = -1, 1
+
+        def pose_of(meta, t):
+            return normalize(np.concatenate((meta['position'][t], meta['orientation'][t])), pose_lo, pose_hi)
+
+        compiled = {'data': [], 'targets': []}
+        n_seq = len(lists["visual"]) // L
+        # the reference appends a sequence only when the NEXT one starts, so the last one never makes it in
+        for s in range(n_seq - 1):
+            meta = metas[s]
+            box = self._bounding_box(self._load_image(finals["seg"][s], resize=False))
+            end_visual = self._load_image(finals["visual"][s], bounding_box=box)
+            end_tactile = self._load_image(finals["tactile"][s], bounding_box=box)
+            end_pose = pose_of(meta, -1)
+            frames, goals = [], []
+            for t in range(L):
+                i = s * L + t
+                box = self._bounding_box(self._load_image(lists["seg"][i], resize=False))
+                seg = self._load_image(lists["seg"][i], bounding_box=box)
+                seg = np.where(seg == 1, 0, seg)
+                visual = self._load_image(lists["visual"][i], bounding_box=box)
+                tactile = self._load_image(lists["tactile"][i], bounding_box=box)
+                avail = np.array([float(np.std(visual, axis=(0, 1)).any()), float(np.std(tactile, axis=(0, 1)).any())])
+                frame = [visual, tactile, pose_of(meta, t), avail]
+                if 'shock' in meta:
+                    frame.append(normalize(np.array(meta['shock'][t]), shock_lo, shock_hi))
+                frames.append(frame)
+                goals.append([end_visual, end_tactile, end_pose, seg])
+            for _ in range(L // 5 if sv else 1):      # 'sv' trees repeat every sequence L//5 times (shallow copies)
+                compiled['data'].append(copy.copy(frames) if sv else frames)
+                compiled['targets'].append(copy.copy(goals) if sv else goals)
+
+        paired = list(zip(compiled['data'], compiled['targets']))
+        random.shuffle(paired)
+        out = defaultdict(list)
+        out['data'], out['targets'] = zip(*paired)
+        with open(os.path.join(self.root, self._compiled_name + ".pickle"), 'wb') as f:
+            pickle.dump(out, f)
+        return out
+
+    @staticmethod
+    def _load_image(img_path, bounding_box=None, resize=True):
+        from PIL import Image
+        img = Image.open(img_path)
+        if bounding_box is not None:
+            img = img.crop(bounding_box)
+        if resize:
+            img = img.resize((256, 256))
+        np_img = np.array(img).copy()
+        if np_img.ndim == 2:
+            np_img = np.repeat(np_img[:, :, np.newaxis], 3, axis=2).astype(np.uint8)
+        img.close()
+        return np_img
+
+    @staticmethod
+    def _bounding_box(img):
+        """Square-ish box around the pixels of the highest segmentation id (datasets.py:336-350)."""
+        mask = np.where(img == np.max(img))
+        ymin, ymax = np.min(mask[0]), np.max(mask[0])
+        xmin, xmax = np.min(mask[1]), np.max(mask[1])
+        diff = (ymax - ymin) - (xmax - xmin)
+        if diff > 0:
+            xmin = max(0, xmin - diff / 2)
+            xmax = min(img.shape[1], xmax + diff / 2)
+        elif diff < 0:
+            ymin = max(0, ymin - abs(diff) / 2)
+            ymax = min(img.shape[0], ymax + abs(diff) / 2)
+        return xmin, ymin, xmax, ymax
+
+
+class DeviceLoader:
+    """Mini-batch iterator over a device-resident split: ``drop_last=True``, optional shuffling, and the two
+    collation shapes of the reference's DataLoader (``seq_collate_fn`` -> [B*L, ...]; default -> [B, L, ...])."""
+
+    def __init__(self, dataset, batch_size, shuffle=False, fold=True, device=None, seed=None):
+        self.dataset, self.batch_size, self.shuffle, self.fold = dataset, int(batch_size), shuffle, fold
+        self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.generator = torch.Generator()
+        if seed is not None:
+            self.generator.manual_seed(seed)
+        self.shock_dim = dataset.shock_dim
+
+    def __len__(self):
+        return len(self.dataset) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.dataset)
+        order = torch.randperm(n, generator=self.generator) if self.shuffle else torch.arange(n)
+        for b in range(len(self)):
+            yield self.dataset.batch(order[b * self.batch_size:(b + 1) * self.batch_size], self.device, self.fold)
+
+
+def seq_collate_fn(batch):
+    """datasets.py:395-404 (for code that collates decoded samples itself)."""
+    data_input, data_target = zip(*batch)
+    data_input = list(map(list, zip(*data_input)))
+    data_target = list(map(list, zip(*data_target)))
+    return ([torch.cat(x, dim=0) for x in data_input], [torch.cat(x, dim=0) for x in data_target])
+
+
+def dataset_setup(dataset_path, problem_type, **kwargs):
+    """datasets.py:20-68: same keys in the returned dict; the loaders are :class:`DeviceLoader`."""
+    print("Loading dataset from {}".format(dataset_path))
+    size = kwargs.get('input_size', 64)
+    train_dataset = VisuoTactileDataset(train=True, dataset_path=dataset_path, input_size=size)
+    test_dataset = VisuoTactileDataset(train=False, dataset_path=dataset_path, input_size=size)
+    fold = 'seq' in problem_type
+    device = kwargs.get('device')
+    out_dict = {
+        'train_dataset': train_dataset,
+        'test_dataset': test_dataset,
+        'train_loader': DeviceLoader(train_dataset, kwargs['batchsize'], shuffle=kwargs['shuffle'], fold=fold, device=device),
+        'test_loader': DeviceLoader(test_dataset, kwargs['batchsize'], shuffle=False, fold=fold, device=device),
+        'seq_length': train_dataset.seq_length,
+    }
+    if hasattr(train_dataset, 'classes'):
+        out_dict['classes'] = train_dataset.classes
+    return out_dict

@@ -8,6 +8,8 @@ imported by the product.  GPU tests (-m gpu) run the real library and compare ag
 """
 import math
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -451,3 +453,21 @@ class EmuBackend:
         d = g * grad_scale + weight_decay * p
         buf.copy_(d if first else momentum * buf + d)
         p.sub_(lr * buf)
+
+    # ---- image decode ----
+    def resize_plan(self, in_size, out_size, device):
+        ks = self.lib.mmdyn_resize_ksize(in_size, out_size)
+        bounds = torch.empty(out_size, 2, dtype=torch.int32)
+        coeffs = torch.empty(out_size, ks, dtype=torch.int32)
+        assert self.lib.mmdyn_resize_plan(in_size, out_size, bounds.data_ptr(), coeffs.data_ptr()) == ks
+        return bounds, coeffs
+
+    def resize_u8_to_chw_f32(self, src, index, dst, n_out, Hin, Win, Hout, Wout, xb, xk, yb, yk):
+        from oracle import resize_oracle as RO
+        frames = src.reshape(-1, Hin, Win, 3).numpy()
+        out = dst.reshape(n_out, 3, Hout, Wout)
+        for b in range(n_out):
+            img = frames[int(index[b]) if index is not None else b]
+            r = RO.resize_bilinear_u8(img, Hout, Wout)
+            out[b] = torch.from_numpy(np.ascontiguousarray(r.transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0))
+

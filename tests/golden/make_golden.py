@@ -19,6 +19,7 @@ What it does (SURVEY.md section 8c recipe):
     outputs as ``.npz`` (data only; no reference source is stored).
 """
 import io
+import pickle
 import os
 import sys
 import types
@@ -319,6 +320,48 @@ def gen_regressor(batch, fname):
     print(fname, "loss", float(out["plain/loss"]), float(out["cond/loss"]))
 
 
+def gen_dataset(fname):
+    """The reference's own tree compiler (datasets.py:159-267) on tests/synthetic_tree.build_tree, and PIL's
+    Resize(64)+ToTensor arithmetic (datasets.py:23-31) on sample frames.  torchvision is not installed here; what its
+    Resize does to a PIL image is ``img.resize((w, h), BILINEAR)`` with the short side scaled to 64."""
+    import random
+    import tempfile
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synthetic_tree as ST
+    from mmdyn.pytorch.utils import datasets as RD
+    out = {}
+    for tag, shock in (("shock", True), ("plain", False)):
+        with tempfile.TemporaryDirectory() as tmp:
+            ST.build_tree(tmp, shock=shock)
+            random.seed(7)
+            ds = RD.VisuoTactileDataset(train=True, transform=None, dataset_path=tmp)
+            with open(ds.dataset_path, "rb") as f:
+                comp = pickle.load(f)
+            desc = ST.describe(comp)
+            out[f"tree/{tag}/keys"] = np.array(list(desc.keys()))
+            out[f"tree/{tag}/sha"] = np.array(list(desc.values()))
+            out[f"tree/{tag}/n_train"] = len(ds)
+            out[f"tree/{tag}/seq_length"] = ds.seq_length
+            out[f"tree/{tag}/n_test"] = len(RD.VisuoTactileDataset(train=False, transform=None, dataset_path=tmp))
+            if shock:
+                out["tree/sample_pose"] = np.asarray(comp["data"][0][1][2])
+                out["tree/sample_shock"] = np.asarray(comp["data"][0][1][4])
+                out["tree/sample_visual"] = comp["data"][0][0][0]
+                img = comp["data"][0][0][0]
+                out["tree/sample_visual_64"] = np.array(Image.fromarray(img).resize((64, 64), Image.BILINEAR))
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+    out["resize/noise"] = noise
+    out["resize/noise_64"] = np.array(Image.fromarray(noise).resize((64, 64), Image.BILINEAR))
+    out["resize/noise_128"] = np.array(Image.fromarray(noise).resize((128, 128), Image.BILINEAR))
+    rect = rng.integers(0, 256, (120, 200, 3), dtype=np.uint8)
+    out["resize/rect"] = rect
+    out["resize/rect_64"] = np.array(Image.fromarray(rect).resize((106, 64), Image.BILINEAR))     # Resize(64): 64 x int(64*200/120)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "sequences", int(out["tree/shock/n_train"]), int(out["tree/shock/n_test"]))
+
+
 def gen_small_ops(fname):
     g = torch.Generator().manual_seed(2024)
     out = {}
@@ -395,6 +438,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "conditional":
         gen_conditional(2, "mvae_conditional_B2.npz")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        gen_dataset("dataset_tree.npz")
+        sys.exit(0)
+    gen_dataset("dataset_tree.npz")
     if len(sys.argv) > 1 and sys.argv[1] == "regressor":
         gen_regressor(4, "regressor_B4.npz")
         sys.exit(0)
