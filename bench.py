@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16), no sparsity
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = fp32 vector peak
 ALGO_GFLOP_PER_SAMPLE = 2.024      # distinct contractions of one train step
 KL_WEIGHT = 1.0 / 50               # epoch 0 of the reference's annealing schedule (problems.py:212-216)
@@ -107,6 +108,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a HIP graph")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32: the BASELINE configs[1] line (default).  bf16: bf16 matrix-core operands with fp32 "
+                         "accumulate/storage/master weights, the per-GPU share of configs[2] (use --batch 128)")
     ap.add_argument("--single-lane", action="store_true",
                     help="no visual/tactile stream overlap: per-kernel durations in a rocprofv3 trace then match "
                          "the roofline object's live HIP-event measurement")
@@ -135,7 +139,8 @@ def main():
     model = setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=4096, architecture="cnn",
                         conditional=False, categorical_conditions=False, latent_size=256, use_pose=True).to(dev).train()
     step = MVAEStep(model, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), process_group=pg,
-                    world_size=world, two_lanes=not args.single_lane)
+                    world_size=world, two_lanes=not args.single_lane,
+                    precision="bf16" if args.dtype == "bf16" else "fp32")
     inputs, targets = seeded_batch(args.batch, 1234 + rank)
     inputs, targets = [x.to(dev) for x in inputs], [x.to(dev) for x in targets]
 
@@ -187,24 +192,30 @@ def main():
     dom_name = "igemm_nt_kernel" if dom is ig else "wgrad_tn_kernel"
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     total_ms = sum(d["ms"] for d in kern.values())
+    peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     out = {
         "metric": "visuotactile samples/sec (train) + ELBO vs CPU ref, cnn-mvae 64x64 bs256 @1/2/4/8 GPU",
         "value": sps, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cnn-mvae visuotactile+pose 64x64, bs=256 per GPU, fp32, seq_modeling train step "
-                               "(7 subset ELBOs + backward + Adam), BASELINE configs[1]",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": (f"cnn-mvae visuotactile+pose 64x64, bs={args.batch} per GPU, fp32, seq_modeling "
+                                "train step (7 subset ELBOs + backward + Adam), BASELINE configs[1]")
+                   if args.dtype == "f32" else
+                   (f"cnn-mvae visuotactile+pose 64x64, bs={args.batch} per GPU, bf16 matrix-core operands (fp32 "
+                    "accumulate, storage and master weights), seq_modeling train step, per-GPU share of BASELINE "
+                    "configs[2]"),
                    "global_batch": global_batch, "parallelism": f"dp{world}", "bn": "local",
                    "launch": "eager" if args.no_graph else "hip_graph",
                    "final_loss": final_loss},
-        "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom_name),
+        "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": peak,
+                     "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": pmc_traffic(dom_name) if args.dtype == "f32" else None,
                      "algorithmic_flops_per_launch": dom["flops"] / max(dom["calls"], 1),
                      "operand_bytes_per_launch": dom["bytes"] / max(dom["calls"], 1),
                      "launches_per_step": dom["calls"], "avg_launch_ms": dom["ms"] / max(dom["calls"], 1),
                      "kernel_share_of_step": dom["ms"] / total_ms if total_ms else None,
                      "step_algorithmic_tflops": sps / world * ALGO_GFLOP_PER_SAMPLE * 1e9 / 1e12,
-                     "step_frac_of_peak": sps / world * ALGO_GFLOP_PER_SAMPLE * 1e9 / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                     "step_frac_of_peak": sps / world * ALGO_GFLOP_PER_SAMPLE * 1e9 / 1e12 / peak},
     }
     if args.breakdown:
         for k, d in sorted(kern.items(), key=lambda kv: -kv[1]["ms"]):

@@ -66,6 +66,13 @@ int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C,
                    float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
                    int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
                    void* stream);
+/* Same contract, bf16 matrix cores: the fp32 operands are rounded to bf16 (round-to-nearest-even) on their way
+ * into the MFMA (v_mfma_f32_32x32x16_bf16), products are accumulated in fp32, everything in HBM stays fp32.
+ * The reduced-precision mode of BASELINE configs[2] ("bf16"); never used by the fp32 path. */
+int mmdyn_igemm_nt_bf16(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
+                        float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
+                        int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
+                        void* stream);
 int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
 int mmdyn_splitk_reduce(const float* ws, const float* bias, float* C, float* C_act, int splitk,
                         int rows, int N, int act, void* stream);
@@ -83,6 +90,9 @@ int mmdyn_splitk_reduce(const float* ws, const float* bias, float* C, float* C_a
  * Requirements: Cd % 32 == 0, Cg % 32 == 0. */
 int mmdyn_wgrad_tn(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr, int Wr,
                    int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks, void* stream);
+/* bf16 matrix cores (v_mfma_f32_32x32x8_bf16), fp32 accumulate; see mmdyn_igemm_nt_bf16 */
+int mmdyn_wgrad_tn_bf16(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr, int Wr,
+                        int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks, void* stream);
 /* recommended `chunks` (a multiple of 4) for mmdyn_wgrad_tn; partial must hold chunks*taps*Cd*Cg floats */
 int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg);
 int mmdyn_wgrad_reduce(const float* partial, float* canon, int chunks, int taps, int Cd, int Cg,

@@ -49,7 +49,17 @@ constexpr int LDS_LD = BK + 4;      // row stride: one 16-byte pad slot keeps ds
 constexpr int GRANS = BK / 4;       // 16-byte granules per tile row
 constexpr int ROWS_PER_PASS = 256 / GRANS;
 
-template <int MODE, int BM, int BN, int WM, int WN>
+// BF16 = true: the fp32 tiles in LDS are rounded to bf16 (RNE) as they are read into fragments and multiplied
+// with v_mfma_f32_32x32x16_bf16 (fp32 accumulate): 16x fewer matrix-core cycles, the staging is unchanged.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {
+  bf16x8 r;
+  r[0] = (__bf16)lo[0]; r[1] = (__bf16)lo[1]; r[2] = (__bf16)lo[2]; r[3] = (__bf16)lo[3];
+  r[4] = (__bf16)hi[0]; r[5] = (__bf16)hi[1]; r[6] = (__bf16)hi[2]; r[7] = (__bf16)hi[3];
+  return r;
+}
+
+template <int MODE, int BM, int BN, int WM, int WN, bool BF16>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__ A,
                                                        const float* __restrict__ Bp,
                                                        const float* __restrict__ bias,
@@ -261,6 +271,27 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
 #endif
       const float* Ac = As + cur * STAGE;
       const float* Bc = Bs + cur * STAGE;
+      if constexpr (BF16) {
+#pragma unroll
+        for (int q = 0; q < BK / 8; q += 2) {     // one 16-deep bf16 MFMA = the k-slices of two fp32 fragment reads
+          bf16x8 pa[MT], pb[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float* p = &Ac[(wm * WM + mt * 32) * LDS_LD + frag_off + q * 8];
+            pa[mt] = pack_bf16(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 8));
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const float* p = &Bc[(wn * WN + nt * 32) * LDS_LD + frag_off + q * 8];
+            pb[nt] = pack_bf16(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 8));
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mt], pb[nt], acc[mt][nt], 0, 0, 0);
+        }
+      } else
 #pragma unroll
       for (int q = 0; q < BK / 8; ++q) {
         f32x4 af[MT], bf[NT];
@@ -424,7 +455,7 @@ static void pick_tile(int N, int rows_per_group, int G, int ncls, int splitk, in
 
 template <int MODE, int BM, int BN, int WM, int WN>
 static int launch_m(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats,
-                    float* ws, IgemmGeom g, hipStream_t st) {
+                    float* ws, IgemmGeom g, hipStream_t st, bool bf16) {
   g.tiles_per_group = ceil_div(g.Bg * g.Hr * g.Wr, BM);
   if (MODE == MMDYN_TCONV_S1P0) {
     g.tiles_per_pixel = ceil_div(g.Bg, BM);
@@ -433,19 +464,25 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   const int mx8 = (g.G * g.tiles_per_group + 7) / 8 * 8;
   dim3 grid((unsigned)mx8 * (g.N / BN) * g.nclasses * g.splitk);
   size_t smem = (size_t)(IG_DBUF ? 2 : 1) * (BM + BN) * LDS_LD * sizeof(float) + (size_t)BM * 4 * sizeof(int);
-  hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN>), grid, dim3(256), smem, st, A, Bp, bias, C, C_act,
-                     stats, ws, g);
+  if (bf16)
+    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true>), grid, dim3(256), smem, st, A, Bp, bias, C,
+                       C_act, stats, ws, g);
+  else
+    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, false>), grid, dim3(256), smem, st, A, Bp, bias, C,
+                       C_act, stats, ws, g);
   MMDYN_LAUNCH_CHECK();
 }
 
 template <int BM, int BN, int WM, int WN>
 static int launch(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats,
-                  float* ws, IgemmGeom g, hipStream_t st) {
-  if (g.mode == MMDYN_DENSE) return launch_m<MMDYN_DENSE, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
-  if (g.mode == MMDYN_CONV) return launch_m<MMDYN_CONV, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
-  if (g.mode == MMDYN_IM2COL3) return launch_m<MMDYN_IM2COL3, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
-  if (g.mode == MMDYN_TCONV_S1P0) return launch_m<MMDYN_TCONV_S1P0, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
-  return launch_m<MMDYN_TCONV_S2P1, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st);
+                  float* ws, IgemmGeom g, hipStream_t st, bool bf16) {
+  if (g.mode == MMDYN_DENSE) return launch_m<MMDYN_DENSE, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  if (g.mode == MMDYN_CONV) return launch_m<MMDYN_CONV, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  if (g.mode == MMDYN_IM2COL3)
+    return launch_m<MMDYN_IM2COL3, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  if (g.mode == MMDYN_TCONV_S1P0)
+    return launch_m<MMDYN_TCONV_S1P0, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  return launch_m<MMDYN_TCONV_S2P1, BM, BN, WM, WN>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
 }
 
 }  // namespace
@@ -469,10 +506,10 @@ extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, i
   return ncls * ceil_div(Bg * Hr * Wr, bm);
 }
 
-extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
-                              float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
-                              int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
-                              void* stream) {
+static int igemm_entry(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
+                       float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
+                       int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
+                       void* stream, bool bf16) {
   if (!A || !Bp || !C) return MMDYN_ERR_NULL;
   if (Cin <= 0 || N <= 0 || Cin % BK || N % 32 || G <= 0 || Bg <= 0 || ldc < N) return MMDYN_ERR_SHAPE;
   if (splitk < 1) splitk = 1;
@@ -545,12 +582,28 @@ extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias
     pick_tile(N, Bg, G * 16, 1, 1, 0, &bm, &bn);
   else
     pick_tile(N, Bg * g.Hr * g.Wr, G, g.nclasses, splitk, g.ntaps * (Cin / BK), &bm, &bn);
-  if (bn == 128 && bm == 128) return launch<128, 128, 64, 64>(A, Bp, bias, C, C_act, stats, ws, g, st);
-  if (bn == 128 && bm == 64) return launch<64, 128, 32, 64>(A, Bp, bias, C, C_act, stats, ws, g, st);
-  if (bn == 64 && bm == 128) return launch<128, 64, 64, 32>(A, Bp, bias, C, C_act, stats, ws, g, st);
-  if (bn == 64 && bm == 64) return launch<64, 64, 32, 32>(A, Bp, bias, C, C_act, stats, ws, g, st);
-  if (bn == 32 && bm == 256) return launch<256, 32, 64, 32>(A, Bp, bias, C, C_act, stats, ws, g, st);
-  return launch<128, 32, 32, 32>(A, Bp, bias, C, C_act, stats, ws, g, st);
+  if (bn == 128 && bm == 128) return launch<128, 128, 64, 64>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  if (bn == 128 && bm == 64) return launch<64, 128, 32, 64>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  if (bn == 64 && bm == 128) return launch<128, 64, 64, 32>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  if (bn == 64 && bm == 64) return launch<64, 64, 32, 32>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  if (bn == 32 && bm == 256) return launch<256, 32, 64, 32>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  return launch<128, 32, 32, 32>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+}
+
+extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
+                              float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
+                              int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
+                              void* stream) {
+  return igemm_entry(A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act,
+                     splitk, stream, false);
+}
+
+extern "C" int mmdyn_igemm_nt_bf16(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
+                                   float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
+                                   int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
+                                   void* stream) {
+  return igemm_entry(A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act,
+                     splitk, stream, true);
 }
 
 extern "C" int mmdyn_splitk_reduce(const float* ws, const float* bias, float* C, float* C_act, int splitk,

@@ -31,7 +31,17 @@ constexpr int RK = 32;  // rows per K-step
 
 // WK = number of waves that split the rows of one K-step between them (small channel tiles cannot
 // occupy four waves with distinct 32x32 outputs); each of them owns its own partial slab.
-template <int BD, int BG, int WD, int WG, int WK>
+// BF16 = true: fragments are rounded to bf16 (RNE) as they leave LDS and multiplied 8 rows at a time with
+// v_mfma_f32_32x32x8_bf16 (fp32 accumulate); the staging and the partial-slab scheme are unchanged.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 pack4_bf16(float a, float b, float c, float d) {
+  bf16x4 r;
+  r[0] = (__bf16)a; r[1] = (__bf16)b; r[2] = (__bf16)c; r[3] = (__bf16)d;
+  return __builtin_bit_cast(s16x4, r);
+}
+
+template <int BD, int BG, int WD, int WG, int WK, bool BF16>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__ D,
                                                        const float* __restrict__ Gt,
                                                        float* __restrict__ partial, const WgradGeom g) {
@@ -155,6 +165,27 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
     for (int r0 = row_begin; r0 < row_end; r0 += RK) {
       gload(r0 + RK);                      // past the chunk end every row is masked: a harmless dummy fetch
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BF16) {
+#pragma unroll
+        for (int r8 = wk * 2 * KPW; r8 < (wk + 1) * 2 * KPW; r8 += 8) {     // 8 rows per bf16 MFMA: lane half h -> 4 rows
+          s16x4 pa[DT], pb[GT];
+#pragma unroll
+          for (int a = 0; a < DT; ++a) {
+            const float* p = &Ds[(r8 + 4 * h) * BD + wd * WD + a * 32 + cl];
+            pa[a] = pack4_bf16(p[0], p[BD], p[2 * BD], p[3 * BD]);
+          }
+#pragma unroll
+          for (int b = 0; b < GT; ++b) {
+            const float* p = &Gs[(r8 + 4 * h) * BG + wg * WG + b * 32 + cl];
+            pb[b] = pack4_bf16(p[0], p[BG], p[2 * BG], p[3 * BG]);
+          }
+#pragma unroll
+          for (int a = 0; a < DT; ++a)
+#pragma unroll
+            for (int b = 0; b < GT; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(pa[a], pb[b], acc[a][b], 0, 0, 0);
+        }
+      } else
 #pragma unroll
       for (int kk = wk * KPW; kk < (wk + 1) * KPW; ++kk) {
         float af[DT], bf[GT];
@@ -192,7 +223,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
 // the four kw taps of one kernel row kh and share ONE dense-operand tile, so D is fetched once per 4 taps instead
 // of once per tap (half the L2 traffic of the one-tap kernel on these shapes) and no wave has to split the row
 // reduction (WK = 1: a quarter / half of the partial slabs).  grid.y = kh.
-template <int BD, int BG>
+template <int BD, int BG, bool BF16>
 __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict__ D, const float* __restrict__ Gt,
                                                         float* __restrict__ partial, const WgradGeom g) {
   constexpr int DT = BD / 32, GT = BG / 32;
@@ -275,6 +306,27 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
     for (int r0 = row_begin; r0 < row_end; r0 += RK) {
       gload(r0 + RK);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BF16) {
+#pragma unroll
+        for (int r8 = 0; r8 < RK; r8 += 8) {
+          s16x4 pa[DT], pb[GT];
+#pragma unroll
+          for (int a = 0; a < DT; ++a) {
+            const float* p = &Ds[(r8 + 4 * h) * BD + a * 32 + cl];
+            pa[a] = pack4_bf16(p[0], p[BD], p[2 * BD], p[3 * BD]);
+          }
+#pragma unroll
+          for (int b = 0; b < GT; ++b) {
+            const float* p = &Gw[(r8 + 4 * h) * BG + b * 32 + cl];
+            pb[b] = pack4_bf16(p[0], p[BG], p[2 * BG], p[3 * BG]);
+          }
+#pragma unroll
+          for (int a = 0; a < DT; ++a)
+#pragma unroll
+            for (int b = 0; b < GT; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(pa[a], pb[b], acc[a][b], 0, 0, 0);
+        }
+      } else
 #pragma unroll
       for (int kk = 0; kk < RK / 2; ++kk) {
         float af[DT], bf[GT];
@@ -305,12 +357,15 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
 }
 
 template <int BD, int BG>
-static int launch4(const float* D, const float* Gt, float* partial, WgradGeom g, hipStream_t st) {
+static int launch4(const float* D, const float* Gt, float* partial, WgradGeom g, hipStream_t st, bool bf16) {
   int rpc = ceil_div(g.rows, g.chunks);
   g.rows_per_chunk = ceil_div(rpc, RK) * RK;
   dim3 grid((g.Cd / BD) * (g.Cg / BG), 4, g.chunks);
   size_t smem = (size_t)RK * (BD + 4 * BG) * sizeof(float);
-  hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  if (bf16)
+    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  else
+    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, false>), grid, dim3(256), smem, st, D, Gt, partial, g);
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -364,21 +419,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 template <int BD, int BG, int WD, int WG, int WK>
-static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, hipStream_t st) {
+static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, hipStream_t st, bool bf16) {
   const int zblocks = g.chunks / WK;  // chunks % 4 == 0 is checked by the caller
   int rpc = ceil_div(g.rows, zblocks);
   g.rows_per_chunk = ceil_div(rpc, RK) * RK;
   dim3 grid((g.Cd / BD) * (g.Cg / BG), g.ntaps, zblocks);
   size_t smem = (size_t)RK * (BD + BG) * sizeof(float);
-  hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  if (bf16)
+    hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  else
+    hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK, false>), grid, dim3(256), smem, st, D, Gt, partial, g);
   MMDYN_LAUNCH_CHECK();
 }
 
 }  // namespace
 
-extern "C" int mmdyn_wgrad_tn(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr,
-                              int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
-                              void* stream) {
+static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr,
+                       int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
+                       void* stream, bool bf16) {
   if (!D || !Gt || !partial) return MMDYN_ERR_NULL;
   if (Cd % 32 || Cg % 32 || Cd <= 0 || Cg <= 0 || chunks < 4 || chunks % 4) return MMDYN_ERR_SHAPE;
   if (mode != MMDYN_DENSE && mode != MMDYN_CONV && mode != MMDYN_IM2COL3) return MMDYN_ERR_SHAPE;
@@ -401,17 +459,29 @@ extern "C" int mmdyn_wgrad_tn(const float* D, const float* Gt, float* partial, i
   g.chunks = chunks;
   hipStream_t st = (hipStream_t)stream;
   const bool d64 = (Cd % 64 == 0), g64 = (Cg % 64 == 0);
-  if (Cd % 128 == 0 && Cg % 128 == 0) return launch<128, 128, 64, 64, 1>(D, Gt, partial, g, st);
+  if (Cd % 128 == 0 && Cg % 128 == 0) return launch<128, 128, 64, 64, 1>(D, Gt, partial, g, st, bf16);
   if (mode == MMDYN_CONV && !(d64 && g64)) {   // narrow channel tiles: four kw taps per block share the dense
-    if (d64) return launch4<64, 32>(D, Gt, partial, g, st);   // operand (measured +11 %; 64x64 tiles are faster
+    if (d64) return launch4<64, 32>(D, Gt, partial, g, st, bf16);   // operand (measured +11 %; 64x64 tiles are faster
                                                               // on the one-tap kernel, so they stay there)
-    if (g64) return launch4<32, 64>(D, Gt, partial, g, st);
-    return launch4<32, 32>(D, Gt, partial, g, st);
+    if (g64) return launch4<32, 64>(D, Gt, partial, g, st, bf16);
+    return launch4<32, 32>(D, Gt, partial, g, st, bf16);
   }
-  if (d64 && g64) return launch<64, 64, 32, 32, 1>(D, Gt, partial, g, st);
-  if (d64) return launch<64, 32, 32, 32, 2>(D, Gt, partial, g, st);
-  if (g64) return launch<32, 64, 32, 32, 2>(D, Gt, partial, g, st);
-  return launch<32, 32, 32, 32, 4>(D, Gt, partial, g, st);
+  if (d64 && g64) return launch<64, 64, 32, 32, 1>(D, Gt, partial, g, st, bf16);
+  if (d64) return launch<64, 32, 32, 32, 2>(D, Gt, partial, g, st, bf16);
+  if (g64) return launch<32, 64, 32, 32, 2>(D, Gt, partial, g, st, bf16);
+  return launch<32, 32, 32, 32, 4>(D, Gt, partial, g, st, bf16);
+}
+
+extern "C" int mmdyn_wgrad_tn(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr,
+                              int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
+                              void* stream) {
+  return wgrad_entry(D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks, stream, false);
+}
+
+extern "C" int mmdyn_wgrad_tn_bf16(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr,
+                                   int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
+                                   void* stream) {
+  return wgrad_entry(D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks, stream, true);
 }
 
 // recommended number of partial slabs: ~1024 blocks in flight, at least 128 rows per block

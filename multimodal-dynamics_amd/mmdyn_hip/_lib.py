@@ -29,9 +29,11 @@ MAX_EXPERTS = 4
 # name -> argument type codes, in header order: p pointer, i int, l int64, f float, Q uint64
 _SIGNATURES = {
     "mmdyn_igemm_nt": "ppppppp" + "iiiiiiiiiiiiii" + "p",
+    "mmdyn_igemm_nt_bf16": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_stat_tiles": "iiiiiiiii",
     "mmdyn_splitk_reduce": "pppp" + "iiii" + "p",
     "mmdyn_wgrad_tn": "ppp" + "iiiiiiiiiii" + "p",
+    "mmdyn_wgrad_tn_bf16": "ppp" + "iiiiiiiiiii" + "p",
     "mmdyn_wgrad_chunks": "iiii",
     "mmdyn_wgrad_reduce": "pp" + "iiiiii" + "f" + "p",
     "mmdyn_pack_conv_weight": "pp" + "iii" + "p",

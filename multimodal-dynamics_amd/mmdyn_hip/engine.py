@@ -109,14 +109,33 @@ class _Lanes:
                 main.wait_event(s.record_event())
 
 
+def _with_precision(fn):
+    """Run a step method with the engine's matrix-core precision selected on the active backend."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        prev = getattr(ops.B, "precision", "fp32")
+        ops.B.precision = self.precision
+        try:
+            return fn(self, *a, **k)
+        finally:
+            ops.B.precision = prev
+    return wrapped
+
+
 class MVAEStep:
     """Fused train / eval step for an :class:`mmdyn_hip.models.MVAE` on one GPU (one rank)."""
 
     def __init__(self, model, lr=1e-3, pose_multiplier=1000.0, betas=(0.9, 0.999), eps=1e-8, noise=None,
-                 process_group=None, world_size=1, two_lanes=True):
+                 process_group=None, world_size=1, two_lanes=True, precision="fp32"):
         if getattr(model, "conditional", False):
             raise NotImplementedError("mmdyn_hip: the fused step is built for the unconditional cnn-mvae; run conditional "
                                       "models through the module API (Problem(..., fused=False))")
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' (the reference's arithmetic) or 'bf16' (bf16 matrix-core "
+                             "operands, fp32 accumulate and storage: BASELINE configs[2])")
+        self.precision = precision
         self.model = model
         self.use_pose = bool(model._use_pose)
         self.L = model.latent_size
@@ -338,6 +357,7 @@ class MVAEStep:
         layers.interleave([(lambda: LN.lane(0), phase("v")), (lambda: LN.lane(1), phase("t"))])
 
     # ------------------------------------------------------------------------------------------
+    @_with_precision
     def forward(self, inputs, targets, kl_weight, train=True):
         """Runs the forward schedule and the loss; with train=True also fills the loss gradients needed by
         :meth:`backward`.  Returns the device scalar loss (fp32)."""
@@ -378,6 +398,7 @@ class MVAEStep:
         return out
 
     # ------------------------------------------------------------------------------------------
+    @_with_precision
     def backward(self):
         """Reverse schedule; fills the flat gradient buffer.  Returns async all-reduce handles (if any)."""
         LN = self.lanes
@@ -411,6 +432,7 @@ class MVAEStep:
         ops.B.adam_step(self.params.flat, self.params.grad, self.adam_m, self.adam_v, self.adam_state, self.lr,
                         self.betas[0], self.betas[1], self.eps, 1.0 / self.world)
 
+    @_with_precision
     def train_step(self, inputs, targets, kl_weight):
         """zero_grad -> forward -> backward -> (all-reduce) -> Adam, as problems.py:150-155.  Gradients are
         overwritten, not accumulated, so no zero_grad pass is needed."""
@@ -420,6 +442,7 @@ class MVAEStep:
         return loss
 
     # ------------------------------------------------------------------------------------------
+    @_with_precision
     def train_step_graphed(self, inputs, targets, kl_weight):
         """Same as :meth:`train_step`, replayed from HIP graphs: the ~300 kernel launches of a step are captured
         once per (batch shape, kl_weight).  Each phase is its OWN graph: the visual and the tactile phases are
@@ -512,6 +535,7 @@ class MVAEStep:
                     main.wait_event(side[lane].record_event())
 
     @torch.no_grad()
+    @_with_precision
     def eval_step(self, inputs, targets, kl_weight):
         loss = self.forward(inputs, targets, kl_weight, train=False)
         self.ctx = None

@@ -40,6 +40,9 @@ class HipBackend:
 
     def __init__(self):
         self._l = None
+        # "fp32": v_mfma_f32_32x32x2_f32 (the reference's arithmetic, the default and the BASELINE configs[1] path);
+        # "bf16": operands rounded to bf16 on their way into the matrix cores, fp32 accumulate (configs[2])
+        self.precision = "fp32"
 
     @property
     def lib(self):
@@ -63,17 +66,18 @@ class HipBackend:
     # ---- GEMMs ----
     def igemm_nt(self, A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride,
                  offset, act, splitk):
-        check(self.lib.mmdyn_igemm_nt(_ptr(A), _ptr(Bp), _ptr(bias), _ptr(C), _ptr(C_act), _ptr(stats), _ptr(ws),
-                                      mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk,
-                                      _stream()), "mmdyn_igemm_nt")
+        fn = self.lib.mmdyn_igemm_nt_bf16 if self.precision == "bf16" else self.lib.mmdyn_igemm_nt
+        check(fn(_ptr(A), _ptr(Bp), _ptr(bias), _ptr(C), _ptr(C_act), _ptr(stats), _ptr(ws),
+                 mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, _stream()), "mmdyn_igemm_nt")
 
     def splitk_reduce(self, ws, bias, C, C_act, splitk, rows, N, act):
         check(self.lib.mmdyn_splitk_reduce(_ptr(ws), _ptr(bias), _ptr(C), _ptr(C_act), splitk, rows, N, act,
                                            _stream()), "mmdyn_splitk_reduce")
 
     def wgrad_tn(self, D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks):
-        check(self.lib.mmdyn_wgrad_tn(_ptr(D), _ptr(Gt), _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride,
-                                      offset, chunks, _stream()), "mmdyn_wgrad_tn")
+        fn = self.lib.mmdyn_wgrad_tn_bf16 if self.precision == "bf16" else self.lib.mmdyn_wgrad_tn
+        check(fn(_ptr(D), _ptr(Gt), _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks,
+                 _stream()), "mmdyn_wgrad_tn")
 
     def wgrad_reduce(self, partial, canon, chunks, taps, Cd, Cg, cg_canon, perm, beta):
         check(self.lib.mmdyn_wgrad_reduce(_ptr(partial), _ptr(canon), chunks, taps, Cd, Cg, cg_canon, perm,

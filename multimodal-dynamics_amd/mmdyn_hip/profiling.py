@@ -45,6 +45,14 @@ class TimedBackend:
         self._inner = inner
         self.records = []
 
+    @property
+    def precision(self):
+        return self._inner.precision
+
+    @precision.setter
+    def precision(self, value):
+        self._inner.precision = value
+
     def __getattr__(self, attr):
         fn = getattr(self._inner, attr)
         if attr in HOST_ONLY or not callable(fn):

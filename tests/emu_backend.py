@@ -76,6 +76,8 @@ class EmuBackend:
         assert Cin % 32 == 0 and N % 32 == 0 and ldc == N
         Bt = G * Bg
         Bp = Bp.reshape(-1, N, Cin)
+        if getattr(self, "precision", "fp32") == "bf16":       # operands rounded to bf16 (RNE), fp32 accumulate
+            A, Bp = A.to(torch.bfloat16).to(torch.float32), Bp.to(torch.bfloat16).to(torch.float32)
         if mode == IM2COL3:
             assert Cin == 64
             A = self._unfold3(A, Bt, Hi, Wi)
@@ -136,6 +138,8 @@ class EmuBackend:
     def wgrad_tn(self, D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks):
         assert chunks % 4 == 0 and Cd % 32 == 0 and Cg % 32 == 0
         rows = Bt * Hr * Wr
+        if getattr(self, "precision", "fp32") == "bf16":
+            D, Gt = D.to(torch.bfloat16).to(torch.float32), Gt.to(torch.bfloat16).to(torch.float32)
         Dm = D.reshape(-1)[: rows * Cd].reshape(rows, Cd)
         partial.zero_()
         taps = 16 if mode == CONV else 1

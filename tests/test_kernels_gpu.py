@@ -85,6 +85,21 @@ def test_igemm_nt(case):
          [3, 4])
 
 
+@pytest.fixture()
+def bf16_mode():
+    """bf16 matrix cores: the kernels round fp32 operands to bf16 (RNE) and accumulate in fp32; the emulation does
+    the same rounding, so both agree to fp32 summation-order error -- a wrong rounding mode or k-slice layout would
+    show up at the 1e-3 level."""
+    HIP.precision = EMU.precision = "bf16"
+    yield
+    HIP.precision = EMU.precision = "fp32"
+
+
+@pytest.mark.parametrize("case", IGEMM_CASES)
+def test_igemm_nt_bf16(case, bf16_mode):
+    test_igemm_nt(case)
+
+
 @pytest.mark.parametrize("rows,K,N,splitk", [(256, 6400, 512, 25), (64, 512, 256, 3), (1024, 6400, 256, 8), (5, 64, 32, 2)])
 def test_igemm_splitk(rows, K, N, splitk):
     A, Bp, bias = rnd(rows, K, seed=4), rnd(N, K, seed=5, scale=0.1), rnd(N, seed=6)
@@ -132,6 +147,25 @@ def test_wgrad(case):
     # accumulate form
     HIP.wgrad_reduce(ga[2], canon_g, chunks, taps, Cd, Cg, cgc, perm, 1.0)
     assert rel(canon_g, 2 * canon_c) < 5e-5
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad_bf16(case, bf16_mode):
+    test_wgrad(case)
+
+
+def test_bf16_differs_from_fp32_by_bf16_rounding_only():
+    """Sanity on the size of the effect: relative error of the bf16 product vs the fp32 one is ~2^-9 per operand."""
+    A, Bp = rnd(512, 256, seed=21), rnd(128, 256, seed=22, scale=0.2)
+    outs = []
+    for prec in ("fp32", "bf16"):
+        HIP.precision = prec
+        C = torch.zeros(512, 128, device=DEV)
+        HIP.igemm_nt(A.to(DEV), Bp.to(DEV), None, C, None, None, None, DENSE, 1, 512, 1, 1, 256, 1, 1, 128, 128, 1, 0, 0, 1)
+        outs.append(C.cpu())
+    HIP.precision = "fp32"
+    assert rel(outs[0], A @ Bp.t()) < 2e-5
+    assert 1e-4 < rel(outs[1], outs[0]) < 1e-2
 
 
 def test_pack_and_layout_kernels():

@@ -309,3 +309,25 @@ def check_regressor(golden_dir, device, tmp_path):
 
 def test_regressor(golden_dir, tmp_path):
     check_regressor(golden_dir, "cpu", tmp_path)
+
+
+def test_bf16_precision_plumbing():
+    """MVAEStep(precision='bf16') switches the matrix-core precision of the backend for the duration of each call
+    (the emulation rounds the GEMM operands to bf16) and leaves the default in place afterwards."""
+    from mmdyn_hip import ops
+    from mmdyn_hip.engine import MVAEStep
+    B, klw = 2, 0.02
+    inputs, targets = seeded_batch(B, 5)
+    eps, masks = seeded_noise(B, 256, 7, 8, 6)
+    losses = {}
+    for prec in ("fp32", "bf16"):
+        m = build("cnn-mvae", True, True, "cpu")
+        step = MVAEStep(m, noise=InjectedNoise(eps, masks), precision=prec)
+        losses[prec] = float(step.forward(inputs, targets, klw))
+        step.backward()
+        assert ops.B.precision == "fp32"
+        assert torch.isfinite(step.params.grad).all()
+    r = abs(losses["bf16"] - losses["fp32"]) / abs(losses["fp32"])
+    assert 1e-8 < r < 5e-3, r
+    with pytest.raises(ValueError):
+        MVAEStep(build("cnn-mvae", True, True, "cpu"), precision="fp16")

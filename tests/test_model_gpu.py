@@ -79,6 +79,36 @@ def test_fused_engine_vs_oracle(B, n_steps):
         opt.step()
 
 
+def test_bf16_engine_vs_oracle():
+    """BASELINE configs[2] arithmetic (bf16 matrix-core operands, fp32 accumulate / storage / master weights) against
+    the fp32 CPU oracle, B=32, injected noise.  Stated tolerance for this mode: ELBO and each partial within 5e-3
+    relative (measured 8e-5 on the total), gradients within 1e-1 relative L2 per tensor (measured: median 1.9e-2,
+    worst 7.5e-2 on the encoder conv weights, whose gradients come through the longest bf16 chains)."""
+    B, klw = 32, 1.0 / 50
+    sd = seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True), 0)
+    prm, buf = O.split_state(sd)
+    inputs, targets = seeded_batch(B, 1234)
+    eps, masks = seeded_noise(B, 256, 7, 8, 4321)
+    m = T.build("cnn-mvae", True, True, DEV)
+    step = MVAEStep(m, noise=InjectedNoise(eps, masks), precision="bf16")
+    _, loss_o, partials_o = O.evaluate_mvae(prm, inputs, targets, eps, masks, klw, 1000.0, True, buf)
+    loss_o.backward()
+    loss = step.forward([x.to(DEV) for x in inputs], [x.to(DEV) for x in targets], klw)
+    rel_loss = abs(float(loss) - float(loss_o.detach())) / abs(float(loss_o.detach()))
+    assert rel_loss < 5e-3, rel_loss
+    np.testing.assert_allclose(step.partials[:7].cpu().numpy(), [float(x.detach()) for x in partials_o], rtol=5e-3)
+    step.backward()
+    named = dict(m.named_parameters())
+    errs = sorted(((float((named[k].grad.double().cpu() - prm[k].grad.double()).norm()
+                           / (prm[k].grad.double().norm() + 1e-30)), k) for k in prm), reverse=True)
+    print("bf16 loss rel err", rel_loss, "worst gradient rel-L2:", errs[:6], "median", errs[len(errs) // 2])
+    worst = errs[0][0]
+    assert worst < 1e-1, errs[:6]
+    assert rel_loss > 1e-7          # and it really is a different arithmetic from the fp32 path
+    from mmdyn_hip import ops
+    assert ops.B.precision == "fp32"          # the engine restores the default after every call
+
+
 def test_full_size_properties_b256():
     """BASELINE batch (256): properties that need no CPU run of the same size --
     (i) the total equals the sum of the 7 partial ELBOs; (ii) replaying the same step from the same state and
