@@ -148,7 +148,7 @@ int mmdyn_colstats_tiles(int rows_per_group);
  * order, `repeat` times each (the reference re-runs identical encoder trunks: SURVEY.md 3.2);
  * num_batches_tracked (int64) += G*repeat.  running_* may be null. */
 int mmdyn_bn_finalize(const float* partial, float* mean, float* rstd, float* running_mean,
-                      float* running_var, int64_t* num_batches_tracked, double* scratch /* [G][2][C] */,
+                      float* running_var, int64_t* num_batches_tracked, double* scratch /* [32][G][2][C] */,
                       int G, int T, int C, int rows_per_group, float eps, float momentum, int repeat,
                       void* stream);
 /* a = swish(gamma*(y-mean)*rstd + beta) */
@@ -159,7 +159,7 @@ int mmdyn_bn_swish_bwd_reduce(const float* da, const float* y, const float* mean
                               const float* gamma, const float* beta, float* partial, int G,
                               int rows_per_group, int C, void* stream);
 int mmdyn_bn_bwd_finalize(const float* partial, float* sums, float* dgamma, float* dbeta,
-                          double* scratch /* [G][2][C] */, int G, int T, int C, float beta_acc,
+                          double* scratch /* [32][G][2][C] */, int G, int T, int C, float beta_acc,
                           void* stream);
 int mmdyn_bn_swish_bwd_apply(const float* da, const float* y, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, const float* sums, float* dy, int G,

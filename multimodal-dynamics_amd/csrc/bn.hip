@@ -90,13 +90,23 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   }
 }
 
-// sums over the T tile partials of one group, 32 channels per block: out[g][2][C] (double accumulate)
+// sums over the T tile partials of one group, 32 channels per block and one of S slices of the tiles per
+// blockIdx.z (a 32-channel layer has only G x 1 channel blocks; the slices give the big layers 100+ blocks):
+// out[s][g][2][C] (double accumulate); the finish kernels add the S slices in a fixed order.
+constexpr int BN_MAX_SPLITS = 32;
+static inline int bn_splits(int T) {
+  int s = T / 128;
+  return s < 1 ? 1 : (s > BN_MAX_SPLITS ? BN_MAX_SPLITS : s);
+}
 __global__ __launch_bounds__(256) void tile_sum_kernel(const float* __restrict__ partial,
                                                        double* __restrict__ out, int T, int C) {
   __shared__ double red[2][8][32];
   const int g = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31), tl = threadIdx.x >> 5;
+  const int per = (T + gridDim.z - 1) / gridDim.z;
+  const int t_lo = blockIdx.z * per, t_hi = min(T, t_lo + per);
+  out += (size_t)blockIdx.z * gridDim.y * 2 * C;
   double a = 0.0, b = 0.0;
-  for (int t = tl; t < T; t += 8) {
+  for (int t = t_lo + tl; t < t_hi; t += 8) {
     const size_t o = ((size_t)(g * T + t) * 2) * C + c;
     a += (double)partial[o];
     b += (double)partial[o + C];
@@ -116,14 +126,19 @@ __global__ __launch_bounds__(256) void tile_sum_kernel(const float* __restrict__
 __global__ void bn_stats_finish_kernel(const double* __restrict__ sums, float* __restrict__ mean,
                                        float* __restrict__ rstd, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, int64_t* __restrict__ nbt, int G,
-                                       int C, int n, float eps, float momentum, int repeat) {
+                                       int C, int n, float eps, float momentum, int repeat, int S) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float rm = running_mean ? running_mean[c] : 0.f;
   float rv = running_var ? running_var[c] : 0.f;
   for (int g = 0; g < G; ++g) {
-    double m = sums[((size_t)g * 2 + 0) * C + c] / n;
-    double var = sums[((size_t)g * 2 + 1) * C + c] / n - m * m;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < S; ++s) {
+      s1 += sums[(((size_t)s * G + g) * 2 + 0) * C + c];
+      s2 += sums[(((size_t)s * G + g) * 2 + 1) * C + c];
+    }
+    double m = s1 / n;
+    double var = s2 / n - m * m;
     if (var < 0.0) var = 0.0;
     mean[(size_t)g * C + c] = (float)m;
     rstd[(size_t)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -160,12 +175,16 @@ __global__ void bn_swish_fwd_kernel(const float* __restrict__ y, BnParams bp, fl
 
 __global__ void bn_bwd_param_kernel(const double* __restrict__ sums, float* __restrict__ sums_f,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int C,
-                                    float beta_acc) {
+                                    float beta_acc, int S) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double sb = 0.0, sg = 0.0;
   for (int g = 0; g < G; ++g) {
-    double a = sums[((size_t)g * 2 + 0) * C + c], b = sums[((size_t)g * 2 + 1) * C + c];
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < S; ++s) {
+      a += sums[(((size_t)s * G + g) * 2 + 0) * C + c];
+      b += sums[(((size_t)s * G + g) * 2 + 1) * C + c];
+    }
     sums_f[((size_t)g * 2 + 0) * C + c] = (float)a;
     sums_f[((size_t)g * 2 + 1) * C + c] = (float)b;
     sb += a;
@@ -232,9 +251,10 @@ extern "C" int mmdyn_bn_finalize(const float* partial, float* mean, float* rstd,
   // two launches on purpose: a single fused launch (32 channels per block walking the groups serially) measured
   // 2x slower -- the tile sums want G x C/32 blocks
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(tile_sum_kernel, dim3(C / 32, G), dim3(256), 0, st, partial, g_sums, T, C);
+  const int S = bn_splits(T);
+  hipLaunchKernelGGL(tile_sum_kernel, dim3(C / 32, G, S), dim3(256), 0, st, partial, g_sums, T, C);
   hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, g_sums, mean, rstd,
-                     running_mean, running_var, nbt, G, C, rows_per_group, eps, momentum, repeat);
+                     running_mean, running_var, nbt, G, C, rows_per_group, eps, momentum, repeat, S);
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -267,9 +287,10 @@ extern "C" int mmdyn_bn_bwd_finalize(const float* partial, float* sums, float* d
   if (!partial || !sums || !g_sums) return MMDYN_ERR_NULL;
   if (!bn_shape_ok(G, 1, C) || T <= 0) return MMDYN_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(tile_sum_kernel, dim3(C / 32, G), dim3(256), 0, st, partial, g_sums, T, C);
+  const int S = bn_splits(T);
+  hipLaunchKernelGGL(tile_sum_kernel, dim3(C / 32, G, S), dim3(256), 0, st, partial, g_sums, T, C);
   hipLaunchKernelGGL(bn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, g_sums, sums, dgamma,
-                     dbeta, G, C, beta_acc);
+                     dbeta, G, C, beta_acc, S);
   MMDYN_LAUNCH_CHECK();
 }
 

@@ -92,7 +92,7 @@ class BNState:
 
 def bn_swish_from_partials(y, partial, T, bn, G, rows_per_group, C, repeat=1):
     mean, rstd = _new(y, G, C), _new(y, G, C)
-    scratch = _new(y, G, 2, C, dtype=torch.float64)
+    scratch = _new(y, 32, G, 2, C, dtype=torch.float64)
     ops.B.bn_finalize(partial, mean, rstd, bn.rm, bn.rv, bn.nbt, scratch, G, T, C, rows_per_group, BN_EPS,
                       BN_MOMENTUM, repeat)
     a = torch.empty_like(y)
@@ -104,7 +104,7 @@ def bn_swish_backward(da, y, mean, rstd, bn, dgamma, dbeta, G, rows_per_group, C
     T = ops.B.colstats_tiles(rows_per_group)
     partial = _new(y, G, T, 2, C)
     sums = _new(y, G, 2, C)
-    scratch = _new(y, G, 2, C, dtype=torch.float64)
+    scratch = _new(y, 32, G, 2, C, dtype=torch.float64)
     ops.B.bn_swish_bwd_reduce(da, y, mean, rstd, bn.gamma, bn.beta, partial, G, rows_per_group, C)
     ops.B.bn_bwd_finalize(partial, sums, dgamma, dbeta, scratch, G, T, C, 0.0)
     dy = torch.empty_like(y)

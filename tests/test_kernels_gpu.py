@@ -193,7 +193,7 @@ def test_batchnorm_kernels(G, rpg, C):
     ga, ca = both("colstats", [y, partial, G, rpg, C], [1], lambda i, t: t.sum(1))
     mean, rstd = torch.zeros(G, C), torch.zeros(G, C)
     rm, rv, nbt = rnd(C, seed=18), rnd(C, seed=19).abs() + 0.5, torch.zeros((), dtype=torch.long)
-    scratch = torch.zeros(G, 2, C, dtype=torch.float64)
+    scratch = torch.zeros(32, G, 2, C, dtype=torch.float64)
     args = [partial, mean, rstd, rm, rv, nbt, scratch, G, T, C, rpg, 1e-5, 0.1, 2]
     g_args = [a.to(DEV) if torch.is_tensor(a) else a for a in args]
     g_args[0] = ga[1]
