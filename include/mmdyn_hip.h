@@ -66,6 +66,19 @@ int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C,
                    float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
                    int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
                    void* stream);
+/* Input-gradient GEMM with the BatchNorm+Swish backward of the PRECEDING layer fused into its epilogue.
+ * The tile of dL/d(activation) never reaches HBM as such: with y the layer's saved pre-BatchNorm output (same
+ * rows/columns as C) and xhat = (y - mean[g]) * rstd[g], the kernel writes
+ *     C = du = dL/da * swish'(gamma*xhat + beta)
+ * and the per-tile column sums (du, du*xhat) into stats[G][T][2][N] (T = mmdyn_igemm_stat_tiles), which feed
+ * mmdyn_bn_bwd_finalize directly -- the separate reduction pass (mmdyn_bn_swish_bwd_reduce: one more read of da
+ * and y) disappears; mmdyn_bn_swish_bwd_apply(da_is_du = 1) finishes the layer.  bf16 != 0 selects the bf16
+ * matrix-core variant.  No bias / activation / split-K here. */
+int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C, float* stats, const float* y,
+                            const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
+                            int stride, int offset, int bf16, void* stream);
+
 /* Same contract, bf16 matrix cores: the fp32 operands are rounded to bf16 (round-to-nearest-even) on their way
  * into the MFMA (v_mfma_f32_32x32x16_bf16), products are accumulated in fp32, everything in HBM stays fp32.
  * The reduced-precision mode of BASELINE configs[2] ("bf16"); never used by the fp32 path. */
@@ -161,9 +174,10 @@ int mmdyn_bn_swish_bwd_reduce(const float* da, const float* y, const float* mean
 int mmdyn_bn_bwd_finalize(const float* partial, float* sums, float* dgamma, float* dbeta,
                           double* scratch /* [32][G][2][C] */, int G, int T, int C, float beta_acc,
                           void* stream);
+/* da_is_du != 0: `da` already holds du = da * swish'(gamma*xhat+beta) (written by mmdyn_igemm_nt_dgrad_bn) */
 int mmdyn_bn_swish_bwd_apply(const float* da, const float* y, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, const float* sums, float* dy, int G,
-                             int rows_per_group, int C, void* stream);
+                             int rows_per_group, int C, int da_is_du, void* stream);
 
 /* ---- element-wise ---------------------------------------------------------------------------- */
 int mmdyn_act_fwd(const float* u, float* h, int64_t n, int act, void* stream);

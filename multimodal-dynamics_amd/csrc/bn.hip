@@ -196,7 +196,8 @@ __global__ void bn_bwd_param_kernel(const double* __restrict__ sums, float* __re
 
 __global__ void bn_swish_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ y,
                                           BnParams bp, const float* __restrict__ sums,
-                                          float* __restrict__ dy, int64_t total4, int rows_per_group, int C) {
+                                          float* __restrict__ dy, int64_t total4, int rows_per_group, int C,
+                                          int da_is_du) {
   const int CV = C >> 2;
   const float inv_n = 1.f / (float)rows_per_group;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
@@ -217,7 +218,7 @@ __global__ void bn_swish_bwd_apply_kernel(const float* __restrict__ da, const fl
     for (int k = 0; k < 4; ++k) {
       float xh = (v[k] - m[k]) * r[k];
       float u = ga[k] * xh + be[k];
-      float du = d[k] * swish_gradf_(u);
+      float du = da_is_du ? d[k] : d[k] * swish_gradf_(u);       // the dgrad epilogue may already have applied swish'
       o[k] = ga[k] * r[k] * (du - s0[k] * inv_n - xh * (s1[k] * inv_n));
     }
     reinterpret_cast<f32x4*>(dy)[i] = o;
@@ -297,12 +298,12 @@ extern "C" int mmdyn_bn_bwd_finalize(const float* partial, float* sums, float* d
 extern "C" int mmdyn_bn_swish_bwd_apply(const float* da, const float* y, const float* mean,
                                         const float* rstd, const float* gamma, const float* beta,
                                         const float* sums, float* dy, int G, int rows_per_group, int C,
-                                        void* stream) {
+                                        int da_is_du, void* stream) {
   if (!da || !y || !mean || !rstd || !gamma || !beta || !sums || !dy) return MMDYN_ERR_NULL;
   if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
   BnParams bp{mean, rstd, gamma, beta};
   int64_t total4 = (int64_t)G * rows_per_group * (C / 4);
   hipLaunchKernelGGL(bn_swish_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, da,
-                     y, bp, sums, dy, total4, rows_per_group, C);
+                     y, bp, sums, dy, total4, rows_per_group, C, da_is_du);
   MMDYN_LAUNCH_CHECK();
 }

@@ -36,6 +36,14 @@ struct IgemmGeom {
   int rows_total;      // G*Bg*Hr*Wr (split-K workspace stride)
   int tiles_per_group; // ceil(Bg*Hr*Wr / BM); TCONV_S1P0: Ho*Wo*ceil(Bg/BM) (tiles never straddle an output pixel)
   int tiles_per_pixel; // TCONV_S1P0 only: ceil(Bg/BM)
+  // optional BatchNorm+Swish backward epilogue (input-gradient launches): the tile of dL/d(activation) is turned
+  // into du = da * swish'(gamma*xhat+beta) with xhat from the layer's saved pre-BN output, written to C, and the
+  // per-tile column sums (du, du*xhat) go to `stats` -- the reduction pass of the BatchNorm backward disappears
+  const float* bn_y;
+  const float* bn_mean;   // [G][N]
+  const float* bn_rstd;   // [G][N]
+  const float* bn_gamma;  // [N]
+  const float* bn_beta;   // [N]
 };
 
 #ifndef IG_BK
@@ -338,6 +346,16 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   float colsum[NT], colsq[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) colsum[nt] = colsq[nt] = 0.f;
+  const bool bnbwd = g.bn_y != nullptr;
+  float bn_m[NT], bn_r[NT], bn_g[NT], bn_b[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + wn * WN + nt * 32 + cl;
+    bn_m[nt] = bnbwd ? g.bn_mean[(size_t)grp * g.N + col] : 0.f;
+    bn_r[nt] = bnbwd ? g.bn_rstd[(size_t)grp * g.N + col] : 0.f;
+    bn_g[nt] = bnbwd ? g.bn_gamma[col] : 0.f;
+    bn_b[nt] = bnbwd ? g.bn_beta[col] : 0.f;
+  }
 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -349,8 +367,18 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       for (int nt = 0; nt < NT; ++nt) {
         const int col = n0 + wn * WN + nt * 32 + cl;
         float v = acc[mt][nt][e];
-        colsum[nt] += v;
-        colsq[nt] += v * v;
+        if (bnbwd) {
+          float xh = 0.f;
+          if (ooff >= 0) {
+            xh = (g.bn_y[(size_t)ooff + col] - bn_m[nt]) * bn_r[nt];
+            v *= swish_gradf_(bn_g[nt] * xh + bn_b[nt]);
+          }
+          colsum[nt] += v;
+          colsq[nt] += v * xh;
+        } else {
+          colsum[nt] += v;
+          colsq[nt] += v * v;
+        }
         if (ooff >= 0) {
           if (g.splitk > 1) {
             const int grow = grp * Mg + tile * BM + r;  // dense row id (DENSE mode only)
@@ -509,7 +537,9 @@ extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, i
 static int igemm_entry(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
                        float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
                        int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
-                       void* stream, bool bf16) {
+                       void* stream, bool bf16, const float* bn_y = nullptr, const float* bn_mean = nullptr,
+                       const float* bn_rstd = nullptr, const float* bn_gamma = nullptr,
+                       const float* bn_beta = nullptr) {
   if (!A || !Bp || !C) return MMDYN_ERR_NULL;
   if (Cin <= 0 || N <= 0 || Cin % BK || N % 32 || G <= 0 || Bg <= 0 || ldc < N) return MMDYN_ERR_SHAPE;
   if (splitk < 1) splitk = 1;
@@ -528,6 +558,11 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   g.act = act;
   g.has_bias = bias != nullptr;
   g.want_stats = stats != nullptr;
+  g.bn_y = bn_y;
+  g.bn_mean = bn_mean;
+  g.bn_rstd = bn_rstd;
+  g.bn_gamma = bn_gamma;
+  g.bn_beta = bn_beta;
   g.want_act_out = C_act != nullptr;
   g.splitk = splitk;
   g.nclasses = 1;
@@ -596,6 +631,15 @@ extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias
                               void* stream) {
   return igemm_entry(A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act,
                      splitk, stream, false);
+}
+
+extern "C" int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C, float* stats, const float* y,
+                                       const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                       int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
+                                       int stride, int offset, int bf16, void* stream) {
+  if (!stats || !y || !mean || !rstd || !gamma || !beta) return MMDYN_ERR_NULL;
+  return igemm_entry(A, Bp, nullptr, C, nullptr, stats, nullptr, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset,
+                     MMDYN_ACT_NONE, 1, stream, bf16 != 0, y, mean, rstd, gamma, beta);
 }
 
 extern "C" int mmdyn_igemm_nt_bf16(const float* A, const float* Bp, const float* bias, float* C, float* C_act,

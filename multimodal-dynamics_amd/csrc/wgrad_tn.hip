@@ -14,6 +14,7 @@
 // Ds[k][cd0+i] and the B operand B[k][j] as Gs[k][cg0+j]: consecutive lanes read consecutive floats,
 // conflict-free ds_read_b32.  The row reduction is split over `chunks` blocks (deterministic partial
 // slabs, no atomics); a second kernel sums the slabs and scatters into the canonical layout.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -499,7 +500,9 @@ extern "C" int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg) {
     tiles = (long)(Cd / bd) * (Cg / bg) * 4;
     wk = 1;
   }
-  long z = 1024 / tiles;
+  long target = 1024;
+  if (const char* ov = getenv("MMDYN_WGRAD_BLOCKS")) target = atol(ov);   // kernel experiments only
+  long z = target / tiles;
   const long zmax = rows / 128;
   if (z > zmax) z = zmax;
   if (z < 1) z = 1;

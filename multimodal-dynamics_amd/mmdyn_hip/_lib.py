@@ -29,6 +29,7 @@ MAX_EXPERTS = 4
 # name -> argument type codes, in header order: p pointer, i int, l int64, f float, Q uint64
 _SIGNATURES = {
     "mmdyn_igemm_nt": "ppppppp" + "iiiiiiiiiiiiii" + "p",
+    "mmdyn_igemm_nt_dgrad_bn": "ppppppppp" + "iiiiiiiiiiii" + "p",
     "mmdyn_igemm_nt_bf16": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_stat_tiles": "iiiiiiiii",
     "mmdyn_splitk_reduce": "pppp" + "iiii" + "p",
@@ -49,7 +50,7 @@ _SIGNATURES = {
     "mmdyn_bn_swish_fwd": "pppppp" + "iii" + "p",
     "mmdyn_bn_swish_bwd_reduce": "ppppppp" + "iii" + "p",
     "mmdyn_bn_bwd_finalize": "ppppp" + "iii" + "f" + "p",
-    "mmdyn_bn_swish_bwd_apply": "pppppppp" + "iii" + "p",
+    "mmdyn_bn_swish_bwd_apply": "pppppppp" + "iiii" + "p",
     "mmdyn_act_fwd": "pp" + "l" + "i" + "p",
     "mmdyn_act_bwd": "ppp" + "l" + "i" + "p",
     "mmdyn_dropout_expand": "ppp" + "iii" + "f" + "p",

@@ -112,6 +112,24 @@ def bn_swish_backward(da, y, mean, rstd, bn, dgamma, dbeta, G, rows_per_group, C
     return dy
 
 
+def dgrad_bn_swish_backward(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride, offset, y, mean, rstd, bn, dgamma, dbeta):
+    """Input-gradient GEMM of the layer ABOVE fused with this layer's BatchNorm+Swish backward: the GEMM epilogue
+    turns dL/da into du = dL/da * swish'(.) and emits the per-tile sums, so only finalize + apply remain.
+    Returns dL/dy (gradient w.r.t. this layer's conv output)."""
+    rows_per_group = Bg * Ho * Ho
+    T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
+    du = torch.empty_like(y)
+    partial = _new(y, G, T, 2, N)
+    ops.B.igemm_nt_dgrad_bn(x, Wp, du, partial, y, mean, rstd, bn.gamma, bn.beta, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N,
+                            stride, offset)
+    sums = _new(y, G, 2, N)
+    scratch = _new(y, 32, G, 2, N, dtype=torch.float64)
+    ops.B.bn_bwd_finalize(partial, sums, dgamma, dbeta, scratch, G, T, N, 0.0)
+    dy = torch.empty_like(y)
+    ops.B.bn_swish_bwd_apply(du, y, mean, rstd, bn.gamma, bn.beta, sums, dy, G, rows_per_group, N, True)
+    return dy
+
+
 def wgrad(D, Gt, canon, mode, Bt, Hr, Cd, Hi, Cg, stride=1, offset=0, cg_canon=None, perm=0):
     """canon[cd][cg][taps] = sum_rows D[row][cd] * G_tap[row][cg]  (reference weight-gradient layout)."""
     rows = Bt * Hr * Hr
@@ -405,10 +423,10 @@ def encoder_trunk_backward_steps(P, c, dh, grads):
     dy3 = bn_swish_backward(da3, c["y3"], c["m3"], c["r3"], bn3, grads["conv_net.6.weight"],
                             grads["conv_net.6.bias"], G, Bg * 64, 128)
     wgrad(dy3, c["a2"], grads["conv_net.5.weight"], CONV, Bt, 8, 128, 16, 64, 2, -1)
-    da2, _, _ = conv_like(dy3, pk["W3s"], TCONV_S2P1, 1, Bt, 8, 128, 16, 64)
     yield
-    dy2 = bn_swish_backward(da2, c["y2"], c["m2"], c["r2"], bn2, grads["conv_net.3.weight"],
-                            grads["conv_net.3.bias"], G, Bg * 256, 64)
+    # conv3's input gradient with conv2's BatchNorm+Swish backward in its epilogue
+    dy2 = dgrad_bn_swish_backward(dy3, pk["W3s"], TCONV_S2P1, G, Bg, 8, 128, 16, 64, 1, 0, c["y2"], c["m2"], c["r2"], bn2,
+                                  grads["conv_net.3.weight"], grads["conv_net.3.bias"])
     wgrad(dy2, c["a1"], grads["conv_net.2.weight"], CONV, Bt, 16, 64, 32, 32, 2, -1)
     da1, _, _ = conv_like(dy2, pk["W2s"], TCONV_S2P1, 1, Bt, 16, 64, 32, 32)
     yield
@@ -471,22 +489,18 @@ def decoder_backward_steps(P, c, dlogits, grads, need_dz=True):
     bn1, bn2, bn3 = c["bn"]
     # last layer backward: both GEMMs gather the k4 s2 p1 window of the NCHW logit gradient on the fly
     wgrad(c["a3"], dlogits, grads["hallucinate.9.weight"], IM2COL3, Bt, 32, 32, 64, 64, cg_canon=48)
-    da3 = _new(dlogits, Bt * 1024, 32)
-    ops.B.igemm_nt(dlogits, pk["W4p"], None, da3, None, None, None, IM2COL3, 1, Bt, 64, 64, 64, 32, 32, 32, 32, 1, 0,
-                   ACT_NONE, 1)
+    # the input-gradient GEMM of every layer carries the BatchNorm+Swish backward of the layer below in its epilogue
+    dy3 = dgrad_bn_swish_backward(dlogits, pk["W4p"], IM2COL3, G, Bg, 64, 64, 32, 32, 1, 0, c["y3"], c["m3"], c["r3"], bn3,
+                                  grads["hallucinate.7.weight"], grads["hallucinate.7.bias"])
     yield
-    dy3 = bn_swish_backward(da3, c["y3"], c["m3"], c["r3"], bn3, grads["hallucinate.7.weight"],
-                            grads["hallucinate.7.bias"], G, Bg * 1024, 32)
     wgrad(c["a2"], dy3, grads["hallucinate.6.weight"], CONV, Bt, 16, 64, 32, 32, 2, -1)
-    da2, _, _ = conv_like(dy3, pk["W3k"], CONV, 1, Bt, 32, 32, 16, 64, 2, -1)
+    dy2 = dgrad_bn_swish_backward(dy3, pk["W3k"], CONV, G, Bg, 32, 32, 16, 64, 2, -1, c["y2"], c["m2"], c["r2"], bn2,
+                                  grads["hallucinate.4.weight"], grads["hallucinate.4.bias"])
     yield
-    dy2 = bn_swish_backward(da2, c["y2"], c["m2"], c["r2"], bn2, grads["hallucinate.4.weight"],
-                            grads["hallucinate.4.bias"], G, Bg * 256, 64)
     wgrad(c["a1"], dy2, grads["hallucinate.3.weight"], CONV, Bt, 8, 128, 16, 64, 2, -1)
-    da1, _, _ = conv_like(dy2, pk["W2k"], CONV, 1, Bt, 16, 64, 8, 128, 2, -1)
+    dy1 = dgrad_bn_swish_backward(dy2, pk["W2k"], CONV, G, Bg, 16, 64, 8, 128, 2, -1, c["y1"], c["m1"], c["r1"], bn1,
+                                  grads["hallucinate.1.weight"], grads["hallucinate.1.bias"])
     yield
-    dy1 = bn_swish_backward(da1, c["y1"], c["m1"], c["r1"], bn1, grads["hallucinate.1.weight"],
-                            grads["hallucinate.1.bias"], G, Bg * 64, 128)
     wgrad(c["h0"], dy1, grads["hallucinate.0.weight"], CONV, Bt, 5, 256, 8, 128, 1, 0)
     dh0, _, _ = conv_like(dy1, pk["W1k"], CONV, 1, Bt, 8, 128, 5, 256, 1, 0)
     yield

@@ -70,6 +70,13 @@ class HipBackend:
         check(fn(_ptr(A), _ptr(Bp), _ptr(bias), _ptr(C), _ptr(C_act), _ptr(stats), _ptr(ws),
                  mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, _stream()), "mmdyn_igemm_nt")
 
+    def igemm_nt_dgrad_bn(self, A, Bp, C, stats, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N,
+                          stride, offset):
+        check(self.lib.mmdyn_igemm_nt_dgrad_bn(_ptr(A), _ptr(Bp), _ptr(C), _ptr(stats), _ptr(y), _ptr(mean), _ptr(rstd),
+                                               _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride,
+                                               offset, int(self.precision == "bf16"), _stream()),
+              "mmdyn_igemm_nt_dgrad_bn")
+
     def splitk_reduce(self, ws, bias, C, C_act, splitk, rows, N, act):
         check(self.lib.mmdyn_splitk_reduce(_ptr(ws), _ptr(bias), _ptr(C), _ptr(C_act), splitk, rows, N, act,
                                            _stream()), "mmdyn_splitk_reduce")
@@ -142,9 +149,9 @@ class HipBackend:
                                              _ptr(scratch, torch.float64), G, T, C, float(beta_acc), _stream()),
               "mmdyn_bn_bwd_finalize")
 
-    def bn_swish_bwd_apply(self, da, y, mean, rstd, gamma, beta, sums, dy, G, rows_per_group, C):
+    def bn_swish_bwd_apply(self, da, y, mean, rstd, gamma, beta, sums, dy, G, rows_per_group, C, da_is_du=False):
         check(self.lib.mmdyn_bn_swish_bwd_apply(_ptr(da), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
-                                                _ptr(sums), _ptr(dy), G, rows_per_group, C, _stream()),
+                                                _ptr(sums), _ptr(dy), G, rows_per_group, C, int(da_is_du), _stream()),
               "mmdyn_bn_swish_bwd_apply")
 
     # ---- element-wise ----

@@ -274,9 +274,21 @@ class EmuBackend:
         if dgamma is not None:
             dgamma.copy_((beta_acc * dgamma if beta_acc else 0) + s[:, 1].sum(0))
 
-    def bn_swish_bwd_apply(self, da, y, mean, rstd, gamma, beta, sums, dy, G, rpg, C):
+    def igemm_nt_dgrad_bn(self, A, Bp, C, stats, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N,
+                          stride, offset):
+        self.igemm_nt(A, Bp, None, C, None, None, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset, 0, 1)
+        rpg = Bg * Ho * Wo
+        xh = self._xhat(y, mean, rstd, G, rpg, N)
+        du = C.reshape(G, rpg, N) * _act_grad(xh * gamma + beta, 1)
+        C.reshape(-1).copy_(du.reshape(-1))
+        stats.zero_()
+        st = stats.reshape(G, -1, 2, N)
+        st[:, 0, 0] = du.sum(1)
+        st[:, 0, 1] = (du * xh).sum(1)
+
+    def bn_swish_bwd_apply(self, da, y, mean, rstd, gamma, beta, sums, dy, G, rpg, C, da_is_du=False):
         xh = self._xhat(y, mean, rstd, G, rpg, C)
-        du = da.reshape(G, rpg, C) * _act_grad(xh * gamma + beta, 1)
+        du = da.reshape(G, rpg, C) if da_is_du else da.reshape(G, rpg, C) * _act_grad(xh * gamma + beta, 1)
         out = gamma * rstd[:, None] * (du - sums[:, 0][:, None] / rpg - xh * sums[:, 1][:, None] / rpg)
         dy.reshape(-1).copy_(out.reshape(-1))
 

@@ -85,6 +85,26 @@ def test_igemm_nt(case):
          [3, 4])
 
 
+@pytest.mark.parametrize("case", [c for c in IGEMM_CASES if c[0] != DENSE][:6] + [IGEMM_CASES[0]])
+def test_igemm_dgrad_bn_epilogue(case):
+    """Input-gradient GEMM with the BatchNorm+Swish backward of the layer below in its epilogue: C = du and the
+    per-tile (sum du, sum du*xhat) partials, against GEMM -> bn_swish_bwd_reduce composed from the emulation."""
+    mode, G, Bg, Hi, Cin, Ho, N, stride, offset = case
+    Bt = G * Bg
+    taps = 16 if mode != DENSE else 1
+    A = rnd(Bt * Hi * Hi, Cin, seed=31)
+    Bp = rnd(taps, N, Cin, seed=32, scale=0.2)
+    rows = Bt * Ho * Ho
+    y = rnd(rows, N, seed=33) * 1.5 + 0.2
+    mean, rstd = rnd(G, N, seed=34) * 0.3, rnd(G, N, seed=35).abs() + 0.5
+    gamma, beta = rnd(N, seed=36) + 1.2, rnd(N, seed=37)
+    T = HIP.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
+    C, stats = torch.zeros(rows, N), torch.zeros(G, T, 2, N)
+    post = lambda i, t: t.sum(1) if i == 3 else t
+    both("igemm_nt_dgrad_bn", [A, Bp, C, stats, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride,
+                               offset], [2, 3], post, tol=5e-5)
+
+
 @pytest.fixture()
 def bf16_mode():
     """bf16 matrix cores: the kernels round fp32 operands to bf16 (RNE) and accumulate in fp32; the emulation does
