@@ -124,9 +124,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("MMDYN_BENCH_FORCE_PG") == "1":      # (the flag: 1-rank rehearsal of the RCCL path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
 
@@ -155,18 +156,18 @@ def main():
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if pg is not None:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if pg is not None:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if pg is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -177,10 +178,10 @@ def main():
     lanes_on, step.lanes.on = step.lanes.on, False
     kern = profile_step(eager_step)
     step.lanes.on = lanes_on
-    if world > 1:
+    if pg is not None:
         dist.barrier()
     if rank != 0:
-        if world > 1:
+        if pg is not None:
             dist.destroy_process_group()
         return
 
@@ -231,7 +232,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.batch, host_cpu_share())
     print(json.dumps(out))
-    if world > 1:
+    if pg is not None:
         dist.destroy_process_group()
 
 

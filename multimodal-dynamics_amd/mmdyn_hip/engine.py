@@ -418,12 +418,14 @@ class MVAEStep:
         self.ctx = None
         return handles
 
-    def _reduce_bucket(self, i):
-        if self.world <= 1 or self._capturing:
+    def _reduce_bucket(self, i, last=None):
+        """Async all-reduce(sum) of gradient bucket ``i`` (.. ``last``) of the flat buffer; the collective is ordered
+        after everything already enqueued on the current stream and overlaps whatever is enqueued next."""
+        if self.pg is None or self._capturing:
             return []
         import torch.distributed as dist
         lo = 0 if i == 0 else self.params.bucket_bounds[i - 1]
-        hi = self.params.bucket_bounds[i]
+        hi = self.params.bucket_bounds[i if last is None else last]
         return [dist.all_reduce(self.params.grad[lo:hi], group=self.pg, async_op=True)]
 
     def optimizer_step(self, handles=()):
@@ -466,11 +468,11 @@ class MVAEStep:
         for dst, src in zip(self._static_in + self._static_tg, list(inputs) + list(targets)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
-        self._replay(self._graph[1])
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.params.grad, group=self.pg)
-            self.optimizer_step(())
+        handles = self._replay(self._graph[1])
+        if self.pg is not None:
+            # decoder gradients were reduced while the encoder backward graphs ran; the rest goes now
+            handles += self._reduce_bucket(1, last=2)
+            self.optimizer_step(handles)
         return self.loss
 
     def _capture(self, kl_weight):
@@ -488,7 +490,7 @@ class MVAEStep:
             [("l0", lambda: run(self._ph_enc_bwd_steps("v"))), ("l1", lambda: run(self._ph_enc_bwd_steps("t"))),
              ("main", lambda: self._ph_pose_enc_bwd())],
         ]
-        if self.world <= 1:
+        if self.pg is None:
             stages.append([("main", lambda: self.optimizer_step(()))])
         cap_stream = {"main": torch.cuda.Stream(), "l0": LN.side[0], "l1": LN.side[1]}
         pools = {k: torch.cuda.graph_pool_handle() for k in cap_stream}
@@ -513,11 +515,16 @@ class MVAEStep:
             self.ctx = None
         return captured
 
+    DEC_STAGE = 3          # index of the decoder forward+backward stage in _capture's list
+
     def _replay(self, captured):
         LN = self.lanes
         main = torch.cuda.current_stream()
         side = {"l0": LN.side[0], "l1": LN.side[1]}
-        for row in captured:
+        handles = []
+        for ri, row in enumerate(captured):
+            if ri == self.DEC_STAGE + 1:
+                handles += self._reduce_bucket(0)          # decoders done: reduce them under the encoder backward
             if len(row) == 1:
                 row[0][1].replay()
                 continue
@@ -533,6 +540,7 @@ class MVAEStep:
             for lane, g in row:
                 if lane != "main":
                     main.wait_event(side[lane].record_event())
+        return handles
 
     @torch.no_grad()
     @_with_precision
