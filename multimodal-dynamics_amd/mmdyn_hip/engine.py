@@ -171,7 +171,9 @@ class MVAEStep:
                      "dt": layers.decoder_pack_specs(FP.sub("tactile_decoder"))}
             if self.use_pose:
                 specs["hp"] = layers.heads_pack_specs(FP.sub("pose_encoder"))
-            self.plan = layers.PackPlan(specs)
+            # what the encoder forward reads goes first (critical path); the transposed / decoder packs are launched
+            # next to the encoder phase (run_late) and are ready long before the decoders start
+            self.plan = layers.PackPlan(specs, early=("W1p", "W2k", "W3k", "W4k", "Wf", "Wh", "bh"))
         self._capturing = False
         self._graph = None
 
@@ -235,12 +237,17 @@ class MVAEStep:
         LN.fork()
         if self.plan is not None:
             with LN.lane(1):
-                self.plan.run()
+                self.plan.run_early()
             c["pk"] = self.plan.packed
         c["eps"], mv, mt = self._draw(c["B"], c["dev"])
         c["mask"] = {"v": mv, "t": mt}
         LN.join()
         self.acc.zero_()
+
+    def _ph_pack_late(self):
+        """Decoder and backward (transposed) weight packs: on the joint stream while the lanes run the encoders."""
+        if self.plan is not None:
+            self.plan.run_late()
 
     def _ph_enc_steps(self, m):
         """Encoder trunk once per modality; per-pass dropout batched; fused heads for all passes of the modality."""
@@ -365,6 +372,7 @@ class MVAEStep:
         self._begin(inputs, targets, kl_weight, train)
         self._ph_pre()
         LN.fork()
+        self._ph_pack_late()
         self._two(self._ph_enc_steps)
         self._ph_pose_enc()
         LN.join()
@@ -481,7 +489,7 @@ class MVAEStep:
         stages = [
             [("main", lambda: self._ph_pre())],
             [("l0", lambda: run(self._ph_enc_steps("v"))), ("l1", lambda: run(self._ph_enc_steps("t"))),
-             ("main", lambda: self._ph_pose_enc())],
+             ("main", lambda: (self._ph_pack_late(), self._ph_pose_enc()))],
             [("main", lambda: self._ph_poe())],
             [("l0", lambda: (run(self._ph_dec_fwd_steps("v")), run(self._ph_dec_bwd_steps("v")))),
              ("l1", lambda: (run(self._ph_dec_fwd_steps("t")), run(self._ph_dec_bwd_steps("t")))),

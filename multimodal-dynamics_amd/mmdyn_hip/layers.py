@@ -252,14 +252,21 @@ class PackPlan:
     """All repacks of the given spec lists as ONE kernel launch (mmdyn_pack_plan).  Source and destination
     storage must not move afterwards (the fused engine's flat parameter buffer and these outputs never do)."""
 
-    def __init__(self, named_specs):
+    def __init__(self, named_specs, early=()):
+        """``early``: names of the packed tensors the first phase of the step needs; they go to the front of the
+        table so that :meth:`run_early` / :meth:`run_late` can launch the two halves at different points."""
         import ctypes
         from ._lib import PackEntry
         self.packed, entries = {}, []
+        order = []
         for key, specs in named_specs.items():
             outs = _alloc_packed(specs, specs[0]["src"])
             self.packed[key] = outs
-            for s in specs:
+            order += [(0 if s["name"] in early else 1, len(order) + i, outs, s) for i, s in enumerate(specs)]
+        order.sort(key=lambda t: (t[0], t[1]))
+        self.n_early = sum(1 for t in order if t[0] == 0)
+        for _, _, outs, s in order:
+            for s in (s,):
                 dst = outs[s["name"]]
                 e = PackEntry()
                 e.src = s["src"].data_ptr()
@@ -278,8 +285,18 @@ class PackPlan:
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self._ptrs = [(e.src, e.dst) for e in entries]
 
+        self.entry_bytes = len(raw) // max(self.n, 1)
+
     def run(self):
         ops.B.pack_plan(self.table, self.n)
+
+    def run_early(self):
+        if self.n_early:
+            ops.B.pack_plan(self.table[: self.n_early * self.entry_bytes], self.n_early)
+
+    def run_late(self):
+        if self.n > self.n_early:
+            ops.B.pack_plan(self.table[self.n_early * self.entry_bytes:], self.n - self.n_early)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -46,11 +46,12 @@ def test_conditional_training_loops(tmp_path):
     T.check_conditional_loops(tmp_path, no_cuda=False)
 
 
-@pytest.mark.parametrize("B,n_steps", [(32, 3), (256, 1)])
+@pytest.mark.parametrize("B,n_steps", [(32, 3), (256, 1), (1, 1), (5, 2), (37, 1), (130, 1)])
 def test_fused_engine_vs_oracle(B, n_steps):
     """ELBO (total and each of the 7 partials) within 1e-4 relative of the CPU oracle, gradients within 1e-3
     relative L2 per tensor, loss still within 1e-4 after 3 Adam steps; B=256 is the
-    BASELINE batch (one oracle step takes a few seconds on the host cores)."""
+    BASELINE batch (one oracle step takes a few seconds on the host cores); 1, 5, 37 and 130 are ragged sizes: no
+    row count is a multiple of any tile, split-K / chunk / band sizes all hit their remainders."""
     klw = 1.0 / 50
     sd = seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True), 0)
     prm, buf = O.split_state(sd)
