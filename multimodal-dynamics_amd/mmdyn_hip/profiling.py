@@ -12,6 +12,15 @@ from . import ops
 HOST_ONLY = {"igemm_stat_tiles", "colstats_tiles", "wgrad_chunks"}
 
 
+def _canon(name, a):
+    """The dgrad+BatchNorm-backward launch is the same kernel family: book it as igemm_nt with igemm_nt's argument
+    order (A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk)."""
+    if name == "igemm_nt_dgrad_bn":
+        A, Bp, C, stats, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset = a
+        return "igemm_nt", (A, Bp, y, C, None, stats, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset, 0, 1)
+    return name, a
+
+
 def _flops(name, a):
     if name == "igemm_nt":
         (mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) = a[7:16]
@@ -63,8 +72,11 @@ class TimedBackend:
             s.record()
             r = fn(*a, **k)
             e.record()
-            sig = tuple(x for x in a if isinstance(x, (int, bool))) if attr in ("igemm_nt", "wgrad_tn") else ()
-            self.records.append((attr, _flops(attr, a), _bytes(a), s, e, sig))
+            name, ca = _canon(attr, a)
+            sig = tuple(x for x in ca if isinstance(x, (int, bool))) if name in ("igemm_nt", "wgrad_tn") else ()
+            if attr != name:
+                sig = sig + ("bn_bwd_epilogue",)
+            self.records.append((name, _flops(name, ca), _bytes(ca), s, e, sig))
             return r
         return wrapped
 
