@@ -128,7 +128,7 @@ class MVAEStep:
     """Fused train / eval step for an :class:`mmdyn_hip.models.MVAE` on one GPU (one rank)."""
 
     def __init__(self, model, lr=1e-3, pose_multiplier=1000.0, betas=(0.9, 0.999), eps=1e-8, noise=None,
-                 process_group=None, world_size=1, two_lanes=True, precision="fp32"):
+                 process_group=None, world_size=1, two_lanes=True, precision="fp32", exact_running_stats=False):
         if getattr(model, "conditional", False):
             raise NotImplementedError("mmdyn_hip: the fused step is built for the unconditional cnn-mvae; run conditional "
                                       "models through the module API (Problem(..., fused=False))")
@@ -136,6 +136,11 @@ class MVAEStep:
             raise ValueError("precision must be 'fp32' (the reference's arithmetic) or 'bf16' (bf16 matrix-core "
                              "operands, fp32 accumulate and storage: BASELINE configs[2])")
         self.precision = precision
+        # False (default): each image decoder runs only on the passes whose reconstruction enters the loss, so its
+        # BatchNorm running buffers see 4 EMA updates per step (2 without pose) where the reference applies 7 (3).
+        # True: the decoders also run on the passes the reference computes and discards, in pass order, with zero
+        # loss gradient -- identical running_mean / running_var / num_batches_tracked, ~1.4x the step time.
+        self.exact_running_stats = bool(exact_running_stats)
         self.model = model
         self.use_pose = bool(model._use_pose)
         self.L = model.latent_size
@@ -231,6 +236,10 @@ class MVAEStep:
     def _passes_of(self, m):
         return self.pass_v if m == "v" else self.pass_t
 
+    def _dec_passes(self, m):
+        """Passes the image decoder of modality ``m`` is run on (group order = pass order)."""
+        return list(range(self.P)) if self.exact_running_stats else self._passes_of(m)
+
     def _ph_pre(self):
         """Weight repack (one launch, side lane) overlapped with the noise draws."""
         c, LN = self.ctx, self.lanes
@@ -277,13 +286,17 @@ class MVAEStep:
     def _ph_dec_fwd_steps(self, m):
         """Image decoder on its live passes (groups) followed by the BCE sums (+ logit gradients when training)."""
         c, FP, B = self.ctx, self.params, self.ctx["B"]
-        dec, plist = self._MOD[m][1], self._passes_of(m)
+        dec, plist, live = self._MOD[m][1], self._dec_passes(m), self._passes_of(m)
         zz = torch.cat([c["z"][p] for p in plist])
         lg, c["d" + m] = yield from layers.decoder_forward_steps(FP.sub(dec), self._buffers(dec), zz, len(plist),
                                                                  packed=c["pk"].get("d" + m))
         dl = torch.empty_like(lg) if c["train"] else None
         n_img = B * 3 * 64 * 64
         for g, p in enumerate(plist):
+            if p not in live:                      # exact_running_stats: a pass whose reconstruction is discarded
+                if dl is not None:
+                    dl[g * B:(g + 1) * B].zero_()
+                continue
             ops.B.bce_logits(lg[g * B:(g + 1) * B], c["tg"][m], None, None if dl is None else dl[g * B:(g + 1) * B],
                              self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, 1.0 / B)
         c["lg" + m], c["dl" + m] = lg, dl
@@ -320,10 +333,12 @@ class MVAEStep:
         """Latent gradients of every pass (summed over the decoders that consumed z) through PoE / KL."""
         c, B, L, P = self.ctx, self.ctx["B"], self.L, self.P
         blocks = [[None, None, None] for _ in range(P)]
-        for g, p in enumerate(self.pass_v):
-            blocks[p][0] = c["dzv"][g * B:(g + 1) * B]
-        for g, p in enumerate(self.pass_t):
-            blocks[p][1] = c["dzt"][g * B:(g + 1) * B]
+        for g, p in enumerate(self._dec_passes("v")):
+            if p in self.pass_v:
+                blocks[p][0] = c["dzv"][g * B:(g + 1) * B]
+        for g, p in enumerate(self._dec_passes("t")):
+            if p in self.pass_t:
+                blocks[p][1] = c["dzt"][g * B:(g + 1) * B]
         if self.use_pose:
             for g, p in enumerate(self.pass_p):
                 blocks[p][2] = c["dzp"][g * B:(g + 1) * B]
@@ -350,7 +365,7 @@ class MVAEStep:
     def _publish(self):
         c, B, P = self.ctx, self.ctx["B"], self.P
         joint = self.subsets.index((1, 1, 1)) if self.use_pose else 0
-        gv, gt = self.pass_v.index(joint), self.pass_t.index(joint)
+        gv, gt = self._dec_passes("v").index(joint), self._dec_passes("t").index(joint)
         recon = [c["lgv"][gv * B:(gv + 1) * B], c["lgt"][gt * B:(gt + 1) * B]]
         if self.use_pose:
             gp = self.pass_p.index(joint)

@@ -100,7 +100,7 @@ def check_reference_schedule_step(golden_dir, device, fname, use_pose):
             np.testing.assert_allclose(sd[k].double().cpu().numpy(), g["buffer_step0/" + k], rtol=2e-5, atol=2e-6, err_msg=k)
 
 
-def check_fused_engine(golden_dir, device, fname, use_pose):
+def check_fused_engine(golden_dir, device, fname, use_pose, exact=False):
     g = load(golden_dir, fname)
     B, n_steps = int(g["batch"]), int(g["n_steps"])
     m = build("cnn-mvae", True, use_pose, device)
@@ -108,7 +108,8 @@ def check_fused_engine(golden_dir, device, fname, use_pose):
     inputs, targets = [x.to(device) for x in inputs], [x.to(device) for x in targets]
     n_pass, n_mask = (7, 8) if use_pose else (3, 4)
     eps, masks = seeded_noise(B, 256, n_pass * n_steps, n_mask * n_steps, 4321)
-    step = MVAEStep(m, lr=float(g["lr"]), pose_multiplier=float(g["pose_multiplier"]), noise=InjectedNoise(eps, masks))
+    step = MVAEStep(m, lr=float(g["lr"]), pose_multiplier=float(g["pose_multiplier"]), noise=InjectedNoise(eps, masks),
+                    exact_running_stats=exact)
     for s in range(n_steps):
         loss = step.forward(inputs, targets, float(g["kl_weight"]), train=True)
         assert float(loss) == pytest.approx(float(g[f"loss_step{s}"]), rel=1e-4), s
@@ -127,10 +128,11 @@ def check_fused_engine(golden_dir, device, fname, use_pose):
         if s in (0, n_steps - 1):
             for k, p_ in m.named_parameters():
                 close_params(summarize(p_.detach().cpu()), g[f"param_step{s}/" + k], float(g["lr"]), s + 1, f"param {k}")
-    # encoder running statistics follow the reference exactly (4 identical EMA updates per step)
+    # encoder running statistics follow the reference exactly (4 identical EMA updates per step); the decoders' too
+    # when the engine also runs the passes whose reconstructions the reference discards (exact_running_stats)
     sd = m.state_dict()
     for k in sd:
-        if "encoder" in k and ("running" in k or "num_batches" in k):
+        if ("encoder" in k or exact) and ("running" in k or "num_batches" in k):
             np.testing.assert_allclose(sd[k].double().cpu().numpy(), g[f"buffer_step{n_steps - 1}/" + k], rtol=2e-5,
                                        atol=2e-3 if n_steps > 1 else 2e-6, err_msg=k)
 
@@ -147,6 +149,11 @@ def test_reference_schedule_step(golden_dir, fname, use_pose):
 @pytest.mark.parametrize("fname,use_pose", [("mvae_pose_B4.npz", True), ("mvae_nopose_B4.npz", False)])
 def test_fused_engine_matches_reference(golden_dir, fname, use_pose):
     check_fused_engine(golden_dir, "cpu", fname, use_pose)
+
+
+@pytest.mark.parametrize("fname,use_pose", [("mvae_pose_B4.npz", True), ("mvae_nopose_B4.npz", False)])
+def test_fused_engine_exact_running_stats(golden_dir, fname, use_pose):
+    check_fused_engine(golden_dir, "cpu", fname, use_pose, exact=True)
 
 
 def check_vae_config1(golden_dir, device):

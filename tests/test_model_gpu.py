@@ -30,6 +30,11 @@ def test_fused_engine_matches_reference(golden_dir, fname, use_pose):
     T.check_fused_engine(golden_dir, DEV, fname, use_pose)
 
 
+@pytest.mark.parametrize("fname,use_pose", [("mvae_pose_B4.npz", True), ("mvae_nopose_B4.npz", False)])
+def test_fused_engine_exact_running_stats(golden_dir, fname, use_pose):
+    T.check_fused_engine(golden_dir, DEV, fname, use_pose, exact=True)
+
+
 def test_vae_config1(golden_dir):
     T.check_vae_config1(golden_dir, DEV)
 
