@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32: the BASELINE configs[1] line (default).  bf16: bf16 matrix-core operands with fp32 "
                          "accumulate/storage/master weights, the per-GPU share of configs[2] (use --batch 128)")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="BatchNorm statistics over the global batch (N > 1; eager launches, one small all-reduce per "
+                         "BatchNorm layer and direction).  Default: local statistics")
     ap.add_argument("--single-lane", action="store_true",
                     help="no visual/tactile stream overlap: per-kernel durations in a rocprofv3 trace then match "
                          "the roofline object's live HIP-event measurement")
@@ -141,7 +144,7 @@ def main():
                         conditional=False, categorical_conditions=False, latent_size=256, use_pose=True).to(dev).train()
     step = MVAEStep(model, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), process_group=pg,
                     world_size=world, two_lanes=not args.single_lane,
-                    precision="bf16" if args.dtype == "bf16" else "fp32")
+                    precision="bf16" if args.dtype == "bf16" else "fp32", sync_bn=args.sync_bn and pg is not None)
     inputs, targets = seeded_batch(args.batch, 1234 + rank)
     inputs, targets = [x.to(dev) for x in inputs], [x.to(dev) for x in targets]
 
@@ -205,8 +208,8 @@ def main():
                    (f"cnn-mvae visuotactile+pose 64x64, bs={args.batch} per GPU, bf16 matrix-core operands (fp32 "
                     "accumulate, storage and master weights), seq_modeling train step, per-GPU share of BASELINE "
                     "configs[2]"),
-                   "global_batch": global_batch, "parallelism": f"dp{world}", "bn": "local",
-                   "launch": "eager" if args.no_graph else "hip_graph",
+                   "global_batch": global_batch, "parallelism": f"dp{world}", "bn": "sync" if (args.sync_bn and pg is not None) else "local",
+                   "launch": "eager" if (args.no_graph or (args.sync_bn and pg is not None)) else "hip_graph",
                    "final_loss": final_loss},
         "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak,

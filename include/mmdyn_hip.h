@@ -174,6 +174,18 @@ int mmdyn_bn_swish_bwd_reduce(const float* da, const float* y, const float* mean
 int mmdyn_bn_bwd_finalize(const float* partial, float* sums, float* dgamma, float* dbeta,
                           double* scratch /* [32][G][2][C] */, int G, int T, int C, float beta_acc,
                           void* stream);
+/* Synchronised BatchNorm across data-parallel ranks (optional): the per-channel sums are
+ * collapsed to double [G][2][C], all-reduced by the host (RCCL), and the statistics / backward coefficients are
+ * finished from the GLOBAL sums.  reduce_partials: scratch like mmdyn_bn_finalize.  finalize_sums: n = global rows per
+ * group.  bwd_finalize_sums: dgamma/dbeta (nullable) = local parameter gradients (the gradient all-reduce adds the
+ * ranks); sums_f (nullable) = float copy of the sums times sums_scale (global sums x n_local/n_global, so that
+ * mmdyn_bn_swish_bwd_apply, which divides by the local row count, applies the global means). */
+int mmdyn_bn_reduce_partials(const float* partial, double* sums, double* scratch, int G, int T, int C, void* stream);
+int mmdyn_bn_finalize_sums(const double* sums, float* mean, float* rstd, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, int G, int C, int n, float eps, float momentum, int repeat,
+                           void* stream);
+int mmdyn_bn_bwd_finalize_sums(const double* sums, float* sums_f, float* dgamma, float* dbeta, int G, int C,
+                               float sums_scale, float beta_acc, void* stream);
 /* da_is_du != 0: `da` already holds du = da * swish'(gamma*xhat+beta) (written by mmdyn_igemm_nt_dgrad_bn) */
 int mmdyn_bn_swish_bwd_apply(const float* da, const float* y, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, const float* sums, float* dy, int G,

@@ -123,6 +123,15 @@ __global__ __launch_bounds__(256) void tile_sum_kernel(const float* __restrict__
   }
 }
 
+// adds the S slices of tile_sum_kernel: out[g][2][C] (the quantity a synchronised BatchNorm all-reduces)
+__global__ void bn_collapse_kernel(const double* __restrict__ sliced, double* __restrict__ out, int n, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < S; ++k) s += sliced[(size_t)k * n + i];
+  out[i] = s;
+}
+
 __global__ void bn_stats_finish_kernel(const double* __restrict__ sums, float* __restrict__ mean,
                                        float* __restrict__ rstd, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, int64_t* __restrict__ nbt, int G,
@@ -175,7 +184,7 @@ __global__ void bn_swish_fwd_kernel(const float* __restrict__ y, BnParams bp, fl
 
 __global__ void bn_bwd_param_kernel(const double* __restrict__ sums, float* __restrict__ sums_f,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int C,
-                                    float beta_acc, int S) {
+                                    float beta_acc, int S, float sums_scale) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double sb = 0.0, sg = 0.0;
@@ -185,8 +194,10 @@ __global__ void bn_bwd_param_kernel(const double* __restrict__ sums, float* __re
       a += sums[(((size_t)s * G + g) * 2 + 0) * C + c];
       b += sums[(((size_t)s * G + g) * 2 + 1) * C + c];
     }
-    sums_f[((size_t)g * 2 + 0) * C + c] = (float)a;
-    sums_f[((size_t)g * 2 + 1) * C + c] = (float)b;
+    if (sums_f) {
+      sums_f[((size_t)g * 2 + 0) * C + c] = (float)(a * sums_scale);
+      sums_f[((size_t)g * 2 + 1) * C + c] = (float)(b * sums_scale);
+    }
     sb += a;
     sg += b;
   }
@@ -259,6 +270,37 @@ extern "C" int mmdyn_bn_finalize(const float* partial, float* mean, float* rstd,
   MMDYN_LAUNCH_CHECK();
 }
 
+/* ---- synchronised BatchNorm (multi-GPU option): the three pieces around the all-reduce of the per-channel sums -- */
+extern "C" int mmdyn_bn_reduce_partials(const float* partial, double* sums, double* g_sums, int G, int T, int C,
+                                        void* stream) {
+  if (!partial || !sums || !g_sums) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, 1, C) || T <= 0) return MMDYN_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int S = bn_splits(T), n = G * 2 * C;
+  hipLaunchKernelGGL(tile_sum_kernel, dim3(C / 32, G, S), dim3(256), 0, st, partial, g_sums, T, C);
+  hipLaunchKernelGGL(bn_collapse_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, g_sums, sums, n, S);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bn_finalize_sums(const double* sums, float* mean, float* rstd, float* running_mean,
+                                      float* running_var, int64_t* nbt, int G, int C, int n, float eps,
+                                      float momentum, int repeat, void* stream) {
+  if (!sums || !mean || !rstd) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, 1, C) || n <= 0 || repeat < 1) return MMDYN_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, mean,
+                     rstd, running_mean, running_var, nbt, G, C, n, eps, momentum, repeat, 1);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bn_bwd_finalize_sums(const double* sums, float* sums_f, float* dgamma, float* dbeta, int G, int C,
+                                          float sums_scale, float beta_acc, void* stream) {
+  if (!sums) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, 1, C)) return MMDYN_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, sums_f,
+                     dgamma, dbeta, G, C, beta_acc, 1, sums_scale);
+  MMDYN_LAUNCH_CHECK();
+}
+
 extern "C" int mmdyn_bn_swish_fwd(const float* y, const float* mean, const float* rstd, const float* gamma,
                                   const float* beta, float* a, int G, int rows_per_group, int C,
                                   void* stream) {
@@ -291,7 +333,7 @@ extern "C" int mmdyn_bn_bwd_finalize(const float* partial, float* sums, float* d
   const int S = bn_splits(T);
   hipLaunchKernelGGL(tile_sum_kernel, dim3(C / 32, G, S), dim3(256), 0, st, partial, g_sums, T, C);
   hipLaunchKernelGGL(bn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, g_sums, sums, dgamma,
-                     dbeta, G, C, beta_acc, S);
+                     dbeta, G, C, beta_acc, S, 1.0f);
   MMDYN_LAUNCH_CHECK();
 }
 

@@ -46,13 +46,7 @@ struct IgemmGeom {
   const float* bn_beta;   // [N]
 };
 
-#ifndef IG_BK
-#define IG_BK 32
-#endif
-#ifndef IG_DBUF
-#define IG_DBUF 0
-#endif
-constexpr int BK = IG_BK;           // K-step (channels of one tap per stage)
+constexpr int BK = 32;              // K-step (channels of one tap per stage)
 constexpr int LDS_LD = BK + 4;      // row stride: one 16-byte pad slot keeps ds_read_b128 conflict-free
 constexpr int GRANS = BK / 4;       // 16-byte granules per tile row
 constexpr int ROWS_PER_PASS = 256 / GRANS;
@@ -81,12 +75,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   constexpr int A_LOADS = BM / ROWS_PER_PASS, B_LOADS = BN / ROWS_PER_PASS;
   static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile smaller than one load pass");
   constexpr int STAGE = (BM + BN) * LDS_LD;
-  constexpr int NSTAGE = IG_DBUF ? 2 : 1;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* As = reinterpret_cast<float*>(smem);            // stage s: [BM][LDS_LD] then [BN][LDS_LD]
+  float* As = reinterpret_cast<float*>(smem);            // [BM][LDS_LD] then [BN][LDS_LD]
   float* Bs = As + BM * LDS_LD;
-  int* rowinfo = reinterpret_cast<int*>(As + NSTAGE * STAGE);  // [BM][4]: b, y0, x0, out offset (-1: none)
+  int* rowinfo = reinterpret_cast<int*>(As + STAGE);  // [BM][4]: b, y0, x0, out offset (-1: none)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -107,9 +100,6 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   const int n0 = (inner - cls * NY) * BN;
   const int ph = cls >> 1, pw = cls & 1;
 
-#ifdef IG_STAGGER
-  if (mx & 1) __builtin_amdgcn_s_sleep(IG_STAGGER);   // experiment: de-phase co-resident blocks
-#endif
   // TCONV_S1P0: rows are ordered (output pixel, sample) so that a tile sees ONE output pixel and multiplies only
   // the kernel taps that reach the input for it (1..16 of them for k4 s1 p0).  To balance the blocks, each block
   // walks the FOUR pixels {(h,w),(h+4,w),(h,w+4),(h+4,w+4)} of the 8x8 output: their valid-tap counts always sum
@@ -240,7 +230,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
     cstep = last ? cstep : ncstep;
     tap = last ? tap : ntap;
   };
-  auto lds_store = [&](int stage) {
+  auto lds_store = [&]() {
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const unsigned m = okmask >> (4 * i);
@@ -249,11 +239,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       v[1] = (m & 2u) ? ra[i][1] : 0.f;
       v[2] = (m & 4u) ? ra[i][2] : 0.f;
       v[3] = (m & 8u) ? ra[i][3] : 0.f;
-      *reinterpret_cast<f32x4*>(&As[stage * STAGE + (lrow + ROWS_PER_PASS * i) * LDS_LD + gran * 4]) = v;
+      *reinterpret_cast<f32x4*>(&As[(lrow + ROWS_PER_PASS * i) * LDS_LD + gran * 4]) = v;
     }
 #pragma unroll
     for (int j = 0; j < B_LOADS; ++j)
-      *reinterpret_cast<f32x4*>(&Bs[stage * STAGE + (lrow + ROWS_PER_PASS * j) * LDS_LD + gran * 4]) = rbv[j];
+      *reinterpret_cast<f32x4*>(&Bs[(lrow + ROWS_PER_PASS * j) * LDS_LD + gran * 4]) = rbv[j];
   };
 
   f32x16 acc[MT][NT];
@@ -267,18 +257,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
   if (s_begin < s_end) {
     gload();
-    lds_store(0);
+    lds_store();
     __syncthreads();
-    int cur = 0;
     for (int s = s_begin; s < s_end; ++s) {
-#if !defined(IG_ABL) || IG_ABL < 1
       gload();
-#endif
-#ifndef IG_SGB
       __builtin_amdgcn_sched_barrier(0);   // keep the fetch of step s+1 in front of the MFMAs of step s
-#endif
-      const float* Ac = As + cur * STAGE;
-      const float* Bc = Bs + cur * STAGE;
+      const float* Ac = As;
+      const float* Bc = Bs;
       if constexpr (BF16) {
 #pragma unroll
         for (int q = 0; q < BK / 8; q += 2) {     // one 16-deep bf16 MFMA = the k-slices of two fp32 fragment reads
@@ -317,27 +302,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
             for (int nt = 0; nt < NT; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
       }
-#ifdef IG_SGB
-      // experiment: ask the scheduler to weave the fetch (VALU address math + VMEM) between the MFMAs
-#pragma unroll
-      for (int i = 0; i < A_LOADS + B_LOADS; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, (MT * NT * 4 * (BK / 8)) / (A_LOADS + B_LOADS) / 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, IG_SGB, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-#endif
-      if (IG_DBUF) {
-        // two LDS stages: the next tile goes to the other stage, one barrier per K-step
-        lds_store(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-      } else {
-#if !defined(IG_ABL) || IG_ABL < 2
-        __syncthreads();
-        lds_store(0);
-        __syncthreads();
-#endif
-      }
+      __syncthreads();
+      lds_store();
+      __syncthreads();
     }
   }
 
@@ -491,7 +458,7 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   }
   const int mx8 = (g.G * g.tiles_per_group + 7) / 8 * 8;
   dim3 grid((unsigned)mx8 * (g.N / BN) * g.nclasses * g.splitk);
-  size_t smem = (size_t)(IG_DBUF ? 2 : 1) * (BM + BN) * LDS_LD * sizeof(float) + (size_t)BM * 4 * sizeof(int);
+  size_t smem = (size_t)(BM + BN) * LDS_LD * sizeof(float) + (size_t)BM * 4 * sizeof(int);
   if (bf16)
     hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true>), grid, dim3(256), smem, st, A, Bp, bias, C,
                        C_act, stats, ws, g);

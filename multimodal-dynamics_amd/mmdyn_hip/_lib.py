@@ -50,6 +50,9 @@ _SIGNATURES = {
     "mmdyn_bn_swish_fwd": "pppppp" + "iii" + "p",
     "mmdyn_bn_swish_bwd_reduce": "ppppppp" + "iii" + "p",
     "mmdyn_bn_bwd_finalize": "ppppp" + "iii" + "f" + "p",
+    "mmdyn_bn_reduce_partials": "ppp" + "iii" + "p",
+    "mmdyn_bn_finalize_sums": "pppppp" + "iii" + "ff" + "i" + "p",
+    "mmdyn_bn_bwd_finalize_sums": "pppp" + "ii" + "ff" + "p",
     "mmdyn_bn_swish_bwd_apply": "pppppppp" + "iiii" + "p",
     "mmdyn_act_fwd": "pp" + "l" + "i" + "p",
     "mmdyn_act_bwd": "ppp" + "l" + "i" + "p",

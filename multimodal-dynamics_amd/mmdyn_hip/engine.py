@@ -115,12 +115,14 @@ def _with_precision(fn):
 
     @functools.wraps(fn)
     def wrapped(self, *a, **k):
-        prev = getattr(ops.B, "precision", "fp32")
+        prev, prev_sync = getattr(ops.B, "precision", "fp32"), layers.SYNC
         ops.B.precision = self.precision
+        layers.SYNC = self._sync
         try:
             return fn(self, *a, **k)
         finally:
             ops.B.precision = prev
+            layers.SYNC = prev_sync
     return wrapped
 
 
@@ -128,7 +130,7 @@ class MVAEStep:
     """Fused train / eval step for an :class:`mmdyn_hip.models.MVAE` on one GPU (one rank)."""
 
     def __init__(self, model, lr=1e-3, pose_multiplier=1000.0, betas=(0.9, 0.999), eps=1e-8, noise=None,
-                 process_group=None, world_size=1, two_lanes=True, precision="fp32", exact_running_stats=False):
+                 process_group=None, world_size=1, two_lanes=True, precision="fp32", exact_running_stats=False, sync_bn=False):
         if getattr(model, "conditional", False):
             raise NotImplementedError("mmdyn_hip: the fused step is built for the unconditional cnn-mvae; run conditional "
                                       "models through the module API (Problem(..., fused=False))")
@@ -141,6 +143,12 @@ class MVAEStep:
         # True: the decoders also run on the passes the reference computes and discards, in pass order, with zero
         # loss gradient -- identical running_mean / running_var / num_batches_tracked, ~1.4x the step time.
         self.exact_running_stats = bool(exact_running_stats)
+        # BatchNorm statistics over the global batch of the process group instead of each rank's shard (default:
+        # local, like DistributedDataParallel).  Adds one small fp64 all-reduce per BatchNorm layer and direction and
+        # runs eagerly (the collectives sit between kernels of a phase, so the phase graphs are not used).
+        if sync_bn and process_group is None:
+            raise ValueError("sync_bn needs a process group")
+        self._sync = layers.SyncBN(process_group, world_size) if sync_bn else None
         self.model = model
         self.use_pose = bool(model._use_pose)
         self.L = model.latent_size
@@ -477,6 +485,8 @@ class MVAEStep:
         Inputs are copied into static buffers; random draws advance through a device-side counter and Adam's step
         count lives on the device, so every replay is a real optimiser step.  With more than one rank the gradient
         all-reduce and Adam run after the graphs."""
+        if self._sync is not None:
+            return self.train_step(inputs, targets, kl_weight)
         key = (tuple(tuple(x.shape) for x in inputs), float(kl_weight))
         if self._graph is None or self._graph[0] != key:
             self._static_in = [x.clone() for x in inputs]

@@ -90,11 +90,54 @@ class BNState:
         self.gamma, self.beta, self.rm, self.rv, self.nbt = gamma, beta, rm, rv, nbt
 
 
-def bn_swish_from_partials(y, partial, T, bn, G, rows_per_group, C, repeat=1):
+class SyncBN:
+    """Synchronised BatchNorm over a data-parallel process group: set ``layers.SYNC = SyncBN(pg, world)`` and every
+    BatchNorm of this module uses the statistics of the GLOBAL batch (one tiny fp64 all-reduce per layer and
+    direction).  ``None`` (default) = local statistics, the semantics of DistributedDataParallel and of bench.py."""
+
+    def __init__(self, group, world):
+        self.group, self.world = group, int(world)
+
+    def all_reduce(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t, group=self.group)
+
+
+SYNC = None
+
+
+def _bn_forward_stats(y, partial, T, bn, G, rows_per_group, C, repeat):
     mean, rstd = _new(y, G, C), _new(y, G, C)
     scratch = _new(y, 32, G, 2, C, dtype=torch.float64)
-    ops.B.bn_finalize(partial, mean, rstd, bn.rm, bn.rv, bn.nbt, scratch, G, T, C, rows_per_group, BN_EPS,
-                      BN_MOMENTUM, repeat)
+    if SYNC is None:
+        ops.B.bn_finalize(partial, mean, rstd, bn.rm, bn.rv, bn.nbt, scratch, G, T, C, rows_per_group, BN_EPS,
+                          BN_MOMENTUM, repeat)
+    else:
+        sums = _new(y, G, 2, C, dtype=torch.float64)
+        ops.B.bn_reduce_partials(partial, sums, scratch, G, T, C)
+        SYNC.all_reduce(sums)
+        ops.B.bn_finalize_sums(sums, mean, rstd, bn.rm, bn.rv, bn.nbt, G, C, rows_per_group * SYNC.world, BN_EPS,
+                               BN_MOMENTUM, repeat)
+    return mean, rstd
+
+
+def _bn_backward_sums(y, partial, T, dgamma, dbeta, G, C):
+    """Parameter gradients (local) and the [G][2][C] sums the apply kernel needs (global under SyncBN)."""
+    sums = _new(y, G, 2, C)
+    scratch = _new(y, 32, G, 2, C, dtype=torch.float64)
+    if SYNC is None:
+        ops.B.bn_bwd_finalize(partial, sums, dgamma, dbeta, scratch, G, T, C, 0.0)
+    else:
+        s64 = _new(y, G, 2, C, dtype=torch.float64)
+        ops.B.bn_reduce_partials(partial, s64, scratch, G, T, C)
+        ops.B.bn_bwd_finalize_sums(s64, None, dgamma, dbeta, G, C, 1.0, 0.0)
+        SYNC.all_reduce(s64)
+        ops.B.bn_bwd_finalize_sums(s64, sums, None, None, G, C, 1.0 / SYNC.world, 0.0)
+    return sums
+
+
+def bn_swish_from_partials(y, partial, T, bn, G, rows_per_group, C, repeat=1):
+    mean, rstd = _bn_forward_stats(y, partial, T, bn, G, rows_per_group, C, repeat)
     a = torch.empty_like(y)
     ops.B.bn_swish_fwd(y, mean, rstd, bn.gamma, bn.beta, a, G, rows_per_group, C)
     return a, mean, rstd
@@ -103,10 +146,8 @@ def bn_swish_from_partials(y, partial, T, bn, G, rows_per_group, C, repeat=1):
 def bn_swish_backward(da, y, mean, rstd, bn, dgamma, dbeta, G, rows_per_group, C):
     T = ops.B.colstats_tiles(rows_per_group)
     partial = _new(y, G, T, 2, C)
-    sums = _new(y, G, 2, C)
-    scratch = _new(y, 32, G, 2, C, dtype=torch.float64)
     ops.B.bn_swish_bwd_reduce(da, y, mean, rstd, bn.gamma, bn.beta, partial, G, rows_per_group, C)
-    ops.B.bn_bwd_finalize(partial, sums, dgamma, dbeta, scratch, G, T, C, 0.0)
+    sums = _bn_backward_sums(y, partial, T, dgamma, dbeta, G, C)
     dy = torch.empty_like(y)
     ops.B.bn_swish_bwd_apply(da, y, mean, rstd, bn.gamma, bn.beta, sums, dy, G, rows_per_group, C)
     return dy
@@ -122,9 +163,7 @@ def dgrad_bn_swish_backward(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride, offset, 
     partial = _new(y, G, T, 2, N)
     ops.B.igemm_nt_dgrad_bn(x, Wp, du, partial, y, mean, rstd, bn.gamma, bn.beta, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N,
                             stride, offset)
-    sums = _new(y, G, 2, N)
-    scratch = _new(y, 32, G, 2, N, dtype=torch.float64)
-    ops.B.bn_bwd_finalize(partial, sums, dgamma, dbeta, scratch, G, T, N, 0.0)
+    sums = _bn_backward_sums(y, partial, T, dgamma, dbeta, G, N)
     dy = torch.empty_like(y)
     ops.B.bn_swish_bwd_apply(du, y, mean, rstd, bn.gamma, bn.beta, sums, dy, G, rows_per_group, N, True)
     return dy

@@ -149,6 +149,21 @@ class HipBackend:
                                              _ptr(scratch, torch.float64), G, T, C, float(beta_acc), _stream()),
               "mmdyn_bn_bwd_finalize")
 
+    def bn_reduce_partials(self, partial, sums, scratch, G, T, C):
+        F64 = torch.float64
+        check(self.lib.mmdyn_bn_reduce_partials(_ptr(partial), _ptr(sums, F64), _ptr(scratch, F64), G, T, C, _stream()),
+              "mmdyn_bn_reduce_partials")
+
+    def bn_finalize_sums(self, sums, mean, rstd, running_mean, running_var, nbt, G, C, n, eps, momentum, repeat):
+        check(self.lib.mmdyn_bn_finalize_sums(_ptr(sums, torch.float64), _ptr(mean), _ptr(rstd), _ptr(running_mean),
+                                              _ptr(running_var), _ptr(nbt, torch.int64), G, C, n, eps, momentum, repeat,
+                                              _stream()), "mmdyn_bn_finalize_sums")
+
+    def bn_bwd_finalize_sums(self, sums, sums_f, dgamma, dbeta, G, C, sums_scale, beta_acc):
+        check(self.lib.mmdyn_bn_bwd_finalize_sums(_ptr(sums, torch.float64), _ptr(sums_f), _ptr(dgamma), _ptr(dbeta), G, C,
+                                                  float(sums_scale), float(beta_acc), _stream()),
+              "mmdyn_bn_bwd_finalize_sums")
+
     def bn_swish_bwd_apply(self, da, y, mean, rstd, gamma, beta, sums, dy, G, rows_per_group, C, da_is_du=False):
         check(self.lib.mmdyn_bn_swish_bwd_apply(_ptr(da), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
                                                 _ptr(sums), _ptr(dy), G, rows_per_group, C, int(da_is_du), _stream()),

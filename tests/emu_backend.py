@@ -251,6 +251,21 @@ class EmuBackend:
         if nbt is not None:
             nbt += G * repeat
 
+    def bn_reduce_partials(self, partial, sums, scratch, G, T, C):
+        sums.copy_(partial.reshape(G, T, 2, C).double().sum(1))
+
+    def bn_finalize_sums(self, sums, mean, rstd, rm, rv, nbt, G, C, n, eps, momentum, repeat):
+        self.bn_finalize(sums.reshape(G, 1, 2, C), mean, rstd, rm, rv, nbt, None, G, 1, C, n, eps, momentum, repeat)
+
+    def bn_bwd_finalize_sums(self, sums, sums_f, dgamma, dbeta, G, C, sums_scale, beta_acc):
+        s = sums.reshape(G, 2, C)
+        if sums_f is not None:
+            sums_f.copy_((s * sums_scale).float())
+        if dbeta is not None:
+            dbeta.copy_((beta_acc * dbeta if beta_acc else 0) + s[:, 0].sum(0).float())
+        if dgamma is not None:
+            dgamma.copy_((beta_acc * dgamma if beta_acc else 0) + s[:, 1].sum(0).float())
+
     @staticmethod
     def _xhat(y, mean, rstd, G, rpg, C):
         return (y.reshape(G, rpg, C) - mean[:, None]) * rstd[:, None]

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, sync_bn=False):
     for p in (ROOT, os.path.join(ROOT, "multimodal-dynamics_amd"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -40,7 +40,8 @@ def _worker(rank, world, port, out_dir):
     sl = slice(rank * B, (rank + 1) * B)
     eps, masks = seeded_noise(B, 256, 7, 8, 100 + rank)
     m = T.build("cnn-mvae", True, True, "cpu")
-    step = MVAEStep(m, noise=InjectedNoise(eps, masks), process_group=dist.group.WORLD, world_size=world)
+    step = MVAEStep(m, noise=InjectedNoise(eps, masks), process_group=dist.group.WORLD, world_size=world,
+                    sync_bn=sync_bn)
     loss = step.train_step([x[sl] for x in inputs], [x[sl] for x in targets], 0.02)
     torch.save({"flat": step.params.flat.clone(), "order": step.params.order, "offsets": step.params.offsets,
                 "loss": float(loss)}, os.path.join(out_dir, f"rank{rank}.pt"))
@@ -81,5 +82,39 @@ def test_two_rank_step_matches_averaged_gradients(tmp_path):
         got = r0["flat"][o:o + prm[k].numel()].view_as(prm[k])
         err = (got - prm[k].detach()).abs()
         # first Adam step moves every element by ~lr*sign(g): allow sign flips only where the gradient is at noise level
+        assert float((err > 1e-5).float().mean()) < 0.02, (k, float(err.max()))
+        assert float(err.max()) <= 2.1e-3, k
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sync_bn_equals_global_batch(tmp_path):
+    """sync_bn=True: BatchNorm statistics over the global batch.  Two ranks with 2 samples each must then reproduce
+    the single-process reference step on the concatenated batch of 4: loss = mean of the rank losses, parameters after
+    one Adam step equal (the gradient average over ranks is the global-batch gradient)."""
+    world = 2
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True,
+                       start_method="spawn")
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
+    torch.testing.assert_close(r0["flat"], r1["flat"], rtol=0, atol=0)
+
+    from oracle import mvae_oracle as O
+    from mmdyn_hip.models.shapes import state_dict_shapes
+    from mmdyn_hip.utils.seeded_init import seeded_state_dict, seeded_batch, seeded_noise
+    sd = seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True), 0)
+    inputs, targets = seeded_batch(4, 1234)
+    per_rank = [seeded_noise(2, 256, 7, 8, 100 + r) for r in range(world)]
+    eps = [torch.cat([per_rank[r][0][i] for r in range(world)]) for i in range(7)]
+    masks = [torch.cat([per_rank[r][1][i] for r in range(world)]) for i in range(8)]
+    prm, buf = O.split_state(sd)
+    _, loss, _ = O.evaluate_mvae(prm, inputs, targets, eps, masks, 0.02, 1000.0, True, buf)
+    loss.backward()
+    assert 0.5 * (r0["loss"] + r1["loss"]) == pytest.approx(float(loss.detach()), rel=1e-4)
+    names = list(prm)
+    O.Adam([prm[k] for k in names], lr=1e-3).step()
+    for k in names:
+        o = r0["offsets"][k]
+        got = r0["flat"][o:o + prm[k].numel()].view_as(prm[k])
+        err = (got - prm[k].detach()).abs()
         assert float((err > 1e-5).float().mean()) < 0.02, (k, float(err.max()))
         assert float(err.max()) <= 2.1e-3, k

@@ -237,6 +237,21 @@ def test_batchnorm_kernels(G, rpg, C):
     for i in (1, 2, 3):
         assert rel(g2[i], c2[i]) < 1e-4, i
     both("bn_swish_bwd_apply", [da, y, mean, rstd, gamma, beta, sums, torch.zeros(G * rpg, C), G, rpg, C], [7], tol=1e-4)
+    # the synchronised-BatchNorm pieces: reduce_partials -> (all-reduce) -> finalize_sums must equal bn_finalize on one
+    # rank, and with the sums doubled / n doubled ("two identical ranks") the statistics must not move
+    s64 = torch.zeros(G, 2, C, dtype=torch.float64, device=DEV)
+    HIP.bn_reduce_partials(g_args[0], s64, scratch.to(DEV), G, T, C)
+    assert rel(s64, g_args[0].double().sum(1)) < 1e-6
+    for world in (1, 2):
+        m2, r2 = torch.zeros(G, C, device=DEV), torch.zeros(G, C, device=DEV)
+        HIP.bn_finalize_sums(s64 * world, m2, r2, None, None, None, G, C, rpg * world, 1e-5, 0.1, 1)
+        assert rel(m2, g_args[1]) < 1e-6 and rel(r2, g_args[2]) < 1e-5
+    b64 = torch.zeros(G, 2, C, dtype=torch.float64, device=DEV)
+    HIP.bn_reduce_partials(ga[6], b64, scratch.to(DEV), G, T, C)
+    sf, dg2, db2 = torch.zeros(G, 2, C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    HIP.bn_bwd_finalize_sums(b64, None, dg2, db2, G, C, 1.0, 0.0)
+    HIP.bn_bwd_finalize_sums(b64 * 2, sf, None, None, G, C, 0.5, 0.0)
+    assert rel(dg2, g2[2]) < 1e-5 and rel(db2, g2[3]) < 1e-5 and rel(sf, g2[1]) < 1e-5
 
 
 def test_elementwise_kernels():

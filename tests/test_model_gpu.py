@@ -115,6 +115,33 @@ def test_bf16_engine_vs_oracle():
     assert ops.B.precision == "fp32"          # the engine restores the default after every call
 
 
+def test_sync_bn_single_rank_equals_local(tmp_path):
+    """sync_bn with a one-rank RCCL group: the all-reduces are identities, so loss and gradients must equal the local
+    BatchNorm step bit for bit up to the fp64 -> fp32 rounding of the statistics (exercises the RCCL + kernel path)."""
+    import torch.distributed as dist
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B, klw = 8, 0.02
+        inputs, targets = seeded_batch(B, 77)
+        eps, masks = seeded_noise(B, 256, 7, 8, 78)
+        gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+        out = []
+        for sync in (False, True):
+            m = T.build("cnn-mvae", True, True, DEV)
+            step = MVAEStep(m, noise=InjectedNoise(eps, masks), process_group=dist.group.WORLD, world_size=1, sync_bn=sync)
+            loss = float(step.forward(gi, gt, klw))
+            for h in step.backward():
+                h.wait()
+            out.append((loss, step.params.grad.clone()))
+        assert out[0][0] == pytest.approx(out[1][0], rel=1e-6)
+        assert float((out[0][1] - out[1][1]).norm() / out[0][1].norm()) < 1e-5
+    finally:
+        dist.destroy_process_group()
+
+
 def test_full_size_properties_b256():
     """BASELINE batch (256): properties that need no CPU run of the same size --
     (i) the total equals the sum of the 7 partial ELBOs; (ii) replaying the same step from the same state and
