@@ -578,10 +578,11 @@ def heads_forward(P, hd, packed=None, cond=None):
     L, K = P["linear_means.weight"].shape
     Kp = _pad32(K)
     pk = packed if packed is not None else pack_now(heads_pack_specs(P))
-    if cond is not None or Kp != hd.shape[1]:
+    K0 = hd.shape[1]                                   # width of the features proper (512 for the image encoders)
+    if cond is not None or Kp != K0:
         hd = concat_condition(hd, cond, Kp)
     out, _ = dense(hd, pk["Wh"], pk["bh"], hd.shape[0], Kp, 2 * L)
-    return out, {"hd": hd, "pk": pk, "L": L, "K": K, "Kp": Kp}
+    return out, {"hd": hd, "pk": pk, "L": L, "K": K, "Kp": Kp, "K0": K0}
 
 
 def heads_backward(c, dout, grads, need_dx=True):
@@ -597,7 +598,7 @@ def heads_backward(c, dout, grads, need_dx=True):
     if not need_dx:
         return None
     dx, _ = dense(dout, c["pk"]["WhT"], None, rows, 2 * L, Kp)
-    return dx if Kp == 512 else crop_columns(dx, Kp, 512)
+    return dx if Kp == c["K0"] else crop_columns(dx, Kp, c["K0"])
 
 
 HEAD_KEYS = ["linear_means.weight", "linear_means.bias", "linear_log_var.weight", "linear_log_var.bias"]

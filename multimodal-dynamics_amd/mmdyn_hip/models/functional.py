@@ -122,6 +122,35 @@ class PoseDecoderFn(torch.autograd.Function):
         return (dz,) + tuple(grads[k] for k in layers.POSE_DEC_KEYS)
 
 
+class MLPFn(torch.autograd.Function):
+    """``mlp(sizes, ReLU, Identity)`` of the reference (vae.py:14-19) for any widths: Linear layers with ReLU between
+    them, none after the last.  MFMA GEMMs where both widths are multiples of 32, the small kernel otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        Ws, bs = [p.detach() for p in params[0::2]], [p.detach() for p in params[1::2]]
+        hs = [x.detach().contiguous()]
+        for i, (W, b) in enumerate(zip(Ws, bs)):
+            last = i == len(Ws) - 1
+            _, h = layers.linear_forward(hs[-1], W, b, layers.ACT_NONE if last else layers.ACT_RELU)
+            hs.append(h)
+        ctx.Ws, ctx.hs = Ws, hs
+        return hs[-1]
+
+    @staticmethod
+    def backward(ctx, dout):
+        Ws, hs = ctx.Ws, ctx.hs
+        grads = [None] * (2 * len(Ws))
+        d = dout.contiguous()
+        for i in range(len(Ws) - 1, -1, -1):
+            if i < len(Ws) - 1:
+                d = layers.act_backward(d, hs[i + 1], layers.ACT_RELU)      # ReLU: output sign == input sign
+            gW, gb = torch.empty_like(Ws[i]), torch.empty(Ws[i].shape[0], device=d.device)
+            d = layers.linear_backward(d, hs[i], Ws[i], gW, gb, need_dx=(i > 0 or ctx.needs_input_grad[0]))
+            grads[2 * i], grads[2 * i + 1] = gW, gb
+        return (d,) + tuple(grads)
+
+
 class PoEReparamFn(torch.autograd.Function):
     """prior + up to three fused-head experts -> (means, log_var, z) in one kernel (vae.py:139-159)."""
 

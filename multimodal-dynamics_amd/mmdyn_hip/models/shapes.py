@@ -97,9 +97,29 @@ def regressor_shapes(out_dim=7, cond=0):
     return d
 
 
+def mlp_vae_shapes(input_dim=784, hidden=(256, 256), latent=32, output_dim=784):
+    """mlp-vae: Encoder fc_net = mlp([input_dim] + hidden) + heads, Decoder deconv_net = mlp([latent] + hidden +
+    [output_dim]) (vae.py:218-222, 281-283); Linear layers sit at even Sequential indices."""
+    d = OrderedDict()
+    sizes = [input_dim] + list(hidden)
+    for j in range(len(sizes) - 1):
+        d[f"encoder.fc_net.{2 * j}.weight"] = (sizes[j + 1], sizes[j])
+        d[f"encoder.fc_net.{2 * j}.bias"] = (sizes[j + 1],)
+    for h in ("linear_means", "linear_log_var"):
+        d[f"encoder.{h}.weight"] = (latent, sizes[-1])
+        d[f"encoder.{h}.bias"] = (latent,)
+    sizes = [latent] + list(hidden) + [output_dim]
+    for j in range(len(sizes) - 1):
+        d[f"decoder.deconv_net.{2 * j}.weight"] = (sizes[j + 1], sizes[j])
+        d[f"decoder.deconv_net.{2 * j}.bias"] = (sizes[j + 1],)
+    return d
+
+
 def state_dict_shapes(model_name, use_pose=False, latent=256, cond=0):
     """``{key: shape}`` in the reference's registration order."""
     d = OrderedDict()
+    if "mlp" in model_name:
+        return mlp_vae_shapes(latent=latent)
     if "regressor" in model_name:
         return regressor_shapes(cond=cond)
     if "mvae" in model_name:

@@ -253,10 +253,10 @@ class Encoder(nn.Module):
             self.linear_means = LinearParams(HID + cond_w, latent_size)
             self.linear_log_var = LinearParams(HID + cond_w, latent_size)
         else:
+            if conditional:
+                raise NotImplementedError("mmdyn_hip: a conditional mlp Encoder cannot run in the reference either (its "
+                                          "heads are sized without the condition, vae.py:220-222 vs 237)")
             layer_sizes = [input_dim] + layer_sizes
-            if not (len(layer_sizes) == 3 and layer_sizes[1] % 32 == 0 and layer_sizes[2] % 32 == 0):
-                raise NotImplementedError("mmdyn_hip: the mlp Encoder is built for the MVAE pose branch "
-                                          "(two hidden layers, widths multiple of 32)")
             self.fc_net = mlp(layer_sizes)
             self.linear_means = LinearParams(layer_sizes[-1], latent_size)
             self.linear_log_var = LinearParams(layer_sizes[-1], latent_size)
@@ -278,8 +278,8 @@ class Encoder(nn.Module):
         if self.architecture == 'cnn':
             sd = dict(self.named_parameters())
             return Fn.ImageEncoderTrunkFn.apply(x, self, *[sd[k] for k in layers.ENC_KEYS])
-        sd = dict(self.named_parameters())
-        return Fn.PoseEncoderTrunkFn.apply(x, *[sd[k] for k in layers.POSE_ENC_KEYS])
+        lin = [m for m in self.fc_net if isinstance(m, LinearParams)]
+        return Fn.MLPFn.apply(x, *[p for m in lin for p in (m.weight, m.bias)])
 
     def heads(self, h, c=None):
         out = Fn.HeadsFn.apply(h, self.linear_means.weight, self.linear_means.bias, self.linear_log_var.weight,
@@ -324,9 +324,7 @@ class Decoder(nn.Module):
                 Conv2dParams(64, 32, 4, 2, 1, True), BatchNorm2dParams(32), Swish(),
                 Conv2dParams(32, 3, 4, 2, 1, True))
         else:
-            layer_sizes = [latent_size] + layer_sizes + [output_dim]
-            if len(layer_sizes) != 4:
-                raise NotImplementedError("mmdyn_hip: the mlp Decoder is built for the MVAE pose branch")
+            layer_sizes = [latent_size + cond_w] + layer_sizes + [output_dim]
             self.deconv_net = mlp(layer_sizes)
 
     def bn_buffers(self):
@@ -344,7 +342,11 @@ class Decoder(nn.Module):
                 return Fn.ImageDecoderFn.apply(z, self, *[sd[k] for k in layers.DEC_KEYS])
             finally:
                 self._cond = None
-        return Fn.PoseDecoderFn.apply(z, *[sd[k] for k in layers.POSE_DEC_KEYS])
+        cc = _condition(c, self.conditional)
+        if cc is not None:
+            z = torch.cat((z, cc), dim=-1)                   # vae.py:286-291 (a copy; no arithmetic)
+        lin = [m for m in self.deconv_net if isinstance(m, LinearParams)]
+        return Fn.MLPFn.apply(z, *[p for m in lin for p in (m.weight, m.bias)])
 
 
 class ProductOfExperts(nn.Module):
@@ -366,13 +368,13 @@ class VAE(Autoencoder):
 
     def __init__(self, use_pose=False, **kwargs):
         super().__init__(**kwargs)
-        if kwargs.get('architecture', 'mlp') != 'cnn':
-            raise NotImplementedError("mmdyn_hip: mlp-vae is outside the cnn hot path (SURVEY.md section 8a)")
         self.encoder = Encoder(**kwargs)
         self.decoder = Decoder(**kwargs)
 
     def forward(self, x, c=None):
         noise = _noise_of(self)
+        if x.dim() > 2 and self.architecture == 'mlp':
+            x = x.view(-1, self.input_dim)
         out = self.encoder.forward_fused(x, noise, c)
         L = self.latent_size
         means, log_var = out[:, :L], out[:, L:]

@@ -120,6 +120,28 @@ def pose_decoder(z, prm, pre="pose_decoder"):
     return F.linear(h, prm[pre + ".deconv_net.4.weight"], prm[pre + ".deconv_net.4.bias"])
 
 
+def mlp_stack(x, prm, pre, n_layers):
+    """``mlp(sizes, nn.ReLU, nn.Identity)`` (vae.py:14-19): Linear at even indices, ReLU between, none at the end."""
+    for j in range(n_layers):
+        x = F.linear(x, prm[f"{pre}.{2 * j}.weight"], prm[f"{pre}.{2 * j}.bias"])
+        if j < n_layers - 1:
+            x = torch.relu(x)
+    return x
+
+
+def mlp_vae_forward(prm, x, eps_noise, input_dim=784):
+    """VAE.forward with the mlp architecture (vae.py:81-88): flatten, fc_net, heads, reparametrize, deconv_net."""
+    if x.dim() > 2:
+        x = x.reshape(-1, input_dim)
+    n_enc = sum(1 for k in prm if k.startswith("encoder.fc_net.") and k.endswith(".weight"))
+    n_dec = sum(1 for k in prm if k.startswith("decoder.deconv_net.") and k.endswith(".weight"))
+    h = mlp_stack(x, prm, "encoder.fc_net", n_enc)
+    mu = F.linear(h, prm["encoder.linear_means.weight"], prm["encoder.linear_means.bias"])
+    lv = F.linear(h, prm["encoder.linear_log_var.weight"], prm["encoder.linear_log_var.bias"])
+    z = reparametrize(mu, lv, eps_noise)
+    return mlp_stack(z, prm, "decoder.deconv_net", n_dec), mu, lv
+
+
 def regressor_forward(prm, x, keep_mask, c=None, buffers=None):
     """Regressor.forward (models.py:66-77): the image-encoder trunk, dropout, optional condition concat, then
     out_net = Linear(512[+cd],256) ReLU Linear(256,256) ReLU Linear(256,out_dim) (models.py:57-63)."""

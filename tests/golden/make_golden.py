@@ -362,6 +362,31 @@ def gen_dataset(fname):
     print(fname, "sequences", int(out["tree/shock/n_train"]), int(out["tree/shock/n_test"]))
 
 
+def gen_mlp_vae(batch, fname):
+    """mlp-vae (config.MODELS[0]): VAE with the mlp Encoder / Decoder (vae.py:14-19, 218-222, 281-283) on flat inputs.
+    The reference's Decoder takes ``output_dim`` (default 784), not ``input_dim``, so only input_dim = 784 is
+    self-consistent; that is the case pinned here, with problems._elbo_loss as the criterion."""
+    model = M.setup_model("mlp-vae", input_dim=784, architecture="mlp", latent_size=32, condition_dim=0,
+                          conditional=False, categorical_conditions=False)
+    model.load_state_dict(seeded_state_dict(model.state_dict(), 0))
+    model.train()
+    g = torch.Generator().manual_seed(99)
+    x = torch.rand(batch, 1, 28, 28, generator=g)          # > 2-D input: VAE.forward flattens it (vae.py:82-83)
+    eps = [torch.randn(batch, 32, generator=g)]
+    slf = make_self(model, False, "mlp-vae", kl_weight=0.1, input_type="visual")
+    with Injector(eps, []):
+        recon, means, log_var = model(x)
+        loss = slf._elbo_loss(recon, x, means, log_var)
+        loss.backward()
+    out = {"batch": batch, "x": x.numpy(), "eps": eps[0].numpy(), "recon": recon.detach().numpy(),
+           "means": means.detach().numpy(), "log_var": log_var.detach().numpy(), "loss": np.float64(loss.item()),
+           "keys": np.array(list(model.state_dict().keys()))}
+    for n, p_ in model.named_parameters():
+        out["grad/" + n] = summarize(p_.grad)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "loss", float(out["loss"]))
+
+
 def gen_small_ops(fname):
     g = torch.Generator().manual_seed(2024)
     out = {}
@@ -438,6 +463,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "conditional":
         gen_conditional(2, "mvae_conditional_B2.npz")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mlp":
+        gen_mlp_vae(6, "mlp_vae_B6.npz")
+        sys.exit(0)
+    gen_mlp_vae(6, "mlp_vae_B6.npz")
     if len(sys.argv) > 1 and sys.argv[1] == "dataset":
         gen_dataset("dataset_tree.npz")
         sys.exit(0)

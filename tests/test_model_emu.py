@@ -338,3 +338,29 @@ def test_bf16_precision_plumbing():
     assert 1e-8 < r < 5e-3, r
     with pytest.raises(ValueError):
         MVAEStep(build("cnn-mvae", True, True, "cpu"), precision="fp16")
+
+
+def check_mlp_vae(golden_dir, device):
+    """'mlp-vae' through setup_model and the Reconstruction criterion against vectors from the reference."""
+    g = load(golden_dir, "mlp_vae_B6.npz")
+    m = setup_model("mlp-vae", input_dim=784, architecture="mlp", latent_size=32, condition_dim=0, conditional=False,
+                    categorical_conditions=False)
+    assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 0))
+    m.to(device).train()
+    m.noise = InjectedNoise([torch.tensor(g["eps"]), torch.randn(3, 32)], [])
+    x = torch.tensor(g["x"]).to(device)
+    recon, mu, lv = m(x)
+    prob = SeqModeling.__new__(SeqModeling)
+    prob._kl_weight = 0.1
+    loss = prob._elbo_loss(recon, x, mu, lv)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-4)
+    np.testing.assert_allclose(recon.detach().cpu().numpy(), g["recon"], rtol=1e-4, atol=3e-5)
+    for k, p_ in m.named_parameters():
+        close_summary(summarize(p_.grad.cpu()), g["grad/" + k], 1e-3, "grad " + k)
+    assert tuple(m.inference(3).shape) == (3, 784)
+
+
+def test_mlp_vae(golden_dir):
+    check_mlp_vae(golden_dir, "cpu")

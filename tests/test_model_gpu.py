@@ -43,6 +43,10 @@ def test_conditional_mvae(golden_dir):
     T.check_conditional(golden_dir, DEV)
 
 
+def test_mlp_vae(golden_dir):
+    T.check_mlp_vae(golden_dir, DEV)
+
+
 def test_regressor(golden_dir, tmp_path):
     T.check_regressor(golden_dir, DEV, tmp_path)
 

@@ -215,3 +215,21 @@ def test_regressor(golden_dir, tag):
         close_summary(summarize(prm[k].grad), g[f"{tag}/grad/" + k], 2e-4, "grad " + k)
     for k in buf:
         np.testing.assert_allclose(buf[k].double().numpy(), g[f"{tag}/buffer/" + k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_mlp_vae(golden_dir):
+    """config.MODELS[0] 'mlp-vae' on flat 784 inputs (the only input size the reference's mlp Decoder is consistent
+    with) + problems._elbo_loss."""
+    g = load(golden_dir, "mlp_vae_B6.npz")
+    shapes = state_dict_shapes("mlp-vae", latent=32)
+    assert list(shapes.keys()) == [str(k) for k in g["keys"]]
+    prm, _ = O.split_state(seeded_state_dict(shapes, 0))
+    x = torch.tensor(g["x"])
+    recon, mu, lv = O.mlp_vae_forward(prm, x, torch.tensor(g["eps"]))
+    loss = O.elbo_loss(recon, x, mu, lv, 0.1)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=2e-5)
+    np.testing.assert_allclose(recon.detach().numpy(), g["recon"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(mu.detach().numpy(), g["means"], rtol=1e-4, atol=2e-5)
+    for k in prm:
+        close_summary(summarize(prm[k].grad), g["grad/" + k], 2e-4, "grad " + k)
