@@ -419,6 +419,39 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// Few slabs (<= 32: every layer with many weights): one thread sums ALL slabs of four consecutive elements --
+// `chunks` independent 16-byte loads in flight, no LDS, no barrier -- in slab order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __restrict__ partial,
+                                                               float* __restrict__ canon, int chunks, int taps,
+                                                               int Cd, int Cg, int cg_canon, int perm, float beta) {
+  const int64_t slab = (int64_t)taps * Cd * Cg, nvec = slab >> 2;     // Cg % 32 == 0: a float4 never straddles a row
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = v << 2;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int c = 0; c < chunks; ++c) s += *reinterpret_cast<const f32x4*>(partial + (size_t)c * slab + i);
+    const int cg0 = (int)(i % Cg);
+    const int64_t t = i / Cg;
+    const int cd = (int)(t % Cd), tap = (int)(t / Cd);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cg = cg0 + k;
+      if (cg >= cg_canon) continue;
+      int64_t o;
+      if (perm == 0) {
+        o = ((int64_t)cd * cg_canon + cg) * taps + tap;
+      } else if (perm == 1) {
+        int hw = cg / 256, ch = cg - hw * 256;
+        o = (int64_t)cd * cg_canon + ch * 25 + hw;
+      } else {
+        int hw = cd / 256, ch = cd - hw * 256;
+        o = (int64_t)(ch * 25 + hw) * cg_canon + cg;
+      }
+      canon[o] = (beta != 0.f) ? (beta * canon[o] + s[k]) : s[k];
+    }
+  }
+}
+
 template <int BD, int BG, int WD, int WG, int WK>
 static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, hipStream_t st, bool bf16) {
   const int zblocks = g.chunks / WK;  // chunks % 4 == 0 is checked by the caller
@@ -518,6 +551,11 @@ extern "C" int mmdyn_wgrad_reduce(const float* partial, float* canon, int chunks
   if (perm == 1 && (Cg % 256 || Cg / 256 != 25)) return MMDYN_ERR_SHAPE;
   if (perm == 2 && (Cd % 256 || Cd / 256 != 25)) return MMDYN_ERR_SHAPE;
   int64_t slab = (int64_t)taps * Cd * Cg;
+  if (chunks <= 32 && slab >= 65536) {
+    hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(ew_grid(slab >> 2)), dim3(256), 0, (hipStream_t)stream, partial,
+                       canon, chunks, taps, Cd, Cg, cg_canon, perm, beta);
+    MMDYN_LAUNCH_CHECK();
+  }
   int64_t ntiles = (slab + 31) / 32;
   int grid = (int)(ntiles < 8192 ? ntiles : 8192);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partial, canon, chunks,
