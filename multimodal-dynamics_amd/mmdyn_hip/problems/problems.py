@@ -175,7 +175,10 @@ class Problem:
         if self.parameters['optimizer'] == 'SGD':      # reference: momentum 0.9, weight decay 5e-4 (problems.py:132-136)
             self._optimizer = FusedSGD(self._model.parameters(), lr=self.parameters['lr'], momentum=0.9, weight_decay=5e-4)
             return
-        use_engine = self._fused and 'mvae' in self.parameters['model_name'] and not self._conditional
+        # the fused step takes the dict-shaped inputs of seq / dyn modeling and has no loss-mask or condition input;
+        # everything else (plain reconstruction, --mask-loss, --conditional, cnn-vae, regressor) runs the module path
+        use_engine = (self._fused and 'mvae' in self.parameters['model_name'] and not self._conditional
+                      and isinstance(self, SeqModeling) and not self.parameters.get('mask_loss'))
         if use_engine:
             self._step = MVAEStep(self._model, lr=self.parameters['lr'], pose_multiplier=self._pose_multiplier)
         else:

@@ -364,3 +364,35 @@ def check_mlp_vae(golden_dir, device):
 
 def test_mlp_vae(golden_dir):
     check_mlp_vae(golden_dir, "cpu")
+
+
+def check_dyn_modeling_and_cli(tmp_path, no_cuda):
+    """BASELINE configs[3]'s problem type at the reference's own resolution: dyn_modeling (one-step predictor,
+    problems.py:765-803) trains through the fused engine on sequences of 3 frames; and the CLI (main.py flags)
+    drives seq_modeling / reconstruction end to end on synthetic batches."""
+    from mmdyn_hip.main import main
+    prob = DynModeling(args(problem_type="dyn_modeling", num_epochs=1, no_cuda=no_cuda, batchsize=2),
+                       log_dir=str(tmp_path / "dyn"), seq_length=3,
+                       train_loader=SyntheticVisuoTactile(2, 2, seq_length=3), test_loader=SyntheticVisuoTactile(1, 2, 3, seed=7))
+    assert prob._step is not None
+    prob.train()
+    assert prob._step.last["means"].shape[0] == 6            # every frame of the 2 x 3 batch is a sample
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        mv = ["--input-type", "visuotactile", "--model-name", "cnn-mvae"]
+        for extra in (mv + ["--problem-type", "seq_modeling", "--use-pose"], mv + ["--problem-type", "reconstruction"],
+                      mv + ["--problem-type", "seq_modeling", "--mask-loss"],       # (with pose the reference raises too)
+                      mv + ["--problem-type", "seq_modeling", "--use-pose", "--conditional", "--optimizer", "SGD"],
+                      ["--problem-type", "seq_modeling", "--model-name", "cnn-vae", "--input-type", "tactile"],
+                      ["--problem-type", "regression", "--model-name", "regressor", "--input-type", "visual"]):
+            argv = ["--batchsize", "2", "--num-epochs", "1", "--synthetic-batches", "2", "--save-name", "cli"] + extra \
+                + (["--no-cuda"] if no_cuda else [])
+            p = main(argv)
+            assert os.path.exists(os.path.join(p.log_dir, "results.pkl"))
+    finally:
+        os.chdir(cwd)
+
+
+def test_dyn_modeling_and_cli(tmp_path):
+    check_dyn_modeling_and_cli(tmp_path, no_cuda=True)

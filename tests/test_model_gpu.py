@@ -43,6 +43,10 @@ def test_conditional_mvae(golden_dir):
     T.check_conditional(golden_dir, DEV)
 
 
+def test_dyn_modeling_and_cli(tmp_path):
+    T.check_dyn_modeling_and_cli(tmp_path, no_cuda=False)
+
+
 def test_mlp_vae(golden_dir):
     T.check_mlp_vae(golden_dir, DEV)
 
