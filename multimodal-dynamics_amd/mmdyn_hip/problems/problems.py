@@ -499,6 +499,14 @@ class SeqModeling(Reconstruction):
 
 class DynModeling(SeqModeling):
 
+    def set_dataset(self):
+        """The reader reports seq_length only when it has just compiled the tree (datasets.py:88-93 vs 167-171; with
+        an existing pickle the reference gets None, and its ``l-1::l`` below raises).  The one-step predictor needs the
+        real frame count, so it is read off the data in that case."""
+        super().set_dataset()
+        if self._seq_length is None:
+            self._seq_length = self.train_dataset.frames_per_item
+
     def parse_input(self, data, target):
         """One-step-ahead targets on flat [B*L, ...] frames (problems.py:765-803): roll by -1, the last frame
         of each sequence takes the dataset's final target (images only; the pose target keeps the plain

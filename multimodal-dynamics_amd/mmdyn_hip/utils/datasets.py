@@ -316,7 +316,11 @@ def dataset_setup(dataset_path, problem_type, **kwargs):
     size = kwargs.get('input_size', 64)
     train_dataset = VisuoTactileDataset(train=True, dataset_path=dataset_path, input_size=size)
     test_dataset = VisuoTactileDataset(train=False, dataset_path=dataset_path, input_size=size)
-    fold = 'seq' in problem_type
+    # the reference folds the frame axis into the batch only for 'seq' problem types (datasets.py:42-43); its
+    # dyn_modeling then receives [B, L, 3, 64, 64] batches that neither DynModeling.parse_input (which rolls and
+    # strides a flat [B*L] frame axis, problems.py:765-803) nor Conv2d can take, so that combination cannot run
+    # there.  Here dyn_modeling gets the flat layout its parse_input is written for.
+    fold = 'seq' in problem_type or 'dyn' in problem_type
     device = kwargs.get('device')
     out_dict = {
         'train_dataset': train_dataset,

@@ -86,3 +86,11 @@ def test_device_loader_and_training_on_a_tree(tmp_path):
     assert prob._seq_length is None and len(prob.train_loader) == 2
     prob.train()
     assert os.path.exists(os.path.join(str(tmp_path / "log"), "results.pkl"))
+    # dyn_modeling (one-step predictor) on the same tree: flat frame axis, every frame a sample
+    from mmdyn_hip.problems.problems import DynModeling
+    dyn = DynModeling(T.args(problem_type="dyn_modeling", num_epochs=1, batchsize=2, dataset_path=str(tmp_path)),
+                      log_dir=str(tmp_path / "dyn"))
+    d, t = next(iter(dyn.train_loader))
+    assert tuple(d[0].shape) == (6, 3, 64, 64) and dyn._seq_length == 3      # read off the data (the pickle exists)
+    dyn.train()
+    assert dyn._step.last["means"].shape[0] == 6
