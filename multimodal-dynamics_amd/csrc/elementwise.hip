@@ -198,6 +198,39 @@ __global__ void linear_small_fwd_kernel(const float* __restrict__ x, const float
     y[i] = apply_act(s, act);
   }
 }
+// narrow outputs over a long reduction (the 512 -> 7 pose head): one wavefront per row, lanes stride over K with
+// coalesced reads of x and of the N weight rows, N accumulators per lane, then a 64-lane shuffle reduction
+template <int NMAX>
+__global__ __launch_bounds__(256) void linear_small_fwd_rowwave_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ W,
+                                                                       const float* __restrict__ b,
+                                                                       float* __restrict__ y, int rows, int K, int N,
+                                                                       int act) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int r = wave; r < rows; r += nwaves) {
+    float s[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) s[n] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float xv = x[(size_t)r * K + k];
+#pragma unroll
+      for (int n = 0; n < NMAX; ++n)
+        if (n < N) s[n] = fmaf(xv, W[(size_t)n * K + k], s[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) s[n] = wave_sum(s[n]);
+    if (lane < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int n = 0; n < NMAX; ++n)
+        if (n == lane) v = s[n];
+      if (b) v += b[lane];
+      y[(size_t)r * N + lane] = apply_act(v, act);
+    }
+  }
+}
+
 __global__ void linear_small_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W,
                                        float* __restrict__ dx, int rows, int K, int N) {
   const int64_t total = (int64_t)rows * K;
@@ -375,6 +408,11 @@ extern "C" int mmdyn_sum_blocks(const float* x, float* out, int P, int64_t n, vo
 extern "C" int mmdyn_linear_small_fwd(const float* x, const float* W, const float* b, float* y, int rows,
                                       int K, int N, int act, void* stream) {
   if (!x || !W || !y) return MMDYN_ERR_NULL;
+  if (N <= 8 && K >= 64) {
+    hipLaunchKernelGGL(linear_small_fwd_rowwave_kernel<8>, dim3(ew_grid((int64_t)rows * 64)), dim3(256), 0, ST, x, W,
+                       b, y, rows, K, N, act);
+    MMDYN_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(linear_small_fwd_kernel, dim3(ew_grid((int64_t)rows * N)), dim3(256), 0, ST, x, W, b, y,
                      rows, K, N, act);
   MMDYN_LAUNCH_CHECK();
