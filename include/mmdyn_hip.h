@@ -174,6 +174,10 @@ int mmdyn_bn_swish_bwd_reduce(const float* da, const float* y, const float* mean
 int mmdyn_bn_bwd_finalize(const float* partial, float* sums, float* dgamma, float* dbeta,
                           double* scratch /* [32][G][2][C] */, int G, int T, int C, float beta_acc,
                           void* stream);
+/* eval mode (model.eval(): nn.BatchNorm2d with training=False): mean[g][c] = running_mean[c],
+ * rstd[g][c] = 1/sqrt(running_var[c] + eps); mmdyn_bn_swish_fwd then applies them.  No buffer update. */
+int mmdyn_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* rstd, int G, int C,
+                        float eps, void* stream);
 /* Synchronised BatchNorm across data-parallel ranks (optional): the per-channel sums are
  * collapsed to double [G][2][C], all-reduced by the host (RCCL), and the statistics / backward coefficients are
  * finished from the GLOBAL sums.  reduce_partials: scratch like mmdyn_bn_finalize.  finalize_sums: n = global rows per

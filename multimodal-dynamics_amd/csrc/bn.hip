@@ -123,6 +123,16 @@ __global__ __launch_bounds__(256) void tile_sum_kernel(const float* __restrict__
   }
 }
 
+// eval mode: the "statistics" are the running estimates
+__global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                     float* __restrict__ mean, float* __restrict__ rstd, int G, int C, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  const int c = i % C;
+  mean[i] = running_mean[c];
+  rstd[i] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
 // adds the S slices of tile_sum_kernel: out[g][2][C] (the quantity a synchronised BatchNorm all-reduces)
 __global__ void bn_collapse_kernel(const double* __restrict__ sliced, double* __restrict__ out, int n, int S) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -267,6 +277,15 @@ extern "C" int mmdyn_bn_finalize(const float* partial, float* mean, float* rstd,
   hipLaunchKernelGGL(tile_sum_kernel, dim3(C / 32, G, S), dim3(256), 0, st, partial, g_sums, T, C);
   hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, g_sums, mean, rstd,
                      running_mean, running_var, nbt, G, C, rows_per_group, eps, momentum, repeat, S);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* rstd,
+                                   int G, int C, float eps, void* stream) {
+  if (!running_mean || !running_var || !mean || !rstd) return MMDYN_ERR_NULL;
+  if (G <= 0 || C <= 0) return MMDYN_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(ceil_div(G * C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean,
+                     running_var, mean, rstd, G, C, eps);
   MMDYN_LAUNCH_CHECK();
 }
 

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "mmdyn_bn_swish_fwd": "pppppp" + "iii" + "p",
     "mmdyn_bn_swish_bwd_reduce": "ppppppp" + "iii" + "p",
     "mmdyn_bn_bwd_finalize": "ppppp" + "iii" + "f" + "p",
+    "mmdyn_bn_eval_stats": "pppp" + "ii" + "f" + "p",
     "mmdyn_bn_reduce_partials": "ppp" + "iii" + "p",
     "mmdyn_bn_finalize_sums": "pppppp" + "iii" + "ff" + "i" + "p",
     "mmdyn_bn_bwd_finalize_sums": "pppp" + "ii" + "ff" + "p",

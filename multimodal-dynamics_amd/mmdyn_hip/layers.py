@@ -137,7 +137,11 @@ def _bn_backward_sums(y, partial, T, dgamma, dbeta, G, C):
 
 
 def bn_swish_from_partials(y, partial, T, bn, G, rows_per_group, C, repeat=1):
-    mean, rstd = _bn_forward_stats(y, partial, T, bn, G, rows_per_group, C, repeat)
+    if partial is None:             # eval mode: running estimates, no update (nn.BatchNorm2d, training=False)
+        mean, rstd = _new(y, G, C), _new(y, G, C)
+        ops.B.bn_eval_stats(bn.rm, bn.rv, mean, rstd, G, C, BN_EPS)
+    else:
+        mean, rstd = _bn_forward_stats(y, partial, T, bn, G, rows_per_group, C, repeat)
     a = torch.empty_like(y)
     ops.B.bn_swish_fwd(y, mean, rstd, bn.gamma, bn.beta, a, G, rows_per_group, C)
     return a, mean, rstd
@@ -427,7 +431,7 @@ def encoder_trunk_forward(*a, **k):
     return run(encoder_trunk_forward_steps(*a, **k))
 
 
-def encoder_trunk_forward_steps(P, buf, x, G=1, repeat=1, packed=None):
+def encoder_trunk_forward_steps(P, buf, x, G=1, repeat=1, packed=None, training=True):
     """x: NCHW [Bt,3,64,64] -> h = Swish(fc(conv stack)) [Bt,512]; returns (h, ctx).  Generator: yields after
     every layer (see :func:`interleave`).
     ``repeat``: how many reference forward calls this one stands for (running-stat EMA updates).
@@ -443,13 +447,13 @@ def encoder_trunk_forward_steps(P, buf, x, G=1, repeat=1, packed=None):
                    ACT_SWISH, 1)
     yield
     bn2, bn3, bn4 = (_bn_of(P, buf, k) for k in ENC_BN)
-    y2, st, T = conv_like(a1, pk["W2k"], CONV, G, Bg, 32, 32, 16, 64, 2, -1, True)
+    y2, st, T = conv_like(a1, pk["W2k"], CONV, G, Bg, 32, 32, 16, 64, 2, -1, training)
     a2, m2, r2 = bn_swish_from_partials(y2, st, T, bn2, G, Bg * 256, 64, repeat)
     yield
-    y3, st, T = conv_like(a2, pk["W3k"], CONV, G, Bg, 16, 64, 8, 128, 2, -1, True)
+    y3, st, T = conv_like(a2, pk["W3k"], CONV, G, Bg, 16, 64, 8, 128, 2, -1, training)
     a3, m3, r3 = bn_swish_from_partials(y3, st, T, bn3, G, Bg * 64, 128, repeat)
     yield
-    y4, st, T = conv_like(a3, pk["W4k"], CONV, G, Bg, 8, 128, 5, 256, 1, 0, True)
+    y4, st, T = conv_like(a3, pk["W4k"], CONV, G, Bg, 8, 128, 5, 256, 1, 0, training)
     a4, m4, r4 = bn_swish_from_partials(y4, st, T, bn4, G, Bg * 25, 256, repeat)
     yield
     u5, h = dense(a4, pk["Wf"], P["fc_net.0.bias"], Bt, FEAT, 512, ACT_SWISH, want_act=True)   # columns hw*256+c
@@ -503,7 +507,7 @@ def decoder_forward(*a, **k):
     return run(decoder_forward_steps(*a, **k))
 
 
-def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, cond=None):
+def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, cond=None, training=True):
     """z: [Bt, L] -> logits NCHW [Bt,3,64,64]; returns (logits, ctx).  ``logits=False`` stops after the last
     BatchNorm (used only to reproduce the running statistics of the reference's unused decoder passes)."""
     Bt, L0 = z.shape
@@ -517,13 +521,13 @@ def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, co
     u0, h0 = dense(z, pk["Wu"], pk["bu"], Bt, L, FEAT, ACT_SWISH, want_act=True)      # rows -> hw*256+c
     yield
     bn1, bn2, bn3 = (_bn_of(P, buf, k) for k in DEC_BN)
-    y1, st, T = tconv_s1p0(h0, pk["W1s"], G, Bg, 256, 128, stats=True)        # W1s: [16][128 co][256 ci]
+    y1, st, T = tconv_s1p0(h0, pk["W1s"], G, Bg, 256, 128, stats=training)        # W1s: [16][128 co][256 ci]
     a1, m1, r1 = bn_swish_from_partials(y1, st, T, bn1, G, Bg * 64, 128, repeat)
     yield
-    y2, st, T = conv_like(a1, pk["W2s"], TCONV_S2P1, G, Bg, 8, 128, 16, 64, stats=True)
+    y2, st, T = conv_like(a1, pk["W2s"], TCONV_S2P1, G, Bg, 8, 128, 16, 64, stats=training)
     a2, m2, r2 = bn_swish_from_partials(y2, st, T, bn2, G, Bg * 256, 64, repeat)
     yield
-    y3, st, T = conv_like(a2, pk["W3s"], TCONV_S2P1, G, Bg, 16, 64, 32, 32, stats=True)
+    y3, st, T = conv_like(a2, pk["W3s"], TCONV_S2P1, G, Bg, 16, 64, 32, 32, stats=training)
     a3, m3, r3 = bn_swish_from_partials(y3, st, T, bn3, G, Bg * 1024, 32, repeat)
     yield
     out = None

@@ -54,13 +54,16 @@ class Regressor(nn.Module):
                 for n in ("running_mean", "running_var", "num_batches_tracked")}
 
     def forward(self, x, c=None):
-        if not self.training:
-            raise NotImplementedError("mmdyn_hip: eval-mode BatchNorm / dropout is not built (the reference trains "
-                                      "and validates in train mode, problems.py:145,174)")
+        import torch
         sd = dict(self.named_parameters())
-        h = Fn.ImageEncoderTrunkFn.apply(x, self, *[sd[k] for k in layers.ENC_KEYS])
-        h = Fn.DropoutFn.apply(h, _noise_of(self).keep_mask(tuple(h.shape), h.device))
+        if self.training:
+            h = Fn.ImageEncoderTrunkFn.apply(x, self, *[sd[k] for k in layers.ENC_KEYS])
+            h = Fn.DropoutFn.apply(h, _noise_of(self).keep_mask(tuple(h.shape), h.device))
+        else:                       # eval: running-estimate BatchNorm, no dropout, forward only
+            with torch.no_grad():
+                P = {k: sd[k].detach() for k in layers.ENC_KEYS}
+                h = layers.run(layers.encoder_trunk_forward_steps(P, self.bn_buffers(), x.detach().contiguous(),
+                                                                  training=False))[0]
         if self.conditional:
-            import torch
             h = torch.cat((h, _condition(c, True)), dim=-1)
         return Fn.PoseDecoderFn.apply(h, *[sd[f"out_net.{i}.{n}"] for i in (0, 2, 4) for n in ("weight", "bias")])

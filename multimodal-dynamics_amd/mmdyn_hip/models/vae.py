@@ -266,17 +266,16 @@ class Encoder(nn.Module):
         return {f"conv_net.{i}.{n}": getattr(self.conv_net[i], n) for i in (3, 6, 9)
                 for n in ("running_mean", "running_var", "num_batches_tracked")}
 
-    def _check_mode(self):
-        if not self.training:
-            raise NotImplementedError("mmdyn_hip: eval-mode (running-statistics BatchNorm, no dropout) is not "
-                                      "built; the reference keeps the model in train mode everywhere "
-                                      "(problems.py:145,174)")
-
     def trunk(self, x):
-        """Everything before the dropout: [B,512] features."""
-        self._check_mode()
+        """Everything before the dropout: [B,512] features.  ``model.eval()``: BatchNorm uses the running estimates
+        (forward only: the result carries no autograd graph)."""
         if self.architecture == 'cnn':
             sd = dict(self.named_parameters())
+            if not self.training:
+                with torch.no_grad():
+                    P = {k: sd[k].detach() for k in layers.ENC_KEYS}
+                    return layers.run(layers.encoder_trunk_forward_steps(P, self.bn_buffers(), x.detach().contiguous(),
+                                                                         training=False))[0]
             return Fn.ImageEncoderTrunkFn.apply(x, self, *[sd[k] for k in layers.ENC_KEYS])
         lin = [m for m in self.fc_net if isinstance(m, LinearParams)]
         return Fn.MLPFn.apply(x, *[p for m in lin for p in (m.weight, m.bias)])
@@ -289,7 +288,7 @@ class Encoder(nn.Module):
     def forward_fused(self, x, noise, c=None):
         """Returns the fused heads output [B, 2L] (means | log_vars)."""
         h = self.trunk(x)
-        if self.architecture == 'cnn':
+        if self.architecture == 'cnn' and self.training:        # nn.Dropout is the identity in eval mode
             h = Fn.DropoutFn.apply(h, noise.keep_mask(tuple(h.shape), h.device))
         return self.heads(h, c)
 
@@ -332,10 +331,12 @@ class Decoder(nn.Module):
                 for n in ("running_mean", "running_var", "num_batches_tracked")}
 
     def forward(self, z, c=None):
-        if not self.training:
-            raise NotImplementedError("mmdyn_hip: eval-mode BatchNorm is not built (the reference never leaves "
-                                      "train mode: problems.py:145,174)")
         sd = dict(self.named_parameters())
+        if self.architecture == 'cnn' and not self.training:   # eval: running-estimate BatchNorm, forward only
+            with torch.no_grad():
+                P = {k: sd[k].detach() for k in layers.DEC_KEYS}
+                return layers.run(layers.decoder_forward_steps(P, self.bn_buffers(), z.detach().contiguous(),
+                                                               cond=_condition(c, self.conditional), training=False))[0]
         if self.architecture == 'cnn':
             self._cond = _condition(c, self.conditional)      # read by ImageDecoderFn.forward through `holder`
             try:

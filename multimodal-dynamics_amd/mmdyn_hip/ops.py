@@ -149,6 +149,10 @@ class HipBackend:
                                              _ptr(scratch, torch.float64), G, T, C, float(beta_acc), _stream()),
               "mmdyn_bn_bwd_finalize")
 
+    def bn_eval_stats(self, running_mean, running_var, mean, rstd, G, C, eps):
+        check(self.lib.mmdyn_bn_eval_stats(_ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(rstd), G, C, eps,
+                                           _stream()), "mmdyn_bn_eval_stats")
+
     def bn_reduce_partials(self, partial, sums, scratch, G, T, C):
         F64 = torch.float64
         check(self.lib.mmdyn_bn_reduce_partials(_ptr(partial), _ptr(sums, F64), _ptr(scratch, F64), G, T, C, _stream()),

@@ -88,3 +88,17 @@ def seeded_noise(batch, latent, n_eps, n_masks, seed=4321, hidden=512, p=0.1):
     eps = [torch.randn(batch, latent, generator=g) for _ in range(n_eps)]
     masks = [(torch.rand(batch, hidden, generator=g) >= p).to(torch.uint8) for _ in range(n_masks)]
     return eps, masks
+
+
+def seeded_running_stats(state, seed=7):
+    """Non-trivial BatchNorm running estimates for eval-mode vectors: running_mean ~ U(-0.2, 0.2), running_var ~
+    U(0.5, 1.5), num_batches_tracked = 3 -- a pure function of (seed, key name), applied in place to a state dict."""
+    for name, v in state.items():
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "running_mean":
+            state[name] = (0.4 * torch.rand(v.shape, generator=_gen(seed, name), dtype=torch.float64) - 0.2).to(v.dtype)
+        elif leaf == "running_var":
+            state[name] = (0.5 + torch.rand(v.shape, generator=_gen(seed, name), dtype=torch.float64)).to(v.dtype)
+        elif leaf == "num_batches_tracked":
+            state[name] = torch.full_like(v, 3)
+    return state

@@ -43,9 +43,28 @@ def swish(x):
     return x * torch.sigmoid(x)                                             # vae.py:331-334
 
 
+EVAL = False          # module.eval(): BatchNorm2d normalises with the running estimates and leaves them alone
+
+
+class eval_mode:
+    """``with O.eval_mode():`` -- the restatement of ``model.eval()`` (dropout is off when keep_mask is None)."""
+
+    def __enter__(self):
+        global EVAL
+        self._prev, EVAL = EVAL, True
+
+    def __exit__(self, *exc):
+        global EVAL
+        EVAL = self._prev
+
+
 def batchnorm_train(x, prm, prefix, buffers=None):
     """Train-mode BatchNorm2d: batch statistics, biased variance for normalisation,
-    unbiased for the running estimate (momentum 0.1)."""
+    unbiased for the running estimate (momentum 0.1).  Under :class:`eval_mode`: F.batch_norm(training=False)."""
+    if EVAL:
+        rm, rv = buffers[prefix + ".running_mean"], buffers[prefix + ".running_var"]
+        y = (x - rm[None, :, None, None]) * torch.rsqrt(rv + BN_EPS)[None, :, None, None]
+        return y * prm[prefix + ".weight"][None, :, None, None] + prm[prefix + ".bias"][None, :, None, None]
     n = x.numel() // x.shape[1]
     mean = x.mean(dim=(0, 2, 3))
     var = ((x - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))

@@ -251,6 +251,10 @@ class EmuBackend:
         if nbt is not None:
             nbt += G * repeat
 
+    def bn_eval_stats(self, rm, rv, mean, rstd, G, C, eps):
+        mean.copy_(rm.reshape(1, C).expand(G, C))
+        rstd.copy_((1.0 / torch.sqrt(rv + eps)).reshape(1, C).expand(G, C))
+
     def bn_reduce_partials(self, partial, sums, scratch, G, T, C):
         sums.copy_(partial.reshape(G, T, 2, C).double().sum(1))
 

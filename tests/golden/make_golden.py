@@ -36,7 +36,7 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 from mmdyn_hip.utils.seeded_init import (  # noqa: E402
-    seeded_state_dict, seeded_batch, seeded_noise)
+    seeded_state_dict, seeded_batch, seeded_noise, seeded_running_stats)
 
 
 def import_reference():
@@ -86,7 +86,9 @@ class Injector:
             return e.clone()
 
         def dropout(x, p=0.5, training=True, inplace=False):
-            assert training and abs(p - self.p) < 1e-12
+            if not training:                      # module.eval(): nn.Dropout is the identity
+                return x
+            assert abs(p - self.p) < 1e-12
             m = self.masks[self.used_masks]
             self.used_masks += 1
             assert m.shape == x.shape
@@ -387,6 +389,41 @@ def gen_mlp_vae(batch, fname):
     print(fname, "loss", float(out["loss"]))
 
 
+def gen_eval_mode(batch, fname):
+    """model.eval(): BatchNorm2d on the running estimates, Dropout off (deployment-style inference; the reference's
+    own loops never leave train mode).  cnn-mvae forward + inference, cnn-vae forward, Regressor."""
+    out = {"batch": batch}
+    inputs, _ = seeded_batch(batch, 4242, with_pose=True)
+    eps = [torch.randn(batch, 256, generator=torch.Generator().manual_seed(11 + i)) for i in range(4)]
+    model = build("cnn-mvae", True, use_pose=True)
+    model.load_state_dict(seeded_running_stats(model.state_dict()))
+    model.eval()
+    with torch.no_grad(), Injector(eps[:2], []):
+        v, t, p, mu, lv = model([inputs[0], inputs[1]], pose=inputs[2])
+        iv, it = model.inference(n=batch)
+    out.update({"mvae/visual": summarize(v, 256), "mvae/tactile": summarize(t, 256), "mvae/visual0": v[0].numpy(),
+                "mvae/pose": p.numpy(), "mvae/means": mu.numpy(), "mvae/log_var": lv.numpy(),
+                "mvae/inference_visual0": iv[0].numpy(), "mvae/inference_tactile": summarize(it, 256)})
+    for k, b in model.named_buffers():
+        out["mvae/buffer/" + k] = b.numpy().astype(np.float64)          # must be untouched by eval forwards
+    vae = build("cnn-vae", False)
+    vae.load_state_dict(seeded_running_stats(vae.state_dict()))
+    vae.eval()
+    with torch.no_grad(), Injector(eps[2:3], []):
+        r, mu, lv = vae(inputs[1])
+    out.update({"vae/recon": summarize(r, 256), "vae/recon0": r[0].numpy(), "vae/means": mu.numpy()})
+    reg = M.Regressor(out_dim=7, conditional=False, num_classes=0)
+    sd = seeded_running_stats(seeded_state_dict(reg.state_dict(), 0))
+    reg.load_state_dict(sd)
+    reg.eval()
+    with torch.no_grad():
+        out["regressor/out"] = reg(inputs[0]).numpy()
+    for i in range(4):
+        out[f"eps{i}"] = eps[i].numpy()
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "ok")
+
+
 def gen_small_ops(fname):
     g = torch.Generator().manual_seed(2024)
     out = {}
@@ -463,6 +500,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "conditional":
         gen_conditional(2, "mvae_conditional_B2.npz")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "eval":
+        gen_eval_mode(3, "eval_mode_B3.npz")
+        sys.exit(0)
+    gen_eval_mode(3, "eval_mode_B3.npz")
     if len(sys.argv) > 1 and sys.argv[1] == "mlp":
         gen_mlp_vae(6, "mlp_vae_B6.npz")
         sys.exit(0)

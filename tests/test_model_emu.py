@@ -396,3 +396,46 @@ def check_dyn_modeling_and_cli(tmp_path, no_cuda):
 
 def test_dyn_modeling_and_cli(tmp_path):
     check_dyn_modeling_and_cli(tmp_path, no_cuda=True)
+
+
+def check_eval_mode(golden_dir, device):
+    """model.eval() on the HIP modules: running-estimate BatchNorm, no dropout, buffers untouched; back in train()
+    the batch-statistics path is used again."""
+    from mmdyn_hip.utils.seeded_init import seeded_running_stats
+    g = load(golden_dir, "eval_mode_B3.npz")
+    B = int(g["batch"])
+    inputs, _ = seeded_batch(B, 4242, with_pose=True)
+    inputs = [x.to(device) for x in inputs]
+    eps = [torch.tensor(g[f"eps{i}"]) for i in range(4)]
+    m = build("cnn-mvae", True, True, device)
+    m.load_state_dict(seeded_running_stats({k: v.cpu() for k, v in m.state_dict().items()}))
+    m.eval()
+    m.noise = InjectedNoise(eps[:2], [])
+    v, t, p, mu, lv = m([inputs[0], inputs[1]], pose=inputs[2])
+    np.testing.assert_allclose(v[0].cpu().numpy(), g["mvae/visual0"], rtol=1e-4, atol=3e-5)
+    close_summary(summarize(t.cpu(), 256), g["mvae/tactile"], 3e-5, "tactile")
+    np.testing.assert_allclose(p.detach().cpu().numpy(), g["mvae/pose"], rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(mu.detach().cpu().numpy(), g["mvae/means"], rtol=1e-4, atol=3e-5)
+    iv, it = m.inference(n=B)
+    np.testing.assert_allclose(iv[0].cpu().numpy(), g["mvae/inference_visual0"], rtol=1e-4, atol=3e-5)
+    close_summary(summarize(it.cpu(), 256), g["mvae/inference_tactile"], 3e-5, "inference tactile")
+    for k, b in m.named_buffers():
+        np.testing.assert_allclose(b.double().cpu().numpy(), g["mvae/buffer/" + k], rtol=1e-6, err_msg=k)
+    m.train()                                                   # batch statistics again: the buffers move
+    m.noise = InjectedNoise([eps[3]], [torch.ones(B, 512, dtype=torch.uint8)] * 2)
+    m([inputs[0], inputs[1]], pose=inputs[2])
+    assert int(m.visual_encoder.conv_net[3].num_batches_tracked) == 4
+    vae = build("cnn-vae", False, None, device)
+    vae.load_state_dict(seeded_running_stats({k: v.cpu() for k, v in vae.state_dict().items()}))
+    vae.eval()
+    vae.noise = InjectedNoise([eps[2]], [])
+    r, mu, _ = vae(inputs[1])
+    np.testing.assert_allclose(r[0].cpu().numpy(), g["vae/recon0"], rtol=1e-4, atol=3e-5)
+    reg = setup_model("regressor", out_dim=7, conditional=False, num_classes=0)
+    reg.load_state_dict(seeded_running_stats(seeded_state_dict(reg.state_dict(), 0)))
+    reg.to(device).eval()
+    np.testing.assert_allclose(reg(inputs[0]).detach().cpu().numpy(), g["regressor/out"], rtol=1e-4, atol=3e-5)
+
+
+def test_eval_mode(golden_dir):
+    check_eval_mode(golden_dir, "cpu")

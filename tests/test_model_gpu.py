@@ -47,6 +47,10 @@ def test_dyn_modeling_and_cli(tmp_path):
     T.check_dyn_modeling_and_cli(tmp_path, no_cuda=False)
 
 
+def test_eval_mode(golden_dir):
+    T.check_eval_mode(golden_dir, DEV)
+
+
 def test_mlp_vae(golden_dir):
     T.check_mlp_vae(golden_dir, DEV)
 

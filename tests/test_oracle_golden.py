@@ -233,3 +233,36 @@ def test_mlp_vae(golden_dir):
     np.testing.assert_allclose(mu.detach().numpy(), g["means"], rtol=1e-4, atol=2e-5)
     for k in prm:
         close_summary(summarize(prm[k].grad), g["grad/" + k], 2e-4, "grad " + k)
+
+
+def test_eval_mode(golden_dir):
+    """model.eval(): BatchNorm2d with the running estimates, no dropout -- cnn-mvae forward + inference, cnn-vae,
+    Regressor, against the reference in eval mode."""
+    from mmdyn_hip.utils.seeded_init import seeded_running_stats
+    g = load(golden_dir, "eval_mode_B3.npz")
+    B = int(g["batch"])
+    inputs, _ = seeded_batch(B, 4242, with_pose=True)
+    eps = [torch.tensor(g[f"eps{i}"]) for i in range(4)]
+    with O.eval_mode(), torch.no_grad():
+        sd = seeded_running_stats(seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True), 0))
+        prm, buf = O.split_state(sd)
+        before = {k: v.clone() for k, v in buf.items()}
+        v, t, p, mu, lv = O.mvae_forward(prm, inputs[0], inputs[1], inputs[2], eps[0], iter([None, None]), True, buf)
+        np.testing.assert_allclose(v[0].numpy(), g["mvae/visual0"], rtol=1e-4, atol=2e-5)
+        close_summary(summarize(t, 256), g["mvae/tactile"], 2e-5, "tactile")
+        np.testing.assert_allclose(p.numpy(), g["mvae/pose"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(mu.numpy(), g["mvae/means"], rtol=1e-4, atol=2e-5)
+        iv, it = O.mvae_inference(prm, eps[1], buf)
+        np.testing.assert_allclose(iv[0].numpy(), g["mvae/inference_visual0"], rtol=1e-4, atol=2e-5)
+        for k in buf:
+            assert torch.equal(buf[k], before[k]), k
+            np.testing.assert_allclose(buf[k].double().numpy(), g["mvae/buffer/" + k], rtol=1e-6)
+        sd = seeded_running_stats(seeded_state_dict(state_dict_shapes("cnn-vae"), 0))
+        prm, buf = O.split_state(sd)
+        r, mu, _ = O.vae_forward(prm, inputs[1], eps[2], None, buf)
+        np.testing.assert_allclose(r[0].numpy(), g["vae/recon0"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(mu.numpy(), g["vae/means"], rtol=1e-4, atol=2e-5)
+        sd = seeded_running_stats(seeded_state_dict(state_dict_shapes("regressor"), 0))
+        prm, buf = O.split_state(sd)
+        out = O.regressor_forward(prm, inputs[0], torch.ones(B, 512) * (1 - O.DROPOUT_P), None, buf)
+        np.testing.assert_allclose(out.numpy(), g["regressor/out"], rtol=1e-4, atol=2e-5)
