@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--sync-bn", action="store_true",
                     help="BatchNorm statistics over the global batch (N > 1; eager launches, one small all-reduce per "
                          "BatchNorm layer and direction).  Default: local statistics")
+    ap.add_argument("--infer", action="store_true",
+                    help="time forward-only inference instead (model.eval(): joint visual+tactile+pose pass through the "
+                         "module API, running-estimate BatchNorm); prints its own JSON line, not the BASELINE metric")
     ap.add_argument("--single-lane", action="store_true",
                     help="no visual/tactile stream overlap: per-kernel durations in a rocprofv3 trace then match "
                          "the roofline object's live HIP-event measurement")
@@ -142,6 +145,30 @@ def main():
     torch.manual_seed(0)
     model = setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=4096, architecture="cnn",
                         conditional=False, categorical_conditions=False, latent_size=256, use_pose=True).to(dev).train()
+    if args.infer:
+        inputs, _ = seeded_batch(args.batch, 1234 + rank)
+        v, t, p = [z.to(dev) for z in inputs]
+        from mmdyn_hip.engine import MVAEInference
+        model.eval()
+        eng = MVAEInference(model, precision="bf16" if args.dtype == "bf16" else "fp32", use_graph=not args.no_graph,
+                            seed=1234 + rank)
+        for _ in range(args.warmup):
+            eng([v, t], pose=p)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = eng([v, t], pose=p)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"metric": "visuotactile samples/sec (inference, joint v+t+p forward, eval mode)",
+                          "value": args.batch * args.steps / dt, "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+                          "dtype": args.dtype, "data": "synthetic",
+                          "config": {"workload": f"cnn-mvae joint inference forward, bs={args.batch}, engine.MVAEInference "
+                                                 f"(prepacked weights, two streams, {'eager' if args.no_graph else 'HIP graph'})",
+                                     "algorithmic_gflop_per_sample": 0.274,
+                                     "tflops": args.batch * args.steps / dt * 0.274e9 / 1e12}}))
+        return
     step = MVAEStep(model, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), process_group=pg,
                     world_size=world, two_lanes=not args.single_lane,
                     precision="bf16" if args.dtype == "bf16" else "fp32", sync_bn=args.sync_bn and pg is not None)

@@ -581,3 +581,161 @@ class MVAEStep:
         loss = self.forward(inputs, targets, kl_weight, train=False)
         self.ctx = None
         return loss
+
+
+class MVAEInference:
+    """Forward-only serving path for a trained :class:`mmdyn_hip.models.MVAE` in ``eval()`` mode
+    (MVAE.forward / MVAE.inference of the reference, vae.py:126-176, with running-estimate BatchNorm and no
+    dropout -- what ``model.eval()`` gives).
+
+    What a deployment needs and the training step does not: the weights never change, so they are packed into GEMM
+    operand form ONCE (``refresh()`` after loading new weights); the visual and the tactile halves run on two HIP
+    streams; and the whole forward for a given (batch shape, modality subset) is captured into a HIP graph on first
+    use and replayed afterwards, so a request costs one graph launch.  Latent draws come from the device-side Philox
+    stream, so replays draw fresh noise."""
+
+    def __init__(self, model, precision="fp32", use_graph=True, seed=0):
+        from .models.vae import NoiseSource
+        if getattr(model, "conditional", False):
+            raise NotImplementedError("mmdyn_hip: MVAEInference is built for the unconditional cnn-mvae")
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.model, self.precision, self.use_graph = model, precision, use_graph
+        self.use_pose = bool(model._use_pose)
+        self.L = model.latent_size
+        self.dev = next(model.parameters()).device
+        self.lanes = _Lanes(self.dev, True)
+        self.noise = NoiseSource(seed)
+        self._sync = None
+        self._graphs = {}
+        self.refresh()
+
+    def _P(self, name, keys):
+        sd = dict(getattr(self.model, name).named_parameters())
+        return {k: sd[k].detach() for k in keys}
+
+    def refresh(self):
+        """(Re)pack the weights -- call after ``load_state_dict``.  Captured graphs stay valid (the packed buffers and
+        the parameter storage do not move)."""
+        m = self.model
+        self.P = {"ve": self._P("visual_encoder", layers.ENC_KEYS + layers.HEAD_KEYS),
+                  "te": self._P("tactile_encoder", layers.ENC_KEYS + layers.HEAD_KEYS),
+                  "vd": self._P("visual_decoder", layers.DEC_KEYS), "td": self._P("tactile_decoder", layers.DEC_KEYS)}
+        self.buf = {"ve": m.visual_encoder.bn_buffers(), "te": m.tactile_encoder.bn_buffers(),
+                    "vd": m.visual_decoder.bn_buffers(), "td": m.tactile_decoder.bn_buffers()}
+        if self.use_pose:
+            self.P["pe"] = self._P("pose_encoder", layers.POSE_ENC_KEYS + layers.HEAD_KEYS)
+            self.P["pd"] = self._P("pose_decoder", layers.POSE_DEC_KEYS)
+        specs = {"ve": layers.encoder_pack_specs(self.P["ve"]), "te": layers.encoder_pack_specs(self.P["te"]),
+                 "vh": layers.heads_pack_specs(self.P["ve"]), "th": layers.heads_pack_specs(self.P["te"]),
+                 "vd": layers.decoder_pack_specs(self.P["vd"]), "td": layers.decoder_pack_specs(self.P["td"])}
+        if self.use_pose:
+            specs["ph"] = layers.heads_pack_specs(self.P["pe"])
+        if getattr(self, "pk", None) is None:
+            if ops.B.name == "hip":
+                self._plan = layers.PackPlan(specs)
+                self.pk = self._plan.packed
+            else:
+                self._plan, self._specs = None, specs
+        if self._plan is not None:
+            self._plan.run()
+        else:
+            self.pk = {k: layers.pack_now(v) for k, v in specs.items()}
+
+    # ---- the forward itself (eager; captured by _graphed) -------------------------------------------------
+    def _encode(self, key, x):
+        h, _ = layers.run(layers.encoder_trunk_forward_steps(self.P[key], self.buf[key], x, packed=self.pk[key],
+                                                             training=False))
+        return layers.heads_forward(self.P[key], h, self.pk[key[0] + "h"])[0]
+
+    def _forward(self, visual, tactile, pose):
+        LN, L = self.lanes, self.L
+        ref = visual if visual is not None else (tactile if tactile is not None else pose)
+        B = ref.shape[0]
+        heads = [None, None, None]
+        LN.fork()
+        if visual is not None:
+            with LN.lane(0):
+                heads[0] = self._encode("ve", visual)
+        if tactile is not None:
+            with LN.lane(1):
+                heads[1] = self._encode("te", tactile)
+        if pose is not None and self.use_pose:
+            hp, _ = layers.pose_encoder_trunk_forward(self.P["pe"], pose)
+            heads[2] = layers.heads_forward(self.P["pe"], hp, self.pk["ph"])[0]
+        LN.join()
+        eps = self._draw_latent(B)
+        mu, lv, z = (torch.empty(B, L, device=ref.device) for _ in range(3))
+        p = {"mu": [None if h is None else h[:, :L] for h in heads], "lv": [None if h is None else h[:, L:] for h in heads],
+             "dmu": [None] * 3, "dlv": [None] * 3, "ld": [2 * L] * 3}
+        ops.B.poe_fwd([p], eps, mu, lv, z, None, True, 1, B, L)
+        return self._decode(z) + (mu, lv)
+
+    def _decode(self, z):
+        LN = self.lanes
+        LN.fork()
+        with LN.lane(0):
+            v, _ = layers.run(layers.decoder_forward_steps(self.P["vd"], self.buf["vd"], z, packed=self.pk["vd"],
+                                                           training=False))
+        with LN.lane(1):
+            t, _ = layers.run(layers.decoder_forward_steps(self.P["td"], self.buf["td"], z, packed=self.pk["td"],
+                                                           training=False))
+        pr = layers.pose_decoder_forward(self.P["pd"], z)[0] if self.use_pose else None
+        LN.join()
+        return v, t, pr
+
+    def _sample(self, n):
+        return self._decode(self._draw_latent(n))[:2]
+
+    def _draw_latent(self, n):
+        """[n, L] standard-normal draw; the commit moves the stream position into the device counter, inside the
+        captured region, so that every graph replay draws fresh numbers."""
+        z = self.noise.eps((n, self.L), self.dev)
+        self.noise.commit()
+        return z
+
+    # ---- graph capture / replay ---------------------------------------------------------------------------
+    def _run(self, key, fn, static_inputs, new_inputs):
+        prev = getattr(ops.B, "precision", "fp32")
+        ops.B.precision = self.precision
+        try:
+            if not (self.use_graph and self.dev.type == "cuda"):
+                return fn(*new_inputs)
+            ent = self._graphs.get(key)
+            if ent is None:
+                static = [None if x is None else x.clone() for x in new_inputs]
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):                   # warm-up outside capture
+                    fn(*static)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = fn(*static)
+                ent = self._graphs[key] = (g, static, out)      # (capture records, it does not execute: replay below)
+            g, static, out = ent
+            for dst, src in zip(static, new_inputs):
+                if dst is not None and dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+            g.replay()
+            return out
+        finally:
+            ops.B.precision = prev
+
+    @torch.no_grad()
+    def forward(self, x, pose=None):
+        """``MVAE.forward`` semantics: x = [visual | None, tactile | None]; returns (visual_recon, tactile_recon,
+        pose_recon | None, means, log_var) -- logits, like the reference.  The returned tensors are the graph's static
+        outputs: copy them if they must survive the next call with the same shapes."""
+        visual, tactile = x
+        c = lambda t: None if t is None else t.contiguous()
+        ins = [c(visual), c(tactile), c(pose) if self.use_pose else None]
+        key = ("fwd",) + tuple(None if t is None else tuple(t.shape) for t in ins)
+        return self._run(key, self._forward, None, ins)
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def inference(self, n=1):
+        """``MVAE.inference``: z ~ N(0, I) -> (visual, tactile) logits."""
+        return self._run(("sample", int(n)), lambda: self._sample(int(n)), None, [])

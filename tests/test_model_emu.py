@@ -439,3 +439,44 @@ def check_eval_mode(golden_dir, device):
 
 def test_eval_mode(golden_dir):
     check_eval_mode(golden_dir, "cpu")
+
+
+def check_inference_engine(golden_dir, device):
+    """engine.MVAEInference (prepacked weights, two streams, HIP-graph replay) == the eval-mode module forward ==
+    the reference in eval mode; replays draw fresh latent noise; subsets of modalities work."""
+    from mmdyn_hip.engine import MVAEInference
+    from mmdyn_hip.utils.seeded_init import seeded_running_stats
+    g = load(golden_dir, "eval_mode_B3.npz")
+    B = int(g["batch"])
+    inputs, _ = seeded_batch(B, 4242, with_pose=True)
+    inputs = [x.to(device) for x in inputs]
+    m = build("cnn-mvae", True, True, device)
+    m.load_state_dict(seeded_running_stats({k: v.cpu() for k, v in m.state_dict().items()}))
+    m.eval()
+    eng = MVAEInference(m)
+    eng.noise = InjectedNoise([torch.tensor(g["eps0"]), torch.tensor(g["eps1"])], [])
+    eng.use_graph = False                                   # injected noise: compare with the reference's vectors
+    v, t, p, mu, lv = eng([inputs[0], inputs[1]], pose=inputs[2])
+    np.testing.assert_allclose(v[0].cpu().numpy(), g["mvae/visual0"], rtol=1e-4, atol=3e-5)
+    close_summary(summarize(t.cpu(), 256), g["mvae/tactile"], 3e-5, "tactile")
+    np.testing.assert_allclose(p.cpu().numpy(), g["mvae/pose"], rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mvae/means"], rtol=1e-4, atol=3e-5)
+    iv, it = eng.inference(B)
+    np.testing.assert_allclose(iv[0].cpu().numpy(), g["mvae/inference_visual0"], rtol=1e-4, atol=3e-5)
+    # device noise + graph replay (on the GPU): deterministic means, fresh latent draws per call, subsets
+    eng = MVAEInference(m, seed=5)
+    outs = [tuple(x.clone() for x in eng([inputs[0], inputs[1]], pose=inputs[2])) for _ in range(3)]
+    for o in outs[1:]:
+        assert torch.equal(o[3], outs[0][3]) and torch.equal(o[4], outs[0][4])       # means / log_var: no randomness
+    assert not torch.equal(outs[1][0], outs[0][0]) and not torch.equal(outs[2][0], outs[1][0])   # z differs per call
+    np.testing.assert_allclose(outs[0][3].cpu().numpy(), g["mvae/means"], rtol=1e-4, atol=3e-5)
+    v_only = eng([inputs[0], None])
+    assert v_only[2] is not None and tuple(v_only[0].shape) == (B, 3, 64, 64)
+    a, b = eng.inference(5), None
+    assert tuple(a[0].shape) == (5, 3, 64, 64)
+    for k, bb in m.named_buffers():
+        np.testing.assert_allclose(bb.double().cpu().numpy(), g["mvae/buffer/" + k], rtol=1e-6, err_msg=k)
+
+
+def test_inference_engine(golden_dir):
+    check_inference_engine(golden_dir, "cpu")

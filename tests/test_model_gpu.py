@@ -51,6 +51,10 @@ def test_eval_mode(golden_dir):
     T.check_eval_mode(golden_dir, DEV)
 
 
+def test_inference_engine(golden_dir):
+    T.check_inference_engine(golden_dir, DEV)
+
+
 def test_mlp_vae(golden_dir):
     T.check_mlp_vae(golden_dir, DEV)
 
