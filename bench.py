@@ -92,10 +92,12 @@ def cpu_baseline(batch, threads):
     probe, _ = run(32, 2)
     est_full = probe[-1] * (batch / 32.0)
     bs = batch if est_full * 3 <= 45.0 else 64
-    times, loss = run(bs, 3)
-    best = min(times[1:])
+    n_timed = 6 if est_full * 7 <= 30.0 else 2             # ~10-30 s of CPU work in total
+    times, loss = run(bs, 1 + n_timed)
+    best, med = min(times[1:]), sorted(times[1:])[len(times[1:]) // 2]
     return {"value": bs / best, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"2 timed steps (+1 warm-up) of the cnn-mvae+pose train step at bs={bs}, min; {best:.2f} s/step",
+            "sample": f"{n_timed} timed steps (+1 warm-up) of the cnn-mvae+pose train step at bs={bs}; "
+                      f"min {best:.2f} s/step (value), median {med:.2f} s/step",
             "loss": loss}
 
 
