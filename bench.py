@@ -95,9 +95,17 @@ def cpu_baseline(batch, threads):
     n_timed = 6 if est_full * 7 <= 30.0 else 2             # ~10-30 s of CPU work in total
     times, loss = run(bs, 1 + n_timed)
     best, med = min(times[1:]), sorted(times[1:])[len(times[1:]) // 2]
+    cpu = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": bs / best, "unit": "samples/s", "cores": threads, "kind": "port",
             "sample": f"{n_timed} timed steps (+1 warm-up) of the cnn-mvae+pose train step at bs={bs}; "
-                      f"min {best:.2f} s/step (value), median {med:.2f} s/step",
+                      f"min {best:.2f} s/step (value), median {med:.2f} s/step; {cpu}, os.cpu_count()={os.cpu_count()}",
             "loss": loss}
 
 
