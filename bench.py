@@ -118,9 +118,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a HIP graph")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="f32: the BASELINE configs[1] line (default).  bf16: bf16 matrix-core operands with fp32 "
-                         "accumulate/storage/master weights, the per-GPU share of configs[2] (use --batch 128)")
+    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16s"), default="f32",
+                    help="f32: the BASELINE configs[1] line (default).  bf16s: bf16 activation storage + bf16 matrix "
+                         "cores, fp32 accumulate / master weights = the per-GPU share of configs[2] (use --batch 128).  "
+                         "bf16: bf16 matrix-core operands only (fp32 storage)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="BatchNorm statistics over the global batch (N > 1; eager launches, one small all-reduce per "
                          "BatchNorm layer and direction).  Default: local statistics")
@@ -181,7 +182,8 @@ def main():
         return
     step = MVAEStep(model, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), process_group=pg,
                     world_size=world, two_lanes=not args.single_lane,
-                    precision="bf16" if args.dtype == "bf16" else "fp32", sync_bn=args.sync_bn and pg is not None)
+                    precision={"f32": "fp32", "bf16": "bf16", "bf16s": "bf16s"}[args.dtype],
+                    sync_bn=args.sync_bn and pg is not None)
     inputs, targets = seeded_batch(args.batch, 1234 + rank)
     inputs, targets = [x.to(dev) for x in inputs], [x.to(dev) for x in targets]
 
@@ -242,9 +244,11 @@ def main():
         "config": {"workload": (f"cnn-mvae visuotactile+pose 64x64, bs={args.batch} per GPU, fp32, seq_modeling "
                                 "train step (7 subset ELBOs + backward + Adam), BASELINE configs[1]")
                    if args.dtype == "f32" else
-                   (f"cnn-mvae visuotactile+pose 64x64, bs={args.batch} per GPU, bf16 matrix-core operands (fp32 "
-                    "accumulate, storage and master weights), seq_modeling train step, per-GPU share of BASELINE "
-                    "configs[2]"),
+                   (f"cnn-mvae visuotactile+pose 64x64, bs={args.batch} per GPU, "
+                    + ("bf16 activation storage + " if args.dtype == "bf16s" else "")
+                    + "bf16 matrix-core operands (fp32 accumulate"
+                    + (", storage" if args.dtype == "bf16" else "")
+                    + " and master weights), seq_modeling train step, per-GPU share of BASELINE configs[2]"),
                    "global_batch": global_batch, "parallelism": f"dp{world}", "bn": "sync" if (args.sync_bn and pg is not None) else "local",
                    "launch": "eager" if (args.no_graph or (args.sync_bn and pg is not None)) else "hip_graph",
                    "final_loss": final_loss},

@@ -293,6 +293,34 @@ int mmdyn_resize_u8_to_chw_f32(const uint8_t* src, const int* index, float* dst,
                                int Hout, int Wout, const int* xb, const int* xk, const int* yb, const int* yk,
                                void* stream);
 
+/* ---- bf16 activation storage (BASELINE configs[2]: "bf16 storage, fp32 accumulate / master weights") -----------
+ * The activations between the convolution layers (pre-BatchNorm outputs, post-Swish activations and their
+ * gradients) are bf16 in HBM (RNE on store, exact widening on load); weights, BatchNorm statistics and parameters,
+ * the FC-level tensors, logits, losses and optimiser state stay fp32; all arithmetic is fp32 in registers except the
+ * bf16 matrix-core products (fp32 accumulate).
+ *   mmdyn_igemm_nt_mx : mmdyn_igemm_nt / _dgrad_bn with per-tensor storage flags --
+ *       bit 0 bf16 matrix cores (required when any other bit is set), bit 1 A is bf16 (not IM2COL3), bit 2 C and
+ *       C_act are bf16, bit 3 the BatchNorm-backward operand y is bf16.  y == NULL: plain GEMM epilogue.  Split-K (fp32 workspace) is
+ *       allowed with a bf16 A, not with a bf16 C.
+ *   mmdyn_wgrad_tn_mx : bit 0 as above, bit 1 D is bf16, bit 2 Gt is bf16 (not IM2COL3).
+ *   *_b16             : the element-wise kernels on bf16 activation tensors. */
+int mmdyn_igemm_nt_mx(const void* A, const float* Bp, const float* bias, void* C, void* C_act, float* stats,
+                      float* ws, const void* y, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
+                      int ldc, int stride, int offset, int act, int splitk, int flags, void* stream);
+int mmdyn_wgrad_tn_mx(const void* D, const void* Gt, float* partial, int mode, int Bt, int Hr, int Wr, int Cd, int Hi,
+                      int Wi, int Cg, int stride, int offset, int chunks, int flags, void* stream);
+int mmdyn_bn_swish_fwd_b16(const uint16_t* y, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, uint16_t* a, int G, int rows_per_group, int C, void* stream);
+int mmdyn_bn_swish_bwd_reduce_b16(const uint16_t* da, const uint16_t* y, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, float* partial, int G, int rows_per_group,
+                                  int C, void* stream);
+int mmdyn_bn_swish_bwd_apply_b16(const uint16_t* da, const uint16_t* y, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, const float* sums, uint16_t* dy, int G,
+                                 int rows_per_group, int C, int da_is_du, void* stream);
+int mmdyn_act_bwd_b16(const uint16_t* dh, const uint16_t* u, uint16_t* du, int64_t n, int act, void* stream);
+int mmdyn_tconv_out3_fwd_b16(const uint16_t* a, const float* w, float* out, int Bt, int Hi, int Wi, void* stream);
+
 /* ---- misc ------------------------------------------------------------------------------------- */
 int mmdyn_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, void* stream);
 int mmdyn_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, void* stream);

@@ -19,9 +19,9 @@ struct BnParams {
 
 // column sums of two per-element quantities over a tile of rows -> partial[g][t][2][C]
 // MODE 0: (y, y^2).  MODE 1: (du, du * xhat) with du = da * swish'(gamma*xhat+beta).
-template <int MODE>
-__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ y,
-                                                        const float* __restrict__ da, BnParams bp,
+template <int MODE, typename TA>
+__global__ __launch_bounds__(256) void colreduce_kernel(const TA* __restrict__ y,
+                                                        const TA* __restrict__ da, BnParams bp,
                                                         float* __restrict__ partial, int rows_per_group,
                                                         int C, int T) {
   __shared__ float red[256 * 8];
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
       for (int u4 = 0; u4 < 4; ++u4) {
         const int rr = r + u4 * RL;
         const size_t off = (base + (rr < r_end ? rr : r)) * C + cv * 4;
-        v[u4] = *reinterpret_cast<const f32x4*>(y + off);
-        if (MODE == 1) d[u4] = *reinterpret_cast<const f32x4*>(da + off);
+        v[u4] = ld4<TA>(y + off);
+        if (MODE == 1) d[u4] = ld4<TA>(da + off);
       }
 #pragma unroll
       for (int u4 = 0; u4 < 4; ++u4) {
@@ -172,23 +172,30 @@ __global__ void bn_stats_finish_kernel(const double* __restrict__ sums, float* _
   if (nbt && c == 0) *nbt += (int64_t)G * repeat;
 }
 
-__global__ void bn_swish_fwd_kernel(const float* __restrict__ y, BnParams bp, float* __restrict__ a,
+template <typename T>
+__global__ void bn_swish_fwd_kernel(const T* __restrict__ y, BnParams bp, T* __restrict__ a,
                                     int64_t total4, int rows_per_group, int C) {
-  const int CV = C >> 2;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+  constexpr int V = vecw<T>::n, NV = V / 4;          // one 16-byte access per thread and iteration
+  const int CV = C / V;
+  const int64_t totalv = total4 * 4 / V;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < totalv;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int cv = (int)(i % CV);
     const int64_t row = i / CV;
     const int g = (int)(row / rows_per_group);
-    f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
-    f32x4 m = *reinterpret_cast<const f32x4*>(bp.mean + (size_t)g * C + cv * 4);
-    f32x4 r = *reinterpret_cast<const f32x4*>(bp.rstd + (size_t)g * C + cv * 4);
-    f32x4 ga = *reinterpret_cast<const f32x4*>(bp.gamma + cv * 4);
-    f32x4 be = *reinterpret_cast<const f32x4*>(bp.beta + cv * 4);
-    f32x4 o;
+    f32x4 v[NV], o[NV];
+    ldv<T>(y + i * V, v);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = swishf_(ga[k] * ((v[k] - m[k]) * r[k]) + be[k]);
-    reinterpret_cast<f32x4*>(a)[i] = o;
+    for (int q = 0; q < NV; ++q) {
+      const int c0 = cv * V + q * 4;
+      f32x4 m = *reinterpret_cast<const f32x4*>(bp.mean + (size_t)g * C + c0);
+      f32x4 r = *reinterpret_cast<const f32x4*>(bp.rstd + (size_t)g * C + c0);
+      f32x4 ga = *reinterpret_cast<const f32x4*>(bp.gamma + c0);
+      f32x4 be = *reinterpret_cast<const f32x4*>(bp.beta + c0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[q][k] = swishf_(ga[k] * ((v[q][k] - m[k]) * r[k]) + be[k]);
+    }
+    stv<T>(a + i * V, o);
   }
 }
 
@@ -215,34 +222,41 @@ __global__ void bn_bwd_param_kernel(const double* __restrict__ sums, float* __re
   if (dgamma) dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)sg;
 }
 
-__global__ void bn_swish_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ y,
+template <typename T>
+__global__ void bn_swish_bwd_apply_kernel(const T* __restrict__ da, const T* __restrict__ y,
                                           BnParams bp, const float* __restrict__ sums,
-                                          float* __restrict__ dy, int64_t total4, int rows_per_group, int C,
+                                          T* __restrict__ dy, int64_t total4, int rows_per_group, int C,
                                           int da_is_du) {
-  const int CV = C >> 2;
+  constexpr int V = vecw<T>::n, NV = V / 4;
+  const int CV = C / V;
+  const int64_t totalv = total4 * 4 / V;
   const float inv_n = 1.f / (float)rows_per_group;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < totalv;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int cv = (int)(i % CV);
     const int64_t row = i / CV;
     const int g = (int)(row / rows_per_group);
-    f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
-    f32x4 d = reinterpret_cast<const f32x4*>(da)[i];
-    f32x4 m = *reinterpret_cast<const f32x4*>(bp.mean + (size_t)g * C + cv * 4);
-    f32x4 r = *reinterpret_cast<const f32x4*>(bp.rstd + (size_t)g * C + cv * 4);
-    f32x4 ga = *reinterpret_cast<const f32x4*>(bp.gamma + cv * 4);
-    f32x4 be = *reinterpret_cast<const f32x4*>(bp.beta + cv * 4);
-    f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + ((size_t)g * 2 + 0) * C + cv * 4);
-    f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + ((size_t)g * 2 + 1) * C + cv * 4);
-    f32x4 o;
+    f32x4 v[NV], d[NV], o[NV];
+    ldv<T>(y + i * V, v);
+    ldv<T>(da + i * V, d);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float xh = (v[k] - m[k]) * r[k];
-      float u = ga[k] * xh + be[k];
-      float du = da_is_du ? d[k] : d[k] * swish_gradf_(u);       // the dgrad epilogue may already have applied swish'
-      o[k] = ga[k] * r[k] * (du - s0[k] * inv_n - xh * (s1[k] * inv_n));
+    for (int q = 0; q < NV; ++q) {
+      const int c0 = cv * V + q * 4;
+      f32x4 m = *reinterpret_cast<const f32x4*>(bp.mean + (size_t)g * C + c0);
+      f32x4 r = *reinterpret_cast<const f32x4*>(bp.rstd + (size_t)g * C + c0);
+      f32x4 ga = *reinterpret_cast<const f32x4*>(bp.gamma + c0);
+      f32x4 be = *reinterpret_cast<const f32x4*>(bp.beta + c0);
+      f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + ((size_t)g * 2 + 0) * C + c0);
+      f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + ((size_t)g * 2 + 1) * C + c0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float xh = (v[q][k] - m[k]) * r[k];
+        float u = ga[k] * xh + be[k];
+        float du = da_is_du ? d[q][k] : d[q][k] * swish_gradf_(u);   // the dgrad epilogue may already have applied swish'
+        o[q][k] = ga[k] * r[k] * (du - s0[k] * inv_n - xh * (s1[k] * inv_n));
+      }
     }
-    reinterpret_cast<f32x4*>(dy)[i] = o;
+    stv<T>(dy + i * V, o);
   }
 }
 
@@ -260,8 +274,8 @@ extern "C" int mmdyn_colstats(const float* y, float* partial, int G, int rows_pe
   if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
   const int T = ceil_div(rows_per_group, TILE_ROWS);
   BnParams bp{};
-  hipLaunchKernelGGL(colreduce_kernel<0>, dim3(T, G), dim3(256), 0, (hipStream_t)stream, y, nullptr, bp,
-                     partial, rows_per_group, C, T);
+  hipLaunchKernelGGL((colreduce_kernel<0, float>), dim3(T, G), dim3(256), 0, (hipStream_t)stream, y,
+                     (const float*)nullptr, bp, partial, rows_per_group, C, T);
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -327,10 +341,48 @@ extern "C" int mmdyn_bn_swish_fwd(const float* y, const float* mean, const float
   if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
   BnParams bp{mean, rstd, gamma, beta};
   int64_t total4 = (int64_t)G * rows_per_group * (C / 4);
-  hipLaunchKernelGGL(bn_swish_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, bp, a,
+  hipLaunchKernelGGL(bn_swish_fwd_kernel<float>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, bp, a,
                      total4, rows_per_group, C);
   MMDYN_LAUNCH_CHECK();
 }
+
+/* bf16 activation storage (BASELINE configs[2]): same kernels, y / a / da / dy are bf16 in HBM (fp32 in registers);
+ * statistics, affine parameters and sums stay fp32 */
+extern "C" int mmdyn_bn_swish_fwd_b16(const uint16_t* y, const float* mean, const float* rstd, const float* gamma,
+                                      const float* beta, uint16_t* a, int G, int rows_per_group, int C, void* stream) {
+  if (!y || !mean || !rstd || !gamma || !beta || !a) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
+  BnParams bp{mean, rstd, gamma, beta};
+  int64_t total4 = (int64_t)G * rows_per_group * (C / 4);
+  hipLaunchKernelGGL(bn_swish_fwd_kernel<bf16_t>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, bp, a,
+                     total4, rows_per_group, C);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bn_swish_bwd_reduce_b16(const uint16_t* da, const uint16_t* y, const float* mean,
+                                             const float* rstd, const float* gamma, const float* beta, float* partial,
+                                             int G, int rows_per_group, int C, void* stream) {
+  if (!da || !y || !mean || !rstd || !gamma || !beta || !partial) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
+  const int T = ceil_div(rows_per_group, TILE_ROWS);
+  BnParams bp{mean, rstd, gamma, beta};
+  hipLaunchKernelGGL((colreduce_kernel<1, bf16_t>), dim3(T, G), dim3(256), 0, (hipStream_t)stream, y, da, bp, partial,
+                     rows_per_group, C, T);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bn_swish_bwd_apply_b16(const uint16_t* da, const uint16_t* y, const float* mean, const float* rstd,
+                                            const float* gamma, const float* beta, const float* sums, uint16_t* dy,
+                                            int G, int rows_per_group, int C, int da_is_du, void* stream) {
+  if (!da || !y || !mean || !rstd || !gamma || !beta || !sums || !dy) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
+  BnParams bp{mean, rstd, gamma, beta};
+  int64_t total4 = (int64_t)G * rows_per_group * (C / 4);
+  hipLaunchKernelGGL(bn_swish_bwd_apply_kernel<bf16_t>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, da,
+                     y, bp, sums, dy, total4, rows_per_group, C, da_is_du);
+  MMDYN_LAUNCH_CHECK();
+}
+
 
 extern "C" int mmdyn_bn_swish_bwd_reduce(const float* da, const float* y, const float* mean,
                                          const float* rstd, const float* gamma, const float* beta,
@@ -339,7 +391,7 @@ extern "C" int mmdyn_bn_swish_bwd_reduce(const float* da, const float* y, const 
   if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
   const int T = ceil_div(rows_per_group, TILE_ROWS);
   BnParams bp{mean, rstd, gamma, beta};
-  hipLaunchKernelGGL(colreduce_kernel<1>, dim3(T, G), dim3(256), 0, (hipStream_t)stream, y, da, bp, partial,
+  hipLaunchKernelGGL((colreduce_kernel<1, float>), dim3(T, G), dim3(256), 0, (hipStream_t)stream, y, da, bp, partial,
                      rows_per_group, C, T);
   MMDYN_LAUNCH_CHECK();
 }
@@ -364,7 +416,7 @@ extern "C" int mmdyn_bn_swish_bwd_apply(const float* da, const float* y, const f
   if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
   BnParams bp{mean, rstd, gamma, beta};
   int64_t total4 = (int64_t)G * rows_per_group * (C / 4);
-  hipLaunchKernelGGL(bn_swish_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, da,
+  hipLaunchKernelGGL(bn_swish_bwd_apply_kernel<float>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, da,
                      y, bp, sums, dy, total4, rows_per_group, C, da_is_du);
   MMDYN_LAUNCH_CHECK();
 }

@@ -7,6 +7,68 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Activation storage type of the bf16-storage mode (BASELINE configs[2]): bf16 in HBM, fp32 in registers.
+// ld4 / st4 move four consecutive elements (16 bytes of fp32 or 8 bytes of bf16); rounding is RNE (v_cvt_pk_bf16_f32).
+typedef uint16_t bf16_t;
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  f32x4 v;
+  v[0] = __uint_as_float(u.x << 16);
+  v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16);
+  v[3] = __uint_as_float(u.y & 0xffff0000u);
+  return v;
+}
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return __uint_as_float((uint32_t)*p << 16); }
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 r;
+  r[0] = (__bf16)lo;
+  r[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, r);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f32x4 v) {
+  uint2 u;
+  u.x = pack2_bf16(v[0], v[1]);
+  u.y = pack2_bf16(v[2], v[3]);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+// 16-byte accesses for both storage types: VECW<T> elements per access (4 floats or 8 bf16), as VECW/4 f32x4 groups
+template <typename T> struct vecw { static constexpr int n = 4; };
+template <> struct vecw<bf16_t> { static constexpr int n = 8; };
+template <typename T> __device__ __forceinline__ void ldv(const T* p, f32x4* v);
+template <> __device__ __forceinline__ void ldv<float>(const float* p, f32x4* v) { v[0] = *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ void ldv<bf16_t>(const bf16_t* p, f32x4* v) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  v[0][0] = __uint_as_float(u.x << 16);
+  v[0][1] = __uint_as_float(u.x & 0xffff0000u);
+  v[0][2] = __uint_as_float(u.y << 16);
+  v[0][3] = __uint_as_float(u.y & 0xffff0000u);
+  v[1][0] = __uint_as_float(u.z << 16);
+  v[1][1] = __uint_as_float(u.z & 0xffff0000u);
+  v[1][2] = __uint_as_float(u.w << 16);
+  v[1][3] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void stv(T* p, const f32x4* v);
+template <> __device__ __forceinline__ void stv<float>(float* p, const f32x4* v) { *reinterpret_cast<f32x4*>(p) = v[0]; }
+template <> __device__ __forceinline__ void stv<bf16_t>(bf16_t* p, const f32x4* v) {
+  uint4 u;
+  u.x = pack2_bf16(v[0][0], v[0][1]);
+  u.y = pack2_bf16(v[0][2], v[0][3]);
+  u.z = pack2_bf16(v[1][0], v[1][1]);
+  u.w = pack2_bf16(v[1][2], v[1][3]);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = (bf16_t)(pack2_bf16(v, 0.f) & 0xffffu); }
+
 #define MMDYN_LAUNCH_CHECK()                      \
   do {                                            \
     hipError_t e__ = hipGetLastError();           \

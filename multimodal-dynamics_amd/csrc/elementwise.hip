@@ -20,19 +20,20 @@ __global__ void act_fwd_kernel(const float* __restrict__ u, float* __restrict__ 
     h[i] = apply_act(u[i], act);
 }
 
-__global__ void act_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ u,
-                               float* __restrict__ du, int64_t n, int act) {
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ u, T* __restrict__ du, int64_t n,
+                               int act) {
   const int64_t n4 = n >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
-    f32x4 v = reinterpret_cast<const f32x4*>(u)[i], d = reinterpret_cast<const f32x4*>(dh)[i], o;
+    f32x4 v = ld4<T>(u + i * 4), d = ld4<T>(dh + i * 4), o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = d[k] * act_grad(v[k], act);
-    reinterpret_cast<f32x4*>(du)[i] = o;
+    st4<T>(du + i * 4, o);
   }
   for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x)
-    du[i] = dh[i] * act_grad(u[i], act);
+    st1<T>(du + i, ld1<T>(dh + i) * act_grad(ld1<T>(u + i), act));
 }
 
 __global__ void dropout_expand_kernel(const float* __restrict__ h, const uint8_t* __restrict__ masks,
@@ -344,7 +345,13 @@ extern "C" int mmdyn_act_fwd(const float* u, float* h, int64_t n, int act, void*
 }
 extern "C" int mmdyn_act_bwd(const float* dh, const float* u, float* du, int64_t n, int act, void* stream) {
   if (!dh || !u || !du) return MMDYN_ERR_NULL;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, dh, u, du, n, act);
+  hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, dh, u, du, n, act);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_act_bwd_b16(const uint16_t* dh, const uint16_t* u, uint16_t* du, int64_t n, int act,
+                                 void* stream) {
+  if (!dh || !u || !du) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, dh, u, du, n, act);
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_dropout_expand(const float* h, const uint8_t* masks, float* out, int P, int B, int H,

@@ -44,6 +44,8 @@ struct IgemmGeom {
   const float* bn_rstd;   // [G][N]
   const float* bn_gamma;  // [N]
   const float* bn_beta;   // [N]
+  // bf16 activation storage (bf16 matrix-core variants only): which of the activation tensors are bf16 in HBM
+  int a_b16, c_b16, bny_b16;
 };
 
 constexpr int BK = 32;              // K-step (channels of one tap per stage)
@@ -213,7 +215,10 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       const int y = ry[i] + dh, x = rx[i] + dw;
       const bool ok = (rb[i] >= 0) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
       const int pix = ok ? (rb[i] * g.Hi + y) * g.Wi + x : 0;
-      ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)pix * g.Cin + c0);
+      if (BF16 && g.a_b16)
+        ra[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(A) + (size_t)pix * g.Cin + c0);
+      else
+        ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)pix * g.Cin + c0);
       okmask = ok ? (okmask | (0xFu << (4 * i))) : (okmask & ~(0xFu << (4 * i)));   // consumed at lds_store
     }
 #pragma unroll
@@ -337,7 +342,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
         if (bnbwd) {
           float xh = 0.f;
           if (ooff >= 0) {
-            xh = (g.bn_y[(size_t)ooff + col] - bn_m[nt]) * bn_r[nt];
+            const float yv = (BF16 && g.bny_b16) ? ld1<bf16_t>(reinterpret_cast<const bf16_t*>(g.bn_y) + (size_t)ooff + col)
+                                                 : g.bn_y[(size_t)ooff + col];
+            xh = (yv - bn_m[nt]) * bn_r[nt];
             v *= swish_gradf_(bn_g[nt] * xh + bn_b[nt]);
           }
           colsum[nt] += v;
@@ -352,8 +359,20 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
             ws[((size_t)split * g.rows_total + grow) * g.N + col] = v;
           } else {
             if (g.has_bias) v += bias[col];
-            C[(size_t)ooff + col] = v;
-            if (g.want_act_out) C_act[(size_t)ooff + col] = apply_act(v, g.act);
+            if (BF16 && g.c_b16) {
+              // two adjacent columns live in adjacent lanes: the even lane stores both as one dword (no sub-dword
+              // stores; ooff + col is even there, so the address is 4-byte aligned)
+              const float vn = __shfl_down(v, 1, 64);
+              if (!(cl & 1)) {
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C) + (size_t)ooff + col) = pack2_bf16(v, vn);
+                if (g.want_act_out)
+                  *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C_act) + (size_t)ooff + col) =
+                      pack2_bf16(apply_act(v, g.act), apply_act(vn, g.act));
+              }
+            } else {
+              C[(size_t)ooff + col] = v;
+              if (g.want_act_out) C_act[(size_t)ooff + col] = apply_act(v, g.act);
+            }
           }
         }
       }
@@ -506,7 +525,7 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
                        int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
                        void* stream, bool bf16, const float* bn_y = nullptr, const float* bn_mean = nullptr,
                        const float* bn_rstd = nullptr, const float* bn_gamma = nullptr,
-                       const float* bn_beta = nullptr) {
+                       const float* bn_beta = nullptr, int storage_flags = 0) {
   if (!A || !Bp || !C) return MMDYN_ERR_NULL;
   if (Cin <= 0 || N <= 0 || Cin % BK || N % 32 || G <= 0 || Bg <= 0 || ldc < N) return MMDYN_ERR_SHAPE;
   if (splitk < 1) splitk = 1;
@@ -530,6 +549,10 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   g.bn_rstd = bn_rstd;
   g.bn_gamma = bn_gamma;
   g.bn_beta = bn_beta;
+  g.a_b16 = (storage_flags & 2) != 0;
+  g.c_b16 = (storage_flags & 4) != 0;
+  g.bny_b16 = (storage_flags & 8) != 0;
+  if (storage_flags && (!bf16 || (g.c_b16 && splitk > 1) || (g.a_b16 && mode == MMDYN_IM2COL3))) return MMDYN_ERR_SHAPE;
   g.want_act_out = C_act != nullptr;
   g.splitk = splitk;
   g.nclasses = 1;
@@ -607,6 +630,19 @@ extern "C" int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C
   if (!stats || !y || !mean || !rstd || !gamma || !beta) return MMDYN_ERR_NULL;
   return igemm_entry(A, Bp, nullptr, C, nullptr, stats, nullptr, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset,
                      MMDYN_ACT_NONE, 1, stream, bf16 != 0, y, mean, rstd, gamma, beta);
+}
+
+/* One entry point for the mixed-storage variants: flags bit 0 = bf16 matrix cores (required for the others),
+ * bit 1 = A is bf16 in HBM, bit 2 = C / C_act are bf16, bit 3 = the BatchNorm-backward operand y is bf16. */
+extern "C" int mmdyn_igemm_nt_mx(const void* A, const float* Bp, const float* bias, void* C, void* C_act, float* stats,
+                                 float* ws, const void* bn_y, const float* bn_mean, const float* bn_rstd,
+                                 const float* bn_gamma, const float* bn_beta, int mode, int G, int Bg, int Hi, int Wi,
+                                 int Cin, int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
+                                 int flags, void* stream) {
+  if (bn_y && (!stats || !bn_mean || !bn_rstd || !bn_gamma || !bn_beta)) return MMDYN_ERR_NULL;
+  return igemm_entry((const float*)A, Bp, bias, (float*)C, (float*)C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho,
+                     Wo, N, ldc, stride, offset, act, splitk, stream, (flags & 1) != 0, (const float*)bn_y, bn_mean,
+                     bn_rstd, bn_gamma, bn_beta, flags & ~1);
 }
 
 extern "C" int mmdyn_igemm_nt_bf16(const float* A, const float* Bp, const float* bias, float* C, float* C_act,

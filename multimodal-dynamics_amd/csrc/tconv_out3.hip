@@ -16,7 +16,8 @@ constexpr int TI = 16;          // input tile edge
 constexpr int TH = TI + 2;      // with halo
 constexpr int PIX_LD = 36;      // floats per staged pixel (32 channels + 16-byte pad)
 
-__global__ __launch_bounds__(256) void tconv_out3_kernel(const float* __restrict__ a,      // [Bt][Hi][Wi][32]
+template <typename TA>
+__global__ __launch_bounds__(256) void tconv_out3_kernel(const TA* __restrict__ a,         // [Bt][Hi][Wi][32]
                                                          const float* __restrict__ w,      // [32][3][4][4]
                                                          float* __restrict__ out,          // [Bt][3][2Hi][2Wi]
                                                          int Hi, int Wi) {
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void tconv_out3_kernel(const float* __restrict
     const int y = y0 + py, x = x0 + px;
     f32x4 val = {0.f, 0.f, 0.f, 0.f};
     if ((unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi)
-      val = *reinterpret_cast<const f32x4*>(a + ((size_t)(b * Hi + y) * Wi + x) * 32 + v * 4);
+      val = ld4<TA>(a + ((size_t)(b * Hi + y) * Wi + x) * 32 + v * 4);
     *reinterpret_cast<f32x4*>(&tile[p * PIX_LD + v * 4]) = val;
   }
   __syncthreads();
@@ -99,6 +100,18 @@ extern "C" int mmdyn_tconv_out3_fwd(const float* a, const float* w, float* out, 
   if ((int64_t)Bt * Hi * Wi * 32 >= (1LL << 31)) return MMDYN_ERR_RANGE;
   dim3 grid((Hi / TI) * (Wi / TI), Bt);
   size_t smem = (size_t)TH * TH * PIX_LD * sizeof(float);
-  hipLaunchKernelGGL(tconv_out3_kernel, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi);
+  hipLaunchKernelGGL(tconv_out3_kernel<float>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi);
+  MMDYN_LAUNCH_CHECK();
+}
+
+/* bf16 activation storage: the input activations are bf16, weights and logits stay fp32 */
+extern "C" int mmdyn_tconv_out3_fwd_b16(const uint16_t* a, const float* w, float* out, int Bt, int Hi, int Wi,
+                                        void* stream) {
+  if (!a || !w || !out) return MMDYN_ERR_NULL;
+  if (Bt <= 0 || Hi % TI || Wi % TI || Bt > 65535) return MMDYN_ERR_SHAPE;
+  if ((int64_t)Bt * Hi * Wi * 32 >= (1LL << 31)) return MMDYN_ERR_RANGE;
+  dim3 grid((Hi / TI) * (Wi / TI), Bt);
+  size_t smem = (size_t)TH * TH * PIX_LD * sizeof(float);
+  hipLaunchKernelGGL(tconv_out3_kernel<bf16_t>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi);
   MMDYN_LAUNCH_CHECK();
 }

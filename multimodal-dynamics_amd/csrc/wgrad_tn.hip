@@ -20,6 +20,7 @@
 namespace {
 
 struct WgradGeom {
+  int d_b16, g_b16;  // bf16 activation storage (bf16 matrix-core variants only): D / Gt are bf16 in HBM
   int mode;  // MMDYN_DENSE or MMDYN_CONV
   int rows;  // Bt*Hr*Wr
   int Hr, Wr, Cd;
@@ -91,7 +92,10 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
       const int r = idx / DV, v = idx - r * DV;
       const int row = r0 + r;
       const bool ok = row < row_end;
-      rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
+      if (BF16 && g.d_b16)
+        rd[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
+      else
+        rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       okd = ok ? (okd | (1u << i)) : (okd & ~(1u << i));
     }
 #pragma unroll
@@ -129,7 +133,10 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
         ok = ok & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
         pix = (bb * g.Hi + y) * g.Wi + x;
       }
-      rg[i] = *reinterpret_cast<const f32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
+      if (BF16 && g.g_b16)
+        rg[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
+      else
+        rg[i] = *reinterpret_cast<const f32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       okg = ok ? (okg | (0xFu << (4 * i))) : (okg & ~(0xFu << (4 * i)));
     }
   };
@@ -263,7 +270,10 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       const int r = idx / DV, v = idx - r * DV;
       const int row = r0 + r;
       const bool ok = (idx < RK * DV) & (row < row_end);
-      rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
+      if (BF16 && g.d_b16)
+        rd[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
+      else
+        rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       okd = ok ? (okd | (1u << i)) : (okd & ~(1u << i));
     }
 #pragma unroll
@@ -277,7 +287,10 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       const int y = rr * g.rs + g.ro + kh, x = cc * g.rs + g.ro + kw;
       const bool ok = (row < row_end) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
       const int pix = (bb * g.Hi + y) * g.Wi + x;
-      rg[i] = *reinterpret_cast<const f32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
+      if (BF16 && g.g_b16)
+        rg[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
+      else
+        rg[i] = *reinterpret_cast<const f32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       okg = ok ? (okg | (1u << i)) : (okg & ~(1u << i));
     }
   };
@@ -470,12 +483,15 @@ static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, 
 
 static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr,
                        int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
-                       void* stream, bool bf16) {
+                       void* stream, bool bf16, int storage_flags = 0) {
   if (!D || !Gt || !partial) return MMDYN_ERR_NULL;
   if (Cd % 32 || Cg % 32 || Cd <= 0 || Cg <= 0 || chunks < 4 || chunks % 4) return MMDYN_ERR_SHAPE;
   if (mode != MMDYN_DENSE && mode != MMDYN_CONV && mode != MMDYN_IM2COL3) return MMDYN_ERR_SHAPE;
   if (mode == MMDYN_IM2COL3 && (Cg != 64 || Hi != 2 * Hr || Wi != 2 * Wr)) return MMDYN_ERR_SHAPE;
   WgradGeom g{};
+  g.d_b16 = (storage_flags & 2) != 0;
+  g.g_b16 = (storage_flags & 4) != 0;
+  if (storage_flags && (!bf16 || (g.g_b16 && mode == MMDYN_IM2COL3))) return MMDYN_ERR_SHAPE;
   g.mode = mode;
   const int64_t rows = (int64_t)Bt * Hr * Wr;
   if (rows * Cd >= (1LL << 31) || (int64_t)Bt * Hi * Wi * (mode == MMDYN_IM2COL3 ? 3 : Cg) >= (1LL << 31))
@@ -510,6 +526,14 @@ extern "C" int mmdyn_wgrad_tn(const float* D, const float* Gt, float* partial, i
                               int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
                               void* stream) {
   return wgrad_entry(D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks, stream, false);
+}
+
+/* mixed storage: flags bit 0 = bf16 matrix cores (required), bit 1 = D is bf16 in HBM, bit 2 = Gt is bf16 */
+extern "C" int mmdyn_wgrad_tn_mx(const void* D, const void* Gt, float* partial, int mode, int Bt, int Hr, int Wr,
+                                 int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks, int flags,
+                                 void* stream) {
+  return wgrad_entry((const float*)D, (const float*)Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset,
+                     chunks, stream, (flags & 1) != 0, flags & ~1);
 }
 
 extern "C" int mmdyn_wgrad_tn_bf16(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr,

@@ -77,6 +77,13 @@ _SIGNATURES = {
     "mmdyn_elbo_assemble": "ppppp" + "ii" + "ff" + "p",
     "mmdyn_adam_step": "ppppp" + "l" + "fffff" + "p",
     "mmdyn_sgd_step": "ppp" + "l" + "ffff" + "i" + "p",
+    "mmdyn_igemm_nt_mx": "pppppppppppp" + "iiiiiiiiiiiiii" + "i" + "p",
+    "mmdyn_wgrad_tn_mx": "ppp" + "iiiiiiiiiii" + "i" + "p",
+    "mmdyn_bn_swish_fwd_b16": "pppppp" + "iii" + "p",
+    "mmdyn_bn_swish_bwd_reduce_b16": "ppppppp" + "iii" + "p",
+    "mmdyn_bn_swish_bwd_apply_b16": "pppppppp" + "iiii" + "p",
+    "mmdyn_act_bwd_b16": "ppp" + "l" + "i" + "p",
+    "mmdyn_tconv_out3_fwd_b16": "ppp" + "iii" + "p",
     "mmdyn_resize_ksize": "ii",
     "mmdyn_resize_plan": "ii" + "pp",
     "mmdyn_resize_u8_to_chw_f32": "ppp" + "iiiii" + "pppp" + "p",

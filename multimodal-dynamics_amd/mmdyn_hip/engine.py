@@ -115,14 +115,16 @@ def _with_precision(fn):
 
     @functools.wraps(fn)
     def wrapped(self, *a, **k):
-        prev, prev_sync = getattr(ops.B, "precision", "fp32"), layers.SYNC
+        prev, prev_sync, prev_act = getattr(ops.B, "precision", "fp32"), layers.SYNC, layers.ACT_DTYPE
         ops.B.precision = self.precision
         layers.SYNC = self._sync
+        layers.ACT_DTYPE = torch.bfloat16 if self.precision == "bf16s" else torch.float32
         try:
             return fn(self, *a, **k)
         finally:
             ops.B.precision = prev
             layers.SYNC = prev_sync
+            layers.ACT_DTYPE = prev_act
     return wrapped
 
 
@@ -134,9 +136,10 @@ class MVAEStep:
         if getattr(model, "conditional", False):
             raise NotImplementedError("mmdyn_hip: the fused step is built for the unconditional cnn-mvae; run conditional "
                                       "models through the module API (Problem(..., fused=False))")
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' (the reference's arithmetic) or 'bf16' (bf16 matrix-core "
-                             "operands, fp32 accumulate and storage: BASELINE configs[2])")
+        if precision not in ("fp32", "bf16", "bf16s"):
+            raise ValueError("precision must be 'fp32' (the reference's arithmetic), 'bf16s' (bf16 activation storage + "
+                             "bf16 matrix cores, fp32 accumulate / master weights: BASELINE configs[2]) or 'bf16' (bf16 matrix-core "
+                             "operands only, fp32 storage)")
         self.precision = precision
         # False (default): each image decoder runs only on the passes whose reconstruction enters the loss, so its
         # BatchNorm running buffers see 4 EMA updates per step (2 without pose) where the reference applies 7 (3).

@@ -25,6 +25,17 @@ def _new(like, *shape, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
 
+# Storage type of the activations BETWEEN the convolution layers (pre-BatchNorm outputs, post-Swish activations and
+# their gradients).  torch.float32 everywhere except in the bf16-storage mode of the engine (precision="bf16s",
+# BASELINE configs[2]), which sets torch.bfloat16 for the duration of its calls.  FC-level tensors, logits, statistics
+# and weights are always fp32.
+ACT_DTYPE = torch.float32
+
+
+def _act(like, *shape):
+    return torch.empty(shape, device=like.device, dtype=ACT_DTYPE)
+
+
 def _cdiv(a, b):
     return (a + b - 1) // b
 
@@ -32,16 +43,16 @@ def _cdiv(a, b):
 # ------------------------------------------------------------------------------------------------
 # primitive helpers
 # ------------------------------------------------------------------------------------------------
-def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False):
+def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch.float32):
     """C = A[rows][K] . Bp[N][K]^T (+bias) on the MFMA GEMM; picks split-K for short, wide-K problems.
     Returns (pre_activation, activated or None)."""
-    C = _new(A, rows, N)
-    Ca = _new(A, rows, N) if want_act else None
+    C = _new(A, rows, N, dtype=out_dtype)
+    Ca = _new(A, rows, N, dtype=out_dtype) if want_act else None
     # split-K only when the 64x64 tiling leaves most of the 256 CUs idle AND K is long enough to amortise the
     # partial-sum pass (measured: tests/microbench/sweep_dense.py)
     tiles = _cdiv(rows, 64) * _cdiv(N, 64)
     steps = K // 32
-    splitk = max(1, min(512 // tiles, steps // 8)) if N % 64 == 0 else 1
+    splitk = max(1, min(512 // tiles, steps // 8)) if (N % 64 == 0 and out_dtype == torch.float32) else 1
     if splitk > 1:
         ws = _new(A, splitk, rows, N)
         ops.B.igemm_nt(A, Bp, None, C, None, None, ws, DENSE, 1, rows, 1, 1, K, 1, 1, N, N, 1, 0, ACT_NONE, splitk)
@@ -51,10 +62,10 @@ def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False):
     return C, Ca
 
 
-def conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride=1, offset=0, stats=False):
+def conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride=1, offset=0, stats=False, out_dtype=None):
     """Implicit-GEMM conv / transposed conv on NHWC rows; optional per-tile BatchNorm partial sums."""
     Bt = G * Bg
-    y = _new(x, Bt * Ho * Ho, N)
+    y = _new(x, Bt * Ho * Ho, N, dtype=ACT_DTYPE if out_dtype is None else out_dtype)
     st, T = None, 0
     if stats:
         T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
@@ -69,7 +80,7 @@ def tconv_s1p0(x, Wsp, G, Bg, Cin, N, stats=False):
     Large batches: the tap-skipping implicit GEMM (exactly the useful MACs, balanced pixel quads).  Small ones
     (too few blocks to fill 256 CUs): dense GEMM to a [rows][16*N] column matrix + col2im gather."""
     Bt = G * Bg
-    if G * 16 * _cdiv(Bg, 64) * (N // 64) >= 512:
+    if G * 16 * _cdiv(Bg, 64) * (N // 64) >= 512 or ACT_DTYPE != torch.float32:      # (bf16 storage: no column matrix)
         return conv_like(x, Wsp, TCONV_S1P0, G, Bg, 5, Cin, 8, N, stats=stats)
     col, _ = dense(x, Wsp, None, Bt * 25, Cin, 16 * N)
     y = _new(x, Bt * 64, N)
@@ -441,7 +452,7 @@ def encoder_trunk_forward_steps(P, buf, x, G=1, repeat=1, packed=None, training=
     pk = packed if packed is not None else pack_now(encoder_pack_specs(P))
     c = {"Bt": Bt, "G": G, "Bg": Bg, "pk": pk}
     W1p = pk["W1p"]                                                          # [32][64], cols 48.. zero
-    u1, a1 = _new(x, Bt * 1024, 32), _new(x, Bt * 1024, 32)
+    u1, a1 = _act(x, Bt * 1024, 32), _act(x, Bt * 1024, 32)
     # first layer: the k4 s2 p1 window of the NCHW image is gathered on the fly (no im2col matrix in HBM)
     ops.B.igemm_nt(x, W1p, None, u1, a1, None, None, IM2COL3, 1, Bt, 64, 64, 64, 32, 32, 32, 32, 1, 0,
                    ACT_SWISH, 1)
@@ -473,7 +484,7 @@ def encoder_trunk_backward_steps(P, c, dh, grads):
     du5 = act_backward(dh, c["u5"], ACT_SWISH)
     wgrad(du5, c["a4"], grads["fc_net.0.weight"], DENSE, Bt, 1, 512, 1, FEAT, perm=1)
     ops.B.colsum(du5, grads["fc_net.0.bias"], Bt, 512, 0, 0.0)
-    da4, _ = dense(du5, pk["WfT"], None, Bt, 512, FEAT)                      # WfT: [hw*256+c][512]
+    da4, _ = dense(du5, pk["WfT"], None, Bt, 512, FEAT, out_dtype=ACT_DTYPE)  # WfT: [hw*256+c][512]
     yield
     dy4 = bn_swish_backward(da4, c["y4"], c["m4"], c["r4"], bn4, grads["conv_net.9.weight"],
                             grads["conv_net.9.bias"], G, Bg * 25, 256)
@@ -562,7 +573,7 @@ def decoder_backward_steps(P, c, dlogits, grads, need_dz=True):
                                   grads["hallucinate.1.weight"], grads["hallucinate.1.bias"])
     yield
     wgrad(c["h0"], dy1, grads["hallucinate.0.weight"], CONV, Bt, 5, 256, 8, 128, 1, 0)
-    dh0, _, _ = conv_like(dy1, pk["W1k"], CONV, 1, Bt, 8, 128, 5, 256, 1, 0)
+    dh0, _, _ = conv_like(dy1, pk["W1k"], CONV, 1, Bt, 8, 128, 5, 256, 1, 0, out_dtype=torch.float32)   # FC level
     yield
     du0 = act_backward(dh0, c["u0"], ACT_SWISH)
     wgrad(du0, c["z"], grads["upsample.0.weight"], DENSE, Bt, 1, FEAT, 1, L, cg_canon=c["Lc"], perm=2)

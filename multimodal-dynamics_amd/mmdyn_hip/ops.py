@@ -31,6 +31,15 @@ def _ptr(t, dtype=torch.float32):
     return t.data_ptr()
 
 
+def _aptr(t):
+    """Pointer of an ACTIVATION tensor: fp32, or bf16 in the bf16-storage mode.  Returns (pointer, is_bf16)."""
+    if t is None:
+        return None, False
+    if t.dtype == torch.bfloat16:
+        return _ptr(t, torch.bfloat16), True
+    return _ptr(t), False
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -66,15 +75,34 @@ class HipBackend:
     # ---- GEMMs ----
     def igemm_nt(self, A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride,
                  offset, act, splitk):
-        fn = self.lib.mmdyn_igemm_nt_bf16 if self.precision == "bf16" else self.lib.mmdyn_igemm_nt
-        check(fn(_ptr(A), _ptr(Bp), _ptr(bias), _ptr(C), _ptr(C_act), _ptr(stats), _ptr(ws),
+        (pa, a16), (pc, c16), (pca, ca16) = _aptr(A), _aptr(C), _aptr(C_act)
+        if a16 or c16 or ca16:                       # bf16 activation storage: the mixed-storage entry point
+            if self.precision == "fp32" or (c16 and splitk != 1) or (C_act is not None and ca16 != c16):
+                raise ValueError("mmdyn_hip: bf16 activation tensors need a bf16 precision mode, no split-K into a "
+                                 "bf16 output, and C / C_act of one type")
+            check(self.lib.mmdyn_igemm_nt_mx(pa, _ptr(Bp), _ptr(bias), pc, pca, _ptr(stats), _ptr(ws), None, None, None,
+                                             None, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act,
+                                             splitk, 1 | (2 if a16 else 0) | (4 if c16 else 0), _stream()),
+                  "mmdyn_igemm_nt_mx")
+            return
+        fn = self.lib.mmdyn_igemm_nt_bf16 if self.precision != "fp32" else self.lib.mmdyn_igemm_nt
+        check(fn(pa, _ptr(Bp), _ptr(bias), pc, pca, _ptr(stats), _ptr(ws),
                  mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, _stream()), "mmdyn_igemm_nt")
 
     def igemm_nt_dgrad_bn(self, A, Bp, C, stats, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N,
                           stride, offset):
-        check(self.lib.mmdyn_igemm_nt_dgrad_bn(_ptr(A), _ptr(Bp), _ptr(C), _ptr(stats), _ptr(y), _ptr(mean), _ptr(rstd),
+        (pa, a16), (pc, c16), (py, y16) = _aptr(A), _aptr(C), _aptr(y)
+        if a16 or c16 or y16:
+            if self.precision == "fp32":
+                raise ValueError("mmdyn_hip: bf16 activation tensors need a bf16 precision mode")
+            check(self.lib.mmdyn_igemm_nt_mx(pa, _ptr(Bp), None, pc, None, _ptr(stats), None, py, _ptr(mean), _ptr(rstd),
+                                             _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride,
+                                             offset, ACT_NONE, 1, 1 | (2 if a16 else 0) | (4 if c16 else 0) |
+                                             (8 if y16 else 0), _stream()), "mmdyn_igemm_nt_mx")
+            return
+        check(self.lib.mmdyn_igemm_nt_dgrad_bn(pa, _ptr(Bp), pc, _ptr(stats), py, _ptr(mean), _ptr(rstd),
                                                _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride,
-                                               offset, int(self.precision == "bf16"), _stream()),
+                                               offset, int(self.precision != "fp32"), _stream()),
               "mmdyn_igemm_nt_dgrad_bn")
 
     def splitk_reduce(self, ws, bias, C, C_act, splitk, rows, N, act):
@@ -82,8 +110,15 @@ class HipBackend:
                                            _stream()), "mmdyn_splitk_reduce")
 
     def wgrad_tn(self, D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks):
-        fn = self.lib.mmdyn_wgrad_tn_bf16 if self.precision == "bf16" else self.lib.mmdyn_wgrad_tn
-        check(fn(_ptr(D), _ptr(Gt), _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks,
+        (pd, d16), (pg, g16) = _aptr(D), _aptr(Gt)
+        if d16 or g16:
+            if self.precision == "fp32":
+                raise ValueError("mmdyn_hip: bf16 activation tensors need a bf16 precision mode")
+            check(self.lib.mmdyn_wgrad_tn_mx(pd, pg, _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks,
+                                             1 | (2 if d16 else 0) | (4 if g16 else 0), _stream()), "mmdyn_wgrad_tn_mx")
+            return
+        fn = self.lib.mmdyn_wgrad_tn_bf16 if self.precision != "fp32" else self.lib.mmdyn_wgrad_tn
+        check(fn(pd, pg, _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks,
                  _stream()), "mmdyn_wgrad_tn")
 
     def wgrad_reduce(self, partial, canon, chunks, taps, Cd, Cg, cg_canon, perm, beta):
@@ -116,7 +151,9 @@ class HipBackend:
                                        int(tap_major), _stream()), "mmdyn_col2im_k4")
 
     def tconv_out3_fwd(self, a, w, out, Bt, Hi, Wi):
-        check(self.lib.mmdyn_tconv_out3_fwd(_ptr(a), _ptr(w), _ptr(out), Bt, Hi, Wi, _stream()), "mmdyn_tconv_out3_fwd")
+        pa, a16 = _aptr(a)
+        fn = self.lib.mmdyn_tconv_out3_fwd_b16 if a16 else self.lib.mmdyn_tconv_out3_fwd
+        check(fn(pa, _ptr(w), _ptr(out), Bt, Hi, Wi, _stream()), "mmdyn_tconv_out3_fwd")
 
     def nchw_to_nhwc(self, src, dst, B, C, HW):
         check(self.lib.mmdyn_nchw_to_nhwc(_ptr(src), _ptr(dst), B, C, HW, _stream()), "mmdyn_nchw_to_nhwc")
@@ -136,12 +173,19 @@ class HipBackend:
               "mmdyn_bn_finalize")
 
     def bn_swish_fwd(self, y, mean, rstd, gamma, beta, a, G, rows_per_group, C):
-        check(self.lib.mmdyn_bn_swish_fwd(_ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(a), G,
-                                          rows_per_group, C, _stream()), "mmdyn_bn_swish_fwd")
+        (py, y16), (pa, a16) = _aptr(y), _aptr(a)
+        if y16 != a16:
+            raise TypeError("mmdyn_hip: bn_swish_fwd input and output must share the storage type")
+        fn = self.lib.mmdyn_bn_swish_fwd_b16 if y16 else self.lib.mmdyn_bn_swish_fwd
+        check(fn(py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), pa, G, rows_per_group, C, _stream()),
+              "mmdyn_bn_swish_fwd")
 
     def bn_swish_bwd_reduce(self, da, y, mean, rstd, gamma, beta, partial, G, rows_per_group, C):
-        check(self.lib.mmdyn_bn_swish_bwd_reduce(_ptr(da), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma),
-                                                 _ptr(beta), _ptr(partial), G, rows_per_group, C, _stream()),
+        (pd, d16), (py, y16) = _aptr(da), _aptr(y)
+        if d16 != y16:
+            raise TypeError("mmdyn_hip: bn_swish_bwd_reduce operands must share the storage type")
+        fn = self.lib.mmdyn_bn_swish_bwd_reduce_b16 if y16 else self.lib.mmdyn_bn_swish_bwd_reduce
+        check(fn(pd, py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(partial), G, rows_per_group, C, _stream()),
               "mmdyn_bn_swish_bwd_reduce")
 
     def bn_bwd_finalize(self, partial, sums, dgamma, dbeta, scratch, G, T, C, beta_acc):
@@ -169,16 +213,23 @@ class HipBackend:
               "mmdyn_bn_bwd_finalize_sums")
 
     def bn_swish_bwd_apply(self, da, y, mean, rstd, gamma, beta, sums, dy, G, rows_per_group, C, da_is_du=False):
-        check(self.lib.mmdyn_bn_swish_bwd_apply(_ptr(da), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
-                                                _ptr(sums), _ptr(dy), G, rows_per_group, C, int(da_is_du), _stream()),
-              "mmdyn_bn_swish_bwd_apply")
+        (pd, d16), (py, y16), (po, o16) = _aptr(da), _aptr(y), _aptr(dy)
+        if not (d16 == y16 == o16):
+            raise TypeError("mmdyn_hip: bn_swish_bwd_apply tensors must share the storage type")
+        fn = self.lib.mmdyn_bn_swish_bwd_apply_b16 if y16 else self.lib.mmdyn_bn_swish_bwd_apply
+        check(fn(pd, py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums), po, G, rows_per_group, C,
+                 int(da_is_du), _stream()), "mmdyn_bn_swish_bwd_apply")
 
     # ---- element-wise ----
     def act_fwd(self, u, h, act):
         check(self.lib.mmdyn_act_fwd(_ptr(u), _ptr(h), u.numel(), act, _stream()), "mmdyn_act_fwd")
 
     def act_bwd(self, dh, u, du, act):
-        check(self.lib.mmdyn_act_bwd(_ptr(dh), _ptr(u), _ptr(du), u.numel(), act, _stream()), "mmdyn_act_bwd")
+        (pd, d16), (pu, u16), (po, o16) = _aptr(dh), _aptr(u), _aptr(du)
+        if not (d16 == u16 == o16):
+            raise TypeError("mmdyn_hip: act_bwd tensors must share the storage type")
+        fn = self.lib.mmdyn_act_bwd_b16 if u16 else self.lib.mmdyn_act_bwd
+        check(fn(pd, pu, po, u.numel(), act, _stream()), "mmdyn_act_bwd")
 
     def dropout_expand(self, h, masks, out, P, B, H, p_drop):
         check(self.lib.mmdyn_dropout_expand(_ptr(h), _ptr(masks, torch.uint8), _ptr(out), P, B, H, p_drop,

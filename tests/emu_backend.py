@@ -38,9 +38,28 @@ def _act_grad(u, act):
 class EmuBackend:
     name = "emu"
 
+    # ops that may see bf16 ACTIVATION tensors (bf16-storage mode): the emulation computes in fp32 on widened copies
+    # and rounds what it wrote back into the bf16 tensors (RNE), which is the kernels' contract
+    BF16_OPS = ("igemm_nt", "igemm_nt_dgrad_bn", "wgrad_tn", "bn_swish_fwd", "bn_swish_bwd_reduce", "bn_swish_bwd_apply",
+                "act_bwd", "tconv_out3_fwd")
+
     def __init__(self):
         self.lib = _lib.load()   # host-only helpers (tile counts) come from the real library
         self.calls = []
+        self.precision = "fp32"
+        for name in self.BF16_OPS:
+            setattr(self, name, self._with_bf16(getattr(self, name)))
+
+    @staticmethod
+    def _with_bf16(fn):
+        def wrapped(*args):
+            conv = [a.float() if torch.is_tensor(a) and a.dtype == torch.bfloat16 else a for a in args]
+            r = fn(*conv)
+            for o, c in zip(args, conv):
+                if torch.is_tensor(o) and o.dtype == torch.bfloat16:
+                    o.copy_(c)
+            return r
+        return wrapped
 
     # host helpers
     def igemm_stat_tiles(self, *a):
@@ -76,7 +95,7 @@ class EmuBackend:
         assert Cin % 32 == 0 and N % 32 == 0 and ldc == N
         Bt = G * Bg
         Bp = Bp.reshape(-1, N, Cin)
-        if getattr(self, "precision", "fp32") == "bf16":       # operands rounded to bf16 (RNE), fp32 accumulate
+        if getattr(self, "precision", "fp32") != "fp32":       # operands rounded to bf16 (RNE), fp32 accumulate
             A, Bp = A.to(torch.bfloat16).to(torch.float32), Bp.to(torch.bfloat16).to(torch.float32)
         if mode == IM2COL3:
             assert Cin == 64
@@ -138,7 +157,7 @@ class EmuBackend:
     def wgrad_tn(self, D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks):
         assert chunks % 4 == 0 and Cd % 32 == 0 and Cg % 32 == 0
         rows = Bt * Hr * Wr
-        if getattr(self, "precision", "fp32") == "bf16":
+        if getattr(self, "precision", "fp32") != "fp32":
             D, Gt = D.to(torch.bfloat16).to(torch.float32), Gt.to(torch.bfloat16).to(torch.float32)
         Dm = D.reshape(-1)[: rows * Cd].reshape(rows, Cd)
         partial.zero_()

@@ -174,6 +174,68 @@ def test_wgrad_bf16(case, bf16_mode):
     test_wgrad(case)
 
 
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("case", [IGEMM_CASES[1], IGEMM_CASES[4], IGEMM_CASES[6], IGEMM_CASES[9], IGEMM_CASES[13]])
+def test_igemm_bf16_storage(case, bf16_mode):
+    """bf16 activation storage: A and / or C (+ the activated copy, + the BatchNorm-backward operand) are bf16 in HBM.
+    The emulation widens, computes in fp32 and rounds the outputs, so agreement is to one bf16 ulp of the outputs
+    (a value on a rounding boundary may fall either way after fp32 summation-order differences)."""
+    mode, G, Bg, Hi, Cin, Ho, N, stride, offset = case
+    Bt = G * Bg
+    taps = 16 if mode != DENSE else 1
+    A = bf(rnd(Bt * Hi * Hi, Cin, seed=41))
+    Bp = rnd(taps, N, Cin, seed=42, scale=0.2)
+    bias = rnd(N, seed=43)
+    rows = Bt * Ho * Ho
+    T = HIP.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
+    post = lambda i, t: (t.sum(1) if t.dim() == 4 else t.float())
+    for c_dtype in (torch.bfloat16, torch.float32):
+        C, Ca, stats = torch.zeros(rows, N, dtype=c_dtype), torch.zeros(rows, N, dtype=c_dtype), torch.zeros(G, T, 2, N)
+        both("igemm_nt", [A, Bp, None, C, None, stats, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1],
+             [3, 5], post, tol=4e-3 if c_dtype == torch.bfloat16 else 2e-5)
+        both("igemm_nt", [A, Bp, bias, C, Ca, None, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 1, 1],
+             [3, 4], post, tol=4e-3 if c_dtype == torch.bfloat16 else 2e-5)
+    y = bf(rnd(rows, N, seed=44) * 1.5 + 0.2)
+    mean, rstd = rnd(G, N, seed=45) * 0.3, rnd(G, N, seed=46).abs() + 0.5
+    gamma, beta = rnd(N, seed=47) + 1.2, rnd(N, seed=48)
+    C, stats = torch.zeros(rows, N, dtype=torch.bfloat16), torch.zeros(G, T, 2, N)
+    both("igemm_nt_dgrad_bn", [A, Bp, C, stats, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride,
+                               offset], [2, 3], post, tol=4e-3)
+
+
+def test_elementwise_bf16_storage(bf16_mode):
+    G, rpg, C = 3, 1000, 64
+    y, da = bf(rnd(G * rpg, C, seed=51) * 2 + 0.3), bf(rnd(G * rpg, C, seed=52))
+    mean, rstd = rnd(G, C, seed=53) * 0.2, rnd(G, C, seed=54).abs() + 0.6
+    gamma, beta = rnd(C, seed=55) + 1.5, rnd(C, seed=56)
+    f32 = lambda i, t: t.float()
+    both("bn_swish_fwd", [y, mean, rstd, gamma, beta, torch.zeros(G * rpg, C, dtype=torch.bfloat16), G, rpg, C], [5], f32,
+         tol=4e-3)
+    T = HIP.colstats_tiles(rpg)
+    ga, ca = both("bn_swish_bwd_reduce", [da, y, mean, rstd, gamma, beta, torch.zeros(G, T, 2, C), G, rpg, C], [6],
+                  lambda i, t: t.sum(1), tol=1e-4)
+    sums = ca[6].sum(1)
+    both("bn_swish_bwd_apply", [da, y, mean, rstd, gamma, beta, sums, torch.zeros(G * rpg, C, dtype=torch.bfloat16), G, rpg,
+                                C, False], [7], f32, tol=4e-3)
+    both("act_bwd", [da, y, torch.zeros(G * rpg, C, dtype=torch.bfloat16), 1], [2], f32, tol=4e-3)
+    a = bf(rnd(2 * 32 * 32, 32, seed=57))
+    both("tconv_out3_fwd", [a, rnd(32, 3, 4, 4, seed=58, scale=0.2), torch.zeros(2, 3, 64, 64), 2, 32, 32], [2], tol=2e-5)
+    # wgrad with bf16 operands (dense, conv and the im2col mode with a bf16 dense operand)
+    for mode, Bt, Hr, Cd, Hi, Cg, stride, offset in ((DENSE, 300, 1, 512, 1, 512, 1, 0), (CONV, 3, 8, 128, 16, 64, 2, -1)):
+        rows, taps = Bt * Hr * Hr, 16 if mode == CONV else 1
+        D, Gt = bf(rnd(rows, Cd, seed=59)), bf(rnd(Bt * Hi * Hi, Cg, seed=60))
+        chunks = HIP.wgrad_chunks(mode, rows, Cd, Cg)
+        both("wgrad_tn", [D, Gt, torch.zeros(chunks, taps, Cd, Cg), mode, Bt, Hr, Hr, Cd, Hi, Hi, Cg, stride, offset, chunks],
+             [2], lambda i, t: t.sum(0), tol=5e-5)
+    D, x = bf(rnd(2 * 1024, 32, seed=61)), rnd(2 * 3 * 64 * 64, seed=62)
+    chunks = HIP.wgrad_chunks(IM2COL3, 2 * 1024, 32, 64)
+    both("wgrad_tn", [D, x, torch.zeros(chunks, 1, 32, 64), IM2COL3, 2, 32, 32, 32, 64, 64, 64, 1, 0, chunks], [2],
+         lambda i, t: t.sum(0), tol=5e-5)
+
+
 def test_bf16_differs_from_fp32_by_bf16_rounding_only():
     """Sanity on the size of the effect: relative error of the bf16 product vs the fp32 one is ~2^-9 per operand."""
     A, Bp = rnd(512, 256, seed=21), rnd(128, 256, seed=22, scale=0.2)

@@ -327,15 +327,23 @@ def test_bf16_precision_plumbing():
     inputs, targets = seeded_batch(B, 5)
     eps, masks = seeded_noise(B, 256, 7, 8, 6)
     losses = {}
-    for prec in ("fp32", "bf16"):
+    from mmdyn_hip import layers
+    grads = {}
+    for prec in ("fp32", "bf16", "bf16s"):
         m = build("cnn-mvae", True, True, "cpu")
         step = MVAEStep(m, noise=InjectedNoise(eps, masks), precision=prec)
         losses[prec] = float(step.forward(inputs, targets, klw))
+        if prec == "bf16s":                      # conv-level activations are stored in bf16, FC level / logits in fp32
+            assert step.ctx["ev"]["a2"].dtype == torch.bfloat16 and step.ctx["dv"]["y3"].dtype == torch.bfloat16
+            assert step.ctx["lgv"].dtype == torch.float32 and step.ctx["ov"].dtype == torch.float32
         step.backward()
-        assert ops.B.precision == "fp32"
+        assert ops.B.precision == "fp32" and layers.ACT_DTYPE == torch.float32
         assert torch.isfinite(step.params.grad).all()
-    r = abs(losses["bf16"] - losses["fp32"]) / abs(losses["fp32"])
-    assert 1e-8 < r < 5e-3, r
+        grads[prec] = step.params.grad.clone()
+    for prec in ("bf16", "bf16s"):
+        r = abs(losses[prec] - losses["fp32"]) / abs(losses["fp32"])
+        assert 1e-8 < r < 5e-3, (prec, r)
+        assert float((grads[prec] - grads["fp32"]).norm() / grads["fp32"].norm()) < 0.1
     with pytest.raises(ValueError):
         MVAEStep(build("cnn-mvae", True, True, "cpu"), precision="fp16")
 

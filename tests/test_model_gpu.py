@@ -158,6 +158,35 @@ def test_sync_bn_single_rank_equals_local(tmp_path):
         dist.destroy_process_group()
 
 
+def test_bf16_storage_engine_vs_oracle():
+    """precision="bf16s" (BASELINE configs[2]: bf16 activation storage + bf16 matrix cores, fp32 accumulate / master
+    weights) against the fp32 CPU oracle, B=32.  Stated tolerance: ELBO and partials within 1e-2 relative, gradients
+    within 2e-1 relative L2 per tensor (measured values are printed)."""
+    B, klw = 32, 1.0 / 50
+    sd = seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True), 0)
+    prm, buf = O.split_state(sd)
+    inputs, targets = seeded_batch(B, 1234)
+    eps, masks = seeded_noise(B, 256, 7 * 4, 8 * 4, 4321)
+    m = T.build("cnn-mvae", True, True, DEV)
+    step = MVAEStep(m, noise=InjectedNoise(eps, masks), precision="bf16s")
+    _, loss_o, partials_o = O.evaluate_mvae(prm, inputs, targets, eps[:7], masks[:8], klw, 1000.0, True, buf)
+    loss_o.backward()
+    loss = step.forward([x.to(DEV) for x in inputs], [x.to(DEV) for x in targets], klw)
+    assert step.ctx["dv"]["y3"].dtype == torch.bfloat16
+    loss0 = float(loss)                     # (the engine's loss tensor is overwritten by later steps)
+    rel_loss = abs(loss0 - float(loss_o.detach())) / abs(float(loss_o.detach()))
+    np.testing.assert_allclose(step.partials[:7].cpu().numpy(), [float(x.detach()) for x in partials_o], rtol=1e-2)
+    step.backward()
+    named = dict(m.named_parameters())
+    errs = sorted(((float((named[k].grad.double().cpu() - prm[k].grad.double()).norm()
+                           / (prm[k].grad.double().norm() + 1e-30)), k) for k in prm), reverse=True)
+    print("bf16s loss rel err", rel_loss, "worst gradient rel-L2:", errs[:4], "median", errs[len(errs) // 2])
+    assert rel_loss < 1e-2 and errs[0][0] < 2e-1, (rel_loss, errs[:4])
+    for s in range(3):                      # and it trains: a few Adam steps on the fixed batch lower the loss
+        l = step.train_step([x.to(DEV) for x in inputs], [x.to(DEV) for x in targets], klw)
+    assert float(l) < loss0
+
+
 def test_full_size_properties_b256():
     """BASELINE batch (256): properties that need no CPU run of the same size --
     (i) the total equals the sum of the 7 partial ELBOs; (ii) replaying the same step from the same state and
