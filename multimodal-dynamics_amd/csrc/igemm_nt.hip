@@ -63,7 +63,7 @@ __device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {
   return r;
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, bool BF16>
+template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__ A,
                                                        const float* __restrict__ Bp,
                                                        const float* __restrict__ bias,
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       const int y = ry[i] + dh, x = rx[i] + dw;
       const bool ok = (rb[i] >= 0) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
       const int pix = ok ? (rb[i] * g.Hi + y) * g.Wi + x : 0;
-      if (BF16 && g.a_b16)
+      if constexpr (A16)          // compile-time: the fetch stays one branch-free basic block
         ra[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(A) + (size_t)pix * g.Cin + c0);
       else
         ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)pix * g.Cin + c0);
@@ -478,11 +478,14 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   const int mx8 = (g.G * g.tiles_per_group + 7) / 8 * 8;
   dim3 grid((unsigned)mx8 * (g.N / BN) * g.nclasses * g.splitk);
   size_t smem = (size_t)(BM + BN) * LDS_LD * sizeof(float) + (size_t)BM * 4 * sizeof(int);
-  if (bf16)
-    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true>), grid, dim3(256), smem, st, A, Bp, bias, C,
+  if (bf16 && g.a_b16 && MODE != MMDYN_IM2COL3)
+    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, MODE != MMDYN_IM2COL3>), grid, dim3(256), smem, st, A,
+                       Bp, bias, C, C_act, stats, ws, g);
+  else if (bf16)
+    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, false>), grid, dim3(256), smem, st, A, Bp, bias, C,
                        C_act, stats, ws, g);
   else
-    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, false>), grid, dim3(256), smem, st, A, Bp, bias, C,
+    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, false, false>), grid, dim3(256), smem, st, A, Bp, bias, C,
                        C_act, stats, ws, g);
   MMDYN_LAUNCH_CHECK();
 }

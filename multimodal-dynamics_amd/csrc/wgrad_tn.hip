@@ -43,7 +43,9 @@ __device__ __forceinline__ s16x4 pack4_bf16(float a, float b, float c, float d) 
   return __builtin_bit_cast(s16x4, r);
 }
 
-template <int BD, int BG, int WD, int WG, int WK, bool BF16>
+// ST: operand storage known at compile time (keeps the fetch one branch-free basic block): 1 = D and Gt bf16,
+// 2 = D bf16 / Gt fp32, 0 = read the run-time flags (fp32 operands and the rare mixed case)
+template <int BD, int BG, int WD, int WG, int WK, bool BF16, int ST>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__ D,
                                                        const float* __restrict__ Gt,
                                                        float* __restrict__ partial, const WgradGeom g) {
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
       const int r = idx / DV, v = idx - r * DV;
       const int row = r0 + r;
       const bool ok = row < row_end;
-      if (BF16 && g.d_b16)
+      if (BF16 && (ST != 0 || g.d_b16))
         rd[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       else
         rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
         ok = ok & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
         pix = (bb * g.Hi + y) * g.Wi + x;
       }
-      if (BF16 && g.g_b16)
+      if (BF16 && (ST == 1 || (ST == 0 && g.g_b16)))
         rg[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       else
         rg[i] = *reinterpret_cast<const f32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
 // the four kw taps of one kernel row kh and share ONE dense-operand tile, so D is fetched once per 4 taps instead
 // of once per tap (half the L2 traffic of the one-tap kernel on these shapes) and no wave has to split the row
 // reduction (WK = 1: a quarter / half of the partial slabs).  grid.y = kh.
-template <int BD, int BG, bool BF16>
+template <int BD, int BG, bool BF16, int ST>
 __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict__ D, const float* __restrict__ Gt,
                                                         float* __restrict__ partial, const WgradGeom g) {
   constexpr int DT = BD / 32, GT = BG / 32;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       const int r = idx / DV, v = idx - r * DV;
       const int row = r0 + r;
       const bool ok = (idx < RK * DV) & (row < row_end);
-      if (BF16 && g.d_b16)
+      if (BF16 && (ST != 0 || g.d_b16))
         rd[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       else
         rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       const int y = rr * g.rs + g.ro + kh, x = cc * g.rs + g.ro + kw;
       const bool ok = (row < row_end) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
       const int pix = (bb * g.Hi + y) * g.Wi + x;
-      if (BF16 && g.g_b16)
+      if (BF16 && (ST == 1 || (ST == 0 && g.g_b16)))
         rg[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       else
         rg[i] = *reinterpret_cast<const f32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
@@ -376,10 +378,12 @@ static int launch4(const float* D, const float* Gt, float* partial, WgradGeom g,
   g.rows_per_chunk = ceil_div(rpc, RK) * RK;
   dim3 grid((g.Cd / BD) * (g.Cg / BG), 4, g.chunks);
   size_t smem = (size_t)RK * (BD + 4 * BG) * sizeof(float);
-  if (bf16)
-    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  if (bf16 && g.d_b16 && g.g_b16)
+    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 1>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  else if (bf16)
+    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 0>), grid, dim3(256), smem, st, D, Gt, partial, g);
   else
-    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, false>), grid, dim3(256), smem, st, D, Gt, partial, g);
+    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, false, 0>), grid, dim3(256), smem, st, D, Gt, partial, g);
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -472,10 +476,14 @@ static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, 
   g.rows_per_chunk = ceil_div(rpc, RK) * RK;
   dim3 grid((g.Cd / BD) * (g.Cg / BG), g.ntaps, zblocks);
   size_t smem = (size_t)RK * (BD + BG) * sizeof(float);
-  if (bf16)
-    hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  if (bf16 && g.d_b16 && g.g_b16)
+    hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK, true, 1>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  else if (bf16 && g.d_b16 && !g.g_b16)
+    hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK, true, 2>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  else if (bf16)
+    hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK, true, 0>), grid, dim3(256), smem, st, D, Gt, partial, g);
   else
-    hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK, false>), grid, dim3(256), smem, st, D, Gt, partial, g);
+    hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK, false, 0>), grid, dim3(256), smem, st, D, Gt, partial, g);
   MMDYN_LAUNCH_CHECK();
 }
 
