@@ -168,7 +168,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   // a select, so one K-step is a single basic block and the scheduler can slot the address arithmetic and the
   // global loads between the 64-cycle MFMAs instead of in front of them.
   f32x4 ra[A_LOADS], rbv[B_LOADS];
+  uint2 ra16[A_LOADS];          // A16: the raw bf16 granule (widening it here would wait for the load before the MFMAs)
   unsigned okmask = 0;
+  // bf16 matrix-core variants keep the tiles in LDS as bf16 ([row][40] halves: 32 + one 16-byte pad slot): half the
+  // LDS bytes, one ds_read_b128 per operand and 16-deep MFMA, conversion once per element on the store side
+  constexpr int LDH = BK + 8;
+  bf16_t* As16 = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Bs16 = As16 + BM * LDH;
   int tap = s_begin / cin_steps;            // running (tap, channel-step) position of the NEXT fetch
   int cstep = s_begin - tap * cin_steps;
   auto gload = [&]() {
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       const bool ok = (rb[i] >= 0) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
       const int pix = ok ? (rb[i] * g.Hi + y) * g.Wi + x : 0;
       if constexpr (A16)          // compile-time: the fetch stays one branch-free basic block
-        ra[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(A) + (size_t)pix * g.Cin + c0);
+        ra16[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(A) + (size_t)pix * g.Cin + c0);
       else
         ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)pix * g.Cin + c0);
       okmask = ok ? (okmask | (0xFu << (4 * i))) : (okmask & ~(0xFu << (4 * i)));   // consumed at lds_store
@@ -236,6 +242,29 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
     tap = last ? tap : ntap;
   };
   auto lds_store = [&]() {
+    if constexpr (BF16) {
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        const unsigned m = okmask >> (4 * i);
+        uint2 v;
+        if constexpr (A16) {
+          v.x = (m & 1u) ? ra16[i].x : 0u;           // (all four mask bits are equal outside IM2COL3)
+          v.y = (m & 1u) ? ra16[i].y : 0u;
+        } else {
+          v.x = pack2_bf16((m & 1u) ? ra[i][0] : 0.f, (m & 2u) ? ra[i][1] : 0.f);
+          v.y = pack2_bf16((m & 4u) ? ra[i][2] : 0.f, (m & 8u) ? ra[i][3] : 0.f);
+        }
+        *reinterpret_cast<uint2*>(&As16[(lrow + ROWS_PER_PASS * i) * LDH + gran * 4]) = v;
+      }
+#pragma unroll
+      for (int j = 0; j < B_LOADS; ++j) {
+        uint2 v;
+        v.x = pack2_bf16(rbv[j][0], rbv[j][1]);
+        v.y = pack2_bf16(rbv[j][2], rbv[j][3]);
+        *reinterpret_cast<uint2*>(&Bs16[(lrow + ROWS_PER_PASS * j) * LDH + gran * 4]) = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const unsigned m = okmask >> (4 * i);
@@ -270,19 +299,16 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       const float* Ac = As;
       const float* Bc = Bs;
       if constexpr (BF16) {
+        const int frag16 = (lane & 31) * LDH + (lane >> 5) * 8;      // lane (row i, half h): k = 16m + 8h .. +7
 #pragma unroll
-        for (int q = 0; q < BK / 8; q += 2) {     // one 16-deep bf16 MFMA = the k-slices of two fp32 fragment reads
+        for (int m = 0; m < BK / 16; ++m) {
           bf16x8 pa[MT], pb[NT];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const float* p = &Ac[(wm * WM + mt * 32) * LDS_LD + frag_off + q * 8];
-            pa[mt] = pack_bf16(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 8));
-          }
+          for (int mt = 0; mt < MT; ++mt)
+            pa[mt] = *reinterpret_cast<const bf16x8*>(&As16[(wm * WM + mt * 32) * LDH + frag16 + m * 16]);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const float* p = &Bc[(wn * WN + nt * 32) * LDS_LD + frag_off + q * 8];
-            pb[nt] = pack_bf16(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 8));
-          }
+          for (int nt = 0; nt < NT; ++nt)
+            pb[nt] = *reinterpret_cast<const bf16x8*>(&Bs16[(wn * WN + nt * 32) * LDH + frag16 + m * 16]);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
