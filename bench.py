@@ -161,7 +161,8 @@ def main():
         v, t, p = [z.to(dev) for z in inputs]
         from mmdyn_hip.engine import MVAEInference
         model.eval()
-        eng = MVAEInference(model, precision="bf16" if args.dtype == "bf16" else "fp32", use_graph=not args.no_graph,
+        eng = MVAEInference(model, precision={"f32": "fp32", "bf16": "bf16", "bf16s": "bf16s"}[args.dtype],
+                            use_graph=not args.no_graph,
                             seed=1234 + rank)
         for _ in range(args.warmup):
             eng([v, t], pose=p)

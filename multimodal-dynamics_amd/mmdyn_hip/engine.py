@@ -601,8 +601,8 @@ class MVAEInference:
         from .models.vae import NoiseSource
         if getattr(model, "conditional", False):
             raise NotImplementedError("mmdyn_hip: MVAEInference is built for the unconditional cnn-mvae")
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in ("fp32", "bf16", "bf16s"):
+            raise ValueError("precision must be 'fp32', 'bf16' (matrix-core operands) or 'bf16s' (+ bf16 activation storage)")
         self.model, self.precision, self.use_graph = model, precision, use_graph
         self.use_pose = bool(model._use_pose)
         self.L = model.latent_size
@@ -699,8 +699,9 @@ class MVAEInference:
 
     # ---- graph capture / replay ---------------------------------------------------------------------------
     def _run(self, key, fn, static_inputs, new_inputs):
-        prev = getattr(ops.B, "precision", "fp32")
+        prev, prev_act = getattr(ops.B, "precision", "fp32"), layers.ACT_DTYPE
         ops.B.precision = self.precision
+        layers.ACT_DTYPE = torch.bfloat16 if self.precision == "bf16s" else torch.float32
         try:
             if not (self.use_graph and self.dev.type == "cuda"):
                 return fn(*new_inputs)
@@ -724,6 +725,7 @@ class MVAEInference:
             return out
         finally:
             ops.B.precision = prev
+            layers.ACT_DTYPE = prev_act
 
     @torch.no_grad()
     def forward(self, x, pose=None):
