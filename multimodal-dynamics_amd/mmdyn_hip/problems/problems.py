@@ -198,7 +198,10 @@ class Problem:
         for batch_idx, (data_input, data_target) in enumerate(self.train_loader):
             inputs, targets = self.parse_input(data_input, data_target)
             if self._step is not None and self._fused_applicable(inputs):
-                loss = self._step.train_step(*self._fused_io(inputs, targets), self._kl_weight)
+                # on the GPU the step is replayed from HIP graphs (re-captured when the batch shape or the annealed
+                # KL weight changes, i.e. once per epoch); the emulation has no graphs
+                run = self._step.train_step_graphed if self._device.type == 'cuda' else self._step.train_step
+                loss = run(*self._fused_io(inputs, targets), self._kl_weight)
                 outputs = {'perf_measure': self._fused_perf()}
             else:
                 self._optimizer.zero_grad()
