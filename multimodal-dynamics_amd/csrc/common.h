@@ -109,6 +109,15 @@ __device__ __forceinline__ float act_grad(float x, int act) {
   return 1.f;
 }
 
+// conv3.hip: direct kernels for the 3-channel k4 s2 p1 layers (MMDYN_IM2COL3 geometry).  Return MMDYN_OK / an error
+// code, or 1 when the shape is not theirs (the caller then takes the generic tiled kernel).
+int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void* C, void* C_act, float* stats, int G,
+                       int Bg, int Hi, int Wi, int Ho, int Wo, int N, int ldc, int act, int splitk, const void* bn_y,
+                       const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
+                       int c_b16, int bny_b16, hipStream_t st);
+int mmdyn_conv3_wgrad_try(const void* D, const float* Gt, float* partial, int Bt, int Hr, int Wr, int Cd, int Hi,
+                          int Wi, int Cg, int chunks, int d_b16, hipStream_t st);
+
 // grid size for a grid-stride element-wise launch: enough blocks to fill 256 CUs x 8, no more
 static inline int ew_grid(int64_t work_items, int block = 256) {
   int64_t b = ceil_div64(work_items, block);

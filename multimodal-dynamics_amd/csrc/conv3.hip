@@ -1,0 +1,331 @@
+// Direct MFMA kernels for the two 3-channel layers of every image network: the encoder's first Conv2d(3, 32, k4 s2 p1)
+// and the decoder's last ConvTranspose2d(32, 3, k4 s2 p1) (/root/reference/mmdyn/pytorch/models/vae.py:198, 277).
+// Both reduce to the same geometry (MMDYN_IM2COL3): a GEMM row is an output pixel of the 32-channel side, its 48
+// "K" entries are the k4 s2 p1 window of the NCHW 3-channel image, k = ci*16 + kh*4 + kw.
+//
+// These GEMMs are skinny (N = 32, K = 48, a million rows at G*Bg = 1024): 1.5 kFLOP per row against 256 B of
+// activations, i.e. bound by HBM, not by the matrix cores.  The generic tiled kernels spend their time in the
+// per-tile prologue (two K-steps only) and in 4-byte window gathers through LDS.  Here instead
+//   * conv3_nt (forward of conv1 / input gradient of the last tconv): a wave owns one output image row (32 pixels
+//     = the 32 rows of one 32x32 MFMA tile) and reads its A fragments STRAIGHT from the image -- with the K order
+//     permuted so that lane half h takes kw = h, h+2, the 64 lanes of one load cover 64 consecutive floats of one
+//     image row.  The weights live in 24 VGPRs for the life of the (persistent) block.  No LDS on the operand path.
+//   * conv3_wgrad (weight gradient of both layers): the reduction runs over pixels, so the window is the MFMA B
+//     operand and is gathered per lane.  Each wave stages the 12 image rows its output row touches in a private,
+//     zero-padded LDS patch (coalesced 16-byte loads, double buffered, no block barrier in the loop) and gathers
+//     from there conflict-free; the 32-channel operand is read from HBM directly in fragment order (64 lanes =
+//     256 contiguous bytes).
+// fp32 matrix cores in every precision mode: there is nothing to gain from bf16 operands on an HBM-bound layer.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+struct Conv3Geom {
+  int G, Bg, Hi, Wi, Ho, ldc;
+  int act, want_act_out, want_stats;
+  int tiles_per_group;   // Bg*Ho*32/128
+  const void* bn_y;
+  const float* bn_mean;
+  const float* bn_rstd;
+  const float* bn_gamma;
+  const float* bn_beta;
+};
+
+// slot j (0..23) of lane half h is the window element (ci, kh, kw) = (j>>3, (j>>1)&3, 2*(j&1)+h); MFMA j multiplies
+// slot j of A and B, so any bijection works as long as both operands use it
+// BN: BatchNorm+Swish backward epilogue; ACT: -1 = no second output, else the activation of the second output
+template <typename T, bool BN, int ACT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3_nt_kernel(const float* __restrict__ img, const float* __restrict__ Wp,
+                                                       T* __restrict__ C, T* __restrict__ C_act,
+                                                       float* __restrict__ stats, const Conv3Geom g) {
+  __shared__ float Ws[32 * 65];
+  __shared__ float red[4][2][32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: row / sample arithmetic stays scalar
+  const int x = lane & 31, h = lane >> 5;
+  for (int i = tid; i < 512; i += 256) {           // Wp: [32 n][64 k] (k >= 48 zero, never read)
+    const f32x4 v = reinterpret_cast<const f32x4*>(Wp)[i];
+    const int n = i >> 4, k = (i & 15) * 4;
+    Ws[n * 65 + k + 0] = v[0];
+    Ws[n * 65 + k + 1] = v[1];
+    Ws[n * 65 + k + 2] = v[2];
+    Ws[n * 65 + k + 3] = v[3];
+  }
+  __syncthreads();
+  float bw[24];
+#pragma unroll
+  for (int j = 0; j < 24; ++j) bw[j] = Ws[x * 65 + (j >> 3) * 16 + ((j >> 1) & 3) * 4 + 2 * (j & 1) + h];
+
+  constexpr bool bnbwd = BN;
+  const T* bn_y = reinterpret_cast<const T*>(g.bn_y);
+  const float bn_g = bnbwd ? g.bn_gamma[x] : 0.f, bn_b = bnbwd ? g.bn_beta[x] : 0.f;
+  const int HWo = g.Ho * 32;
+  const int ntiles = g.G * g.tiles_per_group;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int grp = t / g.tiles_per_group, tile = t - grp * g.tiles_per_group;
+    const int row0 = tile * 128 + wave * 32;         // first GEMM row of this wave inside the group
+    const int s = row0 / HWo, y = (row0 - s * HWo) >> 5;
+    const int ib = grp * g.Bg + s;
+    const float* base = img + (size_t)ib * 3 * g.Hi * g.Wi;
+    float a[24];
+    int xo[2];
+    bool xok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int xin = 2 * x - 1 + 2 * q + h;
+      xok[q] = (unsigned)xin < (unsigned)g.Wi;
+      xo[q] = xok[q] ? xin : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 24; ++j) {
+      const int ci = j >> 3, kh = (j >> 1) & 3;
+      const int yin = 2 * y - 1 + kh;                          // wave-uniform
+      const bool yok = (unsigned)yin < (unsigned)g.Hi;
+      const float* rowp = base + (ci * g.Hi + (yok ? yin : 0)) * g.Wi;
+      const float v = rowp[xo[j & 1]];
+      a[j] = (yok & xok[j & 1]) ? v : 0.f;
+    }
+    const int obase = ((ib * g.Ho + y) * 32) * g.ldc + x;     // + r*ldc: pixel r of the row, channel x
+    float yv[16];
+    float bn_m = 0.f, bn_r = 0.f;
+    if (bnbwd) {
+      bn_m = g.bn_mean[grp * 32 + x];
+      bn_r = g.bn_rstd[grp * 32 + x];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) yv[e] = ld1<T>(bn_y + obase + ((e & 3) + 8 * (e >> 2) + 4 * h) * g.ldc);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 24; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bw[j], acc, 0, 0, 0);
+
+    float cs = 0.f, cq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int off = obase + ((e & 3) + 8 * (e >> 2) + 4 * h) * g.ldc;
+      float v = acc[e];
+      if (bnbwd) {
+        const float xh = (yv[e] - bn_m) * bn_r;
+        v *= swish_gradf_(bn_g * xh + bn_b);
+        cs += v;
+        cq += v * xh;
+      } else {
+        cs += v;
+        cq += v * v;
+      }
+      if (sizeof(T) == 2) {
+        // adjacent channels sit in adjacent lanes: the even lane stores both as one dword
+        const float vn = __shfl_down(v, 1, 64);
+        if (!(x & 1)) {
+          *reinterpret_cast<uint32_t*>(C + off) = pack2_bf16(v, vn);
+          if (ACT >= 0) *reinterpret_cast<uint32_t*>(C_act + off) = pack2_bf16(apply_act(v, ACT), apply_act(vn, ACT));
+        }
+      } else {
+        st1<T>(C + off, v);
+        if (ACT >= 0) st1<T>(C_act + off, apply_act(v, ACT));
+      }
+    }
+    if (g.want_stats) {
+      cs += __shfl_xor(cs, 32, 64);
+      cq += __shfl_xor(cq, 32, 64);
+      if (h == 0) {
+        red[wave][0][x] = cs;
+        red[wave][1][x] = cq;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        float s0 = 0.f, q0 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s0 += red[w][0][tid];
+          q0 += red[w][1][tid];
+        }
+        const size_t sb = ((size_t)(grp * g.tiles_per_group + tile) * 2) * 32 + tid;
+        stats[sb] = s0;
+        stats[sb + 32] = q0;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---- weight gradient --------------------------------------------------------------------------------------------
+struct Conv3WgradGeom {
+  int Bt, Hr, Hi, Wi;       // Wr = 32
+  int img_rows;             // Bt*Hr output image rows = K-blocks of 32 pixels
+  int rows_per_chunk;       // output image rows per block
+};
+
+constexpr int PATCH_LD = 76;                 // 3 pad + 1 (x = -1) + 64 + 1 (x = 64) + pad; 76 % 32 = 12 spreads the
+constexpr int PATCH_ROWS = 13;               // 8 rows of one fragment over all banks; row 12 stays zero (k >= 48)
+constexpr int PATCH = PATCH_ROWS * PATCH_LD;
+
+template <typename TD>
+__global__ __launch_bounds__(256) void conv3_wgrad_kernel(const TD* __restrict__ D, const float* __restrict__ img,
+                                                          float* __restrict__ partial, const Conv3WgradGeom g) {
+  __shared__ __attribute__((aligned(16))) float smem[8192];       // 4 waves x 2 patches (7904 floats); reused as [4][32][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, kk = lane >> 5;
+  for (int i = tid; i < 8192; i += 256) smem[i] = 0.f;
+  __syncthreads();
+  float* patch = smem + wave * 2 * PATCH;
+
+  // gather offsets of the two B fragments (cg = n and cg = 32 + n) inside a patch, for pixel x = kk (+ 2j later)
+  int lofs[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int cg = nt * 32 + n;
+    const int r = cg < 48 ? (cg >> 2) : 12;
+    lofs[nt] = r * PATCH_LD + 3 + (cg & 3) + 2 * kk;
+  }
+  const int it_begin = blockIdx.x * g.rows_per_chunk;
+  const int it_end = min(g.img_rows, it_begin + g.rows_per_chunk);
+
+  f32x4 ri[3];
+  float dc[16], dn[16];
+  auto load_img = [&](int it) {                 // the 12 input rows (3 ci x 4 kh) of output image row `it`
+    const int b = it / g.Hr, y = it - b * g.Hr;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int r = (lane >> 4) + 4 * i;        // r = ci*4 + kh with ci = i
+      const int yin = 2 * y - 1 + (r & 3);
+      const bool ok = (unsigned)yin < (unsigned)g.Hi;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(img + ((size_t)(b * 3 + i) * g.Hi + (ok ? yin : 0)) * g.Wi +
+                                                      (lane & 15) * 4);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ri[i] = ok ? v : z;
+    }
+  };
+  auto store_img = [&](float* p) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      *reinterpret_cast<f32x4*>(p + ((lane >> 4) + 4 * i) * PATCH_LD + 4 + (lane & 15) * 4) = ri[i];
+  };
+  auto load_d = [&](int it, float* d) {         // fragment order: lane (cd = n, pixel 2j + kk) = 64 consecutive elements
+    const TD* p = D + (size_t)it * 32 * 32 + lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d[j] = ld1<TD>(p + 64 * j);
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+
+  int it = it_begin + wave;
+  int cur = 0;
+  if (it < it_end) {
+    load_img(it);
+    load_d(it, dc);
+    store_img(patch);
+  }
+  for (; it < it_end; it += 4) {
+    const bool more = it + 4 < it_end;
+    const int nx = more ? it + 4 : it;          // the last iteration re-reads its own rows (branch-free body)
+    load_img(nx);
+    load_d(nx, dn);
+    const float* p = patch + cur * PATCH;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float b0 = p[lofs[0] + 4 * j], b1 = p[lofs[1] + 4 * j];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[j], b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[j], b1, acc[1], 0, 0, 0);
+    }
+    store_img(patch + (cur ^ 1) * PATCH);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dc[j] = dn[j];
+    cur ^= 1;
+  }
+
+  // block reduction of the four waves' 32x64 accumulators, then one slab per block
+  __syncthreads();
+  float* redw = smem + wave * 2048;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) redw[((e & 3) + 8 * (e >> 2) + 4 * kk) * 64 + nt * 32 + n] = acc[nt][e];
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * 2048;
+  for (int i = tid; i < 512; i += 256) {
+    f32x4 s = reinterpret_cast<const f32x4*>(smem)[i];
+    s += reinterpret_cast<const f32x4*>(smem + 2048)[i];
+    s += reinterpret_cast<const f32x4*>(smem + 4096)[i];
+    s += reinterpret_cast<const f32x4*>(smem + 6144)[i];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+  }
+}
+
+// persistent grid: four blocks per CU stay resident (<= 128 VGPRs), each walks ntiles/1024 tiles
+constexpr int CONV3_GRID = 1024;
+
+}  // namespace
+
+// Returns MMDYN_OK / an error, or 1 when the shape is not one of this file's (the caller then takes the generic path).
+int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void* C, void* C_act, float* stats, int G,
+                       int Bg, int Hi, int Wi, int Ho, int Wo, int N, int ldc, int act, int splitk, const void* bn_y,
+                       const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
+                       int c_b16, int bny_b16, hipStream_t st) {
+  if (getenv("MMDYN_NO_CONV3")) return 1;     // kernel experiments only: take the generic tiled kernel
+  if (N != 32 || Wo != 32 || Wi != 64 || Hi != 2 * Ho || Ho % 4 || bias || splitk != 1 || (ldc & 1)) return 1;
+  if (bn_y && (c_b16 != bny_b16 || C_act)) return 1;
+  if (C_act && act != MMDYN_ACT_NONE && act != MMDYN_ACT_SWISH && act != MMDYN_ACT_RELU) return 1;
+  if ((int64_t)G * Bg * Ho * 32 * ldc >= (1LL << 31)) return 1;
+  Conv3Geom g{};
+  g.G = G;
+  g.Bg = Bg;
+  g.Hi = Hi;
+  g.Wi = Wi;
+  g.Ho = Ho;
+  g.ldc = ldc;
+  g.act = act;
+  g.want_act_out = C_act != nullptr;
+  g.want_stats = stats != nullptr;
+  g.tiles_per_group = Bg * Ho * 32 / 128;
+  g.bn_y = bn_y;
+  g.bn_mean = bn_mean;
+  g.bn_rstd = bn_rstd;
+  g.bn_gamma = bn_gamma;
+  g.bn_beta = bn_beta;
+  const int ntiles = G * g.tiles_per_group;
+  const dim3 grid(ntiles < CONV3_GRID ? ntiles : CONV3_GRID);
+  const int variant = bn_y ? 4 : (C_act ? act : -1);
+#define CONV3_CASE(V, BN_, ACT_)                                                                                   \
+  if (variant == (V)) {                                                                                            \
+    if (c_b16)                                                                                                     \
+      hipLaunchKernelGGL((conv3_nt_kernel<bf16_t, BN_, ACT_>), grid, dim3(256), 0, st, A, Bp, (bf16_t*)C,          \
+                         (bf16_t*)C_act, stats, g);                                                                \
+    else                                                                                                           \
+      hipLaunchKernelGGL((conv3_nt_kernel<float, BN_, ACT_>), grid, dim3(256), 0, st, A, Bp, (float*)C,            \
+                         (float*)C_act, stats, g);                                                                 \
+  }
+  CONV3_CASE(4, true, -1)
+  CONV3_CASE(-1, false, -1)
+  CONV3_CASE(MMDYN_ACT_NONE, false, MMDYN_ACT_NONE)
+  CONV3_CASE(MMDYN_ACT_SWISH, false, MMDYN_ACT_SWISH)
+  CONV3_CASE(MMDYN_ACT_RELU, false, MMDYN_ACT_RELU)
+#undef CONV3_CASE
+  MMDYN_LAUNCH_CHECK();
+}
+
+// chunks = partial slabs = blocks; 1 when the shape is not this file's
+int mmdyn_conv3_wgrad_try(const void* D, const float* Gt, float* partial, int Bt, int Hr, int Wr, int Cd, int Hi,
+                          int Wi, int Cg, int chunks, int d_b16, hipStream_t st) {
+  if (getenv("MMDYN_NO_CONV3")) return 1;
+  if (Cd != 32 || Cg != 64 || Wr != 32 || Wi != 64 || Hi != 2 * Hr) return 1;
+  Conv3WgradGeom g{};
+  g.Bt = Bt;
+  g.Hr = Hr;
+  g.Hi = Hi;
+  g.Wi = Wi;
+  g.img_rows = Bt * Hr;
+  g.rows_per_chunk = ceil_div(g.img_rows, chunks);
+  if (d_b16)
+    hipLaunchKernelGGL(conv3_wgrad_kernel<bf16_t>, dim3(chunks), dim3(256), 0, st, (const bf16_t*)D, Gt, partial, g);
+  else
+    hipLaunchKernelGGL(conv3_wgrad_kernel<float>, dim3(chunks), dim3(256), 0, st, (const float*)D, Gt, partial, g);
+  MMDYN_LAUNCH_CHECK();
+}

@@ -516,6 +516,10 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
   g.ntaps = (mode == MMDYN_CONV) ? 16 : 1;
   g.chunks = chunks;
   hipStream_t st = (hipStream_t)stream;
+  if (mode == MMDYN_IM2COL3) {     // the 3-channel layers have their own direct kernel (conv3.hip)
+    const int rc = mmdyn_conv3_wgrad_try(D, Gt, partial, Bt, Hr, Wr, Cd, Hi, Wi, Cg, chunks, g.d_b16, st);
+    if (rc != 1) return rc;
+  }
   const bool d64 = (Cd % 64 == 0), g64 = (Cg % 64 == 0);
   if (Cd % 128 == 0 && Cg % 128 == 0) return launch<128, 128, 64, 64, 1>(D, Gt, partial, g, st, bf16);
   if (mode == MMDYN_CONV && !(d64 && g64)) {   // narrow channel tiles: four kw taps per block share the dense
@@ -567,6 +571,10 @@ extern "C" int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg) {
   }
   long target = 1024;
   if (const char* ov = getenv("MMDYN_WGRAD_BLOCKS")) target = atol(ov);   // kernel experiments only
+  if (mode == MMDYN_IM2COL3) {            // conv3_wgrad: one block (four waves, one slab) per chunk
+    tiles = 1;
+    wk = 1;
+  }
   long z = target / tiles;
   const long zmax = rows / 128;
   if (z > zmax) z = zmax;

@@ -95,7 +95,9 @@ class EmuBackend:
         assert Cin % 32 == 0 and N % 32 == 0 and ldc == N
         Bt = G * Bg
         Bp = Bp.reshape(-1, N, Cin)
-        if getattr(self, "precision", "fp32") != "fp32":       # operands rounded to bf16 (RNE), fp32 accumulate
+        # operands rounded to bf16 (RNE), fp32 accumulate -- except on the HBM-bound 3-channel layers, whose kernels
+        # (conv3.hip) keep fp32 matrix cores in every precision mode
+        if getattr(self, "precision", "fp32") != "fp32" and mode != IM2COL3:
             A, Bp = A.to(torch.bfloat16).to(torch.float32), Bp.to(torch.bfloat16).to(torch.float32)
         if mode == IM2COL3:
             assert Cin == 64
@@ -157,7 +159,7 @@ class EmuBackend:
     def wgrad_tn(self, D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks):
         assert chunks % 4 == 0 and Cd % 32 == 0 and Cg % 32 == 0
         rows = Bt * Hr * Wr
-        if getattr(self, "precision", "fp32") != "fp32":
+        if getattr(self, "precision", "fp32") != "fp32" and mode != IM2COL3:
             D, Gt = D.to(torch.bfloat16).to(torch.float32), Gt.to(torch.bfloat16).to(torch.float32)
         Dm = D.reshape(-1)[: rows * Cd].reshape(rows, Cd)
         partial.zero_()

@@ -462,6 +462,31 @@ def test_im2col_on_the_fly_modes(Bt):
     both("wgrad_tn", [D, x, partial, IM2COL3, Bt, 32, 32, 32, 64, 64, 64, 1, 0, chunks], [2], lambda i, t: t.sum(0), tol=5e-5)
 
 
+@pytest.mark.parametrize("G,Bg", [(1, 2), (2, 3), (4, 8)])
+def test_conv3_direct_kernels(G, Bg):
+    """The 3-channel layers' own kernels (conv3.hip) behind the IM2COL3 geometry: forward with per-tile BatchNorm
+    partials, input gradient with the BatchNorm+Swish backward epilogue, weight gradient -- grouped batches."""
+    Bt = G * Bg
+    x = rnd(Bt, 3, 64, 64, seed=90)
+    Bp = rnd(1, 32, 64, seed=91, scale=0.2)
+    Bp[:, :, 48:] = 0
+    rows = Bt * 1024
+    T = HIP.igemm_stat_tiles(IM2COL3, G, Bg, 64, 64, 64, 32, 32, 32)
+    assert T == Bg * 8
+    post = lambda i, t: t.sum(1) if t.dim() == 4 else t
+    C, stats = torch.zeros(rows, 32), torch.zeros(G, T, 2, 32)
+    both("igemm_nt", [x, Bp, None, C, None, stats, None, IM2COL3, G, Bg, 64, 64, 64, 32, 32, 32, 32, 1, 0, 0, 1], [3, 5], post)
+    y = rnd(rows, 32, seed=92) * 1.5 + 0.2
+    mean, rstd = rnd(G, 32, seed=93) * 0.3, rnd(G, 32, seed=94).abs() + 0.5
+    gamma, beta = rnd(32, seed=95) + 1.2, rnd(32, seed=96)
+    both("igemm_nt_dgrad_bn", [x, Bp, C, stats, y, mean, rstd, gamma, beta, IM2COL3, G, Bg, 64, 64, 64, 32, 32, 32, 1, 0],
+         [2, 3], post, tol=5e-5)
+    D = rnd(rows, 32, seed=97)
+    for chunks in (HIP.wgrad_chunks(IM2COL3, rows, 32, 64), 4, 12):
+        both("wgrad_tn", [D, x, torch.zeros(chunks, 1, 32, 64), IM2COL3, Bt, 32, 32, 32, 64, 64, 64, 1, 0, chunks], [2],
+             lambda i, t: t.sum(0), tol=5e-5)
+
+
 def test_sgd_matches_torch():
     n = 50001
     p0, g = rnd(n, seed=80), rnd(n, seed=81) * 0.1

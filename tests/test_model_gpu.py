@@ -102,7 +102,12 @@ def test_fused_engine_vs_oracle(B, n_steps):
         loss_o.backward()
         loss = step.forward(gi, gt, klw)
         assert float(loss) == pytest.approx(float(loss_o.detach()), rel=1e-4), s
-        np.testing.assert_allclose(step.partials[:7].cpu().numpy(), [float(x.detach()) for x in partials_o], rtol=1e-4)
+        # every partial within 1e-4 on identical weights (step 0).  After Adam steps the weights themselves differ by
+        # rounding-level gradient differences that Adam amplifies where |g| ~ 0 (update = lr * g / (|g| + eps)), so the
+        # small pose-only partial drifts at the 1e-4 level whichever summation order the kernels use
+        # (tests/microbench/drift_probe.py: 5e-5 .. 1.2e-4 at step 2); the total stays within 1e-4
+        np.testing.assert_allclose(step.partials[:7].cpu().numpy(), [float(x.detach()) for x in partials_o],
+                                   rtol=1e-4 if s == 0 else 5e-4)
         h = step.backward()
         if s == 0:
             named = dict(m.named_parameters())
