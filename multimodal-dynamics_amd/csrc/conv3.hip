@@ -32,13 +32,31 @@ struct Conv3Geom {
   const float* bn_beta;
 };
 
+// A wave-uniform pointer, pinned into a scalar register pair (and kept in the GLOBAL address space): the compiler then
+// emits the (SGPR base + 32-bit VGPR offset) form of global_load / global_store instead of building a 64-bit address
+// per access on the vector ALU
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef GLOBAL_AS char* gchar_p;
+__device__ __forceinline__ gchar_p sgpr_ptr(const void* p) {
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return (gchar_p)(((uint64_t)hi << 32) | lo);
+}
+template <typename T> __device__ __forceinline__ float gld1(gchar_p p);
+template <> __device__ __forceinline__ float gld1<float>(gchar_p p) { return *(GLOBAL_AS const float*)p; }
+template <> __device__ __forceinline__ float gld1<bf16_t>(gchar_p p) {
+  return __uint_as_float((uint32_t)(*(GLOBAL_AS const bf16_t*)p) << 16);
+}
+
 // slot j (0..23) of lane half h is the window element (ci, kh, kw) = (j>>3, (j>>1)&3, 2*(j&1)+h); MFMA j multiplies
-// slot j of A and B, so any bijection works as long as both operands use it
+// slot j of A and B, so any bijection works as long as both operands use it.
+// The kernel is specialised to the reference's 64x64 images: 32x32 output pixels, N = ldc = 32 channels.
 // BN: BatchNorm+Swish backward epilogue; ACT: -1 = no second output, else the activation of the second output
+constexpr int C3_HI = 64, C3_HO = 32, C3_N = 32;
 template <typename T, bool BN, int ACT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3_nt_kernel(const float* __restrict__ img, const float* __restrict__ Wp,
-                                                       T* __restrict__ C, T* __restrict__ C_act,
-                                                       float* __restrict__ stats, const Conv3Geom g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3_nt_kernel(
+    const float* __restrict__ img, const float* __restrict__ Wp, T* __restrict__ C, T* __restrict__ C_act,
+    float* __restrict__ stats, const Conv3Geom g) {
   __shared__ float Ws[32 * 65];
   __shared__ float red[4][2][32];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -53,61 +71,98 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     Ws[n * 65 + k + 3] = v[3];
   }
   __syncthreads();
+  // weight fragments: kept in 24 VGPRs for the life of the block, except in the BatchNorm-backward variant, which
+  // needs the registers for the prefetched pre-BN values and re-reads them from LDS per tile instead
   float bw[24];
+  auto load_bw = [&]() {
 #pragma unroll
-  for (int j = 0; j < 24; ++j) bw[j] = Ws[x * 65 + (j >> 3) * 16 + ((j >> 1) & 3) * 4 + 2 * (j & 1) + h];
+    for (int j = 0; j < 24; ++j) bw[j] = Ws[x * 65 + (j >> 3) * 16 + ((j >> 1) & 3) * 4 + 2 * (j & 1) + h];
+  };
+  if (!BN) load_bw();
 
-  constexpr bool bnbwd = BN;
-  const T* bn_y = reinterpret_cast<const T*>(g.bn_y);
-  const float bn_g = bnbwd ? g.bn_gamma[x] : 0.f, bn_b = bnbwd ? g.bn_beta[x] : 0.f;
-  const int HWo = g.Ho * 32;
+  const float bn_g = BN ? g.bn_gamma[x] : 0.f, bn_b = BN ? g.bn_beta[x] : 0.f;
   const int ntiles = g.G * g.tiles_per_group;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int grp = t / g.tiles_per_group, tile = t - grp * g.tiles_per_group;
-    const int row0 = tile * 128 + wave * 32;         // first GEMM row of this wave inside the group
-    const int s = row0 / HWo, y = (row0 - s * HWo) >> 5;
-    const int ib = grp * g.Bg + s;
-    const float* base = img + (size_t)ib * 3 * g.Hi * g.Wi;
-    float a[24];
-    int xo[2];
-    bool xok[2];
+
+  // Addressing is kept off the vector ALU: every access is (uniform 64-bit base, scalar instructions) + (one of three
+  // per-lane BYTE offsets that never change) + (a compile-time immediate), the saddr form of global_load/store.
+  unsigned xoB[2];
+  bool xok[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int xin = 2 * x - 1 + 2 * q + h;
-      xok[q] = (unsigned)xin < (unsigned)g.Wi;
-      xo[q] = xok[q] ? xin : 0;
-    }
+  for (int q = 0; q < 2; ++q) {
+    const int xin = 2 * x - 1 + 2 * q + h;
+    xok[q] = (unsigned)xin < (unsigned)C3_HI;
+    xoB[q] = (xok[q] ? xin : 0) * 4u;
+  }
+  const unsigned voffB = (4 * h * C3_N + x) * sizeof(T);              // pixel +4h of the row, channel x
+  constexpr unsigned IMG_B = 3 * C3_HI * C3_HI * sizeof(float);       // bytes per sample of the image
+  constexpr unsigned OROW_B = C3_HO * C3_N * sizeof(T);               // bytes per output image row (32 px x 32 ch)
+
+  // tile t = 128 GEMM rows = output image rows 4*(t&7) .. +3 of sample t>>3 (8 tiles per sample); wave w takes row +w
+  struct TileAt {
+    gchar_p imgb;       // the sample's image
+    size_t orow;        // byte offset of the wave's output row (the same in C, C_act and bn_y)
+    int y;
+  };
+  auto locate = [&](int t) {
+    TileAt p;
+    const int ib = t >> 3;
+    p.y = (t & 7) * 4 + wave;
+    p.imgb = sgpr_ptr(reinterpret_cast<const char*>(img) + (size_t)ib * IMG_B);
+    p.orow = (size_t)(ib * C3_HO + p.y) * OROW_B;
+    return p;
+  };
+  auto load_a = [&](const TileAt& p, int j) {         // window slot j of the wave's 32 pixels: one 256-byte load
+    const int ci = j >> 3, yin = 2 * p.y - 1 + ((j >> 1) & 3);            // wave-uniform
+    const bool yok = (unsigned)yin < (unsigned)C3_HI;
+    const gchar_p rowp = p.imgb + (unsigned)((ci * C3_HI + (yok ? yin : 0)) * C3_HI) * 4u;
+    return gld1<float>(rowp + xoB[j & 1]);
+  };
+  auto erow = [](int e) { return (unsigned)(((e & 3) + 8 * (e >> 2)) * C3_N * sizeof(T)); };   // immediate offsets
+
+  // Software pipeline over the block's tiles: the loads of tile t+1 are issued behind the MFMA / epilogue step
+  // that consumed the same register of tile t, so they fly during the rest of tile t (no second register set).
+  float a[24], yv[16];
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  TileAt cur = locate(t);
 #pragma unroll
-    for (int j = 0; j < 24; ++j) {
-      const int ci = j >> 3, kh = (j >> 1) & 3;
-      const int yin = 2 * y - 1 + kh;                          // wave-uniform
-      const bool yok = (unsigned)yin < (unsigned)g.Hi;
-      const float* rowp = base + (ci * g.Hi + (yok ? yin : 0)) * g.Wi;
-      const float v = rowp[xo[j & 1]];
-      a[j] = (yok & xok[j & 1]) ? v : 0.f;
-    }
-    const int obase = ((ib * g.Ho + y) * 32) * g.ldc + x;     // + r*ldc: pixel r of the row, channel x
-    float yv[16];
+  for (int j = 0; j < 24; ++j) a[j] = load_a(cur, j);
+  if (BN) {
+    const gchar_p yb = sgpr_ptr(reinterpret_cast<const char*>(g.bn_y) + cur.orow) + voffB;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) yv[e] = gld1<T>(yb + erow(e));
+  }
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x < ntiles ? t + gridDim.x : t;      // last tile: harmless re-read of its own data
+    const TileAt nxt = locate(tn);
+    const int grp = (BN || g.want_stats) ? __builtin_amdgcn_readfirstlane((t >> 3) / g.Bg) : 0;
+    if (BN) load_bw();
     float bn_m = 0.f, bn_r = 0.f;
-    if (bnbwd) {
+    if (BN) {
       bn_m = g.bn_mean[grp * 32 + x];
       bn_r = g.bn_rstd[grp * 32 + x];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) yv[e] = ld1<T>(bn_y + obase + ((e & 3) + 8 * (e >> 2) + 4 * h) * g.ldc);
     }
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 24; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bw[j], acc, 0, 0, 0);
+    for (int j = 0; j < 24; ++j) {
+      const int yin = 2 * cur.y - 1 + ((j >> 1) & 3);
+      const bool ok = ((unsigned)yin < (unsigned)C3_HI) & xok[j & 1];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? a[j] : 0.f, bw[j], acc, 0, 0, 0);
+      a[j] = load_a(nxt, j);
+    }
 
+    const gchar_p cb = sgpr_ptr(reinterpret_cast<const char*>(C) + cur.orow) + voffB;
+    const gchar_p ab = sgpr_ptr(reinterpret_cast<const char*>(C_act) + cur.orow) + voffB;
+    const gchar_p yb = sgpr_ptr(reinterpret_cast<const char*>(g.bn_y) + nxt.orow) + voffB;
     float cs = 0.f, cq = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int off = obase + ((e & 3) + 8 * (e >> 2) + 4 * h) * g.ldc;
       float v = acc[e];
-      if (bnbwd) {
+      if (BN) {
         const float xh = (yv[e] - bn_m) * bn_r;
+        yv[e] = gld1<T>(yb + erow(e));
         v *= swish_gradf_(bn_g * xh + bn_b);
         cs += v;
         cq += v * xh;
@@ -119,12 +174,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // adjacent channels sit in adjacent lanes: the even lane stores both as one dword
         const float vn = __shfl_down(v, 1, 64);
         if (!(x & 1)) {
-          *reinterpret_cast<uint32_t*>(C + off) = pack2_bf16(v, vn);
-          if (ACT >= 0) *reinterpret_cast<uint32_t*>(C_act + off) = pack2_bf16(apply_act(v, ACT), apply_act(vn, ACT));
+          *(GLOBAL_AS uint32_t*)(cb + erow(e)) = pack2_bf16(v, vn);
+          if (ACT >= 0) *(GLOBAL_AS uint32_t*)(ab + erow(e)) = pack2_bf16(apply_act(v, ACT), apply_act(vn, ACT));
         }
       } else {
-        st1<T>(C + off, v);
-        if (ACT >= 0) st1<T>(C_act + off, apply_act(v, ACT));
+        *(GLOBAL_AS float*)(cb + erow(e)) = v;
+        if (ACT >= 0) *(GLOBAL_AS float*)(ab + erow(e)) = apply_act(v, ACT);
       }
     }
     if (g.want_stats) {
@@ -142,12 +197,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           s0 += red[w][0][tid];
           q0 += red[w][1][tid];
         }
-        const size_t sb = ((size_t)(grp * g.tiles_per_group + tile) * 2) * 32 + tid;
+        const size_t sb = ((size_t)t * 2) * 32 + tid;      // slot = grp * tiles_per_group + tile = t
         stats[sb] = s0;
         stats[sb + 32] = q0;
       }
       __syncthreads();
     }
+    cur = nxt;
   }
 }
 
@@ -270,7 +326,7 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
                        const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
                        int c_b16, int bny_b16, hipStream_t st) {
   if (getenv("MMDYN_NO_CONV3")) return 1;     // kernel experiments only: take the generic tiled kernel
-  if (N != 32 || Wo != 32 || Wi != 64 || Hi != 2 * Ho || Ho % 4 || bias || splitk != 1 || (ldc & 1)) return 1;
+  if (N != C3_N || ldc != C3_N || Ho != C3_HO || Wo != C3_HO || Hi != C3_HI || Wi != C3_HI || bias || splitk != 1) return 1;
   if (bn_y && (c_b16 != bny_b16 || C_act)) return 1;
   if (C_act && act != MMDYN_ACT_NONE && act != MMDYN_ACT_SWISH && act != MMDYN_ACT_RELU) return 1;
   if ((int64_t)G * Bg * Ho * 32 * ldc >= (1LL << 31)) return 1;
@@ -291,7 +347,9 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
   g.bn_gamma = bn_gamma;
   g.bn_beta = bn_beta;
   const int ntiles = G * g.tiles_per_group;
-  const dim3 grid(ntiles < CONV3_GRID ? ntiles : CONV3_GRID);
+  int gcap = CONV3_GRID;
+  if (const char* ov = getenv("MMDYN_CONV3_GRID")) gcap = atoi(ov);   // kernel experiments only
+  const dim3 grid(ntiles < gcap ? ntiles : gcap);
   const int variant = bn_y ? 4 : (C_act ? act : -1);
 #define CONV3_CASE(V, BN_, ACT_)                                                                                   \
   if (variant == (V)) {                                                                                            \
