@@ -127,6 +127,11 @@ int mmdyn_repack2d(const float* in, float* out, int rows_in, int cols_in, int ro
 /* mmdyn_repack2d writing a rows_out x cols_out block into a wider matrix (row stride ld_out >= cols_out) */
 int mmdyn_repack2d_ld(const float* in, float* out, int rows_in, int cols_in, int rows_out, int cols_out,
                       int ld_out, int mode, void* stream);
+/* the same two packs with a bf16 destination (RNE): in the bf16 precision modes the weights are packed straight to
+ * the matrix cores' operand type, which halves the weight bytes every implicit-GEMM block pulls through L2 */
+int mmdyn_pack_conv_weight_b16(const float* Wc, void* P, int d0, int d1, int swap, void* stream);
+int mmdyn_repack2d_ld_b16(const float* in, void* out, int rows_in, int cols_in, int rows_out, int cols_out,
+                          int ld_out, int mode, void* stream);
 /* A whole step's weight repacks in one launch.  `plan_dev` is a DEVICE array of n entries (built once: the
  * parameter storage of a training run does not move).  kind 0..5 = mmdyn_repack2d modes with an output leading
  * dimension ld_out (>= cols_out); kind 100 / 101 = mmdyn_pack_conv_weight with swap 0 / 1 (rows_in = d0,
@@ -135,6 +140,7 @@ typedef struct {
   const float* src;
   float* dst;
   int kind, rows_in, cols_in, rows_out, cols_out, ld_out;
+  int dst_bf16;   /* 1: dst is a bf16 tensor (ld_out in elements); the GEMM operands of the bf16 precision modes */
 } mmdyn_pack_entry;
 int mmdyn_pack_plan(const mmdyn_pack_entry* plan_dev, int n, void* stream);
 
@@ -300,11 +306,12 @@ int mmdyn_resize_u8_to_chw_f32(const uint8_t* src, const int* index, float* dst,
  * bf16 matrix-core products (fp32 accumulate).
  *   mmdyn_igemm_nt_mx : mmdyn_igemm_nt / _dgrad_bn with per-tensor storage flags --
  *       bit 0 bf16 matrix cores (required when any other bit is set), bit 1 A is bf16 (not IM2COL3), bit 2 C and
- *       C_act are bf16, bit 3 the BatchNorm-backward operand y is bf16.  y == NULL: plain GEMM epilogue.  Split-K (fp32 workspace) is
- *       allowed with a bf16 A, not with a bf16 C.
+ *       C_act are bf16, bit 3 the BatchNorm-backward operand y is bf16, bit 4 the packed weights Bp are bf16
+ *       (mmdyn_pack_conv_weight_b16 / mmdyn_repack2d_ld_b16 / a dst_bf16 plan entry).  y == NULL: plain GEMM
+ *       epilogue.  Split-K (fp32 workspace) is allowed with a bf16 A, not with a bf16 C.
  *   mmdyn_wgrad_tn_mx : bit 0 as above, bit 1 D is bf16, bit 2 Gt is bf16 (not IM2COL3).
  *   *_b16             : the element-wise kernels on bf16 activation tensors. */
-int mmdyn_igemm_nt_mx(const void* A, const float* Bp, const float* bias, void* C, void* C_act, float* stats,
+int mmdyn_igemm_nt_mx(const void* A, const void* Bp, const float* bias, void* C, void* C_act, float* stats,
                       float* ws, const void* y, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
                       int ldc, int stride, int offset, int act, int splitk, int flags, void* stream);

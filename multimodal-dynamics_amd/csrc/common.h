@@ -115,7 +115,7 @@ __device__ __forceinline__ float act_grad(float x, int act) {
 int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void* C, void* C_act, float* stats, int G,
                        int Bg, int Hi, int Wi, int Ho, int Wo, int N, int ldc, int act, int splitk, const void* bn_y,
                        const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
-                       int c_b16, int bny_b16, hipStream_t st);
+                       int c_b16, int bny_b16, int b_b16, hipStream_t st);
 int mmdyn_conv3_wgrad_try(const void* D, const float* Gt, float* partial, int Bt, int Hr, int Wr, int Cd, int Hi,
                           int Wi, int Cg, int chunks, int d_b16, hipStream_t st);
 

@@ -23,7 +23,7 @@ namespace {
 
 struct Conv3Geom {
   int G, Bg, Hi, Wi, Ho, ldc;
-  int act, want_act_out, want_stats;
+  int act, want_act_out, want_stats, w_b16;
   int tiles_per_group;   // Bg*Ho*32/128
   const void* bn_y;
   const float* bn_mean;
@@ -62,8 +62,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: row / sample arithmetic stays scalar
   const int x = lane & 31, h = lane >> 5;
-  for (int i = tid; i < 512; i += 256) {           // Wp: [32 n][64 k] (k >= 48 zero, never read)
-    const f32x4 v = reinterpret_cast<const f32x4*>(Wp)[i];
+  for (int i = tid; i < 512; i += 256) {           // Wp: [32 n][64 k] (k >= 48 zero, never read), fp32 or bf16
+    const f32x4 v = g.w_b16 ? ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Wp) + 4 * i)
+                            : reinterpret_cast<const f32x4*>(Wp)[i];
     const int n = i >> 4, k = (i & 15) * 4;
     Ws[n * 65 + k + 0] = v[0];
     Ws[n * 65 + k + 1] = v[1];
@@ -324,7 +325,7 @@ constexpr int CONV3_GRID = 1024;
 int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void* C, void* C_act, float* stats, int G,
                        int Bg, int Hi, int Wi, int Ho, int Wo, int N, int ldc, int act, int splitk, const void* bn_y,
                        const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
-                       int c_b16, int bny_b16, hipStream_t st) {
+                       int c_b16, int bny_b16, int b_b16, hipStream_t st) {
   if (getenv("MMDYN_NO_CONV3")) return 1;     // kernel experiments only: take the generic tiled kernel
   if (N != C3_N || ldc != C3_N || Ho != C3_HO || Wo != C3_HO || Hi != C3_HI || Wi != C3_HI || bias || splitk != 1) return 1;
   if (bn_y && (c_b16 != bny_b16 || C_act)) return 1;
@@ -340,6 +341,7 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
   g.act = act;
   g.want_act_out = C_act != nullptr;
   g.want_stats = stats != nullptr;
+  g.w_b16 = b_b16;
   g.tiles_per_group = Bg * Ho * 32 / 128;
   g.bn_y = bn_y;
   g.bn_mean = bn_mean;

@@ -46,6 +46,7 @@ struct IgemmGeom {
   const float* bn_beta;   // [N]
   // bf16 activation storage (bf16 matrix-core variants only): which of the activation tensors are bf16 in HBM
   int a_b16, c_b16, bny_b16;
+  int b_b16;   // packed weights are bf16 (written so by the pack kernels in the bf16 modes: half the L2 -> LDS traffic)
 };
 
 constexpr int BK = 32;              // K-step (channels of one tap per stage)
@@ -63,7 +64,7 @@ __device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {
   return r;
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16>
+template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16, bool B16>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__ A,
                                                        const float* __restrict__ Bp,
                                                        const float* __restrict__ bias,
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   // global loads between the 64-cycle MFMAs instead of in front of them.
   f32x4 ra[A_LOADS], rbv[B_LOADS];
   uint2 ra16[A_LOADS];          // A16: the raw bf16 granule (widening it here would wait for the load before the MFMAs)
+  uint2 rbv16[B_LOADS];         // B16: likewise for bf16 packed weights
   unsigned okmask = 0;
   // bf16 matrix-core variants keep the tiles in LDS as bf16 ([row][40] halves: 32 + one 16-byte pad slot): half the
   // LDS bytes, one ds_read_b128 per operand and 16-deep MFMA, conversion once per element on the store side
@@ -230,7 +232,10 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < B_LOADS; ++j) {
       const int n = n0 + lrow + ROWS_PER_PASS * j;
-      rbv[j] = *reinterpret_cast<const f32x4*>(Bp + ((size_t)wi * g.N + n) * g.Cin + c0);
+      if constexpr (B16)
+        rbv16[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(Bp) + ((size_t)wi * g.N + n) * g.Cin + c0);
+      else
+        rbv[j] = *reinterpret_cast<const f32x4*>(Bp + ((size_t)wi * g.N + n) * g.Cin + c0);
     }
     // advance; the fetch issued during the last K-step is a harmless repeat of a valid tile (keeps the loop
     // body free of branches)
@@ -259,8 +264,12 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < B_LOADS; ++j) {
         uint2 v;
-        v.x = pack2_bf16(rbv[j][0], rbv[j][1]);
-        v.y = pack2_bf16(rbv[j][2], rbv[j][3]);
+        if constexpr (B16) {
+          v = rbv16[j];
+        } else {
+          v.x = pack2_bf16(rbv[j][0], rbv[j][1]);
+          v.y = pack2_bf16(rbv[j][2], rbv[j][3]);
+        }
         *reinterpret_cast<uint2*>(&Bs16[(lrow + ROWS_PER_PASS * j) * LDH + gran * 4]) = v;
       }
       return;
@@ -504,15 +513,16 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   const int mx8 = (g.G * g.tiles_per_group + 7) / 8 * 8;
   dim3 grid((unsigned)mx8 * (g.N / BN) * g.nclasses * g.splitk);
   size_t smem = (size_t)(BM + BN) * LDS_LD * sizeof(float) + (size_t)BM * 4 * sizeof(int);
-  if (bf16 && g.a_b16 && MODE != MMDYN_IM2COL3)
-    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, MODE != MMDYN_IM2COL3>), grid, dim3(256), smem, st, A,
-                       Bp, bias, C, C_act, stats, ws, g);
-  else if (bf16)
-    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, false>), grid, dim3(256), smem, st, A, Bp, bias, C,
-                       C_act, stats, ws, g);
-  else
-    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, false, false>), grid, dim3(256), smem, st, A, Bp, bias, C,
-                       C_act, stats, ws, g);
+#define IGEMM_LAUNCH(BF, A16_, B16_)                                                                                     \
+  hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, BF, A16_, B16_>), grid, dim3(256), smem, st, A, Bp, bias, C, \
+                     C_act, stats, ws, g)
+  constexpr bool CAN_A16 = MODE != MMDYN_IM2COL3;
+  if (!bf16) IGEMM_LAUNCH(false, false, false);
+  else if (g.a_b16 && g.b_b16) IGEMM_LAUNCH(true, CAN_A16, true);
+  else if (g.a_b16) IGEMM_LAUNCH(true, CAN_A16, false);
+  else if (g.b_b16) IGEMM_LAUNCH(true, false, true);
+  else IGEMM_LAUNCH(true, false, false);
+#undef IGEMM_LAUNCH
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -581,6 +591,7 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   g.a_b16 = (storage_flags & 2) != 0;
   g.c_b16 = (storage_flags & 4) != 0;
   g.bny_b16 = (storage_flags & 8) != 0;
+  g.b_b16 = (storage_flags & 16) != 0;
   if (storage_flags && (!bf16 || (g.c_b16 && splitk > 1) || (g.a_b16 && mode == MMDYN_IM2COL3))) return MMDYN_ERR_SHAPE;
   g.want_act_out = C_act != nullptr;
   g.splitk = splitk;
@@ -633,7 +644,7 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   hipStream_t st = (hipStream_t)stream;
   if (mode == MMDYN_IM2COL3) {     // the 3-channel layers have their own direct kernel (conv3.hip)
     const int rc = mmdyn_conv3_nt_try(A, Bp, bias, C, C_act, stats, G, Bg, Hi, Wi, Ho, Wo, N, ldc, act, splitk, bn_y,
-                                      bn_mean, bn_rstd, bn_gamma, bn_beta, g.c_b16, g.bny_b16, st);
+                                      bn_mean, bn_rstd, bn_gamma, bn_beta, g.c_b16, g.bny_b16, g.b_b16, st);
     if (rc != 1) return rc;
   }
   int bm, bn;
@@ -668,13 +679,13 @@ extern "C" int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C
 
 /* One entry point for the mixed-storage variants: flags bit 0 = bf16 matrix cores (required for the others),
  * bit 1 = A is bf16 in HBM, bit 2 = C / C_act are bf16, bit 3 = the BatchNorm-backward operand y is bf16. */
-extern "C" int mmdyn_igemm_nt_mx(const void* A, const float* Bp, const float* bias, void* C, void* C_act, float* stats,
+extern "C" int mmdyn_igemm_nt_mx(const void* A, const void* Bp, const float* bias, void* C, void* C_act, float* stats,
                                  float* ws, const void* bn_y, const float* bn_mean, const float* bn_rstd,
                                  const float* bn_gamma, const float* bn_beta, int mode, int G, int Bg, int Hi, int Wi,
                                  int Cin, int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
                                  int flags, void* stream) {
   if (bn_y && (!stats || !bn_mean || !bn_rstd || !bn_gamma || !bn_beta)) return MMDYN_ERR_NULL;
-  return igemm_entry((const float*)A, Bp, bias, (float*)C, (float*)C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho,
+  return igemm_entry((const float*)A, (const float*)Bp, bias, (float*)C, (float*)C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho,
                      Wo, N, ldc, stride, offset, act, splitk, stream, (flags & 1) != 0, (const float*)bn_y, bn_mean,
                      bn_rstd, bn_gamma, bn_beta, flags & ~1);
 }

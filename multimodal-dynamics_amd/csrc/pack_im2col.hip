@@ -9,7 +9,10 @@
 
 namespace {
 
-__global__ void pack_conv_weight_kernel(const float* __restrict__ Wc, float* __restrict__ P, int d0, int d1,
+// TO = float or bf16_t: in the bf16 precision modes the GEMM operands are packed straight to bf16 (RNE), which halves
+// what the implicit-GEMM blocks pull through L2 for the weight tiles
+template <typename TO>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ Wc, TO* __restrict__ P, int d0, int d1,
                                         int swap) {
   const int64_t total = (int64_t)16 * d0 * d1;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -21,7 +24,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ Wc, float* __r
     int x = (int)(t % nx);
     int tap = (int)(t / nx);
     int a = swap ? y : x, b = swap ? x : y;  // canonical indices (d0, d1)
-    P[i] = Wc[((int64_t)a * d1 + b) * 16 + tap];
+    st1<TO>(P + i, Wc[((int64_t)a * d1 + b) * 16 + tap]);
   }
 }
 
@@ -61,19 +64,20 @@ __device__ __forceinline__ float repack_fetch(const float* __restrict__ in, int 
   return (ri < rows_in && ci < cols_in) ? in[(int64_t)ri * cols_in + ci] : 0.f;
 }
 
-__global__ void repack2d_ld_kernel(const float* __restrict__ in, float* __restrict__ out, int rows_in, int cols_in,
+template <typename TO>
+__global__ void repack2d_ld_kernel(const float* __restrict__ in, TO* __restrict__ out, int rows_in, int cols_in,
                                    int rows_out, int cols_out, int ld_out, int mode) {
   const int64_t total = (int64_t)rows_out * cols_out;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int c = (int)(i % cols_out), r = (int)(i / cols_out);
-    out[(int64_t)r * ld_out + c] = repack_fetch(in, rows_in, cols_in, r, c, mode);
+    st1<TO>(out + (int64_t)r * ld_out + c, repack_fetch(in, rows_in, cols_in, r, c, mode));
   }
 }
 
-__global__ void pack_plan_kernel(const mmdyn_pack_entry* __restrict__ plan) {
-  const mmdyn_pack_entry e = plan[blockIdx.y];
+template <typename TO>
+__device__ __forceinline__ void pack_plan_entry(const mmdyn_pack_entry& e) {
   const float* __restrict__ src = e.src;
-  float* __restrict__ dst = e.dst;
+  TO* __restrict__ dst = reinterpret_cast<TO*>(e.dst);
   if (e.kind >= 100) {                       // conv weight: Wc[d0][d1][16] -> P[tap][x][y]
     const int swap = e.kind - 100, d0 = e.rows_in, d1 = e.cols_in;
     const int nx = swap ? d1 : d0, ny = swap ? d0 : d1;
@@ -84,15 +88,23 @@ __global__ void pack_plan_kernel(const mmdyn_pack_entry* __restrict__ plan) {
       int x = (int)(t % nx);
       int tap = (int)(t / nx);
       int a = swap ? y : x, b = swap ? x : y;
-      dst[i] = src[((int64_t)a * d1 + b) * 16 + tap];
+      st1<TO>(dst + i, src[((int64_t)a * d1 + b) * 16 + tap]);
     }
   } else {                                   // 2-D repack with output leading dimension
     const int64_t total = (int64_t)e.rows_out * e.cols_out;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
       int c = (int)(i % e.cols_out), r = (int)(i / e.cols_out);
-      dst[(int64_t)r * e.ld_out + c] = repack_fetch(src, e.rows_in, e.cols_in, r, c, e.kind);
+      st1<TO>(dst + (int64_t)r * e.ld_out + c, repack_fetch(src, e.rows_in, e.cols_in, r, c, e.kind));
     }
   }
+}
+
+__global__ void pack_plan_kernel(const mmdyn_pack_entry* __restrict__ plan) {
+  const mmdyn_pack_entry e = plan[blockIdx.y];
+  if (e.dst_bf16)
+    pack_plan_entry<bf16_t>(e);
+  else
+    pack_plan_entry<float>(e);
 }
 
 // one thread per (output pixel, ci*4+kh): writes one float4 = the 4 kw taps; 16 threads cover a 64-float row
@@ -205,8 +217,16 @@ extern "C" const char* mmdyn_version(void) { return "mmdyn_hip 0.1 (gfx950)"; }
 extern "C" int mmdyn_pack_conv_weight(const float* Wc, float* P, int d0, int d1, int swap, void* stream) {
   if (!Wc || !P) return MMDYN_ERR_NULL;
   if (d0 <= 0 || d1 <= 0) return MMDYN_ERR_SHAPE;
-  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(ew_grid((int64_t)16 * d0 * d1)), dim3(256), 0,
+  hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(ew_grid((int64_t)16 * d0 * d1)), dim3(256), 0,
                      (hipStream_t)stream, Wc, P, d0, d1, swap);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_pack_conv_weight_b16(const float* Wc, void* P, int d0, int d1, int swap, void* stream) {
+  if (!Wc || !P) return MMDYN_ERR_NULL;
+  if (d0 <= 0 || d1 <= 0) return MMDYN_ERR_SHAPE;
+  hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, dim3(ew_grid((int64_t)16 * d0 * d1)), dim3(256), 0,
+                     (hipStream_t)stream, Wc, (bf16_t*)P, d0, d1, swap);
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -223,8 +243,17 @@ extern "C" int mmdyn_repack2d_ld(const float* in, float* out, int rows_in, int c
                                  int ld_out, int mode, void* stream) {
   if (!in || !out) return MMDYN_ERR_NULL;
   if (mode < 0 || mode > 5 || rows_out <= 0 || cols_out <= 0 || ld_out < cols_out) return MMDYN_ERR_SHAPE;
-  hipLaunchKernelGGL(repack2d_ld_kernel, dim3(ew_grid((int64_t)rows_out * cols_out)), dim3(256), 0,
+  hipLaunchKernelGGL(repack2d_ld_kernel<float>, dim3(ew_grid((int64_t)rows_out * cols_out)), dim3(256), 0,
                      (hipStream_t)stream, in, out, rows_in, cols_in, rows_out, cols_out, ld_out, mode);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_repack2d_ld_b16(const float* in, void* out, int rows_in, int cols_in, int rows_out, int cols_out,
+                                     int ld_out, int mode, void* stream) {
+  if (!in || !out) return MMDYN_ERR_NULL;
+  if (mode < 0 || mode > 5 || rows_out <= 0 || cols_out <= 0 || ld_out < cols_out) return MMDYN_ERR_SHAPE;
+  hipLaunchKernelGGL(repack2d_ld_kernel<bf16_t>, dim3(ew_grid((int64_t)rows_out * cols_out)), dim3(256), 0,
+                     (hipStream_t)stream, in, (bf16_t*)out, rows_in, cols_in, rows_out, cols_out, ld_out, mode);
   MMDYN_LAUNCH_CHECK();
 }
 

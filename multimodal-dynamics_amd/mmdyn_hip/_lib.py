@@ -20,7 +20,7 @@ class PassExperts(ctypes.Structure):
 class PackEntry(ctypes.Structure):
     """mmdyn_pack_entry (include/mmdyn_hip.h)."""
     _fields_ = [("src", _P), ("dst", _P), ("kind", _I), ("rows_in", _I), ("cols_in", _I), ("rows_out", _I),
-                ("cols_out", _I), ("ld_out", _I)]
+                ("cols_out", _I), ("ld_out", _I), ("dst_bf16", _I)]
 
 
 MAX_PASSES = 8
@@ -40,6 +40,8 @@ _SIGNATURES = {
     "mmdyn_pack_conv_weight": "pp" + "iii" + "p",
     "mmdyn_repack2d": "pp" + "iiiii" + "p",
     "mmdyn_repack2d_ld": "pp" + "iiiiii" + "p",
+    "mmdyn_pack_conv_weight_b16": "pp" + "iii" + "p",
+    "mmdyn_repack2d_ld_b16": "pp" + "iiiiii" + "p",
     "mmdyn_pack_plan": "p" + "i" + "p",
     "mmdyn_im2col_nchw3": "pp" + "iii" + "p",
     "mmdyn_col2im_k4": "pp" + "iiiiiiiiii" + "p",

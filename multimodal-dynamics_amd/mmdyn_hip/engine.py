@@ -115,16 +115,18 @@ def _with_precision(fn):
 
     @functools.wraps(fn)
     def wrapped(self, *a, **k):
-        prev, prev_sync, prev_act = getattr(ops.B, "precision", "fp32"), layers.SYNC, layers.ACT_DTYPE
+        prev, prev_sync, prev_act, prev_w = getattr(ops.B, "precision", "fp32"), layers.SYNC, layers.ACT_DTYPE, layers.W_DTYPE
         ops.B.precision = self.precision
         layers.SYNC = self._sync
         layers.ACT_DTYPE = torch.bfloat16 if self.precision == "bf16s" else torch.float32
+        layers.W_DTYPE = torch.float32 if self.precision == "fp32" else torch.bfloat16
         try:
             return fn(self, *a, **k)
         finally:
             ops.B.precision = prev
             layers.SYNC = prev_sync
             layers.ACT_DTYPE = prev_act
+            layers.W_DTYPE = prev_w
     return wrapped
 
 
@@ -189,7 +191,8 @@ class MVAEStep:
                 specs["hp"] = layers.heads_pack_specs(FP.sub("pose_encoder"))
             # what the encoder forward reads goes first (critical path); the transposed / decoder packs are launched
             # next to the encoder phase (run_late) and are ready long before the decoders start
-            self.plan = layers.PackPlan(specs, early=("W1p", "W2k", "W3k", "W4k", "Wf", "Wh", "bh"))
+            self.plan = layers.PackPlan(specs, early=("W1p", "W2k", "W3k", "W4k", "Wf", "Wh", "bh"),
+                                        w_dtype=torch.float32 if precision == "fp32" else torch.bfloat16)
         self._capturing = False
         self._graph = None
 
@@ -611,6 +614,7 @@ class MVAEInference:
         self.noise = NoiseSource(seed)
         self._sync = None
         self._graphs = {}
+        self._w_dtype = torch.float32 if precision == "fp32" else torch.bfloat16     # packed GEMM operands
         self.refresh()
 
     def _P(self, name, keys):
@@ -636,14 +640,18 @@ class MVAEInference:
             specs["ph"] = layers.heads_pack_specs(self.P["pe"])
         if getattr(self, "pk", None) is None:
             if ops.B.name == "hip":
-                self._plan = layers.PackPlan(specs)
+                self._plan = layers.PackPlan(specs, w_dtype=self._w_dtype)
                 self.pk = self._plan.packed
             else:
                 self._plan, self._specs = None, specs
         if self._plan is not None:
             self._plan.run()
         else:
-            self.pk = {k: layers.pack_now(v) for k, v in specs.items()}
+            prev_w, layers.W_DTYPE = layers.W_DTYPE, self._w_dtype
+            try:
+                self.pk = {k: layers.pack_now(v) for k, v in specs.items()}
+            finally:
+                layers.W_DTYPE = prev_w
 
     # ---- the forward itself (eager; captured by _graphed) -------------------------------------------------
     def _encode(self, key, x):
@@ -699,9 +707,10 @@ class MVAEInference:
 
     # ---- graph capture / replay ---------------------------------------------------------------------------
     def _run(self, key, fn, static_inputs, new_inputs):
-        prev, prev_act = getattr(ops.B, "precision", "fp32"), layers.ACT_DTYPE
+        prev, prev_act, prev_w = getattr(ops.B, "precision", "fp32"), layers.ACT_DTYPE, layers.W_DTYPE
         ops.B.precision = self.precision
         layers.ACT_DTYPE = torch.bfloat16 if self.precision == "bf16s" else torch.float32
+        layers.W_DTYPE = self._w_dtype
         try:
             if not (self.use_graph and self.dev.type == "cuda"):
                 return fn(*new_inputs)
@@ -726,6 +735,7 @@ class MVAEInference:
         finally:
             ops.B.precision = prev
             layers.ACT_DTYPE = prev_act
+            layers.W_DTYPE = prev_w
 
     @torch.no_grad()
     def forward(self, x, pose=None):

@@ -30,6 +30,10 @@ def _new(like, *shape, dtype=torch.float32):
 # BASELINE configs[2]), which sets torch.bfloat16 for the duration of its calls.  FC-level tensors, logits, statistics
 # and weights are always fp32.
 ACT_DTYPE = torch.float32
+# Storage type of the PACKED GEMM operands (the [tap][n][k] weight copies the pack kernels write every step): bf16 in
+# both bf16 precision modes -- the matrix cores round them to bf16 anyway, and packing them so halves the weight bytes
+# each implicit-GEMM block pulls through L2.  Master weights, biases and gradients stay fp32.
+W_DTYPE = torch.float32
 
 
 def _act(like, *shape):
@@ -278,11 +282,12 @@ def heads_pack_specs(P):
             _spec("WhT", Wl, 1, L, K, Kp, L, (Kp, 2 * L), (0, L, 2 * L))]
 
 
-def _alloc_packed(specs, like):
+def _alloc_packed(specs, like, w_dtype=None):
+    wd = W_DTYPE if w_dtype is None else w_dtype
     out = {}
     for s in specs:
-        if s["name"] not in out:
-            out[s["name"]] = torch.zeros(s["shape"], device=like.device, dtype=torch.float32)
+        if s["name"] not in out:       # matrices are GEMM operands (W_DTYPE); vectors are biases (always fp32)
+            out[s["name"]] = torch.zeros(s["shape"], device=like.device, dtype=wd if len(s["shape"]) >= 2 else torch.float32)
     return out
 
 
@@ -294,7 +299,7 @@ def pack_now(specs):
         if s["kind"] >= K_KEEP:
             ops.B.pack_conv_weight(s["src"], dst, s["rin"], s["cin"], s["kind"] - K_KEEP)
         elif s["part"] is None:
-            ops.B.repack2d(s["src"], dst, s["rin"], s["cin"], s["rout"], s["cout"], s["kind"])
+            ops.B.repack2d_ld(s["src"], dst, s["rin"], s["cin"], s["rout"], s["cout"], s["cout"], s["kind"])
         else:
             r0, c0, ld = s["part"]
             corner = dst.view(-1)[r0 * ld + c0:]
@@ -306,7 +311,7 @@ class PackPlan:
     """All repacks of the given spec lists as ONE kernel launch (mmdyn_pack_plan).  Source and destination
     storage must not move afterwards (the fused engine's flat parameter buffer and these outputs never do)."""
 
-    def __init__(self, named_specs, early=()):
+    def __init__(self, named_specs, early=(), w_dtype=None):
         """``early``: names of the packed tensors the first phase of the step needs; they go to the front of the
         table so that :meth:`run_early` / :meth:`run_late` can launch the two halves at different points."""
         import ctypes
@@ -314,7 +319,7 @@ class PackPlan:
         self.packed, entries = {}, []
         order = []
         for key, specs in named_specs.items():
-            outs = _alloc_packed(specs, specs[0]["src"])
+            outs = _alloc_packed(specs, specs[0]["src"], w_dtype)
             self.packed[key] = outs
             order += [(0 if s["name"] in early else 1, len(order) + i, outs, s) for i, s in enumerate(specs)]
         order.sort(key=lambda t: (t[0], t[1]))
@@ -329,8 +334,9 @@ class PackPlan:
                     e.dst, e.rows_out, e.cols_out, e.ld_out = dst.data_ptr(), 0, 0, 0
                 else:
                     r0, c0, ld = s["part"] if s["part"] is not None else (0, 0, s["cout"])
-                    e.dst = dst.data_ptr() + 4 * (r0 * ld + c0)
+                    e.dst = dst.data_ptr() + dst.element_size() * (r0 * ld + c0)
                     e.rows_out, e.cols_out, e.ld_out = s["rout"], s["cout"], ld
+                e.dst_bf16 = int(dst.dtype == torch.bfloat16)
                 entries.append(e)
         self.n = len(entries)
         arr = (PackEntry * self.n)(*entries)

@@ -75,15 +75,15 @@ class HipBackend:
     # ---- GEMMs ----
     def igemm_nt(self, A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride,
                  offset, act, splitk):
-        (pa, a16), (pc, c16), (pca, ca16) = _aptr(A), _aptr(C), _aptr(C_act)
-        if a16 or c16 or ca16:                       # bf16 activation storage: the mixed-storage entry point
+        (pa, a16), (pc, c16), (pca, ca16), (pb, b16) = _aptr(A), _aptr(C), _aptr(C_act), _aptr(Bp)
+        if a16 or c16 or ca16 or b16:      # bf16 activation storage / bf16 packed weights: the mixed-storage entry point
             if self.precision == "fp32" or (c16 and splitk != 1) or (C_act is not None and ca16 != c16):
-                raise ValueError("mmdyn_hip: bf16 activation tensors need a bf16 precision mode, no split-K into a "
+                raise ValueError("mmdyn_hip: bf16 tensors need a bf16 precision mode, no split-K into a "
                                  "bf16 output, and C / C_act of one type")
-            check(self.lib.mmdyn_igemm_nt_mx(pa, _ptr(Bp), _ptr(bias), pc, pca, _ptr(stats), _ptr(ws), None, None, None,
+            check(self.lib.mmdyn_igemm_nt_mx(pa, pb, _ptr(bias), pc, pca, _ptr(stats), _ptr(ws), None, None, None,
                                              None, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act,
-                                             splitk, 1 | (2 if a16 else 0) | (4 if c16 else 0), _stream()),
-                  "mmdyn_igemm_nt_mx")
+                                             splitk, 1 | (2 if a16 else 0) | (4 if c16 else 0) | (16 if b16 else 0),
+                                             _stream()), "mmdyn_igemm_nt_mx")
             return
         fn = self.lib.mmdyn_igemm_nt_bf16 if self.precision != "fp32" else self.lib.mmdyn_igemm_nt
         check(fn(pa, _ptr(Bp), _ptr(bias), pc, pca, _ptr(stats), _ptr(ws),
@@ -91,14 +91,14 @@ class HipBackend:
 
     def igemm_nt_dgrad_bn(self, A, Bp, C, stats, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N,
                           stride, offset):
-        (pa, a16), (pc, c16), (py, y16) = _aptr(A), _aptr(C), _aptr(y)
-        if a16 or c16 or y16:
+        (pa, a16), (pc, c16), (py, y16), (pb, b16) = _aptr(A), _aptr(C), _aptr(y), _aptr(Bp)
+        if a16 or c16 or y16 or b16:
             if self.precision == "fp32":
-                raise ValueError("mmdyn_hip: bf16 activation tensors need a bf16 precision mode")
-            check(self.lib.mmdyn_igemm_nt_mx(pa, _ptr(Bp), None, pc, None, _ptr(stats), None, py, _ptr(mean), _ptr(rstd),
+                raise ValueError("mmdyn_hip: bf16 tensors need a bf16 precision mode")
+            check(self.lib.mmdyn_igemm_nt_mx(pa, pb, None, pc, None, _ptr(stats), None, py, _ptr(mean), _ptr(rstd),
                                              _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride,
                                              offset, ACT_NONE, 1, 1 | (2 if a16 else 0) | (4 if c16 else 0) |
-                                             (8 if y16 else 0), _stream()), "mmdyn_igemm_nt_mx")
+                                             (8 if y16 else 0) | (16 if b16 else 0), _stream()), "mmdyn_igemm_nt_mx")
             return
         check(self.lib.mmdyn_igemm_nt_dgrad_bn(pa, _ptr(Bp), pc, _ptr(stats), py, _ptr(mean), _ptr(rstd),
                                                _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride,
@@ -127,17 +127,22 @@ class HipBackend:
 
     # ---- packing / layout ----
     def pack_conv_weight(self, Wc, P, d0, d1, swap):
-        check(self.lib.mmdyn_pack_conv_weight(_ptr(Wc), _ptr(P), d0, d1, int(swap), _stream()),
-              "mmdyn_pack_conv_weight")
+        pp, p16 = _aptr(P)                 # a bf16 destination: the GEMM operand type of the bf16 precision modes
+        fn = self.lib.mmdyn_pack_conv_weight_b16 if p16 else self.lib.mmdyn_pack_conv_weight
+        check(fn(_ptr(Wc), pp, d0, d1, int(swap), _stream()), "mmdyn_pack_conv_weight")
 
     def repack2d(self, src, dst, rows_in, cols_in, rows_out, cols_out, mode):
+        if dst.dtype == torch.bfloat16:
+            return self.repack2d_ld(src, dst, rows_in, cols_in, rows_out, cols_out, cols_out, mode)
         check(self.lib.mmdyn_repack2d(_ptr(src), _ptr(dst), rows_in, cols_in, rows_out, cols_out, mode, _stream()),
               "mmdyn_repack2d")
 
     def repack2d_ld(self, src, dst, rows_in, cols_in, rows_out, cols_out, ld_out, mode):
-        """dst: any fp32 view whose first element is the block's top-left corner (row stride ld_out)."""
-        check(self.lib.mmdyn_repack2d_ld(_ptr(src), dst.data_ptr(), rows_in, cols_in, rows_out, cols_out, ld_out, mode,
-                                         _stream()), "mmdyn_repack2d_ld")
+        """dst: any fp32 (or bf16) view whose first element is the block's top-left corner (row stride ld_out)."""
+        _aptr(dst)                         # device / contiguity / dtype check
+        fn = self.lib.mmdyn_repack2d_ld_b16 if dst.dtype == torch.bfloat16 else self.lib.mmdyn_repack2d_ld
+        check(fn(_ptr(src), dst.data_ptr(), rows_in, cols_in, rows_out, cols_out, ld_out, mode, _stream()),
+              "mmdyn_repack2d_ld")
 
     def pack_plan(self, plan_dev, n):
         """plan_dev: uint8 device tensor holding n mmdyn_pack_entry structs (see layers.PackPlan)."""

@@ -41,7 +41,7 @@ class EmuBackend:
     # ops that may see bf16 ACTIVATION tensors (bf16-storage mode): the emulation computes in fp32 on widened copies
     # and rounds what it wrote back into the bf16 tensors (RNE), which is the kernels' contract
     BF16_OPS = ("igemm_nt", "igemm_nt_dgrad_bn", "wgrad_tn", "bn_swish_fwd", "bn_swish_bwd_reduce", "bn_swish_bwd_apply",
-                "act_bwd", "tconv_out3_fwd")
+                "act_bwd", "tconv_out3_fwd", "pack_conv_weight", "repack2d", "repack2d_ld")
 
     def __init__(self):
         self.lib = _lib.load()   # host-only helpers (tile counts) come from the real library

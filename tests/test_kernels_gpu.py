@@ -487,6 +487,34 @@ def test_conv3_direct_kernels(G, Bg):
              lambda i, t: t.sum(0), tol=5e-5)
 
 
+def test_bf16_packed_weights(bf16_mode):
+    """bf16 precision modes pack the GEMM operands straight to bf16 (pack kernels with a bf16 destination) and the
+    implicit GEMM reads them as such: same products as rounding fp32 packed weights inside the kernel."""
+    f32 = lambda i, t: t.float()
+    Wc = rnd(128, 64, 4, 4, seed=101, scale=0.2)
+    for swap in (0, 1):
+        both("pack_conv_weight", [Wc, torch.zeros(16, 64 if swap else 128, 128 if swap else 64, dtype=torch.bfloat16), 128, 64, swap],
+             [1], f32, tol=0.0)
+    W = rnd(40, 500, seed=102)
+    out = torch.zeros(64, 512, dtype=torch.bfloat16)
+    both("repack2d_ld", [W, out.view(-1)[512 * 8:], 40, 500, 40, 512, 512, 0], [1], f32, tol=0.0)
+    for mode, G, Bg, Hi, Cin, Ho, N, stride, offset in ((CONV, 2, 3, 16, 64, 8, 128, 2, -1), (TCONV_S2P1, 1, 5, 8, 128, 16, 64, 1, 0),
+                                                       (DENSE, 1, 300, 1, 512, 1, 512, 1, 0), (TCONV_S1P0, 2, 70, 5, 256, 8, 128, 1, 0)):
+        Bt, taps = G * Bg, 16 if mode != DENSE else 1
+        Bp = bf(rnd(taps, N, Cin, seed=103, scale=0.2))
+        for a_dtype in (torch.float32, torch.bfloat16):
+            A = rnd(Bt * Hi * Hi, Cin, seed=104)
+            A = bf(A) if a_dtype == torch.bfloat16 else A
+            C = torch.zeros(Bt * Ho * Ho, N, dtype=a_dtype)
+            both("igemm_nt", [A, Bp, None, C, None, None, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1],
+                 [3], f32, tol=4e-3 if a_dtype == torch.bfloat16 else 2e-5)
+    # the 3-channel layer's kernel takes the bf16 [32][64] operand too
+    x = rnd(3, 3, 64, 64, seed=105)
+    Bp = bf(rnd(1, 32, 64, seed=106, scale=0.2))
+    both("igemm_nt", [x, Bp, None, torch.zeros(3 * 1024, 32), torch.zeros(3 * 1024, 32), None, None, IM2COL3, 1, 3, 64, 64, 64, 32,
+                      32, 32, 32, 1, 0, 1, 1], [3, 4])
+
+
 def test_sgd_matches_torch():
     n = 50001
     p0, g = rnd(n, seed=80), rnd(n, seed=81) * 0.1
