@@ -205,6 +205,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
+    host_enqueue = time.perf_counter() - t0      # host side done enqueueing; the GPU is still running if it is ahead
     torch.cuda.synchronize()
     if pg is not None:
         dist.barrier()
@@ -252,7 +253,7 @@ def main():
                     + " and master weights), seq_modeling train step, per-GPU share of BASELINE configs[2]"),
                    "global_batch": global_batch, "parallelism": f"dp{world}", "bn": "sync" if (args.sync_bn and pg is not None) else "local",
                    "launch": "eager" if (args.no_graph or (args.sync_bn and pg is not None)) else "hip_graph",
-                   "final_loss": final_loss},
+                   "final_loss": final_loss, "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps},
         "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": pmc_traffic(dom_name) if args.dtype == "f32" else None,

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Diagnostic (no profiler attached): when, inside a graph-replayed train step, does each lane's graph of every stage
+start and end?  HIP events are recorded on the lane streams around every graph launch of the last of a few steps."""
+import os
+import sys
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-dynamics_amd"))
+from mmdyn_hip.engine import MVAEStep  # noqa: E402
+from mmdyn_hip.models import setup_model, NoiseSource  # noqa: E402
+from mmdyn_hip.utils.seeded_init import seeded_batch  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda")
+    prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+    torch.manual_seed(0)
+    model = setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=4096, architecture="cnn", conditional=False,
+                        categorical_conditions=False, latent_size=256, use_pose=True).to(dev).train()
+    step = MVAEStep(model, noise=NoiseSource(1), precision=prec)
+    inputs, targets = seeded_batch(256, 1234)
+    inputs, targets = [x.to(dev) for x in inputs], [x.to(dev) for x in targets]
+    for _ in range(5):
+        step.train_step_graphed(inputs, targets, 0.02)
+    marks = []
+    E = lambda: torch.cuda.Event(enable_timing=True)
+
+    def replay(captured):
+        LN = step.lanes
+        main = torch.cuda.current_stream()
+        side = {"l0": LN.side[0], "l1": LN.side[1]}
+        handles = []
+        for ri, row in enumerate(captured):
+            if len(row) == 1:
+                a, b = E(), E()
+                a.record()
+                row[0][1].replay()
+                b.record()
+                marks.append((ri, "main", a, b))
+                continue
+            ev = main.record_event()
+            for lane, g in row:
+                if lane != "main":
+                    side[lane].wait_event(ev)
+                    with torch.cuda.stream(side[lane]):
+                        a, b = E(), E()
+                        a.record()
+                        g.replay()
+                        b.record()
+                        marks.append((ri, lane, a, b))
+            for lane, g in row:
+                if lane == "main":
+                    a, b = E(), E()
+                    a.record()
+                    g.replay()
+                    b.record()
+                    marks.append((ri, "main", a, b))
+            for lane, g in row:
+                if lane != "main":
+                    main.wait_event(side[lane].record_event())
+        return handles
+
+    step._replay = replay
+    for _ in range(3):
+        marks.clear()
+        torch.cuda.synchronize()
+        step.train_step_graphed(inputs, targets, 0.02)
+    torch.cuda.synchronize()
+    ref = marks[0][2]
+    for ri, lane, a, b in marks:
+        print(f"stage {ri} {lane:4s} start {ref.elapsed_time(a):7.3f} ms  end {ref.elapsed_time(b):7.3f} ms  ({a.elapsed_time(b):6.3f})")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Diagnostic on a rocprofv3 --kernel-trace CSV of bench.py (two lanes, graph replay): per step, how long at least one
+MFMA kernel (igemm_nt / wgrad_tn / conv3) is running, how long only other kernels run, how long nothing runs, and
+which non-MFMA kernels account for the MFMA-free time.
+CAVEAT (measured): under the profiler the two lanes' graphs start up to 1.6 ms apart, so the trace overstates the
+MFMA-free time; without a profiler attached the lanes start and end within 50 us of each other
+(tests/microbench/lane_timeline.py, HIP events) and the step is close to the serial sum of its MFMA kernels.
+usage: trace_overlap.py <kernel_trace.csv> [steps_to_skip]"""
+import collections
+import csv
+import sys
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    skip = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows]
+    ev.sort()
+    # step boundaries: the Adam kernel ends a step
+    adam_ends = [e for s, e, n in ev if "adam_kernel" in n]
+    if len(adam_ends) < skip + 3:
+        print("not enough steps in trace", len(adam_ends))
+        return
+    t0, t1 = adam_ends[skip], adam_ends[-2]          # (the last step of bench.py is its eager single-lane profiling step)
+    nsteps = len(adam_ends) - 2 - skip
+    win = [(max(s, t0), min(e, t1), n) for s, e, n in ev if e > t0 and s < t1]
+    is_mfma = lambda n: ("igemm_nt_kernel" in n) or ("wgrad_tn" in n) or ("conv3_" in n)
+    pts = []
+    for s, e, n in win:
+        pts.append((s, 1, n))
+        pts.append((e, -1, n))
+    pts.sort(key=lambda p: (p[0], p[1]))
+    active = collections.Counter()
+    n_m = n_o = 0
+    last = t0
+    t_m = t_o = t_idle = 0
+    blame = collections.Counter()
+    for t, d, n in pts:
+        dt = t - last
+        if dt > 0:
+            if n_m > 0:
+                t_m += dt
+            elif n_o > 0:
+                t_o += dt
+                for k, c in active.items():
+                    if c > 0:
+                        blame[k] += dt / sum(1 for c2 in active.values() if c2 > 0)
+            else:
+                t_idle += dt
+        last = t
+        short = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:48]
+        if is_mfma(n):
+            n_m += d
+        else:
+            n_o += d
+            active[short] += d
+    tot = (t1 - t0) / nsteps / 1e6
+    print(f"{nsteps} steps, {tot:.3f} ms/step: MFMA kernel running {t_m / nsteps / 1e6:.3f} ms, only other kernels "
+          f"{t_o / nsteps / 1e6:.3f} ms, idle {t_idle / nsteps / 1e6:.3f} ms")
+    for k, v in blame.most_common(16):
+        print(f"   {k:50s} {v / nsteps / 1e3:8.1f} us/step")
+
+
+if __name__ == "__main__":
+    main()
