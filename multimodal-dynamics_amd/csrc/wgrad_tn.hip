@@ -229,6 +229,168 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
     }
 }
 
+// ---- all-bf16 variant (bf16-storage mode: D and Gt are bf16 in HBM) ------------------------------------------------
+// Same problem split (tile, tap, chunk) and partial-slab output as wgrad_tn_kernel, but the operand path is built for
+// 16-bit data on CDNA4: 16-byte global loads (eight bf16), bf16 tiles in LDS, and the k-strided MFMA fragments (the
+// reduction index is the tile ROW) fetched with the hardware transposing read ds_read_b64_tr_b16: per 16-lane group it
+// returns, for each of 16 consecutive columns, the four elements of four consecutive rows -- two of them are one
+// operand of v_mfma_f32_32x32x16_bf16.  Against the fp32-LDS path above (four strided ds_read_b32 + a pack per 8-deep
+// MFMA) this is 4x fewer LDS cycles per k, no conversion VALU work and half the MFMA issues.
+// Row stride of a tile: bytes = 64 (mod 256), so the four rows of a transposed read (64 B each) fill all 64 banks.
+typedef __bf16 wb16x8 __attribute__((ext_vector_type(8)));
+template <int BX> struct b16_ld { static constexpr int v = (BX == 32) ? 32 : BX + 32; };   // in elements
+
+// (waves_per_eu: without the hint the register allocator aims at eight waves per SIMD and spills the prefetched
+//  granules to scratch right after loading them)
+template <int MODE, int BD, int BG, int WD, int WG, int WK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void wgrad_b16_kernel(const bf16_t* __restrict__ D, const bf16_t* __restrict__ Gt,
+                                                        float* __restrict__ partial, const WgradGeom g) {
+  constexpr int DT = WD / 32, GT = WG / 32;
+  constexpr int WAVES_G = BG / WG;
+  constexpr int WAVES_DG = (BD / WD) * WAVES_G;
+  static_assert(WAVES_DG * WK == 4 && (WK == 1 || WK == 2), "4 waves per block, at most two of them share a tile");
+  constexpr int LDD = b16_ld<BD>::v, LDG = b16_ld<BG>::v;
+  constexpr int DV = BD / 8, GV = BG / 8;                    // 16-byte granules per tile row
+  constexpr int D_LOADS = (RK * DV + 255) / 256, G_LOADS = (RK * GV + 255) / 256;
+  constexpr bool D_ALL = (RK * DV) % 256 == 0, G_ALL = (RK * GV) % 256 == 0;
+
+  __shared__ __attribute__((aligned(16))) bf16_t Ds[RK * LDD];
+  __shared__ __attribute__((aligned(16))) bf16_t Gs[RK * LDG];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / WAVES_DG, wdg = wave % WAVES_DG;
+  const int wd = wdg / WAVES_G, wg = wdg % WAVES_G;
+  const int tiles_g = g.Cg / BG;
+  const int td = blockIdx.x / tiles_g, tg = blockIdx.x - td * tiles_g;
+  const int cd0 = td * BD, cg0 = tg * BG;
+  const int tap = blockIdx.y, chunk = blockIdx.z;
+  const int dh = (MODE == MMDYN_CONV) ? (tap >> 2) : 0;      // (the gather mode is a template parameter: the fetch below
+  const int dw = (MODE == MMDYN_CONV) ? (tap & 3) : 0;       //  must stay one basic block, see wgrad_tn_kernel)
+  const int HWr = g.Hr * g.Wr;
+  const int row_begin = chunk * g.rows_per_chunk;
+  const int row_end = min(g.rows, row_begin + g.rows_per_chunk);
+  const float inv_hw = 1.0f / (float)HWr, inv_w = 1.0f / (float)g.Wr;
+  auto fdiv = [](int n, int d, float inv, int& q, int& r) {
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { q -= 1; r += d; }
+    if (r >= d) { q += 1; r -= d; }
+  };
+
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));     // (a native vector: arrays of HIP's uint4 struct with a
+  u32x4 rd[D_LOADS], rg[G_LOADS];                                  //  whole-struct select end up in scratch memory)
+  unsigned okd = 0, okg = 0;
+  auto gload = [&](int r0) {          // branch-free: masked rows read a valid dummy address, zeroed at the LDS store
+#pragma unroll
+    for (int i = 0; i < D_LOADS; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx / DV, v = idx - r * DV;
+      const int row = r0 + r;
+      const bool ok = (D_ALL || idx < RK * DV) & (row < row_end);
+      rd[i] = *reinterpret_cast<const u32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + (D_ALL || idx < RK * DV ? v : 0) * 8);
+      okd = ok ? (okd | (1u << i)) : (okd & ~(1u << i));
+    }
+#pragma unroll
+    for (int i = 0; i < G_LOADS; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx / GV, v = idx - r * GV;
+      const int row = r0 + r;
+      bool ok = (G_ALL || idx < RK * GV) & (row < row_end);
+      int pix = row;
+      if constexpr (MODE == MMDYN_CONV) {
+        int bb, p, rr, cc;
+        fdiv(row, HWr, inv_hw, bb, p);
+        fdiv(p, g.Wr, inv_w, rr, cc);
+        const int y = rr * g.rs + g.ro + dh, xx = cc * g.rs + g.ro + dw;
+        ok = ok & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)xx < (unsigned)g.Wi);
+        pix = (bb * g.Hi + y) * g.Wi + xx;
+      }
+      rg[i] = *reinterpret_cast<const u32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + (G_ALL || idx < RK * GV ? v : 0) * 8);
+      okg = ok ? (okg | (1u << i)) : (okg & ~(1u << i));
+    }
+  };
+  auto lds_store = [&]() {
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < D_LOADS; ++i) {
+      const int idx = tid + 256 * i;
+      if (D_ALL || idx < RK * DV) {
+        const int r = idx / DV, v = idx - r * DV;
+        *reinterpret_cast<u32x4*>(&Ds[r * LDD + v * 8]) = ((okd >> i) & 1u) ? rd[i] : zero;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G_LOADS; ++i) {
+      const int idx = tid + 256 * i;
+      if (G_ALL || idx < RK * GV) {
+        const int r = idx / GV, v = idx - r * GV;
+        *reinterpret_cast<u32x4*>(&Gs[r * LDG + v * 8]) = ((okg >> i) & 1u) ? rg[i] : zero;
+      }
+    }
+  };
+
+  f32x16 acc[DT][GT];
+#pragma unroll
+  for (int a = 0; a < DT; ++a)
+#pragma unroll
+    for (int b = 0; b < GT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  // transposed-read lane roles: group gq = lane>>4 (columns 16*(gq&1).., k half gq>>1), lane 4q+p of the group supplies
+  // the address of row q, columns 4p..4p+3 of its block
+  const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int trow = 8 * (gq >> 1) + tq, tcol = 16 * (gq & 1) + 4 * tp;
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+  auto frag = [&](const bf16_t* tile, int ld, int col0, int k0) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(&tile[(k0 + trow) * ld + col0 + tcol]));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(&tile[(k0 + trow + 4) * ld + col0 + tcol]));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(wb16x8, v);
+  };
+
+  const int h = lane >> 5, cl = lane & 31;
+  if (row_begin < row_end) {
+    gload(row_begin);
+    lds_store();
+    __syncthreads();
+    for (int r0 = row_begin; r0 < row_end; r0 += RK) {
+      gload(r0 + RK);                      // past the chunk end every row is masked: a harmless dummy fetch
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kc = wk * (2 / WK); kc < (wk + 1) * (2 / WK); ++kc) {          // 16 rows per MFMA; WK waves split the 32
+        wb16x8 pa[DT], pb[GT];
+#pragma unroll
+        for (int a = 0; a < DT; ++a) pa[a] = frag(Ds, LDD, wd * WD + a * 32, kc * 16);
+#pragma unroll
+        for (int b = 0; b < GT; ++b) pb[b] = frag(Gs, LDG, wg * WG + b * 32, kc * 16);
+#pragma unroll
+        for (int a = 0; a < DT; ++a)
+#pragma unroll
+          for (int b = 0; b < GT; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a], pb[b], acc[a][b], 0, 0, 0);
+      }
+      __syncthreads();
+      lds_store();
+      __syncthreads();
+    }
+  }
+
+  float* out = partial + ((size_t)((chunk * WK + wk) * g.ntaps + tap) * g.Cd) * g.Cg;
+#pragma unroll
+  for (int a = 0; a < DT; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int cd = cd0 + wd * WD + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+#pragma unroll
+      for (int b = 0; b < GT; ++b) {
+        const int cg = cg0 + wg * WG + b * 32 + cl;
+        out[(size_t)cd * g.Cg + cg] = acc[a][b][e];
+      }
+    }
+}
+
 // Four-taps-per-block variant for the small-channel convolutions (tile <= 64x64): the four waves of a block own
 // the four kw taps of one kernel row kh and share ONE dense-operand tile, so D is fetched once per 4 taps instead
 // of once per tap (half the L2 traffic of the one-tap kernel on these shapes) and no wave has to split the row
@@ -470,6 +632,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __re
 }
 
 template <int BD, int BG, int WD, int WG, int WK>
+static int launch_b16(const float* D, const float* Gt, float* partial, WgradGeom g, hipStream_t st) {
+  const int zblocks = g.chunks / WK;
+  int rpc = ceil_div(g.rows, zblocks);
+  g.rows_per_chunk = ceil_div(rpc, RK) * RK;
+  dim3 grid((g.Cd / BD) * (g.Cg / BG), g.ntaps, zblocks);
+  if (g.mode == MMDYN_CONV)
+    hipLaunchKernelGGL((wgrad_b16_kernel<MMDYN_CONV, BD, BG, WD, WG, WK>), grid, dim3(256), 0, st,
+                       reinterpret_cast<const bf16_t*>(D), reinterpret_cast<const bf16_t*>(Gt), partial, g);
+  else
+    hipLaunchKernelGGL((wgrad_b16_kernel<MMDYN_DENSE, BD, BG, WD, WG, WK>), grid, dim3(256), 0, st,
+                       reinterpret_cast<const bf16_t*>(D), reinterpret_cast<const bf16_t*>(Gt), partial, g);
+  MMDYN_LAUNCH_CHECK();
+}
+
+template <int BD, int BG, int WD, int WG, int WK>
 static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, hipStream_t st, bool bf16) {
   const int zblocks = g.chunks / WK;  // chunks % 4 == 0 is checked by the caller
   int rpc = ceil_div(g.rows, zblocks);
@@ -521,6 +698,15 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
     if (rc != 1) return rc;
   }
   const bool d64 = (Cd % 64 == 0), g64 = (Cg % 64 == 0);
+  if (bf16 && g.d_b16 && g.g_b16 && mode != MMDYN_IM2COL3 && !getenv("MMDYN_NO_WGRAD_B16")) {
+    // both operands bf16 in HBM: the transposing-LDS-read kernel (two waves share a 64x32 / 32x64 tile's rows)
+    if (Cd % 128 == 0 && Cg % 128 == 0) return launch_b16<128, 128, 64, 64, 1>(D, Gt, partial, g, st);
+    if (d64 && g64) return launch_b16<64, 64, 32, 32, 1>(D, Gt, partial, g, st);
+    if (mode == MMDYN_DENSE) {           // (narrow convolution tiles stay on the four-tap kernel below: measured faster)
+      if (d64) return launch_b16<64, 32, 32, 32, 2>(D, Gt, partial, g, st);
+      if (g64) return launch_b16<32, 64, 32, 32, 2>(D, Gt, partial, g, st);
+    }
+  }
   if (Cd % 128 == 0 && Cg % 128 == 0) return launch<128, 128, 64, 64, 1>(D, Gt, partial, g, st, bf16);
   if (mode == MMDYN_CONV && !(d64 && g64)) {   // narrow channel tiles: four kw taps per block share the dense
     if (d64) return launch4<64, 32>(D, Gt, partial, g, st, bf16);   // operand (measured +11 %; 64x64 tiles are faster

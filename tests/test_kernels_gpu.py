@@ -224,7 +224,10 @@ def test_elementwise_bf16_storage(bf16_mode):
     a = bf(rnd(2 * 32 * 32, 32, seed=57))
     both("tconv_out3_fwd", [a, rnd(32, 3, 4, 4, seed=58, scale=0.2), torch.zeros(2, 3, 64, 64), 2, 32, 32], [2], tol=2e-5)
     # wgrad with bf16 operands (dense, conv and the im2col mode with a bf16 dense operand)
-    for mode, Bt, Hr, Cd, Hi, Cg, stride, offset in ((DENSE, 300, 1, 512, 1, 512, 1, 0), (CONV, 3, 8, 128, 16, 64, 2, -1)):
+    # (all tile shapes of the all-bf16 kernel: 128x128, 64x64, 64x32 and 32x64 with two waves per tile, ragged row counts)
+    for mode, Bt, Hr, Cd, Hi, Cg, stride, offset in ((DENSE, 300, 1, 512, 1, 512, 1, 0), (CONV, 3, 8, 128, 16, 64, 2, -1),
+                                                     (CONV, 5, 5, 256, 8, 128, 1, 0), (CONV, 3, 16, 64, 32, 32, 2, -1),
+                                                     (CONV, 2, 8, 32, 16, 64, 2, -1), (DENSE, 77, 1, 256, 1, 6400, 1, 0)):
         rows, taps = Bt * Hr * Hr, 16 if mode == CONV else 1
         D, Gt = bf(rnd(rows, Cd, seed=59)), bf(rnd(Bt * Hi * Hi, Cg, seed=60))
         chunks = HIP.wgrad_chunks(mode, rows, Cd, Cg)
