@@ -64,7 +64,9 @@ __device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {
   return r;
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16, bool B16>
+// WIDE (bf16 activations AND bf16 packed weights, Cin % 64 == 0): K-step of 64 channels moved as 16-byte granules of
+// eight bf16; thread -> (row, granule) mapping and LDS bytes per row (144) are the same as in the 32-channel variants
+template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16, bool B16, bool WIDE = false>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__ A,
                                                        const float* __restrict__ Bp,
                                                        const float* __restrict__ bias,
@@ -75,6 +77,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
   static_assert(WAVES_N * WAVES_M == 4, "4 waves per block");
+  static_assert(!WIDE || (BF16 && A16 && B16), "the 64-channel K-step is a bf16-operand variant");
+  constexpr int KB = WIDE ? 64 : BK;                  // channels per K-step
   constexpr int A_LOADS = BM / ROWS_PER_PASS, B_LOADS = BN / ROWS_PER_PASS;
   static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile smaller than one load pass");
   constexpr int STAGE = (BM + BN) * LDS_LD;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
     rx[i] = rowinfo[r * 4 + 2];
   }
 
-  const int cin_steps = g.Cin / BK;
+  const int cin_steps = g.Cin / KB;
   const int total_steps = (MODE == MMDYN_TCONV_S1P0 ? nkh * nkw : g.ntaps) * cin_steps;
   const int per_split = (total_steps + g.splitk - 1) / g.splitk;
   const int s_begin = split * per_split;
@@ -171,16 +175,18 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   f32x4 ra[A_LOADS], rbv[B_LOADS];
   uint2 ra16[A_LOADS];          // A16: the raw bf16 granule (widening it here would wait for the load before the MFMAs)
   uint2 rbv16[B_LOADS];         // B16: likewise for bf16 packed weights
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // (native vector: arrays of HIP's uint4 struct spill to scratch)
+  u32x4 raw[A_LOADS], rbw[B_LOADS];   // WIDE: eight bf16 per granule
   unsigned okmask = 0;
   // bf16 matrix-core variants keep the tiles in LDS as bf16 ([row][40] halves: 32 + one 16-byte pad slot): half the
   // LDS bytes, one ds_read_b128 per operand and 16-deep MFMA, conversion once per element on the store side
-  constexpr int LDH = BK + 8;
+  constexpr int LDH = KB + 8;
   bf16_t* As16 = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Bs16 = As16 + BM * LDH;
   int tap = s_begin / cin_steps;            // running (tap, channel-step) position of the NEXT fetch
   int cstep = s_begin - tap * cin_steps;
   auto gload = [&]() {
-    const int c0 = cstep * BK + gran * 4;
+    const int c0 = cstep * KB + gran * (WIDE ? 8 : 4);
     int dh = 0, dw = 0, wi = 0;
     if (MODE == MMDYN_CONV) {
       dh = tap >> 2;
@@ -223,7 +229,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       const int y = ry[i] + dh, x = rx[i] + dw;
       const bool ok = (rb[i] >= 0) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
       const int pix = ok ? (rb[i] * g.Hi + y) * g.Wi + x : 0;
-      if constexpr (A16)          // compile-time: the fetch stays one branch-free basic block
+      if constexpr (WIDE)
+        raw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(A) + (size_t)pix * g.Cin + c0);
+      else if constexpr (A16)     // compile-time: the fetch stays one branch-free basic block
         ra16[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(A) + (size_t)pix * g.Cin + c0);
       else
         ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)pix * g.Cin + c0);
@@ -232,7 +240,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < B_LOADS; ++j) {
       const int n = n0 + lrow + ROWS_PER_PASS * j;
-      if constexpr (B16)
+      if constexpr (WIDE)
+        rbw[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(Bp) + ((size_t)wi * g.N + n) * g.Cin + c0);
+      else if constexpr (B16)
         rbv16[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(Bp) + ((size_t)wi * g.N + n) * g.Cin + c0);
       else
         rbv[j] = *reinterpret_cast<const f32x4*>(Bp + ((size_t)wi * g.N + n) * g.Cin + c0);
@@ -247,6 +257,16 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
     tap = last ? tap : ntap;
   };
   auto lds_store = [&]() {
+    if constexpr (WIDE) {
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i)
+        *reinterpret_cast<u32x4*>(&As16[(lrow + ROWS_PER_PASS * i) * LDH + gran * 8]) = ((okmask >> (4 * i)) & 1u) ? raw[i] : zero;
+#pragma unroll
+      for (int j = 0; j < B_LOADS; ++j)
+        *reinterpret_cast<u32x4*>(&Bs16[(lrow + ROWS_PER_PASS * j) * LDH + gran * 8]) = rbw[j];
+      return;
+    }
     if constexpr (BF16) {
 #pragma unroll
       for (int i = 0; i < A_LOADS; ++i) {
@@ -310,7 +330,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       if constexpr (BF16) {
         const int frag16 = (lane & 31) * LDH + (lane >> 5) * 8;      // lane (row i, half h): k = 16m + 8h .. +7
 #pragma unroll
-        for (int m = 0; m < BK / 16; ++m) {
+        for (int m = 0; m < KB / 16; ++m) {
           bf16x8 pa[MT], pb[NT];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
@@ -518,6 +538,9 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
                      C_act, stats, ws, g)
   constexpr bool CAN_A16 = MODE != MMDYN_IM2COL3;
   if (!bf16) IGEMM_LAUNCH(false, false, false);
+  else if (g.a_b16 && g.b_b16 && CAN_A16 && g.Cin % 64 == 0 && !getenv("MMDYN_NO_WIDE"))
+    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, CAN_A16, true, CAN_A16>), grid, dim3(256), smem, st, A, Bp,
+                       bias, C, C_act, stats, ws, g);
   else if (g.a_b16 && g.b_b16) IGEMM_LAUNCH(true, CAN_A16, true);
   else if (g.a_b16) IGEMM_LAUNCH(true, CAN_A16, false);
   else if (g.b_b16) IGEMM_LAUNCH(true, false, true);
