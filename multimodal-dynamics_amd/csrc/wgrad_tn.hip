@@ -43,9 +43,14 @@ __device__ __forceinline__ s16x4 pack4_bf16(float a, float b, float c, float d) 
   return __builtin_bit_cast(s16x4, r);
 }
 
-// ST: operand storage known at compile time (keeps the fetch one branch-free basic block): 1 = D and Gt bf16,
-// 2 = D bf16 / Gt fp32, 0 = read the run-time flags (fp32 operands and the rare mixed case)
-template <int BD, int BG, int WD, int WG, int WK, bool BF16, int ST>
+// ST: operand storage, always a compile-time constant (a run-time test inside the fetch puts every load in its own
+// branch and the loads then wait for one another): 0 = D and Gt fp32, 1 = both bf16, 2 = D bf16 / Gt fp32,
+// 3 = D fp32 / Gt bf16
+// MODE (DENSE / CONV / IM2COL3) is a template parameter: with a run-time mode test inside the fetch each gathered load
+// sat in its own branch, and because the two sides of the branch write the same registers the compiler put
+// s_waitcnt vmcnt(0) in front of every one of them -- five serial memory round trips per K-step instead of one
+// (found in the ISA; the comment "branch-free fetch" below was only true of the source).
+template <int MODE, int BD, int BG, int WD, int WG, int WK, bool BF16, int ST>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__ D,
                                                        const float* __restrict__ Gt,
                                                        float* __restrict__ partial, const WgradGeom g) {
@@ -69,8 +74,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
   const int td = blockIdx.x / tiles_g, tg = blockIdx.x - td * tiles_g;
   const int cd0 = td * BD, cg0 = tg * BG;
   const int tap = blockIdx.y, chunk = blockIdx.z;
-  const int dh = (g.mode == MMDYN_CONV) ? (tap >> 2) : 0;
-  const int dw = (g.mode == MMDYN_CONV) ? (tap & 3) : 0;
+  const int dh = (MODE == MMDYN_CONV) ? (tap >> 2) : 0;
+  const int dw = (MODE == MMDYN_CONV) ? (tap & 3) : 0;
   const int HWr = g.Hr * g.Wr;
 
   const int row_begin = chunk * g.rows_per_chunk;
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
       const int r = idx / DV, v = idx - r * DV;
       const int row = r0 + r;
       const bool ok = row < row_end;
-      if (BF16 && (ST != 0 || g.d_b16))
+      if constexpr (BF16 && (ST == 1 || ST == 2))
         rd[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       else
         rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
       const int row = r0 + r;
       bool ok = row < row_end;
       int pix = row;
-      if (g.mode == MMDYN_IM2COL3) {
+      if constexpr (MODE == MMDYN_IM2COL3) {
         // G row = im2col of the NCHW 3-channel tensor: columns ci*16 + kh*4 + kw (48 real + 16 zero)
         int bb, p, rr, cc;
         fdiv(row, HWr, inv_hw, bb, p);
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
         okg = (okg & ~(0xFu << (4 * i))) | (m << (4 * i));
         continue;
       }
-      if (g.mode == MMDYN_CONV) {
+      if constexpr (MODE == MMDYN_CONV) {
         int bb, p, rr, cc;
         fdiv(row, HWr, inv_hw, bb, p);
         fdiv(p, g.Wr, inv_w, rr, cc);
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
         ok = ok & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
         pix = (bb * g.Hi + y) * g.Wi + x;
       }
-      if (BF16 && (ST == 1 || (ST == 0 && g.g_b16)))
+      if constexpr (BF16 && (ST == 1 || ST == 3))
         rg[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       else
         rg[i] = *reinterpret_cast<const f32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
@@ -209,6 +214,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
           for (int b = 0; b < GT; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);   // the masking selects of lds_store (which wait for the loads) stay behind the MFMAs
       __syncthreads();
       lds_store();
       __syncthreads();
@@ -254,8 +260,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
   constexpr int D_LOADS = (RK * DV + 255) / 256, G_LOADS = (RK * GV + 255) / 256;
   constexpr bool D_ALL = (RK * DV) % 256 == 0, G_ALL = (RK * GV) % 256 == 0;
 
-  __shared__ __attribute__((aligned(16))) bf16_t Ds[RK * LDD];
-  __shared__ __attribute__((aligned(16))) bf16_t Gs[RK * LDG];
+  // (tiles narrower than 64 channels need fewer than 256 granules per K-step: the surplus threads load a valid dummy
+  //  address and store into rows RK.. that nobody reads -- predicating them instead makes the compiler sink the load
+  //  into the store branch, behind the barrier, where its latency is exposed)
+  constexpr int D_ROWS = D_LOADS * 256 / DV, G_ROWS = G_LOADS * 256 / GV;
+  __shared__ __attribute__((aligned(16))) bf16_t Ds[D_ROWS * LDD];
+  __shared__ __attribute__((aligned(16))) bf16_t Gs[G_ROWS * LDG];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / WAVES_DG, wdg = wave % WAVES_DG;
@@ -294,8 +304,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
       const int idx = tid + 256 * i;
       const int r = idx / DV, v = idx - r * DV;
       const int row = r0 + r;
-      const bool ok = (D_ALL || idx < RK * DV) & (row < row_end);
-      rd[i] = *reinterpret_cast<const u32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + (D_ALL || idx < RK * DV ? v : 0) * 8);
+      const bool ok = (D_ALL || r < RK) & (row < row_end);
+      rd[i] = *reinterpret_cast<const u32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 8);
       okd = ok ? (okd | (1u << i)) : (okd & ~(1u << i));
     }
 #pragma unroll
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
       const int idx = tid + 256 * i;
       const int r = idx / GV, v = idx - r * GV;
       const int row = r0 + r;
-      bool ok = (G_ALL || idx < RK * GV) & (row < row_end);
+      bool ok = (G_ALL || r < RK) & (row < row_end);
       int pix = row;
       if constexpr (MODE == MMDYN_CONV) {
         int bb, p, rr, cc;
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         ok = ok & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)xx < (unsigned)g.Wi);
         pix = (bb * g.Hi + y) * g.Wi + xx;
       }
-      rg[i] = *reinterpret_cast<const u32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + (G_ALL || idx < RK * GV ? v : 0) * 8);
+      rg[i] = *reinterpret_cast<const u32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 8);
       okg = ok ? (okg | (1u << i)) : (okg & ~(1u << i));
     }
   };
@@ -322,18 +332,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 #pragma unroll
     for (int i = 0; i < D_LOADS; ++i) {
       const int idx = tid + 256 * i;
-      if (D_ALL || idx < RK * DV) {
-        const int r = idx / DV, v = idx - r * DV;
-        *reinterpret_cast<u32x4*>(&Ds[r * LDD + v * 8]) = ((okd >> i) & 1u) ? rd[i] : zero;
-      }
+      const int r = idx / DV, v = idx - r * DV;
+      *reinterpret_cast<u32x4*>(&Ds[r * LDD + v * 8]) = ((okd >> i) & 1u) ? rd[i] : zero;
     }
 #pragma unroll
     for (int i = 0; i < G_LOADS; ++i) {
       const int idx = tid + 256 * i;
-      if (G_ALL || idx < RK * GV) {
-        const int r = idx / GV, v = idx - r * GV;
-        *reinterpret_cast<u32x4*>(&Gs[r * LDG + v * 8]) = ((okg >> i) & 1u) ? rg[i] : zero;
-      }
+      const int r = idx / GV, v = idx - r * GV;
+      *reinterpret_cast<u32x4*>(&Gs[r * LDG + v * 8]) = ((okg >> i) & 1u) ? rg[i] : zero;
     }
   };
 
@@ -379,6 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
           for (int b = 0; b < GT; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a], pb[b], acc[a][b], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);   // the masking selects of lds_store (which wait for the loads) stay behind the MFMAs
       __syncthreads();
       lds_store();
       __syncthreads();
@@ -409,6 +416,9 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
   constexpr int DT = BD / 32, GT = BG / 32;
   constexpr int DV = BD / 4, GV = BG / 4;
   constexpr int D_LOADS = (RK * DV + 255) / 256;          // float4 per thread for the shared D tile
+  // (compile-time: with a run-time `idx < RK * DV` test the compiler sinks that load into the LDS-store branch, behind
+  //  the barrier, and waits for it there -- a full memory round trip exposed in every K-step)
+  constexpr bool D_ALL = (RK * DV) % 256 == 0;
   constexpr int G_LOADS = (RK * GV) / 64;                 // float4 per lane: each wave fetches its own tap's tile
   static_assert(DT <= 2 && GT <= 2, "tile too large for four accumulator sets");
 
@@ -441,8 +451,8 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       const int idx = tid + 256 * i;
       const int r = idx / DV, v = idx - r * DV;
       const int row = r0 + r;
-      const bool ok = (idx < RK * DV) & (row < row_end);
-      if (BF16 && (ST != 0 || g.d_b16))
+      const bool ok = (D_ALL || idx < RK * DV) & (row < row_end);
+      if constexpr (BF16 && (ST == 1 || ST == 2))
         rd[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       else
         rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       const int y = rr * g.rs + g.ro + kh, x = cc * g.rs + g.ro + kw;
       const bool ok = (row < row_end) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
       const int pix = (bb * g.Hi + y) * g.Wi + x;
-      if (BF16 && (ST == 1 || (ST == 0 && g.g_b16)))
+      if constexpr (BF16 && (ST == 1 || ST == 3))
         rg[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       else
         rg[i] = *reinterpret_cast<const f32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < D_LOADS; ++i)
-      if (tid + 256 * i < RK * DV) reinterpret_cast<f32x4*>(Ds)[tid + 256 * i] = ((okd >> i) & 1u) ? rd[i] : zero;
+      if (D_ALL || tid + 256 * i < RK * DV) reinterpret_cast<f32x4*>(Ds)[tid + 256 * i] = ((okd >> i) & 1u) ? rd[i] : zero;
 #pragma unroll
     for (int i = 0; i < G_LOADS; ++i)
       reinterpret_cast<f32x4*>(Gw)[lane + 64 * i] = ((okg >> i) & 1u) ? rg[i] : zero;
@@ -526,6 +536,7 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
           for (int b = 0; b < GT; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);   // the masking selects of lds_store (which wait for the loads) stay behind the MFMAs
       __syncthreads();
       lds_store();
       __syncthreads();
@@ -550,6 +561,10 @@ static int launch4(const float* D, const float* Gt, float* partial, WgradGeom g,
   size_t smem = (size_t)RK * (BD + 4 * BG) * sizeof(float);
   if (bf16 && g.d_b16 && g.g_b16)
     hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 1>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  else if (bf16 && g.d_b16)
+    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 2>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  else if (bf16 && g.g_b16)
+    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 3>), grid, dim3(256), smem, st, D, Gt, partial, g);
   else if (bf16)
     hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 0>), grid, dim3(256), smem, st, D, Gt, partial, g);
   else
@@ -661,14 +676,22 @@ static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, 
   g.rows_per_chunk = ceil_div(rpc, RK) * RK;
   dim3 grid((g.Cd / BD) * (g.Cg / BG), g.ntaps, zblocks);
   size_t smem = (size_t)RK * (BD + BG) * sizeof(float);
-  if (bf16 && g.d_b16 && g.g_b16)
-    hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK, true, 1>), grid, dim3(256), smem, st, D, Gt, partial, g);
-  else if (bf16 && g.d_b16 && !g.g_b16)
-    hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK, true, 2>), grid, dim3(256), smem, st, D, Gt, partial, g);
-  else if (bf16)
-    hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK, true, 0>), grid, dim3(256), smem, st, D, Gt, partial, g);
-  else
-    hipLaunchKernelGGL((wgrad_tn_kernel<BD, BG, WD, WG, WK, false, 0>), grid, dim3(256), smem, st, D, Gt, partial, g);
+#define WGRAD_LAUNCH(M, BF, ST_)                                                                                      \
+  hipLaunchKernelGGL((wgrad_tn_kernel<M, BD, BG, WD, WG, WK, BF, ST_>), grid, dim3(256), smem, st, D, Gt, partial, g)
+#define WGRAD_MODE(M)                                                  \
+  do {                                                                 \
+    if (bf16 && g.d_b16 && g.g_b16) WGRAD_LAUNCH(M, true, 1);          \
+    else if (bf16 && g.d_b16) WGRAD_LAUNCH(M, true, 2);                \
+    else if (bf16 && g.g_b16) WGRAD_LAUNCH(M, true, 3);                \
+    else if (bf16) WGRAD_LAUNCH(M, true, 0);                           \
+    else WGRAD_LAUNCH(M, false, 0);                                    \
+  } while (0)
+  if (g.mode == MMDYN_CONV) WGRAD_MODE(MMDYN_CONV);
+  else if (g.mode == MMDYN_DENSE) WGRAD_MODE(MMDYN_DENSE);
+  else if constexpr (BG == 64) WGRAD_MODE(MMDYN_IM2COL3);     // (Cg = 64: only the 64-wide gathered tiles can occur)
+  else return MMDYN_ERR_SHAPE;
+#undef WGRAD_MODE
+#undef WGRAD_LAUNCH
   MMDYN_LAUNCH_CHECK();
 }
 
