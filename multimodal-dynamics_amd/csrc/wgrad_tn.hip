@@ -771,7 +771,7 @@ extern "C" int mmdyn_wgrad_tn_bf16(const float* D, const float* Gt, float* parti
   return wgrad_entry(D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks, stream, true);
 }
 
-// recommended number of partial slabs: ~1024 blocks in flight, at least 128 rows per block
+// recommended number of partial slabs: ~768 blocks in flight, at least 128 rows per block
 extern "C" int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg) {
   if (Cd % 32 || Cg % 32 || rows <= 0) return MMDYN_ERR_SHAPE;
   int bd, bg, wk;
@@ -786,7 +786,7 @@ extern "C" int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg) {
     tiles = (long)(Cd / bd) * (Cg / bg) * 4;
     wk = 1;
   }
-  long target = 1024;
+  long target = 768;      // blocks in flight (whole-step sweep after the fetch fixes: 768 beats 512 / 1024 in all three precisions)
   if (const char* ov = getenv("MMDYN_WGRAD_BLOCKS")) target = atol(ov);   // kernel experiments only
   if (mode == MMDYN_IM2COL3) {            // conv3_wgrad: one block (four waves, one slab) per chunk
     tiles = 1;
