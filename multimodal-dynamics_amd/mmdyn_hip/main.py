@@ -15,40 +15,44 @@ from . import config
 from .problems.problems import Reconstruction, Regression, SeqModeling, DynModeling, SyntheticVisuoTactile
 
 
+# The reference's flags (same names and defaults: main.py:13-54 there) as data.  (flag, default, type or None for a switch,
+# what it selects here).  Defaults are API: a reference command line must mean the same thing with this build.
+_REFERENCE_FLAGS = (
+    ("problem-type", "seq_modeling", str, "which problem class runs: " + " | ".join(config.PROBLEM_TYPES)),
+    ("model-name", "cnn-mvae", str, "registry name of the model: " + " | ".join(config.MODELS)),
+    ("input-type", "visual", str, "modality fed to the model: visual | tactile | visuotactile"),
+    ("use-pose", False, None, "cnn-mvae only: the 7-DoF pose as a third modality"),
+    ("lr", 0.001, float, "learning rate of the fused Adam / SGD step"),
+    ("dataset-path", "~/dataset", str, "PNG + json tree or its compiled pickle (frames are decoded on the GPU)"),
+    ("batchsize", 128, int, "samples per step"),
+    ("criterion", "crossentropy", str, "accepted for compatibility; the VAE problems use the ELBO"),
+    ("optimizer", "Adam", str, " | ".join(config.OPTIMIZERS)),
+    ("num-epochs", 100, int, "training epochs"),
+    ("mask-loss", False, None, "restrict the reconstruction loss to the object segment"),
+    ("vis-pose", False, None, "accepted for compatibility (no plotting in this build)"),
+    ("pose-multiplier", 1000, float, "weight of the pose MSE inside the ELBO"),
+    ("save-name", "run", str, "name of the log directory"),
+    ("no-cuda", False, None, "rejected with an error: this build has no CPU path"),
+    ("kl-weight", 1.0, float, "KL weight before the annealing schedule overwrites it"),
+    ("latent-size", 256, int, "latent dimension"),
+    ("annealing-epochs", 50, int, "epochs over which the KL weight is ramped"),
+    ("conditional", False, None, "condition encoders / decoders on the shock force"),
+)
+# switches of this build only
+_BUILD_FLAGS = (
+    ("synthetic-batches", 0, int, "train on this many random batches per epoch instead of --dataset-path"),
+    ("synthetic-seq-length", 1, int, "frames per synthetic sequence"),
+    ("reference-schedule", False, None, "run the reference's 7-forward autograd schedule instead of the fused step"),
+)
+
+
 def build_parser():
-    parser = argparse.ArgumentParser(description='MI355X-native cnn-VAE / cnn-MVAE training')
-    # Problem (same names, defaults and help as the reference)
-    parser.add_argument('--problem-type', default='seq_modeling', type=str, help='Problem type (default: seq_modeling)')
-    parser.add_argument('--model-name', default='cnn-mvae', type=str, help='Model architecture name')
-    parser.add_argument('--input-type', default='visual', type=str,
-                        help='The input modality (valid: visual, tactile, visuotactile)')
-    parser.add_argument('--use-pose', action='store_true', default=False,
-                        help="Use pose as additional modality, only works for MVAE) (default: False)")
-    parser.add_argument('--lr', default=0.001, type=float, help='learning rate (default: 0.001)')
-    parser.add_argument('--dataset-path', default="~/dataset", type=str, help='Absolute path to the dataset.')
-    parser.add_argument('--batchsize', default=128, type=int, help='Batchsize (default: 128)')
-    parser.add_argument('--criterion', default="crossentropy", type=str, help='Training loss (default: crossentropy)')
-    parser.add_argument('--optimizer', default="Adam", type=str, help='Optimizer name (default: Adam)')
-    parser.add_argument('--num-epochs', default=100, type=int, help='Number of training epochs (default: 100)')
-    parser.add_argument('--mask-loss', action='store_true', default=False,
-                        help="Mask the reconstruction loss to the object segment (default: False)")
-    parser.add_argument('--vis-pose', action='store_true', default=False, help="Visualize pose (ignored here)")
-    parser.add_argument('--pose-multiplier', default=1000, type=float, help="Multiplier for pose loss (default: 1000)")
-    # Misc
-    parser.add_argument('--save-name', default='run', type=str, help='Name used for the log directory (default: run)')
-    parser.add_argument('--no-cuda', action='store_true', default=False,
-                        help="Rejected: this build has no CPU path (use the reference for CPU runs)")
-    # VAE specific
-    parser.add_argument('--kl-weight', type=float, default=1.0, help="KL weight (overwritten by the annealing schedule)")
-    parser.add_argument('--latent-size', type=int, default=256, help="Latent dimension (default: 256)")
-    parser.add_argument('--annealing-epochs', type=int, default=50, help="Number of epochs to anneal KL for (default: 50)")
-    parser.add_argument('--conditional', action='store_true', default=False, help="Conditional VAE (conditioned on the shock force)")
-    # this build only
-    parser.add_argument('--synthetic-batches', type=int, default=0,
-                        help="train on this many random batches per epoch instead of --dataset-path")
-    parser.add_argument('--synthetic-seq-length', type=int, default=1, help="frames per synthetic sequence")
-    parser.add_argument('--reference-schedule', action='store_true', default=False,
-                        help="run the reference's 7-forward autograd schedule instead of the fused step")
+    parser = argparse.ArgumentParser(description="cnn-VAE / cnn-MVAE training on MI355X (mmdyn_hip)")
+    for name, default, kind, text in _REFERENCE_FLAGS + _BUILD_FLAGS:
+        if kind is None:
+            parser.add_argument("--" + name, action="store_true", default=default, help=text)
+        else:
+            parser.add_argument("--" + name, type=kind, default=default, help=f"{text} (default: {default})")
     return parser
 
 

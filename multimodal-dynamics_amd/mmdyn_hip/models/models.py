@@ -10,23 +10,33 @@ from .shapes import FEAT, HID
 
 
 def count_parameters(model):
-    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+    """Number of trainable scalars (printed by the problem classes, like the reference does)."""
+    return sum(int(p.numel()) for p in model.parameters() if p.requires_grad)
+
+
+def _family(model_name):
+    """Registry name -> model family.  The reference dispatches on substrings of the name; the order matters
+    ('cnn-mvae' contains 'vae' too)."""
+    for key in ("mvae", "vae", "regressor"):
+        if key in model_name:
+            return key
+    return None
 
 
 def setup_model(model_name, cross_modal=False, **kwargs):
-    """Same dispatch rules and assertions as the reference: 'mvae' needs cross-modal input, 'vae' must not
-    get it; 'regressor' builds the pose-regression baseline."""
+    """``--model-name`` plug-in point.  Behaviour kept from the reference: an unknown name fails the registry assertion;
+    a multimodal VAE is only built for cross-modal input (a 'cnn-mvae' asked for a single modality falls through to the
+    plain VAE, which then refuses cross-modal input); anything else terminates the process with a message."""
     assert (model_name in config.MODELS), "Model is not implement yet"
-    if 'mvae' in model_name and cross_modal:
-        model = MVAE(**kwargs)
-    elif 'vae' in model_name:
+    family = _family(model_name)
+    if family == "mvae" and cross_modal:
+        return MVAE(**kwargs)
+    if family in ("mvae", "vae"):
         assert not cross_modal, "VAE does not work with cross modal inputs."
-        model = VAE(**kwargs)
-    elif 'regressor' in model_name:
-        model = Regressor(**kwargs)
-    else:
-        exit("The model and modality combination is not valid.")
-    return model
+        return VAE(**kwargs)
+    if family == "regressor":
+        return Regressor(**kwargs)
+    exit("The model and modality combination is not valid.")
 
 
 class Regressor(nn.Module):
