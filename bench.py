@@ -109,7 +109,26 @@ def cpu_baseline(batch, threads):
             "loss": loss}
 
 
+_RESULT_FD = None
+
+
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner when
+    its communicator is created), so the real stdout is set aside for the result and everything else -- C libraries
+    included, they share file descriptor 1 -- goes to stderr."""
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def _emit(obj):
+    sys.stdout.flush()
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, (json.dumps(obj) + "\n").encode())
+
+
 def main():
+    _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -172,14 +191,14 @@ def main():
             out = eng([v, t], pose=p)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(json.dumps({"metric": "visuotactile samples/sec (inference, joint v+t+p forward, eval mode)",
+        _emit({"metric": "visuotactile samples/sec (inference, joint v+t+p forward, eval mode)",
                           "value": args.batch * args.steps / dt, "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
                           "dtype": args.dtype, "data": "synthetic",
                           "config": {"workload": f"cnn-mvae joint inference forward, bs={args.batch}, engine.MVAEInference "
                                                  f"(prepacked weights, two streams, {'eager' if args.no_graph else 'HIP graph'})",
                                      "algorithmic_gflop_per_sample": 0.274,
-                                     "tflops": args.batch * args.steps / dt * 0.274e9 / 1e12}}))
+                                     "tflops": args.batch * args.steps / dt * 0.274e9 / 1e12}})
         return
     step = MVAEStep(model, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), process_group=pg,
                     world_size=world, two_lanes=not args.single_lane,
@@ -277,7 +296,7 @@ def main():
             print(f"  {k[0]:9s} {str(k[1:]):70s} x{d['calls']:2d} {d['ms']:7.3f} ms {tf:6.1f} TF/s", file=sys.stderr)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.batch, host_cpu_share())
-    print(json.dumps(out))
+    _emit(out)
     if pg is not None:
         dist.destroy_process_group()
 
