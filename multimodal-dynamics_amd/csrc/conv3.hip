@@ -17,7 +17,6 @@
 //     256 contiguous bytes).
 // fp32 matrix cores in every precision mode: there is nothing to gain from bf16 operands on an HBM-bound layer.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -316,7 +315,8 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const TD* __restrict__
   }
 }
 
-// persistent grid: four blocks per CU stay resident (<= 128 VGPRs), each walks ntiles/1024 tiles
+// persistent grid: four blocks per CU stay resident (<= 128 VGPRs), each walks ntiles/1024 tiles (whole-step sweep of
+// 512 / 768 / 1024 / 2048 blocks: 1024 is best in fp32 and bf16s)
 constexpr int CONV3_GRID = 1024;
 
 }  // namespace
@@ -326,7 +326,6 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
                        int Bg, int Hi, int Wi, int Ho, int Wo, int N, int ldc, int act, int splitk, const void* bn_y,
                        const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
                        int c_b16, int bny_b16, int b_b16, hipStream_t st) {
-  if (getenv("MMDYN_NO_CONV3")) return 1;     // kernel experiments only: take the generic tiled kernel
   if (N != C3_N || ldc != C3_N || Ho != C3_HO || Wo != C3_HO || Hi != C3_HI || Wi != C3_HI || bias || splitk != 1) return 1;
   if (bn_y && (c_b16 != bny_b16 || C_act)) return 1;
   if (C_act && act != MMDYN_ACT_NONE && act != MMDYN_ACT_SWISH && act != MMDYN_ACT_RELU) return 1;
@@ -349,9 +348,7 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
   g.bn_gamma = bn_gamma;
   g.bn_beta = bn_beta;
   const int ntiles = G * g.tiles_per_group;
-  int gcap = CONV3_GRID;
-  if (const char* ov = getenv("MMDYN_CONV3_GRID")) gcap = atoi(ov);   // kernel experiments only
-  const dim3 grid(ntiles < gcap ? ntiles : gcap);
+  const dim3 grid(ntiles < CONV3_GRID ? ntiles : CONV3_GRID);
   const int variant = bn_y ? 4 : (C_act ? act : -1);
 #define CONV3_CASE(V, BN_, ACT_)                                                                                   \
   if (variant == (V)) {                                                                                            \
@@ -374,7 +371,6 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
 // chunks = partial slabs = blocks; 1 when the shape is not this file's
 int mmdyn_conv3_wgrad_try(const void* D, const float* Gt, float* partial, int Bt, int Hr, int Wr, int Cd, int Hi,
                           int Wi, int Cg, int chunks, int d_b16, hipStream_t st) {
-  if (getenv("MMDYN_NO_CONV3")) return 1;
   if (Cd != 32 || Cg != 64 || Wr != 32 || Wi != 64 || Hi != 2 * Hr) return 1;
   Conv3WgradGeom g{};
   g.Bt = Bt;

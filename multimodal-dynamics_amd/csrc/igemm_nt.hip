@@ -538,7 +538,7 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
                      C_act, stats, ws, g)
   constexpr bool CAN_A16 = MODE != MMDYN_IM2COL3;
   if (!bf16) IGEMM_LAUNCH(false, false, false);
-  else if (g.a_b16 && g.b_b16 && CAN_A16 && g.Cin % 64 == 0 && !getenv("MMDYN_NO_WIDE"))
+  else if (g.a_b16 && g.b_b16 && CAN_A16 && g.Cin % 64 == 0)
     hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, CAN_A16, true, CAN_A16>), grid, dim3(256), smem, st, A, Bp,
                        bias, C, C_act, stats, ws, g);
   else if (g.a_b16 && g.b_b16) IGEMM_LAUNCH(true, CAN_A16, true);

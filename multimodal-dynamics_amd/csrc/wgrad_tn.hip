@@ -729,7 +729,7 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
     if (rc != 1) return rc;
   }
   const bool d64 = (Cd % 64 == 0), g64 = (Cg % 64 == 0);
-  if (bf16 && g.d_b16 && g.g_b16 && mode != MMDYN_IM2COL3 && !getenv("MMDYN_NO_WGRAD_B16")) {
+  if (bf16 && g.d_b16 && g.g_b16 && mode != MMDYN_IM2COL3) {
     // both operands bf16 in HBM: the transposing-LDS-read kernel (two waves share a 64x32 / 32x64 tile's rows)
     if (Cd % 128 == 0 && Cg % 128 == 0) return launch_b16<128, 128, 64, 64, 1>(D, Gt, partial, g, st);
     if (d64 && g64) return launch_b16<64, 64, 32, 32, 1>(D, Gt, partial, g, st);
