@@ -406,6 +406,143 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     }
 }
 
+// All-bf16 four-taps-per-block variant (narrow channel tiles of the k4 convolutions, see wgrad_tn4_kernel below for the
+// idea): the four waves own the four kw taps of kernel row kh = blockIdx.y and share one D tile; each wave stages its own
+// tap's gathered G tile.  Operand path as in wgrad_b16_kernel (16-byte granules, bf16 LDS tiles, transposing reads).
+template <int BD, int BG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void wgrad_b16_tn4_kernel(
+    const bf16_t* __restrict__ D, const bf16_t* __restrict__ Gt, float* __restrict__ partial, const WgradGeom g) {
+  constexpr int DT = BD / 32, GT = BG / 32;
+  constexpr int LDD = b16_ld<BD>::v, LDG = b16_ld<BG>::v;
+  constexpr int DV = BD / 8, GV = BG / 8;                  // 16-byte granules per tile row
+  constexpr int D_LOADS = (RK * DV + 255) / 256;           // granules per thread of the shared D tile
+  constexpr int D_ROWS = D_LOADS * 256 / DV;               // (surplus threads fill rows RK.. that nobody reads)
+  constexpr int G_LOADS = (RK * GV + 63) / 64;             // granules per lane of the wave's own G tile
+  constexpr int G_ROWS = G_LOADS * 64 / GV;
+  static_assert(DT <= 2 && GT <= 2, "tile too large for four accumulator sets");
+
+  __shared__ __attribute__((aligned(16))) bf16_t Ds[D_ROWS * LDD];
+  __shared__ __attribute__((aligned(16))) bf16_t Gs[4 * G_ROWS * LDG];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_g = g.Cg / BG;
+  const int td = blockIdx.x / tiles_g, tg = blockIdx.x - td * tiles_g;
+  const int cd0 = td * BD, cg0 = tg * BG;
+  const int kh = blockIdx.y, kw = wave, chunk = blockIdx.z;
+  const int HWr = g.Hr * g.Wr;
+  const int row_begin = chunk * g.rows_per_chunk;
+  const int row_end = min(g.rows, row_begin + g.rows_per_chunk);
+  const float inv_hw = 1.0f / (float)HWr, inv_w = 1.0f / (float)g.Wr;
+  auto fdiv = [](int n, int d, float inv, int& q, int& r) {
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { q -= 1; r += d; }
+    if (r >= d) { q += 1; r -= d; }
+  };
+  bf16_t* Gw = Gs + wave * G_ROWS * LDG;
+
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 rd[D_LOADS], rg[G_LOADS];
+  unsigned okd = 0, okg = 0;
+  auto gload = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < D_LOADS; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx / DV, v = idx - r * DV;
+      const int row = r0 + r;
+      const bool ok = (r < RK) & (row < row_end);
+      rd[i] = *reinterpret_cast<const u32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 8);
+      okd = ok ? (okd | (1u << i)) : (okd & ~(1u << i));
+    }
+#pragma unroll
+    for (int i = 0; i < G_LOADS; ++i) {
+      const int idx = lane + 64 * i;
+      const int r = idx / GV, v = idx - r * GV;
+      const int row = r0 + r;
+      int bb, p, rr, cc;
+      fdiv(row, HWr, inv_hw, bb, p);
+      fdiv(p, g.Wr, inv_w, rr, cc);
+      const int y = rr * g.rs + g.ro + kh, xx = cc * g.rs + g.ro + kw;
+      const bool ok = (r < RK) & (row < row_end) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)xx < (unsigned)g.Wi);
+      const int pix = (bb * g.Hi + y) * g.Wi + xx;
+      rg[i] = *reinterpret_cast<const u32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 8);
+      okg = ok ? (okg | (1u << i)) : (okg & ~(1u << i));
+    }
+  };
+  auto lds_store = [&]() {
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < D_LOADS; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx / DV, v = idx - r * DV;
+      *reinterpret_cast<u32x4*>(&Ds[r * LDD + v * 8]) = ((okd >> i) & 1u) ? rd[i] : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < G_LOADS; ++i) {
+      const int idx = lane + 64 * i;
+      const int r = idx / GV, v = idx - r * GV;
+      *reinterpret_cast<u32x4*>(&Gw[r * LDG + v * 8]) = ((okg >> i) & 1u) ? rg[i] : zero;
+    }
+  };
+
+  f32x16 acc[DT][GT];
+#pragma unroll
+  for (int a = 0; a < DT; ++a)
+#pragma unroll
+    for (int b = 0; b < GT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int trow = 8 * (gq >> 1) + tq, tcol = 16 * (gq & 1) + 4 * tp;
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+  auto frag = [&](const bf16_t* tile, int ld, int col0, int k0) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(&tile[(k0 + trow) * ld + col0 + tcol]));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(&tile[(k0 + trow + 4) * ld + col0 + tcol]));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(wb16x8, v);
+  };
+
+  const int h = lane >> 5, cl = lane & 31;
+  if (row_begin < row_end) {
+    gload(row_begin);
+    lds_store();
+    __syncthreads();
+    for (int r0 = row_begin; r0 < row_end; r0 += RK) {
+      gload(r0 + RK);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        wb16x8 pa[DT], pb[GT];
+#pragma unroll
+        for (int a = 0; a < DT; ++a) pa[a] = frag(Ds, LDD, a * 32, kc * 16);
+#pragma unroll
+        for (int b = 0; b < GT; ++b) pb[b] = frag(Gw, LDG, b * 32, kc * 16);
+#pragma unroll
+        for (int a = 0; a < DT; ++a)
+#pragma unroll
+          for (int b = 0; b < GT; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a], pb[b], acc[a][b], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      lds_store();
+      __syncthreads();
+    }
+  }
+  float* out = partial + ((size_t)(chunk * g.ntaps + kh * 4 + kw) * g.Cd) * g.Cg;
+#pragma unroll
+  for (int a = 0; a < DT; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int cd = cd0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+#pragma unroll
+      for (int b = 0; b < GT; ++b) out[(size_t)cd * g.Cg + cg0 + b * 32 + cl] = acc[a][b][e];
+    }
+}
+
 // Four-taps-per-block variant for the small-channel convolutions (tile <= 64x64): the four waves of a block own
 // the four kw taps of one kernel row kh and share ONE dense-operand tile, so D is fetched once per 4 taps instead
 // of once per tap (half the L2 traffic of the one-tap kernel on these shapes) and no wave has to split the row
@@ -559,8 +696,9 @@ static int launch4(const float* D, const float* Gt, float* partial, WgradGeom g,
   g.rows_per_chunk = ceil_div(rpc, RK) * RK;
   dim3 grid((g.Cd / BD) * (g.Cg / BG), 4, g.chunks);
   size_t smem = (size_t)RK * (BD + 4 * BG) * sizeof(float);
-  if (bf16 && g.d_b16 && g.g_b16)
-    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 1>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  if (bf16 && g.d_b16 && g.g_b16)      // both operands bf16: transposing-LDS-read variant
+    hipLaunchKernelGGL((wgrad_b16_tn4_kernel<BD, BG>), grid, dim3(256), 0, st, reinterpret_cast<const bf16_t*>(D),
+                       reinterpret_cast<const bf16_t*>(Gt), partial, g);
   else if (bf16 && g.d_b16)
     hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 2>), grid, dim3(256), smem, st, D, Gt, partial, g);
   else if (bf16 && g.g_b16)
