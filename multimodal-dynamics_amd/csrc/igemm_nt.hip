@@ -36,6 +36,7 @@ struct IgemmGeom {
   int rows_total;      // G*Bg*Hr*Wr (split-K workspace stride)
   int tiles_per_group; // ceil(Bg*Hr*Wr / BM); TCONV_S1P0: Ho*Wo*ceil(Bg/BM) (tiles never straddle an output pixel)
   int tiles_per_pixel; // TCONV_S1P0 only: ceil(Bg/BM)
+  int s1p0_split;      // TCONV_S1P0 only: 1 = a block walks the four pixels of its quad, 2 = two blocks share the walk
   // optional BatchNorm+Swish backward epilogue (input-gradient launches): the tile of dL/d(activation) is turned
   // into du = da * swish'(gamma*xhat+beta) with xhat from the layer's saved pre-BN output, written to C, and the
   // per-tile column sums (du, du*xhat) go to `stats` -- the reduction pass of the BatchNorm backward disappears
@@ -111,24 +112,29 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   // the kernel taps that reach the input for it (1..16 of them for k4 s1 p0).  To balance the blocks, each block
   // walks the FOUR pixels {(h,w),(h+4,w),(h,w+4),(h+4,w+4)} of the 8x8 output: their valid-tap counts always sum
   // to (1+4)*(1+4) = 25, so every block does identical work.
-  constexpr int NSUB = (MODE == MMDYN_TCONV_S1P0) ? 4 : 1;
-  for (int sub = 0; sub < NSUB; ++sub) {
+  // (g.s1p0_split = 2: the quad walk is shared by TWO blocks, {(h,w),(h+4,w+4)} and {(h+4,w),(h,w+4)} -- 8..17 valid taps
+  // each instead of a uniform 25, but twice the blocks in flight: used by the latency-bound bf16 variants)
+  const int nsub = (MODE == MMDYN_TCONV_S1P0) ? 4 / g.s1p0_split : 1;
+  const int qtile = (MODE == MMDYN_TCONV_S1P0) ? tile / g.s1p0_split : tile;          // tile index inside the quad
+  const int qhalf = (MODE == MMDYN_TCONV_S1P0) ? tile - qtile * g.s1p0_split : 0;
+  for (int ksub = 0; ksub < nsub; ++ksub) {
+  const int sub = (MODE == MMDYN_TCONV_S1P0 && g.s1p0_split == 2) ? (qhalf ? (ksub ? 2 : 1) : (ksub ? 3 : 0)) : ksub;
   int px_y = 0, px_x = 0, kh0 = 0, kw0 = 0, nkh = 4, nkw = 4;
   if (MODE == MMDYN_TCONV_S1P0) {
-    const int quad = tile / g.tiles_per_pixel;
+    const int quad = qtile / g.tiles_per_pixel;
     px_y = (quad >> 2) + 4 * (sub >> 1);
     px_x = (quad & 3) + 4 * (sub & 1);
     kh0 = max(0, px_y - (g.Hi - 1));
     kw0 = max(0, px_x - (g.Wi - 1));
     nkh = min(3, px_y) - kh0 + 1;
     nkw = min(3, px_x) - kw0 + 1;
-    if (sub > 0) __syncthreads();      // previous sub-tile's epilogue still reads rowinfo / stats scratch
+    if (ksub > 0) __syncthreads();     // previous sub-tile's epilogue still reads rowinfo / stats scratch
   }
   for (int r = tid; r < BM; r += 256) {
     int ml = tile * BM + r;
     int ib = -1, y0 = 0, x0 = 0, ooff = -1;
     if (MODE == MMDYN_TCONV_S1P0) {
-      const int sidx = (tile % g.tiles_per_pixel) * BM + r;
+      const int sidx = (qtile % g.tiles_per_pixel) * BM + r;
       if (sidx < g.Bg) {
         ib = grp * g.Bg + sidx;
         y0 = px_y;
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       int T = g.nclasses * g.tiles_per_group, slot = cls * g.tiles_per_group + tile;
       if (MODE == MMDYN_TCONV_S1P0) {     // one slot per (output pixel, sample chunk)
         T = g.Ho * g.Wo * g.tiles_per_pixel;
-        slot = (px_y * g.Wo + px_x) * g.tiles_per_pixel + tile % g.tiles_per_pixel;
+        slot = (px_y * g.Wo + px_x) * g.tiles_per_pixel + qtile % g.tiles_per_pixel;
       }
       const size_t base = ((size_t)(grp * T + slot) * 2) * g.N + n0 + tid;
       stats[base] = s;
@@ -528,7 +534,8 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   g.tiles_per_group = ceil_div(g.Bg * g.Hr * g.Wr, BM);
   if (MODE == MMDYN_TCONV_S1P0) {
     g.tiles_per_pixel = ceil_div(g.Bg, BM);
-    g.tiles_per_group = 16 * g.tiles_per_pixel;       // 16 pixel quads per group, 4 pixels walked per block
+    g.s1p0_split = bf16 ? 2 : 1;
+    g.tiles_per_group = 16 * g.tiles_per_pixel * g.s1p0_split;   // 16 pixel quads per group, 4 pixels walked per block (pair)
   }
   const int mx8 = (g.G * g.tiles_per_group + 7) / 8 * 8;
   dim3 grid((unsigned)mx8 * (g.N / BN) * g.nclasses * g.splitk);
