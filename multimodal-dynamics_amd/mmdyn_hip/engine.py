@@ -27,8 +27,9 @@ SUBSETS_POSE = [(1, 1, 0), (1, 0, 0), (0, 1, 0), (1, 1, 1), (1, 0, 1), (0, 1, 1)
 SUBSETS_NOPOSE = SUBSETS_POSE[:3]
 
 _PREFIX_ORDER = ["pose_decoder", "visual_decoder", "tactile_decoder",         # bucket 0: ready first
-                 "heads", "pose_encoder",                                    # bucket 1
-                 "visual_encoder", "tactile_encoder"]                        # bucket 2: ready last
+                 "heads", "pose_encoder", "encoder_fc",                      # bucket 1: heads, pose encoder and the image
+                 #                      encoders' FC layer (two thirds of the encoder parameters, first in their backward)
+                 "visual_encoder", "tactile_encoder"]                        # bucket 2: the encoder conv stacks, ready last
 
 
 def _align4(n):
@@ -46,11 +47,13 @@ class FlatParams:
         for k in named:
             if k in heads:
                 groups["heads"].append(k)
+            elif k.split(".", 1)[0] in ("visual_encoder", "tactile_encoder") and ".fc_net." in k:
+                groups["encoder_fc"].append(k)
             else:
                 groups[k.split(".", 1)[0]].append(k)
         self.order, self.offsets, self.bucket_bounds = [], {}, []
         off = 0
-        marks = {"tactile_decoder": None, "pose_encoder": None, "tactile_encoder": None}
+        marks = {"tactile_decoder": None, "encoder_fc": None, "tactile_encoder": None}
         for g in _PREFIX_ORDER:
             for k in groups[g]:
                 self.order.append(k)
@@ -509,8 +512,8 @@ class MVAEStep:
                 dst.copy_(src)
         handles = self._replay(self._graph[1])
         if self.pg is not None:
-            # decoder gradients were reduced while the encoder backward graphs ran; the rest goes now
-            handles += self._reduce_bucket(1, last=2)
+            # buckets 0 and 1 were reduced under the encoder backward graphs; the conv stacks' gradients go now
+            handles += self._reduce_bucket(2)
             self.optimizer_step(handles)
         return self.loss
 
@@ -526,11 +529,27 @@ class MVAEStep:
              ("l1", lambda: (run(self._ph_dec_fwd_steps("t")), run(self._ph_dec_bwd_steps("t")))),
              ("main", lambda: (self._ph_pose_dec_fwd(), self._ph_pose_dec_bwd()))],
             [("main", lambda: (self._ph_assemble(), self._ph_poe_bwd()))],
-            [("l0", lambda: run(self._ph_enc_bwd_steps("v"))), ("l1", lambda: run(self._ph_enc_bwd_steps("t"))),
-             ("main", lambda: self._ph_pose_enc_bwd())],
         ]
         if self.pg is None:
+            stages.append([("l0", lambda: run(self._ph_enc_bwd_steps("v"))), ("l1", lambda: run(self._ph_enc_bwd_steps("t"))),
+                           ("main", lambda: self._ph_pose_enc_bwd())])
             stages.append([("main", lambda: self.optimizer_step(()))])
+        else:
+            # data parallel: the encoder backward is cut after the heads + FC layer (gradient bucket 1: 31 MB of the 37 MB
+            # still to be reduced), so that bucket's all-reduce runs under the conv stacks' backward instead of after it
+            gens = {}
+
+            def head(m):
+                gens[m] = self._ph_enc_bwd_steps(m)
+                next(gens[m])                  # heads + dropout
+                next(gens[m])                  # FC layer: weight / bias gradients and the input gradient
+
+            def tail(m):
+                for _ in gens.pop(m):
+                    pass
+
+            stages.append([("l0", lambda: head("v")), ("l1", lambda: head("t")), ("main", lambda: self._ph_pose_enc_bwd())])
+            stages.append([("l0", lambda: tail("v")), ("l1", lambda: tail("t"))])
         cap_stream = {"main": torch.cuda.Stream(), "l0": LN.side[0], "l1": LN.side[1]}
         pools = {k: torch.cuda.graph_pool_handle() for k in cap_stream}
         self._capturing = True
@@ -564,6 +583,8 @@ class MVAEStep:
         for ri, row in enumerate(captured):
             if ri == self.DEC_STAGE + 1:
                 handles += self._reduce_bucket(0)          # decoders done: reduce them under the encoder backward
+            if ri == self.DEC_STAGE + 3 and self.pg is not None:
+                handles += self._reduce_bucket(1)          # heads / pose encoder / encoder FC: under the conv stacks' backward
             if len(row) == 1:
                 row[0][1].replay()
                 continue

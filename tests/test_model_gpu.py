@@ -148,31 +148,56 @@ def test_bf16_engine_vs_oracle():
     assert ops.B.precision == "fp32"          # the engine restores the default after every call
 
 
-def test_sync_bn_single_rank_equals_local(tmp_path):
-    """sync_bn with a one-rank RCCL group: the all-reduces are identities, so loss and gradients must equal the local
-    BatchNorm step bit for bit up to the fp64 -> fp32 rounding of the statistics (exercises the RCCL + kernel path)."""
-    import torch.distributed as dist
+@pytest.fixture(scope="module")
+def nccl_group():
+    """ONE one-rank RCCL group for the whole module (creating a second group after destroying the first in the same
+    process aborts inside the runtime on this stack)."""
     import os
+    import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        B, klw = 8, 0.02
-        inputs, targets = seeded_batch(B, 77)
-        eps, masks = seeded_noise(B, 256, 7, 8, 78)
-        gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
-        out = []
-        for sync in (False, True):
-            m = T.build("cnn-mvae", True, True, DEV)
-            step = MVAEStep(m, noise=InjectedNoise(eps, masks), process_group=dist.group.WORLD, world_size=1, sync_bn=sync)
-            loss = float(step.forward(gi, gt, klw))
-            for h in step.backward():
-                h.wait()
-            out.append((loss, step.params.grad.clone()))
-        assert out[0][0] == pytest.approx(out[1][0], rel=1e-6)
-        assert float((out[0][1] - out[1][1]).norm() / out[0][1].norm()) < 1e-5
-    finally:
-        dist.destroy_process_group()
+    yield dist.group.WORLD
+    dist.destroy_process_group()
+
+
+def test_sync_bn_single_rank_equals_local(tmp_path, nccl_group):
+    """sync_bn with a one-rank RCCL group: the all-reduces are identities, so loss and gradients must equal the local
+    BatchNorm step bit for bit up to the fp64 -> fp32 rounding of the statistics (exercises the RCCL + kernel path)."""
+    B, klw = 8, 0.02
+    inputs, targets = seeded_batch(B, 77)
+    eps, masks = seeded_noise(B, 256, 7, 8, 78)
+    gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+    out = []
+    for sync in (False, True):
+        m = T.build("cnn-mvae", True, True, DEV)
+        step = MVAEStep(m, noise=InjectedNoise(eps, masks), process_group=nccl_group, world_size=1, sync_bn=sync)
+        loss = float(step.forward(gi, gt, klw))
+        for h in step.backward():
+            h.wait()
+        out.append((loss, step.params.grad.clone()))
+    assert out[0][0] == pytest.approx(out[1][0], rel=1e-6)
+    assert float((out[0][1] - out[1][1]).norm() / out[0][1].norm()) < 1e-5
+
+
+def test_graphed_step_with_process_group_equals_single(tmp_path, nccl_group):
+    """The data-parallel form of the graph-replayed step (encoder backward cut after the FC layer, three gradient
+    buckets all-reduced between graph launches, Adam outside the graphs) with a one-rank RCCL group -- the all-reduces
+    are identities -- must train exactly like the single-process graphs: same losses over four steps, same weights."""
+    B, klw, steps = 8, 0.02, 4
+    inputs, targets = seeded_batch(B, 91)
+    gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+    out = []
+    for pg in (None, nccl_group):
+        m = T.build("cnn-mvae", True, True, DEV)
+        step = MVAEStep(m, noise=NoiseSource(92), process_group=pg, world_size=1)    # device-side Philox: capturable
+        losses = [float(step.train_step_graphed(gi, gt, klw)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        out.append((losses, step.params.flat.clone()))
+    assert out[0][0] == pytest.approx(out[1][0], rel=1e-6)
+    assert float((out[0][1] - out[1][1]).norm() / out[0][1].norm()) < 1e-6
+    # the bucket bounds cover the flat buffer in the order the gradients become ready
+    assert step.params.bucket_bounds[-1] == step.params.total and len(step.params.bucket_bounds) == 3
 
 
 def test_bf16_storage_engine_vs_oracle():
