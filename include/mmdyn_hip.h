@@ -267,6 +267,13 @@ int mmdyn_reparam_bwd(const float* mu, const float* lv, const float* eps_noise, 
  * targets are multiplied by it first (problems.py:445-447). */
 int mmdyn_bce_logits(const float* logits, const float* target, const float* mask, float* dlogit,
                      double* loss_sum, int64_t n, int chw, int hw, float grad_scale, void* stream);
+/* The unmasked term for G decoder passes that share one target, in ONE launch: logits / dlogit [G][n], target [n];
+ * pass g adds its sum to loss_slots[slot_of_group[g]] (a host array, copied by value into the launch: capturable);
+ * a negative slot marks a discarded reconstruction (zero gradient, no loss).  The multi-subset ELBO of
+ * problems.py:462-545 compares every subset's reconstruction of a modality with the same target. */
+#define MMDYN_BCE_GROUPS_MAX 8
+int mmdyn_bce_logits_groups(const float* logits, const float* target, float* dlogit, double* loss_slots,
+                            const int* slot_of_group, int G, int64_t n, float grad_scale, void* stream);
 /* sum (r-t)^2 added to *loss_sum; dr = 2 (r-t) grad_scale */
 int mmdyn_mse(const float* r, const float* t, float* dr, double* loss_sum, int64_t n, float grad_scale,
               void* stream);

@@ -200,6 +200,43 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
   block_atomic_add(acc, loss);
 }
 
+// The same reconstruction term for several decoder passes that share ONE target (the live passes of a modality in the
+// multi-subset ELBO): logits [G][n], target [n], one loss slot per pass; blockIdx.y = pass.  A pass whose slot is negative
+// is a discarded reconstruction: its logit gradient is zero and it adds nothing to the loss.
+struct BceGroups {
+  int slot[MMDYN_BCE_GROUPS_MAX];
+};
+__global__ __launch_bounds__(256) void bce_logits_groups_kernel(const float* __restrict__ logits,
+                                                                const float* __restrict__ target,
+                                                                float* __restrict__ dlogit, double* __restrict__ loss,
+                                                                const BceGroups gs, int64_t n, float grad_scale) {
+  const int grp = blockIdx.y, slot = gs.slot[grp];
+  const float* __restrict__ lg = logits + (size_t)grp * n;
+  float* __restrict__ dl = dlogit ? dlogit + (size_t)grp * n : nullptr;
+  const int64_t n4 = n >> 2;
+  if (slot < 0) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (dl)
+      for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(dl)[i] = zero;
+    return;
+  }
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 xv = reinterpret_cast<const f32x4*>(lg)[i], t = reinterpret_cast<const f32x4*>(target)[i];
+    f32x4 d;
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      part += fmaxf(xv[k], 0.f) - xv[k] * t[k] + log1pf(expf(-fabsf(xv[k])));
+      d[k] = (1.f / (1.f + expf(-xv[k])) - t[k]) * grad_scale;
+    }
+    acc += (double)part;
+    if (dl) reinterpret_cast<f32x4*>(dl)[i] = d;
+  }
+  block_atomic_add(acc, loss + slot);
+}
+
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ r, const float* __restrict__ t,
                                                   float* __restrict__ dr, double* __restrict__ loss, int64_t n,
                                                   float grad_scale) {
@@ -304,6 +341,19 @@ extern "C" int mmdyn_bce_logits(const float* logits, const float* target, const 
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(bce_logits_kernel, dim3(g), dim3(256), 0, ST, logits, target, mask, dlogit, loss_sum, n,
                      chw, hw, grad_scale);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bce_logits_groups(const float* logits, const float* target, float* dlogit, double* loss_slots,
+                                       const int* slot_of_group, int G, int64_t n, float grad_scale, void* stream) {
+  if (!logits || !target || !loss_slots || !slot_of_group) return MMDYN_ERR_NULL;
+  if (G <= 0 || G > MMDYN_BCE_GROUPS_MAX || n <= 0 || n % 4) return MMDYN_ERR_SHAPE;
+  BceGroups gs{};
+  for (int i = 0; i < G; ++i) gs.slot[i] = slot_of_group[i];
+  int g = ew_grid(n / 4);
+  if (g > 512) g = 512;
+  hipLaunchKernelGGL(bce_logits_groups_kernel, dim3(g, G), dim3(256), 0, ST, logits, target, dlogit, loss_slots, gs, n,
+                     grad_scale);
   MMDYN_LAUNCH_CHECK();
 }
 

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "mmdyn_reparam_fwd": "ppppp" + "iii" + "p",
     "mmdyn_reparam_bwd": "pppp" + "f" + "pp" + "iii" + "p",
     "mmdyn_bce_logits": "ppppp" + "l" + "ii" + "f" + "p",
+    "mmdyn_bce_logits_groups": "ppppp" + "i" + "l" + "f" + "p",
     "mmdyn_mse": "pppp" + "l" + "f" + "p",
     "mmdyn_elbo_assemble": "ppppp" + "ii" + "ff" + "p",
     "mmdyn_adam_step": "ppppp" + "l" + "fffff" + "p",

@@ -308,14 +308,10 @@ class MVAEStep:
         lg, c["d" + m] = yield from layers.decoder_forward_steps(FP.sub(dec), self._buffers(dec), zz, len(plist),
                                                                  packed=c["pk"].get("d" + m))
         dl = torch.empty_like(lg) if c["train"] else None
-        n_img = B * 3 * 64 * 64
-        for g, p in enumerate(plist):
-            if p not in live:                      # exact_running_stats: a pass whose reconstruction is discarded
-                if dl is not None:
-                    dl[g * B:(g + 1) * B].zero_()
-                continue
-            ops.B.bce_logits(lg[g * B:(g + 1) * B], c["tg"][m], None, None if dl is None else dl[g * B:(g + 1) * B],
-                             self.acc[0, p:p + 1], n_img, 3 * 4096, 4096, 1.0 / B)
+        # every live pass of the modality against the same target: one launch, one loss slot per pass
+        # (slot -1: exact_running_stats ran a pass whose reconstruction is discarded -- zero gradient, no loss)
+        ops.B.bce_logits_groups(lg, c["tg"][m], dl, self.acc[0], [p if p in live else -1 for p in plist],
+                                B * 3 * 64 * 64, 1.0 / B)
         c["lg" + m], c["dl" + m] = lg, dl
 
     def _ph_pose_dec_fwd(self):

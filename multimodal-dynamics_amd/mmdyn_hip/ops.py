@@ -321,6 +321,14 @@ class HipBackend:
                                         loss_sum.data_ptr(), n, chw, hw, float(grad_scale), _stream()),
               "mmdyn_bce_logits")
 
+    def bce_logits_groups(self, logits, target, dlogit, loss_slots, slot_of_group, n, grad_scale):
+        """logits / dlogit: [G*n]; target: [n]; loss_slots: fp64 vector; slot_of_group[g] < 0 = discarded pass."""
+        G = len(slot_of_group)
+        slots = (ctypes.c_int * G)(*[int(s) for s in slot_of_group])
+        check(self.lib.mmdyn_bce_logits_groups(_ptr(logits), _ptr(target), _ptr(dlogit), loss_slots.data_ptr(),
+                                               ctypes.addressof(slots), G, n, float(grad_scale), _stream()),
+              "mmdyn_bce_logits_groups")
+
     def mse(self, r, t, dr, loss_sum, n, grad_scale):
         check(self.lib.mmdyn_mse(_ptr(r), _ptr(t), _ptr(dr), loss_sum.data_ptr(), n, float(grad_scale), _stream()),
               "mmdyn_mse")

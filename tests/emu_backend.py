@@ -479,6 +479,16 @@ class EmuBackend:
                 d = d * mk
             dlogit.reshape(-1)[:n] = d
 
+    def bce_logits_groups(self, logits, target, dlogit, loss_slots, slot_of_group, n, grad_scale):
+        lg = logits.reshape(len(slot_of_group), -1)
+        dl = None if dlogit is None else dlogit.reshape(len(slot_of_group), -1)
+        for g, slot in enumerate(slot_of_group):
+            if slot < 0:
+                if dl is not None:
+                    dl[g].zero_()
+                continue
+            self.bce_logits(lg[g], target, None, None if dl is None else dl[g], loss_slots[slot:slot + 1], n, 0, 0, grad_scale)
+
     def mse(self, r, t, dr, loss_sum, n, grad_scale):
         d = r.reshape(-1)[:n] - t.reshape(-1)[:n]
         loss_sum += (d * d).double().sum()

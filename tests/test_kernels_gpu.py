@@ -518,6 +518,28 @@ def test_bf16_packed_weights(bf16_mode):
                       32, 32, 32, 1, 0, 1, 1], [3, 4])
 
 
+def test_bce_logits_groups_equals_per_pass_launches():
+    """One launch for all decoder passes of a modality (shared target, one loss slot per pass, a discarded pass marked by
+    slot -1) against one mmdyn_bce_logits per pass."""
+    B, G = 5, 4
+    n = B * 3 * 64 * 64
+    lg, tg = rnd(G * n, seed=400) * 3, torch.rand(n, generator=torch.Generator().manual_seed(401))
+    slots = [3, -1, 0, 5]
+    ref_loss, ref_d = torch.zeros(8, dtype=torch.float64, device=DEV), torch.zeros(G * n, device=DEV)
+    lgd, tgd = lg.to(DEV), tg.to(DEV)
+    for g, s in enumerate(slots):
+        if s >= 0:
+            HIP.bce_logits(lgd[g * n:(g + 1) * n], tgd, None, ref_d[g * n:(g + 1) * n], ref_loss[s:s + 1], n, 3 * 4096, 4096, 0.2)
+    loss, d = torch.zeros(8, dtype=torch.float64, device=DEV), torch.full((G * n,), 7.0, device=DEV)
+    HIP.bce_logits_groups(lgd, tgd, d, loss, slots, n, 0.2)
+    torch.cuda.synchronize()
+    assert torch.equal(d.cpu(), ref_d.cpu())
+    assert torch.allclose(loss.cpu(), ref_loss.cpu(), rtol=1e-12)
+    cpu_loss, cpu_d = torch.zeros(8, dtype=torch.float64), torch.zeros(G * n)
+    EMU.bce_logits_groups(lg.clone(), tg.clone(), cpu_d, cpu_loss, slots, n, 0.2)
+    assert rel(d.cpu(), cpu_d) <= 2e-5 and torch.allclose(loss.cpu(), cpu_loss, rtol=1e-5)
+
+
 def test_sgd_matches_torch():
     n = 50001
     p0, g = rnd(n, seed=80), rnd(n, seed=81) * 0.1
