@@ -540,6 +540,32 @@ def test_bce_logits_groups_equals_per_pass_launches():
     assert rel(d.cpu(), cpu_d) <= 2e-5 and torch.allclose(loss.cpu(), cpu_loss, rtol=1e-5)
 
 
+def test_im2col_generic_fallback_for_other_image_sizes():
+    """Images that are not 64x64 do not fit the specialised 3-channel kernels (conv3.hip) and take the tiled
+    implicit-GEMM / weight-gradient kernels with the on-the-fly im2col gather: forward with statistics, input gradient
+    with the BatchNorm epilogue, weight gradient."""
+    G, Bg, H = 2, 3, 32
+    Bt, Ho = G * Bg, H // 2
+    x = rnd(Bt, 3, H, H, seed=110)
+    Bp = rnd(1, 32, 64, seed=111, scale=0.2)
+    Bp[:, :, 48:] = 0
+    rows = Bt * Ho * Ho
+    T = HIP.igemm_stat_tiles(IM2COL3, G, Bg, H, H, 64, Ho, Ho, 32)
+    post = lambda i, t: t.sum(1) if t.dim() == 4 else t
+    C, Ca, stats = torch.zeros(rows, 32), torch.zeros(rows, 32), torch.zeros(G, T, 2, 32)
+    both("igemm_nt", [x, Bp, None, C, None, stats, None, IM2COL3, G, Bg, H, H, 64, Ho, Ho, 32, 32, 1, 0, 0, 1], [3, 5], post)
+    both("igemm_nt", [x, Bp, None, C, Ca, None, None, IM2COL3, G, Bg, H, H, 64, Ho, Ho, 32, 32, 1, 0, 1, 1], [3, 4], post)
+    y = rnd(rows, 32, seed=112) * 1.5 + 0.2
+    mean, rstd = rnd(G, 32, seed=113) * 0.3, rnd(G, 32, seed=114).abs() + 0.5
+    gamma, beta = rnd(32, seed=115) + 1.2, rnd(32, seed=116)
+    both("igemm_nt_dgrad_bn", [x, Bp, C, stats, y, mean, rstd, gamma, beta, IM2COL3, G, Bg, H, H, 64, Ho, Ho, 32, 1, 0],
+         [2, 3], post, tol=5e-5)
+    D = rnd(rows, 32, seed=117)
+    chunks = HIP.wgrad_chunks(IM2COL3, rows, 32, 64)
+    both("wgrad_tn", [D, x, torch.zeros(chunks, 1, 32, 64), IM2COL3, Bt, Ho, Ho, 32, H, H, 64, 1, 0, chunks], [2],
+         lambda i, t: t.sum(0), tol=5e-5)
+
+
 def test_sgd_matches_torch():
     n = 50001
     p0, g = rnd(n, seed=80), rnd(n, seed=81) * 0.1
