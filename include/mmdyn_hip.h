@@ -86,7 +86,10 @@ int mmdyn_igemm_nt_bf16(const float* A, const float* Bp, const float* bias, floa
                         float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
                         int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
                         void* stream);
+/* T of the `stats` argument for the shape: what mmdyn_igemm_nt / mmdyn_igemm_nt_dgrad_bn(bf16 = 0) write ... */
 int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
+/* ... and what the bf16 matrix-core variants (mmdyn_igemm_nt_bf16, mmdyn_igemm_nt_mx, dgrad_bn(bf16 = 1)) write */
+int mmdyn_igemm_stat_tiles_bf16(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
 int mmdyn_splitk_reduce(const float* ws, const float* bias, float* C, float* C_act, int splitk,
                         int rows, int N, int act, void* stream);
 
@@ -263,10 +266,11 @@ int mmdyn_reparam_bwd(const float* mu, const float* lv, const float* eps_noise, 
 
 /* ---- ELBO reconstruction terms (problems.py:433-449) ----------------------------------------- */
 /* sum over all elements of BCE-with-logits(x, t) added to *loss_sum (double); optional dlogit =
- * (sigmoid(x) - t) * grad_scale.  With `mask` (broadcast over channels: [B][1][H][W]) both logits and
- * targets are multiplied by it first (problems.py:445-447). */
+ * (sigmoid(x) - t) * grad_scale.  With `mask` ([B][mask_channels][H][W]; mask_channels = 1: broadcast over the
+ * channels, = C: elementwise, the dataset's 3-channel segmentation mask) both logits and targets are multiplied by it
+ * first (problems.py:445-447); any other channel count is MMDYN_ERR_SHAPE. */
 int mmdyn_bce_logits(const float* logits, const float* target, const float* mask, float* dlogit,
-                     double* loss_sum, int64_t n, int chw, int hw, float grad_scale, void* stream);
+                     double* loss_sum, int64_t n, int chw, int hw, int mask_channels, float grad_scale, void* stream);
 /* The unmasked term for G decoder passes that share one target, in ONE launch: logits / dlogit [G][n], target [n];
  * pass g adds its sum to loss_slots[slot_of_group[g]] (a host array, copied by value into the launch: capturable);
  * a negative slot marks a discarded reconstruction (zero gradient, no loss).  The multi-subset ELBO of

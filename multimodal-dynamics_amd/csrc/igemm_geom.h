@@ -1,0 +1,39 @@
+// Geometry of one implicit-GEMM launch, shared by the LDS-tiled kernels (igemm_nt.hip) and the wave-independent
+// direct-fragment kernels (igemm_d16.hip).
+#pragma once
+#include "common.h"
+
+struct IgemmGeom {
+  int mode;            // MMDYN_DENSE / MMDYN_CONV / MMDYN_TCONV_S2P1
+  int G, Bg;           // groups, samples per group
+  int Hr, Wr;          // row grid per sample (rows per sample = Hr*Wr)
+  int Hi, Wi, Cin;     // gathered operand
+  int Ho, Wo, N, ldc;  // output pixel grid, channels, row stride
+  int rs, ro;          // input base of a row: y0 = r*rs + ro
+  int os;              // output pixel of a row: (r*os + ph, c*os + pw)
+  int ntaps, nclasses, splitk;
+  int act, has_bias, want_stats, want_act_out;
+  int rows_total;      // G*Bg*Hr*Wr (split-K workspace stride)
+  int tiles_per_group; // ceil(Bg*Hr*Wr / BM); TCONV_S1P0: Ho*Wo*ceil(Bg/BM) (tiles never straddle an output pixel)
+  int tiles_per_pixel; // TCONV_S1P0 only: ceil(Bg/BM)
+  int s1p0_split;      // TCONV_S1P0 only: 1 = a block walks the four pixels of its quad, 2 = two blocks share the walk
+  // optional BatchNorm+Swish backward epilogue (input-gradient launches): the tile of dL/d(activation) is turned
+  // into du = da * swish'(gamma*xhat+beta) with xhat from the layer's saved pre-BN output, written to C, and the
+  // per-tile column sums (du, du*xhat) go to `stats` -- the reduction pass of the BatchNorm backward disappears
+  const float* bn_y;
+  const float* bn_mean;   // [G][N]
+  const float* bn_rstd;   // [G][N]
+  const float* bn_gamma;  // [N]
+  const float* bn_beta;   // [N]
+  // bf16 activation storage (bf16 matrix-core variants only): which of the activation tensors are bf16 in HBM
+  int a_b16, c_b16, bny_b16;
+  int b_b16;   // packed weights are bf16 (written so by the pack kernels in the bf16 modes: half the L2 -> LDS traffic)
+};
+
+// igemm_d16.hip: fp32 implicit GEMM on v_mfma_f32_16x16x4_f32 with operand fragments loaded straight from global
+// memory (no LDS, no block barrier).  Returns MMDYN_OK / an error code, or 1 when the shape is not served (the caller
+// then takes the LDS-tiled kernel).  d16_stat_tiles: number of BatchNorm partial-sum tiles per group it writes, 0 when
+// the shape is not served.
+int mmdyn_igemm_d16_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats,
+                        float* ws, IgemmGeom g, int stride, int offset, hipStream_t st);
+int mmdyn_igemm_d16_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);

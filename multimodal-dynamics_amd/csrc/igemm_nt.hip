@@ -18,37 +18,12 @@
 //   * epilogue: optional bias, optional second (activated) output, optional per-tile BatchNorm
 //     partial sums (column sums of the tile and of its squares), deterministic (no atomics).
 #include "common.h"
+#include "igemm_geom.h"
 #include <cstdio>
 #include <cstdlib>
 
 namespace {
 
-struct IgemmGeom {
-  int mode;            // MMDYN_DENSE / MMDYN_CONV / MMDYN_TCONV_S2P1
-  int G, Bg;           // groups, samples per group
-  int Hr, Wr;          // row grid per sample (rows per sample = Hr*Wr)
-  int Hi, Wi, Cin;     // gathered operand
-  int Ho, Wo, N, ldc;  // output pixel grid, channels, row stride
-  int rs, ro;          // input base of a row: y0 = r*rs + ro
-  int os;              // output pixel of a row: (r*os + ph, c*os + pw)
-  int ntaps, nclasses, splitk;
-  int act, has_bias, want_stats, want_act_out;
-  int rows_total;      // G*Bg*Hr*Wr (split-K workspace stride)
-  int tiles_per_group; // ceil(Bg*Hr*Wr / BM); TCONV_S1P0: Ho*Wo*ceil(Bg/BM) (tiles never straddle an output pixel)
-  int tiles_per_pixel; // TCONV_S1P0 only: ceil(Bg/BM)
-  int s1p0_split;      // TCONV_S1P0 only: 1 = a block walks the four pixels of its quad, 2 = two blocks share the walk
-  // optional BatchNorm+Swish backward epilogue (input-gradient launches): the tile of dL/d(activation) is turned
-  // into du = da * swish'(gamma*xhat+beta) with xhat from the layer's saved pre-BN output, written to C, and the
-  // per-tile column sums (du, du*xhat) go to `stats` -- the reduction pass of the BatchNorm backward disappears
-  const float* bn_y;
-  const float* bn_mean;   // [G][N]
-  const float* bn_rstd;   // [G][N]
-  const float* bn_gamma;  // [N]
-  const float* bn_beta;   // [N]
-  // bf16 activation storage (bf16 matrix-core variants only): which of the activation tensors are bf16 in HBM
-  int a_b16, c_b16, bny_b16;
-  int b_b16;   // packed weights are bf16 (written so by the pack kernels in the bf16 modes: half the L2 -> LDS traffic)
-};
 
 constexpr int BK = 32;              // K-step (channels of one tap per stage)
 constexpr int LDS_LD = BK + 4;      // row stride: one 16-byte pad slot keeps ds_read_b128 conflict-free
@@ -570,7 +545,7 @@ static int launch(const float* A, const float* Bp, const float* bias, float* C, 
 
 }  // namespace
 
-extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+static int lds_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   if (mode == MMDYN_TCONV_S1P0) {
     int bm, bn;
     pick_tile(N, Bg, G * 16, 1, 1, 0, &bm, &bn);
@@ -587,6 +562,16 @@ extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, i
   int bm, bn;
   pick_tile(N, Bg * Hr * Wr, G, ncls, 1, ksteps, &bm, &bn);
   return ncls * ceil_div(Bg * Hr * Wr, bm);
+}
+
+// fp32 launches go to the wave-independent kernels of igemm_d16.hip where those serve the shape; the bf16 matrix-core
+// modes always take the LDS-tiled kernels of this file.  The number of partial-sum tiles follows the kernel.
+extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+  const int t = mmdyn_igemm_d16_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  return t > 0 ? t : lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+}
+extern "C" int mmdyn_igemm_stat_tiles_bf16(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+  return lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
 }
 
 static int igemm_entry(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
@@ -675,6 +660,10 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   if (mode == MMDYN_IM2COL3) {     // the 3-channel layers have their own direct kernel (conv3.hip)
     const int rc = mmdyn_conv3_nt_try(A, Bp, bias, C, C_act, stats, G, Bg, Hi, Wi, Ho, Wo, N, ldc, act, splitk, bn_y,
                                       bn_mean, bn_rstd, bn_gamma, bn_beta, g.c_b16, g.bny_b16, g.b_b16, st);
+    if (rc != 1) return rc;
+  }
+  if (!bf16 && mode != MMDYN_IM2COL3) {
+    const int rc = mmdyn_igemm_d16_try(A, Bp, bias, C, C_act, stats, ws, g, stride, offset, st);
     if (rc != 1) return rc;
   }
   int bm, bn;

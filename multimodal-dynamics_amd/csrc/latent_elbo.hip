@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
                                                          const float* __restrict__ target,
                                                          const float* __restrict__ mask,
                                                          float* __restrict__ dlogit, double* __restrict__ loss,
-                                                         int64_t n, int chw, int hw, float grad_scale) {
+                                                         int64_t n, int chw, int hw, int mask_c, float grad_scale) {
   double acc = 0.0;
   const int64_t n4 = n >> 2;  // n is a multiple of 4 for image tensors (checked by the caller)
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
@@ -181,9 +181,12 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
     f32x4 mk = {1.f, 1.f, 1.f, 1.f};
     if (mask) {
       const int64_t e0 = i * 4;
+      // mask is [B][mask_c][H][W] with mask_c == 1 (broadcast over the channels) or == C (the dataset's 3-channel
+      // segmentation mask, elementwise): torch.mul(recon_i, loss_mask) of problems.py:445-447
       const int64_t b = e0 / chw;
-      const int pix = (int)((e0 - b * chw) % hw);
-      mk = *reinterpret_cast<const f32x4*>(mask + b * hw + pix);
+      const int rem = (int)(e0 - b * chw);
+      const int ch = rem / hw, pix = rem - ch * hw;
+      mk = *reinterpret_cast<const f32x4*>(mask + (b * mask_c + (mask_c == 1 ? 0 : ch)) * hw + pix);
     }
     f32x4 d;
     float part = 0.f;
@@ -333,14 +336,15 @@ extern "C" int mmdyn_reparam_bwd(const float* mu, const float* lv, const float* 
 }
 
 extern "C" int mmdyn_bce_logits(const float* logits, const float* target, const float* mask, float* dlogit,
-                                double* loss_sum, int64_t n, int chw, int hw, float grad_scale,
+                                double* loss_sum, int64_t n, int chw, int hw, int mask_channels, float grad_scale,
                                 void* stream) {
   if (!logits || !target || !loss_sum) return MMDYN_ERR_NULL;
-  if (n % 4 || (mask && (hw % 4 || chw % hw))) return MMDYN_ERR_SHAPE;
+  if (n % 4 || (mask && (hw <= 0 || hw % 4 || chw % hw || n % chw || (mask_channels != 1 && mask_channels != chw / hw))))
+    return MMDYN_ERR_SHAPE;
   int g = ew_grid(n / 4);
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(bce_logits_kernel, dim3(g), dim3(256), 0, ST, logits, target, mask, dlogit, loss_sum, n,
-                     chw, hw, grad_scale);
+                     chw, hw, mask_channels, grad_scale);
   MMDYN_LAUNCH_CHECK();
 }
 

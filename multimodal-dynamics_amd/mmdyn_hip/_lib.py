@@ -32,6 +32,7 @@ _SIGNATURES = {
     "mmdyn_igemm_nt_dgrad_bn": "ppppppppp" + "iiiiiiiiiiii" + "p",
     "mmdyn_igemm_nt_bf16": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_stat_tiles": "iiiiiiiii",
+    "mmdyn_igemm_stat_tiles_bf16": "iiiiiiiii",
     "mmdyn_splitk_reduce": "pppp" + "iiii" + "p",
     "mmdyn_wgrad_tn": "ppp" + "iiiiiiiiiii" + "p",
     "mmdyn_wgrad_tn_bf16": "ppp" + "iiiiiiiiiii" + "p",
@@ -74,7 +75,7 @@ _SIGNATURES = {
     "mmdyn_poe_bwd": "ppppppp" + "f" + "iiii" + "p",
     "mmdyn_reparam_fwd": "ppppp" + "iii" + "p",
     "mmdyn_reparam_bwd": "pppp" + "f" + "pp" + "iii" + "p",
-    "mmdyn_bce_logits": "ppppp" + "l" + "ii" + "f" + "p",
+    "mmdyn_bce_logits": "ppppp" + "l" + "iii" + "f" + "p",
     "mmdyn_bce_logits_groups": "ppppp" + "i" + "l" + "f" + "p",
     "mmdyn_mse": "pppp" + "l" + "f" + "p",
     "mmdyn_elbo_assemble": "ppppp" + "ii" + "ff" + "p",

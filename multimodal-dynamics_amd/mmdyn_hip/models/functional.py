@@ -265,8 +265,16 @@ class BCEWithLogitsSumFn(torch.autograd.Function):
         chw = n // x.shape[0]
         acc = torch.zeros(1, dtype=torch.float64, device=x.device)
         d = torch.empty_like(x)
-        mk = None if mask is None else mask.detach().to(x.dtype).contiguous()
-        ops.B.bce_logits(x, t, mk, d, acc, n, chw, hw, 1.0)
+        mk, mc = None, 1
+        if mask is not None:
+            # torch.mul(recon_i, loss_mask) broadcasts: the synthetic mask is [B,1,H,W], the dataset's segmentation
+            # mask [B,C,H,W] (datasets.py: 3-channel PNG); anything else is expanded to the logits' shape first
+            mk = mask.detach().to(x.dtype)
+            if mk.dim() != 4 or mk.shape[0] != x.shape[0] or mk.shape[2:] != x.shape[2:] or mk.shape[1] not in (1, x.shape[1]):
+                mk = mk.expand_as(x)
+            mk = mk.contiguous()
+            mc = mk.shape[1]
+        ops.B.bce_logits(x, t, mk, d, acc, n, chw, hw, 1.0, mc)
         ctx.save_for_backward(d)
         return acc[0].to(torch.float32)
 

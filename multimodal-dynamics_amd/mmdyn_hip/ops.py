@@ -61,7 +61,9 @@ class HipBackend:
 
     # ---- host-only helpers (no GPU needed) ----
     def igemm_stat_tiles(self, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N):
-        return self.lib.mmdyn_igemm_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+        """T of the per-tile BatchNorm partial sums the implicit GEMM of the current precision mode writes."""
+        fn = self.lib.mmdyn_igemm_stat_tiles if self.precision == "fp32" else self.lib.mmdyn_igemm_stat_tiles_bf16
+        return fn(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
 
     def colstats_tiles(self, rows_per_group):
         return self.lib.mmdyn_colstats_tiles(rows_per_group)
@@ -316,9 +318,12 @@ class HipBackend:
         check(self.lib.mmdyn_reparam_bwd(mu.data_ptr(), lv.data_ptr(), _ptr(eps_noise), _ptr(dz), float(kl_scale),
                                          dmu.data_ptr(), dlv.data_ptr(), B, L, ld, _stream()), "mmdyn_reparam_bwd")
 
-    def bce_logits(self, logits, target, mask, dlogit, loss_sum, n, chw, hw, grad_scale):
+    def bce_logits(self, logits, target, mask, dlogit, loss_sum, n, chw, hw, grad_scale, mask_channels=1):
+        if mask is not None and mask.numel() * chw != n * mask_channels * hw:
+            raise ValueError(f"mmdyn_bce_logits: mask of {mask.numel()} elements does not match [B={n // chw}]"
+                             f"[{mask_channels}][hw={hw}]")
         check(self.lib.mmdyn_bce_logits(_ptr(logits), _ptr(target), _ptr(mask), _ptr(dlogit),
-                                        loss_sum.data_ptr(), n, chw, hw, float(grad_scale), _stream()),
+                                        loss_sum.data_ptr(), n, chw, hw, int(mask_channels), float(grad_scale), _stream()),
               "mmdyn_bce_logits")
 
     def bce_logits_groups(self, logits, target, dlogit, loss_slots, slot_of_group, n, grad_scale):

@@ -466,11 +466,12 @@ class EmuBackend:
         dmu[:, :L] = gm
         dlv[:, :L] = gv
 
-    def bce_logits(self, logits, target, mask, dlogit, loss_sum, n, chw, hw, grad_scale):
+    def bce_logits(self, logits, target, mask, dlogit, loss_sum, n, chw, hw, grad_scale, mask_channels=1):
         x, t = logits.reshape(-1)[:n], target.reshape(-1)[:n]
         if mask is not None:
             c = chw // hw
-            mk = mask.reshape(-1, 1, hw).expand(-1, c, hw).reshape(-1)
+            assert mask_channels in (1, c) and mask.numel() == (n // chw) * mask_channels * hw
+            mk = mask.reshape(-1, mask_channels, hw).expand(-1, c, hw).reshape(-1)
             x, t = x * mk, t * mk
         loss_sum += F.binary_cross_entropy_with_logits(x, t, reduction="sum").double()
         if dlogit is not None:

@@ -106,6 +106,60 @@ def test_igemm_dgrad_bn_epilogue(case):
 
 
 @pytest.fixture()
+def d16_tile(request, monkeypatch):
+    """Force one wave-tile shape of the direct-fragment fp32 kernels (igemm_d16.hip); without this the small test shapes
+    fall below its work threshold and run the LDS-tiled kernel."""
+    monkeypatch.setenv("MMDYN_D16_TILE", request.param)
+    yield request.param
+    monkeypatch.delenv("MMDYN_D16_TILE")
+
+
+D16_TILES = ["4,4", "8,2", "4,2", "2,2"]
+
+
+@pytest.mark.parametrize("d16_tile", D16_TILES, indirect=True)
+@pytest.mark.parametrize("case", IGEMM_CASES)
+def test_igemm_d16(case, d16_tile):
+    test_igemm_nt(case)
+
+
+@pytest.mark.parametrize("d16_tile", D16_TILES, indirect=True)
+@pytest.mark.parametrize("case", [c for c in IGEMM_CASES if c[0] != DENSE][:6] + [IGEMM_CASES[0]])
+def test_igemm_d16_dgrad_bn_epilogue(case, d16_tile):
+    test_igemm_dgrad_bn_epilogue(case)
+
+
+@pytest.mark.parametrize("d16_tile", D16_TILES, indirect=True)
+@pytest.mark.parametrize("rows,K,N,splitk", [(256, 6400, 512, 25), (64, 512, 256, 3), (1024, 6400, 256, 8), (5, 64, 32, 2)])
+def test_igemm_d16_splitk(rows, K, N, splitk, d16_tile):
+    test_igemm_splitk(rows, K, N, splitk)
+
+
+def test_igemm_d16_full_size_shapes():
+    """The bs-256 step's own decoder shapes (tile rule unforced: these are the launches the direct kernels serve):
+    row-sum / column-sum identities instead of an O(M N K) reference.  sum_n C[row][n] = A_row . (sum_n B_n) per tap."""
+    for mode, G, Bg, Hi, Cin, Ho, N, stride, offset in [(TCONV_S2P1, 4, 256, 8, 128, 16, 64, 1, 0),
+                                                        (CONV, 1, 1024, 16, 64, 8, 128, 2, -1),
+                                                        (TCONV_S1P0, 4, 256, 5, 256, 8, 128, 1, 0),
+                                                        (TCONV_S2P1, 4, 256, 16, 64, 32, 32, 1, 0)]:
+        Bt = G * Bg
+        A = rnd(Bt * Hi * Hi, Cin, seed=61).to(DEV)
+        Bp = rnd(16, N, Cin, seed=62, scale=0.2).to(DEV)
+        C = torch.zeros(Bt * Ho * Ho, N, device=DEV)
+        T = HIP.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
+        stats = torch.zeros(G, T, 2, N, device=DEV)
+        HIP.igemm_nt(A, Bp, None, C, None, stats, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1)
+        # the same launch with the N columns collapsed into 32 identical columns of sum_n B: every column = row sums of C
+        Bs = Bp.sum(1, keepdim=True).expand(16, 32, Cin).contiguous()
+        Cs = torch.zeros(Bt * Ho * Ho, 32, device=DEV)
+        HIP.igemm_nt(A, Bs, None, Cs, None, None, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, 32, 32, stride, offset, 0, 1)
+        assert rel(C.sum(1), Cs[:, 0]) < 2e-5, (mode, "row sums")
+        # BatchNorm partial sums are the column sums of what was written
+        Cg = C.view(G, -1, N)
+        assert rel(stats[:, :, 0].sum(1), Cg.sum(1)) < 2e-5 and rel(stats[:, :, 1].sum(1), (Cg * Cg).sum(1)) < 2e-5
+
+
+@pytest.fixture()
 def bf16_mode():
     """bf16 matrix cores: the kernels round fp32 operands to bf16 (RNE) and accumulate in fp32; the emulation does
     the same rounding, so both agree to fp32 summation-order error -- a wrong rounding mode or k-slice layout would
