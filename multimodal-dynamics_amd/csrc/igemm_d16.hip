@@ -69,8 +69,8 @@ __global__ __launch_bounds__(256, 2) void igemm_d16_kernel(const float* __restri
   const int nb = gridDim.x, b = blockIdx.x;
   const int xq = nb >> 3, xr = nb & 7, xcd = b & 7;
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
-  const int wt = logical * 4 + wave;
-  if (wt >= p.tiles) return;                      // (no barrier anywhere in this kernel)
+  // persistent form (grid smaller than the tile count): a wave walks tiles first, first + slots, ...
+  for (int wt = logical * 4 + wave; wt < p.tiles; wt += nb * 4) {      // (no barrier anywhere in this kernel)
   const int per_split = p.MX * p.S;
   const int split = wt / per_split;
   const int rest = wt - split * per_split;
@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void igemm_d16_kernel(const float* __restri
       }
     }
   }  // sub-pixel walk
+  }  // tile walk
 }
 
 // ---- tile choice ------------------------------------------------------------------------------------------------
@@ -332,6 +333,21 @@ static bool d16_pick(const IgemmGeom& g, D16Tile* t) {
     }
   }
   const D16Tile* cand = (g.N % 64 == 0) ? wide : narrow;
+  static int min_tiles = -1, min_steps = -1, only_big = -1;
+  if (min_tiles < 0) {
+    const char* a = getenv("MMDYN_D16_MIN_TILES");
+    const char* b = getenv("MMDYN_D16_MIN_STEPS");
+    const char* c = getenv("MMDYN_D16_ONLY_BIG");
+    min_tiles = a ? atoi(a) : 512;
+    min_steps = b ? atoi(b) : 0;
+    only_big = c ? atoi(c) : 0;
+  }
+  const int steps = (g.mode == MMDYN_TCONV_S1P0 ? 6 : g.ntaps) * (g.Cin / 32) / g.splitk;
+  if (steps < min_steps) return false;
+  if (only_big) {                   // experiments: the first candidate tile or nothing
+    *t = cand[0];
+    return d16_tiles(g, cand[0].mt, cand[0].nt) >= min_tiles;
+  }
   D16Tile best = cand[0];
   for (int i = 0; i < 3; ++i) {
     best = cand[i];
@@ -339,11 +355,16 @@ static bool d16_pick(const IgemmGeom& g, D16Tile* t) {
   }
   *t = best;
   // too little work even for the smallest tile: the block-tiled kernel (4 waves per 64 x 64 tile) spreads it further
-  return d16_tiles(g, best.mt, best.nt) >= 512;
+  return d16_tiles(g, best.mt, best.nt) >= min_tiles;
 }
 
+// Opt-in (MMDYN_D16=1, or a forced tile shape): alone on the chip these kernels are the fastest fp32 GEMMs of the library
+// on long-K shapes (119-137 TFLOP/s), but a launch keeps two 212-register waves resident on every SIMD for its whole
+// duration, and inside the two-lane training step that starves the other lane's kernels: measured 7.26-7.9 ms per step
+// against 7.0 ms with the LDS-tiled kernels, whatever subset of shapes was routed here (profiles/r2/d16_step_sweep.txt).
 static bool d16_serves(const IgemmGeom& g) {
-  if (getenv("MMDYN_NO_D16")) return false;
+  const char* en = getenv("MMDYN_D16");
+  if (!(en && atoi(en) != 0) && !getenv("MMDYN_D16_TILE")) return false;
   if (g.mode != MMDYN_DENSE && g.mode != MMDYN_CONV && g.mode != MMDYN_TCONV_S2P1 && g.mode != MMDYN_TCONV_S1P0) return false;
   if (g.a_b16 || g.c_b16 || g.bny_b16 || g.b_b16) return false;
   if (g.Cin % 32 || g.N % 32) return false;
@@ -375,8 +396,16 @@ static int launch_mt(const float* A, const float* Bp, const float* bias, float* 
   p.a_bytes = (unsigned)((long)g.G * g.Bg * g.Hi * g.Wi * g.Cin * 4);
   const int ntaps_w = (g.mode == MMDYN_DENSE) ? 1 : 16;
   p.b_bytes = (unsigned)((long)ntaps_w * g.N * g.Cin * 4);
-  hipLaunchKernelGGL((igemm_d16_kernel<MODE, MT, NT>), dim3(ceil_div(p.tiles, 4)), dim3(256), 0, st, A, Bp, bias, C, C_act,
-                     stats, ws, p);
+  // MMDYN_D16_BLOCKS = n: persistent launch of at most n workgroups (256 = one wave per SIMD: the two lanes of the
+  // step then hold one wave slot per SIMD each instead of one lane's launch filling both)
+  static int max_blocks = -1;
+  if (max_blocks < 0) {
+    const char* e = getenv("MMDYN_D16_BLOCKS");
+    max_blocks = e ? atoi(e) : 0;
+  }
+  int blocks = ceil_div(p.tiles, 4);
+  if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL((igemm_d16_kernel<MODE, MT, NT>), dim3(blocks), dim3(256), 0, st, A, Bp, bias, C, C_act, stats, ws, p);
   MMDYN_LAUNCH_CHECK();
 }
 

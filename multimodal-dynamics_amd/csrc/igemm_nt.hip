@@ -26,7 +26,7 @@ namespace {
 
 
 constexpr int BK = 32;              // K-step (channels of one tap per stage)
-constexpr int LDS_LD = BK + 4;      // row stride: one 16-byte pad slot keeps ds_read_b128 conflict-free
+constexpr int LDS_LD32 = BK + 4;    // row stride of the 32x32x2 variants: one 16-byte pad slot keeps ds_read_b128 conflict-free
 constexpr int GRANS = BK / 4;       // 16-byte granules per tile row
 constexpr int ROWS_PER_PASS = 256 / GRANS;
 
@@ -42,14 +42,22 @@ __device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {
 
 // WIDE (bf16 activations AND bf16 packed weights, Cin % 64 == 0): K-step of 64 channels moved as 16-byte granules of
 // eight bf16; thread -> (row, granule) mapping and LDS bytes per row (144) are the same as in the 32-channel variants
-template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16, bool B16, bool WIDE = false>
+// M16 (fp32 only): the wave's WM x WN outputs are 16x16 tiles of v_mfma_f32_16x16x4_f32 instead of 32x32 tiles of
+// v_mfma_f32_32x32x2_f32 -- same rate per clock, but a 32x32-output wave then owns FOUR independent accumulators instead of
+// one dependent chain.  Measured (tests/microbench/lds_mfma_shape.hip, MI355X): +7..17 % on the 64x64 block tile, no
+// difference on 128x128 (which keeps the 32x32 shape).  LDS row stride 40 floats keeps its ds_read_b128 conflict-free.
+template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16, bool B16, bool WIDE = false, bool M16 = false>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__ A,
                                                        const float* __restrict__ Bp,
                                                        const float* __restrict__ bias,
                                                        float* __restrict__ C, float* __restrict__ C_act,
                                                        float* __restrict__ stats, float* __restrict__ ws,
                                                        const IgemmGeom g) {
-  constexpr int MT = WM / 32, NT = WN / 32;
+  static_assert(!M16 || !BF16, "the 16x16x4 shape is the fp32 variant");
+  constexpr int TS = M16 ? 16 : 32;                   // side of one MFMA output tile
+  constexpr int NE = M16 ? 4 : 16;                    // accumulator registers per tile
+  constexpr int LDS_LD = M16 ? BK + 8 : BK + 4;       // fp32 tile row stride (floats): conflict-free fragment reads
+  constexpr int MT = WM / TS, NT = WN / TS;
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
   static_assert(WAVES_N * WAVES_M == 4, "4 waves per block");
@@ -57,12 +65,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   constexpr int KB = WIDE ? 64 : BK;                  // channels per K-step
   constexpr int A_LOADS = BM / ROWS_PER_PASS, B_LOADS = BN / ROWS_PER_PASS;
   static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile smaller than one load pass");
-  constexpr int STAGE = (BM + BN) * LDS_LD;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* As = reinterpret_cast<float*>(smem);            // [BM][LDS_LD] then [BN][LDS_LD]
   float* Bs = As + BM * LDS_LD;
-  int* rowinfo = reinterpret_cast<int*>(As + STAGE);  // [BM][4]: b, y0, x0, out offset (-1: none)
+  int* rowinfo = reinterpret_cast<int*>(As + (BM + BN) * LDS_LD);  // [BM][4]: b, y0, x0, out offset (-1: none)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -290,15 +297,18 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       *reinterpret_cast<f32x4*>(&Bs[(lrow + ROWS_PER_PASS * j) * LDS_LD + gran * 4]) = rbv[j];
   };
 
-  f32x16 acc[MT][NT];
+  typedef float accv_t __attribute__((ext_vector_type(NE)));
+  accv_t acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+      for (int e = 0; e < NE; ++e) acc[mt][nt][e] = 0.f;
 
-  const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
+  // 32x32x2: lane (row l&31, half l>>5) reads k = 8q + 4h .. +3;  16x16x4: lane (row l&15, quarter l>>4) reads
+  // k = 16q + 4*(l>>4) .. +3 (MFMA j multiplies the j-th element of the four lanes' granules)
+  const int frag_off = M16 ? (lane & 15) * LDS_LD + (lane >> 4) * 4 : (lane & 31) * LDS_LD + (lane >> 5) * 4;
   if (s_begin < s_end) {
     gload();
     lds_store();
@@ -325,6 +335,24 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
             for (int nt = 0; nt < NT; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mt], pb[nt], acc[mt][nt], 0, 0, 0);
         }
+      } else if constexpr (M16) {
+#pragma unroll
+        for (int q = 0; q < BK / 16; ++q) {
+          f32x4 af[MT], bf[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            af[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * WM + mt * 16) * LDS_LD + frag_off + q * 16]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            bf[nt] = *reinterpret_cast<const f32x4*>(&Bc[(wn * WN + nt * 16) * LDS_LD + frag_off + q * 16]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+        }
       } else
 #pragma unroll
       for (int q = 0; q < BK / 8; ++q) {
@@ -350,7 +378,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   }
 
   // ---- epilogue ----
-  const int h = lane >> 5, cl = lane & 31;
+  // accumulator element e of tile (mt, nt): 32x32 -> row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31;
+  //                                        16x16 -> row 4*(l>>4) + e, column l&15
+  const int h = M16 ? (lane >> 4) : (lane >> 5), cl = M16 ? (lane & 15) : (lane & 31);
   float colsum[NT], colsq[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) colsum[nt] = colsq[nt] = 0.f;
@@ -358,7 +388,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   float bn_m[NT], bn_r[NT], bn_g[NT], bn_b[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int col = n0 + wn * WN + nt * 32 + cl;
+    const int col = n0 + wn * WN + nt * TS + cl;
     bn_m[nt] = bnbwd ? g.bn_mean[(size_t)grp * g.N + col] : 0.f;
     bn_r[nt] = bnbwd ? g.bn_rstd[(size_t)grp * g.N + col] : 0.f;
     bn_g[nt] = bnbwd ? g.bn_gamma[col] : 0.f;
@@ -368,12 +398,12 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = wm * WM + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    for (int e = 0; e < NE; ++e) {
+      const int r = wm * WM + mt * TS + (M16 ? 4 * h + e : (e & 3) + 8 * (e >> 2) + 4 * h);
       const int ooff = rowinfo[r * 4 + 3];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int col = n0 + wn * WN + nt * 32 + cl;
+        const int col = n0 + wn * WN + nt * TS + cl;
         float v = acc[mt][nt][e];
         if (bnbwd) {
           float xh = 0.f;
@@ -423,9 +453,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
     for (int nt = 0; nt < NT; ++nt) {
       float s = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
       float q = colsq[nt] + __shfl_xor(colsq[nt], 32, 64);
+      if constexpr (M16) {               // a column's rows sit in the four lanes l, l+16, l+32, l+48
+        s += __shfl_xor(s, 16, 64);
+        q += __shfl_xor(q, 16, 64);
+      }
       if (h == 0) {
-        red[(wm * 2 + 0) * BN + wn * WN + nt * 32 + cl] = s;
-        red[(wm * 2 + 1) * BN + wn * WN + nt * 32 + cl] = q;
+        red[(wm * 2 + 0) * BN + wn * WN + nt * TS + cl] = s;
+        red[(wm * 2 + 1) * BN + wn * WN + nt * TS + cl] = q;
       }
     }
     __syncthreads();
@@ -514,12 +548,24 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   }
   const int mx8 = (g.G * g.tiles_per_group + 7) / 8 * 8;
   dim3 grid((unsigned)mx8 * (g.N / BN) * g.nclasses * g.splitk);
-  size_t smem = (size_t)(BM + BN) * LDS_LD * sizeof(float) + (size_t)BM * 4 * sizeof(int);
+  // fp32: 16x16x4 MFMA tiles (see the M16 note at the kernel) where the per-shape sweep of the step's launches shows a win
+  // (profiles/r2/igemm_mfma_shape_sweep.txt): large launches (>= 2048 blocks, >= 8 K-steps) of every block tile but
+  // 128x128: +3..6 % there, -2..4 % on the small encoder-side launches, which keep the 32x32x2 shape.
+  // MMDYN_IGEMM_M32=1 / MMDYN_IGEMM_M16=1 force one shape everywhere (kernel experiments)
+  constexpr bool M16_TILE = !(BM == 128 && BN == 128);
+  const bool force_m32 = getenv("MMDYN_IGEMM_M32") != nullptr, force_m16 = getenv("MMDYN_IGEMM_M16") != nullptr;
+  const long nblocks = (long)g.G * g.tiles_per_group * (g.N / BN) * g.nclasses * g.splitk;
+  const int ksteps = (MODE == MMDYN_TCONV_S1P0 ? 6 : g.ntaps) * (g.Cin / BK) / g.splitk;
+  const bool m16 = !bf16 && M16_TILE && !force_m32 && (force_m16 || (nblocks >= 2048 && ksteps >= 8));
+  size_t smem = (size_t)(BM + BN) * (m16 ? BK + 8 : LDS_LD32) * sizeof(float) + (size_t)BM * 4 * sizeof(int);
 #define IGEMM_LAUNCH(BF, A16_, B16_)                                                                                     \
   hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, BF, A16_, B16_>), grid, dim3(256), smem, st, A, Bp, bias, C, \
                      C_act, stats, ws, g)
   constexpr bool CAN_A16 = MODE != MMDYN_IM2COL3;
-  if (!bf16) IGEMM_LAUNCH(false, false, false);
+  if (m16)
+    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, false, false, false, false, M16_TILE>), grid, dim3(256), smem, st, A,
+                       Bp, bias, C, C_act, stats, ws, g);
+  else if (!bf16) IGEMM_LAUNCH(false, false, false);
   else if (g.a_b16 && g.b_b16 && CAN_A16 && g.Cin % 64 == 0)
     hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, CAN_A16, true, CAN_A16>), grid, dim3(256), smem, st, A, Bp,
                        bias, C, C_act, stats, ws, g);

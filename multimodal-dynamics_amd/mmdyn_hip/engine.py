@@ -194,7 +194,7 @@ class MVAEStep:
                 specs["hp"] = layers.heads_pack_specs(FP.sub("pose_encoder"))
             # what the encoder forward reads goes first (critical path); the transposed / decoder packs are launched
             # next to the encoder phase (run_late) and are ready long before the decoders start
-            self.plan = layers.PackPlan(specs, early=("W1p", "W2k", "W3k", "W4k", "Wf", "Wh", "bh"),
+            self.plan = layers.PackPlan(specs, early=("W1p", "W2k", "W3k", "W4k", "W5k", "W6k", "Wf", "Wh", "bh"),
                                         w_dtype=torch.float32 if precision == "fp32" else torch.bfloat16)
         self._capturing = False
         self._graph = None
@@ -311,7 +311,7 @@ class MVAEStep:
         # every live pass of the modality against the same target: one launch, one loss slot per pass
         # (slot -1: exact_running_stats ran a pass whose reconstruction is discarded -- zero gradient, no loss)
         ops.B.bce_logits_groups(lg, c["tg"][m], dl, self.acc[0], [p if p in live else -1 for p in plist],
-                                B * 3 * 64 * 64, 1.0 / B)
+                                c["tg"][m].numel(), 1.0 / B)
         c["lg" + m], c["dl" + m] = lg, dl
 
     def _ph_pose_dec_fwd(self):
@@ -642,9 +642,10 @@ class MVAEInference:
         """(Re)pack the weights -- call after ``load_state_dict``.  Captured graphs stay valid (the packed buffers and
         the parameter storage do not move)."""
         m = self.model
-        self.P = {"ve": self._P("visual_encoder", layers.ENC_KEYS + layers.HEAD_KEYS),
-                  "te": self._P("tactile_encoder", layers.ENC_KEYS + layers.HEAD_KEYS),
-                  "vd": self._P("visual_decoder", layers.DEC_KEYS), "td": self._P("tactile_decoder", layers.DEC_KEYS)}
+        self.P = {"ve": self._P("visual_encoder", m.visual_encoder.param_keys() + layers.HEAD_KEYS),
+                  "te": self._P("tactile_encoder", m.tactile_encoder.param_keys() + layers.HEAD_KEYS),
+                  "vd": self._P("visual_decoder", m.visual_decoder.param_keys()),
+                  "td": self._P("tactile_decoder", m.tactile_decoder.param_keys())}
         self.buf = {"ve": m.visual_encoder.bn_buffers(), "te": m.tactile_encoder.bn_buffers(),
                     "vd": m.visual_decoder.bn_buffers(), "td": m.tactile_decoder.bn_buffers()}
         if self.use_pose:

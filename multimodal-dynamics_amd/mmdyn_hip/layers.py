@@ -245,29 +245,66 @@ def _spec(name, src, kind, rin, cin, rout, cout, shape, part=None):
     return dict(name=name, src=src, kind=kind, rin=rin, cin=cin, rout=rout, cout=cout, shape=tuple(shape), part=part)
 
 
+def enc_layout(P):
+    """Sequential indices of the convolutions that follow conv_net.0 (each has its BatchNorm at index + 1) and the
+    input size they imply: 64 * 2**extra (models/shapes.py: the 128 / 256 pixel extensions add 32 -> 32 stages)."""
+    idx = sorted(int(k.split(".")[1]) for k in P if k.startswith("conv_net.") and k.endswith(".weight") and P[k].dim() == 4)
+    assert idx[0] == 0 and len(idx) >= 4, idx
+    return idx[1:], 64 << (len(idx) - 4)
+
+
+def dec_layout(P):
+    """Sequential indices of the transposed convolutions in front of the last one, the index of the last one, and the
+    output size."""
+    idx = sorted(int(k.split(".")[1]) for k in P if k.startswith("hallucinate.") and k.endswith(".weight") and P[k].dim() == 4)
+    assert len(idx) >= 4, idx
+    return idx[:-1], idx[-1], 64 << (len(idx) - 4)
+
+
+def enc_keys(extra=0):
+    ks = ["conv_net.0.weight"]
+    for j in range(3 + extra):
+        ks += [f"conv_net.{2 + 3 * j}.weight", f"conv_net.{3 + 3 * j}.weight", f"conv_net.{3 + 3 * j}.bias"]
+    return ks + ["fc_net.0.weight", "fc_net.0.bias"]
+
+
+def dec_keys(extra=0):
+    ks = ["upsample.0.weight", "upsample.0.bias"]
+    for j in range(3 + extra):
+        ks += [f"hallucinate.{3 * j}.weight", f"hallucinate.{3 * j + 1}.weight", f"hallucinate.{3 * j + 1}.bias"]
+    return ks + [f"hallucinate.{3 * (3 + extra)}.weight"]
+
+
 def encoder_pack_specs(P):
-    c = lambda k, kind, d0, d1: _spec(k[0], P[k[1]], kind, d0, d1, 0, 0, (16, d1, d0) if kind == K_SWAP else (16, d0, d1))
-    return [_spec("W1p", P["conv_net.0.weight"], 0, 32, 48, 32, 64, (32, 64)),
-            c(("W2k", "conv_net.2.weight"), K_KEEP, 64, 32), c(("W3k", "conv_net.5.weight"), K_KEEP, 128, 64),
-            c(("W4k", "conv_net.8.weight"), K_KEEP, 256, 128),
-            _spec("Wf", P["fc_net.0.weight"], 2, 512, FEAT, 512, FEAT, (512, FEAT)),
-            _spec("WfT", P["fc_net.0.weight"], 4, 512, FEAT, FEAT, 512, (FEAT, 512)),
-            c(("W4s", "conv_net.8.weight"), K_SWAP, 256, 128), c(("W3s", "conv_net.5.weight"), K_SWAP, 128, 64),
-            c(("W2s", "conv_net.2.weight"), K_SWAP, 64, 32)]
+    """Packed GEMM operands of an image encoder: W1p (first layer, im2col form), W{j}k / W{j}s (tap-major forward /
+    swapped input-gradient form of the j-th convolution, j = 2..), Wf / WfT (FC, flatten order absorbed)."""
+    def c(name, key, kind):
+        d0, d1 = P[key].shape[0], P[key].shape[1]
+        return _spec(name, P[key], kind, d0, d1, 0, 0, (16, d1, d0) if kind == K_SWAP else (16, d0, d1))
+    convs, _ = enc_layout(P)
+    fwd = [c(f"W{j + 2}k", f"conv_net.{i}.weight", K_KEEP) for j, i in enumerate(convs)]
+    bwd = [c(f"W{j + 2}s", f"conv_net.{i}.weight", K_SWAP) for j, i in reversed(list(enumerate(convs)))]
+    return ([_spec("W1p", P["conv_net.0.weight"], 0, 32, 48, 32, 64, (32, 64))] + fwd +
+            [_spec("Wf", P["fc_net.0.weight"], 2, 512, FEAT, 512, FEAT, (512, FEAT)),
+             _spec("WfT", P["fc_net.0.weight"], 4, 512, FEAT, FEAT, 512, (FEAT, 512))] + bwd)
 
 
 def decoder_pack_specs(P):
+    """Wu / bu / WuT (FC), W{j}s (forward form of the j-th transposed convolution, j = 1..), W{n}p (last layer's
+    input-gradient operand, im2col form), W{j}k (input-gradient form)."""
     L = P["upsample.0.weight"].shape[1]          # latent (+ condition_dim)
     Lp = _pad32(L)
-    c = lambda k, kind, d0, d1: _spec(k[0], P[k[1]], kind, d0, d1, 0, 0, (16, d1, d0) if kind == K_SWAP else (16, d0, d1))
-    return [_spec("Wu", P["upsample.0.weight"], 3, FEAT, L, FEAT, Lp, (FEAT, Lp)),
-            _spec("bu", P["upsample.0.bias"], 3, FEAT, 1, FEAT, 1, (FEAT,)),
-            c(("W1s", "hallucinate.0.weight"), K_SWAP, 256, 128), c(("W2s", "hallucinate.3.weight"), K_SWAP, 128, 64),
-            c(("W3s", "hallucinate.6.weight"), K_SWAP, 64, 32),
-            _spec("W4p", P["hallucinate.9.weight"], 0, 32, 48, 32, 64, (32, 64)),
-            c(("W3k", "hallucinate.6.weight"), K_KEEP, 64, 32), c(("W2k", "hallucinate.3.weight"), K_KEEP, 128, 64),
-            c(("W1k", "hallucinate.0.weight"), K_KEEP, 256, 128),
-            _spec("WuT", P["upsample.0.weight"], 5, FEAT, L, Lp, FEAT, (Lp, FEAT))]
+
+    def c(name, key, kind):
+        d0, d1 = P[key].shape[0], P[key].shape[1]
+        return _spec(name, P[key], kind, d0, d1, 0, 0, (16, d1, d0) if kind == K_SWAP else (16, d0, d1))
+    convs, last, _ = dec_layout(P)
+    fwd = [c(f"W{j + 1}s", f"hallucinate.{i}.weight", K_SWAP) for j, i in enumerate(convs)]
+    bwd = [c(f"W{j + 1}k", f"hallucinate.{i}.weight", K_KEEP) for j, i in reversed(list(enumerate(convs)))]
+    return ([_spec("Wu", P["upsample.0.weight"], 3, FEAT, L, FEAT, Lp, (FEAT, Lp)),
+             _spec("bu", P["upsample.0.bias"], 3, FEAT, 1, FEAT, 1, (FEAT,))] + fwd +
+            [_spec(f"W{len(convs) + 1}p", P[f"hallucinate.{last}.weight"], 0, 32, 48, 32, 64, (32, 64))] + bwd +
+            [_spec("WuT", P["upsample.0.weight"], 5, FEAT, L, Lp, FEAT, (Lp, FEAT))])
 
 
 def heads_pack_specs(P):
@@ -404,10 +441,7 @@ def act_backward(dh, u, act):
 # ------------------------------------------------------------------------------------------------
 # image encoder trunk: conv_net + fc_net (up to, not including, the dropout)
 # ------------------------------------------------------------------------------------------------
-ENC_KEYS = ["conv_net.0.weight", "conv_net.2.weight", "conv_net.3.weight", "conv_net.3.bias",
-            "conv_net.5.weight", "conv_net.6.weight", "conv_net.6.bias", "conv_net.8.weight",
-            "conv_net.9.weight", "conv_net.9.bias", "fc_net.0.weight", "fc_net.0.bias"]
-ENC_BN = ["conv_net.3", "conv_net.6", "conv_net.9"]
+ENC_KEYS = enc_keys(0)                      # the reference's 64 x 64 encoder
 
 
 def _bn_of(P, buf, pre):
@@ -449,33 +483,38 @@ def encoder_trunk_forward(*a, **k):
 
 
 def encoder_trunk_forward_steps(P, buf, x, G=1, repeat=1, packed=None, training=True):
-    """x: NCHW [Bt,3,64,64] -> h = Swish(fc(conv stack)) [Bt,512]; returns (h, ctx).  Generator: yields after
-    every layer (see :func:`interleave`).
+    """x: NCHW [Bt,3,S,S] (S = 64, or 128 / 256 for the extended stacks) -> h = Swish(fc(conv stack)) [Bt,512];
+    returns (h, ctx).  Generator: yields after every layer (see :func:`interleave`).
     ``repeat``: how many reference forward calls this one stands for (running-stat EMA updates).
     ``packed``: pre-packed weights (PackPlan); packed here, one kernel each, when absent."""
     Bt = x.shape[0]
     Bg = Bt // G
+    convs, S = enc_layout(P)
+    if tuple(x.shape[1:]) != (3, S, S):
+        raise ValueError(f"mmdyn_hip: this encoder takes [B,3,{S},{S}] images, got {tuple(x.shape)}")
     pk = packed if packed is not None else pack_now(encoder_pack_specs(P))
-    c = {"Bt": Bt, "G": G, "Bg": Bg, "pk": pk}
+    c = {"Bt": Bt, "G": G, "Bg": Bg, "pk": pk, "S": S}
+    H = S // 2
     W1p = pk["W1p"]                                                          # [32][64], cols 48.. zero
-    u1, a1 = _act(x, Bt * 1024, 32), _act(x, Bt * 1024, 32)
+    u1, a1 = _act(x, Bt * H * H, 32), _act(x, Bt * H * H, 32)
     # first layer: the k4 s2 p1 window of the NCHW image is gathered on the fly (no im2col matrix in HBM)
-    ops.B.igemm_nt(x, W1p, None, u1, a1, None, None, IM2COL3, 1, Bt, 64, 64, 64, 32, 32, 32, 32, 1, 0,
+    ops.B.igemm_nt(x, W1p, None, u1, a1, None, None, IM2COL3, 1, Bt, S, S, 64, H, H, 32, 32, 1, 0,
                    ACT_SWISH, 1)
     yield
-    bn2, bn3, bn4 = (_bn_of(P, buf, k) for k in ENC_BN)
-    y2, st, T = conv_like(a1, pk["W2k"], CONV, G, Bg, 32, 32, 16, 64, 2, -1, training)
-    a2, m2, r2 = bn_swish_from_partials(y2, st, T, bn2, G, Bg * 256, 64, repeat)
-    yield
-    y3, st, T = conv_like(a2, pk["W3k"], CONV, G, Bg, 16, 64, 8, 128, 2, -1, training)
-    a3, m3, r3 = bn_swish_from_partials(y3, st, T, bn3, G, Bg * 64, 128, repeat)
-    yield
-    y4, st, T = conv_like(a3, pk["W4k"], CONV, G, Bg, 8, 128, 5, 256, 1, 0, training)
-    a4, m4, r4 = bn_swish_from_partials(y4, st, T, bn4, G, Bg * 25, 256, repeat)
-    yield
-    u5, h = dense(a4, pk["Wf"], P["fc_net.0.bias"], Bt, FEAT, 512, ACT_SWISH, want_act=True)   # columns hw*256+c
-    c.update(x=x, u1=u1, a1=a1, y2=y2, a2=a2, m2=m2, r2=r2, y3=y3, a3=a3, m3=m3, r3=r3, y4=y4, a4=a4,
-             m4=m4, r4=r4, u5=u5, bn=(bn2, bn3, bn4))
+    stages, a, cin = [], a1, 32
+    for j, i in enumerate(convs):
+        cout = P[f"conv_net.{i}.weight"].shape[0]
+        last = j == len(convs) - 1                                           # Conv2d(128,256,4,1,0): 8 -> 5
+        Ho, stride, offset = (H - 3, 1, 0) if last else (H // 2, 2, -1)
+        bn = _bn_of(P, buf, f"conv_net.{i + 1}")
+        y, st, T = conv_like(a, pk[f"W{j + 2}k"], CONV, G, Bg, H, cin, Ho, cout, stride, offset, training)
+        an, m, r = bn_swish_from_partials(y, st, T, bn, G, Bg * Ho * Ho, cout, repeat)
+        stages.append(dict(i=i, Hi=H, Ho=Ho, cin=cin, cout=cout, stride=stride, offset=offset, a_in=a, y=y, a=an, m=m, r=r,
+                           bn=bn))
+        a, cin, H = an, cout, Ho
+        yield
+    u5, h = dense(a, pk["Wf"], P["fc_net.0.bias"], Bt, FEAT, 512, ACT_SWISH, want_act=True)   # columns hw*256+c
+    c.update(x=x, u1=u1, a1=a1, u5=u5, stages=stages)
     return h, c
 
 
@@ -485,39 +524,46 @@ def encoder_trunk_backward(*a, **k):
 
 def encoder_trunk_backward_steps(P, c, dh, grads):
     """dh: [Bt,512]; writes every weight gradient of the trunk into ``grads[key]`` (canonical layout)."""
-    Bt, G, Bg, pk = c["Bt"], c["G"], c["Bg"], c["pk"]
-    bn2, bn3, bn4 = c["bn"]
+    Bt, G, Bg, pk, S, st = c["Bt"], c["G"], c["Bg"], c["pk"], c["S"], c["stages"]
+    n = len(st)
     du5 = act_backward(dh, c["u5"], ACT_SWISH)
-    wgrad(du5, c["a4"], grads["fc_net.0.weight"], DENSE, Bt, 1, 512, 1, FEAT, perm=1)
+    wgrad(du5, st[-1]["a"], grads["fc_net.0.weight"], DENSE, Bt, 1, 512, 1, FEAT, perm=1)
     ops.B.colsum(du5, grads["fc_net.0.bias"], Bt, 512, 0, 0.0)
-    da4, _ = dense(du5, pk["WfT"], None, Bt, 512, FEAT, out_dtype=ACT_DTYPE)  # WfT: [hw*256+c][512]
+    da, _ = dense(du5, pk["WfT"], None, Bt, 512, FEAT, out_dtype=ACT_DTYPE)  # WfT: [hw*256+c][512]
     yield
-    dy4 = bn_swish_backward(da4, c["y4"], c["m4"], c["r4"], bn4, grads["conv_net.9.weight"],
-                            grads["conv_net.9.bias"], G, Bg * 25, 256)
-    wgrad(dy4, c["a3"], grads["conv_net.8.weight"], CONV, Bt, 5, 256, 8, 128, 1, 0)
-    da3 = tconv_s1p0(dy4, pk["W4s"], 1, Bt, 256, 128)[0]                     # W4s: [16][128 ci][256 co]
+
+    def bn_keys(t):
+        return grads[f"conv_net.{t['i'] + 1}.weight"], grads[f"conv_net.{t['i'] + 1}.bias"]
+
+    # the k4 s1 p0 stage (8 -> 5): its input gradient is the tap-skipping transposed convolution
+    t = st[n - 1]
+    dy = bn_swish_backward(da, t["y"], t["m"], t["r"], t["bn"], *bn_keys(t), G, Bg * t["Ho"] ** 2, t["cout"])
+    wgrad(dy, t["a_in"], grads[f"conv_net.{t['i']}.weight"], CONV, Bt, t["Ho"], t["cout"], t["Hi"], t["cin"], 1, 0)
+    da = tconv_s1p0(dy, pk[f"W{n + 1}s"], 1, Bt, t["cout"], t["cin"])[0]     # W{n+1}s: [16][Cin][Cout]
     yield
-    dy3 = bn_swish_backward(da3, c["y3"], c["m3"], c["r3"], bn3, grads["conv_net.6.weight"],
-                            grads["conv_net.6.bias"], G, Bg * 64, 128)
-    wgrad(dy3, c["a2"], grads["conv_net.5.weight"], CONV, Bt, 8, 128, 16, 64, 2, -1)
+    t = st[n - 2]
+    dy = bn_swish_backward(da, t["y"], t["m"], t["r"], t["bn"], *bn_keys(t), G, Bg * t["Ho"] ** 2, t["cout"])
+    wgrad(dy, t["a_in"], grads[f"conv_net.{t['i']}.weight"], CONV, Bt, t["Ho"], t["cout"], t["Hi"], t["cin"], 2, -1)
     yield
-    # conv3's input gradient with conv2's BatchNorm+Swish backward in its epilogue
-    dy2 = dgrad_bn_swish_backward(dy3, pk["W3s"], TCONV_S2P1, G, Bg, 8, 128, 16, 64, 1, 0, c["y2"], c["m2"], c["r2"], bn2,
-                                  grads["conv_net.3.weight"], grads["conv_net.3.bias"])
-    wgrad(dy2, c["a1"], grads["conv_net.2.weight"], CONV, Bt, 16, 64, 32, 32, 2, -1)
-    da1, _, _ = conv_like(dy2, pk["W2s"], TCONV_S2P1, 1, Bt, 16, 64, 32, 32)
+    for k in range(n - 3, -1, -1):
+        # input gradient of stage k+1 with stage k's BatchNorm+Swish backward in its epilogue
+        up, t = st[k + 1], st[k]
+        dy = dgrad_bn_swish_backward(dy, pk[f"W{k + 3}s"], TCONV_S2P1, G, Bg, up["Ho"], up["cout"], up["Hi"], up["cin"], 1, 0,
+                                     t["y"], t["m"], t["r"], t["bn"], *bn_keys(t))
+        wgrad(dy, t["a_in"], grads[f"conv_net.{t['i']}.weight"], CONV, Bt, t["Ho"], t["cout"], t["Hi"], t["cin"], 2, -1)
+        if k > 0:
+            yield
+    t = st[0]
+    da1, _, _ = conv_like(dy, pk["W2s"], TCONV_S2P1, 1, Bt, t["Ho"], t["cout"], t["Hi"], t["cin"])
     yield
     du1 = act_backward(da1, c["u1"], ACT_SWISH)
-    wgrad(du1, c["x"], grads["conv_net.0.weight"], IM2COL3, Bt, 32, 32, 64, 64, cg_canon=48)
+    wgrad(du1, c["x"], grads["conv_net.0.weight"], IM2COL3, Bt, S // 2, 32, S, 64, cg_canon=48)
 
 
 # ------------------------------------------------------------------------------------------------
 # image decoder: upsample FC + hallucinate stack -> logits (NCHW)
 # ------------------------------------------------------------------------------------------------
-DEC_KEYS = ["upsample.0.weight", "upsample.0.bias", "hallucinate.0.weight", "hallucinate.1.weight",
-            "hallucinate.1.bias", "hallucinate.3.weight", "hallucinate.4.weight", "hallucinate.4.bias",
-            "hallucinate.6.weight", "hallucinate.7.weight", "hallucinate.7.bias", "hallucinate.9.weight"]
-DEC_BN = ["hallucinate.1", "hallucinate.4", "hallucinate.7"]
+DEC_KEYS = dec_keys(0)                      # the reference's 64 x 64 decoder
 
 
 def decoder_forward(*a, **k):
@@ -525,34 +571,38 @@ def decoder_forward(*a, **k):
 
 
 def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, cond=None, training=True):
-    """z: [Bt, L] -> logits NCHW [Bt,3,64,64]; returns (logits, ctx).  ``logits=False`` stops after the last
+    """z: [Bt, L] -> logits NCHW [Bt,3,S,S]; returns (logits, ctx).  ``logits=False`` stops after the last
     BatchNorm (used only to reproduce the running statistics of the reference's unused decoder passes)."""
     Bt, L0 = z.shape
     Bg = Bt // G
+    convs, last, S = dec_layout(P)
     pk = packed if packed is not None else pack_now(decoder_pack_specs(P))
     Lc = P["upsample.0.weight"].shape[1]         # latent + condition_dim
     L = _pad32(Lc)
     if cond is not None or L != L0:
         z = concat_condition(z, cond, L)          # [z | c | 0]  (vae.py:286-291)
-    c = {"Bt": Bt, "G": G, "Bg": Bg, "L": L, "L0": L0, "Lc": Lc, "z": z, "pk": pk}
+    c = {"Bt": Bt, "G": G, "Bg": Bg, "L": L, "L0": L0, "Lc": Lc, "z": z, "pk": pk, "S": S, "last": last}
     u0, h0 = dense(z, pk["Wu"], pk["bu"], Bt, L, FEAT, ACT_SWISH, want_act=True)      # rows -> hw*256+c
     yield
-    bn1, bn2, bn3 = (_bn_of(P, buf, k) for k in DEC_BN)
-    y1, st, T = tconv_s1p0(h0, pk["W1s"], G, Bg, 256, 128, stats=training)        # W1s: [16][128 co][256 ci]
-    a1, m1, r1 = bn_swish_from_partials(y1, st, T, bn1, G, Bg * 64, 128, repeat)
-    yield
-    y2, st, T = conv_like(a1, pk["W2s"], TCONV_S2P1, G, Bg, 8, 128, 16, 64, stats=training)
-    a2, m2, r2 = bn_swish_from_partials(y2, st, T, bn2, G, Bg * 256, 64, repeat)
-    yield
-    y3, st, T = conv_like(a2, pk["W3s"], TCONV_S2P1, G, Bg, 16, 64, 32, 32, stats=training)
-    a3, m3, r3 = bn_swish_from_partials(y3, st, T, bn3, G, Bg * 1024, 32, repeat)
-    yield
+    stages, a, H = [], h0, 5
+    for j, i in enumerate(convs):
+        cin, cout = P[f"hallucinate.{i}.weight"].shape[0], P[f"hallucinate.{i}.weight"].shape[1]
+        bn = _bn_of(P, buf, f"hallucinate.{i + 1}")
+        if j == 0:                                                           # ConvTranspose2d(256,128,4,1,0): 5 -> 8
+            Ho = H + 3
+            y, st, T = tconv_s1p0(a, pk["W1s"], G, Bg, cin, cout, stats=training)       # W1s: [16][Cout][Cin]
+        else:
+            Ho = 2 * H
+            y, st, T = conv_like(a, pk[f"W{j + 1}s"], TCONV_S2P1, G, Bg, H, cin, Ho, cout, stats=training)
+        an, m, r = bn_swish_from_partials(y, st, T, bn, G, Bg * Ho * Ho, cout, repeat)
+        stages.append(dict(i=i, Hi=H, Ho=Ho, cin=cin, cout=cout, a_in=a, y=y, a=an, m=m, r=r, bn=bn))
+        a, H = an, Ho
+        yield
     out = None
     if logits:
-        out = _new(z, Bt, 3, 64, 64)
-        ops.B.tconv_out3_fwd(a3, P["hallucinate.9.weight"], out, Bt, 32, 32)   # direct kernel, canonical weights
-    c.update(u0=u0, h0=h0, y1=y1, a1=a1, m1=m1, r1=r1, y2=y2, a2=a2, m2=m2, r2=r2, y3=y3, a3=a3, m3=m3, r3=r3,
-             bn=(bn1, bn2, bn3))
+        out = _new(z, Bt, 3, S, S)
+        ops.B.tconv_out3_fwd(a, P[f"hallucinate.{last}.weight"], out, Bt, H, H)     # direct kernel, canonical weights
+    c.update(u0=u0, h0=h0, stages=stages)
     return out, c
 
 
@@ -561,25 +611,29 @@ def decoder_backward(*a, **k):
 
 
 def decoder_backward_steps(P, c, dlogits, grads, need_dz=True):
-    """dlogits: NCHW [Bt,3,64,64] -> dz [Bt, L]; weight gradients into ``grads``."""
-    Bt, G, Bg, L, pk = c["Bt"], c["G"], c["Bg"], c["L"], c["pk"]
-    bn1, bn2, bn3 = c["bn"]
+    """dlogits: NCHW [Bt,3,S,S] -> dz [Bt, L]; weight gradients into ``grads``."""
+    Bt, G, Bg, L, pk, S, st = c["Bt"], c["G"], c["Bg"], c["L"], c["pk"], c["S"], c["stages"]
+    n = len(st)
+
+    def bn_keys(t):
+        return grads[f"hallucinate.{t['i'] + 1}.weight"], grads[f"hallucinate.{t['i'] + 1}.bias"]
+
     # last layer backward: both GEMMs gather the k4 s2 p1 window of the NCHW logit gradient on the fly
-    wgrad(c["a3"], dlogits, grads["hallucinate.9.weight"], IM2COL3, Bt, 32, 32, 64, 64, cg_canon=48)
+    t = st[n - 1]
+    wgrad(t["a"], dlogits, grads[f"hallucinate.{c['last']}.weight"], IM2COL3, Bt, S // 2, 32, S, 64, cg_canon=48)
     # the input-gradient GEMM of every layer carries the BatchNorm+Swish backward of the layer below in its epilogue
-    dy3 = dgrad_bn_swish_backward(dlogits, pk["W4p"], IM2COL3, G, Bg, 64, 64, 32, 32, 1, 0, c["y3"], c["m3"], c["r3"], bn3,
-                                  grads["hallucinate.7.weight"], grads["hallucinate.7.bias"])
+    dy = dgrad_bn_swish_backward(dlogits, pk[f"W{n + 1}p"], IM2COL3, G, Bg, S, 64, S // 2, 32, 1, 0, t["y"], t["m"], t["r"],
+                                 t["bn"], *bn_keys(t))
     yield
-    wgrad(c["a2"], dy3, grads["hallucinate.6.weight"], CONV, Bt, 16, 64, 32, 32, 2, -1)
-    dy2 = dgrad_bn_swish_backward(dy3, pk["W3k"], CONV, G, Bg, 32, 32, 16, 64, 2, -1, c["y2"], c["m2"], c["r2"], bn2,
-                                  grads["hallucinate.4.weight"], grads["hallucinate.4.bias"])
-    yield
-    wgrad(c["a1"], dy2, grads["hallucinate.3.weight"], CONV, Bt, 8, 128, 16, 64, 2, -1)
-    dy1 = dgrad_bn_swish_backward(dy2, pk["W2k"], CONV, G, Bg, 16, 64, 8, 128, 2, -1, c["y1"], c["m1"], c["r1"], bn1,
-                                  grads["hallucinate.1.weight"], grads["hallucinate.1.bias"])
-    yield
-    wgrad(c["h0"], dy1, grads["hallucinate.0.weight"], CONV, Bt, 5, 256, 8, 128, 1, 0)
-    dh0, _, _ = conv_like(dy1, pk["W1k"], CONV, 1, Bt, 8, 128, 5, 256, 1, 0, out_dtype=torch.float32)   # FC level
+    for k in range(n - 1, 0, -1):
+        up, t = st[k], st[k - 1]
+        wgrad(up["a_in"], dy, grads[f"hallucinate.{up['i']}.weight"], CONV, Bt, up["Hi"], up["cin"], up["Ho"], up["cout"], 2, -1)
+        dy = dgrad_bn_swish_backward(dy, pk[f"W{k + 1}k"], CONV, G, Bg, up["Ho"], up["cout"], up["Hi"], up["cin"], 2, -1,
+                                     t["y"], t["m"], t["r"], t["bn"], *bn_keys(t))
+        yield
+    t = st[0]
+    wgrad(c["h0"], dy, grads[f"hallucinate.{t['i']}.weight"], CONV, Bt, 5, t["cin"], 8, t["cout"], 1, 0)
+    dh0, _, _ = conv_like(dy, pk["W1k"], CONV, 1, Bt, 8, t["cout"], 5, t["cin"], 1, 0, out_dtype=torch.float32)   # FC level
     yield
     du0 = act_backward(dh0, c["u0"], ACT_SWISH)
     wgrad(du0, c["z"], grads["upsample.0.weight"], DENSE, Bt, 1, FEAT, 1, L, cg_canon=c["Lc"], perm=2)

@@ -43,6 +43,9 @@ _BUILD_FLAGS = (
     ("synthetic-batches", 0, int, "train on this many random batches per epoch instead of --dataset-path"),
     ("synthetic-seq-length", 1, int, "frames per synthetic sequence"),
     ("reference-schedule", False, None, "run the reference's 7-forward autograd schedule instead of the fused step"),
+    ("image-size", 64, int, "side of the input images: 64 (the reference's only size) or the 128 / 256 pixel extended stacks "
+                            "(models/shapes.py; BASELINE configs[3] / configs[4], no reference architecture)"),
+    ("precision", "fp32", str, "matrix-core arithmetic of the fused step: fp32 | bf16 | bf16s | fp16"),
 )
 
 
@@ -63,9 +66,9 @@ def main(argv=None):
     shock = 3 if args.conditional else 0
     if args.synthetic_batches > 0:
         loaders = dict(train_loader=SyntheticVisuoTactile(args.synthetic_batches, args.batchsize, L, seed=1234,
-                                                          shock_dim=shock),
+                                                          shock_dim=shock, size=args.image_size),
                        test_loader=SyntheticVisuoTactile(max(1, args.synthetic_batches // 4), args.batchsize, L,
-                                                         seed=4321, shock_dim=shock),
+                                                         seed=4321, shock_dim=shock, size=args.image_size),
                        seq_length=L, fused=not args.reference_schedule)
     else:
         loaders = dict(fused=not args.reference_schedule)      # Problem.set_dataset reads --dataset-path

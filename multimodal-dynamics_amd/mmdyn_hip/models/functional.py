@@ -27,33 +27,35 @@ class ImageEncoderTrunkFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, holder, *params):
-        P = _dict(layers.ENC_KEYS, [p.detach() for p in params])
+        keys = holder.param_keys()
+        P = _dict(keys, [p.detach() for p in params])
         h, c = layers.encoder_trunk_forward(P, holder.bn_buffers(), x.detach().contiguous(), G=1)
-        ctx.P, ctx.c = P, c
+        ctx.P, ctx.c, ctx.keys = P, c, keys
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        grads = {k: torch.empty_like(ctx.P[k]) for k in layers.ENC_KEYS}
+        grads = {k: torch.empty_like(ctx.P[k]) for k in ctx.keys}
         layers.encoder_trunk_backward(ctx.P, ctx.c, dh.contiguous(), grads)
         ctx.c = None
-        return (None, None) + tuple(grads[k] for k in layers.ENC_KEYS)
+        return (None, None) + tuple(grads[k] for k in ctx.keys)
 
 
 class ImageDecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, holder, *params):
-        P = _dict(layers.DEC_KEYS, [p.detach() for p in params])
+        keys = holder.param_keys()
+        P = _dict(keys, [p.detach() for p in params])
         out, c = layers.decoder_forward(P, holder.bn_buffers(), z.detach().contiguous(), G=1, cond=holder._cond)
-        ctx.P, ctx.c = P, c
+        ctx.P, ctx.c, ctx.keys = P, c, keys
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        grads = {k: torch.empty_like(ctx.P[k]) for k in layers.DEC_KEYS}
+        grads = {k: torch.empty_like(ctx.P[k]) for k in ctx.keys}
         dz = layers.decoder_backward(ctx.P, ctx.c, dout.contiguous(), grads, need_dz=ctx.needs_input_grad[0])
         ctx.c = None
-        return (dz, None) + tuple(grads[k] for k in layers.DEC_KEYS)
+        return (dz, None) + tuple(grads[k] for k in ctx.keys)
 
 
 class HeadsFn(torch.autograd.Function):

@@ -63,6 +63,9 @@ class Regressor(nn.Module):
         return {f"conv_net.{i}.{n}": getattr(self.conv_net[i], n) for i in (3, 6, 9)
                 for n in ("running_mean", "running_var", "num_batches_tracked")}
 
+    def param_keys(self):
+        return layers.ENC_KEYS
+
     def forward(self, x, c=None):
         import torch
         sd = dict(self.named_parameters())

@@ -20,7 +20,7 @@ import torch.nn as nn
 from .. import config, ops
 from . import functional as Fn
 from .. import layers
-from .shapes import FEAT, HID, DROPOUT_P
+from .shapes import FEAT, HID, DROPOUT_P, IMG_SIZES, extra_stages, encoder_channels, decoder_channels
 
 
 # ------------------------------------------------------------------------------------------------
@@ -217,6 +217,17 @@ def _check_supported(architecture, conditional, categorical_conditions=False):
                                   "problems use real-valued shock conditions (problems.py:675-681)")
 
 
+def cnn_image_size(input_dim):
+    """Side of the square input image of a cnn Encoder / Decoder.  The reference passes ``input_dim = 64 * 64``
+    (problems.py:370) and never reads it in the cnn branch (its stack is fixed at 64 x 64); here it selects the stack:
+    4096 (or the constructor default 784) -> the reference's, 128*128 / 256*256 -> the extended stacks of
+    models/shapes.py."""
+    for s in IMG_SIZES:
+        if input_dim == s * s:
+            return s
+    return 64
+
+
 def _condition(c, conditional):
     """The reference's treatment of the condition tensor (vae.py:231-237): 1-D -> column, cast to float."""
     if not conditional:
@@ -244,11 +255,14 @@ class Encoder(nn.Module):
         _check_supported(architecture, conditional, categorical_conditions)
         cond_w = (condition_dim or 0) if conditional else 0
         if architecture == 'cnn':
-            self.conv_net = nn.Sequential(
-                Conv2dParams(3, 32, 4, 2, 1), Swish(),
-                Conv2dParams(32, 64, 4, 2, 1), BatchNorm2dParams(64), Swish(),
-                Conv2dParams(64, 128, 4, 2, 1), BatchNorm2dParams(128), Swish(),
-                Conv2dParams(128, 256, 4, 1, 0), BatchNorm2dParams(256), Swish())
+            self.image_size = cnn_image_size(input_dim)
+            self.extra = extra_stages(self.image_size)
+            chans = encoder_channels(self.extra)
+            mods = [Conv2dParams(3, 32, 4, 2, 1), Swish()]
+            for j, (cin, cout) in enumerate(chans):
+                last = j == len(chans) - 1
+                mods += [Conv2dParams(cin, cout, 4, 1 if last else 2, 0 if last else 1), BatchNorm2dParams(cout), Swish()]
+            self.conv_net = nn.Sequential(*mods)
             self.fc_net = nn.Sequential(LinearParams(FEAT, HID), Swish(), _Marker("Dropout(p=0.1)"))
             self.linear_means = LinearParams(HID + cond_w, latent_size)
             self.linear_log_var = LinearParams(HID + cond_w, latent_size)
@@ -263,8 +277,11 @@ class Encoder(nn.Module):
         self.noise = None
 
     def bn_buffers(self):
-        return {f"conv_net.{i}.{n}": getattr(self.conv_net[i], n) for i in (3, 6, 9)
+        return {f"conv_net.{i}.{n}": getattr(self.conv_net[i], n) for i in range(3, 3 * (4 + self.extra), 3)
                 for n in ("running_mean", "running_var", "num_batches_tracked")}
+
+    def param_keys(self):
+        return layers.enc_keys(self.extra)
 
     def trunk(self, x):
         """Everything before the dropout: [B,512] features.  ``model.eval()``: BatchNorm uses the running estimates
@@ -273,10 +290,10 @@ class Encoder(nn.Module):
             sd = dict(self.named_parameters())
             if not self.training:
                 with torch.no_grad():
-                    P = {k: sd[k].detach() for k in layers.ENC_KEYS}
+                    P = {k: sd[k].detach() for k in self.param_keys()}
                     return layers.run(layers.encoder_trunk_forward_steps(P, self.bn_buffers(), x.detach().contiguous(),
                                                                          training=False))[0]
-            return Fn.ImageEncoderTrunkFn.apply(x, self, *[sd[k] for k in layers.ENC_KEYS])
+            return Fn.ImageEncoderTrunkFn.apply(x, self, *[sd[k] for k in self.param_keys()])
         lin = [m for m in self.fc_net if isinstance(m, LinearParams)]
         return Fn.MLPFn.apply(x, *[p for m in lin for p in (m.weight, m.bias)])
 
@@ -317,30 +334,36 @@ class Decoder(nn.Module):
             if latent_size % 32:
                 raise NotImplementedError("mmdyn_hip: latent_size must be a multiple of 32 (MFMA K-step)")
             self.upsample = nn.Sequential(LinearParams(latent_size + cond_w, FEAT), Swish())
-            self.hallucinate = nn.Sequential(
-                Conv2dParams(256, 128, 4, 1, 0, True), BatchNorm2dParams(128), Swish(),
-                Conv2dParams(128, 64, 4, 2, 1, True), BatchNorm2dParams(64), Swish(),
-                Conv2dParams(64, 32, 4, 2, 1, True), BatchNorm2dParams(32), Swish(),
-                Conv2dParams(32, 3, 4, 2, 1, True))
+            # (the reference's Decoder receives the flat pixel count as ``input_dim`` through **kwargs and ignores it)
+            self.image_size = cnn_image_size(kwargs.get("input_dim", output_dim))
+            self.extra = extra_stages(self.image_size)
+            mods = []
+            for j, (cin, cout) in enumerate(decoder_channels(self.extra)):
+                mods += [Conv2dParams(cin, cout, 4, 1 if j == 0 else 2, 0 if j == 0 else 1, True), BatchNorm2dParams(cout),
+                         Swish()]
+            self.hallucinate = nn.Sequential(*mods, Conv2dParams(32, 3, 4, 2, 1, True))
         else:
             layer_sizes = [latent_size + cond_w] + layer_sizes + [output_dim]
             self.deconv_net = mlp(layer_sizes)
 
     def bn_buffers(self):
-        return {f"hallucinate.{i}.{n}": getattr(self.hallucinate[i], n) for i in (1, 4, 7)
+        return {f"hallucinate.{i}.{n}": getattr(self.hallucinate[i], n) for i in range(1, 3 * (3 + self.extra), 3)
                 for n in ("running_mean", "running_var", "num_batches_tracked")}
+
+    def param_keys(self):
+        return layers.dec_keys(self.extra)
 
     def forward(self, z, c=None):
         sd = dict(self.named_parameters())
         if self.architecture == 'cnn' and not self.training:   # eval: running-estimate BatchNorm, forward only
             with torch.no_grad():
-                P = {k: sd[k].detach() for k in layers.DEC_KEYS}
+                P = {k: sd[k].detach() for k in self.param_keys()}
                 return layers.run(layers.decoder_forward_steps(P, self.bn_buffers(), z.detach().contiguous(),
                                                                cond=_condition(c, self.conditional), training=False))[0]
         if self.architecture == 'cnn':
             self._cond = _condition(c, self.conditional)      # read by ImageDecoderFn.forward through `holder`
             try:
-                return Fn.ImageDecoderFn.apply(z, self, *[sd[k] for k in layers.DEC_KEYS])
+                return Fn.ImageDecoderFn.apply(z, self, *[sd[k] for k in self.param_keys()])
             finally:
                 self._cond = None
         cc = _condition(c, self.conditional)

@@ -139,7 +139,7 @@ class Problem:
     def set_dataset(self):
         """problems.py:110-125: the on-disk dataset at --dataset-path, decoded on the GPU (utils/datasets.py)."""
         from ..utils.datasets import dataset_setup
-        self._input_size = (64, 64)
+        self._input_size = (int(self.parameters.get('image_size', 64)),) * 2      # reference: (64, 64), problems.py:111
         self._n_channels = 3
         self.dataset_dict = dataset_setup(self.parameters['dataset_path'], self.parameters['problem_type'],
                                           input_size=self._input_size, batchsize=self.parameters['batchsize'],
@@ -177,12 +177,19 @@ class Problem:
             return
         # the fused step takes the dict-shaped inputs of seq / dyn modeling and has no loss-mask or condition input;
         # everything else (plain reconstruction, --mask-loss, --conditional, cnn-vae, regressor) runs the module path
-        use_engine = (self._fused and 'mvae' in self.parameters['model_name'] and not self._conditional
+        # (decided from the model that was actually built: 'cnn-mvae' with a single-modality --input-type is a plain VAE)
+        from ..models.vae import MVAE
+        use_engine = (self._fused and isinstance(self._model, MVAE) and self._cross_modal and not self._conditional
                       and isinstance(self, SeqModeling) and not self.parameters.get('mask_loss'))
+        precision = self.parameters.get('precision', 'fp32')
         if use_engine:
-            self._step = MVAEStep(self._model, lr=self.parameters['lr'], pose_multiplier=self._pose_multiplier)
-        else:
-            self._optimizer = FusedAdam(self._model.parameters(), lr=self.parameters['lr'])
+            self._step = MVAEStep(self._model, lr=self.parameters['lr'], pose_multiplier=self._pose_multiplier,
+                                  precision=precision)
+        elif precision != 'fp32':
+            raise ValueError("--precision %s is a mode of the fused cnn-mvae step; this configuration runs the module "
+                             "path, which computes in fp32" % precision)
+        # the module path's optimiser: also what a batch the fused step does not take falls back to
+        self._optimizer = FusedAdam(self._model.parameters(), lr=self.parameters['lr'])
 
     def _anneal_KL(self, epoch):
         if epoch < self.parameters['annealing_epochs']:
@@ -350,7 +357,7 @@ class Reconstruction(Problem):
 
     def set_model(self):
         self._set_condition_dim()
-        model_kwargs = {'condition_dim': self._condition_dim, 'input_dim': 64 * 64,
+        model_kwargs = {'condition_dim': self._condition_dim, 'input_dim': int(self.parameters.get('image_size', 64)) ** 2,
                         'architecture': self.parameters['model_name'].split('-')[0],
                         'conditional': self._conditional, 'categorical_conditions': self._categorical_conditions,
                         'latent_size': self.parameters.get('latent_size', 256)}

@@ -79,15 +79,22 @@ def batchnorm_train(x, prm, prefix, buffers=None):
     return y
 
 
+def _conv_indices(prm, pre):
+    """Sequential indices of the 4-D weights under ``pre`` (conv_net / hallucinate), ascending."""
+    return sorted(int(k[len(pre) + 1:].split(".")[0]) for k in prm
+                  if k.startswith(pre + ".") and k.endswith(".weight") and prm[k].dim() == 4)
+
+
 def image_encoder_trunk(x, prm, pre, buffers=None):
-    """conv_net + fc_net up to (not including) the dropout: vae.py:197-212, 224-229."""
+    """conv_net + fc_net up to (not including) the dropout: vae.py:197-212, 224-229.  Four convolutions for the
+    reference's 64 x 64 input; the 128 / 256 pixel EXTENSIONS (no reference architecture: its FC is fixed at 256*5*5)
+    have one / two more stride-2 Conv+BN+Swish stages behind the first convolution, found here by their keys."""
+    idx = _conv_indices(prm, pre + ".conv_net")
     h = swish(F.conv2d(x, prm[pre + ".conv_net.0.weight"], stride=2, padding=1))
-    h = F.conv2d(h, prm[pre + ".conv_net.2.weight"], stride=2, padding=1)
-    h = swish(batchnorm_train(h, prm, pre + ".conv_net.3", buffers))
-    h = F.conv2d(h, prm[pre + ".conv_net.5.weight"], stride=2, padding=1)
-    h = swish(batchnorm_train(h, prm, pre + ".conv_net.6", buffers))
-    h = F.conv2d(h, prm[pre + ".conv_net.8.weight"], stride=1, padding=0)
-    h = swish(batchnorm_train(h, prm, pre + ".conv_net.9", buffers))
+    for i in idx[1:]:
+        last = i == idx[-1]                                                  # Conv2d(128, 256, 4, 1, 0): 8 -> 5
+        h = F.conv2d(h, prm[pre + f".conv_net.{i}.weight"], stride=1 if last else 2, padding=0 if last else 1)
+        h = swish(batchnorm_train(h, prm, pre + f".conv_net.{i + 1}", buffers))
     h = h.reshape(h.shape[0], -1)
     return swish(F.linear(h, prm[pre + ".fc_net.0.weight"], prm[pre + ".fc_net.0.bias"]))
 
@@ -124,13 +131,12 @@ def image_decoder(z, prm, pre, buffers=None, c=None):
         z = torch.cat((z, c.to(z.dtype)), dim=-1)
     h = swish(F.linear(z, prm[pre + ".upsample.0.weight"], prm[pre + ".upsample.0.bias"]))
     h = h.reshape(-1, 256, 5, 5)
-    h = F.conv_transpose2d(h, prm[pre + ".hallucinate.0.weight"], stride=1, padding=0)
-    h = swish(batchnorm_train(h, prm, pre + ".hallucinate.1", buffers))
-    h = F.conv_transpose2d(h, prm[pre + ".hallucinate.3.weight"], stride=2, padding=1)
-    h = swish(batchnorm_train(h, prm, pre + ".hallucinate.4", buffers))
-    h = F.conv_transpose2d(h, prm[pre + ".hallucinate.6.weight"], stride=2, padding=1)
-    h = swish(batchnorm_train(h, prm, pre + ".hallucinate.7", buffers))
-    return F.conv_transpose2d(h, prm[pre + ".hallucinate.9.weight"], stride=2, padding=1)
+    idx = _conv_indices(prm, pre + ".hallucinate")                           # (more than four: the size extensions)
+    for i in idx[:-1]:
+        first = i == idx[0]                                                  # ConvTranspose2d(256, 128, 4, 1, 0): 5 -> 8
+        h = F.conv_transpose2d(h, prm[pre + f".hallucinate.{i}.weight"], stride=1 if first else 2, padding=0 if first else 1)
+        h = swish(batchnorm_train(h, prm, pre + f".hallucinate.{i + 1}", buffers))
+    return F.conv_transpose2d(h, prm[pre + f".hallucinate.{idx[-1]}.weight"], stride=2, padding=1)
 
 
 def pose_decoder(z, prm, pre="pose_decoder"):

@@ -117,6 +117,24 @@ def d16_tile(request, monkeypatch):
 D16_TILES = ["4,4", "8,2", "4,2", "2,2"]
 
 
+@pytest.fixture()
+def mfma16(monkeypatch):
+    """The LDS-tiled fp32 kernels on v_mfma_f32_16x16x4_f32 (taken by default only for large launches)."""
+    monkeypatch.setenv("MMDYN_IGEMM_M16", "1")
+    yield
+    monkeypatch.delenv("MMDYN_IGEMM_M16")
+
+
+@pytest.mark.parametrize("case", IGEMM_CASES)
+def test_igemm_nt_mfma16(case, mfma16):
+    test_igemm_nt(case)
+
+
+@pytest.mark.parametrize("case", [c for c in IGEMM_CASES if c[0] != DENSE][:6] + [IGEMM_CASES[0]])
+def test_igemm_dgrad_bn_epilogue_mfma16(case, mfma16):
+    test_igemm_dgrad_bn_epilogue(case)
+
+
 @pytest.mark.parametrize("d16_tile", D16_TILES, indirect=True)
 @pytest.mark.parametrize("case", IGEMM_CASES)
 def test_igemm_d16(case, d16_tile):

@@ -27,8 +27,8 @@ def emu():
     ops.set_backend(old)
 
 
-def build(name, cross, use_pose=None, device="cpu"):
-    kw = dict(MODEL_KW)
+def build(name, cross, use_pose=None, device="cpu", size=64):
+    kw = dict(MODEL_KW, input_dim=size * size)
     if use_pose is not None:
         kw["use_pose"] = use_pose
     m = setup_model(name, cross_modal=cross, **kw)
@@ -135,6 +135,73 @@ def check_fused_engine(golden_dir, device, fname, use_pose, exact=False):
         if ("encoder" in k or exact) and ("running" in k or "num_batches" in k):
             np.testing.assert_allclose(sd[k].double().cpu().numpy(), g[f"buffer_step{n_steps - 1}/" + k], rtol=2e-5,
                                        atol=2e-3 if n_steps > 1 else 2e-6, err_msg=k)
+
+
+def check_extended_size_vs_oracle(device, size, B, use_pose=True, n_steps=2, precision="fp32", loss_tol=1e-4, grad_tol=1e-3):
+    """The 128 / 256 pixel extensions (BASELINE configs[3] / configs[4]; no reference architecture exists for them, the
+    reference's FC is fixed at 256*5*5: models/shapes.py): fused engine against the CPU oracle's restatement of the same
+    stack -- total ELBO and each partial, every gradient tensor, and the loss after an Adam step."""
+    from oracle import mvae_oracle as O
+    klw = 1.0 / 50
+    sd = seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=use_pose, size=size), 0)
+    prm, buf = O.split_state(sd)
+    inputs, targets = seeded_batch(B, 1234, with_pose=use_pose, size=size)
+    n_pass, n_mask = (7, 8) if use_pose else (3, 4)
+    eps, masks = seeded_noise(B, 256, n_pass * n_steps, n_mask * n_steps, 4321)
+    m = build("cnn-mvae", True, use_pose, device, size=size)
+    assert set(m.state_dict()) == set(sd), set(m.state_dict()) ^ set(sd)
+    step = MVAEStep(m, noise=InjectedNoise(eps, masks), precision=precision)
+    names = list(prm.keys())
+    opt = O.Adam([prm[k] for k in names], lr=1e-3)
+    gi, gt = [x.to(device) for x in inputs], [x.to(device) for x in targets]
+    worst = 0.0
+    for s in range(n_steps):
+        opt.zero_grad()
+        _, loss_o, partials_o = O.evaluate_mvae(prm, inputs, targets, eps[n_pass * s:n_pass * (s + 1)],
+                                                masks[n_mask * s:n_mask * (s + 1)], klw, 1000.0, use_pose, buf)
+        loss_o.backward()
+        loss = step.forward(gi, gt, klw)
+        assert float(loss) == pytest.approx(float(loss_o.detach()), rel=loss_tol), (size, s)
+        np.testing.assert_allclose(step.partials[:n_pass].cpu().numpy(), [float(x.detach()) for x in partials_o],
+                                   rtol=loss_tol if s == 0 else 5 * loss_tol)
+        h = step.backward()
+        if s == 0:
+            assert tuple(step.last["recon_x"][0].shape) == (B, 3, size, size)
+            named = dict(m.named_parameters())
+            for k in names:
+                a, b = named[k].grad.double().cpu(), prm[k].grad.double()
+                err = float((a - b).norm() / (b.norm() + 1e-30))
+                worst = max(worst, err)
+                assert err < grad_tol, (k, err)
+        step.optimizer_step(h)
+        opt.step()
+    return worst
+
+
+@pytest.mark.parametrize("size,B,use_pose", [(128, 2, True), (128, 3, False), (256, 1, True)])
+def test_extended_image_sizes(size, B, use_pose):
+    check_extended_size_vs_oracle("cpu", size, B, use_pose, n_steps=1 if size == 256 else 2)
+
+
+def test_extended_size_module_api_and_checks():
+    """MVAE.forward / inference of a 128-pixel model, and the input-size check of a 64-pixel one."""
+    from oracle import mvae_oracle as O
+    m = build("cnn-mvae", True, True, "cpu", size=128)
+    inputs, _ = seeded_batch(2, 7, size=128)
+    eps, masks = seeded_noise(2, 256, 1, 2, 5)
+    m.noise = InjectedNoise(eps + [torch.zeros(3, 256)], masks)
+    with torch.no_grad():
+        vr, tr, pr, mu, lv = m([inputs[0], inputs[1]], pose=inputs[2])
+    prm, buf = O.split_state(seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True, size=128), 0))
+    ov, ot, op, omu, olv = O.mvae_forward(prm, inputs[0], inputs[1], inputs[2], eps[0], iter(masks), True, buf)
+    assert tuple(vr.shape) == (2, 3, 128, 128)
+    torch.testing.assert_close(mu, omu.detach(), rtol=1e-4, atol=3e-5)
+    torch.testing.assert_close(vr, ov.detach(), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(tr, ot.detach(), rtol=1e-3, atol=1e-4)
+    assert tuple(m.inference(n=3)[1].shape) == (3, 3, 128, 128)
+    m64 = build("cnn-mvae", True, True, "cpu")
+    with pytest.raises(ValueError):
+        m64([inputs[0], inputs[1]], pose=inputs[2])
 
 
 def test_mvae_forward_subsets(golden_dir):
@@ -334,7 +401,7 @@ def test_bf16_precision_plumbing():
         step = MVAEStep(m, noise=InjectedNoise(eps, masks), precision=prec)
         losses[prec] = float(step.forward(inputs, targets, klw))
         if prec == "bf16s":                      # conv-level activations are stored in bf16, FC level / logits in fp32
-            assert step.ctx["ev"]["a2"].dtype == torch.bfloat16 and step.ctx["dv"]["y3"].dtype == torch.bfloat16
+            assert step.ctx["ev"]["stages"][0]["a"].dtype == torch.bfloat16 and step.ctx["dv"]["stages"][2]["y"].dtype == torch.bfloat16
             assert step.ctx["lgv"].dtype == torch.float32 and step.ctx["ov"].dtype == torch.float32
         step.backward()
         assert ops.B.precision == "fp32" and layers.ACT_DTYPE == torch.float32

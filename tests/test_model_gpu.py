@@ -217,7 +217,7 @@ def test_bf16_storage_engine_vs_oracle(B):
     _, loss_o, partials_o = O.evaluate_mvae(prm, inputs, targets, eps[:7], masks[:8], klw, 1000.0, True, buf)
     loss_o.backward()
     loss = step.forward([x.to(DEV) for x in inputs], [x.to(DEV) for x in targets], klw)
-    assert step.ctx["dv"]["y3"].dtype == torch.bfloat16
+    assert step.ctx["dv"]["stages"][2]["y"].dtype == torch.bfloat16
     loss0 = float(loss)                     # (the engine's loss tensor is overwritten by later steps)
     rel_loss = abs(loss0 - float(loss_o.detach())) / abs(float(loss_o.detach()))
     np.testing.assert_allclose(step.partials[:7].cpu().numpy(), [float(x.detach()) for x in partials_o], rtol=1e-2)
