@@ -9,6 +9,11 @@ One "step" = one optimiser step of the cnn-mvae seq_modeling problem on one synt
 resident in HBM: the 7 modality-subset ELBO passes, backward and Adam (problems.py:148-156, 473-546), fp32,
 64x64 visual + tactile + 7-DoF pose, 256 samples per GPU (weak scaling: pure data parallel, gradients
 all-reduced over RCCL).  Prints ONE JSON line on rank 0.
+
+Other BASELINE configs (same JSON contract, the workload named in config.workload):
+    configs[2]  python bench.py --dtype bf16s --batch 128
+    configs[3]  python bench.py --image-size 128 --problem dyn_modeling --batch 128
+    configs[4]  python bench.py --image-size 256 --dtype fp16 --batch 256
 """
 import argparse
 import json
@@ -24,22 +29,73 @@ import torch  # noqa: E402
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16), no sparsity
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = fp32 vector peak
-ALGO_GFLOP_PER_SAMPLE = 2.024      # distinct contractions of one train step
+PEAK_F16_MFMA_TFLOPS = 2500.0      # same rate as bf16 (MI355X_MICROARCH.md, matrix cores table)
 KL_WEIGHT = 1.0 / 50               # epoch 0 of the reference's annealing schedule (problems.py:212-216)
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled
-    per the gfx950 correction + WRITE_SIZE; profiles/r1/igemm_traffic_pmc.json).  PMC counters cannot be read from
-    inside this process, so the value is the last profiled one, or None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r1", "igemm_traffic_pmc.json")
+def algo_gflop_per_sample(size=64, use_pose=True):
+    """Algorithmic FLOPs of one train step per sample, counted as SURVEY.md section 8(d) does: every mathematically
+    distinct contraction once (encoder trunks once per modality, image heads per pass, the 4 live passes of each image
+    decoder, the pose encoder once, 4 live pose-decoder passes), forward + input gradient + weight gradient, no input
+    gradient for a network's first layer.  size = 64 gives the survey's 1 012 188 160 MAC = 2.024 GFLOP; 128 / 256 apply
+    the same count to the extended stacks of models/shapes.py."""
+    from mmdyn_hip.models.shapes import extra_stages, encoder_channels, decoder_channels, FEAT, HID
+    e = extra_stages(size)
+    L = 256
+    enc, H = [], size // 2
+    first = H * H * 32 * 3 * 16
+    for j, (cin, cout) in enumerate(encoder_channels(e)):
+        last = j == 2 + e
+        Ho = H - 3 if last else H // 2
+        enc.append(Ho * Ho * cout * cin * 16)
+        H = Ho
+    fc = FEAT * HID
+    trunk = first + sum(enc) + fc
+    heads = HID * 2 * L
+    enc_mod = trunk * 2 + (trunk - first) + 4 * 3 * heads            # fwd + wgrad + dgrad (not for conv1); heads x 4 passes
+    dec, H = [], 5
+    for j, (cin, cout) in enumerate(decoder_channels(e)):
+        Ho = H + 3 if j == 0 else 2 * H
+        dec.append(H * H * cin * cout * 16)          # transposed: every INPUT pixel meets all 16 taps
+        H = Ho
+    dec_pass = L * FEAT + sum(dec) + (2 * H) * (2 * H) * 3 * 32 * 4   # last layer: each output pixel sees 4 of the 16 taps
+    macs = 2 * enc_mod + 2 * 4 * 3 * dec_pass
+    if use_pose:
+        macs += (7 * HID + HID * HID) * 2 + HID * HID + 3 * heads + 4 * 3 * (L * HID + HID * HID + HID * 7)
+    return 2.0 * macs / 1e9
+
+
+ALGO_GFLOP_PER_SAMPLE = 2.024      # SURVEY.md section 8(d), 64 x 64 (== algo_gflop_per_sample(64), asserted in main)
+
+
+def _sha256(path):
+    import hashlib
     try:
-        d = json.load(open(path))
-        if kernel.startswith(d["kernel"].split(" ")[0]):
-            return d["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
+    the gfx950 correction + WRITE_SIZE).  PMC counters cannot be read from inside this process, so the value is the
+    last profiled one -- WITH its provenance: the profile records the sha-256 of the kernel source it was taken on, and
+    the value is reported as None (plus the reason) when the source has changed since.  Returns (bytes | None, note)."""
+    for rel in (("profiles", "r2", "igemm_traffic_pmc.json"), ("profiles", "r1", "igemm_traffic_pmc.json")):
+        path = os.path.join(ROOT, *rel)
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if not kernel.startswith(d.get("kernel", "?").split(" ")[0]):
+            continue
+        src = os.path.join(ROOT, "multimodal-dynamics_amd", "csrc", d.get("source", "igemm_nt.hip"))
+        note = {"profile": "/".join(rel), "collected": d.get("collected"), "source_sha256": d.get("source_sha256")}
+        if d.get("source_sha256") and d["source_sha256"] == _sha256(src):
+            return d["hbm_bytes_per_launch"], note
+        note["stale"] = "kernel source changed since the profile was collected (or the profile predates provenance)"
+        return None, note
+    return None, {"stale": "no PMC profile committed"}
 
 
 def host_cpu_share():
@@ -64,18 +120,31 @@ def host_cpu_share():
     return max(1, n)
 
 
-def cpu_baseline(batch, threads):
+def host_cpu_all():
+    """os.cpu_count() as SURVEY.md section 8(d) specifies for the CPU baseline, bounded by the affinity mask and by a
+    cgroup quota when one is visible (more runnable threads than the quota allows only thrash)."""
+    n = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(batch, threads, size=64, budget_s=30.0):
     """The CPU oracle (a port of the reference path executing the reference's own schedule: 8 encoder + 14
     decoder forwards, autograd backward, Adam) timed on this box's host cores.  Bounded: a probe step at bs=32
-    decides whether the full bs=256 step fits the ~30 s budget; otherwise a bs=64 sample is timed."""
+    decides whether the full bs=256 step fits the budget; otherwise a bs=64 sample is timed."""
     from oracle import mvae_oracle as O
     from mmdyn_hip.models.shapes import state_dict_shapes
     from mmdyn_hip.utils.seeded_init import seeded_state_dict, seeded_batch, seeded_noise
     torch.set_num_threads(threads)
 
     def run(bs, steps):
-        prm, buf = O.split_state(seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True), 0))
-        inputs, targets = seeded_batch(bs, 1234)
+        prm, buf = O.split_state(seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True, size=size), 0))
+        inputs, targets = seeded_batch(bs, 1234, size=size)
         eps, masks = seeded_noise(bs, 256, 7, 8, 4321)
         opt = O.Adam([prm[k] for k in prm], lr=1e-3)
         times, loss = [], None
@@ -89,10 +158,11 @@ def cpu_baseline(batch, threads):
             print(f"[cpu_baseline] bs={bs} step {s}: {times[-1]:.2f} s ({threads} threads)", file=sys.stderr, flush=True)
         return times, float(loss.detach())
 
-    probe, _ = run(32, 2)
-    est_full = probe[-1] * (batch / 32.0)
-    bs = batch if est_full * 3 <= 45.0 else 64
-    n_timed = 6 if est_full * 7 <= 30.0 else 2             # ~10-30 s of CPU work in total
+    pb = 32 if size == 64 else 8
+    probe, _ = run(pb, 2)
+    est_full = probe[-1] * (batch / float(pb))
+    bs = batch if est_full * 3 <= 1.5 * budget_s else max(pb, min(batch, 64 if size == 64 else 16))
+    n_timed = 6 if est_full * 7 <= budget_s else 2             # ~10-30 s of CPU work in total
     times, loss = run(bs, 1 + n_timed)
     best, med = min(times[1:]), sorted(times[1:])[len(times[1:]) // 2]
     cpu = "unknown CPU"
@@ -104,7 +174,7 @@ def cpu_baseline(batch, threads):
     except OSError:
         pass
     return {"value": bs / best, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{n_timed} timed steps (+1 warm-up) of the cnn-mvae+pose train step at bs={bs}; "
+            "sample": f"{n_timed} timed steps (+1 warm-up) of the cnn-mvae+pose {size}x{size} train step at bs={bs}; "
                       f"min {best:.2f} s/step (value), median {med:.2f} s/step; {cpu}, os.cpu_count()={os.cpu_count()}",
             "loss": loss}
 
@@ -137,10 +207,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a HIP graph")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
-    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16s"), default="f32",
+    ap.add_argument("--image-size", type=int, choices=(64, 128, 256), default=64,
+                    help="64: the reference's only input size (BASELINE configs[1], default).  128 / 256: the extended stacks of "
+                         "models/shapes.py (configs[3] / configs[4]; no reference architecture exists for them)")
+    ap.add_argument("--problem", choices=("seq_modeling", "dyn_modeling"), default="seq_modeling",
+                    help="dyn_modeling (configs[3]): the batch is --seq-length frames per sequence, targets are the next frames "
+                         "(DynModeling.parse_input, problems.py:765-803); the step itself is the same computation")
+    ap.add_argument("--seq-length", type=int, default=4)
+    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16s", "fp16"), default="f32",
                     help="f32: the BASELINE configs[1] line (default).  bf16s: bf16 activation storage + bf16 matrix "
                          "cores, fp32 accumulate / master weights = the per-GPU share of configs[2] (use --batch 128).  "
-                         "bf16: bf16 matrix-core operands only (fp32 storage)")
+                         "bf16: bf16 matrix-core operands only (fp32 storage).  fp16: fp16 matrix-core operands, fp32 "
+                         "accumulate / storage / master weights (configs[4])")
     ap.add_argument("--sync-bn", action="store_true",
                     help="BatchNorm statistics over the global batch (N > 1; eager launches, one small all-reduce per "
                          "BatchNorm layer and direction).  Default: local statistics")
@@ -173,14 +251,18 @@ def main():
     from mmdyn_hip.utils.seeded_init import seeded_batch
 
     torch.manual_seed(0)
-    model = setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=4096, architecture="cnn",
+    S = args.image_size
+    PREC = {"f32": "fp32", "bf16": "bf16", "bf16s": "bf16s", "fp16": "fp16"}[args.dtype]
+    assert abs(algo_gflop_per_sample(64) - ALGO_GFLOP_PER_SAMPLE) < 1e-3
+    gflop_per_sample = algo_gflop_per_sample(S)
+    model = setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=S * S, architecture="cnn",
                         conditional=False, categorical_conditions=False, latent_size=256, use_pose=True).to(dev).train()
     if args.infer:
-        inputs, _ = seeded_batch(args.batch, 1234 + rank)
+        inputs, _ = seeded_batch(args.batch, 1234 + rank, size=S)
         v, t, p = [z.to(dev) for z in inputs]
         from mmdyn_hip.engine import MVAEInference
         model.eval()
-        eng = MVAEInference(model, precision={"f32": "fp32", "bf16": "bf16", "bf16s": "bf16s"}[args.dtype],
+        eng = MVAEInference(model, precision=PREC,
                             use_graph=not args.no_graph,
                             seed=1234 + rank)
         for _ in range(args.warmup):
@@ -202,10 +284,21 @@ def main():
         return
     step = MVAEStep(model, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), process_group=pg,
                     world_size=world, two_lanes=not args.single_lane,
-                    precision={"f32": "fp32", "bf16": "bf16", "bf16s": "bf16s"}[args.dtype],
+                    precision=PREC,
                     sync_bn=args.sync_bn and pg is not None)
-    inputs, targets = seeded_batch(args.batch, 1234 + rank)
+    inputs, targets = seeded_batch(args.batch, 1234 + rank, size=S)
     inputs, targets = [x.to(dev) for x in inputs], [x.to(dev) for x in targets]
+    if args.problem == "dyn_modeling":
+        # the frames of --seq-length-long sequences are the samples; the target of a frame is the next frame of its
+        # sequence, the last frame's target is the sequence's final target (DynModeling.parse_input, problems.py:765-803:
+        # roll by -1 and patch the sequence ends; the pose target is rolled without the patch, as the reference does)
+        Lq = args.seq_length
+        if args.batch % Lq:
+            raise SystemExit("--batch must be a multiple of --seq-length for dyn_modeling")
+        final = targets
+        targets = [torch.roll(x, -1, dims=0) for x in inputs]
+        for k in (0, 1):
+            targets[k][Lq - 1::Lq] = final[k][::Lq]
 
     def eager_step():
         return step.train_step(inputs, targets, KL_WEIGHT)
@@ -256,32 +349,37 @@ def main():
     dom_name = "igemm_nt_kernel" if dom is ig else "wgrad_tn_kernel"
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     total_ms = sum(d["ms"] for d in kern.values())
-    peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else (PEAK_F16_MFMA_TFLOPS if args.dtype == "fp16" else PEAK_BF16_MFMA_TFLOPS)
+    traffic, traffic_note = pmc_traffic(dom_name) if args.dtype == "f32" else (None, {"stale": "profiled for fp32 only"})
+    arith = {"f32": "fp32", "bf16": "bf16 matrix-core operands (fp32 accumulate, storage and master weights)",
+             "bf16s": "bf16 activation storage + bf16 matrix-core operands (fp32 accumulate and master weights)",
+             "fp16": "fp16 matrix-core operands (fp32 accumulate, storage and master weights)"}[args.dtype]
+    which = ("BASELINE configs[1]" if (S == 64 and args.dtype == "f32" and args.problem == "seq_modeling") else
+             "per-GPU share of BASELINE configs[2]" if (S == 64 and args.dtype in ("bf16", "bf16s")) else
+             "per-GPU share of BASELINE configs[3] (extension: no reference architecture at this size)" if S == 128 else
+             "per-GPU share of BASELINE configs[4] (extension: no reference architecture at this size)" if S == 256 else
+             "variant")
+    workload = (f"cnn-mvae visuotactile+pose {S}x{S}, bs={args.batch} per GPU, {arith}, {args.problem} train step "
+                f"(7 subset ELBOs + backward + Adam), {which}")
     out = {
         "metric": "visuotactile samples/sec (train) + ELBO vs CPU ref, cnn-mvae 64x64 bs256 @1/2/4/8 GPU",
         "value": sps, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": (f"cnn-mvae visuotactile+pose 64x64, bs={args.batch} per GPU, fp32, seq_modeling "
-                                "train step (7 subset ELBOs + backward + Adam), BASELINE configs[1]")
-                   if args.dtype == "f32" else
-                   (f"cnn-mvae visuotactile+pose 64x64, bs={args.batch} per GPU, "
-                    + ("bf16 activation storage + " if args.dtype == "bf16s" else "")
-                    + "bf16 matrix-core operands (fp32 accumulate"
-                    + (", storage" if args.dtype == "bf16" else "")
-                    + " and master weights), seq_modeling train step, per-GPU share of BASELINE configs[2]"),
+        "config": {"workload": workload,
                    "global_batch": global_batch, "parallelism": f"dp{world}", "bn": "sync" if (args.sync_bn and pg is not None) else "local",
                    "launch": "eager" if (args.no_graph or (args.sync_bn and pg is not None)) else "hip_graph",
                    "final_loss": final_loss, "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps},
         "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": pmc_traffic(dom_name) if args.dtype == "f32" else None,
+                     "traffic": traffic, "traffic_provenance": traffic_note,
                      "algorithmic_flops_per_launch": dom["flops"] / max(dom["calls"], 1),
                      "operand_bytes_per_launch": dom["bytes"] / max(dom["calls"], 1),
                      "launches_per_step": dom["calls"], "avg_launch_ms": dom["ms"] / max(dom["calls"], 1),
                      "kernel_share_of_step": dom["ms"] / total_ms if total_ms else None,
-                     "step_algorithmic_tflops": sps / world * ALGO_GFLOP_PER_SAMPLE * 1e9 / 1e12,
-                     "step_frac_of_peak": sps / world * ALGO_GFLOP_PER_SAMPLE * 1e9 / 1e12 / peak},
+                     "algorithmic_gflop_per_sample": gflop_per_sample,
+                     "step_algorithmic_tflops": sps / world * gflop_per_sample * 1e9 / 1e12,
+                     "step_frac_of_peak": sps / world * gflop_per_sample * 1e9 / 1e12 / peak},
     }
     if args.breakdown:
         for k, d in sorted(kern.items(), key=lambda kv: -kv[1]["ms"]):
@@ -295,7 +393,17 @@ def main():
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
             print(f"  {k[0]:9s} {str(k[1:]):70s} x{d['calls']:2d} {d['ms']:7.3f} ms {tf:6.1f} TF/s", file=sys.stderr)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.batch, host_cpu_share())
+        # torch.set_num_threads(os.cpu_count()).  On a box whose CPU share is smaller than the
+        # machine (the one-GPU box: 16 of 256 hardware threads, no visible quota) the figure at the documented share is
+        # reported next to it; `value` / `cores` are the faster of the two, i.e. the strongest CPU baseline measured.
+        share, allc = host_cpu_share(), host_cpu_all()
+        base = cpu_baseline(args.batch, share, S, 20.0)
+        if allc != share:
+            full = cpu_baseline(args.batch, allc, S, 12.0)
+            best, other = (full, base) if full["value"] > base["value"] else (base, full)
+            base = dict(best)
+            base["other_thread_count"] = {k: other[k] for k in ("value", "cores", "sample")}
+        out["cpu_baseline"] = base
     _emit(out)
     if pg is not None:
         dist.destroy_process_group()

@@ -72,8 +72,8 @@ int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C,
  *     C = du = dL/da * swish'(gamma*xhat + beta)
  * and the per-tile column sums (du, du*xhat) into stats[G][T][2][N] (T = mmdyn_igemm_stat_tiles), which feed
  * mmdyn_bn_bwd_finalize directly -- the separate reduction pass (mmdyn_bn_swish_bwd_reduce: one more read of da
- * and y) disappears; mmdyn_bn_swish_bwd_apply(da_is_du = 1) finishes the layer.  bf16 != 0 selects the bf16
- * matrix-core variant.  No bias / activation / split-K here. */
+ * and y) disappears; mmdyn_bn_swish_bwd_apply(da_is_du = 1) finishes the layer.  bf16: 0 = fp32 matrix cores,
+ * 1 = bf16, 2 = fp16 operands (T = mmdyn_igemm_stat_tiles_bf16 for both).  No bias / activation / split-K here. */
 int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C, float* stats, const float* y,
                             const float* mean, const float* rstd, const float* gamma, const float* beta,
                             int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
@@ -86,6 +86,13 @@ int mmdyn_igemm_nt_bf16(const float* A, const float* Bp, const float* bias, floa
                         float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
                         int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
                         void* stream);
+/* Same contract, fp16 matrix cores: operands rounded to IEEE half (RNE) on their way into v_mfma_f32_32x32x16_f16, fp32
+ * accumulate, everything in HBM fp32 -- "MFMA fp16 conv with fp32 accumulate" of BASELINE configs[4].  Partial-sum tile
+ * count: mmdyn_igemm_stat_tiles_bf16. */
+int mmdyn_igemm_nt_f16(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
+                       float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
+                       int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
+                       void* stream);
 /* T of the `stats` argument for the shape: what mmdyn_igemm_nt / mmdyn_igemm_nt_dgrad_bn(bf16 = 0) write ... */
 int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
 /* ... and what the bf16 matrix-core variants (mmdyn_igemm_nt_bf16, mmdyn_igemm_nt_mx, dgrad_bn(bf16 = 1)) write */
@@ -109,6 +116,9 @@ int mmdyn_wgrad_tn(const float* D, const float* Gt, float* partial, int mode, in
 /* bf16 matrix cores (v_mfma_f32_32x32x8_bf16), fp32 accumulate; see mmdyn_igemm_nt_bf16 */
 int mmdyn_wgrad_tn_bf16(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr, int Wr,
                         int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks, void* stream);
+/* fp16 matrix cores (v_mfma_f32_32x32x8_f16), fp32 accumulate; see mmdyn_igemm_nt_f16 */
+int mmdyn_wgrad_tn_f16(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr, int Wr,
+                       int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks, void* stream);
 /* recommended `chunks` (a multiple of 4) for mmdyn_wgrad_tn; partial must hold chunks*taps*Cd*Cg floats */
 int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg);
 int mmdyn_wgrad_reduce(const float* partial, float* canon, int chunks, int taps, int Cd, int Cg,

@@ -46,7 +46,18 @@ __device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {
 // v_mfma_f32_32x32x2_f32 -- same rate per clock, but a 32x32-output wave then owns FOUR independent accumulators instead of
 // one dependent chain.  Measured (tests/microbench/lds_mfma_shape.hip, MI355X): +7..17 % on the 64x64 block tile, no
 // difference on 128x128 (which keeps the 32x32 shape).  LDS row stride 40 floats keeps its ds_read_b128 conflict-free.
-template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16, bool B16, bool WIDE = false, bool M16 = false>
+// F16 (with BF16, fp32 storage on both sides): the 16-bit operands are IEEE half (RNE) and the product runs on
+// v_mfma_f32_32x32x16_f16 -- BASELINE configs[4] "MFMA fp16 conv with fp32 accumulate"; everything else as in the bf16 mode.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  h2 r;
+  r[0] = (_Float16)lo;
+  r[1] = (_Float16)hi;
+  return __builtin_bit_cast(uint32_t, r);
+}
+template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16, bool B16, bool WIDE = false, bool M16 = false,
+          bool F16 = false>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__ A,
                                                        const float* __restrict__ Bp,
                                                        const float* __restrict__ bias,
@@ -54,6 +65,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
                                                        float* __restrict__ stats, float* __restrict__ ws,
                                                        const IgemmGeom g) {
   static_assert(!M16 || !BF16, "the 16x16x4 shape is the fp32 variant");
+  static_assert(!F16 || (BF16 && !A16 && !B16 && !WIDE), "fp16 operands: 16-bit matrix cores on fp32 storage");
   constexpr int TS = M16 ? 16 : 32;                   // side of one MFMA output tile
   constexpr int NE = M16 ? 4 : 16;                    // accumulator registers per tile
   constexpr int LDS_LD = M16 ? BK + 8 : BK + 4;       // fp32 tile row stride (floats): conflict-free fragment reads
@@ -264,8 +276,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
           v.x = (m & 1u) ? ra16[i].x : 0u;           // (all four mask bits are equal outside IM2COL3)
           v.y = (m & 1u) ? ra16[i].y : 0u;
         } else {
-          v.x = pack2_bf16((m & 1u) ? ra[i][0] : 0.f, (m & 2u) ? ra[i][1] : 0.f);
-          v.y = pack2_bf16((m & 4u) ? ra[i][2] : 0.f, (m & 8u) ? ra[i][3] : 0.f);
+          if constexpr (F16) {
+            v.x = pack2_f16((m & 1u) ? ra[i][0] : 0.f, (m & 2u) ? ra[i][1] : 0.f);
+            v.y = pack2_f16((m & 4u) ? ra[i][2] : 0.f, (m & 8u) ? ra[i][3] : 0.f);
+          } else {
+            v.x = pack2_bf16((m & 1u) ? ra[i][0] : 0.f, (m & 2u) ? ra[i][1] : 0.f);
+            v.y = pack2_bf16((m & 4u) ? ra[i][2] : 0.f, (m & 8u) ? ra[i][3] : 0.f);
+          }
         }
         *reinterpret_cast<uint2*>(&As16[(lrow + ROWS_PER_PASS * i) * LDH + gran * 4]) = v;
       }
@@ -275,8 +292,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
         if constexpr (B16) {
           v = rbv16[j];
         } else {
-          v.x = pack2_bf16(rbv[j][0], rbv[j][1]);
-          v.y = pack2_bf16(rbv[j][2], rbv[j][3]);
+          if constexpr (F16) {
+            v.x = pack2_f16(rbv[j][0], rbv[j][1]);
+            v.y = pack2_f16(rbv[j][2], rbv[j][3]);
+          } else {
+            v.x = pack2_bf16(rbv[j][0], rbv[j][1]);
+            v.y = pack2_bf16(rbv[j][2], rbv[j][3]);
+          }
         }
         *reinterpret_cast<uint2*>(&Bs16[(lrow + ROWS_PER_PASS * j) * LDH + gran * 4]) = v;
       }
@@ -333,7 +355,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mt], pb[nt], acc[mt][nt], 0, 0, 0);
+              if constexpr (F16)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pa[mt]),
+                                                                     __builtin_bit_cast(f16x8, pb[nt]), acc[mt][nt], 0, 0, 0);
+              else
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mt], pb[nt], acc[mt][nt], 0, 0, 0);
         }
       } else if constexpr (M16) {
 #pragma unroll
@@ -566,6 +592,9 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
     hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, false, false, false, false, M16_TILE>), grid, dim3(256), smem, st, A,
                        Bp, bias, C, C_act, stats, ws, g);
   else if (!bf16) IGEMM_LAUNCH(false, false, false);
+  else if (g.f16)
+    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, false, false, false, false, true>), grid, dim3(256), smem, st,
+                       A, Bp, bias, C, C_act, stats, ws, g);
   else if (g.a_b16 && g.b_b16 && CAN_A16 && g.Cin % 64 == 0)
     hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, CAN_A16, true, CAN_A16>), grid, dim3(256), smem, st, A, Bp,
                        bias, C, C_act, stats, ws, g);
@@ -653,6 +682,8 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   g.c_b16 = (storage_flags & 4) != 0;
   g.bny_b16 = (storage_flags & 8) != 0;
   g.b_b16 = (storage_flags & 16) != 0;
+  g.f16 = (storage_flags & 32) != 0;
+  if (g.f16 && (storage_flags & ~32)) return MMDYN_ERR_SHAPE;          // fp16 operands: fp32 storage on both sides
   if (storage_flags && (!bf16 || (g.c_b16 && splitk > 1) || (g.a_b16 && mode == MMDYN_IM2COL3))) return MMDYN_ERR_SHAPE;
   g.want_act_out = C_act != nullptr;
   g.splitk = splitk;
@@ -738,8 +769,19 @@ extern "C" int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C
                                        int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
                                        int stride, int offset, int bf16, void* stream) {
   if (!stats || !y || !mean || !rstd || !gamma || !beta) return MMDYN_ERR_NULL;
+  if (bf16 < 0 || bf16 > 2) return MMDYN_ERR_SHAPE;
   return igemm_entry(A, Bp, nullptr, C, nullptr, stats, nullptr, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset,
-                     MMDYN_ACT_NONE, 1, stream, bf16 != 0, y, mean, rstd, gamma, beta);
+                     MMDYN_ACT_NONE, 1, stream, bf16 != 0, y, mean, rstd, gamma, beta, bf16 == 2 ? 32 : 0);
+}
+
+/* fp16 matrix cores (v_mfma_f32_32x32x16_f16): operands rounded to IEEE half (RNE) on their way into the MFMA, fp32
+ * accumulate, everything in HBM fp32 -- the arithmetic BASELINE configs[4] names */
+extern "C" int mmdyn_igemm_nt_f16(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
+                                  float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
+                                  int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
+                                  void* stream) {
+  return igemm_entry(A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act,
+                     splitk, stream, true, nullptr, nullptr, nullptr, nullptr, nullptr, 32);
 }
 
 /* One entry point for the mixed-storage variants: flags bit 0 = bf16 matrix cores (required for the others),

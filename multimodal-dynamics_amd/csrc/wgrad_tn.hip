@@ -21,6 +21,7 @@ namespace {
 
 struct WgradGeom {
   int d_b16, g_b16;  // bf16 activation storage (bf16 matrix-core variants only): D / Gt are bf16 in HBM
+  int f16;           // 16-bit matrix-core mode with fp16 instead of bf16 operands (fp32 storage only)
   int mode;  // MMDYN_DENSE or MMDYN_CONV
   int rows;  // Bt*Hr*Wr
   int Hr, Wr, Cd;
@@ -37,6 +38,12 @@ constexpr int RK = 32;  // rows per K-step
 // v_mfma_f32_32x32x8_bf16 (fp32 accumulate); the staging and the partial-slab scheme are unchanged.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x4 pack4_f16(float a, float b, float c, float d) {
+  f16x4 r;
+  r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d;
+  return r;
+}
 __device__ __forceinline__ s16x4 pack4_bf16(float a, float b, float c, float d) {
   bf16x4 r;
   r[0] = (__bf16)a; r[1] = (__bf16)b; r[2] = (__bf16)c; r[3] = (__bf16)d;
@@ -45,7 +52,7 @@ __device__ __forceinline__ s16x4 pack4_bf16(float a, float b, float c, float d) 
 
 // ST: operand storage, always a compile-time constant (a run-time test inside the fetch puts every load in its own
 // branch and the loads then wait for one another): 0 = D and Gt fp32, 1 = both bf16, 2 = D bf16 / Gt fp32,
-// 3 = D fp32 / Gt bf16
+// 3 = D fp32 / Gt bf16, 4 = both fp32 in HBM, fragments rounded to fp16 (v_mfma_f32_32x32x8_f16: BASELINE configs[4])
 // MODE (DENSE / CONV / IM2COL3) is a template parameter: with a run-time mode test inside the fetch each gathered load
 // sat in its own branch, and because the two sides of the branch write the same registers the compiler put
 // s_waitcnt vmcnt(0) in front of every one of them -- five serial memory round trips per K-step instead of one
@@ -183,6 +190,24 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
       if constexpr (BF16) {
 #pragma unroll
         for (int r8 = wk * 2 * KPW; r8 < (wk + 1) * 2 * KPW; r8 += 8) {     // 8 rows per bf16 MFMA: lane half h -> 4 rows
+          if constexpr (ST == 4) {
+            f16x4 pa[DT], pb[GT];
+#pragma unroll
+            for (int a = 0; a < DT; ++a) {
+              const float* p = &Ds[(r8 + 4 * h) * BD + wd * WD + a * 32 + cl];
+              pa[a] = pack4_f16(p[0], p[BD], p[2 * BD], p[3 * BD]);
+            }
+#pragma unroll
+            for (int b = 0; b < GT; ++b) {
+              const float* p = &Gs[(r8 + 4 * h) * BG + wg * WG + b * 32 + cl];
+              pb[b] = pack4_f16(p[0], p[BG], p[2 * BG], p[3 * BG]);
+            }
+#pragma unroll
+            for (int a = 0; a < DT; ++a)
+#pragma unroll
+              for (int b = 0; b < GT; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x8f16(pa[a], pb[b], acc[a][b], 0, 0, 0);
+          } else {
           s16x4 pa[DT], pb[GT];
 #pragma unroll
           for (int a = 0; a < DT; ++a) {
@@ -199,6 +224,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
 #pragma unroll
             for (int b = 0; b < GT; ++b)
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(pa[a], pb[b], acc[a][b], 0, 0, 0);
+          }
         }
       } else
 #pragma unroll
@@ -642,6 +668,24 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       if constexpr (BF16) {
 #pragma unroll
         for (int r8 = 0; r8 < RK; r8 += 8) {
+          if constexpr (ST == 4) {
+            f16x4 pa[DT], pb[GT];
+#pragma unroll
+            for (int a = 0; a < DT; ++a) {
+              const float* p = &Ds[(r8 + 4 * h) * BD + a * 32 + cl];
+              pa[a] = pack4_f16(p[0], p[BD], p[2 * BD], p[3 * BD]);
+            }
+#pragma unroll
+            for (int b = 0; b < GT; ++b) {
+              const float* p = &Gw[(r8 + 4 * h) * BG + b * 32 + cl];
+              pb[b] = pack4_f16(p[0], p[BG], p[2 * BG], p[3 * BG]);
+            }
+#pragma unroll
+            for (int a = 0; a < DT; ++a)
+#pragma unroll
+              for (int b = 0; b < GT; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x8f16(pa[a], pb[b], acc[a][b], 0, 0, 0);
+          } else {
           s16x4 pa[DT], pb[GT];
 #pragma unroll
           for (int a = 0; a < DT; ++a) {
@@ -658,6 +702,7 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
 #pragma unroll
             for (int b = 0; b < GT; ++b)
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(pa[a], pb[b], acc[a][b], 0, 0, 0);
+          }
         }
       } else
 #pragma unroll
@@ -703,6 +748,8 @@ static int launch4(const float* D, const float* Gt, float* partial, WgradGeom g,
     hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 2>), grid, dim3(256), smem, st, D, Gt, partial, g);
   else if (bf16 && g.g_b16)
     hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 3>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  else if (bf16 && g.f16)
+    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 4>), grid, dim3(256), smem, st, D, Gt, partial, g);
   else if (bf16)
     hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 0>), grid, dim3(256), smem, st, D, Gt, partial, g);
   else
@@ -821,6 +868,7 @@ static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, 
     if (bf16 && g.d_b16 && g.g_b16) WGRAD_LAUNCH(M, true, 1);          \
     else if (bf16 && g.d_b16) WGRAD_LAUNCH(M, true, 2);                \
     else if (bf16 && g.g_b16) WGRAD_LAUNCH(M, true, 3);                \
+    else if (bf16 && g.f16) WGRAD_LAUNCH(M, true, 4);                  \
     else if (bf16) WGRAD_LAUNCH(M, true, 0);                           \
     else WGRAD_LAUNCH(M, false, 0);                                    \
   } while (0)
@@ -845,6 +893,8 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
   WgradGeom g{};
   g.d_b16 = (storage_flags & 2) != 0;
   g.g_b16 = (storage_flags & 4) != 0;
+  g.f16 = (storage_flags & 32) != 0;
+  if (g.f16 && (storage_flags & ~32)) return MMDYN_ERR_SHAPE;
   if (storage_flags && (!bf16 || (g.g_b16 && mode == MMDYN_IM2COL3))) return MMDYN_ERR_SHAPE;
   g.mode = mode;
   const int64_t rows = (int64_t)Bt * Hr * Wr;
@@ -907,6 +957,13 @@ extern "C" int mmdyn_wgrad_tn_bf16(const float* D, const float* Gt, float* parti
                                    int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
                                    void* stream) {
   return wgrad_entry(D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks, stream, true);
+}
+
+/* fp16 matrix cores (v_mfma_f32_32x32x8_f16), fp32 accumulate, fp32 storage: BASELINE configs[4] */
+extern "C" int mmdyn_wgrad_tn_f16(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr,
+                                  int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
+                                  void* stream) {
+  return wgrad_entry(D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks, stream, true, 32);
 }
 
 // recommended number of partial slabs: ~768 blocks in flight, at least 128 rows per block

@@ -31,11 +31,13 @@ _SIGNATURES = {
     "mmdyn_igemm_nt": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_nt_dgrad_bn": "ppppppppp" + "iiiiiiiiiiii" + "p",
     "mmdyn_igemm_nt_bf16": "ppppppp" + "iiiiiiiiiiiiii" + "p",
+    "mmdyn_igemm_nt_f16": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_stat_tiles": "iiiiiiiii",
     "mmdyn_igemm_stat_tiles_bf16": "iiiiiiiii",
     "mmdyn_splitk_reduce": "pppp" + "iiii" + "p",
     "mmdyn_wgrad_tn": "ppp" + "iiiiiiiiiii" + "p",
     "mmdyn_wgrad_tn_bf16": "ppp" + "iiiiiiiiiii" + "p",
+    "mmdyn_wgrad_tn_f16": "ppp" + "iiiiiiiiiii" + "p",
     "mmdyn_wgrad_chunks": "iiii",
     "mmdyn_wgrad_reduce": "pp" + "iiiiii" + "f" + "p",
     "mmdyn_pack_conv_weight": "pp" + "iii" + "p",

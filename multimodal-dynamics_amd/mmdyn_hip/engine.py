@@ -122,7 +122,7 @@ def _with_precision(fn):
         ops.B.precision = self.precision
         layers.SYNC = self._sync
         layers.ACT_DTYPE = torch.bfloat16 if self.precision == "bf16s" else torch.float32
-        layers.W_DTYPE = torch.float32 if self.precision == "fp32" else torch.bfloat16
+        layers.W_DTYPE = torch.float32 if self.precision in ("fp32", "fp16") else torch.bfloat16
         try:
             return fn(self, *a, **k)
         finally:
@@ -141,10 +141,11 @@ class MVAEStep:
         if getattr(model, "conditional", False):
             raise NotImplementedError("mmdyn_hip: the fused step is built for the unconditional cnn-mvae; run conditional "
                                       "models through the module API (Problem(..., fused=False))")
-        if precision not in ("fp32", "bf16", "bf16s"):
+        if precision not in ("fp32", "bf16", "bf16s", "fp16"):
             raise ValueError("precision must be 'fp32' (the reference's arithmetic), 'bf16s' (bf16 activation storage + "
-                             "bf16 matrix cores, fp32 accumulate / master weights: BASELINE configs[2]) or 'bf16' (bf16 matrix-core "
-                             "operands only, fp32 storage)")
+                             "bf16 matrix cores, fp32 accumulate / master weights: BASELINE configs[2]), 'bf16' (bf16 matrix-core "
+                             "operands only, fp32 storage) or 'fp16' (fp16 matrix-core operands, fp32 accumulate / storage: "
+                             "BASELINE configs[4])")
         self.precision = precision
         # False (default): each image decoder runs only on the passes whose reconstruction enters the loss, so its
         # BatchNorm running buffers see 4 EMA updates per step (2 without pose) where the reference applies 7 (3).
@@ -195,7 +196,7 @@ class MVAEStep:
             # what the encoder forward reads goes first (critical path); the transposed / decoder packs are launched
             # next to the encoder phase (run_late) and are ready long before the decoders start
             self.plan = layers.PackPlan(specs, early=("W1p", "W2k", "W3k", "W4k", "W5k", "W6k", "Wf", "Wh", "bh"),
-                                        w_dtype=torch.float32 if precision == "fp32" else torch.bfloat16)
+                                        w_dtype=torch.float32 if precision in ("fp32", "fp16") else torch.bfloat16)
         self._capturing = False
         self._graph = None
 
@@ -621,8 +622,9 @@ class MVAEInference:
         from .models.vae import NoiseSource
         if getattr(model, "conditional", False):
             raise NotImplementedError("mmdyn_hip: MVAEInference is built for the unconditional cnn-mvae")
-        if precision not in ("fp32", "bf16", "bf16s"):
-            raise ValueError("precision must be 'fp32', 'bf16' (matrix-core operands) or 'bf16s' (+ bf16 activation storage)")
+        if precision not in ("fp32", "bf16", "bf16s", "fp16"):
+            raise ValueError("precision must be 'fp32', 'bf16' / 'fp16' (matrix-core operands) or 'bf16s' (+ bf16 activation "
+                             "storage)")
         self.model, self.precision, self.use_graph = model, precision, use_graph
         self.use_pose = bool(model._use_pose)
         self.L = model.latent_size
@@ -631,7 +633,7 @@ class MVAEInference:
         self.noise = NoiseSource(seed)
         self._sync = None
         self._graphs = {}
-        self._w_dtype = torch.float32 if precision == "fp32" else torch.bfloat16     # packed GEMM operands
+        self._w_dtype = torch.float32 if precision in ("fp32", "fp16") else torch.bfloat16     # packed GEMM operands
         self.refresh()
 
     def _P(self, name, keys):

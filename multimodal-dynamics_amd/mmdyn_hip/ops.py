@@ -50,7 +50,8 @@ class HipBackend:
     def __init__(self):
         self._l = None
         # "fp32": v_mfma_f32_32x32x2_f32 (the reference's arithmetic, the default and the BASELINE configs[1] path);
-        # "bf16": operands rounded to bf16 on their way into the matrix cores, fp32 accumulate (configs[2])
+        # "bf16": operands rounded to bf16 on their way into the matrix cores, fp32 accumulate (configs[2]);
+        # "fp16": the same with IEEE-half operands (configs[4]); "bf16s": bf16 + bf16 activation storage
         self.precision = "fp32"
 
     @property
@@ -87,7 +88,8 @@ class HipBackend:
                                              splitk, 1 | (2 if a16 else 0) | (4 if c16 else 0) | (16 if b16 else 0),
                                              _stream()), "mmdyn_igemm_nt_mx")
             return
-        fn = self.lib.mmdyn_igemm_nt_bf16 if self.precision != "fp32" else self.lib.mmdyn_igemm_nt
+        fn = {"fp32": self.lib.mmdyn_igemm_nt, "fp16": self.lib.mmdyn_igemm_nt_f16}.get(self.precision,
+                                                                                         self.lib.mmdyn_igemm_nt_bf16)
         check(fn(pa, _ptr(Bp), _ptr(bias), pc, pca, _ptr(stats), _ptr(ws),
                  mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, _stream()), "mmdyn_igemm_nt")
 
@@ -104,7 +106,7 @@ class HipBackend:
             return
         check(self.lib.mmdyn_igemm_nt_dgrad_bn(pa, _ptr(Bp), pc, _ptr(stats), py, _ptr(mean), _ptr(rstd),
                                                _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride,
-                                               offset, int(self.precision != "fp32"), _stream()),
+                                               offset, {"fp32": 0, "fp16": 2}.get(self.precision, 1), _stream()),
               "mmdyn_igemm_nt_dgrad_bn")
 
     def splitk_reduce(self, ws, bias, C, C_act, splitk, rows, N, act):
@@ -119,7 +121,8 @@ class HipBackend:
             check(self.lib.mmdyn_wgrad_tn_mx(pd, pg, _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks,
                                              1 | (2 if d16 else 0) | (4 if g16 else 0), _stream()), "mmdyn_wgrad_tn_mx")
             return
-        fn = self.lib.mmdyn_wgrad_tn_bf16 if self.precision != "fp32" else self.lib.mmdyn_wgrad_tn
+        fn = {"fp32": self.lib.mmdyn_wgrad_tn, "fp16": self.lib.mmdyn_wgrad_tn_f16}.get(self.precision,
+                                                                                         self.lib.mmdyn_wgrad_tn_bf16)
         check(fn(pd, pg, _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks,
                  _stream()), "mmdyn_wgrad_tn")
 

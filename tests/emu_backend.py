@@ -98,7 +98,8 @@ class EmuBackend:
         # operands rounded to bf16 (RNE), fp32 accumulate -- except on the HBM-bound 3-channel layers, whose kernels
         # (conv3.hip) keep fp32 matrix cores in every precision mode
         if getattr(self, "precision", "fp32") != "fp32" and mode != IM2COL3:
-            A, Bp = A.to(torch.bfloat16).to(torch.float32), Bp.to(torch.bfloat16).to(torch.float32)
+            h = torch.float16 if self.precision == "fp16" else torch.bfloat16
+            A, Bp = A.to(h).to(torch.float32), Bp.to(h).to(torch.float32)
         if mode == IM2COL3:
             assert Cin == 64
             A = self._unfold3(A, Bt, Hi, Wi)
@@ -160,7 +161,8 @@ class EmuBackend:
         assert chunks % 4 == 0 and Cd % 32 == 0 and Cg % 32 == 0
         rows = Bt * Hr * Wr
         if getattr(self, "precision", "fp32") != "fp32" and mode != IM2COL3:
-            D, Gt = D.to(torch.bfloat16).to(torch.float32), Gt.to(torch.bfloat16).to(torch.float32)
+            h = torch.float16 if self.precision == "fp16" else torch.bfloat16
+            D, Gt = D.to(h).to(torch.float32), Gt.to(h).to(torch.float32)
         Dm = D.reshape(-1)[: rows * Cd].reshape(rows, Cd)
         partial.zero_()
         taps = 16 if mode == CONV else 1

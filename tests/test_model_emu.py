@@ -183,6 +183,12 @@ def test_extended_image_sizes(size, B, use_pose):
     check_extended_size_vs_oracle("cpu", size, B, use_pose, n_steps=1 if size == 256 else 2)
 
 
+def test_fp16_precision_plumbing():
+    """precision="fp16" (BASELINE configs[4] arithmetic) on the emulated kernels: operands rounded to IEEE half, fp32
+    accumulate and storage; the fp32 oracle within the mode's stated tolerance."""
+    check_extended_size_vs_oracle("cpu", 64, 3, True, n_steps=1, precision="fp16", loss_tol=2e-3, grad_tol=1e-1)
+
+
 def test_extended_size_module_api_and_checks():
     """MVAE.forward / inference of a 128-pixel model, and the input-size check of a 64-pixel one."""
     from oracle import mvae_oracle as O
