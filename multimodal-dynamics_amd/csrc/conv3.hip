@@ -49,10 +49,13 @@ template <> __device__ __forceinline__ float gld1<bf16_t>(gchar_p p) {
 
 // slot j (0..23) of lane half h is the window element (ci, kh, kw) = (j>>3, (j>>1)&3, 2*(j&1)+h); MFMA j multiplies
 // slot j of A and B, so any bijection works as long as both operands use it.
-// The kernel is specialised to the reference's 64x64 images: 32x32 output pixels, N = ldc = 32 channels.
+// The kernel is specialised to square images of 64 * SEGS pixels a side (SEGS = 1: the reference's 64x64; 2 / 4: the 128 /
+// 256 pixel extensions of models/shapes.py), N = ldc = 32 channels.  The unit of work of a wave is one 32-pixel segment
+// of an output image row (SEGS segments per row); units are numbered (sample, row, segment), which is also their order
+// in the channels-last output, so unit u owns the 32 x 32 output block at byte offset u * OROW_B.
 // BN: BatchNorm+Swish backward epilogue; ACT: -1 = no second output, else the activation of the second output
-constexpr int C3_HI = 64, C3_HO = 32, C3_N = 32;
-template <typename T, bool BN, int ACT>
+constexpr int C3_N = 32;
+template <typename T, bool BN, int ACT, int SEGS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3_nt_kernel(
     const float* __restrict__ img, const float* __restrict__ Wp, T* __restrict__ C, T* __restrict__ C_act,
     float* __restrict__ stats, const Conv3Geom g) {
@@ -85,37 +88,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   // Addressing is kept off the vector ALU: every access is (uniform 64-bit base, scalar instructions) + (one of three
   // per-lane BYTE offsets that never change) + (a compile-time immediate), the saddr form of global_load/store.
-  unsigned xoB[2];
-  bool xok[2];
+  constexpr int C3_HI = 64 * SEGS, C3_HO = 32 * SEGS;
+  constexpr int UNITS = C3_HO * SEGS;                                  // units per sample
+  int xl[2];                                                           // input column of the lane inside its segment
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int xin = 2 * x - 1 + 2 * q + h;
-    xok[q] = (unsigned)xin < (unsigned)C3_HI;
-    xoB[q] = (xok[q] ? xin : 0) * 4u;
-  }
-  const unsigned voffB = (4 * h * C3_N + x) * sizeof(T);              // pixel +4h of the row, channel x
+  for (int q = 0; q < 2; ++q) xl[q] = 2 * x - 1 + 2 * q + h;           // -1 .. 64
+  const unsigned voffB = (4 * h * C3_N + x) * sizeof(T);              // pixel +4h of the unit, channel x
   constexpr unsigned IMG_B = 3 * C3_HI * C3_HI * sizeof(float);       // bytes per sample of the image
-  constexpr unsigned OROW_B = C3_HO * C3_N * sizeof(T);               // bytes per output image row (32 px x 32 ch)
+  constexpr unsigned OROW_B = 32 * C3_N * sizeof(T);                  // bytes per unit of output (32 px x 32 ch)
 
-  // tile t = 128 GEMM rows = output image rows 4*(t&7) .. +3 of sample t>>3 (8 tiles per sample); wave w takes row +w
+  // tile t = 128 GEMM rows = units 4t .. 4t+3 (wave w takes unit 4t + w); UNITS / 4 tiles per sample
   struct TileAt {
-    gchar_p imgb;       // the sample's image
-    size_t orow;        // byte offset of the wave's output row (the same in C, C_act and bn_y)
-    int y;
+    gchar_p imgb;       // the sample's image, advanced to the unit's segment (+ seg * 64 columns)
+    size_t orow;        // byte offset of the wave's output unit (the same in C, C_act and bn_y)
+    int y, seg;
+    unsigned xoB[2];    // per-lane byte offsets of the two column phases (clamped to a valid address when outside)
+    bool xok[2];
   };
   auto locate = [&](int t) {
     TileAt p;
-    const int ib = t >> 3;
-    p.y = (t & 7) * 4 + wave;
-    p.imgb = sgpr_ptr(reinterpret_cast<const char*>(img) + (size_t)ib * IMG_B);
-    p.orow = (size_t)(ib * C3_HO + p.y) * OROW_B;
+    const int u = t * 4 + wave;                                        // wave-uniform
+    const int ib = u / UNITS, rem = u - ib * UNITS;
+    p.y = rem / SEGS;
+    p.seg = rem - p.y * SEGS;
+    // (one float in front of the segment, so that the per-lane offsets below are never negative: the 32-bit lane offset of
+    //  the scalar-base addressing form is unsigned)
+    p.imgb = sgpr_ptr(reinterpret_cast<const char*>(img) + (size_t)ib * IMG_B + (size_t)p.seg * 256 - 4);
+    p.orow = (size_t)u * OROW_B;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      p.xok[q] = (unsigned)(p.seg * 64 + xl[q]) < (unsigned)C3_HI;
+      p.xoB[q] = (unsigned)((p.xok[q] ? xl[q] + 1 : 1) * 4);          // outside the image: the segment's first column
+    }
     return p;
   };
   auto load_a = [&](const TileAt& p, int j) {         // window slot j of the wave's 32 pixels: one 256-byte load
     const int ci = j >> 3, yin = 2 * p.y - 1 + ((j >> 1) & 3);            // wave-uniform
     const bool yok = (unsigned)yin < (unsigned)C3_HI;
     const gchar_p rowp = p.imgb + (unsigned)((ci * C3_HI + (yok ? yin : 0)) * C3_HI) * 4u;
-    return gld1<float>(rowp + xoB[j & 1]);
+    return gld1<float>(rowp + p.xoB[j & 1]);
   };
   auto erow = [](int e) { return (unsigned)(((e & 3) + 8 * (e >> 2)) * C3_N * sizeof(T)); };   // immediate offsets
 
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   for (; t < ntiles; t += gridDim.x) {
     const int tn = t + gridDim.x < ntiles ? t + gridDim.x : t;      // last tile: harmless re-read of its own data
     const TileAt nxt = locate(tn);
-    const int grp = (BN || g.want_stats) ? __builtin_amdgcn_readfirstlane((t >> 3) / g.Bg) : 0;
+    const int grp = (BN || g.want_stats) ? __builtin_amdgcn_readfirstlane((t / (UNITS / 4)) / g.Bg) : 0;
     if (BN) load_bw();
     float bn_m = 0.f, bn_r = 0.f;
     if (BN) {
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int j = 0; j < 24; ++j) {
       const int yin = 2 * cur.y - 1 + ((j >> 1) & 3);
-      const bool ok = ((unsigned)yin < (unsigned)C3_HI) & xok[j & 1];
+      const bool ok = ((unsigned)yin < (unsigned)C3_HI) & cur.xok[j & 1];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? a[j] : 0.f, bw[j], acc, 0, 0, 0);
       a[j] = load_a(nxt, j);
     }
@@ -209,16 +220,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 // ---- weight gradient --------------------------------------------------------------------------------------------
 struct Conv3WgradGeom {
-  int Bt, Hr, Hi, Wi;       // Wr = 32
-  int img_rows;             // Bt*Hr output image rows = K-blocks of 32 pixels
-  int rows_per_chunk;       // output image rows per block
+  int Bt, Hr, Hi, Wi;       // Wr = Hr = 32 * SEGS
+  int img_rows;             // Bt*Hr*SEGS units (32-pixel segments of output image rows) = K-blocks of 32 pixels
+  int rows_per_chunk;       // units per block
 };
 
 constexpr int PATCH_LD = 76;                 // 3 pad + 1 (x = -1) + 64 + 1 (x = 64) + pad; 76 % 32 = 12 spreads the
 constexpr int PATCH_ROWS = 13;               // 8 rows of one fragment over all banks; row 12 stays zero (k >= 48)
 constexpr int PATCH = PATCH_ROWS * PATCH_LD;
 
-template <typename TD>
+// SEGS as in conv3_nt_kernel: images of 64 * SEGS pixels a side; a K-block is one 32-pixel segment of an output row, its
+// patch the 12 input rows x 64 columns under it plus one halo column on either side (zero at the image border)
+template <typename TD, int SEGS>
 __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const TD* __restrict__ D, const float* __restrict__ img,
                                                           float* __restrict__ partial, const Conv3WgradGeom g) {
   __shared__ __attribute__((aligned(16))) float smem[8192];       // 4 waves x 2 patches (7904 floats); reused as [4][32][64]
@@ -241,24 +254,37 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const TD* __restrict__
   const int it_end = min(g.img_rows, it_begin + g.rows_per_chunk);
 
   f32x4 ri[3];
+  float rh = 0.f;                               // SEGS > 1: halo column (lanes 0..23: row lane>>1, side lane&1)
   float dc[16], dn[16];
-  auto load_img = [&](int it) {                 // the 12 input rows (3 ci x 4 kh) of output image row `it`
-    const int b = it / g.Hr, y = it - b * g.Hr;
+  auto load_img = [&](int it) {                 // the 12 input rows (3 ci x 4 kh) under unit `it`
+    const int b = it / (g.Hr * SEGS), rem = it - b * (g.Hr * SEGS);
+    const int y = rem / SEGS, seg = rem - y * SEGS;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int r = (lane >> 4) + 4 * i;        // r = ci*4 + kh with ci = i
       const int yin = 2 * y - 1 + (r & 3);
       const bool ok = (unsigned)yin < (unsigned)g.Hi;
       const f32x4 v = *reinterpret_cast<const f32x4*>(img + ((size_t)(b * 3 + i) * g.Hi + (ok ? yin : 0)) * g.Wi +
-                                                      (lane & 15) * 4);
+                                                      seg * 64 + (lane & 15) * 4);
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       ri[i] = ok ? v : z;
+    }
+    if constexpr (SEGS > 1) {
+      const int r = (lane >> 1) % 12, side = lane & 1;
+      const int yin = 2 * y - 1 + (r & 3);
+      const int xin = side ? seg * 64 + 64 : seg * 64 - 1;
+      const bool ok = (lane < 24) & ((unsigned)yin < (unsigned)g.Hi) & ((unsigned)xin < (unsigned)g.Wi);
+      const float v = img[((size_t)(b * 3 + (r >> 2)) * g.Hi + (ok ? yin : 0)) * g.Wi + (ok ? xin : 0)];
+      rh = ok ? v : 0.f;
     }
   };
   auto store_img = [&](float* p) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       *reinterpret_cast<f32x4*>(p + ((lane >> 4) + 4 * i) * PATCH_LD + 4 + (lane & 15) * 4) = ri[i];
+    if constexpr (SEGS > 1) {
+      if (lane < 24) p[(lane >> 1) * PATCH_LD + ((lane & 1) ? 68 : 3)] = rh;
+    }
   };
   auto load_d = [&](int it, float* d) {         // fragment order: lane (cd = n, pixel 2j + kk) = 64 consecutive elements
     const TD* p = D + (size_t)it * 32 * 32 + lane;
@@ -326,10 +352,13 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
                        int Bg, int Hi, int Wi, int Ho, int Wo, int N, int ldc, int act, int splitk, const void* bn_y,
                        const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
                        int c_b16, int bny_b16, int b_b16, hipStream_t st) {
-  if (N != C3_N || ldc != C3_N || Ho != C3_HO || Wo != C3_HO || Hi != C3_HI || Wi != C3_HI || bias || splitk != 1) return 1;
+  if (N != C3_N || ldc != C3_N || Wo != Ho || Wi != Hi || Hi != 2 * Ho || (Hi != 64 && Hi != 128 && Hi != 256) || bias ||
+      splitk != 1)
+    return 1;
+  const int segs = Hi / 64;
   if (bn_y && (c_b16 != bny_b16 || C_act)) return 1;
   if (C_act && act != MMDYN_ACT_NONE && act != MMDYN_ACT_SWISH && act != MMDYN_ACT_RELU) return 1;
-  if ((int64_t)G * Bg * Ho * 32 * ldc >= (1LL << 31)) return 1;
+  if ((int64_t)G * Bg * Ho * Ho * ldc >= (1LL << 31) || (int64_t)G * Bg * Ho * Ho / 32 >= (1LL << 29)) return 1;
   Conv3Geom g{};
   g.G = G;
   g.Bg = Bg;
@@ -341,7 +370,7 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
   g.want_act_out = C_act != nullptr;
   g.want_stats = stats != nullptr;
   g.w_b16 = b_b16;
-  g.tiles_per_group = Bg * Ho * 32 / 128;
+  g.tiles_per_group = Bg * Ho * Ho / 128;
   g.bn_y = bn_y;
   g.bn_mean = bn_mean;
   g.bn_rstd = bn_rstd;
@@ -350,20 +379,26 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
   const int ntiles = G * g.tiles_per_group;
   const dim3 grid(ntiles < CONV3_GRID ? ntiles : CONV3_GRID);
   const int variant = bn_y ? 4 : (C_act ? act : -1);
+#define CONV3_LAUNCH(T_, BN_, ACT_, S_)                                                                            \
+  hipLaunchKernelGGL((conv3_nt_kernel<T_, BN_, ACT_, S_>), grid, dim3(256), 0, st, A, Bp, (T_*)C, (T_*)C_act, stats, g)
 #define CONV3_CASE(V, BN_, ACT_)                                                                                   \
   if (variant == (V)) {                                                                                            \
-    if (c_b16)                                                                                                     \
-      hipLaunchKernelGGL((conv3_nt_kernel<bf16_t, BN_, ACT_>), grid, dim3(256), 0, st, A, Bp, (bf16_t*)C,          \
-                         (bf16_t*)C_act, stats, g);                                                                \
-    else                                                                                                           \
-      hipLaunchKernelGGL((conv3_nt_kernel<float, BN_, ACT_>), grid, dim3(256), 0, st, A, Bp, (float*)C,            \
-                         (float*)C_act, stats, g);                                                                 \
+    if (c_b16) {                                                                                                   \
+      if (segs == 1) CONV3_LAUNCH(bf16_t, BN_, ACT_, 1);                                                           \
+      else if (segs == 2) CONV3_LAUNCH(bf16_t, BN_, ACT_, 2);                                                      \
+      else CONV3_LAUNCH(bf16_t, BN_, ACT_, 4);                                                                     \
+    } else {                                                                                                       \
+      if (segs == 1) CONV3_LAUNCH(float, BN_, ACT_, 1);                                                            \
+      else if (segs == 2) CONV3_LAUNCH(float, BN_, ACT_, 2);                                                       \
+      else CONV3_LAUNCH(float, BN_, ACT_, 4);                                                                      \
+    }                                                                                                              \
   }
   CONV3_CASE(4, true, -1)
   CONV3_CASE(-1, false, -1)
   CONV3_CASE(MMDYN_ACT_NONE, false, MMDYN_ACT_NONE)
   CONV3_CASE(MMDYN_ACT_SWISH, false, MMDYN_ACT_SWISH)
   CONV3_CASE(MMDYN_ACT_RELU, false, MMDYN_ACT_RELU)
+#undef CONV3_LAUNCH
 #undef CONV3_CASE
   MMDYN_LAUNCH_CHECK();
 }
@@ -371,17 +406,27 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
 // chunks = partial slabs = blocks; 1 when the shape is not this file's
 int mmdyn_conv3_wgrad_try(const void* D, const float* Gt, float* partial, int Bt, int Hr, int Wr, int Cd, int Hi,
                           int Wi, int Cg, int chunks, int d_b16, hipStream_t st) {
-  if (Cd != 32 || Cg != 64 || Wr != 32 || Wi != 64 || Hi != 2 * Hr) return 1;
+  if (Cd != 32 || Cg != 64 || Wr != Hr || Wi != Hi || Hi != 2 * Hr || (Hi != 64 && Hi != 128 && Hi != 256)) return 1;
+  const int segs = Hi / 64;
+  if ((int64_t)Bt * Hr * segs >= (1LL << 30)) return 1;
   Conv3WgradGeom g{};
   g.Bt = Bt;
   g.Hr = Hr;
   g.Hi = Hi;
   g.Wi = Wi;
-  g.img_rows = Bt * Hr;
+  g.img_rows = Bt * Hr * segs;
   g.rows_per_chunk = ceil_div(g.img_rows, chunks);
-  if (d_b16)
-    hipLaunchKernelGGL(conv3_wgrad_kernel<bf16_t>, dim3(chunks), dim3(256), 0, st, (const bf16_t*)D, Gt, partial, g);
-  else
-    hipLaunchKernelGGL(conv3_wgrad_kernel<float>, dim3(chunks), dim3(256), 0, st, (const float*)D, Gt, partial, g);
+#define CONV3_WG(T_, S_) \
+  hipLaunchKernelGGL((conv3_wgrad_kernel<T_, S_>), dim3(chunks), dim3(256), 0, st, (const T_*)D, Gt, partial, g)
+  if (d_b16) {
+    if (segs == 1) CONV3_WG(bf16_t, 1);
+    else if (segs == 2) CONV3_WG(bf16_t, 2);
+    else CONV3_WG(bf16_t, 4);
+  } else {
+    if (segs == 1) CONV3_WG(float, 1);
+    else if (segs == 2) CONV3_WG(float, 2);
+    else CONV3_WG(float, 4);
+  }
+#undef CONV3_WG
   MMDYN_LAUNCH_CHECK();
 }

@@ -612,11 +612,13 @@ def test_bce_logits_groups_equals_per_pass_launches():
     assert rel(d.cpu(), cpu_d) <= 2e-5 and torch.allclose(loss.cpu(), cpu_loss, rtol=1e-5)
 
 
-def test_im2col_generic_fallback_for_other_image_sizes():
-    """Images that are not 64x64 do not fit the specialised 3-channel kernels (conv3.hip) and take the tiled
-    implicit-GEMM / weight-gradient kernels with the on-the-fly im2col gather: forward with statistics, input gradient
-    with the BatchNorm epilogue, weight gradient."""
-    G, Bg, H = 2, 3, 32
+@pytest.mark.parametrize("H", [32, 128, 256])
+def test_im2col_other_image_sizes(H):
+    """The 3-channel layers at other image sizes.  128 / 256 (the extended stacks of BASELINE configs[3] / configs[4]) run
+    the specialised kernels of conv3.hip with 2 / 4 segments per output row (segment borders need the halo columns, image
+    borders zeros); anything else (32 here) takes the tiled implicit-GEMM / weight-gradient kernels with the on-the-fly
+    im2col gather.  Forward with statistics, input gradient with the BatchNorm epilogue, weight gradient."""
+    G, Bg = 2, 3
     Bt, Ho = G * Bg, H // 2
     x = rnd(Bt, 3, H, H, seed=110)
     Bp = rnd(1, 32, 64, seed=111, scale=0.2)

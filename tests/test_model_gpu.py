@@ -287,10 +287,10 @@ def test_extended_image_sizes_vs_oracle(size, B, use_pose):
 def test_fp16_engine_vs_oracle(size, B):
     """fp16 matrix-core operands (v_mfma_f32_32x32x16_f16 / 32x32x8_f16), fp32 accumulate, storage and master weights
     -- BASELINE configs[4]'s arithmetic -- against the fp32 CPU oracle.  Stated tolerance: ELBO and partials 2e-3
-    relative, gradients 3e-2 relative L2 per tensor (fp16 has 3 more mantissa bits than bf16; measured values are
-    printed)."""
+    relative, gradients 5e-2 relative L2 per tensor at B = 32 (measured 2.4e-2; fp16 has 3 more mantissa bits than bf16,
+    whose bound is 1.5e-1), 1e-1 at B = 4 on 256x256 (measured 4.1e-2)."""
     worst = T.check_extended_size_vs_oracle(DEV, size, B, True, n_steps=1, precision="fp16", loss_tol=2e-3,
-                                            grad_tol=3e-2 if B >= 32 else 1e-1)
+                                            grad_tol=5e-2 if B >= 32 else 1e-1)
     print(f"fp16 size {size} B {B}: worst gradient rel-L2 {worst:.2e}")
 
 
