@@ -267,7 +267,7 @@ int mmdyn_poe_fwd(const mmdyn_pass_experts* passes, const float* eps_noise, floa
  * any may be null; kl_scale = kl_weight / B adds the KL term's gradient. */
 int mmdyn_poe_bwd(const mmdyn_pass_experts* passes, const float* eps_noise, const float* mu,
                   const float* logvar, const float* dz, const float* g_mu, const float* g_lv, float kl_scale,
-                  int with_prior, int P, int B, int L, void* stream);
+                  int with_prior, int P, int B, int L, const float* kl_weight_dev, void* stream);
 /* single-expert path (VAE, vae.py:81-88): reparametrisation and/or KL on mu/lv rows of stride ld */
 int mmdyn_reparam_fwd(const float* mu, const float* lv, const float* eps_noise, float* z, double* kl_sum,
                       int B, int L, int ld, void* stream);
@@ -291,9 +291,12 @@ int mmdyn_bce_logits_groups(const float* logits, const float* target, float* dlo
 /* sum (r-t)^2 added to *loss_sum; dr = 2 (r-t) grad_scale */
 int mmdyn_mse(const float* r, const float* t, float* dr, double* loss_sum, int64_t n, float grad_scale,
               void* stream);
-/* loss[0] = (sum_p bce[p] + pose_multiplier * mse[p] + kl_weight * kl[p]) / B; partial[p] likewise */
+/* loss[0] = (sum_p bce[p] + pose_multiplier * mse[p] + kl_weight * kl[p]) / B; partial[p] likewise.
+ * kl_weight_dev (here and in mmdyn_poe_bwd; may be null): one float in device memory that multiplies kl_weight /
+ * kl_scale -- the annealed KL weight of problems.py:212-216 kept on the device, so that a captured launch serves every
+ * epoch of the schedule. */
 int mmdyn_elbo_assemble(const double* bce, const double* mse, const double* kl, float* loss, float* partials,
-                        int P, int B, float kl_weight, float pose_multiplier, void* stream);
+                        int P, int B, float kl_weight, float pose_multiplier, const float* kl_weight_dev, void* stream);
 
 /* ---- Adam (torch.optim.Adam defaults, problems.py:137-138) ----------------------------------- */
 /* state: 3 doubles {step count, step size, sqrt(bias_correction2)}, advanced on the device by this call

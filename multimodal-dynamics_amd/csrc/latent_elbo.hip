@@ -62,8 +62,11 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(PoeArgs args, const float*
                                                       const float* __restrict__ lv_pd,
                                                       const float* __restrict__ dz,
                                                       const float* __restrict__ g_mu,
-                                                      const float* __restrict__ g_lv, float kl_scale,
-                                                      int with_prior, int B, int L) {
+                                                      const float* __restrict__ g_lv, float kl_scale_arg,
+                                                      const float* __restrict__ kl_weight_dev, int with_prior, int B, int L) {
+  // kl_weight_dev (optional): the KL weight lives in device memory and multiplies kl_scale -- a captured launch then
+  // follows the annealing schedule (problems.py:212-216) without being re-captured
+  const float kl_scale = kl_weight_dev ? kl_scale_arg * kl_weight_dev[0] : kl_scale_arg;
   const int p = blockIdx.y;
   const mmdyn_pass_experts& e = args.pass[p];
   const int64_t n = (int64_t)B * L;
@@ -255,8 +258,9 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ r, c
 
 __global__ void elbo_assemble_kernel(const double* __restrict__ bce, const double* __restrict__ mse,
                                      const double* __restrict__ kl, float* __restrict__ loss,
-                                     float* __restrict__ partials, int P, int B, float kl_weight,
-                                     float pose_multiplier) {
+                                     float* __restrict__ partials, int P, int B, float kl_weight_arg,
+                                     float pose_multiplier, const float* __restrict__ kl_weight_dev) {
+  const float kl_weight = kl_weight_dev ? kl_weight_arg * kl_weight_dev[0] : kl_weight_arg;
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double tot = 0.0;
     for (int p = 0; p < P; ++p) {
@@ -299,7 +303,8 @@ extern "C" int mmdyn_poe_fwd(const mmdyn_pass_experts* passes, const float* eps_
 
 extern "C" int mmdyn_poe_bwd(const mmdyn_pass_experts* passes, const float* eps_noise, const float* mu,
                              const float* logvar, const float* dz, const float* g_mu, const float* g_lv,
-                             float kl_scale, int with_prior, int P, int B, int L, void* stream) {
+                             float kl_scale, int with_prior, int P, int B, int L, const float* kl_weight_dev,
+                             void* stream) {
   if (!mu || !logvar || (dz && !eps_noise)) return MMDYN_ERR_NULL;
   PoeArgs a{};
   if (int e = copy_passes(passes, P, &a)) return e;
@@ -312,7 +317,7 @@ extern "C" int mmdyn_poe_bwd(const mmdyn_pass_experts* passes, const float* eps_
   int gx = ew_grid((int64_t)B * L);
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(poe_bwd_kernel, dim3(gx, P), dim3(256), 0, ST, a, eps_noise, mu, logvar, dz, g_mu, g_lv,
-                     kl_scale, with_prior, B, L);
+                     kl_scale, kl_weight_dev, with_prior, B, L);
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -372,9 +377,9 @@ extern "C" int mmdyn_mse(const float* r, const float* t, float* dr, double* loss
 
 extern "C" int mmdyn_elbo_assemble(const double* bce, const double* mse, const double* kl, float* loss,
                                    float* partials, int P, int B, float kl_weight, float pose_multiplier,
-                                   void* stream) {
+                                   const float* kl_weight_dev, void* stream) {
   if (!loss) return MMDYN_ERR_NULL;
   hipLaunchKernelGGL(elbo_assemble_kernel, dim3(1), dim3(64), 0, ST, bce, mse, kl, loss, partials, P, B,
-                     kl_weight, pose_multiplier);
+                     kl_weight, pose_multiplier, kl_weight_dev);
   MMDYN_LAUNCH_CHECK();
 }

@@ -74,13 +74,13 @@ _SIGNATURES = {
     "mmdyn_linear_small_fwd": "pppp" + "iiii" + "p",
     "mmdyn_linear_small_bwd": "pppppp" + "iii" + "f" + "p",
     "mmdyn_poe_fwd": "pppppp" + "iiii" + "p",
-    "mmdyn_poe_bwd": "ppppppp" + "f" + "iiii" + "p",
+    "mmdyn_poe_bwd": "ppppppp" + "f" + "iiii" + "pp",
     "mmdyn_reparam_fwd": "ppppp" + "iii" + "p",
     "mmdyn_reparam_bwd": "pppp" + "f" + "pp" + "iii" + "p",
     "mmdyn_bce_logits": "ppppp" + "l" + "iii" + "f" + "p",
     "mmdyn_bce_logits_groups": "ppppp" + "i" + "l" + "f" + "p",
     "mmdyn_mse": "pppp" + "l" + "f" + "p",
-    "mmdyn_elbo_assemble": "ppppp" + "ii" + "ff" + "p",
+    "mmdyn_elbo_assemble": "ppppp" + "ii" + "ff" + "pp",
     "mmdyn_adam_step": "ppppp" + "l" + "fffff" + "p",
     "mmdyn_sgd_step": "ppp" + "l" + "ffff" + "i" + "p",
     "mmdyn_igemm_nt_mx": "pppppppppppp" + "iiiiiiiiiiiiii" + "i" + "p",

@@ -178,6 +178,16 @@ class MVAEStep:
         self.acc = torch.zeros(3, 8, dtype=torch.float64, device=dev)          # bce / mse / kl per pass
         self.loss = torch.zeros(1, device=dev)
         self.partials = torch.zeros(8, device=dev)
+        # the KL weight of the annealing schedule (problems.py:212-216) lives on the device: the loss assembly and the
+        # latent backward read it from there, so a captured step serves every epoch without re-capture
+        self.klw = torch.zeros(1, device=dev)
+        self._klw_host = None
+        if process_group is not None:
+            # replicas must start identical whatever each rank's seeding was: rank 0's parameters and BatchNorm buffers
+            import torch.distributed as dist
+            dist.broadcast(self.params.flat, 0, group=process_group)
+            for b in model.buffers():
+                dist.broadcast(b, 0, group=process_group)
         self.last = {}
         self.lanes = _Lanes(dev, two_lanes)
         # every weight repack of a step (conv tap-major packs, FC permutations / transposes, fused heads) as ONE
@@ -240,7 +250,13 @@ class MVAEStep:
     # ------------------------------------------------------------------------------------------
     _MOD = {"v": ("visual_encoder", "visual_decoder", 0), "t": ("tactile_encoder", "tactile_decoder", 1)}
 
+    def _set_kl_weight(self, kl_weight):
+        if self._klw_host != float(kl_weight) and not self._capturing:
+            self.klw.fill_(float(kl_weight))
+            self._klw_host = float(kl_weight)
+
     def _begin(self, inputs, targets, kl_weight, train):
+        self._set_kl_weight(kl_weight)
         if not self.params.still_attached():
             raise RuntimeError("model parameters were re-allocated (e.g. .to()/.cuda() after MVAEStep was built); "
                                "construct MVAEStep after moving the model")
@@ -330,7 +346,7 @@ class MVAEStep:
     def _ph_assemble(self):
         c = self.ctx
         ops.B.elbo_assemble(self.acc[0], self.acc[1], self.acc[2], self.loss, self.partials, self.P, c["B"],
-                            c["kl_weight"], self.pose_multiplier)
+                            1.0, self.pose_multiplier, self.klw)
 
     def _ph_dec_bwd_steps(self, m):
         c, FP = self.ctx, self.params
@@ -359,7 +375,7 @@ class MVAEStep:
         c["dov"], c["dot"] = torch.empty_like(c["ov"]), torch.empty_like(c["ot"])
         c["dop"] = torch.empty_like(c["op"]) if self.use_pose else None
         ops.B.poe_bwd(self._passes(c, B, [c["dov"], c["dot"], c["dop"]], blocks), c["eps"], c["mu"], c["lv"], None, None,
-                      None, c["kl_weight"] / B, True, P, B, L)
+                      None, 1.0 / B, True, P, B, L, self.klw)
 
     def _ph_enc_bwd_steps(self, m):
         c, FP, B = self.ctx, self.params, self.ctx["B"]
@@ -484,7 +500,7 @@ class MVAEStep:
     @_with_precision
     def train_step_graphed(self, inputs, targets, kl_weight):
         """Same as :meth:`train_step`, replayed from HIP graphs: the ~300 kernel launches of a step are captured
-        once per (batch shape, kl_weight).  Each phase is its OWN graph: the visual and the tactile phases are
+        once per batch shape (the KL weight is read from device memory).  Each phase is its OWN graph: the visual and the tactile phases are
         linear kernel chains that are launched concurrently on two streams (a single graph with parallel branches
         was measured to run its branches mostly one after the other), the joint phases run on the caller's stream.
         Each lane captures into its own memory pool, so concurrently replayed graphs never share scratch memory.
@@ -493,7 +509,8 @@ class MVAEStep:
         all-reduce and Adam run after the graphs."""
         if self._sync is not None:
             return self.train_step(inputs, targets, kl_weight)
-        key = (tuple(tuple(x.shape) for x in inputs), float(kl_weight))
+        key = tuple(tuple(x.shape) for x in inputs)
+        self._set_kl_weight(kl_weight)
         if self._graph is None or self._graph[0] != key:
             self._static_in = [x.clone() for x in inputs]
             self._static_tg = [x.clone() for x in targets]

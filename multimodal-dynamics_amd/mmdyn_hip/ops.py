@@ -305,11 +305,12 @@ class HipBackend:
                                      _ptr(z), _ptr(kl_sum, torch.float64), int(with_prior), P, B, L, _stream()),
               "mmdyn_poe_fwd")
 
-    def poe_bwd(self, passes, eps_noise, mu, logvar, dz, g_mu, g_lv, kl_scale, with_prior, P, B, L):
+    def poe_bwd(self, passes, eps_noise, mu, logvar, dz, g_mu, g_lv, kl_scale, with_prior, P, B, L, kl_weight_dev=None):
+        """kl_weight_dev: optional 1-element device tensor multiplying kl_scale (the annealed KL weight kept on the GPU)."""
         arr = self._passes(passes)
         check(self.lib.mmdyn_poe_bwd(ctypes.cast(arr, ctypes.c_void_p), _ptr(eps_noise), _ptr(mu), _ptr(logvar),
                                      _ptr(dz), _ptr(g_mu), _ptr(g_lv), float(kl_scale), int(with_prior), P, B, L,
-                                     _stream()), "mmdyn_poe_bwd")
+                                     _ptr(kl_weight_dev), _stream()), "mmdyn_poe_bwd")
 
     def reparam_fwd(self, mu, lv, eps_noise, z, kl_sum, B, L, ld):
         """mu/lv may be column views (row stride ld) of the fused heads output."""
@@ -341,10 +342,10 @@ class HipBackend:
         check(self.lib.mmdyn_mse(_ptr(r), _ptr(t), _ptr(dr), loss_sum.data_ptr(), n, float(grad_scale), _stream()),
               "mmdyn_mse")
 
-    def elbo_assemble(self, bce, mse, kl, loss, partials, P, B, kl_weight, pose_multiplier):
+    def elbo_assemble(self, bce, mse, kl, loss, partials, P, B, kl_weight, pose_multiplier, kl_weight_dev=None):
         check(self.lib.mmdyn_elbo_assemble(_ptr(bce, torch.float64), _ptr(mse, torch.float64),
                                            _ptr(kl, torch.float64), _ptr(loss), _ptr(partials), P, B,
-                                           float(kl_weight), float(pose_multiplier), _stream()),
+                                           float(kl_weight), float(pose_multiplier), _ptr(kl_weight_dev), _stream()),
               "mmdyn_elbo_assemble")
 
     def adam_step(self, p, g, m, v, state, lr, beta1, beta2, eps, grad_scale):

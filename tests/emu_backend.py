@@ -422,7 +422,9 @@ class EmuBackend:
             if kl_sum is not None:
                 kl_sum[i] += (-0.5 * (1 + plv - pm * pm - plv.exp()).double().sum())
 
-    def poe_bwd(self, passes, eps_noise, mu, logvar, dz, g_mu, g_lv, kl_scale, with_prior, P, B, L):
+    def poe_bwd(self, passes, eps_noise, mu, logvar, dz, g_mu, g_lv, kl_scale, with_prior, P, B, L, kl_weight_dev=None):
+        if kl_weight_dev is not None:
+            kl_scale = kl_scale * float(kl_weight_dev[0])
         with torch.enable_grad():
             self._poe_bwd(passes, eps_noise, mu, logvar, dz, g_mu, g_lv, kl_scale, with_prior, P, B, L)
 
@@ -498,7 +500,9 @@ class EmuBackend:
         if dr is not None:
             dr.reshape(-1)[:n] = 2 * d * grad_scale
 
-    def elbo_assemble(self, bce, mse, kl, loss, partials, P, B, kl_weight, pose_multiplier):
+    def elbo_assemble(self, bce, mse, kl, loss, partials, P, B, kl_weight, pose_multiplier, kl_weight_dev=None):
+        if kl_weight_dev is not None:
+            kl_weight = kl_weight * float(kl_weight_dev[0])
         tot = 0.0
         for p in range(P):
             v = ((float(bce[p]) if bce is not None else 0.0) + pose_multiplier * (float(mse[p]) if mse is not None else 0.0)

@@ -418,7 +418,7 @@ def test_bf16_precision_plumbing():
         assert 1e-8 < r < 5e-3, (prec, r)
         assert float((grads[prec] - grads["fp32"]).norm() / grads["fp32"].norm()) < 0.1
     with pytest.raises(ValueError):
-        MVAEStep(build("cnn-mvae", True, True, "cpu"), precision="fp16")
+        MVAEStep(build("cnn-mvae", True, True, "cpu"), precision="fp8")
 
 
 def check_mlp_vae(golden_dir, device):

@@ -330,3 +330,26 @@ def test_dyn_modeling_128(tmp_path):
     assert prob._step.last["recon_x"][0].shape == (12, 3, 128, 128)
     tr = prob._logger_dict["Loss/train_epoch"]
     assert all(np.isfinite(tr)) and len(tr) == 2
+
+
+def test_one_graph_capture_serves_the_kl_annealing_schedule():
+    """The annealed KL weight (problems.py:212-216) is read from device memory by the loss assembly and the latent
+    backward: replays with a new weight need no re-capture and equal the eager steps."""
+    B = 8
+    inputs, targets = seeded_batch(B, 5)
+    gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+    kls = [0.02, 0.02, 0.04, 0.5, 1.0]
+    runs, graphs = [], None
+    for graphed in (False, True):
+        m = T.build("cnn-mvae", True, True, DEV)
+        step = MVAEStep(m, noise=NoiseSource(11))
+        losses = []
+        for i, kl in enumerate(kls):
+            loss = step.train_step_graphed(gi, gt, kl) if graphed else step.train_step(gi, gt, kl)
+            losses.append(float(loss))
+            if graphed and i == 1:
+                graphs = step._graph[1]
+        if graphed:
+            assert step._graph[1] is graphs                  # captured once, at the first replayed step
+        runs.append(losses)
+    assert runs[0] == pytest.approx(runs[1], rel=1e-6)
