@@ -233,17 +233,37 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MMDYN_BENCH_DRYRUN=emu (tests only): rehearse the multi-rank control flow of this script -- rendezvous, sharding,
+    # barriers, max-over-ranks timing, the JSON line -- on CPU with gloo and the kernels replaced by the test suite's
+    # emulation.  The numbers are meaningless and the line says so; the product path below never takes this branch.
+    dry = os.environ.get("MMDYN_BENCH_DRYRUN") == "emu"
+    if dry:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu_backend import EmuBackend
+        from mmdyn_hip import ops as _ops
+        _ops.set_backend(EmuBackend())
+        torch.set_num_threads(2)
+        dev = torch.device("cpu")
+        args.no_graph, args.no_cpu_baseline = True, True
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
     pg = None
     if world > 1 or os.environ.get("MMDYN_BENCH_FORCE_PG") == "1":      # (the flag: 1-rank rehearsal of the RCCL path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: one process per GPU is launched by torch.distributed.run "
+              f"--nproc-per-node N; reporting n_gpus={world}", file=sys.stderr)
 
     from mmdyn_hip.engine import MVAEStep
     from mmdyn_hip.models import setup_model, NoiseSource
@@ -310,18 +330,18 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    torch.cuda.synchronize()
+    sync()
     if pg is not None:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
     host_enqueue = time.perf_counter() - t0      # host side done enqueueing; the GPU is still running if it is ahead
-    torch.cuda.synchronize()
+    sync()
     if pg is not None:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     elapsed = time.perf_counter() - t0
     if pg is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -332,7 +352,7 @@ def main():
     # per-kernel timing of one extra (untimed) step, HIP events on the launch stream
     # (one lane, eager launches: per-kernel durations are then not inflated by the other lane's kernels)
     lanes_on, step.lanes.on = step.lanes.on, False
-    kern = profile_step(eager_step)
+    kern = {} if dry else profile_step(eager_step)
     step.lanes.on = lanes_on
     if pg is not None:
         dist.barrier()
@@ -343,8 +363,8 @@ def main():
 
     global_batch = args.batch * world
     sps = global_batch * args.steps / elapsed
-    ig = kern.get("igemm_nt", {"ms": 0.0, "flops": 0.0, "calls": 0})
-    wg = kern.get("wgrad_tn", {"ms": 0.0, "flops": 0.0, "calls": 0})
+    ig = kern.get("igemm_nt", {"ms": 0.0, "flops": 0.0, "calls": 0, "bytes": 0.0})
+    wg = kern.get("wgrad_tn", {"ms": 0.0, "flops": 0.0, "calls": 0, "bytes": 0.0})
     dom = ig if ig["ms"] >= wg["ms"] else wg
     dom_name = "igemm_nt_kernel" if dom is ig else "wgrad_tn_kernel"
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
@@ -381,6 +401,8 @@ def main():
                      "step_algorithmic_tflops": sps / world * gflop_per_sample * 1e9 / 1e12,
                      "step_frac_of_peak": sps / world * gflop_per_sample * 1e9 / 1e12 / peak},
     }
+    if dry:
+        out["dry_run"] = "CPU rehearsal with emulated kernels (MMDYN_BENCH_DRYRUN=emu): control flow only, numbers meaningless"
     if args.breakdown:
         for k, d in sorted(kern.items(), key=lambda kv: -kv[1]["ms"]):
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 and d["flops"] else 0.0

@@ -202,14 +202,22 @@ class Problem:
         self._model.train()
         train_loss, n = 0.0, 0
         perf = defaultdict(float)
+        dev_loss = dev_acc = None        # fused path: loss and per-pass sums accumulate ON THE DEVICE, read once per epoch
+        dev_n = dev_rows = 0             # (the reference's loss.item() per step, problems.py:156, would stall the replay)
         for batch_idx, (data_input, data_target) in enumerate(self.train_loader):
             inputs, targets = self.parse_input(data_input, data_target)
             if self._step is not None and self._fused_applicable(inputs):
-                # on the GPU the step is replayed from HIP graphs (re-captured when the batch shape or the annealed
-                # KL weight changes, i.e. once per epoch); the emulation has no graphs
+                # on the GPU the step is replayed from HIP graphs (captured once per batch shape; the annealed KL weight
+                # is read from device memory); the emulation has no graphs
                 run = self._step.train_step_graphed if self._device.type == 'cuda' else self._step.train_step
                 loss = run(*self._fused_io(inputs, targets), self._kl_weight)
-                outputs = {'perf_measure': self._fused_perf()}
+                if dev_loss is None:
+                    dev_loss, dev_acc = torch.zeros_like(loss, dtype=torch.float64), torch.zeros_like(self._step.acc)
+                dev_loss += loss.detach().to(torch.float64)
+                dev_acc += self._step.acc
+                dev_n += 1
+                dev_rows += self._step.last['means'].shape[0]
+                continue
             else:
                 self._optimizer.zero_grad()
                 outputs, loss = self._evaluate_model(inputs, targets)
@@ -219,6 +227,11 @@ class Problem:
             n += 1
             for k, v in outputs.get('perf_measure', {}).items():
                 perf[k] += v
+        if dev_n:
+            train_loss += float(dev_loss.sum())
+            for k, v in self._fused_perf(dev_acc.cpu(), dev_rows / dev_n).items():
+                perf[k] += v          # (sums over the epoch's steps / rows per step = the sum of the per-step means)
+            n += dev_n
         self._logger_dict['Loss/train_epoch'].append(train_loss / max(n, 1))
         self._logger_dict['KL_annealing/train_epoch'].append(self._kl_weight)
         for k, v in perf.items():
@@ -277,11 +290,14 @@ class Problem:
             return x['model_input'] + x['input_object_pose'], targets['target_output'] + targets['target_object_pose']
         return x['model_input'], targets['target_output']
 
-    def _fused_perf(self):
+    def _fused_perf(self, acc=None, B=None):
+        """Mean BCE / MSE of the single-modality passes (problems.py:499-503, 534-535) from the engine's per-pass sums
+        (``acc``: those sums, or their total over several steps of ``B`` rows each)."""
         st = self._step
-        B = st.last['means'].shape[0]
-        acc = st.acc.cpu()
-        out = {'visual': float(acc[0, 1]) / (B * 12288), 'tactile': float(acc[0, 2]) / (B * 12288)}
+        B = st.last['means'].shape[0] if B is None else B
+        acc = st.acc.cpu() if acc is None else acc
+        npx = st.last['recon_x'][0][0].numel()              # 3 * S * S (12288 for the reference's 64 x 64)
+        out = {'visual': float(acc[0, 1]) / (B * npx), 'tactile': float(acc[0, 2]) / (B * npx)}
         if st.use_pose:
             out['pose'] = float(acc[1, 6]) / (B * 7)
         return out

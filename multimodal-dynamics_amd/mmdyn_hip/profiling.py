@@ -20,9 +20,11 @@ def _canon(name, a):
         name, a = "igemm_nt", (A, Bp, y, C, None, stats, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset, 0, 1)
     # the 3-channel layers run their own kernels (csrc/conv3.hip), not igemm_nt_kernel / wgrad_tn_kernel: booked apart so
     # that the launch counts and average durations of the MFMA families match what rocprofv3 reports per kernel name
-    if name == "igemm_nt" and a[7] == ops.IM2COL3 and tuple(a[10:17]) == (64, 64, 64, 32, 32, 32, 32):
+    if name == "igemm_nt" and a[7] == ops.IM2COL3 and a[10] in (64, 128, 256) and \
+            tuple(a[10:17]) == (a[10], a[10], 64, a[10] // 2, a[10] // 2, 32, 32):
         return "conv3_nt", a
-    if name == "wgrad_tn" and a[3] == ops.IM2COL3 and tuple(a[5:11]) == (32, 32, 32, 64, 64, 64):
+    if name == "wgrad_tn" and a[3] == ops.IM2COL3 and a[8] in (64, 128, 256) and \
+            tuple(a[5:11]) == (a[8] // 2, a[8] // 2, 32, a[8], a[8], 64):
         return "conv3_wgrad", a
     return name, a
 

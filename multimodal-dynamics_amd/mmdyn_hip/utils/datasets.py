@@ -284,22 +284,31 @@ class DeviceLoader:
     """Mini-batch iterator over a device-resident split: ``drop_last=True``, optional shuffling, and the two
     collation shapes of the reference's DataLoader (``seq_collate_fn`` -> [B*L, ...]; default -> [B, L, ...])."""
 
-    def __init__(self, dataset, batch_size, shuffle=False, fold=True, device=None, seed=None):
+    def __init__(self, dataset, batch_size, shuffle=False, fold=True, device=None, seed=None, rank=0, world_size=1):
+        """``seed``: shuffling seed; None draws it from torch's global generator, like the reference's DataLoader
+        (a default-constructed torch.Generator would give every run the same order).  ``rank`` / ``world_size``: data
+        parallel: every rank draws the SAME permutation (the seed is shared: pass one, or seed torch identically) and
+        takes its own contiguous share of each global mini-batch of ``batch_size * world_size`` samples."""
         self.dataset, self.batch_size, self.shuffle, self.fold = dataset, int(batch_size), shuffle, fold
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.rank, self.world_size = int(rank), int(world_size)
+        if not 0 <= self.rank < self.world_size:
+            raise ValueError("rank must be in [0, world_size)")
         self.generator = torch.Generator()
-        if seed is not None:
-            self.generator.manual_seed(seed)
+        self.generator.manual_seed(int(torch.initial_seed() if seed is None and world_size > 1 else
+                                       (torch.randint(0, 2 ** 31 - 1, (1,)).item() if seed is None else seed)))
         self.shock_dim = dataset.shock_dim
 
     def __len__(self):
-        return len(self.dataset) // self.batch_size
+        return len(self.dataset) // (self.batch_size * self.world_size)
 
     def __iter__(self):
         n = len(self.dataset)
         order = torch.randperm(n, generator=self.generator) if self.shuffle else torch.arange(n)
+        gb = self.batch_size * self.world_size
         for b in range(len(self)):
-            yield self.dataset.batch(order[b * self.batch_size:(b + 1) * self.batch_size], self.device, self.fold)
+            lo = b * gb + self.rank * self.batch_size
+            yield self.dataset.batch(order[lo:lo + self.batch_size], self.device, self.fold)
 
 
 def seq_collate_fn(batch):

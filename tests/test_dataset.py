@@ -104,3 +104,34 @@ def test_device_loader_batches(golden_dir, tmp_path, emu):
     # shuffling permutes whole sequences
     sh = D.DeviceLoader(ds, 2, shuffle=True, device="cpu", seed=3)
     assert len(list(sh)) == len(sh)
+
+
+def test_device_loader_seeding_and_rank_sharding(tmp_path):
+    """Shuffling follows a seed (None: drawn from torch's global generator, so runs differ like the reference's
+    DataLoader; a default-constructed torch.Generator would repeat one order for ever), and with world_size > 1 the ranks
+    take disjoint shares of the same permuted global mini-batches."""
+    class Toy:
+        shock_dim = 0
+
+        def __len__(self):
+            return 12
+
+        def batch(self, idx, device, fold):
+            return torch.as_tensor(idx).clone()
+
+    a = [b.tolist() for b in D.DeviceLoader(Toy(), 2, shuffle=True, device="cpu", seed=5)]
+    b = [b.tolist() for b in D.DeviceLoader(Toy(), 2, shuffle=True, device="cpu", seed=5)]
+    c = [b.tolist() for b in D.DeviceLoader(Toy(), 2, shuffle=True, device="cpu", seed=6)]
+    assert a == b and a != c and sorted(sum(a, [])) == list(range(12))
+    torch.manual_seed(123)
+    d = [b.tolist() for b in D.DeviceLoader(Toy(), 2, shuffle=True, device="cpu")]
+    e = [b.tolist() for b in D.DeviceLoader(Toy(), 2, shuffle=True, device="cpu")]
+    assert d != e                                            # unseeded loaders differ from one another
+    shards = [[b.tolist() for b in D.DeviceLoader(Toy(), 2, shuffle=True, device="cpu", seed=9, rank=r, world_size=3)]
+              for r in range(3)]
+    assert all(len(s) == 2 for s in shards)                  # 12 // (2 * 3) global mini-batches
+    seen = sum((sum(s, []) for s in shards), [])
+    assert len(set(seen)) == len(seen) == 12
+    whole = [b.tolist() for b in D.DeviceLoader(Toy(), 6, shuffle=True, device="cpu", seed=9)]
+    for step in range(2):                                    # the ranks' shares tile the single-process batch, in rank order
+        assert sum((shards[r][step] for r in range(3)), []) == whole[step]

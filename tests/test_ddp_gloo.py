@@ -118,3 +118,98 @@ def test_two_rank_sync_bn_equals_global_batch(tmp_path):
         err = (got - prm[k].detach()).abs()
         assert float((err > 1e-5).float().mean()) < 0.02, (k, float(err.max()))
         assert float(err.max()) <= 2.1e-3, k
+
+
+def _worker_uneven(rank, world, port, out_dir, sizes):
+    for p in (ROOT, os.path.join(ROOT, "multimodal-dynamics_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mmdyn_hip import ops
+    from mmdyn_hip.engine import MVAEStep
+    from mmdyn_hip.models import InjectedNoise, setup_model
+    from mmdyn_hip.utils.seeded_init import seeded_batch, seeded_noise, seeded_state_dict
+    from emu_backend import EmuBackend
+    import test_model_emu as T
+    ops.set_backend(EmuBackend())
+    lo, B = sum(sizes[:rank]), sizes[rank]
+    inputs, targets = seeded_batch(sum(sizes), 1234)
+    sl = slice(lo, lo + B)
+    eps, masks = seeded_noise(B, 256, 7, 8, 100 + rank)
+    # every rank seeds its replica DIFFERENTLY: the engine must start all of them from rank 0's weights and buffers
+    m = setup_model("cnn-mvae", cross_modal=True, use_pose=True, **T.MODEL_KW)
+    m.load_state_dict(seeded_state_dict(m.state_dict(), rank))
+    m.train()
+    step = MVAEStep(m, noise=InjectedNoise(eps, masks), process_group=dist.group.WORLD, world_size=world)
+    start = step.params.flat.clone()
+    loss = step.train_step([x[sl] for x in inputs], [x[sl] for x in targets], 0.02)
+    torch.save({"flat": step.params.flat.clone(), "start": start, "offsets": step.params.offsets, "loss": float(loss)},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_four_ranks_uneven_shards_and_unequal_seeds(tmp_path):
+    """world_size 4 with a global batch of 7 that does not divide evenly (shards of 2, 2, 2, 1 samples) and replicas
+    seeded differently per rank: after construction every rank holds rank 0's parameters; after one step all ranks hold
+    the same parameters, equal to 'mean over ranks of the per-shard gradients, one Adam step' (DistributedDataParallel
+    semantics: each rank's loss is the mean over ITS samples, local BatchNorm)."""
+    world, sizes = 4, (2, 2, 2, 1)
+    mp.start_processes(_worker_uneven, args=(world, _free_port(), str(tmp_path), sizes), nprocs=world, join=True,
+                       start_method="spawn")
+    rs = [torch.load(tmp_path / f"rank{r}.pt", weights_only=False) for r in range(world)]
+    for r in rs[1:]:
+        torch.testing.assert_close(r["start"], rs[0]["start"], rtol=0, atol=0)
+        torch.testing.assert_close(r["flat"], rs[0]["flat"], rtol=0, atol=0)
+
+    from oracle import mvae_oracle as O
+    from mmdyn_hip.models.shapes import state_dict_shapes
+    from mmdyn_hip.utils.seeded_init import seeded_state_dict, seeded_batch, seeded_noise
+    sd = seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True), 0)          # rank 0's seed
+    inputs, targets = seeded_batch(sum(sizes), 1234)
+    grads = []
+    for rank in range(world):
+        prm, buf = O.split_state(sd)
+        lo, B = sum(sizes[:rank]), sizes[rank]
+        sl = slice(lo, lo + B)
+        eps, masks = seeded_noise(B, 256, 7, 8, 100 + rank)
+        _, loss, _ = O.evaluate_mvae(prm, [x[sl] for x in inputs], [x[sl] for x in targets], eps, masks, 0.02, 1000.0, True, buf)
+        loss.backward()
+        assert rs[rank]["loss"] == pytest.approx(float(loss.detach()), rel=1e-4)
+        grads.append({k: v.grad for k, v in prm.items()})
+    prm, _ = O.split_state(sd)
+    names = list(prm)
+    for k in names:
+        prm[k].grad = sum(g[k] for g in grads) / world
+    O.Adam([prm[k] for k in names], lr=1e-3).step()
+    for k in names:
+        o = rs[0]["offsets"][k]
+        got = rs[0]["flat"][o:o + prm[k].numel()].view_as(prm[k])
+        err = (got - prm[k].detach()).abs()
+        assert float((err > 1e-5).float().mean()) < 0.02, (k, float(err.max()))
+        assert float(err.max()) <= 2.1e-3, k
+
+
+@pytest.mark.timeout(900)
+def test_bench_multi_rank_dry_run(tmp_path):
+    """bench.py under torch.distributed.run with 2 ranks, rehearsed on CPU (gloo, emulated kernels): the rendezvous,
+    barriers, max-over-ranks timing and the ONE JSON line on rank 0 -- n_gpus, global_batch, parallelism, scaling --
+    are exercised before a multi-GPU node ever runs it."""
+    import json
+    import subprocess
+    env = dict(os.environ, MMDYN_BENCH_DRYRUN="emu", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["scaling"] == "weak" and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "samples/s"
+    assert d["value"] == pytest.approx(4 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-6)
+    assert "dry_run" in d and "cpu_baseline" not in d
