@@ -172,12 +172,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   // Branch-free operand fetch: an out-of-image (or out-of-range) row reads a valid dummy address and is zeroed by
   // a select, so one K-step is a single basic block and the scheduler can slot the address arithmetic and the
   // global loads between the 64-cycle MFMAs instead of in front of them.
-  f32x4 ra[A_LOADS], rbv[B_LOADS];
+  // (two register sets: the M16 variant fetches TWO K-steps ahead -- see PF2 at the K loop; the others use set 0 only)
+  f32x4 raS[2][A_LOADS], rbvS[2][B_LOADS];
+  unsigned okS[2] = {0u, 0u};
   uint2 ra16[A_LOADS];          // A16: the raw bf16 granule (widening it here would wait for the load before the MFMAs)
   uint2 rbv16[B_LOADS];         // B16: likewise for bf16 packed weights
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // (native vector: arrays of HIP's uint4 struct spill to scratch)
   u32x4 raw[A_LOADS], rbw[B_LOADS];   // WIDE: eight bf16 per granule
-  unsigned okmask = 0;
   // bf16 matrix-core variants keep the tiles in LDS as bf16 ([row][40] halves: 32 + one 16-byte pad slot): half the
   // LDS bytes, one ds_read_b128 per operand and 16-deep MFMA, conversion once per element on the store side
   constexpr int LDH = KB + 8;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   bf16_t* Bs16 = As16 + BM * LDH;
   int tap = s_begin / cin_steps;            // running (tap, channel-step) position of the NEXT fetch
   int cstep = s_begin - tap * cin_steps;
-  auto gload = [&]() {
+  auto gload = [&](f32x4 (&ra)[A_LOADS], f32x4 (&rbv)[B_LOADS], unsigned& okmask) {
     const int c0 = cstep * KB + gran * (WIDE ? 8 : 4);
     int dh = 0, dw = 0, wi = 0;
     if (MODE == MMDYN_CONV) {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
     cstep = last ? cstep : ncstep;
     tap = last ? tap : ntap;
   };
-  auto lds_store = [&]() {
+  auto lds_store = [&](const f32x4 (&ra)[A_LOADS], const f32x4 (&rbv)[B_LOADS], const unsigned okmask) {
     if constexpr (WIDE) {
       const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -331,75 +332,104 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   // 32x32x2: lane (row l&31, half l>>5) reads k = 8q + 4h .. +3;  16x16x4: lane (row l&15, quarter l>>4) reads
   // k = 16q + 4*(l>>4) .. +3 (MFMA j multiplies the j-th element of the four lanes' granules)
   const int frag_off = M16 ? (lane & 15) * LDS_LD + (lane >> 4) * 4 : (lane & 31) * LDS_LD + (lane >> 5) * 4;
-  if (s_begin < s_end) {
-    gload();
-    lds_store();
-    __syncthreads();
-    for (int s = s_begin; s < s_end; ++s) {
-      gload();
-      __builtin_amdgcn_sched_barrier(0);   // keep the fetch of step s+1 in front of the MFMAs of step s
+  // PF2: global loads issued TWO K-steps ahead of their use (two register sets).  In the stand-alone dense GEMM of
+  // tests/microbench/lds_mfma_shape.hip the second step of lead is worth 3-5 % (removing the loads from the loop
+  // altogether, a timing diagnostic, +20 %; removing the barriers nothing: the single-stage kernel is exposed to the
+  // fetch, not to its barriers).  HERE it loses: with the gather arithmetic of two fetches live the compiler needs 92
+  // VGPRs + 40 AGPRs (3 waves per SIMD instead of 6) and the launches run 8-10 % SLOWER (step 7.26 vs 6.98 ms,
+  // profiles/r2/igemm_mfma_shape_sweep.txt); capping the registers spills.  Kept switched off.
+  constexpr bool PF2 = false;
+  auto mfma_step = [&]() {
       const float* Ac = As;
-      const float* Bc = Bs;
-      if constexpr (BF16) {
-        const int frag16 = (lane & 31) * LDH + (lane >> 5) * 8;      // lane (row i, half h): k = 16m + 8h .. +7
+    const float* Bc = Bs;
+    if constexpr (BF16) {
+      const int frag16 = (lane & 31) * LDH + (lane >> 5) * 8;      // lane (row i, half h): k = 16m + 8h .. +7
 #pragma unroll
-        for (int m = 0; m < KB / 16; ++m) {
-          bf16x8 pa[MT], pb[NT];
+      for (int m = 0; m < KB / 16; ++m) {
+        bf16x8 pa[MT], pb[NT];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            pa[mt] = *reinterpret_cast<const bf16x8*>(&As16[(wm * WM + mt * 32) * LDH + frag16 + m * 16]);
+        for (int mt = 0; mt < MT; ++mt)
+          pa[mt] = *reinterpret_cast<const bf16x8*>(&As16[(wm * WM + mt * 32) * LDH + frag16 + m * 16]);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            pb[nt] = *reinterpret_cast<const bf16x8*>(&Bs16[(wn * WN + nt * 32) * LDH + frag16 + m * 16]);
+        for (int nt = 0; nt < NT; ++nt)
+          pb[nt] = *reinterpret_cast<const bf16x8*>(&Bs16[(wn * WN + nt * 32) * LDH + frag16 + m * 16]);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              if constexpr (F16)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pa[mt]),
-                                                                     __builtin_bit_cast(f16x8, pb[nt]), acc[mt][nt], 0, 0, 0);
-              else
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mt], pb[nt], acc[mt][nt], 0, 0, 0);
-        }
-      } else if constexpr (M16) {
-#pragma unroll
-        for (int q = 0; q < BK / 16; ++q) {
-          f32x4 af[MT], bf[NT];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            af[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * WM + mt * 16) * LDS_LD + frag_off + q * 16]);
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            bf[nt] = *reinterpret_cast<const f32x4*>(&Bc[(wn * WN + nt * 16) * LDS_LD + frag_off + q * 16]);
+            if constexpr (F16)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pa[mt]),
+                                                                   __builtin_bit_cast(f16x8, pb[nt]), acc[mt][nt], 0, 0, 0);
+            else
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mt], pb[nt], acc[mt][nt], 0, 0, 0);
+      }
+    } else if constexpr (M16) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
-        }
-      } else
-#pragma unroll
-      for (int q = 0; q < BK / 8; ++q) {
+      for (int q = 0; q < BK / 16; ++q) {
         f32x4 af[MT], bf[NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          af[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * WM + mt * 32) * LDS_LD + frag_off + q * 8]);
+          af[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * WM + mt * 16) * LDS_LD + frag_off + q * 16]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          bf[nt] = *reinterpret_cast<const f32x4*>(&Bc[(wn * WN + nt * 32) * LDS_LD + frag_off + q * 8]);
+          bf[nt] = *reinterpret_cast<const f32x4*>(&Bc[(wn * WN + nt * 16) * LDS_LD + frag_off + q * 16]);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
       }
-      __syncthreads();
-      lds_store();
-      __syncthreads();
+    } else
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      f32x4 af[MT], bf[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        af[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * WM + mt * 32) * LDS_LD + frag_off + q * 8]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        bf[nt] = *reinterpret_cast<const f32x4*>(&Bc[(wn * WN + nt * 32) * LDS_LD + frag_off + q * 8]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+    }
+  };
+  if (s_begin < s_end) {
+    gload(raS[0], rbvS[0], okS[0]);
+    lds_store(raS[0], rbvS[0], okS[0]);
+    if constexpr (PF2) gload(raS[1], rbvS[1], okS[1]);
+    __syncthreads();
+    if constexpr (PF2) {
+      for (int s = s_begin; s < s_end; s += 2) {
+        gload(raS[0], rbvS[0], okS[0]);        // step s+2 (set 1 holds step s+1, still in flight)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step();
+        __syncthreads();
+        lds_store(raS[1], rbvS[1], okS[1]);
+        __syncthreads();
+        if (s + 1 >= s_end) break;
+        gload(raS[1], rbvS[1], okS[1]);        // step s+3
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step();
+        __syncthreads();
+        lds_store(raS[0], rbvS[0], okS[0]);
+        __syncthreads();
+      }
+    } else {
+      for (int s = s_begin; s < s_end; ++s) {
+        gload(raS[0], rbvS[0], okS[0]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the fetch of step s+1 in front of the MFMAs of step s
+        mfma_step();
+        __syncthreads();
+        lds_store(raS[0], rbvS[0], okS[0]);
+        __syncthreads();
+      }
     }
   }
 
@@ -578,11 +608,13 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   // (profiles/r2/igemm_mfma_shape_sweep.txt): large launches (>= 2048 blocks, >= 8 K-steps) of every block tile but
   // 128x128: +3..6 % there, -2..4 % on the small encoder-side launches, which keep the 32x32x2 shape.
   // MMDYN_IGEMM_M32=1 / MMDYN_IGEMM_M16=1 force one shape everywhere (kernel experiments)
-  constexpr bool M16_TILE = !(BM == 128 && BN == 128);
+  constexpr bool M16_TILE = true;
+  const bool big_tile_m16 = !(BM == 128 && BN == 128) || getenv("MMDYN_IGEMM_M16_128") != nullptr;
   const bool force_m32 = getenv("MMDYN_IGEMM_M32") != nullptr, force_m16 = getenv("MMDYN_IGEMM_M16") != nullptr;
   const long nblocks = (long)g.G * g.tiles_per_group * (g.N / BN) * g.nclasses * g.splitk;
   const int ksteps = (MODE == MMDYN_TCONV_S1P0 ? 6 : g.ntaps) * (g.Cin / BK) / g.splitk;
-  const bool m16 = !bf16 && M16_TILE && !force_m32 && (force_m16 || (nblocks >= 2048 && ksteps >= 8));
+  const bool m16 = !bf16 && M16_TILE && !force_m32 && (force_m16 || (big_tile_m16 && nblocks >= 2048 && ksteps >= 8) ||
+                                                       (BM == 128 && BN == 128 && getenv("MMDYN_IGEMM_M16_128") != nullptr));
   size_t smem = (size_t)(BM + BN) * (m16 ? BK + 8 : LDS_LD32) * sizeof(float) + (size_t)BM * 4 * sizeof(int);
 #define IGEMM_LAUNCH(BF, A16_, B16_)                                                                                     \
   hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, BF, A16_, B16_>), grid, dim3(256), smem, st, A, Bp, bias, C, \

@@ -15,7 +15,9 @@ constexpr int BK = 32, GRANS = 8, RPP = 32;   // 16-byte granules per tile row, 
 
 // SHAPE 32: wave tile (WM x WN) of 32x32 MFMA tiles, LDS row stride 36 floats (conflict-free ds_read_b128 for that map)
 // SHAPE 16: the same wave tile as 16x16 MFMA tiles, LDS row stride 40 floats
-template <int SHAPE, int BM, int BN, int WM, int WN>
+// DIAG (timing diagnostics, results are wrong for DIAG != 0): 1 = no block barriers in the K loop, 2 = no global loads /
+// LDS stores in the K loop (the MFMAs re-read the first tile), 3 = both
+template <int SHAPE, int BM, int BN, int WM, int WN, int DIAG = 0>
 __global__ __launch_bounds__(256) void lds_gemm(const float* __restrict__ A, const float* __restrict__ B,
                                                 float* __restrict__ C, int M, int N, int K) {
   constexpr int LD = SHAPE == 32 ? 36 : 40;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void lds_gemm(const float* __restrict__ A, con
     lds_store();
     __syncthreads();
     for (int k = 0; k < K; k += BK) {
-      gload(k + BK < K ? k + BK : 0);
+      if (!(DIAG & 2) || (DIAG & 4)) gload(k + BK < K ? k + BK : 0);       // DIAG 6: loads issued, data never stored
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -131,6 +133,88 @@ __global__ __launch_bounds__(256) void lds_gemm(const float* __restrict__ A, con
         for (int nt = 0; nt < NT; ++nt) C[(size_t)row * N + tn * BN + wn * WN + nt * 16 + r] = acc[mt][nt][e];
       }
   }
+}
+
+// 16x16x4 variant with the global loads issued PF K-steps ahead (PF register sets, rotated by full unrolling): is the
+// single-stage kernel exposed to memory latency?  (diag2 above says the loads cost ~20 % and the barriers nothing)
+template <int BM, int BN, int WM, int WN, int PF>
+__global__ __launch_bounds__(256) void lds_gemm_pf(const float* __restrict__ A, const float* __restrict__ B,
+                                                   float* __restrict__ C, int M, int N, int K) {
+  constexpr int LD = 40;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int A_LOADS = BM / RPP, B_LOADS = BN / RPP;
+  constexpr int MT = WM / 16, NT = WN / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);
+  float* Bs = As + BM * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int ntn = N / BN;
+  // XCD-aware: blocks that share A rows (the N tiles of one M tile) get ids equal modulo 8
+  const int L = blockIdx.x, m_lo = L & 7, r8 = L >> 3;
+  const int tn = r8 % ntn, tm = (r8 / ntn) * 8 + m_lo;
+  const int lrow = tid / GRANS, gran = tid % GRANS;
+  f32x4 ra[PF][A_LOADS], rb[PF][B_LOADS];
+  const float* ap = A + (size_t)(tm * BM + lrow) * K + gran * 4;
+  const float* bp = B + (size_t)(tn * BN + lrow) * K + gran * 4;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frag = (lane & 15) * LD + (lane >> 4) * 4;
+#define GLOAD(S, k0)                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                                   \
+      ra[S][i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(RPP * i) * K + ((k0) < K ? (k0) : 0));   \
+  _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j)                                                   \
+      rb[S][j] = *reinterpret_cast<const f32x4*>(bp + (size_t)(RPP * j) * K + ((k0) < K ? (k0) : 0));
+#define LSTORE(S)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                                   \
+      *reinterpret_cast<f32x4*>(&As[(lrow + RPP * i) * LD + gran * 4]) = ra[S][i];                      \
+  _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j)                                                   \
+      *reinterpret_cast<f32x4*>(&Bs[(lrow + RPP * j) * LD + gran * 4]) = rb[S][j];
+  // prologue: tile 0 into LDS, tiles 1..PF-1 in flight in sets 1..PF-1 (set 0 is free again)
+  GLOAD(0, 0);
+  LSTORE(0);
+#pragma unroll
+  for (int s = 1; s < PF; ++s) { GLOAD(s, s * BK); }
+  __syncthreads();
+  for (int k = 0; k < K; k += PF * BK) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {            // K-step k + u*BK is in LDS; set u is free: fetch step k + (u + PF)*BK into it
+      GLOAD(u, k + (u + PF) * BK);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        f32x4 af[MT], bf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(&As[(wm * WM + mt * 16) * LD + frag + q * 16]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const f32x4*>(&Bs[(wn * WN + nt * 16) * LD + frag + q * 16]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+      }
+      __syncthreads();
+      LSTORE((u + 1) % PF);                   // step k + (u+1)*BK, fetched PF-1 iterations ago
+      __syncthreads();
+    }
+  }
+#undef GLOAD
+#undef LSTORE
+  const int g = lane >> 4, r = lane & 15;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = tm * BM + wm * WM + mt * 16 + g * 4 + e;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) C[(size_t)row * N + tn * BN + wn * WN + nt * 16 + r] = acc[mt][nt][e];
+    }
 }
 
 struct Shape { int M, N, K; };
@@ -188,8 +272,31 @@ int main() {
     report("mfma" #SH " " #BM "x" #BN, time_ms([&] {                                                                  \
       hipLaunchKernelGGL((lds_gemm<SH, BM, BN, WM, WN>), dim3((s.M / BM) * (s.N / BN)), dim3(256), smem, 0, A, B, C, s.M, s.N, s.K); }, 20)); \
   }
+#define RUNPF(BM, BN, WM, WN, PF_)                                                                                    \
+  if (s.M % (BM * 8) == 0 && s.N % BN == 0 && s.K % (PF_ * 32) == 0) {                                               \
+    const size_t smem = (size_t)(BM + BN) * 40 * 4;                                                                   \
+    report("mfma16 " #BM "x" #BN " xcd pf" #PF_, time_ms([&] {                                                        \
+      hipLaunchKernelGGL((lds_gemm_pf<BM, BN, WM, WN, PF_>), dim3((s.M / BM) * (s.N / BN)), dim3(256), smem, 0, A, B, C, s.M, s.N, s.K); }, 20)); \
+  }
+#define RUND(SH, BM, BN, WM, WN, DG)                                                                                  \
+  if (s.M % BM == 0 && s.N % BN == 0) {                                                                               \
+    const size_t smem = (size_t)(BM + BN) * (SH == 32 ? 36 : 40) * 4;                                                 \
+    report("mfma" #SH " " #BM "x" #BN " diag" #DG, time_ms([&] {                                                      \
+      hipLaunchKernelGGL((lds_gemm<SH, BM, BN, WM, WN, DG>), dim3((s.M / BM) * (s.N / BN)), dim3(256), smem, 0, A, B, C, s.M, s.N, s.K); }, 20)); \
+  }
       RUN(32, 64, 64, 32, 32)
       RUN(16, 64, 64, 32, 32)
+      RUND(16, 64, 64, 32, 32, 1)
+      RUND(16, 64, 64, 32, 32, 2)
+      RUND(16, 64, 64, 32, 32, 3)
+      RUND(16, 64, 64, 32, 32, 6)
+      RUND(16, 64, 64, 32, 32, 10)
+      RUNPF(64, 64, 32, 32, 1)
+      RUNPF(64, 64, 32, 32, 2)
+      RUNPF(64, 64, 32, 32, 3)
+      RUNPF(64, 64, 32, 32, 4)
+      RUNPF(128, 64, 64, 32, 2)
+      RUNPF(128, 128, 64, 64, 2)
       RUN(32, 128, 128, 64, 64)
       RUN(16, 128, 128, 64, 64)
       RUN(32, 128, 64, 64, 32)
