@@ -74,21 +74,154 @@ __global__ void repack2d_ld_kernel(const float* __restrict__ in, TO* __restrict_
   }
 }
 
+// ---- LDS-tiled forms of the transposing / permuting packs ---------------------------------------------------------
+// Every pack is a permutation (plus zero padding).  Done element-wise with coalesced WRITES, the reads of the transposing
+// kinds are strided: each 4-byte read touches its own 64-byte sector and the step's packs fetched 883 MB to write 107 MB
+// (profiles/r1/hbm_traffic_by_kernel_v5.json).  Here a block moves a tile whose footprint is contiguous runs on BOTH
+// sides: coalesced 16-byte / 4-byte loads of whole runs into LDS, then coalesced stores that gather from LDS (odd LDS row
+// strides: conflict-free).  Tiles are walked grid-stride, one plan entry per blockIdx.y as before.
+constexpr int PACK_LDS_FLOATS = 6912;           // 27 KB (5 blocks per CU): the largest tiles below are 32 x 201 and 400 x 17 floats
+
+// conv weight: Wc[d0][d1][16] -> P[tap][x][y], (x, y) = (a, b) or swapped: tile = TA values of a x TB values of b x 16 taps
 template <typename TO>
-__device__ __forceinline__ void pack_plan_entry(const mmdyn_pack_entry& e) {
+__device__ __forceinline__ void pack_conv_tiled(const float* __restrict__ src, TO* __restrict__ dst, int d0, int d1, int swap,
+                                                float* lds) {
+  // runs on the destination are along y: b for the keep form, a for the swapped one
+  const int TB = swap ? 8 : (d1 < 64 ? d1 : 64), TA = 256 / TB > d0 ? d0 : 256 / TB;
+  const int tiles_b = (d1 + TB - 1) / TB, tiles_a = (d0 + TA - 1) / TA;
+  const int LDT = 17;                                                // [pair][tap], padded
+  for (int t = blockIdx.x; t < tiles_a * tiles_b; t += gridDim.x) {
+    const int a0 = (t / tiles_b) * TA, b0 = (t % tiles_b) * TB;
+    __syncthreads();
+    // source: for each a, the run [b0, b0+TB) x 16 taps is contiguous
+#pragma unroll 4
+    for (int i = threadIdx.x; i < TA * TB * 4; i += blockDim.x) {
+      const int q = i & 3, pr = i >> 2, ia = pr / TB, ib = pr - ia * TB;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (a0 + ia < d0 && b0 + ib < d1) v = *reinterpret_cast<const f32x4*>(src + ((size_t)(a0 + ia) * d1 + b0 + ib) * 16 + q * 4);
+      float* l = lds + (ia * TB + ib) * LDT + q * 4;
+      l[0] = v[0]; l[1] = v[1]; l[2] = v[2]; l[3] = v[3];
+    }
+    __syncthreads();
+    const int nx = swap ? d1 : d0, ny = swap ? d0 : d1;
+    const int TY = swap ? TA : TB, TX = swap ? TB : TA;              // tile extent along y (fast) and x
+#pragma unroll 4
+    for (int i = threadIdx.x; i < 16 * TX * TY; i += blockDim.x) {
+      const int iy = i % TY, r = i / TY, ix = r % TX, tap = r / TX;
+      const int ia = swap ? iy : ix, ib = swap ? ix : iy;
+      const int x = (swap ? b0 : a0) + ix, y = (swap ? a0 : b0) + iy;
+      if (x < nx && y < ny) st1<TO>(dst + ((size_t)tap * nx + x) * ny + y, lds[(ia * TB + ib) * LDT + tap]);
+    }
+  }
+}
+
+// kind 2: out[r][hw*256+ch] = in[r][ch*25+hw] (a permutation inside every 6400-float row): one row per tile
+template <typename TO>
+__device__ __forceinline__ void pack_rowperm_tiled(const mmdyn_pack_entry& e, float* lds) {
+  const float* __restrict__ src = e.src;
+  TO* __restrict__ dst = reinterpret_cast<TO*>(e.dst);
+  const int W = e.cols_in;                                            // 6400
+  for (int r = blockIdx.x; r < e.rows_out; r += gridDim.x) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < W / 4; i += blockDim.x)
+      reinterpret_cast<f32x4*>(lds)[i] = r < e.rows_in ? reinterpret_cast<const f32x4*>(src + (size_t)r * W)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll 5
+    for (int c = threadIdx.x; c < e.cols_out; c += blockDim.x) {
+      const int hw = c >> 8, ch = c & 255;
+      const int ci = ch * 25 + hw;
+      st1<TO>(dst + (size_t)r * e.ld_out + c, ci < W ? lds[ci] : 0.f);
+    }
+  }
+}
+
+// kinds 1, 4, 5: out[r][c] = in[ci][ri] with (ri, ci) a function of (r, c): transposes, with the 25 x 256 flatten
+// permutation on the output rows (4) or columns (5).  Tile = RT input rows x CT contiguous input columns.
+//   kind 1: out[r][c] = in[c][r]
+//   kind 4: out[hw*256+ch][c] = in[c][ch*25+hw]        input rows c, input columns ch*25+hw
+//   kind 5: out[r][hw*256+ch] = in[ch*25+hw][r]        input rows ch*25+hw, input columns r
+template <typename TO>
+__device__ __forceinline__ void pack_transpose_tiled(const mmdyn_pack_entry& e, float* lds) {
+  const float* __restrict__ src = e.src;
+  TO* __restrict__ dst = reinterpret_cast<TO*>(e.dst);
+  const int kind = e.kind, RI = e.rows_in, CI = e.cols_in;
+  // input tile: RT rows x CT columns (CT contiguous floats per row on the source side)
+  const int RT = kind == 5 ? 400 : (kind == 4 ? 32 : 64), CT = kind == 4 ? 200 : (kind == 5 ? 16 : 64);
+  const int LDT = CT + 1;
+  const int tiles_r = (RI + RT - 1) / RT, tiles_c = (CI + CT - 1) / CT;
+  for (int t = blockIdx.x; t < tiles_r * tiles_c; t += gridDim.x) {
+    const int r0 = (t / tiles_c) * RT, c0 = (t % tiles_c) * CT;
+    __syncthreads();
+    if ((CI & 3) == 0) {                        // 16-byte loads (CT and c0 are multiples of 4): several in flight per thread
+      const int CV = CT >> 2;
+#pragma unroll 4
+      for (int i = threadIdx.x; i < RT * CV; i += blockDim.x) {
+        const int ir = i / CV, iv = i - ir * CV;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + ir < RI && c0 + iv * 4 < CI) v = *reinterpret_cast<const f32x4*>(src + (size_t)(r0 + ir) * CI + c0 + iv * 4);
+        float* l = lds + ir * LDT + iv * 4;
+        l[0] = v[0]; l[1] = v[1]; l[2] = v[2]; l[3] = v[3];
+      }
+    } else {
+      for (int i = threadIdx.x; i < RT * CT; i += blockDim.x) {
+        const int ir = i / CT, ic = i - ir * CT;
+        lds[ir * LDT + ic] = (r0 + ir < RI && c0 + ic < CI) ? src[(size_t)(r0 + ir) * CI + c0 + ic] : 0.f;
+      }
+    }
+    __syncthreads();
+    // destination: runs along the input-ROW index (that is what a transpose makes contiguous)
+#pragma unroll 4
+    for (int i = threadIdx.x; i < RT * CT; i += blockDim.x) {
+      int ir, ic;
+      if (kind == 5) {                          // input row = ch*25+hw: make ch (stride 25 rows) the fast index
+        const int ch = i % 16, rest = i / 16, hw = rest % 25;
+        ic = rest / 25;
+        ir = ch * 25 + hw;                      // 16 channels x 25 positions = the tile's 400 rows
+      } else {
+        ir = i % RT;
+        ic = i / RT;
+      }
+      const int ri = r0 + ir, ci = c0 + ic;     // input coordinates
+      if (ri >= RI || ci >= CI) continue;
+      int ro, co;
+      if (kind == 1) {
+        ro = ci;
+        co = ri;
+      } else if (kind == 4) {
+        const int ch = ci / 25, hw = ci - ch * 25;
+        ro = hw * 256 + ch;
+        co = ri;
+      } else {
+        const int ch = ri / 25, hw = ri - ch * 25;
+        ro = ci;
+        co = hw * 256 + ch;
+      }
+      if (ro < e.rows_out && co < e.cols_out) st1<TO>(dst + (size_t)ro * e.ld_out + co, lds[ir * LDT + ic]);
+    }
+  }
+}
+
+template <typename TO>
+__device__ __forceinline__ void pack_plan_entry(const mmdyn_pack_entry& e, float* lds) {
   const float* __restrict__ src = e.src;
   TO* __restrict__ dst = reinterpret_cast<TO*>(e.dst);
   if (e.kind >= 100) {                       // conv weight: Wc[d0][d1][16] -> P[tap][x][y]
-    const int swap = e.kind - 100, d0 = e.rows_in, d1 = e.cols_in;
-    const int nx = swap ? d1 : d0, ny = swap ? d0 : d1;
-    const int64_t total = (int64_t)16 * d0 * d1;
+    pack_conv_tiled<TO>(src, dst, e.rows_in, e.cols_in, e.kind - 100, lds);
+  } else if (e.kind == 2 && e.cols_in == 6400 && e.cols_out == 6400 && e.cols_in % 4 == 0) {
+    pack_rowperm_tiled<TO>(e, lds);
+  } else if (e.kind == 1 || ((e.kind == 4 || e.kind == 5) && (e.kind == 4 ? e.cols_in : e.rows_in) == 6400)) {
+    // (zero padding beyond the transposed source is written by the element-wise pass: only when the shapes differ)
+    const bool padded = e.kind == 1 ? (e.rows_out != e.cols_in || e.cols_out != e.rows_in)
+                                    : (e.kind == 4 ? (e.rows_out != 6400 || e.cols_out != e.rows_in)
+                                                   : (e.cols_out != 6400 || e.rows_out != e.cols_in));
+    if (!padded) {
+      pack_transpose_tiled<TO>(e, lds);
+      return;
+    }
+    const int64_t total = (int64_t)e.rows_out * e.cols_out;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-      int y = (int)(i % ny);
-      int64_t t = i / ny;
-      int x = (int)(t % nx);
-      int tap = (int)(t / nx);
-      int a = swap ? y : x, b = swap ? x : y;
-      st1<TO>(dst + i, src[((int64_t)a * d1 + b) * 16 + tap]);
+      int c = (int)(i % e.cols_out), r = (int)(i / e.cols_out);
+      st1<TO>(dst + (int64_t)r * e.ld_out + c, repack_fetch(src, e.rows_in, e.cols_in, r, c, e.kind));
     }
   } else {                                   // 2-D repack with output leading dimension
     const int64_t total = (int64_t)e.rows_out * e.cols_out;
@@ -99,12 +232,13 @@ __device__ __forceinline__ void pack_plan_entry(const mmdyn_pack_entry& e) {
   }
 }
 
-__global__ void pack_plan_kernel(const mmdyn_pack_entry* __restrict__ plan) {
+__global__ __launch_bounds__(256) void pack_plan_kernel(const mmdyn_pack_entry* __restrict__ plan) {
+  __shared__ __attribute__((aligned(16))) float lds[PACK_LDS_FLOATS];
   const mmdyn_pack_entry e = plan[blockIdx.y];
   if (e.dst_bf16)
-    pack_plan_entry<bf16_t>(e);
+    pack_plan_entry<bf16_t>(e, lds);
   else
-    pack_plan_entry<float>(e);
+    pack_plan_entry<float>(e, lds);
 }
 
 // one thread per (output pixel, ci*4+kh): writes one float4 = the 4 kw taps; 16 threads cover a 64-float row
@@ -260,7 +394,7 @@ extern "C" int mmdyn_repack2d_ld_b16(const float* in, void* out, int rows_in, in
 extern "C" int mmdyn_pack_plan(const mmdyn_pack_entry* plan_dev, int n, void* stream) {
   if (!plan_dev) return MMDYN_ERR_NULL;
   if (n <= 0 || n > 65535) return MMDYN_ERR_SHAPE;
-  hipLaunchKernelGGL(pack_plan_kernel, dim3(512, n), dim3(256), 0, (hipStream_t)stream, plan_dev);
+  hipLaunchKernelGGL(pack_plan_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, plan_dev);
   MMDYN_LAUNCH_CHECK();
 }
 

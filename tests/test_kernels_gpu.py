@@ -651,3 +651,33 @@ def test_sgd_matches_torch():
         ref.grad = g * (step + 1)
         opt.step()
     torch.testing.assert_close(p.cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("size,cond,w_dtype", [(64, 0, torch.float32), (128, 0, torch.float32), (64, 3, torch.float32),
+                                               (64, 0, torch.bfloat16)])
+def test_pack_plan_equals_per_entry_packs(size, cond, w_dtype):
+    """mmdyn_pack_plan (one launch, LDS-tiled transposes / permutations) against the element-wise pack kernels entry by
+    entry: every packed operand of an encoder, its heads and a decoder, bit for bit (a pack is a permutation + padding)."""
+    from mmdyn_hip import layers
+    from mmdyn_hip.models.shapes import image_encoder_shapes, image_decoder_shapes
+    P = {}
+    for k, shp in list(image_encoder_shapes("e", 256, cond, size).items()) + list(image_decoder_shapes("d", 256, cond, size).items()):
+        if "running" in k or "num_batches" in k:
+            continue
+        P[k] = rnd(*shp, seed=len(P) + 7).to(DEV)
+    enc = {k[2:]: v for k, v in P.items() if k.startswith("e.")}
+    dec = {k[2:]: v for k, v in P.items() if k.startswith("d.")}
+    specs = {"e": layers.encoder_pack_specs(enc), "h": layers.heads_pack_specs(enc), "d": layers.decoder_pack_specs(dec)}
+    prev = layers.W_DTYPE
+    layers.W_DTYPE = w_dtype
+    try:
+        plan = layers.PackPlan(specs, early=("W1p", "W2k", "Wf"), w_dtype=w_dtype)
+        plan.run_early()
+        plan.run_late()
+        ref = {k: layers.pack_now(v) for k, v in specs.items()}
+    finally:
+        layers.W_DTYPE = prev
+    torch.cuda.synchronize()
+    for grp in specs:
+        for name, t in ref[grp].items():
+            assert torch.equal(plan.packed[grp][name].float().cpu(), t.float().cpu()), (grp, name)
