@@ -103,7 +103,19 @@ class _Lanes:
 
     def lane(self, i):
         import contextlib
-        return torch.cuda.stream(self.side[i]) if self.on else contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, layers.CUR_LANE = layers.CUR_LANE, i
+            try:
+                if self.on:
+                    with torch.cuda.stream(self.side[i]):
+                        yield
+                else:
+                    yield
+            finally:
+                layers.CUR_LANE = prev
+        return ctx()
 
     def join(self):
         if self.on:
@@ -154,10 +166,19 @@ class MVAEStep:
         self.exact_running_stats = bool(exact_running_stats)
         # BatchNorm statistics over the global batch of the process group instead of each rank's shard (default:
         # local, like DistributedDataParallel).  Adds one small fp64 all-reduce per BatchNorm layer and direction and
-        # runs eagerly (the collectives sit between kernels of a phase, so the phase graphs are not used).
+        # With the RCCL backend the collectives are captured into the lanes' phase graphs (each lane on a communicator of its
+        # own); with gloo (CPU tests) the step runs eagerly.
         if sync_bn and process_group is None:
             raise ValueError("sync_bn needs a process group")
-        self._sync = layers.SyncBN(process_group, world_size) if sync_bn else None
+        self._sync = None
+        if sync_bn:
+            import torch.distributed as dist
+            ranks = dist.get_process_group_ranks(process_group)
+            # one communicator per lane (see layers.SyncBN); created collectively: every rank constructs its engine
+            lane_groups = [dist.new_group(ranks=ranks) for _ in range(2)]
+            self._sync = layers.SyncBN(process_group, world_size, lane_groups)
+            # collectives can be captured into HIP graphs with the RCCL backend only
+            self._sync_graph_ok = dist.get_backend(process_group) == "nccl"
         self.model = model
         self.use_pose = bool(model._use_pose)
         self.L = model.latent_size
@@ -209,6 +230,14 @@ class MVAEStep:
                                         w_dtype=torch.float32 if precision in ("fp32", "fp16") else torch.bfloat16)
         self._capturing = False
         self._graph = None
+
+    def close(self):
+        """Drop the captured HIP graphs (and their memory pools).  Call before tearing down the process group of a
+        data-parallel run: graphs that captured RCCL collectives should not outlive their communicators."""
+        self._graph = None
+        self.ctx = None
+        if self.lanes.on:
+            torch.cuda.synchronize()
 
     # ------------------------------------------------------------------------------------------
     def _noise(self):
@@ -507,8 +536,8 @@ class MVAEStep:
         Inputs are copied into static buffers; random draws advance through a device-side counter and Adam's step
         count lives on the device, so every replay is a real optimiser step.  With more than one rank the gradient
         all-reduce and Adam run after the graphs."""
-        if self._sync is not None:
-            return self.train_step(inputs, targets, kl_weight)
+        if self._sync is not None and not self._sync_graph_ok:
+            return self.train_step(inputs, targets, kl_weight)      # (gloo: collectives cannot be captured)
         key = tuple(tuple(x.shape) for x in inputs)
         self._set_kl_weight(kl_weight)
         if self._graph is None or self._graph[0] != key:
@@ -576,6 +605,7 @@ class MVAEStep:
                 for lane, fn in stage:
                     g = torch.cuda.CUDAGraph()
                     LN.on = lanes_on and lane == "main" and fn is stages[0][0][1]   # ... except the pre-phase fork
+                    layers.CUR_LANE = {"l0": 0, "l1": 1}.get(lane)                  # (SyncBN: the lane's communicator)
                     with torch.cuda.graph(g, pool=pools[lane], stream=cap_stream[lane]):
                         fn()
                     row.append((lane, g))
@@ -584,6 +614,7 @@ class MVAEStep:
         finally:
             self._capturing = False
             LN.on = lanes_on
+            layers.CUR_LANE = None
             self.ctx = None
         return captured
 

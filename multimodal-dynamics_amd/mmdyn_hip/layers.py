@@ -57,6 +57,7 @@ def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch
     tiles = _cdiv(rows, 64) * _cdiv(N, 64)
     steps = K // 32
     splitk = max(1, min(512 // tiles, steps // 8)) if (N % 64 == 0 and out_dtype == torch.float32) else 1
+    # (kept in the 16-bit matrix-core modes too: without it bf16s bs 128 measured 2.45 vs 2.31 ms per step)
     if splitk > 1:
         ws = _new(A, splitk, rows, N)
         ops.B.igemm_nt(A, Bp, None, C, None, None, ws, DENSE, 1, rows, 1, 1, K, 1, 1, N, N, 1, 0, ACT_NONE, splitk)
@@ -110,15 +111,24 @@ class SyncBN:
     BatchNorm of this module uses the statistics of the GLOBAL batch (one tiny fp64 all-reduce per layer and
     direction).  ``None`` (default) = local statistics, the semantics of DistributedDataParallel and of bench.py."""
 
-    def __init__(self, group, world):
+    def __init__(self, group, world, lane_groups=None):
+        """``lane_groups``: one process group per lane of the engine's schedule (same ranks as ``group``).  The visual
+        and the tactile lane issue their statistics all-reduces from two streams -- and, in graph mode, from two
+        concurrently replayed graphs -- whose relative order is not fixed across ranks; collectives of ONE communicator
+        must be issued in the same order everywhere, so each lane gets a communicator of its own."""
         self.group, self.world = group, int(world)
+        self.lane_groups = lane_groups
 
     def all_reduce(self, t):
         import torch.distributed as dist
-        dist.all_reduce(t, group=self.group)
+        g = self.group
+        if self.lane_groups is not None and CUR_LANE is not None and CUR_LANE < len(self.lane_groups):
+            g = self.lane_groups[CUR_LANE]
+        dist.all_reduce(t, group=g)
 
 
 SYNC = None
+CUR_LANE = None          # index of the lane whose kernels are being enqueued (set by engine._Lanes / the graph capture)
 
 
 def _bn_forward_stats(y, partial, T, bn, G, rows_per_group, C, repeat):

@@ -1,6 +1,7 @@
-mkdir -p gpurun_out/r2
-for cfg in "X=1" "MMDYN_IGEMM_M16=1" "MMDYN_IGEMM_TILE=128,128 MMDYN_IGEMM_M16_128=1 MMDYN_IGEMM_M16=1" "MMDYN_IGEMM_TILE=128,128 MMDYN_IGEMM_M32=1" "MMDYN_IGEMM_TILE=128,64 MMDYN_IGEMM_M16=1" "MMDYN_IGEMM_TILE=128,64 MMDYN_IGEMM_M32=1" "MMDYN_IGEMM_TILE=64,128 MMDYN_IGEMM_M16=1"; do
-  echo "== $cfg"
-  env $cfg python tests/microbench/bench_igemm.py 2>&1 | grep igemm | awk '{print $(NF-1)}' | tr '\n' ' '
-  echo
-done
+run() { tag=$1; shift; env "$@" python bench.py --steps 40 --warmup 5 --no-cpu-baseline --dtype bf16s --batch 128 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', round(d['value']), round(d['ms_per_step'],3))"; }
+run base X=1
+run splitk1 MMDYN_SPLITK16=0
+run splitk2 MMDYN_SPLITK16=2
+run splitk4 MMDYN_SPLITK16=4
+run base X=1
+run splitk1 MMDYN_SPLITK16=0

@@ -158,6 +158,9 @@ def nccl_group():
     os.environ.setdefault("MASTER_PORT", "29541")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     yield dist.group.WORLD
+    import gc
+    gc.collect()                       # engines (and their captured graphs) of the tests above are gone before the group
+    torch.cuda.synchronize()
     dist.destroy_process_group()
 
 
@@ -194,10 +197,37 @@ def test_graphed_step_with_process_group_equals_single(tmp_path, nccl_group):
         losses = [float(step.train_step_graphed(gi, gt, klw)) for _ in range(steps)]
         torch.cuda.synchronize()
         out.append((losses, step.params.flat.clone()))
+        # the bucket bounds cover the flat buffer in the order the gradients become ready
+        assert step.params.bucket_bounds[-1] == step.params.total and len(step.params.bucket_bounds) == 3
+        step.close()
+        del step
     assert out[0][0] == pytest.approx(out[1][0], rel=1e-6)
     assert float((out[0][1] - out[1][1]).norm() / out[0][1].norm()) < 1e-6
-    # the bucket bounds cover the flat buffer in the order the gradients become ready
-    assert step.params.bucket_bounds[-1] == step.params.total and len(step.params.bucket_bounds) == 3
+
+
+def test_sync_bn_inside_the_phase_graphs(tmp_path, nccl_group):
+    """SyncBN statistics all-reduces captured INTO the lanes' HIP graphs (each lane on its own RCCL communicator, so the
+    two concurrently replayed graphs never interleave collectives of one communicator): graph replay == eager launches,
+    step for step, with a one-rank group (the only multi-process layout a one-GPU box offers; the two-rank arithmetic is
+    covered on gloo by tests/test_ddp_gloo.py)."""
+    B, klw, steps = 8, 0.02, 4
+    inputs, targets = seeded_batch(B, 93)
+    gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+    out = []
+    for graphed in (False, True):
+        m = T.build("cnn-mvae", True, True, DEV)
+        step = MVAEStep(m, noise=NoiseSource(94), process_group=nccl_group, world_size=1, sync_bn=True)
+        assert step._sync_graph_ok and len(step._sync.lane_groups) == 2
+        run = step.train_step_graphed if graphed else step.train_step
+        losses = [float(run(gi, gt, klw)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        if graphed:
+            assert step._graph is not None          # really replayed from graphs (no silent eager fallback)
+        out.append((losses, step.params.flat.clone()))
+        step.close()                                # graphs with captured collectives go before their communicators
+        del step
+    assert out[0][0] == pytest.approx(out[1][0], rel=1e-6)
+    assert float((out[0][1] - out[1][1]).norm() / out[0][1].norm()) < 1e-6
 
 
 @pytest.mark.parametrize("B", [32, 5, 37])
