@@ -220,8 +220,9 @@ def main():
                          "bf16: bf16 matrix-core operands only (fp32 storage).  fp16: fp16 matrix-core operands, fp32 "
                          "accumulate / storage / master weights (configs[4])")
     ap.add_argument("--sync-bn", action="store_true",
-                    help="BatchNorm statistics over the global batch (N > 1; eager launches, one small all-reduce per "
-                         "BatchNorm layer and direction).  Default: local statistics")
+                    help="BatchNorm statistics over the global batch (N > 1; one small all-reduce per BatchNorm layer and "
+                         "direction, captured into the lanes' HIP graphs, each lane on its own RCCL communicator).  Default: "
+                         "local statistics")
     ap.add_argument("--infer", action="store_true",
                     help="time forward-only inference instead (model.eval(): joint visual+tactile+pose pass through the "
                          "module API, running-estimate BatchNorm); prints its own JSON line, not the BASELINE metric")
@@ -388,7 +389,7 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": global_batch, "parallelism": f"dp{world}", "bn": "sync" if (args.sync_bn and pg is not None) else "local",
-                   "launch": "eager" if (args.no_graph or (args.sync_bn and pg is not None)) else "hip_graph",
+                   "launch": "eager" if (args.no_graph or (args.sync_bn and pg is not None and dry)) else "hip_graph",
                    "final_loss": final_loss, "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps},
         "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak,
