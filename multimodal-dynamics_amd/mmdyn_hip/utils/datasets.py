@@ -84,16 +84,13 @@ class VisuoTactileDataset:
             self._generate_object_seq(real_dataset, sv='sv' in dataset_path)
         with open(self.dataset_path, 'rb') as f:
             datapoint_dict = pickle.load(f)
-        len_dataset = len(datapoint_dict['targets'])
-        frac_index = int(self._train_frac * len_dataset)
-        if 'classes' in datapoint_dict.keys():
+        # the reference's split (datasets.py:99-108): the first train_frac of the sequences train, the rest validate --
+        # EXCEPT the very last sequence, which its `[frac:-1]` slice never uses; reproduced, not fixed
+        n_train = int(self._train_frac * len(datapoint_dict['targets']))
+        if 'classes' in datapoint_dict:
             self.classes = datapoint_dict['classes']
-        if self.train:
-            self.data = datapoint_dict['data'][0:frac_index]
-            self.targets = datapoint_dict['targets'][0:frac_index]
-        else:
-            self.data = datapoint_dict['data'][frac_index:-1]         # sic (datasets.py:107-108)
-            self.targets = datapoint_dict['targets'][frac_index:-1]
+        part = slice(0, n_train) if self.train else slice(n_train, -1)
+        self.data, self.targets = datapoint_dict['data'][part], datapoint_dict['targets'][part]
 
     def __len__(self):
         return len(self.targets)
@@ -252,32 +249,33 @@ class VisuoTactileDataset:
 
     @staticmethod
     def _load_image(img_path, bounding_box=None, resize=True):
+        """One frame as the compiler stores it: uint8 HxWx3, optionally cropped to ``bounding_box`` (left, upper,
+        right, lower) and brought to 256 x 256 with PIL's default resampling; grey images are replicated to 3 channels
+        (datasets.py:318-334; the pickle's sha-256 digests in tests/golden/dataset_tree.npz pin every byte)."""
         from PIL import Image
-        img = Image.open(img_path)
-        if bounding_box is not None:
-            img = img.crop(bounding_box)
-        if resize:
-            img = img.resize((256, 256))
-        np_img = np.array(img).copy()
-        if np_img.ndim == 2:
-            np_img = np.repeat(np_img[:, :, np.newaxis], 3, axis=2).astype(np.uint8)
-        img.close()
-        return np_img
+        with Image.open(img_path) as frame:
+            picture = frame.crop(bounding_box) if bounding_box is not None else frame
+            if resize:
+                picture = picture.resize((256, 256))
+            pixels = np.array(picture).copy()
+        if pixels.ndim == 2:
+            pixels = np.stack([pixels] * 3, axis=2).astype(np.uint8)
+        return pixels
 
     @staticmethod
     def _bounding_box(img):
-        """Square-ish box around the pixels of the highest segmentation id (datasets.py:336-350)."""
-        mask = np.where(img == np.max(img))
-        ymin, ymax = np.min(mask[0]), np.max(mask[0])
-        xmin, xmax = np.min(mask[1]), np.max(mask[1])
-        diff = (ymax - ymin) - (xmax - xmin)
-        if diff > 0:
-            xmin = max(0, xmin - diff / 2)
-            xmax = min(img.shape[1], xmax + diff / 2)
-        elif diff < 0:
-            ymin = max(0, ymin - abs(diff) / 2)
-            ymax = min(img.shape[0], ymax + abs(diff) / 2)
-        return xmin, ymin, xmax, ymax
+        """Box (xmin, ymin, xmax, ymax) around the pixels carrying the largest segmentation id, widened along its
+        shorter side by half the difference of the two extents on each end (clamped to the image), i.e. made as square
+        as the image allows (datasets.py:336-350; the float halves are the reference's)."""
+        rows, cols = np.nonzero(img == img.max())[:2]
+        top, bottom = rows.min(), rows.max()
+        left, right = cols.min(), cols.max()
+        excess = (bottom - top) - (right - left)           # > 0: taller than wide
+        if excess > 0:
+            left, right = max(0, left - excess / 2), min(img.shape[1], right + excess / 2)
+        elif excess < 0:
+            top, bottom = max(0, top - (-excess) / 2), min(img.shape[0], bottom + (-excess) / 2)
+        return left, top, right, bottom
 
 
 class DeviceLoader:

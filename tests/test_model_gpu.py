@@ -134,7 +134,7 @@ def test_bf16_engine_vs_oracle():
     loss_o.backward()
     loss = step.forward([x.to(DEV) for x in inputs], [x.to(DEV) for x in targets], klw)
     rel_loss = abs(float(loss) - float(loss_o.detach())) / abs(float(loss_o.detach()))
-    assert rel_loss < 5e-3, rel_loss
+    assert rel_loss < 5e-4, rel_loss          # measured 8e-5
     np.testing.assert_allclose(step.partials[:7].cpu().numpy(), [float(x.detach()) for x in partials_o], rtol=5e-3)
     step.backward()
     named = dict(m.named_parameters())
@@ -233,8 +233,9 @@ def test_sync_bn_inside_the_phase_graphs(tmp_path, nccl_group):
 @pytest.mark.parametrize("B", [32, 5, 37])
 def test_bf16_storage_engine_vs_oracle(B):
     """precision="bf16s" (BASELINE configs[2]: bf16 activation storage + bf16 matrix cores, fp32 accumulate / master
-    weights) against the fp32 CPU oracle.  Stated tolerance: ELBO and partials within 1e-2 relative, gradients
-    within 2e-1 relative L2 per tensor (measured values are printed).  B = 5 and 37 are ragged: no row count is a multiple
+    weights) against the fp32 CPU oracle.  Stated tolerance: total ELBO within 5e-4 relative (measured 0.8-1.1e-4), partials
+    within 1e-2, gradients within 1.5e-1 relative L2 per tensor = twice the worst measured (7.7e-2, the encoder conv weights,
+    whose gradients come through the longest bf16 chains; median 1.9e-2; values are printed).  B = 5 and 37 are ragged: no row count is a multiple
     of a tile, so the all-bf16 GEMM kernels (64-channel K-steps, transposing LDS reads, shared quad walks) see their
     masked remainders."""
     klw = 1.0 / 50
@@ -256,7 +257,7 @@ def test_bf16_storage_engine_vs_oracle(B):
     errs = sorted(((float((named[k].grad.double().cpu() - prm[k].grad.double()).norm()
                            / (prm[k].grad.double().norm() + 1e-30)), k) for k in prm), reverse=True)
     print("bf16s loss rel err", rel_loss, "worst gradient rel-L2:", errs[:4], "median", errs[len(errs) // 2])
-    assert rel_loss < 1e-2 and errs[0][0] < (2e-1 if B >= 32 else 3e-1), (rel_loss, errs[:4])   # (tiny batches: noisier BN)
+    assert rel_loss < 5e-4 and errs[0][0] < 1.5e-1, (rel_loss, errs[:4])   # measured: 1.1e-4 / 7.7e-2 worst over B = 5, 32, 37
     for s in range(3):                      # and it trains: a few Adam steps on the fixed batch lower the loss
         l = step.train_step([x.to(DEV) for x in inputs], [x.to(DEV) for x in targets], klw)
     assert float(l) < loss0
