@@ -42,6 +42,7 @@ struct D16Args {
   int MX;            // G * tiles_per_group
   float inv_hwr, inv_wr;
   unsigned a_bytes, b_bytes;
+  int prio;
 };
 
 // n / d for 0 <= n < 2^23 with inv = 1.0f / d (one correction step makes the float estimate exact)
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void igemm_d16_kernel(const float* __restri
   // index (K position, scalar buffer offsets) lives in VGPRs and each buffer load is wrapped in a waterfall loop
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q4 = lane >> 4;
+  if (p.prio) __builtin_amdgcn_s_setprio(3);      // (experiment: win the matrix-pipe arbitration against co-resident thin waves)
 
   // workgroup -> contiguous range of tiles per XCD (workgroups are dealt round-robin over the 8 XCDs)
   const int nb = gridDim.x, b = blockIdx.x;
@@ -398,11 +400,13 @@ static int launch_mt(const float* A, const float* Bp, const float* bias, float* 
   p.b_bytes = (unsigned)((long)ntaps_w * g.N * g.Cin * 4);
   // MMDYN_D16_BLOCKS = n: persistent launch of at most n workgroups (256 = one wave per SIMD: the two lanes of the
   // step then hold one wave slot per SIMD each instead of one lane's launch filling both)
-  static int max_blocks = -1;
+  static int max_blocks = -1, prio = 0;
   if (max_blocks < 0) {
     const char* e = getenv("MMDYN_D16_BLOCKS");
     max_blocks = e ? atoi(e) : 0;
+    prio = getenv("MMDYN_D16_PRIO") != nullptr;
   }
+  p.prio = prio;
   int blocks = ceil_div(p.tiles, 4);
   if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
   hipLaunchKernelGGL((igemm_d16_kernel<MODE, MT, NT>), dim3(blocks), dim3(256), 0, st, A, Bp, bias, C, C_act, stats, ws, p);

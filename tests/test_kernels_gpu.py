@@ -153,9 +153,13 @@ def test_igemm_d16_splitk(rows, K, N, splitk, d16_tile):
     test_igemm_splitk(rows, K, N, splitk)
 
 
-def test_igemm_d16_full_size_shapes():
-    """The bs-256 step's own decoder shapes (tile rule unforced: these are the launches the direct kernels serve):
-    row-sum / column-sum identities instead of an O(M N K) reference.  sum_n C[row][n] = A_row . (sum_n B_n) per tap."""
+@pytest.mark.parametrize("path", ["lds", "d16"])
+def test_igemm_full_size_shapes(path, monkeypatch):
+    """The bs-256 step's own decoder shapes, tile rules unforced -- "lds": the default path (LDS-tiled kernels, 16x16x4 MFMA
+    on launches this large), "d16": the opt-in wave-independent kernels (MMDYN_D16=1) -- checked through row-sum /
+    column-sum identities instead of an O(M N K) reference: sum_n C[row][n] = A_row . (sum_n B_n) per tap."""
+    if path == "d16":
+        monkeypatch.setenv("MMDYN_D16", "1")
     for mode, G, Bg, Hi, Cin, Ho, N, stride, offset in [(TCONV_S2P1, 4, 256, 8, 128, 16, 64, 1, 0),
                                                         (CONV, 1, 1024, 16, 64, 8, 128, 2, -1),
                                                         (TCONV_S1P0, 4, 256, 5, 256, 8, 128, 1, 0),
