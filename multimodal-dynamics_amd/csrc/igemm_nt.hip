@@ -652,6 +652,44 @@ static int launch(const float* A, const float* Bp, const float* bias, float* C, 
 
 }  // namespace
 
+// The template instances of one block tile are compiled as their own translation unit (Makefile: -DIGEMM_PART=k, k = 0..5;
+// -DIGEMM_PART=99: the entry points only): six hipcc jobs of ~30 s instead of one of 3 minutes.  Without IGEMM_PART
+// everything is built in one unit.
+#if defined(IGEMM_PART)
+#define IGEMM_HAS(k) (IGEMM_PART == (k))
+#else
+#define IGEMM_HAS(k) 1
+#endif
+#define IGEMM_TILE_ARGS const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws, \
+                        IgemmGeom g, hipStream_t st, bool bf16
+int mmdyn_igemm_tile0(IGEMM_TILE_ARGS);
+int mmdyn_igemm_tile1(IGEMM_TILE_ARGS);
+int mmdyn_igemm_tile2(IGEMM_TILE_ARGS);
+int mmdyn_igemm_tile3(IGEMM_TILE_ARGS);
+int mmdyn_igemm_tile4(IGEMM_TILE_ARGS);
+int mmdyn_igemm_tile5(IGEMM_TILE_ARGS);
+#if IGEMM_HAS(0)
+int mmdyn_igemm_tile0(IGEMM_TILE_ARGS) { return launch<128, 128, 64, 64>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16); }
+#endif
+#if IGEMM_HAS(1)
+int mmdyn_igemm_tile1(IGEMM_TILE_ARGS) { return launch<64, 128, 32, 64>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16); }
+#endif
+#if IGEMM_HAS(2)
+int mmdyn_igemm_tile2(IGEMM_TILE_ARGS) { return launch<128, 64, 64, 32>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16); }
+#endif
+#if IGEMM_HAS(3)
+int mmdyn_igemm_tile3(IGEMM_TILE_ARGS) { return launch<64, 64, 32, 32>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16); }
+#endif
+#if IGEMM_HAS(4)
+int mmdyn_igemm_tile4(IGEMM_TILE_ARGS) { return launch<256, 32, 64, 32>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16); }
+#endif
+#if IGEMM_HAS(5)
+int mmdyn_igemm_tile5(IGEMM_TILE_ARGS) { return launch<128, 32, 32, 32>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16); }
+#endif
+
+#if !defined(IGEMM_PART) || IGEMM_PART == 99
+
+
 static int lds_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   if (mode == MMDYN_TCONV_S1P0) {
     int bm, bn;
@@ -780,12 +818,12 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
     pick_tile(N, Bg, G * 16, 1, 1, 0, &bm, &bn);
   else
     pick_tile(N, Bg * g.Hr * g.Wr, G, g.nclasses, splitk, g.ntaps * (Cin / BK), &bm, &bn);
-  if (bn == 128 && bm == 128) return launch<128, 128, 64, 64>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
-  if (bn == 128 && bm == 64) return launch<64, 128, 32, 64>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
-  if (bn == 64 && bm == 128) return launch<128, 64, 64, 32>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
-  if (bn == 64 && bm == 64) return launch<64, 64, 32, 32>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
-  if (bn == 32 && bm == 256) return launch<256, 32, 64, 32>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
-  return launch<128, 32, 32, 32>(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  if (bn == 128 && bm == 128) return mmdyn_igemm_tile0(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  if (bn == 128 && bm == 64) return mmdyn_igemm_tile1(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  if (bn == 64 && bm == 128) return mmdyn_igemm_tile2(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  if (bn == 64 && bm == 64) return mmdyn_igemm_tile3(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  if (bn == 32 && bm == 256) return mmdyn_igemm_tile4(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+  return mmdyn_igemm_tile5(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
 }
 
 extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
@@ -846,3 +884,4 @@ extern "C" int mmdyn_splitk_reduce(const float* ws, const float* bias, float* C,
                      bias, C, C_act, splitk, total, N, act);
   MMDYN_LAUNCH_CHECK();
 }
+#endif   // entry points
