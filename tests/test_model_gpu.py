@@ -384,3 +384,30 @@ def test_one_graph_capture_serves_the_kl_annealing_schedule():
             assert step._graph[1] is graphs                  # captured once, at the first replayed step
         runs.append(losses)
     assert runs[0] == pytest.approx(runs[1], rel=1e-6)
+
+
+def test_inference_engine_extended_size():
+    """engine.MVAEInference (prepacked weights, HIP-graph replay, eval-mode BatchNorm) on the 128-pixel stack against the
+    oracle in eval mode on the same running statistics."""
+    from mmdyn_hip.engine import MVAEInference
+    from mmdyn_hip.utils.seeded_init import seeded_running_stats
+    size, B = 128, 3
+    sd = seeded_running_stats(seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True, size=size), 0), 7)
+    m = T.build("cnn-mvae", True, True, DEV, size=size)
+    m.load_state_dict(sd)
+    m.eval()
+    inputs, _ = seeded_batch(B, 21, size=size)
+    eng = MVAEInference(m, seed=3)
+    for _ in range(2):                                   # second call: graph replay
+        v, t, p, mu, lv = eng([inputs[0].to(DEV), inputs[1].to(DEV)], pose=inputs[2].to(DEV))
+    prm, buf = O.split_state(sd, requires_grad=False)
+    with O.eval_mode():
+        mo, lo = O.image_encoder(inputs[0], prm, "visual_encoder", None, buf)
+    assert tuple(v.shape) == (B, 3, size, size) and tuple(t.shape) == (B, 3, size, size) and tuple(p.shape) == (B, 7)
+    # means of the joint posterior need all three experts; the visual expert alone is checked through a visual-only call
+    v1, t1, p1, mu1, lv1 = eng([inputs[0].to(DEV), None], pose=None)
+    pm, plv = O.product_of_experts(torch.stack([torch.zeros_like(mo), mo]), torch.stack([torch.zeros_like(lo), lo]))
+    torch.testing.assert_close(mu1.cpu(), pm, rtol=1e-4, atol=3e-5)
+    torch.testing.assert_close(lv1.cpu(), plv, rtol=1e-4, atol=3e-5)
+    s = eng.inference(4)
+    assert tuple(s[0].shape) == (4, 3, size, size)
