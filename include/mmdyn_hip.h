@@ -288,6 +288,13 @@ int mmdyn_bce_logits(const float* logits, const float* target, const float* mask
 #define MMDYN_BCE_GROUPS_MAX 8
 int mmdyn_bce_logits_groups(const float* logits, const float* target, float* dlogit, double* loss_slots,
                             const int* slot_of_group, int G, int64_t n, float grad_scale, void* stream);
+/* The same launch with the loss mask of --mask-loss (problems.py:445-447, 684: torch.mul(recon, mask) against
+ * torch.mul(target, mask)); mask [B][mask_channels][H][W] as in mmdyn_bce_logits (n = B*chw per pass).  unmasked_slots (may be
+ * null) receives the plain sums next to the masked ones: the reference's perf_measure of the single-modality passes is
+ * computed without the mask (problems.py:495-505). */
+int mmdyn_bce_logits_groups_masked(const float* logits, const float* target, const float* mask, float* dlogit,
+                                   double* loss_slots, double* unmasked_slots, const int* slot_of_group, int G, int64_t n,
+                                   int chw, int hw, int mask_channels, float grad_scale, void* stream);
 /* sum (r-t)^2 added to *loss_sum; dr = 2 (r-t) grad_scale */
 int mmdyn_mse(const float* r, const float* t, float* dr, double* loss_sum, int64_t n, float grad_scale,
               void* stream);

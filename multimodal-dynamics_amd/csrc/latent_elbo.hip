@@ -212,10 +212,13 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
 struct BceGroups {
   int slot[MMDYN_BCE_GROUPS_MAX];
 };
+template <bool MASKED>
 __global__ __launch_bounds__(256) void bce_logits_groups_kernel(const float* __restrict__ logits,
                                                                 const float* __restrict__ target,
+                                                                const float* __restrict__ mask,
                                                                 float* __restrict__ dlogit, double* __restrict__ loss,
-                                                                const BceGroups gs, int64_t n, float grad_scale) {
+                                                                double* __restrict__ unmasked, const BceGroups gs,
+                                                                int64_t n, int chw, int hw, int mask_c, float grad_scale) {
   const int grp = blockIdx.y, slot = gs.slot[grp];
   const float* __restrict__ lg = logits + (size_t)grp * n;
   float* __restrict__ dl = dlogit ? dlogit + (size_t)grp * n : nullptr;
@@ -227,20 +230,43 @@ __global__ __launch_bounds__(256) void bce_logits_groups_kernel(const float* __r
         reinterpret_cast<f32x4*>(dl)[i] = zero;
     return;
   }
-  double acc = 0.0;
+  double acc = 0.0, acc_u = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const f32x4 xv = reinterpret_cast<const f32x4*>(lg)[i], t = reinterpret_cast<const f32x4*>(target)[i];
     f32x4 d;
     float part = 0.f;
+    if constexpr (MASKED) {
+      // the loss mask multiplies logits and target (problems.py:445-447): [B][1 or C][H][W], as in bce_logits_kernel
+      const int64_t e0 = i * 4, b = e0 / chw;
+      const int rem = (int)(e0 - b * chw);
+      const int ch = rem / hw, pix = rem - ch * hw;
+      const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + (b * mask_c + (mask_c == 1 ? 0 : ch)) * hw + pix);
+      float part_u = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      part += fmaxf(xv[k], 0.f) - xv[k] * t[k] + log1pf(expf(-fabsf(xv[k])));
-      d[k] = (1.f / (1.f + expf(-xv[k])) - t[k]) * grad_scale;
+      for (int k = 0; k < 4; ++k) {
+        const float xm = xv[k] * mk[k], tm = t[k] * mk[k];
+        part += fmaxf(xm, 0.f) - xm * tm + log1pf(expf(-fabsf(xm)));
+        d[k] = mk[k] * (1.f / (1.f + expf(-xm)) - tm) * grad_scale;
+        part_u += fmaxf(xv[k], 0.f) - xv[k] * t[k] + log1pf(expf(-fabsf(xv[k])));
+      }
+      acc_u += (double)part_u;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        part += fmaxf(xv[k], 0.f) - xv[k] * t[k] + log1pf(expf(-fabsf(xv[k])));
+        d[k] = (1.f / (1.f + expf(-xv[k])) - t[k]) * grad_scale;
+      }
     }
     acc += (double)part;
     if (dl) reinterpret_cast<f32x4*>(dl)[i] = d;
   }
   block_atomic_add(acc, loss + slot);
+  if constexpr (MASKED) {
+    if (unmasked) {
+      __syncthreads();          // block_atomic_add's scratch is reused
+      block_atomic_add(acc_u, unmasked + slot);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ r, const float* __restrict__ t,
@@ -353,17 +379,39 @@ extern "C" int mmdyn_bce_logits(const float* logits, const float* target, const 
   MMDYN_LAUNCH_CHECK();
 }
 
-extern "C" int mmdyn_bce_logits_groups(const float* logits, const float* target, float* dlogit, double* loss_slots,
-                                       const int* slot_of_group, int G, int64_t n, float grad_scale, void* stream) {
+static int bce_groups_launch(const float* logits, const float* target, const float* mask, float* dlogit,
+                             double* loss_slots, double* unmasked_slots, const int* slot_of_group, int G, int64_t n,
+                             int chw, int hw, int mask_channels, float grad_scale, void* stream) {
   if (!logits || !target || !loss_slots || !slot_of_group) return MMDYN_ERR_NULL;
   if (G <= 0 || G > MMDYN_BCE_GROUPS_MAX || n <= 0 || n % 4) return MMDYN_ERR_SHAPE;
+  if (mask && (hw <= 0 || hw % 4 || chw <= 0 || chw % hw || n % chw || (mask_channels != 1 && mask_channels != chw / hw)))
+    return MMDYN_ERR_SHAPE;
   BceGroups gs{};
   for (int i = 0; i < G; ++i) gs.slot[i] = slot_of_group[i];
   int g = ew_grid(n / 4);
   if (g > 512) g = 512;
-  hipLaunchKernelGGL(bce_logits_groups_kernel, dim3(g, G), dim3(256), 0, ST, logits, target, dlogit, loss_slots, gs, n,
-                     grad_scale);
+  if (mask)
+    hipLaunchKernelGGL(bce_logits_groups_kernel<true>, dim3(g, G), dim3(256), 0, ST, logits, target, mask, dlogit,
+                       loss_slots, unmasked_slots, gs, n, chw, hw, mask_channels, grad_scale);
+  else
+    hipLaunchKernelGGL(bce_logits_groups_kernel<false>, dim3(g, G), dim3(256), 0, ST, logits, target, mask, dlogit,
+                       loss_slots, unmasked_slots, gs, n, 0, 0, 1, grad_scale);
   MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bce_logits_groups(const float* logits, const float* target, float* dlogit, double* loss_slots,
+                                       const int* slot_of_group, int G, int64_t n, float grad_scale, void* stream) {
+  return bce_groups_launch(logits, target, nullptr, dlogit, loss_slots, nullptr, slot_of_group, G, n, 0, 0, 1, grad_scale,
+                           stream);
+}
+
+extern "C" int mmdyn_bce_logits_groups_masked(const float* logits, const float* target, const float* mask, float* dlogit,
+                                              double* loss_slots, double* unmasked_slots, const int* slot_of_group, int G,
+                                              int64_t n, int chw, int hw, int mask_channels, float grad_scale,
+                                              void* stream) {
+  if (!mask) return MMDYN_ERR_NULL;
+  return bce_groups_launch(logits, target, mask, dlogit, loss_slots, unmasked_slots, slot_of_group, G, n, chw, hw,
+                           mask_channels, grad_scale, stream);
 }
 
 extern "C" int mmdyn_mse(const float* r, const float* t, float* dr, double* loss_sum, int64_t n,

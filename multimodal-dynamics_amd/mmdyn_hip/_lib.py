@@ -79,6 +79,7 @@ _SIGNATURES = {
     "mmdyn_reparam_bwd": "pppp" + "f" + "pp" + "iii" + "p",
     "mmdyn_bce_logits": "ppppp" + "l" + "iii" + "f" + "p",
     "mmdyn_bce_logits_groups": "ppppp" + "i" + "l" + "f" + "p",
+    "mmdyn_bce_logits_groups_masked": "ppppppp" + "i" + "l" + "iii" + "f" + "p",
     "mmdyn_mse": "pppp" + "l" + "f" + "p",
     "mmdyn_elbo_assemble": "ppppp" + "ii" + "ff" + "pp",
     "mmdyn_adam_step": "ppppp" + "l" + "fffff" + "p",

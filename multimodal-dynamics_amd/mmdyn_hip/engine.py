@@ -196,7 +196,7 @@ class MVAEStep:
         self.adam_m = torch.zeros_like(self.params.flat)
         self.adam_v = torch.zeros_like(self.params.flat)
         self.adam_state = torch.zeros(3, dtype=torch.float64, device=dev)
-        self.acc = torch.zeros(3, 8, dtype=torch.float64, device=dev)          # bce / mse / kl per pass
+        self.acc = torch.zeros(4, 8, dtype=torch.float64, device=dev)   # bce / mse / kl per pass (+ unmasked bce: --mask-loss)
         self.loss = torch.zeros(1, device=dev)
         self.partials = torch.zeros(8, device=dev)
         # the KL weight of the annealing schedule (problems.py:212-216) lives on the device: the loss assembly and the
@@ -230,6 +230,7 @@ class MVAEStep:
                                         w_dtype=torch.float32 if precision in ("fp32", "fp16") else torch.bfloat16)
         self._capturing = False
         self._graph = None
+        self._static_mask = None
 
     def close(self):
         """Drop the captured HIP graphs (and their memory pools).  Call before tearing down the process group of a
@@ -284,8 +285,18 @@ class MVAEStep:
             self.klw.fill_(float(kl_weight))
             self._klw_host = float(kl_weight)
 
-    def _begin(self, inputs, targets, kl_weight, train):
+    def _begin(self, inputs, targets, kl_weight, train, loss_mask=None):
         self._set_kl_weight(kl_weight)
+        if loss_mask is not None:
+            # torch.mul(recon_i, loss_mask) of problems.py:445-447: image-shaped, so the reference fails on the (B, 7) pose term
+            if self.use_pose:
+                raise ValueError("loss_mask is image-shaped and cannot multiply the (B, 7) pose term (use_pose=False)")
+            if loss_mask.dim() == 3:
+                loss_mask = loss_mask.unsqueeze(1)
+            if loss_mask.dim() != 4 or loss_mask.shape[0] != inputs[0].shape[0] or loss_mask.shape[1] not in (1, targets[0].shape[1]) \
+                    or tuple(loss_mask.shape[2:]) != tuple(targets[0].shape[2:]):
+                raise ValueError(f"loss_mask {tuple(loss_mask.shape)} does not broadcast over targets {tuple(targets[0].shape)}")
+            loss_mask = loss_mask.to(torch.float32).contiguous()
         if not self.params.still_attached():
             raise RuntimeError("model parameters were re-allocated (e.g. .to()/.cuda() after MVAEStep was built); "
                                "construct MVAEStep after moving the model")
@@ -294,7 +305,7 @@ class MVAEStep:
                     "tg": {"v": targets[0].contiguous(), "t": targets[1].contiguous()},
                     "pose": inputs[2].contiguous() if self.use_pose else None,
                     "pose_tg": targets[2].contiguous() if self.use_pose else None,
-                    "kl_weight": float(kl_weight), "train": train, "pk": {}}
+                    "kl_weight": float(kl_weight), "train": train, "pk": {}, "lmask": loss_mask}
 
     def _passes_of(self, m):
         return self.pass_v if m == "v" else self.pass_t
@@ -356,8 +367,13 @@ class MVAEStep:
         dl = torch.empty_like(lg) if c["train"] else None
         # every live pass of the modality against the same target: one launch, one loss slot per pass
         # (slot -1: exact_running_stats ran a pass whose reconstruction is discarded -- zero gradient, no loss)
-        ops.B.bce_logits_groups(lg, c["tg"][m], dl, self.acc[0], [p if p in live else -1 for p in plist],
-                                c["tg"][m].numel(), 1.0 / B)
+        tg, mk = c["tg"][m], c["lmask"]
+        if mk is None:
+            ops.B.bce_logits_groups(lg, tg, dl, self.acc[0], [p if p in live else -1 for p in plist], tg.numel(), 1.0 / B)
+        else:
+            ops.B.bce_logits_groups(lg, tg, dl, self.acc[0], [p if p in live else -1 for p in plist], tg.numel(), 1.0 / B,
+                                    mask=mk, chw=tg[0].numel(), hw=tg[0, 0].numel(), mask_channels=mk.shape[1],
+                                    unmasked_slots=self.acc[3])
         c["lg" + m], c["dl" + m] = lg, dl
 
     def _ph_pose_dec_fwd(self):
@@ -430,7 +446,7 @@ class MVAEStep:
             gp = self.pass_p.index(joint)
             recon.append(c["pr"][gp * B:(gp + 1) * B])
         self.last = {"recon_x": recon, "means": c["mu"][P - 1], "log_var": c["lv"][P - 1],
-                     "logits_v": c["lgv"], "logits_t": c["lgt"], "pose_recon": c["pr"]}
+                     "logits_v": c["lgv"], "logits_t": c["lgt"], "pose_recon": c["pr"], "masked": c["lmask"] is not None}
 
     def _two(self, phase):
         """Run a per-modality steps-phase for both modalities, lane 0 / lane 1, enqueued in alternation."""
@@ -439,11 +455,12 @@ class MVAEStep:
 
     # ------------------------------------------------------------------------------------------
     @_with_precision
-    def forward(self, inputs, targets, kl_weight, train=True):
+    def forward(self, inputs, targets, kl_weight, train=True, loss_mask=None):
         """Runs the forward schedule and the loss; with train=True also fills the loss gradients needed by
-        :meth:`backward`.  Returns the device scalar loss (fp32)."""
+        :meth:`backward`.  Returns the device scalar loss (fp32).  ``loss_mask`` ([B][1 or C][H][W], models without pose):
+        the reference's --mask-loss, multiplying logits and targets of every image term."""
         LN = self.lanes
-        self._begin(inputs, targets, kl_weight, train)
+        self._begin(inputs, targets, kl_weight, train, loss_mask)
         self._ph_pre()
         LN.fork()
         self._ph_pack_late()
@@ -517,17 +534,17 @@ class MVAEStep:
                         self.betas[0], self.betas[1], self.eps, 1.0 / self.world)
 
     @_with_precision
-    def train_step(self, inputs, targets, kl_weight):
+    def train_step(self, inputs, targets, kl_weight, loss_mask=None):
         """zero_grad -> forward -> backward -> (all-reduce) -> Adam, as problems.py:150-155.  Gradients are
         overwritten, not accumulated, so no zero_grad pass is needed."""
-        loss = self.forward(inputs, targets, kl_weight, train=True)
+        loss = self.forward(inputs, targets, kl_weight, train=True, loss_mask=loss_mask)
         handles = self.backward()
         self.optimizer_step(handles)
         return loss
 
     # ------------------------------------------------------------------------------------------
     @_with_precision
-    def train_step_graphed(self, inputs, targets, kl_weight):
+    def train_step_graphed(self, inputs, targets, kl_weight, loss_mask=None):
         """Same as :meth:`train_step`, replayed from HIP graphs: the ~300 kernel launches of a step are captured
         once per batch shape (the KL weight is read from device memory).  Each phase is its OWN graph: the visual and the tactile phases are
         linear kernel chains that are launched concurrently on two streams (a single graph with parallel branches
@@ -537,22 +554,25 @@ class MVAEStep:
         count lives on the device, so every replay is a real optimiser step.  With more than one rank the gradient
         all-reduce and Adam run after the graphs."""
         if self._sync is not None and not self._sync_graph_ok:
-            return self.train_step(inputs, targets, kl_weight)      # (gloo: collectives cannot be captured)
-        key = tuple(tuple(x.shape) for x in inputs)
+            return self.train_step(inputs, targets, kl_weight, loss_mask)      # (gloo: collectives cannot be captured)
+        key = tuple(tuple(x.shape) for x in inputs) + ((tuple(loss_mask.shape),) if loss_mask is not None else ())
         self._set_kl_weight(kl_weight)
         if self._graph is None or self._graph[0] != key:
             self._static_in = [x.clone() for x in inputs]
             self._static_tg = [x.clone() for x in targets]
+            self._static_mask = None if loss_mask is None else loss_mask.to(torch.float32).clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                      # warm-up outside capture (allocator, lazy init)
-                self.train_step(self._static_in, self._static_tg, kl_weight)
+                self.train_step(self._static_in, self._static_tg, kl_weight, self._static_mask)
             torch.cuda.current_stream().wait_stream(side)
             self._graph = (key, self._capture(kl_weight))
             return self.loss             # the warm-up above WAS this call's optimiser step
         for dst, src in zip(self._static_in + self._static_tg, list(inputs) + list(targets)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
+        if loss_mask is not None:
+            self._static_mask.copy_(loss_mask.reshape(self._static_mask.shape))
         handles = self._replay(self._graph[1])
         if self.pg is not None:
             # buckets 0 and 1 were reduced under the encoder backward graphs; the conv stacks' gradients go now
@@ -599,7 +619,7 @@ class MVAEStep:
         lanes_on, LN.on = LN.on, False            # inside a lane graph everything stays on the capture stream ...
         captured = []
         try:
-            self._begin(self._static_in, self._static_tg, kl_weight, True)
+            self._begin(self._static_in, self._static_tg, kl_weight, True, self._static_mask)
             for stage in stages:
                 row = []
                 for lane, fn in stage:
@@ -649,8 +669,8 @@ class MVAEStep:
 
     @torch.no_grad()
     @_with_precision
-    def eval_step(self, inputs, targets, kl_weight):
-        loss = self.forward(inputs, targets, kl_weight, train=False)
+    def eval_step(self, inputs, targets, kl_weight, loss_mask=None):
+        loss = self.forward(inputs, targets, kl_weight, train=False, loss_mask=loss_mask)
         self.ctx = None
         return loss
 

@@ -330,13 +330,25 @@ class HipBackend:
                                         loss_sum.data_ptr(), n, chw, hw, int(mask_channels), float(grad_scale), _stream()),
               "mmdyn_bce_logits")
 
-    def bce_logits_groups(self, logits, target, dlogit, loss_slots, slot_of_group, n, grad_scale):
-        """logits / dlogit: [G*n]; target: [n]; loss_slots: fp64 vector; slot_of_group[g] < 0 = discarded pass."""
+    def bce_logits_groups(self, logits, target, dlogit, loss_slots, slot_of_group, n, grad_scale, mask=None, chw=0, hw=0,
+                          mask_channels=1, unmasked_slots=None):
+        """logits / dlogit: [G*n]; target: [n]; loss_slots: fp64 vector; slot_of_group[g] < 0 = discarded pass.
+        mask ([B][mask_channels][hw], n = B*chw): the --mask-loss form; unmasked_slots then also gets the plain sums."""
         G = len(slot_of_group)
         slots = (ctypes.c_int * G)(*[int(s) for s in slot_of_group])
-        check(self.lib.mmdyn_bce_logits_groups(_ptr(logits), _ptr(target), _ptr(dlogit), loss_slots.data_ptr(),
-                                               ctypes.addressof(slots), G, n, float(grad_scale), _stream()),
-              "mmdyn_bce_logits_groups")
+        if mask is None:
+            check(self.lib.mmdyn_bce_logits_groups(_ptr(logits), _ptr(target), _ptr(dlogit), loss_slots.data_ptr(),
+                                                   ctypes.addressof(slots), G, n, float(grad_scale), _stream()),
+                  "mmdyn_bce_logits_groups")
+            return
+        if chw <= 0 or hw <= 0 or mask.numel() * chw != n * mask_channels * hw:
+            raise ValueError(f"mmdyn_bce_logits_groups_masked: mask of {mask.numel()} elements does not match "
+                             f"[B={n // max(chw, 1)}][{mask_channels}][hw={hw}]")
+        check(self.lib.mmdyn_bce_logits_groups_masked(_ptr(logits), _ptr(target), _ptr(mask), _ptr(dlogit),
+                                                      loss_slots.data_ptr(),
+                                                      None if unmasked_slots is None else unmasked_slots.data_ptr(),
+                                                      ctypes.addressof(slots), G, n, chw, hw, int(mask_channels),
+                                                      float(grad_scale), _stream()), "mmdyn_bce_logits_groups_masked")
 
     def mse(self, r, t, dr, loss_sum, n, grad_scale):
         check(self.lib.mmdyn_mse(_ptr(r), _ptr(t), _ptr(dr), loss_sum.data_ptr(), n, float(grad_scale), _stream()),

@@ -175,12 +175,14 @@ class Problem:
         if self.parameters['optimizer'] == 'SGD':      # reference: momentum 0.9, weight decay 5e-4 (problems.py:132-136)
             self._optimizer = FusedSGD(self._model.parameters(), lr=self.parameters['lr'], momentum=0.9, weight_decay=5e-4)
             return
-        # the fused step takes the dict-shaped inputs of seq / dyn modeling and has no loss-mask or condition input;
-        # everything else (plain reconstruction, --mask-loss, --conditional, cnn-vae, regressor) runs the module path
+        # the fused step takes the dict-shaped inputs of seq / dyn modeling (with the loss mask of --mask-loss when the model has
+        # no pose term) and has no condition input; everything else (plain reconstruction, --conditional, cnn-vae, regressor,
+        # --mask-loss with --use-pose, which fails in the reference too: problems.py:445-447) runs the module path
         # (decided from the model that was actually built: 'cnn-mvae' with a single-modality --input-type is a plain VAE)
         from ..models.vae import MVAE
         use_engine = (self._fused and isinstance(self._model, MVAE) and self._cross_modal and not self._conditional
-                      and isinstance(self, SeqModeling) and not self.parameters.get('mask_loss'))
+                      and isinstance(self, SeqModeling)
+                      and not (self.parameters.get('mask_loss') and self.parameters.get('use_pose')))
         precision = self.parameters.get('precision', 'fp32')
         if use_engine:
             self._step = MVAEStep(self._model, lr=self.parameters['lr'], pose_multiplier=self._pose_multiplier,
@@ -210,7 +212,7 @@ class Problem:
                 # on the GPU the step is replayed from HIP graphs (captured once per batch shape; the annealed KL weight
                 # is read from device memory); the emulation has no graphs
                 run = self._step.train_step_graphed if self._device.type == 'cuda' else self._step.train_step
-                loss = run(*self._fused_io(inputs, targets), self._kl_weight)
+                loss = run(*self._fused_io(inputs, targets), self._kl_weight, loss_mask=self._fused_mask(targets))
                 if dev_loss is None:
                     dev_loss, dev_acc = torch.zeros_like(loss, dtype=torch.float64), torch.zeros_like(self._step.acc)
                 dev_loss += loss.detach().to(torch.float64)
@@ -246,7 +248,8 @@ class Problem:
             for batch_idx, (data_input, data_target) in enumerate(self.test_loader):
                 inputs, targets = self.parse_input(data_input, data_target)
                 if self._step is not None and self._fused_applicable(inputs):
-                    loss = self._step.eval_step(*self._fused_io(inputs, targets), self._kl_weight)
+                    loss = self._step.eval_step(*self._fused_io(inputs, targets), self._kl_weight,
+                                                loss_mask=self._fused_mask(targets))
                     outputs = {'perf_measure': self._fused_perf()}
                 else:
                     outputs, loss = self._evaluate_model(inputs, targets)
@@ -283,7 +286,10 @@ class Problem:
 
     # ---- fused-engine plumbing -------------------------------------------------------------------
     def _fused_applicable(self, inputs):
-        return isinstance(inputs, dict) and isinstance(inputs.get('model_input'), list) and not self.parameters['mask_loss']
+        return isinstance(inputs, dict) and isinstance(inputs.get('model_input'), list)
+
+    def _fused_mask(self, targets):
+        return targets['loss_mask'] if self.parameters.get('mask_loss') else None
 
     def _fused_io(self, x, targets):
         if self.parameters['use_pose']:
@@ -297,7 +303,8 @@ class Problem:
         B = st.last['means'].shape[0] if B is None else B
         acc = st.acc.cpu() if acc is None else acc
         npx = st.last['recon_x'][0][0].numel()              # 3 * S * S (12288 for the reference's 64 x 64)
-        out = {'visual': float(acc[0, 1]) / (B * npx), 'tactile': float(acc[0, 2]) / (B * npx)}
+        row = 3 if st.last.get('masked') else 0            # the perf measures are unmasked sums (problems.py:495-505)
+        out = {'visual': float(acc[row, 1]) / (B * npx), 'tactile': float(acc[row, 2]) / (B * npx)}
         if st.use_pose:
             out['pose'] = float(acc[1, 6]) / (B * 7)
         return out

@@ -484,7 +484,8 @@ class EmuBackend:
                 d = d * mk
             dlogit.reshape(-1)[:n] = d
 
-    def bce_logits_groups(self, logits, target, dlogit, loss_slots, slot_of_group, n, grad_scale):
+    def bce_logits_groups(self, logits, target, dlogit, loss_slots, slot_of_group, n, grad_scale, mask=None, chw=0, hw=0,
+                          mask_channels=1, unmasked_slots=None):
         lg = logits.reshape(len(slot_of_group), -1)
         dl = None if dlogit is None else dlogit.reshape(len(slot_of_group), -1)
         for g, slot in enumerate(slot_of_group):
@@ -492,7 +493,10 @@ class EmuBackend:
                 if dl is not None:
                     dl[g].zero_()
                 continue
-            self.bce_logits(lg[g], target, None, None if dl is None else dl[g], loss_slots[slot:slot + 1], n, 0, 0, grad_scale)
+            self.bce_logits(lg[g], target, mask, None if dl is None else dl[g], loss_slots[slot:slot + 1], n, chw, hw,
+                            grad_scale, mask_channels)
+            if mask is not None and unmasked_slots is not None:
+                self.bce_logits(lg[g], target, None, None, unmasked_slots[slot:slot + 1], n, 0, 0, grad_scale)
 
     def mse(self, r, t, dr, loss_sum, n, grad_scale):
         d = r.reshape(-1)[:n] - t.reshape(-1)[:n]

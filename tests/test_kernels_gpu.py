@@ -616,6 +616,38 @@ def test_bce_logits_groups_equals_per_pass_launches():
     assert rel(d.cpu(), cpu_d) <= 2e-5 and torch.allclose(loss.cpu(), cpu_loss, rtol=1e-5)
 
 
+@pytest.mark.parametrize("mask_c", [1, 3])
+def test_bce_logits_groups_masked(mask_c):
+    """The --mask-loss form of the grouped launch: masked sums + gradients equal one masked mmdyn_bce_logits per pass, the
+    unmasked slots equal the unmasked launch (problems.py:445-447, 495-505)."""
+    B, G = 5, 3
+    n = B * 3 * 64 * 64
+    lg, tg = rnd(G * n, seed=410) * 3, torch.rand(n, generator=torch.Generator().manual_seed(411))
+    mk = (torch.rand(B * mask_c * 4096, generator=torch.Generator().manual_seed(412)) > 0.35).float()
+    slots = [2, -1, 6]
+    lgd, tgd, mkd = lg.to(DEV), tg.to(DEV), mk.to(DEV)
+    ref_loss, ref_un = torch.zeros(8, dtype=torch.float64, device=DEV), torch.zeros(8, dtype=torch.float64, device=DEV)
+    ref_d = torch.zeros(G * n, device=DEV)
+    for g, s in enumerate(slots):
+        if s >= 0:
+            HIP.bce_logits(lgd[g * n:(g + 1) * n], tgd, mkd, ref_d[g * n:(g + 1) * n], ref_loss[s:s + 1], n, 3 * 4096, 4096, 0.2,
+                           mask_channels=mask_c)
+            HIP.bce_logits(lgd[g * n:(g + 1) * n], tgd, None, None, ref_un[s:s + 1], n, 3 * 4096, 4096, 0.2)
+    loss, un = torch.zeros(8, dtype=torch.float64, device=DEV), torch.zeros(8, dtype=torch.float64, device=DEV)
+    d = torch.full((G * n,), 7.0, device=DEV)
+    HIP.bce_logits_groups(lgd, tgd, d, loss, slots, n, 0.2, mask=mkd, chw=3 * 4096, hw=4096, mask_channels=mask_c,
+                          unmasked_slots=un)
+    torch.cuda.synchronize()
+    assert torch.equal(d.cpu(), ref_d.cpu())
+    assert torch.allclose(loss.cpu(), ref_loss.cpu(), rtol=1e-12) and torch.allclose(un.cpu(), ref_un.cpu(), rtol=1e-12)
+    cpu_loss, cpu_un, cpu_d = torch.zeros(8, dtype=torch.float64), torch.zeros(8, dtype=torch.float64), torch.zeros(G * n)
+    EMU.bce_logits_groups(lg.clone(), tg.clone(), cpu_d, cpu_loss, slots, n, 0.2, mask=mk, chw=3 * 4096, hw=4096,
+                          mask_channels=mask_c, unmasked_slots=cpu_un)
+    assert rel(d.cpu(), cpu_d) <= 2e-5 and torch.allclose(loss.cpu(), cpu_loss, rtol=1e-5) and torch.allclose(un.cpu(), cpu_un, rtol=1e-5)
+    with pytest.raises(ValueError):
+        HIP.bce_logits_groups(lgd, tgd, d, loss, slots, n, 0.2, mask=mkd[:-4], chw=3 * 4096, hw=4096, mask_channels=mask_c)
+
+
 @pytest.mark.parametrize("H", [32, 128, 256])
 def test_im2col_other_image_sizes(H):
     """The 3-channel layers at other image sizes.  128 / 256 (the extended stacks of BASELINE configs[3] / configs[4]) run

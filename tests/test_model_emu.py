@@ -137,6 +137,66 @@ def check_fused_engine(golden_dir, device, fname, use_pose, exact=False):
                                        atol=2e-3 if n_steps > 1 else 2e-6, err_msg=k)
 
 
+def check_fused_engine_mask_loss(device, mask_channels, B=3, graphed=False):
+    """--mask-loss through the fused engine == the module path (seven... three model() calls + autograd, whose masked ELBO is
+    pinned by the reference's elbo/*_masked vectors): loss, unmasked perf measures, every parameter gradient."""
+    inputs, targets = seeded_batch(B, 77, with_pose=False)
+    inputs, targets = [x.to(device) for x in inputs], [x.to(device) for x in targets]
+    gen = torch.Generator().manual_seed(5)
+    mask = (torch.rand(B, mask_channels, 64, 64, generator=gen) > 0.4).float().to(device)
+    eps, masks = seeded_noise(B, 256, 3, 4, 4321)
+    prob = SeqModeling(args(use_pose=False, mask_loss=True, no_cuda=(device == "cpu")), log_dir="/tmp/mmdyn_test_logs", fused=False)
+    m = prob.model
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 0))
+    m.noise = InjectedNoise(eps, masks)
+    prob._kl_weight = 0.3
+    x = {"model_input": inputs, "input_object_pose": None, "shock": None}
+    t = {"target_output": targets, "target_object_pose": None, "loss_mask": mask}
+    prob._optimizer.zero_grad()
+    outputs, loss = prob._evaluate_model(x, t)
+    loss.backward()
+    m2 = build("cnn-mvae", True, False, device)
+    step = MVAEStep(m2, noise=InjectedNoise(eps, masks))
+    if graphed:
+        floss = step.train_step_graphed(inputs, targets, 0.3, loss_mask=mask)
+        # (the captured step already applied Adam: compare the loss and the perf sums only)
+    else:
+        floss = step.forward(inputs, targets, 0.3, train=True, loss_mask=mask)
+        step.backward()
+    assert float(floss) == pytest.approx(float(loss.detach()), rel=2e-5)
+    npx = B * targets[0][0].numel()
+    acc = step.acc.cpu()
+    assert float(acc[3, 1]) / npx == pytest.approx(outputs["perf_measure"]["visual"], rel=1e-5)
+    assert float(acc[3, 2]) / npx == pytest.approx(outputs["perf_measure"]["tactile"], rel=1e-5)
+    assert float(acc[0, 1]) != pytest.approx(float(acc[3, 1]), rel=1e-3)          # the loss slots hold the masked sums
+    if not graphed:
+        for (k, p1), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
+            d = float((p1.grad - p2.grad).norm() / (p1.grad.norm() + 1e-12))
+            assert d < 1e-3, (k, d)
+    return step
+
+
+@pytest.mark.parametrize("mask_channels", [1, 3])
+def test_fused_engine_mask_loss(mask_channels):
+    check_fused_engine_mask_loss("cpu", mask_channels)
+
+
+def test_mask_loss_engine_selection_and_errors():
+    """--mask-loss runs the fused step when the model has no pose term; with --use-pose the reference fails on the (B, 7)
+    pose term (problems.py:445-447) and so does the engine."""
+    prob = SeqModeling(args(use_pose=False, mask_loss=True, no_cuda=True), log_dir="/tmp/mmdyn_test_logs")
+    assert prob._step is not None
+    prob = SeqModeling(args(use_pose=True, mask_loss=True, no_cuda=True), log_dir="/tmp/mmdyn_test_logs")
+    assert prob._step is None
+    inputs, targets = seeded_batch(2, 1)
+    step = MVAEStep(build("cnn-mvae", True, True, "cpu"))
+    with pytest.raises(ValueError):
+        step.forward(inputs, targets, 1.0, loss_mask=torch.ones(2, 1, 64, 64))
+    step = MVAEStep(build("cnn-mvae", True, False, "cpu"))
+    with pytest.raises(ValueError):
+        step.forward(inputs[:2], targets[:2], 1.0, loss_mask=torch.ones(2, 2, 64, 64))
+
+
 def check_extended_size_vs_oracle(device, size, B, use_pose=True, n_steps=2, precision="fp32", loss_tol=1e-4, grad_tol=1e-3):
     """The 128 / 256 pixel extensions (BASELINE configs[3] / configs[4]; no reference architecture exists for them, the
     reference's FC is fixed at 256*5*5: models/shapes.py): fused engine against the CPU oracle's restatement of the same

@@ -35,6 +35,29 @@ def test_fused_engine_exact_running_stats(golden_dir, fname, use_pose):
     T.check_fused_engine(golden_dir, DEV, fname, use_pose, exact=True)
 
 
+@pytest.mark.parametrize("mask_channels", [1, 3])
+def test_fused_engine_mask_loss(mask_channels):
+    T.check_fused_engine_mask_loss(DEV, mask_channels)
+
+
+def test_fused_engine_mask_loss_graph_replay():
+    """The masked step captured into HIP graphs: the first call (eager warm-up + capture) and a replay on a second mask."""
+    step = T.check_fused_engine_mask_loss(DEV, 1, B=4, graphed=True)
+    assert step._graph is not None
+    inputs, targets = seeded_batch(4, 77, with_pose=False)
+    inputs, targets = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+    ones = torch.ones(4, 1, 64, 64, device=DEV)
+    l_masked = float(step.train_step_graphed(inputs, targets, 0.3, loss_mask=torch.zeros_like(ones)))
+    acc0 = step.acc.cpu().clone()
+    float(step.train_step_graphed(inputs, targets, 0.3, loss_mask=ones))
+    acc1 = step.acc.cpu()
+    # an all-zero mask leaves log(2) per pixel in every image term; an all-one mask makes masked == unmasked sums
+    npx = 4 * 3 * 64 * 64
+    assert float(acc0[0, 1]) == pytest.approx(npx * np.log(2.0), rel=1e-5)
+    assert float(acc1[0, 1]) == pytest.approx(float(acc1[3, 1]), rel=1e-9)
+    assert np.isfinite(l_masked)
+
+
 def test_vae_config1(golden_dir):
     T.check_vae_config1(golden_dir, DEV)
 
