@@ -137,7 +137,7 @@ def check_fused_engine(golden_dir, device, fname, use_pose, exact=False):
                                        atol=2e-3 if n_steps > 1 else 2e-6, err_msg=k)
 
 
-def check_fused_engine_mask_loss(device, mask_channels, B=3, graphed=False):
+def check_fused_engine_mask_loss(device, mask_channels, B=3):
     """--mask-loss through the fused engine == the module path (seven... three model() calls + autograd, whose masked ELBO is
     pinned by the reference's elbo/*_masked vectors): loss, unmasked perf measures, every parameter gradient."""
     inputs, targets = seeded_batch(B, 77, with_pose=False)
@@ -157,23 +157,17 @@ def check_fused_engine_mask_loss(device, mask_channels, B=3, graphed=False):
     loss.backward()
     m2 = build("cnn-mvae", True, False, device)
     step = MVAEStep(m2, noise=InjectedNoise(eps, masks))
-    if graphed:
-        floss = step.train_step_graphed(inputs, targets, 0.3, loss_mask=mask)
-        # (the captured step already applied Adam: compare the loss and the perf sums only)
-    else:
-        floss = step.forward(inputs, targets, 0.3, train=True, loss_mask=mask)
-        step.backward()
+    floss = step.forward(inputs, targets, 0.3, train=True, loss_mask=mask)
+    step.backward()
     assert float(floss) == pytest.approx(float(loss.detach()), rel=2e-5)
     npx = B * targets[0][0].numel()
     acc = step.acc.cpu()
     assert float(acc[3, 1]) / npx == pytest.approx(outputs["perf_measure"]["visual"], rel=1e-5)
     assert float(acc[3, 2]) / npx == pytest.approx(outputs["perf_measure"]["tactile"], rel=1e-5)
     assert float(acc[0, 1]) != pytest.approx(float(acc[3, 1]), rel=1e-3)          # the loss slots hold the masked sums
-    if not graphed:
-        for (k, p1), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
-            d = float((p1.grad - p2.grad).norm() / (p1.grad.norm() + 1e-12))
-            assert d < 1e-3, (k, d)
-    return step
+    for (k, p1), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        d = float((p1.grad - p2.grad).norm() / (p1.grad.norm() + 1e-12))
+        assert d < 1e-3, (k, d)
 
 
 @pytest.mark.parametrize("mask_channels", [1, 3])

@@ -41,21 +41,32 @@ def test_fused_engine_mask_loss(mask_channels):
 
 
 def test_fused_engine_mask_loss_graph_replay():
-    """The masked step captured into HIP graphs: the first call (eager warm-up + capture) and a replay on a second mask."""
-    step = T.check_fused_engine_mask_loss(DEV, 1, B=4, graphed=True)
-    assert step._graph is not None
-    inputs, targets = seeded_batch(4, 77, with_pose=False)
+    """The masked step replayed from HIP graphs (device-side draws): the mask is a static input of the capture, so each
+    replay sees the mask of its call; masked / unmasked sums of the visual passes against torch on the step's own logits."""
+    import torch.nn.functional as F
+    B = 4
+    step = MVAEStep(T.build("cnn-mvae", True, False, DEV), noise=NoiseSource(3))
+    inputs, targets = seeded_batch(B, 77, with_pose=False)
     inputs, targets = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
-    ones = torch.ones(4, 1, 64, 64, device=DEV)
-    l_masked = float(step.train_step_graphed(inputs, targets, 0.3, loss_mask=torch.zeros_like(ones)))
-    acc0 = step.acc.cpu().clone()
-    float(step.train_step_graphed(inputs, targets, 0.3, loss_mask=ones))
-    acc1 = step.acc.cpu()
-    # an all-zero mask leaves log(2) per pixel in every image term; an all-one mask makes masked == unmasked sums
-    npx = 4 * 3 * 64 * 64
-    assert float(acc0[0, 1]) == pytest.approx(npx * np.log(2.0), rel=1e-5)
-    assert float(acc1[0, 1]) == pytest.approx(float(acc1[3, 1]), rel=1e-9)
-    assert np.isfinite(l_masked)
+    gen = torch.Generator().manual_seed(9)
+    masks = [(torch.rand(B, 1, 64, 64, generator=gen) > 0.5).float().to(DEV), torch.zeros(B, 1, 64, 64, device=DEV),
+             torch.ones(B, 1, 64, 64, device=DEV), (torch.rand(B, 1, 64, 64, generator=gen) > 0.2).float().to(DEV)]
+    step.train_step_graphed(inputs, targets, 0.3, loss_mask=masks[2])     # eager warm-up step + capture
+    for i, mk in enumerate(masks):
+        loss = float(step.train_step_graphed(inputs, targets, 0.3, loss_mask=mk))
+        assert np.isfinite(loss)
+        acc = step.acc.cpu()
+        lv, lt = step.last["logits_v"].view(2, B, 3, 64, 64), step.last["logits_t"].view(2, B, 3, 64, 64)
+        bce = lambda lg, tg, m: float(F.binary_cross_entropy_with_logits(lg * m, tg * m, reduction="sum"))
+        one = torch.ones_like(mk)
+        # pass slots: 0 = joint (visual + tactile terms), 1 = visual only, 2 = tactile only
+        for slot, terms in ((0, [(lv[0], targets[0]), (lt[0], targets[1])]), (1, [(lv[1], targets[0])]), (2, [(lt[1], targets[1])])):
+            assert float(acc[0, slot]) == pytest.approx(sum(bce(a, b, mk) for a, b in terms), rel=1e-5), (i, slot)
+            assert float(acc[3, slot]) == pytest.approx(sum(bce(a, b, one) for a, b in terms), rel=1e-5), (i, slot)
+    assert step._graph is not None and step._graph[0][-1] == (B, 1, 64, 64)
+    # a step without mask re-captures (different static inputs) and fills the plain slots only
+    step.train_step_graphed(inputs, targets, 0.3)
+    assert float(step.acc[3].abs().sum()) == 0.0
 
 
 def test_vae_config1(golden_dir):
