@@ -184,7 +184,7 @@ __global__ void bn_swish_fwd_kernel(const T* __restrict__ y, BnParams bp, T* __r
     const int64_t row = i / CV;
     const int g = (int)(row / rows_per_group);
     f32x4 v[NV], o[NV];
-    ldv<T>(y + i * V, v);
+    ldv_nt<T>(y + i * V, v);
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const int c0 = cv * V + q * 4;
@@ -195,7 +195,7 @@ __global__ void bn_swish_fwd_kernel(const T* __restrict__ y, BnParams bp, T* __r
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[q][k] = swishf_(ga[k] * ((v[q][k] - m[k]) * r[k]) + be[k]);
     }
-    stv<T>(a + i * V, o);
+    stv_nt<T>(a + i * V, o);
   }
 }
 
@@ -237,8 +237,8 @@ __global__ void bn_swish_bwd_apply_kernel(const T* __restrict__ da, const T* __r
     const int64_t row = i / CV;
     const int g = (int)(row / rows_per_group);
     f32x4 v[NV], d[NV], o[NV];
-    ldv<T>(y + i * V, v);
-    ldv<T>(da + i * V, d);
+    ldv_nt<T>(y + i * V, v);
+    ldv_nt<T>(da + i * V, d);
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const int c0 = cv * V + q * 4;
@@ -256,7 +256,7 @@ __global__ void bn_swish_bwd_apply_kernel(const T* __restrict__ da, const T* __r
         o[q][k] = ga[k] * r[k] * (du - s0[k] * inv_n - xh * (s1[k] * inv_n));
       }
     }
-    stv<T>(dy + i * V, o);
+    stv_nt<T>(dy + i * V, o);
   }
 }
 
