@@ -150,9 +150,9 @@ class MVAEStep:
 
     def __init__(self, model, lr=1e-3, pose_multiplier=1000.0, betas=(0.9, 0.999), eps=1e-8, noise=None,
                  process_group=None, world_size=1, two_lanes=True, precision="fp32", exact_running_stats=False, sync_bn=False):
-        if getattr(model, "conditional", False):
-            raise NotImplementedError("mmdyn_hip: the fused step is built for the unconditional cnn-mvae; run conditional "
-                                      "models through the module API (Problem(..., fused=False))")
+        # --conditional (vae.py:231-237, 286-291): the condition joins the 512 features in front of the image encoders' heads
+        # and the latent in front of the image decoders' first layer; the pose MLPs are built unconditional (vae.py:117-123)
+        self.conditional = bool(getattr(model, "conditional", False))
         if precision not in ("fp32", "bf16", "bf16s", "fp16"):
             raise ValueError("precision must be 'fp32' (the reference's arithmetic), 'bf16s' (bf16 activation storage + "
                              "bf16 matrix cores, fp32 accumulate / master weights: BASELINE configs[2]), 'bf16' (bf16 matrix-core "
@@ -230,7 +230,7 @@ class MVAEStep:
                                         w_dtype=torch.float32 if precision in ("fp32", "fp16") else torch.bfloat16)
         self._capturing = False
         self._graph = None
-        self._static_mask = None
+        self._static_mask = self._static_cond = None
 
     def close(self):
         """Drop the captured HIP graphs (and their memory pools).  Call before tearing down the process group of a
@@ -285,8 +285,15 @@ class MVAEStep:
             self.klw.fill_(float(kl_weight))
             self._klw_host = float(kl_weight)
 
-    def _begin(self, inputs, targets, kl_weight, train, loss_mask=None):
+    def _begin(self, inputs, targets, kl_weight, train, loss_mask=None, condition=None):
         self._set_kl_weight(kl_weight)
+        if self.conditional:
+            from .models.vae import _condition
+            condition = _condition(condition, True).to(torch.float32).contiguous()
+            if condition.dim() != 2 or condition.shape[0] != inputs[0].shape[0]:
+                raise ValueError(f"condition {tuple(condition.shape)} does not match the batch of {inputs[0].shape[0]}")
+        elif condition is not None:
+            raise ValueError("a condition was passed to an unconditional model")
         if loss_mask is not None:
             # torch.mul(recon_i, loss_mask) of problems.py:445-447: image-shaped, so the reference fails on the (B, 7) pose term
             if self.use_pose:
@@ -305,7 +312,7 @@ class MVAEStep:
                     "tg": {"v": targets[0].contiguous(), "t": targets[1].contiguous()},
                     "pose": inputs[2].contiguous() if self.use_pose else None,
                     "pose_tg": targets[2].contiguous() if self.use_pose else None,
-                    "kl_weight": float(kl_weight), "train": train, "pk": {}, "lmask": loss_mask}
+                    "kl_weight": float(kl_weight), "train": train, "pk": {}, "lmask": loss_mask, "cond": condition}
 
     def _passes_of(self, m):
         return self.pass_v if m == "v" else self.pass_t
@@ -341,7 +348,8 @@ class MVAEStep:
                                                                      c["pk"].get("e" + m))
         hd = torch.empty(n * B, 512, device=c["dev"])
         ops.B.dropout_expand(h, c["mask"][m], hd, n, B, 512, DROPOUT_P)
-        c["o" + m], c["h" + m] = layers.heads_forward(FP.sub(enc), hd, c["pk"].get("h" + m))
+        cond = None if c["cond"] is None else c["cond"].repeat(n, 1)           # the same condition rows for every pass
+        c["o" + m], c["h" + m] = layers.heads_forward(FP.sub(enc), hd, c["pk"].get("h" + m), cond=cond)
 
     def _ph_pose_enc(self):
         c, FP = self.ctx, self.params
@@ -362,8 +370,9 @@ class MVAEStep:
         c, FP, B = self.ctx, self.params, self.ctx["B"]
         dec, plist, live = self._MOD[m][1], self._dec_passes(m), self._passes_of(m)
         zz = torch.cat([c["z"][p] for p in plist])
+        cond = None if c["cond"] is None else c["cond"].repeat(len(plist), 1)
         lg, c["d" + m] = yield from layers.decoder_forward_steps(FP.sub(dec), self._buffers(dec), zz, len(plist),
-                                                                 packed=c["pk"].get("d" + m))
+                                                                 packed=c["pk"].get("d" + m), cond=cond)
         dl = torch.empty_like(lg) if c["train"] else None
         # every live pass of the modality against the same target: one launch, one loss slot per pass
         # (slot -1: exact_running_stats ran a pass whose reconstruction is discarded -- zero gradient, no loss)
@@ -455,12 +464,13 @@ class MVAEStep:
 
     # ------------------------------------------------------------------------------------------
     @_with_precision
-    def forward(self, inputs, targets, kl_weight, train=True, loss_mask=None):
+    def forward(self, inputs, targets, kl_weight, train=True, loss_mask=None, condition=None):
         """Runs the forward schedule and the loss; with train=True also fills the loss gradients needed by
         :meth:`backward`.  Returns the device scalar loss (fp32).  ``loss_mask`` ([B][1 or C][H][W], models without pose):
-        the reference's --mask-loss, multiplying logits and targets of every image term."""
+        the reference's --mask-loss, multiplying logits and targets of every image term.  ``condition`` ([B][condition_dim]):
+        the shock force of the --conditional models."""
         LN = self.lanes
-        self._begin(inputs, targets, kl_weight, train, loss_mask)
+        self._begin(inputs, targets, kl_weight, train, loss_mask, condition)
         self._ph_pre()
         LN.fork()
         self._ph_pack_late()
@@ -534,17 +544,17 @@ class MVAEStep:
                         self.betas[0], self.betas[1], self.eps, 1.0 / self.world)
 
     @_with_precision
-    def train_step(self, inputs, targets, kl_weight, loss_mask=None):
+    def train_step(self, inputs, targets, kl_weight, loss_mask=None, condition=None):
         """zero_grad -> forward -> backward -> (all-reduce) -> Adam, as problems.py:150-155.  Gradients are
         overwritten, not accumulated, so no zero_grad pass is needed."""
-        loss = self.forward(inputs, targets, kl_weight, train=True, loss_mask=loss_mask)
+        loss = self.forward(inputs, targets, kl_weight, train=True, loss_mask=loss_mask, condition=condition)
         handles = self.backward()
         self.optimizer_step(handles)
         return loss
 
     # ------------------------------------------------------------------------------------------
     @_with_precision
-    def train_step_graphed(self, inputs, targets, kl_weight, loss_mask=None):
+    def train_step_graphed(self, inputs, targets, kl_weight, loss_mask=None, condition=None):
         """Same as :meth:`train_step`, replayed from HIP graphs: the ~300 kernel launches of a step are captured
         once per batch shape (the KL weight is read from device memory).  Each phase is its OWN graph: the visual and the tactile phases are
         linear kernel chains that are launched concurrently on two streams (a single graph with parallel branches
@@ -554,17 +564,22 @@ class MVAEStep:
         count lives on the device, so every replay is a real optimiser step.  With more than one rank the gradient
         all-reduce and Adam run after the graphs."""
         if self._sync is not None and not self._sync_graph_ok:
-            return self.train_step(inputs, targets, kl_weight, loss_mask)      # (gloo: collectives cannot be captured)
+            return self.train_step(inputs, targets, kl_weight, loss_mask, condition)      # (gloo: collectives cannot be captured)
         key = tuple(tuple(x.shape) for x in inputs) + ((tuple(loss_mask.shape),) if loss_mask is not None else ())
+        if condition is not None:
+            from .models.vae import _condition
+            condition = _condition(condition, True).to(torch.float32)
+            key += (("cond",) + tuple(condition.shape),)
         self._set_kl_weight(kl_weight)
         if self._graph is None or self._graph[0] != key:
             self._static_in = [x.clone() for x in inputs]
             self._static_tg = [x.clone() for x in targets]
             self._static_mask = None if loss_mask is None else loss_mask.to(torch.float32).clone()
+            self._static_cond = None if condition is None else condition.clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                      # warm-up outside capture (allocator, lazy init)
-                self.train_step(self._static_in, self._static_tg, kl_weight, self._static_mask)
+                self.train_step(self._static_in, self._static_tg, kl_weight, self._static_mask, self._static_cond)
             torch.cuda.current_stream().wait_stream(side)
             self._graph = (key, self._capture(kl_weight))
             return self.loss             # the warm-up above WAS this call's optimiser step
@@ -573,6 +588,8 @@ class MVAEStep:
                 dst.copy_(src)
         if loss_mask is not None:
             self._static_mask.copy_(loss_mask.reshape(self._static_mask.shape))
+        if condition is not None:
+            self._static_cond.copy_(condition)
         handles = self._replay(self._graph[1])
         if self.pg is not None:
             # buckets 0 and 1 were reduced under the encoder backward graphs; the conv stacks' gradients go now
@@ -619,7 +636,7 @@ class MVAEStep:
         lanes_on, LN.on = LN.on, False            # inside a lane graph everything stays on the capture stream ...
         captured = []
         try:
-            self._begin(self._static_in, self._static_tg, kl_weight, True, self._static_mask)
+            self._begin(self._static_in, self._static_tg, kl_weight, True, self._static_mask, self._static_cond)
             for stage in stages:
                 row = []
                 for lane, fn in stage:
@@ -669,8 +686,8 @@ class MVAEStep:
 
     @torch.no_grad()
     @_with_precision
-    def eval_step(self, inputs, targets, kl_weight, loss_mask=None):
-        loss = self.forward(inputs, targets, kl_weight, train=False, loss_mask=loss_mask)
+    def eval_step(self, inputs, targets, kl_weight, loss_mask=None, condition=None):
+        loss = self.forward(inputs, targets, kl_weight, train=False, loss_mask=loss_mask, condition=condition)
         self.ctx = None
         return loss
 

@@ -176,11 +176,11 @@ class Problem:
             self._optimizer = FusedSGD(self._model.parameters(), lr=self.parameters['lr'], momentum=0.9, weight_decay=5e-4)
             return
         # the fused step takes the dict-shaped inputs of seq / dyn modeling (with the loss mask of --mask-loss when the model has
-        # no pose term) and has no condition input; everything else (plain reconstruction, --conditional, cnn-vae, regressor,
+        # no pose term, and the shock condition of --conditional); everything else (plain reconstruction, cnn-vae, regressor,
         # --mask-loss with --use-pose, which fails in the reference too: problems.py:445-447) runs the module path
         # (decided from the model that was actually built: 'cnn-mvae' with a single-modality --input-type is a plain VAE)
         from ..models.vae import MVAE
-        use_engine = (self._fused and isinstance(self._model, MVAE) and self._cross_modal and not self._conditional
+        use_engine = (self._fused and isinstance(self._model, MVAE) and self._cross_modal
                       and isinstance(self, SeqModeling)
                       and not (self.parameters.get('mask_loss') and self.parameters.get('use_pose')))
         precision = self.parameters.get('precision', 'fp32')
@@ -212,7 +212,8 @@ class Problem:
                 # on the GPU the step is replayed from HIP graphs (captured once per batch shape; the annealed KL weight
                 # is read from device memory); the emulation has no graphs
                 run = self._step.train_step_graphed if self._device.type == 'cuda' else self._step.train_step
-                loss = run(*self._fused_io(inputs, targets), self._kl_weight, loss_mask=self._fused_mask(targets))
+                loss = run(*self._fused_io(inputs, targets), self._kl_weight, loss_mask=self._fused_mask(targets),
+                           condition=inputs.get('shock') if self._conditional else None)
                 if dev_loss is None:
                     dev_loss, dev_acc = torch.zeros_like(loss, dtype=torch.float64), torch.zeros_like(self._step.acc)
                 dev_loss += loss.detach().to(torch.float64)
@@ -249,7 +250,8 @@ class Problem:
                 inputs, targets = self.parse_input(data_input, data_target)
                 if self._step is not None and self._fused_applicable(inputs):
                     loss = self._step.eval_step(*self._fused_io(inputs, targets), self._kl_weight,
-                                                loss_mask=self._fused_mask(targets))
+                                                loss_mask=self._fused_mask(targets),
+                                                condition=inputs.get('shock') if self._conditional else None)
                     outputs = {'perf_measure': self._fused_perf()}
                 else:
                     outputs, loss = self._evaluate_model(inputs, targets)

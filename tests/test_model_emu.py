@@ -385,13 +385,47 @@ def test_conditional_mvae(golden_dir):
     check_conditional(golden_dir, "cpu")
 
 
+def check_fused_engine_conditional(golden_dir, device):
+    """The same --conditional step through the fused engine: loss, means, pose reconstruction and every parameter gradient
+    against the reference's vectors; a condition is required, and refused by an unconditional model."""
+    g = load(golden_dir, "mvae_conditional_B2.npz")
+    B = int(g["batch"])
+    kw = dict(MODEL_KW)
+    kw.update(conditional=True, condition_dim=3, use_pose=True)
+    m = setup_model("cnn-mvae", cross_modal=True, **kw)
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 0))
+    m.to(device).train()
+    inputs, targets = seeded_batch(B, 321)
+    inputs, targets = [t.to(device) for t in inputs], [t.to(device) for t in targets]
+    eps, masks = seeded_noise(B, 256, 7, 8, 77)
+    cond = torch.tensor(g["cond"]).to(device)
+    step = MVAEStep(m, noise=InjectedNoise(eps, masks))
+    loss = step.forward(inputs, targets, float(g["kl_weight"]), train=True, condition=cond)
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-4)
+    np.testing.assert_allclose(step.last["means"].cpu().numpy(), g["means"], rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(step.last["recon_x"][2].cpu().numpy(), g["recon2"], rtol=1e-4, atol=3e-5)
+    step.backward()
+    for k, p_ in m.named_parameters():
+        close_summary(summarize(p_.grad.cpu()), g["grad/" + k], 1e-3, "grad " + k)
+    with pytest.raises(ValueError):
+        step.forward(inputs, targets, 1.0)
+    with pytest.raises(ValueError):
+        MVAEStep(build("cnn-mvae", True, True, device)).forward(inputs, targets, 1.0, condition=cond)
+    return step, inputs, targets, cond
+
+
+def test_fused_engine_conditional(golden_dir):
+    check_fused_engine_conditional(golden_dir, "cpu")
+
+
 def check_conditional_loops(tmp_path, no_cuda):
-    """--conditional through Problem.train(): cnn-mvae (shock-conditioned, module API) and cnn-vae with the SGD option."""
+    """--conditional through Problem.train(): cnn-mvae (shock-conditioned: the fused step) and cnn-vae with the SGD option
+    (module API)."""
     for i, over in enumerate((dict(model_name="cnn-mvae"), dict(model_name="cnn-vae", input_type="visual", optimizer="SGD"))):
         prob = SeqModeling(args(num_epochs=1, no_cuda=no_cuda, conditional=True, batchsize=2, **over),
                            log_dir=str(tmp_path / str(i)), train_loader=SyntheticVisuoTactile(2, 2, shock_dim=3),
                            test_loader=SyntheticVisuoTactile(1, 2, seed=7, shock_dim=3))
-        assert prob.condition_dim == 3 and prob._step is None
+        assert prob.condition_dim == 3 and (prob._step is not None) == (i == 0)
         before = {k: v.detach().clone() for k, v in prob.model.state_dict().items()}
         prob.train()
         after = prob.model.state_dict()

@@ -77,6 +77,23 @@ def test_conditional_mvae(golden_dir):
     T.check_conditional(golden_dir, DEV)
 
 
+def test_fused_engine_conditional(golden_dir):
+    """--conditional through the fused engine against the reference's vectors; then the same step captured into HIP graphs
+    (the condition is a static input of the capture): a replay with another condition changes the loss."""
+    T.check_fused_engine_conditional(golden_dir, DEV)
+    m = T.setup_model("cnn-mvae", cross_modal=True, **dict(T.MODEL_KW, conditional=True, condition_dim=3, use_pose=True))
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 0))
+    m.to(DEV).train()
+    step = MVAEStep(m, noise=NoiseSource(2), lr=0.0)
+    inputs, targets = seeded_batch(4, 321)
+    inputs, targets = [t.to(DEV) for t in inputs], [t.to(DEV) for t in targets]
+    c0, c1 = torch.zeros(4, 3, device=DEV), torch.full((4, 3), 2.0, device=DEV)
+    step.train_step_graphed(inputs, targets, 1.0, condition=c0)
+    la = float(step.train_step_graphed(inputs, targets, 1.0, condition=c0))
+    lb = float(step.train_step_graphed(inputs, targets, 1.0, condition=c1))
+    assert step._graph is not None and np.isfinite(la) and np.isfinite(lb) and abs(la - lb) > 1e-3 * abs(la)
+
+
 def test_dyn_modeling_and_cli(tmp_path):
     T.check_dyn_modeling_and_cli(tmp_path, no_cuda=False)
 
