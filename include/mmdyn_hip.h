@@ -338,8 +338,10 @@ int mmdyn_resize_u8_to_chw_f32(const uint8_t* src, const int* index, float* dst,
  *   mmdyn_igemm_nt_mx : mmdyn_igemm_nt / _dgrad_bn with per-tensor storage flags --
  *       bit 0 bf16 matrix cores (required when any other bit is set), bit 1 A is bf16 (not IM2COL3), bit 2 C and
  *       C_act are bf16, bit 3 the BatchNorm-backward operand y is bf16, bit 4 the packed weights Bp are bf16
- *       (mmdyn_pack_conv_weight_b16 / mmdyn_repack2d_ld_b16 / a dst_bf16 plan entry).  y == NULL: plain GEMM
- *       epilogue.  Split-K (fp32 workspace) is allowed with a bf16 A, not with a bf16 C.
+ *       (mmdyn_pack_conv_weight_b16 / mmdyn_repack2d_ld_b16 / a dst_bf16 plan entry), bit 6 C_act alone is bf16 (C stays
+ *       fp32: the Linear layer whose activated output feeds the first transposed convolution, vae.py:264-271; not with
+ *       bit 2 or split-K).  y == NULL: plain GEMM epilogue.  Split-K (fp32 workspace) is allowed with a bf16 A, not with a
+ *       bf16 C.
  *   mmdyn_wgrad_tn_mx : bit 0 as above, bit 1 D is bf16, bit 2 Gt is bf16 (not IM2COL3).
  *   *_b16             : the element-wise kernels on bf16 activation tensors. */
 int mmdyn_igemm_nt_mx(const void* A, const void* Bp, const float* bias, void* C, void* C_act, float* stats,

@@ -27,6 +27,7 @@ struct IgemmGeom {
   const float* bn_beta;   // [N]
   // bf16 activation storage (bf16 matrix-core variants only): which of the activation tensors are bf16 in HBM
   int a_b16, c_b16, bny_b16;
+  int cact_b16;   // the second (activated) output is bf16 while C itself is fp32
   int f16;     // 16-bit matrix-core mode uses fp16 operands (v_mfma_f32_32x32x16_f16) instead of bf16; fp32 storage only
   int b_b16;   // packed weights are bf16 (written so by the pack kernels in the bf16 modes: half the L2 -> LDS traffic)
 };

@@ -57,7 +57,7 @@ __device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, r);
 }
 template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16, bool B16, bool WIDE = false, bool M16 = false,
-          bool F16 = false>
+          bool F16 = false, bool ONEPX = false>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__ A,
                                                        const float* __restrict__ Bp,
                                                        const float* __restrict__ bias,
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
                                                        float* __restrict__ stats, float* __restrict__ ws,
                                                        const IgemmGeom g) {
   static_assert(!M16 || !BF16, "the 16x16x4 shape is the fp32 variant");
+  static_assert(!ONEPX || MODE == MMDYN_TCONV_S1P0, "one output pixel per block is a variant of the k4 s1 p0 walk");
   static_assert(!F16 || (BF16 && !A16 && !B16 && !WIDE), "fp16 operands: 16-bit matrix cores on fp32 storage");
   constexpr int TS = M16 ? 16 : 32;                   // side of one MFMA output tile
   constexpr int NE = M16 ? 4 : 16;                    // accumulator registers per tile
@@ -108,16 +109,25 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   // to (1+4)*(1+4) = 25, so every block does identical work.
   // (g.s1p0_split = 2: the quad walk is shared by TWO blocks, {(h,w),(h+4,w+4)} and {(h+4,w),(h,w+4)} -- 8..17 valid taps
   // each instead of a uniform 25, but twice the blocks in flight: used by the latency-bound bf16 variants)
-  const int nsub = (MODE == MMDYN_TCONV_S1P0) ? 4 / g.s1p0_split : 1;
-  const int qtile = (MODE == MMDYN_TCONV_S1P0) ? tile / g.s1p0_split : tile;          // tile index inside the quad
-  const int qhalf = (MODE == MMDYN_TCONV_S1P0) ? tile - qtile * g.s1p0_split : 0;
+  // (ONEPX: ONE pixel per block, 1..16 taps of work, pixels dealt heaviest first -- along each axis 3,4,2,5,1,6,0,7 with
+  // 4,4,3,3,2,2,1,1 valid taps -- so the blocks that finish a launch are the light ones.  Without the four-pixel loop
+  // around the K loop and the epilogue the kernel needs about half the registers.)
+  const int nsub = (MODE == MMDYN_TCONV_S1P0 && !ONEPX) ? 4 / g.s1p0_split : 1;
+  const int qtile = (MODE == MMDYN_TCONV_S1P0 && !ONEPX) ? tile / g.s1p0_split : tile;          // tile index inside the quad
+  const int qhalf = (MODE == MMDYN_TCONV_S1P0 && !ONEPX) ? tile - qtile * g.s1p0_split : 0;
   for (int ksub = 0; ksub < nsub; ++ksub) {
   const int sub = (MODE == MMDYN_TCONV_S1P0 && g.s1p0_split == 2) ? (qhalf ? (ksub ? 2 : 1) : (ksub ? 3 : 0)) : ksub;
   int px_y = 0, px_x = 0, kh0 = 0, kw0 = 0, nkh = 4, nkw = 4;
   if (MODE == MMDYN_TCONV_S1P0) {
     const int quad = qtile / g.tiles_per_pixel;
-    px_y = (quad >> 2) + 4 * (sub >> 1);
-    px_x = (quad & 3) + 4 * (sub & 1);
+    if constexpr (ONEPX) {
+      const int iy = quad >> 3, ix = quad & 7;
+      px_y = (iy & 1) ? 4 + (iy >> 1) : 3 - (iy >> 1);
+      px_x = (ix & 1) ? 4 + (ix >> 1) : 3 - (ix >> 1);
+    } else {
+      px_y = (quad >> 2) + 4 * (sub >> 1);
+      px_x = (quad & 3) + 4 * (sub & 1);
+    }
     kh0 = max(0, px_y - (g.Hi - 1));
     kw0 = max(0, px_x - (g.Wi - 1));
     nkh = min(3, px_y) - kh0 + 1;
@@ -493,7 +503,16 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
               }
             } else {
               C[(size_t)ooff + col] = v;
-              if (g.want_act_out) C_act[(size_t)ooff + col] = apply_act(v, g.act);
+              if (g.want_act_out) {
+                if (BF16 && g.cact_b16) {       // fp32 pre-activation, bf16 activated output (FC level -> conv level)
+                  const float av = apply_act(v, g.act);
+                  const float an = __shfl_down(av, 1, 64);
+                  if (!(cl & 1))
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C_act) + (size_t)ooff + col) = pack2_bf16(av, an);
+                } else {
+                  C_act[(size_t)ooff + col] = apply_act(v, g.act);
+                }
+              }
             }
           }
         }
@@ -602,6 +621,21 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
     g.s1p0_split = bf16 ? 2 : 1;
     g.tiles_per_group = 16 * g.tiles_per_pixel * g.s1p0_split;   // 16 pixel quads per group, 4 pixels walked per block (pair)
   }
+  // all-bf16 operands (the 64-channel K-step variant) with >= 2048 blocks: ONE output pixel per block (ONEPX at the kernel).
+  // Measured on 4 x 256 samples, 256 -> 128 channels: 79 us against 96 us for the pair walk (4 x 128 samples, 1024 blocks:
+  // 65 vs 59 us, stays on the pair walk).  fp32: the balanced quad walk wins (325 vs 376 us).  MMDYN_S1P0_SPLIT=2 / 4 force
+  // the pair walk / one pixel per block for the bf16 variants (kernel experiments).
+  bool onepx = false;
+  if (MODE == MMDYN_TCONV_S1P0 && bf16 && !g.f16 && g.a_b16 && g.b_b16 && g.Cin % 64 == 0) {
+    const char* e = getenv("MMDYN_S1P0_SPLIT");
+    const int forced = e ? atoi(e) : 0;
+    const long blocks1 = (long)g.G * 64 * g.tiles_per_pixel * (g.N / BN);
+    if (forced == 4 || (forced == 0 && blocks1 >= 2048)) {
+      onepx = true;
+      g.s1p0_split = 4;
+      g.tiles_per_group = 64 * g.tiles_per_pixel;
+    }
+  }
   const int mx8 = (g.G * g.tiles_per_group + 7) / 8 * 8;
   dim3 grid((unsigned)mx8 * (g.N / BN) * g.nclasses * g.splitk);
   // fp32: 16x16x4 MFMA tiles (see the M16 note at the kernel) where the per-shape sweep of the step's launches shows a win
@@ -620,7 +654,11 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, BF, A16_, B16_>), grid, dim3(256), smem, st, A, Bp, bias, C, \
                      C_act, stats, ws, g)
   constexpr bool CAN_A16 = MODE != MMDYN_IM2COL3;
-  if (m16)
+  constexpr bool S1P0 = MODE == MMDYN_TCONV_S1P0;
+  if (S1P0 && onepx)
+    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, CAN_A16, true, CAN_A16, false, false, S1P0>), grid, dim3(256),
+                       smem, st, A, Bp, bias, C, C_act, stats, ws, g);
+  else if (m16)
     hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, false, false, false, false, M16_TILE>), grid, dim3(256), smem, st, A,
                        Bp, bias, C, C_act, stats, ws, g);
   else if (!bf16) IGEMM_LAUNCH(false, false, false);
@@ -753,7 +791,9 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   g.bny_b16 = (storage_flags & 8) != 0;
   g.b_b16 = (storage_flags & 16) != 0;
   g.f16 = (storage_flags & 32) != 0;
+  g.cact_b16 = (storage_flags & 64) != 0;
   if (g.f16 && (storage_flags & ~32)) return MMDYN_ERR_SHAPE;          // fp16 operands: fp32 storage on both sides
+  if (g.cact_b16 && (g.c_b16 || !C_act || splitk > 1 || (N & 1))) return MMDYN_ERR_SHAPE;
   if (storage_flags && (!bf16 || (g.c_b16 && splitk > 1) || (g.a_b16 && mode == MMDYN_IM2COL3))) return MMDYN_ERR_SHAPE;
   g.want_act_out = C_act != nullptr;
   g.splitk = splitk;

@@ -47,16 +47,17 @@ def _cdiv(a, b):
 # ------------------------------------------------------------------------------------------------
 # primitive helpers
 # ------------------------------------------------------------------------------------------------
-def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch.float32):
+def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch.float32, act_dtype=None):
     """C = A[rows][K] . Bp[N][K]^T (+bias) on the MFMA GEMM; picks split-K for short, wide-K problems.
-    Returns (pre_activation, activated or None)."""
+    Returns (pre_activation, activated or None).  ``act_dtype``: storage type of the activated output alone (bf16 when it
+    feeds a convolution of the bf16-storage mode; only without split-K)."""
     C = _new(A, rows, N, dtype=out_dtype)
-    Ca = _new(A, rows, N, dtype=out_dtype) if want_act else None
+    Ca = _new(A, rows, N, dtype=out_dtype if act_dtype is None else act_dtype) if want_act else None
     # split-K only when the 64x64 tiling leaves most of the 256 CUs idle AND K is long enough to amortise the
     # partial-sum pass (measured: tests/microbench/sweep_dense.py)
     tiles = _cdiv(rows, 64) * _cdiv(N, 64)
     steps = K // 32
-    splitk = max(1, min(512 // tiles, steps // 8)) if (N % 64 == 0 and out_dtype == torch.float32) else 1
+    splitk = max(1, min(512 // tiles, steps // 8)) if (N % 64 == 0 and out_dtype == torch.float32 and act_dtype is None) else 1
     # (kept in the 16-bit matrix-core modes too: without it bf16s bs 128 measured 2.45 vs 2.31 ms per step)
     if splitk > 1:
         ws = _new(A, splitk, rows, N)
@@ -592,7 +593,10 @@ def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, co
     if cond is not None or L != L0:
         z = concat_condition(z, cond, L)          # [z | c | 0]  (vae.py:286-291)
     c = {"Bt": Bt, "G": G, "Bg": Bg, "L": L, "L0": L0, "Lc": Lc, "z": z, "pk": pk, "S": S, "last": last}
-    u0, h0 = dense(z, pk["Wu"], pk["bu"], Bt, L, FEAT, ACT_SWISH, want_act=True)      # rows -> hw*256+c
+    # rows -> hw*256+c.  bf16 storage mode: the activated output is the first transposed convolution's operand and is stored
+    # as such (the matrix cores round it to bf16 either way); the pre-activation stays fp32 for the backward
+    u0, h0 = dense(z, pk["Wu"], pk["bu"], Bt, L, FEAT, ACT_SWISH, want_act=True,
+                   act_dtype=ACT_DTYPE if ACT_DTYPE != torch.float32 else None)
     yield
     stages, a, H = [], h0, 5
     for j, i in enumerate(convs):

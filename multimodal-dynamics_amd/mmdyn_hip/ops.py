@@ -80,13 +80,14 @@ class HipBackend:
                  offset, act, splitk):
         (pa, a16), (pc, c16), (pca, ca16), (pb, b16) = _aptr(A), _aptr(C), _aptr(C_act), _aptr(Bp)
         if a16 or c16 or ca16 or b16:      # bf16 activation storage / bf16 packed weights: the mixed-storage entry point
-            if self.precision == "fp32" or (c16 and splitk != 1) or (C_act is not None and ca16 != c16):
+            mixed_out = C_act is not None and ca16 and not c16       # fp32 pre-activation + bf16 activated output
+            if self.precision == "fp32" or ((c16 or mixed_out) and splitk != 1) or (C_act is not None and c16 and not ca16):
                 raise ValueError("mmdyn_hip: bf16 tensors need a bf16 precision mode, no split-K into a "
-                                 "bf16 output, and C / C_act of one type")
+                                 "bf16 output, and a bf16 C only with a bf16 C_act")
             check(self.lib.mmdyn_igemm_nt_mx(pa, pb, _ptr(bias), pc, pca, _ptr(stats), _ptr(ws), None, None, None,
                                              None, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act,
-                                             splitk, 1 | (2 if a16 else 0) | (4 if c16 else 0) | (16 if b16 else 0),
-                                             _stream()), "mmdyn_igemm_nt_mx")
+                                             splitk, 1 | (2 if a16 else 0) | (4 if c16 else 0) | (16 if b16 else 0) |
+                                             (64 if mixed_out else 0), _stream()), "mmdyn_igemm_nt_mx")
             return
         fn = {"fp32": self.lib.mmdyn_igemm_nt, "fp16": self.lib.mmdyn_igemm_nt_f16}.get(self.precision,
                                                                                          self.lib.mmdyn_igemm_nt_bf16)

@@ -594,6 +594,36 @@ def test_bf16_packed_weights(bf16_mode):
                       32, 32, 32, 1, 0, 1, 1], [3, 4])
 
 
+def test_igemm_bf16_mixed_output_and_one_pixel_walk(monkeypatch):
+    """(i) A Linear layer whose activated output alone is bf16 (fp32 pre-activation for the backward, bf16 operand for the
+    convolution behind it: storage flag bit 6).  (ii) The k4 s1 p0 transposed convolution on all-bf16 operands in its three
+    block walks -- pairs of pixels (default below 2048 blocks), one pixel per block (default from 2048 blocks on, forced
+    here on a small launch too) -- with bias, BatchNorm partial sums and ragged sample counts."""
+    f32 = lambda i, t: t.float()
+    HIP.precision = EMU.precision = "bf16s"
+    try:
+        for rows, K, N in ((300, 256, 6400), (37, 288, 640)):
+            A, Bp, bias = rnd(rows, K, seed=120), bf(rnd(1, N, K, seed=121, scale=0.2)), rnd(N, seed=122)
+            both("igemm_nt", [A, Bp, bias, torch.zeros(rows, N), torch.zeros(rows, N, dtype=torch.bfloat16), None, None, DENSE, 1,
+                              rows, 1, 1, K, 1, 1, N, N, 1, 0, 1, 1], [3, 4], f32, tol=4e-3)
+        with pytest.raises(ValueError):      # a bf16 pre-activation next to an fp32 activated output is not a storage layout
+            HIP.igemm_nt(A.to(DEV), Bp.to(DEV), None, torch.zeros(rows, N, dtype=torch.bfloat16, device=DEV),
+                         torch.zeros(rows, N, device=DEV), None, None, DENSE, 1, rows, 1, 1, K, 1, 1, N, N, 1, 0, 1, 1)
+        post = lambda i, t: t.float().sum(1) if t.dim() == 4 else t.float()
+        for forced, G, Bg in ((None, 4, 256), ("2", 4, 256), ("4", 2, 70), (None, 2, 70), ("4", 1, 5)):
+            if forced is None:
+                monkeypatch.delenv("MMDYN_S1P0_SPLIT", raising=False)
+            else:
+                monkeypatch.setenv("MMDYN_S1P0_SPLIT", forced)
+            Bt = G * Bg
+            A, Bp, bias = bf(rnd(Bt * 25, 256, seed=123)), bf(rnd(16, 128, 256, seed=124, scale=0.1)), rnd(128, seed=125)
+            T = HIP.igemm_stat_tiles(TCONV_S1P0, G, Bg, 5, 5, 256, 8, 8, 128)
+            both("igemm_nt", [A, Bp, bias, torch.zeros(Bt * 64, 128, dtype=torch.bfloat16), None, torch.zeros(G, T, 2, 128), None,
+                              TCONV_S1P0, G, Bg, 5, 5, 256, 8, 8, 128, 128, 1, 0, 0, 1], [3, 5], post, tol=4e-3)
+    finally:
+        HIP.precision = EMU.precision = "fp32"
+
+
 def test_bce_logits_groups_equals_per_pass_launches():
     """One launch for all decoder passes of a modality (shared target, one loss slot per pass, a discarded pass marked by
     slot -1) against one mmdyn_bce_logits per pass."""
