@@ -91,12 +91,25 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   // XCD-aware block order (speed only): workgroups are dealt round-robin over the 8 XCDs, each with its own L2.
   // All blocks that read the same rows of A -- the N-tiles and the output-parity classes of one M-tile -- get
   // linear ids that are equal modulo 8, i.e. the same XCD, so the tile's activations are fetched into one L2.
+  // Fewer than 5 M-tiles (a 256-row Linear layer has 4): dealing M-tiles to XCDs would leave XCDs idle, so each M-tile's
+  // N-tiles are spread over 8 / MXp XCDs instead (MXp = M-tiles rounded up to a power of two).
   const int NY = g.N / BN, S = NY * g.nclasses;
   const int MX = g.G * g.tiles_per_group, MX8 = (MX + 7) >> 3;
   const int L = blockIdx.x;
   const int m_lo = L & 7, r8 = L >> 3;
-  const int inner = r8 % S, rest = r8 / S;
-  const int mx = (rest % MX8) * 8 + m_lo, split = rest / MX8;
+  int inner, mx, split;
+  if (MX > 4) {
+    const int rest = r8 / S;
+    inner = r8 % S;
+    mx = (rest % MX8) * 8 + m_lo;
+    split = rest / MX8;
+  } else {
+    const int MXp = MX > 2 ? 4 : MX, nparts = 8 / MXp, Sp = (S + nparts - 1) / nparts;
+    mx = m_lo % MXp;
+    inner = (r8 % Sp) * nparts + m_lo / MXp;
+    split = r8 / Sp;
+    if (inner >= S) return;
+  }
   if (mx >= MX) return;
   const int grp = mx / g.tiles_per_group, tile = mx - grp * g.tiles_per_group;
   const int cls = inner / NY;
@@ -636,8 +649,13 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
       g.tiles_per_group = 64 * g.tiles_per_pixel;
     }
   }
-  const int mx8 = (g.G * g.tiles_per_group + 7) / 8 * 8;
-  dim3 grid((unsigned)mx8 * (g.N / BN) * g.nclasses * g.splitk);
+  const int mx_total = g.G * g.tiles_per_group, mx8 = (mx_total + 7) / 8 * 8;
+  const int s_inner = (g.N / BN) * g.nclasses;
+  dim3 grid((unsigned)mx8 * s_inner * g.splitk);
+  if (mx_total <= 4) {          // few M-tiles: the kernel spreads each M-tile's N-tiles over several XCDs (see its block order)
+    const int mxp = mx_total > 2 ? 4 : mx_total, nparts = 8 / mxp;
+    grid = dim3((unsigned)8 * ((s_inner + nparts - 1) / nparts) * g.splitk);
+  }
   // fp32: 16x16x4 MFMA tiles (see the M16 note at the kernel) where the per-shape sweep of the step's launches shows a win
   // (profiles/r2/igemm_mfma_shape_sweep.txt): large launches (>= 2048 blocks, >= 8 K-steps) of every block tile but
   // 128x128: +3..6 % there, -2..4 % on the small encoder-side launches, which keep the 32x32x2 shape.
