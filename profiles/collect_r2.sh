@@ -34,6 +34,7 @@ else
   python3 $R/bench.py --image-size 128 --problem dyn_modeling --batch 128 --dtype bf16s --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_c3_dyn128_b128_bf16s.json 2>> $O/part3.err
   python3 $R/bench.py --image-size 256 --dtype fp16 --batch 256 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c4_256_fp16_b256.json 2>> $O/part3.err
   python3 $R/bench.py --image-size 256 --batch 64 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c4_256_f32_b64.json 2>> $O/part3.err
+  python3 $R/bench.py --image-size 256 --dtype bf16s --batch 256 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c4_256_bf16s_b256.json 2>> $O/part3.err
   python3 $R/bench.py --dtype fp16 --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_c1_fp16.json 2>> $O/part3.err
   python3 $R/bench.py --infer --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_infer.json 2>> $O/part3.err
   python3 $R/bench.py --image-size 128 --problem dyn_modeling --batch 128 --breakdown --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2> $O/bench_c3_event_breakdown.txt
