@@ -39,3 +39,8 @@ struct IgemmGeom {
 int mmdyn_igemm_d16_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats,
                         float* ws, IgemmGeom g, int stride, int offset, hipStream_t st);
 int mmdyn_igemm_d16_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
+
+// tconv_patch.hip: patch-resident k4 s2 p1 transposed convolution (fp32, 16x16x64 -> 32x32x32).  Same protocol as the d16 hooks.
+int mmdyn_tconv_patch_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
+                          const IgemmGeom& g, hipStream_t st);
+int mmdyn_tconv_patch_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);

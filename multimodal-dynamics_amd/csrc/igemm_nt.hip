@@ -768,6 +768,8 @@ static int lds_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int 
 // fp32 launches go to the wave-independent kernels of igemm_d16.hip where those serve the shape; the bf16 matrix-core
 // modes always take the LDS-tiled kernels of this file.  The number of partial-sum tiles follows the kernel.
 extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+  const int tp = mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  if (tp > 0) return tp;
   const int t = mmdyn_igemm_d16_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   return t > 0 ? t : lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
 }
@@ -865,6 +867,10 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   if (mode == MMDYN_IM2COL3) {     // the 3-channel layers have their own direct kernel (conv3.hip)
     const int rc = mmdyn_conv3_nt_try(A, Bp, bias, C, C_act, stats, G, Bg, Hi, Wi, Ho, Wo, N, ldc, act, splitk, bn_y,
                                       bn_mean, bn_rstd, bn_gamma, bn_beta, g.c_b16, g.bny_b16, g.b_b16, st);
+    if (rc != 1) return rc;
+  }
+  if (!bf16 && mode == MMDYN_TCONV_S2P1) {     // the 64 -> 32 channel up-sampling layer has a patch-resident kernel (tconv_patch.hip)
+    const int rc = mmdyn_tconv_patch_try(A, Bp, bias, C, C_act, stats, ws, g, st);
     if (rc != 1) return rc;
   }
   if (!bf16 && mode != MMDYN_IM2COL3) {

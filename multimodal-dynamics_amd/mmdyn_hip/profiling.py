@@ -23,6 +23,10 @@ def _canon(name, a):
     if name == "igemm_nt" and a[7] == ops.IM2COL3 and a[10] in (64, 128, 256) and \
             tuple(a[10:17]) == (a[10], a[10], 64, a[10] // 2, a[10] // 2, 32, 32):
         return "conv3_nt", a
+    # ... and so does the 64 -> 32 channel transposed convolution on 16x16 inputs in fp32 (csrc/tconv_patch.hip)
+    if name == "igemm_nt" and a[7] == ops.TCONV_S2P1 and tuple(a[10:16]) == (16, 16, 64, 32, 32, 32) and \
+            getattr(ops.B, "precision", "fp32") == "fp32" and all(not torch.is_tensor(t) or t.dtype == torch.float32 for t in a[:4]):
+        return "tconv_patch", a
     if name == "wgrad_tn" and a[3] == ops.IM2COL3 and a[8] in (64, 128, 256) and \
             tuple(a[5:11]) == (a[8] // 2, a[8] // 2, 32, a[8], a[8], 64):
         return "conv3_wgrad", a
@@ -30,7 +34,7 @@ def _canon(name, a):
 
 
 def _flops(name, a):
-    if name in ("igemm_nt", "conv3_nt"):
+    if name in ("igemm_nt", "conv3_nt", "tconv_patch"):
         (mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) = a[7:16]
         if mode == ops.DENSE:
             return 2.0 * G * Bg * Ho * Wo * N * Cin
@@ -81,7 +85,7 @@ class TimedBackend:
             r = fn(*a, **k)
             e.record()
             name, ca = _canon(attr, a)
-            sig = tuple(x for x in ca if isinstance(x, (int, bool))) if name in ("igemm_nt", "wgrad_tn", "conv3_nt", "conv3_wgrad") else ()
+            sig = tuple(x for x in ca if isinstance(x, (int, bool))) if name in ("igemm_nt", "wgrad_tn", "conv3_nt", "conv3_wgrad", "tconv_patch") else ()
             if attr == "igemm_nt_dgrad_bn":
                 sig = sig + ("bn_bwd_epilogue",)
             self.records.append((name, _flops(name, ca), _bytes(ca), s, e, sig))

@@ -624,6 +624,29 @@ def test_igemm_bf16_mixed_output_and_one_pixel_walk(monkeypatch):
         HIP.precision = EMU.precision = "fp32"
 
 
+@pytest.mark.parametrize("G,Bg", [(2, 3), (1, 1), (4, 37)])
+def test_tconv_patch_kernel(G, Bg):
+    """ConvTranspose2d(64, 32, 4, 2, 1) on 16x16 inputs runs the patch-resident kernel (tconv_patch.hip: the input of an image
+    staged in LDS once for all parity classes and taps) in every fp32 launch form: BatchNorm partial sums (one tile per
+    image), bias + Swish second output, and the input-gradient form with the BatchNorm+Swish backward epilogue."""
+    Bt = G * Bg
+    x = rnd(Bt * 256, 64, seed=130)
+    Bp = rnd(16, 32, 64, seed=131, scale=0.1)
+    rows = Bt * 1024
+    T = HIP.igemm_stat_tiles(TCONV_S2P1, G, Bg, 16, 16, 64, 32, 32, 32)
+    assert T == Bg
+    post = lambda i, t: t.sum(1) if t.dim() == 4 else t
+    both("igemm_nt", [x, Bp, None, torch.zeros(rows, 32), None, torch.zeros(G, T, 2, 32), None, TCONV_S2P1, G, Bg, 16, 16, 64, 32, 32,
+                      32, 32, 1, 0, 0, 1], [3, 5], post)
+    both("igemm_nt", [x, Bp, rnd(32, seed=132), torch.zeros(rows, 32), torch.zeros(rows, 32), None, None, TCONV_S2P1, G, Bg, 16, 16,
+                      64, 32, 32, 32, 32, 1, 0, 1, 1], [3, 4])
+    y = rnd(rows, 32, seed=133) * 1.5 + 0.2
+    mean, rstd = rnd(G, 32, seed=134) * 0.3, rnd(G, 32, seed=135).abs() + 0.5
+    gamma, beta = rnd(32, seed=136) + 1.2, rnd(32, seed=137)
+    both("igemm_nt_dgrad_bn", [x, Bp, torch.zeros(rows, 32), torch.zeros(G, T, 2, 32), y, mean, rstd, gamma, beta, TCONV_S2P1, G, Bg,
+                               16, 16, 64, 32, 32, 32, 1, 0], [2, 3], post, tol=5e-5)
+
+
 def test_bce_logits_groups_equals_per_pass_launches():
     """One launch for all decoder passes of a modality (shared target, one loss slot per pass, a discarded pass marked by
     slot -1) against one mmdyn_bce_logits per pass."""
