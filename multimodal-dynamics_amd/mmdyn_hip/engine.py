@@ -581,6 +581,14 @@ class MVAEStep:
             with torch.cuda.stream(side):                      # warm-up outside capture (allocator, lazy init)
                 self.train_step(self._static_in, self._static_tg, kl_weight, self._static_mask, self._static_cond)
             torch.cuda.current_stream().wait_stream(side)
+            if self.pg is not None:
+                # RCCL work objects of the eager warm-up are retired by the process group's watchdog THREAD, which polls their
+                # events.  Once collectives are being captured (SyncBN) the communicator's stream is in capture mode and such a
+                # poll fails ("operation not permitted on an event last recorded in a capturing stream": the watchdog aborts the
+                # process).  Let the warm-up finish and the watchdog (100 ms sweep) drain before the capture starts.
+                import time
+                torch.cuda.synchronize()
+                time.sleep(0.35)
             self._graph = (key, self._capture(kl_weight))
             return self.loss             # the warm-up above WAS this call's optimiser step
         for dst, src in zip(self._static_in + self._static_tg, list(inputs) + list(targets)):
@@ -643,7 +651,8 @@ class MVAEStep:
                     g = torch.cuda.CUDAGraph()
                     LN.on = lanes_on and lane == "main" and fn is stages[0][0][1]   # ... except the pre-phase fork
                     layers.CUR_LANE = {"l0": 0, "l1": 1}.get(lane)                  # (SyncBN: the lane's communicator)
-                    with torch.cuda.graph(g, pool=pools[lane], stream=cap_stream[lane]):
+                    # (thread_local: API calls of OTHER threads -- RCCL's watchdog -- must not invalidate the capture)
+                    with torch.cuda.graph(g, pool=pools[lane], stream=cap_stream[lane], capture_error_mode="thread_local"):
                         fn()
                     row.append((lane, g))
                 captured.append(row)
