@@ -24,7 +24,8 @@ def _canon(name, a):
             tuple(a[10:17]) == (a[10], a[10], 64, a[10] // 2, a[10] // 2, 32, 32):
         return "conv3_nt", a
     # ... and so does the 64 -> 32 channel transposed convolution on 16x16 inputs in fp32 (csrc/tconv_patch.hip)
-    if name == "igemm_nt" and a[7] == ops.TCONV_S2P1 and tuple(a[10:16]) == (16, 16, 64, 32, 32, 32) and \
+    if name == "igemm_nt" and a[7] == ops.TCONV_S2P1 and tuple(a[10:16]) in ((16, 16, 64, 32, 32, 32), (32, 32, 32, 64, 64, 32),
+                                                                            (64, 64, 32, 128, 128, 32)) and \
             getattr(ops.B, "precision", "fp32") == "fp32" and all(not torch.is_tensor(t) or t.dtype == torch.float32 for t in a[:4]):
         return "tconv_patch", a
     if name == "wgrad_tn" and a[3] == ops.IM2COL3 and a[8] in (64, 128, 256) and \

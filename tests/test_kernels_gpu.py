@@ -624,27 +624,29 @@ def test_igemm_bf16_mixed_output_and_one_pixel_walk(monkeypatch):
         HIP.precision = EMU.precision = "fp32"
 
 
-@pytest.mark.parametrize("G,Bg", [(2, 3), (1, 1), (4, 37)])
-def test_tconv_patch_kernel(G, Bg):
-    """ConvTranspose2d(64, 32, 4, 2, 1) on 16x16 inputs runs the patch-resident kernel (tconv_patch.hip: the input of an image
-    staged in LDS once for all parity classes and taps) in every fp32 launch form: BatchNorm partial sums (one tile per
+@pytest.mark.parametrize("H,Cin,G,Bg", [(16, 64, 2, 3), (16, 64, 1, 1), (16, 64, 4, 37), (32, 32, 2, 3), (32, 32, 1, 5), (64, 32, 2, 2),
+                                        (64, 32, 1, 3)])
+def test_tconv_patch_kernel(H, Cin, G, Bg):
+    """The k4 s2 p1 transposed convolutions with 32 output channels (64 -> 32 on 16x16 inputs; the 32 -> 32 stages of the
+    128 / 256 pixel stacks on 32x32 / 64x64 inputs) run the patch-resident kernel (tconv_patch.hip: a tile of input rows staged
+    in LDS once for all parity classes and taps) in every fp32 launch form: BatchNorm partial sums (one tile per row tile of an
     image), bias + Swish second output, and the input-gradient form with the BatchNorm+Swish backward epilogue."""
-    Bt = G * Bg
-    x = rnd(Bt * 256, 64, seed=130)
-    Bp = rnd(16, 32, 64, seed=131, scale=0.1)
-    rows = Bt * 1024
-    T = HIP.igemm_stat_tiles(TCONV_S2P1, G, Bg, 16, 16, 64, 32, 32, 32)
-    assert T == Bg
+    Bt, Ho = G * Bg, 2 * H
+    x = rnd(Bt * H * H, Cin, seed=130)
+    Bp = rnd(16, 32, Cin, seed=131, scale=0.1)
+    rows = Bt * Ho * Ho
+    T = HIP.igemm_stat_tiles(TCONV_S2P1, G, Bg, H, H, Cin, Ho, Ho, 32)
+    assert T == Bg * {16: 1, 32: 2, 64: 8}[H]
     post = lambda i, t: t.sum(1) if t.dim() == 4 else t
-    both("igemm_nt", [x, Bp, None, torch.zeros(rows, 32), None, torch.zeros(G, T, 2, 32), None, TCONV_S2P1, G, Bg, 16, 16, 64, 32, 32,
+    both("igemm_nt", [x, Bp, None, torch.zeros(rows, 32), None, torch.zeros(G, T, 2, 32), None, TCONV_S2P1, G, Bg, H, H, Cin, Ho, Ho,
                       32, 32, 1, 0, 0, 1], [3, 5], post)
-    both("igemm_nt", [x, Bp, rnd(32, seed=132), torch.zeros(rows, 32), torch.zeros(rows, 32), None, None, TCONV_S2P1, G, Bg, 16, 16,
-                      64, 32, 32, 32, 32, 1, 0, 1, 1], [3, 4])
+    both("igemm_nt", [x, Bp, rnd(32, seed=132), torch.zeros(rows, 32), torch.zeros(rows, 32), None, None, TCONV_S2P1, G, Bg, H, H,
+                      Cin, Ho, Ho, 32, 32, 1, 0, 1, 1], [3, 4])
     y = rnd(rows, 32, seed=133) * 1.5 + 0.2
     mean, rstd = rnd(G, 32, seed=134) * 0.3, rnd(G, 32, seed=135).abs() + 0.5
     gamma, beta = rnd(32, seed=136) + 1.2, rnd(32, seed=137)
     both("igemm_nt_dgrad_bn", [x, Bp, torch.zeros(rows, 32), torch.zeros(G, T, 2, 32), y, mean, rstd, gamma, beta, TCONV_S2P1, G, Bg,
-                               16, 16, 64, 32, 32, 32, 1, 0], [2, 3], post, tol=5e-5)
+                               H, H, Cin, Ho, Ho, 32, 1, 0], [2, 3], post, tol=5e-5)
 
 
 def test_bce_logits_groups_equals_per_pass_launches():
