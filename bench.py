@@ -371,7 +371,9 @@ def main():
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     total_ms = sum(d["ms"] for d in kern.values())
     peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else (PEAK_F16_MFMA_TFLOPS if args.dtype == "fp16" else PEAK_BF16_MFMA_TFLOPS)
-    traffic, traffic_note = pmc_traffic(dom_name) if args.dtype == "f32" else (None, {"stale": "profiled for fp32 only"})
+    # (the committed PMC passes were taken on the BASELINE workload: 64x64, bs 256, fp32, seq_modeling)
+    profiled = args.dtype == "f32" and S == 64 and args.batch == 256 and args.problem == "seq_modeling"
+    traffic, traffic_note = pmc_traffic(dom_name) if profiled else (None, {"stale": "profiled for the 64x64 bs 256 fp32 workload only"})
     arith = {"f32": "fp32", "bf16": "bf16 matrix-core operands (fp32 accumulate, storage and master weights)",
              "bf16s": "bf16 activation storage + bf16 matrix-core operands (fp32 accumulate and master weights)",
              "fp16": "fp16 matrix-core operands (fp32 accumulate, storage and master weights)"}[args.dtype]
