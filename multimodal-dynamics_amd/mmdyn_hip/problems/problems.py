@@ -186,7 +186,7 @@ class Problem:
         precision = self.parameters.get('precision', 'fp32')
         if use_engine:
             self._step = MVAEStep(self._model, lr=self.parameters['lr'], pose_multiplier=self._pose_multiplier,
-                                  precision=precision)
+                                  precision=precision, exact_running_stats=bool(self.parameters.get('exact_running_stats')))
         elif precision != 'fp32':
             raise ValueError("--precision %s is a mode of the fused cnn-mvae step; this configuration runs the module "
                              "path, which computes in fp32" % precision)

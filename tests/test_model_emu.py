@@ -175,6 +175,18 @@ def test_fused_engine_mask_loss(mask_channels):
     check_fused_engine_mask_loss("cpu", mask_channels)
 
 
+def test_exact_running_stats_flag_reaches_the_fused_step():
+    """--exact-running-stats (main.py, a switch of this build) makes the fused step reproduce the decoders' BatchNorm
+    running statistics of the reference's 7-forward schedule."""
+    from mmdyn_hip.main import build_parser
+    ns = build_parser().parse_args(["--problem-type", "seq_modeling", "--model-name", "cnn-mvae", "--input-type", "visuotactile",
+                                    "--use-pose", "--exact-running-stats", "--no-cuda"])
+    assert ns.exact_running_stats is True
+    prob = SeqModeling(args(no_cuda=True, exact_running_stats=True), log_dir="/tmp/mmdyn_test_logs")
+    assert prob._step is not None and prob._step.exact_running_stats is True
+    assert SeqModeling(args(no_cuda=True), log_dir="/tmp/mmdyn_test_logs")._step.exact_running_stats is False
+
+
 def test_mask_loss_engine_selection_and_errors():
     """--mask-loss runs the fused step when the model has no pose term; with --use-pose the reference fails on the (B, 7)
     pose term (problems.py:445-447) and so does the engine."""
