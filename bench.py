@@ -197,6 +197,29 @@ def _emit(obj):
     os.write(_RESULT_FD if _RESULT_FD is not None else 1, (json.dumps(obj) + "\n").encode())
 
 
+def _self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks ourselves, the way the driver does for N > 1
+    (``python -m torch.distributed.run --nproc-per-node N``), as a CHILD process -- this process has not touched the GPU
+    and never will; it relays rank 0's single JSON line and exits with the child's return code.  (The reference has no
+    counterpart: it is a single process, problems.py:52, 388.)"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, text=True)
+    lines = [ln for ln in proc.stdout.read().splitlines() if ln.startswith("{")]
+    rc = proc.wait()
+    for ln in lines[-1:]:
+        _emit(json.loads(ln))
+    if rc != 0 or not lines:
+        raise SystemExit(rc or 1)
+
+
 def main():
     _claim_stdout()
     ap = argparse.ArgumentParser()
@@ -230,6 +253,9 @@ def main():
                     help="no visual/tactile stream overlap: per-kernel durations in a rocprofv3 trace then match "
                          "the roofline object's live HIP-event measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _self_launch(args.gpus)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -319,7 +345,7 @@ def main():
         final = targets
         targets = [torch.roll(x, -1, dims=0) for x in inputs]
         for k in (0, 1):
-            targets[k][Lq - 1::Lq] = final[k][::Lq]
+            targets[k][Lq - 1::Lq] = final[k][Lq - 1::Lq]
 
     def eager_step():
         return step.train_step(inputs, targets, KL_WEIGHT)

@@ -213,3 +213,20 @@ def test_bench_multi_rank_dry_run(tmp_path):
     assert d["scaling"] == "weak" and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "samples/s"
     assert d["value"] == pytest.approx(4 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-6)
     assert "dry_run" in d and "cpu_baseline" not in d
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` with no launcher and no WORLD_SIZE must start its two ranks itself (a child
+    torch.distributed.run) and relay ONE JSON line saying n_gpus == 2 -- never silently measure one rank."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MMDYN_BENCH_DRYRUN="emu")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert "launching 2 ranks" in out.stderr
