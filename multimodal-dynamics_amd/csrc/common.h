@@ -150,10 +150,19 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
 int mmdyn_conv3_wgrad_try(const void* D, const float* Gt, float* partial, int Bt, int Hr, int Wr, int Cd, int Hi,
                           int Wi, int Cg, int chunks, int d_b16, hipStream_t st);
 
+// Kernel-experiment knobs (environment variables read by the library: docs/LAB_NOTES.md C) exist only in the LAB build
+// (make lab -> libmmdyn_hip_lab.so, -DMMDYN_LAB).  The product library has one code path per launch: lab_env() is
+// a constant nullptr there and every test of it folds away.
+#ifdef MMDYN_LAB
+static inline const char* lab_env(const char* name) { return getenv(name); }
+#else
+static inline const char* lab_env(const char*) { return nullptr; }
+#endif
+
 // grid size for a grid-stride element-wise launch: enough blocks to fill 256 CUs x 8, no more
 static inline int ew_grid_cap() {
   static const int cap = [] {
-    const char* e = getenv("MMDYN_EW_BLOCKS");
+    const char* e = lab_env("MMDYN_EW_BLOCKS");
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 2048;
   }();

@@ -453,6 +453,7 @@ int mmdyn_igemm_d16_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin,
   g.ldc = N;
   g.splitk = 1;
   g.nclasses = (mode == MMDYN_TCONV_S2P1) ? 4 : 1;
+  g.ntaps = (mode == MMDYN_CONV || mode == MMDYN_TCONV_S1P0) ? 16 : (mode == MMDYN_TCONV_S2P1 ? 4 : 1);   // as igemm_entry
   g.Hr = (mode == MMDYN_TCONV_S2P1) ? Hi : Ho;
   g.Wr = (mode == MMDYN_TCONV_S2P1) ? Wi : Wo;
   D16Tile t;

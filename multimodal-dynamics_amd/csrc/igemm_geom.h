@@ -36,11 +36,23 @@ struct IgemmGeom {
 // memory (no LDS, no block barrier).  Returns MMDYN_OK / an error code, or 1 when the shape is not served (the caller
 // then takes the LDS-tiled kernel).  d16_stat_tiles: number of BatchNorm partial-sum tiles per group it writes, 0 when
 // the shape is not served.
+// LAB build only (igemm_d16.hip is not part of the product library: measured slower inside the two-lane step, LAB_NOTES A.a).
+#ifdef MMDYN_LAB
 int mmdyn_igemm_d16_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats,
                         float* ws, IgemmGeom g, int stride, int offset, hipStream_t st);
 int mmdyn_igemm_d16_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
+#else
+static inline int mmdyn_igemm_d16_try(const float*, const float*, const float*, float*, float*, float*, float*, const IgemmGeom&,
+                                      int, int, hipStream_t) { return 1; }
+static inline int mmdyn_igemm_d16_stat_tiles(int, int, int, int, int, int, int, int, int) { return 0; }
+#endif
 
 // tconv_patch.hip: patch-resident k4 s2 p1 transposed convolution (fp32, 16x16x64 -> 32x32x32).  Same protocol as the d16 hooks.
 int mmdyn_tconv_patch_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
                           const IgemmGeom& g, hipStream_t st);
 int mmdyn_tconv_patch_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
+
+// igemm_ws.hip: wave-specialised fp32 implicit GEMM (loader waves + LDS-DMA ring).  Same protocol as the hooks above.
+int mmdyn_igemm_ws_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
+                       const IgemmGeom& g, hipStream_t st);
+int mmdyn_igemm_ws_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   // altogether, a timing diagnostic, +20 %; removing the barriers nothing: the single-stage kernel is exposed to the
   // fetch, not to its barriers).  HERE it loses: with the gather arithmetic of two fetches live the compiler needs 92
   // VGPRs + 40 AGPRs (3 waves per SIMD instead of 6) and the launches run 8-10 % SLOWER (step 7.26 vs 6.98 ms,
-  // profiles/r2/igemm_mfma_shape_sweep.txt); capping the registers spills.  Kept switched off.
+  // profiles/r2/igemm_tile_x_mfma_shape_sweep.txt); capping the registers spills.  Kept switched off.
   constexpr bool PF2 = false;
   auto mfma_step = [&]() {
       const float* Ac = As;
@@ -616,7 +616,7 @@ static void pick_tile(int N, int rows_per_group, int G, int ncls, int splitk, in
       *bn = 128;
     }
   }
-  if (const char* ov = getenv("MMDYN_IGEMM_TILE")) {   // kernel experiments only
+  if (const char* ov = lab_env("MMDYN_IGEMM_TILE")) {   // kernel experiments only
     int a = 0, b = 0;
     if (sscanf(ov, "%d,%d", &a, &b) == 2 && N % b == 0) {
       *bm = a;
@@ -640,7 +640,7 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   // the pair walk / one pixel per block for the bf16 variants (kernel experiments).
   bool onepx = false;
   if (MODE == MMDYN_TCONV_S1P0 && bf16 && !g.f16 && g.a_b16 && g.b_b16 && g.Cin % 64 == 0) {
-    const char* e = getenv("MMDYN_S1P0_SPLIT");
+    const char* e = lab_env("MMDYN_S1P0_SPLIT");
     const int forced = e ? atoi(e) : 0;
     const long blocks1 = (long)g.G * 64 * g.tiles_per_pixel * (g.N / BN);
     if (forced == 4 || (forced == 0 && blocks1 >= 2048)) {
@@ -657,16 +657,16 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
     grid = dim3((unsigned)8 * ((s_inner + nparts - 1) / nparts) * g.splitk);
   }
   // fp32: 16x16x4 MFMA tiles (see the M16 note at the kernel) where the per-shape sweep of the step's launches shows a win
-  // (profiles/r2/igemm_mfma_shape_sweep.txt): large launches (>= 2048 blocks, >= 8 K-steps) of every block tile but
+  // (profiles/r2/igemm_tile_x_mfma_shape_sweep.txt): large launches (>= 2048 blocks, >= 8 K-steps) of every block tile but
   // 128x128: +3..6 % there, -2..4 % on the small encoder-side launches, which keep the 32x32x2 shape.
   // MMDYN_IGEMM_M32=1 / MMDYN_IGEMM_M16=1 force one shape everywhere (kernel experiments)
   constexpr bool M16_TILE = true;
-  const bool big_tile_m16 = !(BM == 128 && BN == 128) || getenv("MMDYN_IGEMM_M16_128") != nullptr;
-  const bool force_m32 = getenv("MMDYN_IGEMM_M32") != nullptr, force_m16 = getenv("MMDYN_IGEMM_M16") != nullptr;
+  const bool big_tile_m16 = !(BM == 128 && BN == 128) || lab_env("MMDYN_IGEMM_M16_128") != nullptr;
+  const bool force_m32 = lab_env("MMDYN_IGEMM_M32") != nullptr, force_m16 = lab_env("MMDYN_IGEMM_M16") != nullptr;
   const long nblocks = (long)g.G * g.tiles_per_group * (g.N / BN) * g.nclasses * g.splitk;
   const int ksteps = (MODE == MMDYN_TCONV_S1P0 ? 6 : g.ntaps) * (g.Cin / BK) / g.splitk;
   const bool m16 = !bf16 && M16_TILE && !force_m32 && (force_m16 || (big_tile_m16 && nblocks >= 2048 && ksteps >= 8) ||
-                                                       (BM == 128 && BN == 128 && getenv("MMDYN_IGEMM_M16_128") != nullptr));
+                                                       (BM == 128 && BN == 128 && lab_env("MMDYN_IGEMM_M16_128") != nullptr));
   size_t smem = (size_t)(BM + BN) * (m16 ? BK + 8 : LDS_LD32) * sizeof(float) + (size_t)BM * 4 * sizeof(int);
 #define IGEMM_LAUNCH(BF, A16_, B16_)                                                                                     \
   hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, BF, A16_, B16_>), grid, dim3(256), smem, st, A, Bp, bias, C, \
@@ -746,6 +746,12 @@ int mmdyn_igemm_tile5(IGEMM_TILE_ARGS) { return launch<128, 32, 32, 32>(A, Bp, b
 #if !defined(IGEMM_PART) || IGEMM_PART == 99
 
 
+// LAB build: MMDYN_IGEMM_WS=0 sends every launch back to the register-staged kernels (A/B measurements, kernel tests)
+static bool ws_enabled() {
+  const char* e = lab_env("MMDYN_IGEMM_WS");
+  return !(e && e[0] == '0');
+}
+
 static int lds_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   if (mode == MMDYN_TCONV_S1P0) {
     int bm, bn;
@@ -770,7 +776,9 @@ static int lds_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int 
 extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   const int tp = mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   if (tp > 0) return tp;
-  const int t = mmdyn_igemm_d16_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  int t = mmdyn_igemm_d16_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  if (t > 0) return t;
+  t = ws_enabled() ? mmdyn_igemm_ws_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) : 0;
   return t > 0 ? t : lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
 }
 extern "C" int mmdyn_igemm_stat_tiles_bf16(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
@@ -875,6 +883,10 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   }
   if (!bf16 && mode != MMDYN_IM2COL3) {
     const int rc = mmdyn_igemm_d16_try(A, Bp, bias, C, C_act, stats, ws, g, stride, offset, st);
+    if (rc != 1) return rc;
+  }
+  if (!bf16 && ws_enabled()) {      // wave-specialised LDS-DMA ring kernels (igemm_ws.hip)
+    const int rc = mmdyn_igemm_ws_try(A, Bp, bias, C, C_act, stats, ws, g, st);
     if (rc != 1) return rc;
   }
   int bm, bn;

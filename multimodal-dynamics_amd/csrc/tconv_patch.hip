@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512) void tconv_patch_kernel(const float* __restric
 
 bool patch_enabled() {
   static const bool off = [] {
-    const char* e = getenv("MMDYN_TCONV_PATCH");
+    const char* e = lab_env("MMDYN_TCONV_PATCH");
     return e && atoi(e) == 0;
   }();
   return !off;

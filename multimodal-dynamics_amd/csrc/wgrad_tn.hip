@@ -982,7 +982,7 @@ extern "C" int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg) {
     wk = 1;
   }
   long target = 768;      // blocks in flight (whole-step sweep after the fetch fixes: 768 beats 512 / 1024 in all three precisions)
-  if (const char* ov = getenv("MMDYN_WGRAD_BLOCKS")) target = atol(ov);   // kernel experiments only
+  if (const char* ov = lab_env("MMDYN_WGRAD_BLOCKS")) target = atol(ov);   // kernel experiments only
   if (mode == MMDYN_IM2COL3) {            // conv3_wgrad: one block (four waves, one slab) per chunk
     tiles = 1;
     wk = 1;

@@ -101,26 +101,31 @@ _CODES = {"p": _P, "i": _I, "l": _L, "f": _F, "Q": _Q}
 
 EXPORTS = ["mmdyn_version"] + list(_SIGNATURES)
 
-_lib = None
+# the LAB build of the same sources (make lab: -DMMDYN_LAB): experiment environment variables + the opt-in direct-fragment
+# kernels.  Never loaded by the product; tests/microbench and the variant-forcing kernel tests ask for it by path.
+LAB_LIB_PATH = os.path.join(_HERE, "libmmdyn_hip_lab.so")
+
+_libs = {}
 
 
-def load():
-    """Load the library once; raises OSError / AttributeError if it (or a symbol) is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """Load the library (once per path); raises OSError / AttributeError if it (or a symbol) is missing."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise OSError(
-            f"{LIB_PATH} not found: build it with `make -C multimodal-dynamics_amd/csrc` "
+            f"{path} not found: build it with `make -C multimodal-dynamics_amd/csrc`"
+            f"{' lab' if path == LAB_LIB_PATH else ''} "
             "(or python -c 'import __graft_entry__ as g; g.build()').  There is no fallback path.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     lib.mmdyn_version.restype = ctypes.c_char_p
     lib.mmdyn_version.argtypes = []
     for name, sig in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _I
         fn.argtypes = [_CODES[c] for c in sig]
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 

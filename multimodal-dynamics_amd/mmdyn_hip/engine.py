@@ -25,6 +25,7 @@ from .models.shapes import DROPOUT_P
 
 SUBSETS_POSE = [(1, 1, 0), (1, 0, 0), (0, 1, 0), (1, 1, 1), (1, 0, 1), (0, 1, 1), (0, 0, 1)]
 SUBSETS_NOPOSE = SUBSETS_POSE[:3]
+PRECISIONS = ("fp32", "bf16", "bf16s", "fp16")
 
 _PREFIX_ORDER = ["pose_decoder", "visual_decoder", "tactile_decoder",         # bucket 0: ready first
                  "heads", "pose_encoder", "encoder_fc",                      # bucket 1: heads, pose encoder and the image
@@ -153,12 +154,22 @@ class MVAEStep:
         # --conditional (vae.py:231-237, 286-291): the condition joins the 512 features in front of the image encoders' heads
         # and the latent in front of the image decoders' first layer; the pose MLPs are built unconditional (vae.py:117-123)
         self.conditional = bool(getattr(model, "conditional", False))
-        if precision not in ("fp32", "bf16", "bf16s", "fp16"):
+        if precision not in PRECISIONS:
             raise ValueError("precision must be 'fp32' (the reference's arithmetic), 'bf16s' (bf16 activation storage + "
                              "bf16 matrix cores, fp32 accumulate / master weights: BASELINE configs[2]), 'bf16' (bf16 matrix-core "
                              "operands only, fp32 storage) or 'fp16' (fp16 matrix-core operands, fp32 accumulate / storage: "
                              "BASELINE configs[4])")
         self.precision = precision
+        # Loss scale of the fp16 modes: every loss gradient entering the backward (BCE / MSE / KL) is multiplied by
+        # 4 * B and Adam divides it out again (the backward is linear in the loss gradient, BatchNorm included).  Unscaled,
+        # dlogit is (sigmoid - t) / B and the KL gradient kl_w / B * ...: at B = 256 most of that signal sits below fp16's
+        # smallest normal (6.1e-5) once it has passed a few layers and is rounded away on its way into the matrix cores.
+        # Scaled, dlogit = 4 (sigmoid - t) whatever the batch; the largest operand is the pose gradient 8000 * |error|
+        # (fp16 maximum 65504: pose targets and predictions live in [0, 1]).  ``params.grad`` holds the scaled gradients
+        # between backward() and optimizer_step(): divide by ``loss_scale`` to read them.  Set per batch in _begin();
+        # data-parallel ranks must run equal local batches in these modes (bench.py does), the all-reduce adds the ranks.
+        self._scale_per_sample = 4.0 if precision in ("fp16", "fp16s") else 0.0
+        self.loss_scale = 1.0
         # False (default): each image decoder runs only on the passes whose reconstruction enters the loss, so its
         # BatchNorm running buffers see 4 EMA updates per step (2 without pose) where the reference applies 7 (3).
         # True: the decoders also run on the passes the reference computes and discards, in pass order, with zero
@@ -308,6 +319,8 @@ class MVAEStep:
             raise RuntimeError("model parameters were re-allocated (e.g. .to()/.cuda() after MVAEStep was built); "
                                "construct MVAEStep after moving the model")
         v = inputs[0].contiguous()
+        if self._scale_per_sample:
+            self.loss_scale = self._scale_per_sample * v.shape[0]
         self.ctx = {"B": v.shape[0], "dev": v.device, "x": {"v": v, "t": inputs[1].contiguous()},
                     "tg": {"v": targets[0].contiguous(), "t": targets[1].contiguous()},
                     "pose": inputs[2].contiguous() if self.use_pose else None,
@@ -378,10 +391,10 @@ class MVAEStep:
         # (slot -1: exact_running_stats ran a pass whose reconstruction is discarded -- zero gradient, no loss)
         tg, mk = c["tg"][m], c["lmask"]
         if mk is None:
-            ops.B.bce_logits_groups(lg, tg, dl, self.acc[0], [p if p in live else -1 for p in plist], tg.numel(), 1.0 / B)
+            ops.B.bce_logits_groups(lg, tg, dl, self.acc[0], [p if p in live else -1 for p in plist], tg.numel(), self.loss_scale / B)
         else:
-            ops.B.bce_logits_groups(lg, tg, dl, self.acc[0], [p if p in live else -1 for p in plist], tg.numel(), 1.0 / B,
-                                    mask=mk, chw=tg[0].numel(), hw=tg[0, 0].numel(), mask_channels=mk.shape[1],
+            ops.B.bce_logits_groups(lg, tg, dl, self.acc[0], [p if p in live else -1 for p in plist], tg.numel(),
+                                    self.loss_scale / B, mask=mk, chw=tg[0].numel(), hw=tg[0, 0].numel(), mask_channels=mk.shape[1],
                                     unmasked_slots=self.acc[3])
         c["lg" + m], c["dl" + m] = lg, dl
 
@@ -394,7 +407,7 @@ class MVAEStep:
             dpr = torch.empty_like(pr) if c["train"] else None
             for g, p in enumerate(self.pass_p):
                 ops.B.mse(pr[g * B:(g + 1) * B], c["pose_tg"], None if dpr is None else dpr[g * B:(g + 1) * B],
-                          self.acc[1, p:p + 1], B * 7, self.pose_multiplier / B)
+                          self.acc[1, p:p + 1], B * 7, self.loss_scale * self.pose_multiplier / B)
             c["pr"], c["dpr"] = pr, dpr
 
     def _ph_assemble(self):
@@ -429,7 +442,7 @@ class MVAEStep:
         c["dov"], c["dot"] = torch.empty_like(c["ov"]), torch.empty_like(c["ot"])
         c["dop"] = torch.empty_like(c["op"]) if self.use_pose else None
         ops.B.poe_bwd(self._passes(c, B, [c["dov"], c["dot"], c["dop"]], blocks), c["eps"], c["mu"], c["lv"], None, None,
-                      None, 1.0 / B, True, P, B, L, self.klw)
+                      None, self.loss_scale / B, True, P, B, L, self.klw)
 
     def _ph_enc_bwd_steps(self, m):
         c, FP, B = self.ctx, self.params, self.ctx["B"]
@@ -541,7 +554,7 @@ class MVAEStep:
         for h in handles:
             h.wait()
         ops.B.adam_step(self.params.flat, self.params.grad, self.adam_m, self.adam_v, self.adam_state, self.lr,
-                        self.betas[0], self.betas[1], self.eps, 1.0 / self.world)
+                        self.betas[0], self.betas[1], self.eps, 1.0 / (self.world * self.loss_scale))
 
     @_with_precision
     def train_step(self, inputs, targets, kl_weight, loss_mask=None, condition=None):
@@ -578,17 +591,13 @@ class MVAEStep:
             self._static_cond = None if condition is None else condition.clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
+            if self._sync is not None:
+                self._sync.pending = []                        # keep the Work handles of the warm-up's collectives
             with torch.cuda.stream(side):                      # warm-up outside capture (allocator, lazy init)
                 self.train_step(self._static_in, self._static_tg, kl_weight, self._static_mask, self._static_cond)
             torch.cuda.current_stream().wait_stream(side)
             if self.pg is not None:
-                # RCCL work objects of the eager warm-up are retired by the process group's watchdog THREAD, which polls their
-                # events.  Once collectives are being captured (SyncBN) the communicator's stream is in capture mode and such a
-                # poll fails ("operation not permitted on an event last recorded in a capturing stream": the watchdog aborts the
-                # process).  Let the warm-up finish and the watchdog (100 ms sweep) drain before the capture starts.
-                import time
-                torch.cuda.synchronize()
-                time.sleep(0.35)
+                self._drain_before_capture(key)
             self._graph = (key, self._capture(kl_weight))
             return self.loss             # the warm-up above WAS this call's optimiser step
         for dst, src in zip(self._static_in + self._static_tg, list(inputs) + list(targets)):
@@ -604,6 +613,40 @@ class MVAEStep:
             handles += self._reduce_bucket(2)
             self.optimizer_step(handles)
         return self.loss
+
+    WATCHDOG_SWEEP_S = 0.1       # ProcessGroupNCCL's watchdog thread looks at its list of un-retired Work objects every 100 ms
+
+    def _drain_before_capture(self, key):
+        """Everything a captured step with RCCL collectives relies on, made explicit before the capture starts.
+
+        (1) Every rank must be about to capture the SAME step (a capture on one rank only would leave the lane
+        communicators waiting for collectives nobody issues): the capture keys are compared across ranks, a mismatch is an
+        error on every rank instead of a hang.  (2) The warm-up's collectives must be finished AND retired: their Work
+        handles (gradient buckets: waited on in optimizer_step; SyncBN statistics: layers.SyncBN.pending) are waited on,
+        the device is synchronised, and one barrier per communicator proves that every rank got that far.  (3) The process
+        group's watchdog THREAD polls the events of un-retired Work objects; a poll that lands while a communicator's
+        stream is capturing fails ("operation not permitted on an event last recorded in a capturing stream") and aborts
+        the process.  With (2) done every Work is complete, so the next watchdog sweep retires them all; the sweep interval
+        is the documented 100 ms (WATCHDOG_SWEEP_S; TORCH_NCCL_* settings do not change it), we wait 2.5 of them.  The
+        capture itself runs with capture_error_mode="thread_local", so API calls of other threads cannot invalidate it."""
+        import time
+        import torch.distributed as dist
+        keys = [None] * self.world
+        dist.all_gather_object(keys, repr(key), group=self.pg)
+        if any(k != keys[0] for k in keys):
+            raise RuntimeError(f"mmdyn_hip: ranks are about to capture different steps {keys}: every rank must see the same "
+                               "batch shapes (shard evenly, drop the last partial batch)")
+        groups = [self.pg]
+        if self._sync is not None:
+            for w in self._sync.pending or []:
+                w.wait()
+            self._sync.pending = None
+            groups += list(self._sync.lane_groups or [])
+        torch.cuda.synchronize()
+        for g in groups:
+            dist.barrier(group=g)
+        torch.cuda.synchronize()
+        time.sleep(2.5 * self.WATCHDOG_SWEEP_S)
 
     def _capture(self, kl_weight):
         LN = self.lanes

@@ -119,13 +119,20 @@ class SyncBN:
         must be issued in the same order everywhere, so each lane gets a communicator of its own."""
         self.group, self.world = group, int(world)
         self.lane_groups = lane_groups
+        self.pending = None      # list: Work handles of eagerly issued collectives are kept here (engine: the warm-up step
+        #                          in front of a graph capture waits on every one of them before the capture starts)
 
     def all_reduce(self, t):
         import torch.distributed as dist
         g = self.group
         if self.lane_groups is not None and CUR_LANE is not None and CUR_LANE < len(self.lane_groups):
             g = self.lane_groups[CUR_LANE]
-        dist.all_reduce(t, group=g)
+        if self.pending is None:
+            dist.all_reduce(t, group=g)
+        else:
+            w = dist.all_reduce(t, group=g, async_op=True)
+            w.wait()                                  # stream-ordered, like the blocking form
+            self.pending.append(w)
 
 
 SYNC = None

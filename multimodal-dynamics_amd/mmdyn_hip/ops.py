@@ -47,8 +47,8 @@ def _stream():
 class HipBackend:
     name = "hip"
 
-    def __init__(self):
-        self._l = None
+    def __init__(self, lib_path=None):
+        self._l, self._lib_path = None, lib_path       # lib_path: the LAB build (tests / microbenchmarks only)
         # "fp32": v_mfma_f32_32x32x2_f32 (the reference's arithmetic, the default and the BASELINE configs[1] path);
         # "bf16": operands rounded to bf16 on their way into the matrix cores, fp32 accumulate (configs[2]);
         # "fp16": the same with IEEE-half operands (configs[4]); "bf16s": bf16 + bf16 activation storage
@@ -57,7 +57,7 @@ class HipBackend:
     @property
     def lib(self):
         if self._l is None:
-            self._l = _lib.load()
+            self._l = _lib.load(self._lib_path)
         return self._l
 
     # ---- host-only helpers (no GPU needed) ----

@@ -285,16 +285,27 @@ class DeviceLoader:
     def __init__(self, dataset, batch_size, shuffle=False, fold=True, device=None, seed=None, rank=0, world_size=1):
         """``seed``: shuffling seed; None draws it from torch's global generator, like the reference's DataLoader
         (a default-constructed torch.Generator would give every run the same order).  ``rank`` / ``world_size``: data
-        parallel: every rank draws the SAME permutation (the seed is shared: pass one, or seed torch identically) and
-        takes its own contiguous share of each global mini-batch of ``batch_size * world_size`` samples."""
+        parallel: every rank draws the SAME permutation (an explicit seed, or rank 0's draw broadcast over the default
+        process group) and takes its own contiguous share of each global mini-batch of ``batch_size * world_size`` samples."""
         self.dataset, self.batch_size, self.shuffle, self.fold = dataset, int(batch_size), shuffle, fold
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
         self.rank, self.world_size = int(rank), int(world_size)
         if not 0 <= self.rank < self.world_size:
             raise ValueError("rank must be in [0, world_size)")
         self.generator = torch.Generator()
-        self.generator.manual_seed(int(torch.initial_seed() if seed is None and world_size > 1 else
-                                       (torch.randint(0, 2 ** 31 - 1, (1,)).item() if seed is None else seed)))
+        if seed is None:
+            seed = torch.randint(0, 2 ** 31 - 1, (1,)).item()
+            if self.world_size > 1:
+                # every rank must draw the SAME permutation or the shards overlap and samples are skipped silently:
+                # rank 0's draw is the seed (nothing guarantees that the ranks seeded torch identically)
+                import torch.distributed as dist
+                if not (dist.is_available() and dist.is_initialized()):
+                    raise ValueError("DeviceLoader(world_size > 1, seed=None) needs an initialised process group to share "
+                                     "rank 0's shuffling seed; pass an explicit seed otherwise")
+                box = [seed]
+                dist.broadcast_object_list(box, src=0)
+                seed = box[0]
+        self.generator.manual_seed(int(seed))
         self.shock_dim = dataset.shock_dim
 
     def __len__(self):

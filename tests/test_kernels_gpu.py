@@ -13,7 +13,18 @@ from emu_backend import EmuBackend
 pytestmark = pytest.mark.gpu
 
 HIP = ops.HipBackend()
+# the LAB build of the same sources (make lab): reads the MMDYN_* experiment variables and contains the opt-in
+# direct-fragment kernels.  Tests that FORCE a kernel variant on a small shape swap it in for the duration of the test.
+from mmdyn_hip import _lib as _libmod
+HIP_LAB = ops.HipBackend(lib_path=_libmod.LAB_LIB_PATH)
 EMU = EmuBackend()
+
+
+@pytest.fixture()
+def lab(monkeypatch):
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "HIP", HIP_LAB)
+    yield HIP_LAB
 DEV = "cuda"
 
 
@@ -106,7 +117,7 @@ def test_igemm_dgrad_bn_epilogue(case):
 
 
 @pytest.fixture()
-def d16_tile(request, monkeypatch):
+def d16_tile(request, monkeypatch, lab):
     """Force one wave-tile shape of the direct-fragment fp32 kernels (igemm_d16.hip); without this the small test shapes
     fall below its work threshold and run the LDS-tiled kernel."""
     monkeypatch.setenv("MMDYN_D16_TILE", request.param)
@@ -118,9 +129,10 @@ D16_TILES = ["4,4", "8,2", "4,2", "2,2"]
 
 
 @pytest.fixture()
-def mfma16(monkeypatch):
+def mfma16(monkeypatch, lab):
     """The LDS-tiled fp32 kernels on v_mfma_f32_16x16x4_f32 (taken by default only for large launches)."""
     monkeypatch.setenv("MMDYN_IGEMM_M16", "1")
+    monkeypatch.setenv("MMDYN_IGEMM_WS", "0")      # (the register-staged kernel: most fp32 shapes go to igemm_ws.hip by default)
     yield
     monkeypatch.delenv("MMDYN_IGEMM_M16")
 
@@ -128,6 +140,23 @@ def mfma16(monkeypatch):
 @pytest.mark.parametrize("case", IGEMM_CASES)
 def test_igemm_nt_mfma16(case, mfma16):
     test_igemm_nt(case)
+
+
+@pytest.fixture()
+def regstage(monkeypatch, lab):
+    """The register-staged LDS-tiled fp32 kernels (igemm_nt.hip) on shapes the wave-specialised kernels would take."""
+    monkeypatch.setenv("MMDYN_IGEMM_WS", "0")
+    yield
+
+
+@pytest.mark.parametrize("case", IGEMM_CASES)
+def test_igemm_nt_regstage(case, regstage):
+    test_igemm_nt(case)
+
+
+@pytest.mark.parametrize("case", [c for c in IGEMM_CASES if c[0] != DENSE][:6] + [IGEMM_CASES[0]])
+def test_igemm_dgrad_bn_epilogue_regstage(case, regstage):
+    test_igemm_dgrad_bn_epilogue(case)
 
 
 @pytest.mark.parametrize("case", [c for c in IGEMM_CASES if c[0] != DENSE][:6] + [IGEMM_CASES[0]])
@@ -154,11 +183,12 @@ def test_igemm_d16_splitk(rows, K, N, splitk, d16_tile):
 
 
 @pytest.mark.parametrize("path", ["lds", "d16"])
-def test_igemm_full_size_shapes(path, monkeypatch):
+def test_igemm_full_size_shapes(path, monkeypatch, request):
     """The bs-256 step's own decoder shapes, tile rules unforced -- "lds": the default path (LDS-tiled kernels, 16x16x4 MFMA
     on launches this large), "d16": the opt-in wave-independent kernels (MMDYN_D16=1) -- checked through row-sum /
     column-sum identities instead of an O(M N K) reference: sum_n C[row][n] = A_row . (sum_n B_n) per tap."""
     if path == "d16":
+        request.getfixturevalue("lab")
         monkeypatch.setenv("MMDYN_D16", "1")
     for mode, G, Bg, Hi, Cin, Ho, N, stride, offset in [(TCONV_S2P1, 4, 256, 8, 128, 16, 64, 1, 0),
                                                         (CONV, 1, 1024, 16, 64, 8, 128, 2, -1),
@@ -594,7 +624,7 @@ def test_bf16_packed_weights(bf16_mode):
                       32, 32, 32, 1, 0, 1, 1], [3, 4])
 
 
-def test_igemm_bf16_mixed_output_and_one_pixel_walk(monkeypatch):
+def test_igemm_bf16_mixed_output_and_one_pixel_walk(monkeypatch, lab):
     """(i) A Linear layer whose activated output alone is bf16 (fp32 pre-activation for the backward, bf16 operand for the
     convolution behind it: storage flag bit 6).  (ii) The k4 s1 p0 transposed convolution on all-bf16 operands in its three
     block walks -- pairs of pixels (default below 2048 blocks), one pixel per block (default from 2048 blocks on, forced

@@ -235,7 +235,7 @@ def check_extended_size_vs_oracle(device, size, B, use_pose=True, n_steps=2, pre
             assert tuple(step.last["recon_x"][0].shape) == (B, 3, size, size)
             named = dict(m.named_parameters())
             for k in names:
-                a, b = named[k].grad.double().cpu(), prm[k].grad.double()
+                a, b = named[k].grad.double().cpu() / step.loss_scale, prm[k].grad.double()    # (fp16 modes: static loss scale)
                 err = float((a - b).norm() / (b.norm() + 1e-30))
                 worst = max(worst, err)
                 assert err < grad_tol, (k, err)
