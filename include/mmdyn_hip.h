@@ -66,6 +66,14 @@ int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C,
                    float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
                    int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
                    void* stream);
+/* Input-gradient GEMM with the backward of a plain activation in its epilogue (replaces the separate element-wise
+ * x * act'(u) pass of loss.backward() through Swish / ReLU, vae.py:14-19, 215, 267, 331-334):
+ *     C = (A x Bp) * act'(u),   u = the layer's saved pre-activation at the C positions (row stride N),
+ * act = MMDYN_ACT_SWISH or MMDYN_ACT_RELU (for ReLU u may be the activated output: same sign).  No bias, second output,
+ * statistics or split-K.  flags: 0 = fp32 everywhere; otherwise as mmdyn_igemm_nt_mx (bit 3: u is bf16). */
+int mmdyn_igemm_nt_dgrad_act(const void* A, const void* Bp, void* C, const void* u, int act, int mode, int G, int Bg,
+                             int Hi, int Wi, int Cin, int Ho, int Wo, int N, int stride, int offset, int flags,
+                             void* stream);
 /* Input-gradient GEMM with the BatchNorm+Swish backward of the PRECEDING layer fused into its epilogue.
  * The tile of dL/d(activation) never reaches HBM as such: with y the layer's saved pre-BatchNorm output (same
  * rows/columns as C) and xhat = (y - mean[g]) * rstd[g], the kernel writes
@@ -182,7 +190,12 @@ int mmdyn_colstats_tiles(int rows_per_group);
 int mmdyn_bn_finalize(const float* partial, float* mean, float* rstd, float* running_mean,
                       float* running_var, int64_t* num_batches_tracked, double* scratch /* [32][G][2][C] */,
                       int G, int T, int C, int rows_per_group, float eps, float momentum, int repeat,
-                      void* stream);
+                      uint32_t* ticket, void* stream);
+/* `ticket` (here, in mmdyn_bn_bwd_finalize and in mmdyn_colsum; nullable): a zero-initialised 32-bit word in device
+ * memory that no other launch in flight uses.  With it the two stages run as ONE launch: every block publishes its
+ * partial sums (agent-scope release), draws a ticket, and the block that arrives last (agent-scope acquire) adds the
+ * partials in the same fixed order as the separate second kernel -- bit-identical results -- and puts the word back to
+ * zero (a HIP-graph replay finds it zero again).  Without it: two launches. */
 /* a = swish(gamma*(y-mean)*rstd + beta) */
 int mmdyn_bn_swish_fwd(const float* y, const float* mean, const float* rstd, const float* gamma,
                        const float* beta, float* a, int G, int rows_per_group, int C, void* stream);
@@ -192,7 +205,7 @@ int mmdyn_bn_swish_bwd_reduce(const float* da, const float* y, const float* mean
                               int rows_per_group, int C, void* stream);
 int mmdyn_bn_bwd_finalize(const float* partial, float* sums, float* dgamma, float* dbeta,
                           double* scratch /* [32][G][2][C] */, int G, int T, int C, float beta_acc,
-                          void* stream);
+                          uint32_t* ticket, void* stream);
 /* eval mode (model.eval(): nn.BatchNorm2d with training=False): mean[g][c] = running_mean[c],
  * rstd[g][c] = 1/sqrt(running_var[c] + eps); mmdyn_bn_swish_fwd then applies them.  No buffer update. */
 int mmdyn_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* rstd, int G, int C,
@@ -223,7 +236,8 @@ int mmdyn_act_bwd(const float* dh, const float* u, float* du, int64_t n, int act
 int mmdyn_dropout_expand(const float* h, const uint8_t* masks, float* out, int P, int B, int H,
                          float p_drop, void* stream);
 int mmdyn_dropout_reduce(const float* dout, const uint8_t* masks, float* dh, int P, int B, int H,
-                         float p_drop, void* stream);
+                         float p_drop, const float* u /* nullable [B][H]: dh *= act'(u), the activation in front of the
+                         dropout (vae.py:213-216) */, int act, void* stream);
 /* keep-masks / N(0,1) draws from a counter-based Philox-4x32-10 stream (throughput runs; parity runs inject
  * tensors).  The stream position is offset + *offset_dev (offset_dev may be null): keeping the running position
  * in device memory and bumping it with mmdyn_counter_add makes a captured HIP graph draw fresh numbers on replay. */
@@ -234,7 +248,8 @@ int mmdyn_random_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, c
 int mmdyn_counter_add(uint64_t* counter, uint64_t inc, void* stream);
 /* out[c] (+)= sum_r x[r][c]   (bias gradients); deterministic two-stage sum, scratch holds
  * mmdyn_colsum_chunks(rows) * C floats; perm 2 = the upsample-bias permutation hw*256+c -> c*25+hw; C % 4 == 0 */
-int mmdyn_colsum(const float* x, float* out, float* scratch, int rows, int C, int perm, float beta, void* stream);
+int mmdyn_colsum(const float* x, float* out, float* scratch, int rows, int C, int perm, float beta, uint32_t* ticket,
+                 void* stream);
 int mmdyn_colsum_chunks(int rows);
 /* out = x * s[0], s in device memory (chain rule through a scalar loss term without a host sync) */
 int mmdyn_scale_dev(const float* x, const float* s, float* out, int64_t n, void* stream);

@@ -100,6 +100,34 @@ template <typename T> __device__ __forceinline__ void st1(T* p, float v);
 template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = (bf16_t)(pack2_bf16(v, 0.f) & 0xffffu); }
 
+// Last-arriving block finishes (cdna_hip_programming.md section 5 "In-launch split-K reduction", Guideline 16 R1): every
+// block of a launch stores its partial result WRITE-THROUGH (st_wt: sc1 stores, so no release fence -- a fence would write
+// back the whole L2 slice, i.e. the dirty output lines of whatever GEMM the other lane is running: measured +0.16 ms per
+// step), drains them (s_waitcnt vmcnt(0) in every storing wave, then the block barrier) and draws a ticket; the block
+// that draws the last one returns true and may read every block's partial: one agent-scope acquire (one lane, then
+// s_waitcnt vmcnt(0) + the block barrier before the other waves load) drops its CU's stale L1 lines.  Placement-
+// independent.  `counter` is a zero-initialised word owned by this launch site (mmdyn_hip/ops.py hands out a slot per
+// launch); the last block puts it back to zero, so a HIP-graph replay finds it zero again.  The reducer must read the
+// partials through per-lane (vector) loads -- the scalar cache is not covered by the acquire.
+__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool last_block_arrives(unsigned* counter, unsigned nblocks, int* lds_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its write-through partial has left the core
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == nblocks - 1u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *lds_flag = last;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+
 #define MMDYN_LAUNCH_CHECK()                      \
   do {                                            \
     hipError_t e__ = hipGetLastError();           \

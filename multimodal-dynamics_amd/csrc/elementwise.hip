@@ -47,13 +47,15 @@ __global__ void dropout_expand_kernel(const float* __restrict__ h, const uint8_t
   }
 }
 
+// u != nullptr: the backward of the activation in front of the dropout rides along: dh = (sum ...) * act'(u)
 __global__ void dropout_reduce_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ masks,
-                                      float* __restrict__ dh, int P, int64_t bh, float scale) {
+                                      float* __restrict__ dh, int P, int64_t bh, float scale,
+                                      const float* __restrict__ u, int act) {
   for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < bh;
        j += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int p = 0; p < P; ++p) s += dout[(int64_t)p * bh + j] * ((float)masks[(int64_t)p * bh + j] * scale);
-    dh[j] = s;
+    dh[j] = u ? s * act_grad(u[j], act) : s;
   }
 }
 
@@ -132,9 +134,24 @@ __global__ void counter_add_kernel(uint64_t* __restrict__ c, uint64_t inc) {
 // out[c] (+)= sum_r x[r][c], two deterministic stages.  Stage 1: grid (C/128, chunks); a block covers 128 channels
 // (32 float4 columns) x one row chunk with 8 row lanes, 4 rows in flight per thread, LDS finish -> partial[chunk][C].
 // Stage 2 adds the chunks (and applies the upsample-bias row permutation).  C % 4 == 0.
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
-                                                             int rows, int C, int rows_per_chunk) {
+__device__ __forceinline__ void colsum_final_channel(const float* partial, float* out, int chunks, int C, int perm,
+                                                     float beta, int c) {
+  float t = 0.f;
+  for (int k = 0; k < chunks; ++k) t += partial[(size_t)k * C + c];
+  int o = c;
+  if (perm == 2) {
+    int hw = c / 256, ch = c - hw * 256;
+    o = ch * 25 + hw;
+  }
+  out[o] = (beta != 0.f ? beta * out[o] : 0.f) + t;
+}
+
+// ticket != nullptr: the block that arrives last adds the chunks (same order as colsum_final_kernel): one launch
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* partial,
+                                                             int rows, int C, int rows_per_chunk, unsigned* ticket,
+                                                             float* out, int perm, float beta) {
   __shared__ f32x4 red[8][32];
+  __shared__ int last_flag;
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c4 = blockIdx.x * 32 + cl;                     // float4 column
   const int CV = C >> 2;
@@ -159,22 +176,24 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     f32x4 t = red[0][cl];
 #pragma unroll
     for (int l = 1; l < 8; ++l) t += red[l][cl];
-    *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * C + c4 * 4) = t;
+    float* dst = partial + (size_t)blockIdx.y * C + c4 * 4;
+    if (ticket) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) st_wt(dst + k, t[k]);
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = t;
+    }
   }
+  if (!ticket) return;
+  if (!last_block_arrives(ticket, gridDim.x * gridDim.y, &last_flag)) return;
+  for (int c = threadIdx.x; c < C; c += 256) colsum_final_channel(partial, out, gridDim.y, C, perm, beta, c);
 }
 
 __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int chunks, int C,
                                     int perm, float beta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float t = 0.f;
-  for (int k = 0; k < chunks; ++k) t += partial[(size_t)k * C + c];
-  int o = c;
-  if (perm == 2) {
-    int hw = c / 256, ch = c - hw * 256;
-    o = ch * 25 + hw;
-  }
-  out[o] = (beta != 0.f ? beta * out[o] : 0.f) + t;
+  colsum_final_channel(partial, out, chunks, C, perm, beta, c);
 }
 
 __global__ void sum_blocks_kernel(const float* __restrict__ x, float* __restrict__ out, int P, int64_t n) {
@@ -364,12 +383,12 @@ extern "C" int mmdyn_dropout_expand(const float* h, const uint8_t* masks, float*
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_dropout_reduce(const float* dout, const uint8_t* masks, float* dh, int P, int B, int H,
-                                    float p_drop, void* stream) {
+                                    float p_drop, const float* u, int act, void* stream) {
   if (!dout || !masks || !dh) return MMDYN_ERR_NULL;
   if (p_drop < 0.f || p_drop >= 1.f) return MMDYN_ERR_SHAPE;
   int64_t bh = (int64_t)B * H;
   hipLaunchKernelGGL(dropout_reduce_kernel, dim3(ew_grid(bh)), dim3(256), 0, ST, dout, masks, dh, P, bh,
-                     1.0f / (1.0f - p_drop));
+                     1.0f / (1.0f - p_drop), u, act);
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_random_masks(uint8_t* masks, int64_t n, float p_drop, uint64_t seed, uint64_t offset,
@@ -396,13 +415,14 @@ extern "C" int mmdyn_colsum_chunks(int rows) {
   return c < 1 ? 1 : (c > 32 ? 32 : c);
 }
 extern "C" int mmdyn_colsum(const float* x, float* out, float* scratch, int rows, int C, int perm, float beta,
-                            void* stream) {
+                            uint32_t* ticket, void* stream) {
   if (!x || !out || !scratch) return MMDYN_ERR_NULL;
   if ((perm == 2 && C != 6400) || C % 4 || rows <= 0) return MMDYN_ERR_SHAPE;
   const int chunks = mmdyn_colsum_chunks(rows);
   const int rpc = ceil_div(rows, chunks);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C / 4, 32), chunks), dim3(256), 0, ST, x, scratch, rows, C,
-                     rpc);
+                     rpc, ticket, out, perm, beta);
+  if (ticket) MMDYN_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, ST, scratch, out, chunks, C, perm,
                      beta);
   MMDYN_LAUNCH_CHECK();

@@ -428,6 +428,8 @@ static int launch_t(const float* A, const float* Bp, const float* bias, float* C
 
 int mmdyn_igemm_d16_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats,
                         float* ws, IgemmGeom g, int stride, int offset, hipStream_t st) {
+  if (g.bn_y && !g.bn_mean) return 1;          // activation-only backward epilogue: not built here
+
   (void)stride;
   (void)offset;
   D16Tile t;

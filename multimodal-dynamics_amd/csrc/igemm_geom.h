@@ -25,6 +25,10 @@ struct IgemmGeom {
   const float* bn_rstd;   // [G][N]
   const float* bn_gamma;  // [N]
   const float* bn_beta;   // [N]
+  // bn_mean == nullptr with bn_y set: the plain ACTIVATION backward epilogue -- C = acc * act'(u), u = bn_y (the layer's
+  // saved pre-activation at the C positions), act' chosen by bwd_act (MMDYN_ACT_SWISH / MMDYN_ACT_RELU); no statistics.
+  // (with bn_mean set bwd_act is MMDYN_ACT_SWISH: the BatchNorm + Swish backward above)
+  int bwd_act;
   // bf16 activation storage (bf16 matrix-core variants only): which of the activation tensors are bf16 in HBM
   int a_b16, c_b16, bny_b16;
   int cact_b16;   // the second (activated) output is bf16 while C itself is fp32

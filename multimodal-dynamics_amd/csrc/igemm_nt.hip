@@ -468,10 +468,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = n0 + wn * WN + nt * TS + cl;
-    bn_m[nt] = bnbwd ? g.bn_mean[(size_t)grp * g.N + col] : 0.f;
-    bn_r[nt] = bnbwd ? g.bn_rstd[(size_t)grp * g.N + col] : 0.f;
-    bn_g[nt] = bnbwd ? g.bn_gamma[col] : 0.f;
-    bn_b[nt] = bnbwd ? g.bn_beta[col] : 0.f;
+    const bool bn = bnbwd && g.bn_mean != nullptr;        // (activation-only backward: xhat = u, gamma = 1, beta = 0)
+    bn_m[nt] = bn ? g.bn_mean[(size_t)grp * g.N + col] : 0.f;
+    bn_r[nt] = bn ? g.bn_rstd[(size_t)grp * g.N + col] : 1.f;
+    bn_g[nt] = bn ? g.bn_gamma[col] : 1.f;
+    bn_b[nt] = bn ? g.bn_beta[col] : 0.f;
   }
 
 #pragma unroll
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
             const float yv = (BF16 && g.bny_b16) ? ld1<bf16_t>(reinterpret_cast<const bf16_t*>(g.bn_y) + (size_t)ooff + col)
                                                  : g.bn_y[(size_t)ooff + col];
             xh = (yv - bn_m[nt]) * bn_r[nt];
-            v *= swish_gradf_(bn_g[nt] * xh + bn_b[nt]);
+            v *= act_grad(bn_g[nt] * xh + bn_b[nt], g.bwd_act);
           }
           colsum[nt] += v;
           colsq[nt] += v * xh;
@@ -814,6 +815,11 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   g.bn_rstd = bn_rstd;
   g.bn_gamma = bn_gamma;
   g.bn_beta = bn_beta;
+  g.bwd_act = bn_mean ? MMDYN_ACT_SWISH : act;       // activation-only backward epilogue: `act` names the activation
+  if (bn_y && !bn_mean) {
+    if (stats || C_act || bias || splitk > 1 || mode == MMDYN_IM2COL3 || ldc != N) return MMDYN_ERR_SHAPE;
+    g.act = MMDYN_ACT_NONE;
+  }
   g.a_b16 = (storage_flags & 2) != 0;
   g.c_b16 = (storage_flags & 4) != 0;
   g.bny_b16 = (storage_flags & 8) != 0;
@@ -918,6 +924,18 @@ extern "C" int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C
   if (bf16 < 0 || bf16 > 2) return MMDYN_ERR_SHAPE;
   return igemm_entry(A, Bp, nullptr, C, nullptr, stats, nullptr, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset,
                      MMDYN_ACT_NONE, 1, stream, bf16 != 0, y, mean, rstd, gamma, beta, bf16 == 2 ? 32 : 0);
+}
+
+/* Input-gradient GEMM with the backward of a plain ACTIVATION in its epilogue: C = (A x Bp) * act'(u), u the layer's saved
+ * pre-activation, same rows / columns as C.  flags as mmdyn_igemm_nt_mx (bit 3: u is bf16); 0 = fp32 everywhere. */
+extern "C" int mmdyn_igemm_nt_dgrad_act(const void* A, const void* Bp, void* C, const void* u, int act, int mode, int G, int Bg,
+                                        int Hi, int Wi, int Cin, int Ho, int Wo, int N, int stride, int offset, int flags,
+                                        void* stream) {
+  if (!u) return MMDYN_ERR_NULL;
+  if (act != MMDYN_ACT_SWISH && act != MMDYN_ACT_RELU) return MMDYN_ERR_SHAPE;
+  return igemm_entry((const float*)A, (const float*)Bp, nullptr, (float*)C, nullptr, nullptr, nullptr, mode, G, Bg, Hi, Wi, Cin,
+                     Ho, Wo, N, N, stride, offset, act, 1, stream, (flags & 1) != 0 || (flags & 32) != 0, (const float*)u, nullptr,
+                     nullptr, nullptr, nullptr, flags & ~1);
 }
 
 /* fp16 matrix cores (v_mfma_f32_32x32x16_f16): operands rounded to IEEE half (RNE) on their way into the MFMA, fp32

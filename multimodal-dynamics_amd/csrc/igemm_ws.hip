@@ -253,10 +253,11 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int col = n0 + wn * WN + nt * TS + cl;
-      bn_m[nt] = bnbwd ? g.bn_mean[(size_t)grp * g.N + col] : 0.f;
-      bn_r[nt] = bnbwd ? g.bn_rstd[(size_t)grp * g.N + col] : 0.f;
-      bn_g[nt] = bnbwd ? g.bn_gamma[col] : 0.f;
-      bn_b[nt] = bnbwd ? g.bn_beta[col] : 0.f;
+      const bool bn = bnbwd && g.bn_mean != nullptr;      // (activation-only backward: xhat = u, gamma = 1, beta = 0)
+      bn_m[nt] = bn ? g.bn_mean[(size_t)grp * g.N + col] : 0.f;
+      bn_r[nt] = bn ? g.bn_rstd[(size_t)grp * g.N + col] : 1.f;
+      bn_g[nt] = bn ? g.bn_gamma[col] : 1.f;
+      bn_b[nt] = bn ? g.bn_beta[col] : 0.f;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
           float v = acc[mt][nt][e];
           if (bnbwd) {
             const float xh = live ? (yv[mt][e][nt] - bn_m[nt]) * bn_r[nt] : 0.f;
-            v = live ? v * swish_gradf_(bn_g[nt] * xh + bn_b[nt]) : v;
+            v = live ? v * act_grad(bn_g[nt] * xh + bn_b[nt], g.bwd_act) : v;
             colsum[nt] += v;
             colsq[nt] += v * xh;
           } else {

@@ -23,6 +23,7 @@ struct PatchEpi {            // the epilogue set of igemm_nt_kernel (all optiona
   const float* bn_rstd;
   const float* bn_gamma;
   const float* bn_beta;
+  int bwd_act;               // bn_mean == nullptr: activation-only backward, C = acc * act'(bn_y)
 };
 
 template <int H, int W, int CIN, int N, int TH>
@@ -93,10 +94,11 @@ __global__ __launch_bounds__(512) void tconv_patch_kernel(const float* __restric
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int col = n * 16 + r;
-      bn_m[n] = bnbwd ? ep.bn_mean[(size_t)grp_b * N + col] : 0.f;
-      bn_r[n] = bnbwd ? ep.bn_rstd[(size_t)grp_b * N + col] : 0.f;
-      bn_g[n] = bnbwd ? ep.bn_gamma[col] : 0.f;
-      bn_b[n] = bnbwd ? ep.bn_beta[col] : 0.f;
+      const bool bn = bnbwd && ep.bn_mean != nullptr;
+      bn_m[n] = bn ? ep.bn_mean[(size_t)grp_b * N + col] : 0.f;
+      bn_r[n] = bn ? ep.bn_rstd[(size_t)grp_b * N + col] : 1.f;
+      bn_g[n] = bn ? ep.bn_gamma[col] : 1.f;
+      bn_b[n] = bn ? ep.bn_beta[col] : 0.f;
       bias_v[n] = ep.bias ? ep.bias[col] : 0.f;
     }
     for (int cls = 0; cls < 4; ++cls) {
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(512) void tconv_patch_kernel(const float* __restric
             float v = acc[m][n][e];
             if (bnbwd) {               // du = da * swish'(gamma * xhat + beta); the sums are those of the BatchNorm backward
               const float xh = (ep.bn_y[ooff + n * 16] - bn_m[n]) * bn_r[n];
-              v *= swish_gradf_(bn_g[n] * xh + bn_b[n]);
+              v *= act_grad(bn_g[n] * xh + bn_b[n], ep.bwd_act);
               colsum[n] += v;
               colsq[n] += v * xh;
             } else {
@@ -234,7 +236,7 @@ int mmdyn_tconv_patch_try(const float* A, const float* Bp, const float* bias, fl
   if (!patch_tiles(g.mode, g.Hi, g.Wi, g.Cin, g.Ho, g.Wo, g.N)) return 1;
   if (ws || g.splitk != 1) return MMDYN_ERR_SHAPE;          // (split-K is a DENSE-mode feature: the entry point has refused it)
   if (g.bn_y && g.ldc != g.N) return MMDYN_ERR_SHAPE;
-  const PatchEpi ep{bias, C_act, g.act, g.bn_y, g.bn_mean, g.bn_rstd, g.bn_gamma, g.bn_beta};
+  const PatchEpi ep{bias, C_act, g.act, g.bn_y, g.bn_mean, g.bn_rstd, g.bn_gamma, g.bn_beta, g.bwd_act};
   if (g.Hi == 16) return patch_launch<16, 16, 64, 32, 16>(A, Bp, C, stats, g, ep, st);
   if (g.Hi == 32) return patch_launch<32, 32, 32, 32, 16>(A, Bp, C, stats, g, ep, st);
   return patch_launch<64, 64, 32, 32, 8>(A, Bp, C, stats, g, ep, st);

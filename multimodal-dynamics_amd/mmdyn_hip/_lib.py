@@ -30,6 +30,7 @@ MAX_EXPERTS = 4
 _SIGNATURES = {
     "mmdyn_igemm_nt": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_nt_dgrad_bn": "ppppppppp" + "iiiiiiiiiiii" + "p",
+    "mmdyn_igemm_nt_dgrad_act": "pppp" + "i" + "iiiiiiiiiii" + "i" + "p",
     "mmdyn_igemm_nt_bf16": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_nt_f16": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_stat_tiles": "iiiiiiiii",
@@ -51,10 +52,10 @@ _SIGNATURES = {
     "mmdyn_tconv_out3_fwd": "ppp" + "iii" + "p",
     "mmdyn_colstats": "pp" + "iii" + "p",
     "mmdyn_colstats_tiles": "i",
-    "mmdyn_bn_finalize": "ppppppp" + "iiii" + "ff" + "i" + "p",
+    "mmdyn_bn_finalize": "ppppppp" + "iiii" + "ff" + "i" + "pp",
     "mmdyn_bn_swish_fwd": "pppppp" + "iii" + "p",
     "mmdyn_bn_swish_bwd_reduce": "ppppppp" + "iii" + "p",
-    "mmdyn_bn_bwd_finalize": "ppppp" + "iii" + "f" + "p",
+    "mmdyn_bn_bwd_finalize": "ppppp" + "iii" + "f" + "pp",
     "mmdyn_bn_eval_stats": "pppp" + "ii" + "f" + "p",
     "mmdyn_bn_reduce_partials": "ppp" + "iii" + "p",
     "mmdyn_bn_finalize_sums": "pppppp" + "iii" + "ff" + "i" + "p",
@@ -63,11 +64,11 @@ _SIGNATURES = {
     "mmdyn_act_fwd": "pp" + "l" + "i" + "p",
     "mmdyn_act_bwd": "ppp" + "l" + "i" + "p",
     "mmdyn_dropout_expand": "ppp" + "iii" + "f" + "p",
-    "mmdyn_dropout_reduce": "ppp" + "iii" + "f" + "p",
+    "mmdyn_dropout_reduce": "ppp" + "iii" + "f" + "pi" + "p",
     "mmdyn_random_masks": "p" + "l" + "f" + "QQ" + "pp",
     "mmdyn_random_normal": "p" + "l" + "QQ" + "pp",
     "mmdyn_counter_add": "p" + "Q" + "p",
-    "mmdyn_colsum": "ppp" + "iii" + "f" + "p",
+    "mmdyn_colsum": "ppp" + "iii" + "f" + "pp",
     "mmdyn_colsum_chunks": "i",
     "mmdyn_scale_dev": "ppp" + "l" + "p",
     "mmdyn_sum_blocks": "pp" + "i" + "l" + "p",

@@ -43,11 +43,15 @@ class FlatParams:
 
     def __init__(self, model):
         named = dict(model.named_parameters())
-        heads = [k for k in named if ".linear_" in k]
+        # the two heads of an encoder are ONE fused GEMM ([means | log_var] rows): keeping their weights adjacent (and
+        # their biases adjacent) in the flat buffers lets the backward write both gradients as one [2L][K] / [2L] block
+        rank = {"linear_means.weight": 0, "linear_log_var.weight": 1, "linear_means.bias": 2, "linear_log_var.bias": 3}
+        heads = sorted((k for k in named if ".linear_" in k), key=lambda k: (k.split(".", 1)[0], rank[k.split(".", 1)[1]]))
         groups = {p: [] for p in _PREFIX_ORDER}
+        groups["heads"] = list(heads)
         for k in named:
             if k in heads:
-                groups["heads"].append(k)
+                continue
             elif k.split(".", 1)[0] in ("visual_encoder", "tactile_encoder") and ".fc_net." in k:
                 groups["encoder_fc"].append(k)
             else:
@@ -80,6 +84,17 @@ class FlatParams:
         named = dict(self.model.named_parameters())
         k = self.order[0]
         return named[k].data_ptr() == self.P[k].data_ptr()
+
+    def fused_heads_grad(self, prefix):
+        """(gW [2L][K], gb [2L]) views of the flat gradient buffer covering linear_means | linear_log_var of ``prefix``, or
+        None when the two are not adjacent there."""
+        kw = [f"{prefix}.linear_means.weight", f"{prefix}.linear_log_var.weight"]
+        kb = [f"{prefix}.linear_means.bias", f"{prefix}.linear_log_var.bias"]
+        L, K = self.P[kw[0]].shape
+        if self.offsets[kw[1]] != self.offsets[kw[0]] + L * K or self.offsets[kb[1]] != self.offsets[kb[0]] + L:
+            return None
+        ow, ob = self.offsets[kw[0]], self.offsets[kb[0]]
+        return self.grad[ow:ow + 2 * L * K].view(2 * L, K), self.grad[ob:ob + 2 * L]
 
     def sub(self, prefix, which="P"):
         src = self.P if which == "P" else self.G
@@ -447,16 +462,19 @@ class MVAEStep:
     def _ph_enc_bwd_steps(self, m):
         c, FP, B = self.ctx, self.params, self.ctx["B"]
         enc = self._MOD[m][0]
-        dhd = layers.heads_backward(c["h" + m], c["do" + m], FP.sub(enc, "G"))
+        dhd = layers.heads_backward(c["h" + m], c["do" + m], FP.sub(enc, "G"), fused=FP.fused_heads_grad(enc))
         dh = torch.empty(B, 512, device=c["dev"])
-        ops.B.dropout_reduce(dhd, c["mask"][m], dh, len(self._passes_of(m)), B, 512, DROPOUT_P)
+        # (the FC layer's Swish backward rides along: dh is dL/du5)
+        ops.B.dropout_reduce(dhd, c["mask"][m], dh, len(self._passes_of(m)), B, 512, DROPOUT_P, u=c["e" + m]["u5"],
+                             act=ops.ACT_SWISH)
         yield
-        yield from layers.encoder_trunk_backward_steps(FP.sub(enc), c["e" + m], dh, FP.sub(enc, "G"))
+        yield from layers.encoder_trunk_backward_steps(FP.sub(enc), c["e" + m], dh, FP.sub(enc, "G"), dh_is_du=True)
 
     def _ph_pose_enc_bwd(self):
         c, FP = self.ctx, self.params
         if self.use_pose:
-            dhp = layers.heads_backward(c["hp"], c["dop"], FP.sub("pose_encoder", "G"))
+            dhp = layers.heads_backward(c["hp"], c["dop"], FP.sub("pose_encoder", "G"),
+                                        fused=FP.fused_heads_grad("pose_encoder"))
             layers.pose_encoder_trunk_backward(FP.sub("pose_encoder"), c["ep"], dhp, FP.sub("pose_encoder", "G"))
 
     def _publish(self):

@@ -21,6 +21,11 @@ from .ops import ACT_NONE, ACT_SWISH, ACT_RELU, DENSE, CONV, TCONV_S2P1, IM2COL3
 from .models.shapes import BN_EPS, BN_MOMENTUM, FEAT
 
 
+import os as _os
+_AB_OLDSPLITK = bool(_os.environ.get("MMDYN_AB_OLDSPLITK"))     # (A/B measurements of this round; see docs/LAB_NOTES.md)
+_AB_NODGRADACT = bool(_os.environ.get("MMDYN_AB_NODGRADACT"))
+
+
 def _new(like, *shape, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
@@ -54,10 +59,14 @@ def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch
     C = _new(A, rows, N, dtype=out_dtype)
     Ca = _new(A, rows, N, dtype=out_dtype if act_dtype is None else act_dtype) if want_act else None
     # split-K only when the 64x64 tiling leaves most of the 256 CUs idle AND K is long enough to amortise the
-    # partial-sum pass (measured: tests/microbench/sweep_dense.py)
+    # partial-sum pass and its second launch.  Re-measured with the wave-specialised kernels (tests/microbench/
+    # splitk_probe.py, profiles/r3/splitk_probe.txt): K = 512 problems (heads, pose MLPs: 128 tiles) are faster unsplit
+    # (15.7 vs 16.8 us incl. the reduce launch); 256 x 6400 -> 512 wants 8 slices (24 us; 16: 27), 1024 x 6400 -> 256 four.
     tiles = _cdiv(rows, 64) * _cdiv(N, 64)
     steps = K // 32
-    splitk = max(1, min(512 // tiles, steps // 8)) if (N % 64 == 0 and out_dtype == torch.float32 and act_dtype is None) else 1
+    splitk = max(1, min(256 // tiles, steps // 16)) if (N % 64 == 0 and out_dtype == torch.float32 and act_dtype is None) else 1
+    if _AB_OLDSPLITK and (N % 64 == 0 and out_dtype == torch.float32 and act_dtype is None):
+        splitk = max(1, min(512 // tiles, steps // 8))
     # (kept in the 16-bit matrix-core modes too: without it bf16s bs 128 measured 2.45 vs 2.31 ms per step)
     if splitk > 1:
         ws = _new(A, splitk, rows, N)
@@ -79,6 +88,17 @@ def conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride=1, offset=0, stats=Fals
     ops.B.igemm_nt(x, Wp, None, y, None, st, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset,
                    ACT_NONE, 1)
     return y, st, T
+
+
+def dgrad_act(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, u, act, stride=1, offset=0):
+    """Input-gradient GEMM with the backward of the activation whose pre-activation is ``u`` in its epilogue:
+    returns dL/du = (x (*) Wp) * act'(u), stored like ``u``."""
+    if _AB_NODGRADACT:
+        d, _, _ = conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride, offset, out_dtype=u.dtype)
+        return act_backward(d, u, act)
+    du = torch.empty_like(u)
+    ops.B.igemm_nt_dgrad_act(x, Wp, du, u, act, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride, offset)
+    return du
 
 
 def tconv_s1p0(x, Wsp, G, Bg, Cin, N, stats=False):
@@ -432,8 +452,9 @@ def linear_forward(x, W, b, act=ACT_NONE):
     return None, y
 
 
-def linear_backward(dy, x, W, gW, gb, need_dx=True):
-    """Gradients of y = x W^T + b given dy (already through the activation).  Returns dx or None."""
+def linear_backward(dy, x, W, gW, gb, need_dx=True, x_act=ACT_NONE):
+    """Gradients of y = x W^T + b given dy (already through the activation).  Returns dx or None.
+    ``x_act``: x is the OUTPUT of that activation (ReLU: act'(u) = [x > 0]) and dx is returned through it: dL/du."""
     rows, K = x.shape
     N = W.shape[0]
     if K % 32 == 0 and N % 32 == 0:
@@ -443,11 +464,13 @@ def linear_backward(dy, x, W, gW, gb, need_dx=True):
         if not need_dx:
             return None
         Wt = repack(W, N, K, K, N, 1)
+        if x_act != ACT_NONE:
+            return dgrad_act(dy, Wt, DENSE, 1, rows, 1, N, 1, K, x, x_act)
         dx, _ = dense(dy, Wt, None, rows, N, K)
         return dx
     dx = _new(x, rows, K) if need_dx else None
     ops.B.linear_small_bwd(dy, x, W, dx, gW, gb, rows, K, N, 0.0)
-    return dx
+    return act_backward(dx, x, x_act) if (need_dx and x_act != ACT_NONE) else dx
 
 
 def act_backward(dh, u, act):
@@ -540,11 +563,12 @@ def encoder_trunk_backward(*a, **k):
     return run(encoder_trunk_backward_steps(*a, **k))
 
 
-def encoder_trunk_backward_steps(P, c, dh, grads):
-    """dh: [Bt,512]; writes every weight gradient of the trunk into ``grads[key]`` (canonical layout)."""
+def encoder_trunk_backward_steps(P, c, dh, grads, dh_is_du=False):
+    """dh: [Bt,512]; writes every weight gradient of the trunk into ``grads[key]`` (canonical layout).
+    ``dh_is_du``: the caller has already taken dh through the FC layer's Swish (c["u5"]), e.g. in its dropout backward."""
     Bt, G, Bg, pk, S, st = c["Bt"], c["G"], c["Bg"], c["pk"], c["S"], c["stages"]
     n = len(st)
-    du5 = act_backward(dh, c["u5"], ACT_SWISH)
+    du5 = act_backward(dh, c["u5"], ACT_SWISH) if not dh_is_du else dh
     wgrad(du5, st[-1]["a"], grads["fc_net.0.weight"], DENSE, Bt, 1, 512, 1, FEAT, perm=1)
     ops.B.colsum(du5, grads["fc_net.0.bias"], Bt, 512, 0, 0.0)
     da, _ = dense(du5, pk["WfT"], None, Bt, 512, FEAT, out_dtype=ACT_DTYPE)  # WfT: [hw*256+c][512]
@@ -572,9 +596,8 @@ def encoder_trunk_backward_steps(P, c, dh, grads):
         if k > 0:
             yield
     t = st[0]
-    da1, _, _ = conv_like(dy, pk["W2s"], TCONV_S2P1, 1, Bt, t["Ho"], t["cout"], t["Hi"], t["cin"])
+    du1 = dgrad_act(dy, pk["W2s"], TCONV_S2P1, 1, Bt, t["Ho"], t["cout"], t["Hi"], t["cin"], c["u1"], ACT_SWISH)
     yield
-    du1 = act_backward(da1, c["u1"], ACT_SWISH)
     wgrad(du1, c["x"], grads["conv_net.0.weight"], IM2COL3, Bt, S // 2, 32, S, 64, cg_canon=48)
 
 
@@ -654,9 +677,9 @@ def decoder_backward_steps(P, c, dlogits, grads, need_dz=True):
         yield
     t = st[0]
     wgrad(c["h0"], dy, grads[f"hallucinate.{t['i']}.weight"], CONV, Bt, 5, t["cin"], 8, t["cout"], 1, 0)
-    dh0, _, _ = conv_like(dy, pk["W1k"], CONV, 1, Bt, 8, t["cout"], 5, t["cin"], 1, 0, out_dtype=torch.float32)   # FC level
+    # input gradient of the k4 s1 p0 layer with the FC layer's Swish backward in its epilogue (FC level: fp32)
+    du0 = dgrad_act(dy, pk["W1k"], CONV, 1, Bt, 8, t["cout"], 5, t["cin"], c["u0"], ACT_SWISH, 1, 0)
     yield
-    du0 = act_backward(dh0, c["u0"], ACT_SWISH)
     wgrad(du0, c["z"], grads["upsample.0.weight"], DENSE, Bt, 1, FEAT, 1, L, cg_canon=c["Lc"], perm=2)
     ops.B.colsum(du0, grads["upsample.0.bias"], Bt, FEAT, 2, 0.0)
     if not need_dz:
@@ -681,16 +704,22 @@ def heads_forward(P, hd, packed=None, cond=None):
     return out, {"hd": hd, "pk": pk, "L": L, "K": K, "Kp": Kp, "K0": K0}
 
 
-def heads_backward(c, dout, grads, need_dx=True):
+def heads_backward(c, dout, grads, need_dx=True, fused=None):
+    """``fused``: (gW [2L][K], gb [2L]) views covering both heads' gradients where the caller keeps them adjacent (the
+    fused engine's flat buffer): the fused GEMM's gradients are then written in place, no split copies."""
     hd, L, K, Kp = c["hd"], c["L"], c["K"], c["Kp"]
     rows = hd.shape[0]
-    gW, gb = _new(hd, 2 * L, Kp), _new(hd, 2 * L)
-    wgrad(dout, hd, gW, DENSE, rows, 1, 2 * L, 1, Kp)
-    ops.B.colsum(dout, gb, rows, 2 * L, 0, 0.0)
-    ops.B.repack2d(gW[:L], grads["linear_means.weight"], L, Kp, L, K, 0)      # drops the zero-padded columns
-    ops.B.repack2d(gW[L:], grads["linear_log_var.weight"], L, Kp, L, K, 0)
-    ops.B.repack2d(gb[:L], grads["linear_means.bias"], L, 1, L, 1, 0)
-    ops.B.repack2d(gb[L:], grads["linear_log_var.bias"], L, 1, L, 1, 0)
+    if fused is not None and K == Kp:
+        wgrad(dout, hd, fused[0], DENSE, rows, 1, 2 * L, 1, Kp)
+        ops.B.colsum(dout, fused[1], rows, 2 * L, 0, 0.0)
+    else:
+        gW, gb = _new(hd, 2 * L, Kp), _new(hd, 2 * L)
+        wgrad(dout, hd, gW, DENSE, rows, 1, 2 * L, 1, Kp)
+        ops.B.colsum(dout, gb, rows, 2 * L, 0, 0.0)
+        ops.B.repack2d(gW[:L], grads["linear_means.weight"], L, Kp, L, K, 0)      # drops the zero-padded columns
+        ops.B.repack2d(gW[L:], grads["linear_log_var.weight"], L, Kp, L, K, 0)
+        ops.B.repack2d(gb[:L], grads["linear_means.bias"], L, 1, L, 1, 0)
+        ops.B.repack2d(gb[L:], grads["linear_log_var.bias"], L, 1, L, 1, 0)
     if not need_dx:
         return None
     dx, _ = dense(dout, c["pk"]["WhT"], None, rows, 2 * L, Kp)
@@ -711,8 +740,9 @@ def pose_encoder_trunk_forward(P, pose):
 
 
 def pose_encoder_trunk_backward(P, c, dh2, grads):
-    dh1 = linear_backward(dh2, c["h1"], P["fc_net.2.weight"], grads["fc_net.2.weight"], grads["fc_net.2.bias"])
-    du1 = act_backward(dh1, c["h1"], ACT_RELU)       # ReLU: sign of the output equals sign of the input
+    # (ReLU: the sign of the output equals the sign of the input, so h1 stands in for the pre-activation)
+    du1 = linear_backward(dh2, c["h1"], P["fc_net.2.weight"], grads["fc_net.2.weight"], grads["fc_net.2.bias"],
+                          x_act=ACT_RELU)
     linear_backward(du1, c["x"], P["fc_net.0.weight"], grads["fc_net.0.weight"], grads["fc_net.0.bias"],
                     need_dx=False)
 
@@ -726,11 +756,9 @@ def pose_decoder_forward(P, z):
 
 
 def pose_decoder_backward(P, c, dout, grads, need_dz=True):
-    dh2 = linear_backward(dout, c["h2"], P["deconv_net.4.weight"], grads["deconv_net.4.weight"],
-                          grads["deconv_net.4.bias"])
-    du2 = act_backward(dh2, c["h2"], ACT_RELU)
-    dh1 = linear_backward(du2, c["h1"], P["deconv_net.2.weight"], grads["deconv_net.2.weight"],
-                          grads["deconv_net.2.bias"])
-    du1 = act_backward(dh1, c["h1"], ACT_RELU)
+    du2 = linear_backward(dout, c["h2"], P["deconv_net.4.weight"], grads["deconv_net.4.weight"],
+                          grads["deconv_net.4.bias"], x_act=ACT_RELU)
+    du1 = linear_backward(du2, c["h1"], P["deconv_net.2.weight"], grads["deconv_net.2.weight"],
+                          grads["deconv_net.2.bias"], x_act=ACT_RELU)
     return linear_backward(du1, c["z"], P["deconv_net.0.weight"], grads["deconv_net.0.weight"],
                            grads["deconv_net.0.bias"], need_dx=need_dz)

@@ -10,6 +10,8 @@ exercise the host-side orchestration on a machine without a GPU; nothing in the 
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -44,15 +46,42 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# The "last block finishes" single-launch forms of mmdyn_bn_finalize / mmdyn_bn_bwd_finalize / mmdyn_colsum are OFF by
+# default: measured on the two-lane step they cost 0.12 ms (fp32 bs 256: 6.78 -> 6.90 ms; bf16s bs 128: 2.165 -> 2.19 ms) --
+# up to 1024 blocks arrive on one counter (~12 ns per arrival) and every block drains its stores before it may leave
+# (docs/LAB_NOTES.md D).  MMDYN_TICKET=1 switches them on (kernel tests, experiments).
+_USE_TICKET = bool(os.environ.get("MMDYN_TICKET"))
+
+
 class HipBackend:
     name = "hip"
 
     def __init__(self, lib_path=None):
         self._l, self._lib_path = None, lib_path       # lib_path: the LAB build (tests / microbenchmarks only)
+        self._tickets = {}                             # device -> (zeroed int32 pool, next slot)
+        self.force_ticket = False
         # "fp32": v_mfma_f32_32x32x2_f32 (the reference's arithmetic, the default and the BASELINE configs[1] path);
         # "bf16": operands rounded to bf16 on their way into the matrix cores, fp32 accumulate (configs[2]);
         # "fp16": the same with IEEE-half operands (configs[4]); "bf16s": bf16 + bf16 activation storage
         self.precision = "fp32"
+
+    TICKET_SLOTS, TICKET_STRIDE = 4096, 16             # one 64-byte line per slot
+
+    def _ticket(self, like):
+        """Address of a zero-initialised arrival counter for ONE launch (the "last block finishes" kernels:
+        mmdyn_bn_finalize, mmdyn_bn_bwd_finalize, mmdyn_colsum).  Slots are handed out round-robin: a slot comes up again
+        only after 4096 such launches -- far more than a train step issues -- so no two launches in flight (the two lanes
+        of the engine, or the nodes of one captured HIP graph) ever share one; the kernel that used a slot leaves it zero."""
+        if not (_USE_TICKET or self.force_ticket):
+            return None
+        dev = like.device
+        ent = self._tickets.get(dev)
+        if ent is None:
+            ent = [torch.zeros(self.TICKET_SLOTS * self.TICKET_STRIDE, dtype=torch.int32, device=dev), 0]
+            self._tickets[dev] = ent
+        pool, nxt = ent
+        ent[1] = (nxt + 1) % self.TICKET_SLOTS
+        return pool.data_ptr() + 4 * self.TICKET_STRIDE * nxt
 
     @property
     def lib(self):
@@ -109,6 +138,16 @@ class HipBackend:
                                                _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride,
                                                offset, {"fp32": 0, "fp16": 2}.get(self.precision, 1), _stream()),
               "mmdyn_igemm_nt_dgrad_bn")
+
+    def igemm_nt_dgrad_act(self, A, Bp, C, u, act, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset):
+        """C = (A x Bp) * act'(u): input-gradient GEMM with the activation backward in its epilogue."""
+        (pa, a16), (pc, c16), (pu, u16), (pb, b16) = _aptr(A), _aptr(C), _aptr(u), _aptr(Bp)
+        if (a16 or c16 or u16 or b16) and self.precision in ("fp32", "fp16"):
+            raise ValueError("mmdyn_hip: bf16 tensors need a bf16 precision mode")
+        flags = {"fp32": 0, "fp16": 32}.get(self.precision, 1)
+        flags |= (2 if a16 else 0) | (4 if c16 else 0) | (8 if u16 else 0) | (16 if b16 else 0)
+        check(self.lib.mmdyn_igemm_nt_dgrad_act(pa, pb, pc, pu, int(act), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset,
+                                                flags, _stream()), "mmdyn_igemm_nt_dgrad_act")
 
     def splitk_reduce(self, ws, bias, C, C_act, splitk, rows, N, act):
         check(self.lib.mmdyn_splitk_reduce(_ptr(ws), _ptr(bias), _ptr(C), _ptr(C_act), splitk, rows, N, act,
@@ -180,7 +219,7 @@ class HipBackend:
                     eps, momentum, repeat):
         check(self.lib.mmdyn_bn_finalize(_ptr(partial), _ptr(mean), _ptr(rstd), _ptr(running_mean),
                                          _ptr(running_var), _ptr(nbt, torch.int64), _ptr(scratch, torch.float64),
-                                         G, T, C, rows_per_group, eps, momentum, repeat, _stream()),
+                                         G, T, C, rows_per_group, eps, momentum, repeat, self._ticket(partial), _stream()),
               "mmdyn_bn_finalize")
 
     def bn_swish_fwd(self, y, mean, rstd, gamma, beta, a, G, rows_per_group, C):
@@ -201,8 +240,8 @@ class HipBackend:
 
     def bn_bwd_finalize(self, partial, sums, dgamma, dbeta, scratch, G, T, C, beta_acc):
         check(self.lib.mmdyn_bn_bwd_finalize(_ptr(partial), _ptr(sums), _ptr(dgamma), _ptr(dbeta),
-                                             _ptr(scratch, torch.float64), G, T, C, float(beta_acc), _stream()),
-              "mmdyn_bn_bwd_finalize")
+                                             _ptr(scratch, torch.float64), G, T, C, float(beta_acc), self._ticket(partial),
+                                             _stream()), "mmdyn_bn_bwd_finalize")
 
     def bn_eval_stats(self, running_mean, running_var, mean, rstd, G, C, eps):
         check(self.lib.mmdyn_bn_eval_stats(_ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(rstd), G, C, eps,
@@ -246,9 +285,10 @@ class HipBackend:
         check(self.lib.mmdyn_dropout_expand(_ptr(h), _ptr(masks, torch.uint8), _ptr(out), P, B, H, p_drop,
                                             _stream()), "mmdyn_dropout_expand")
 
-    def dropout_reduce(self, dout, masks, dh, P, B, H, p_drop):
+    def dropout_reduce(self, dout, masks, dh, P, B, H, p_drop, u=None, act=ACT_NONE):
+        """u (optional, [B][H] fp32): dh = (sum over the passes) * act'(u) -- the activation backward in the same launch."""
         check(self.lib.mmdyn_dropout_reduce(_ptr(dout), _ptr(masks, torch.uint8), _ptr(dh), P, B, H, p_drop,
-                                            _stream()), "mmdyn_dropout_reduce")
+                                            _ptr(u), int(act), _stream()), "mmdyn_dropout_reduce")
 
     def random_masks(self, masks, p_drop, seed, offset, offset_dev=None):
         check(self.lib.mmdyn_random_masks(_ptr(masks, torch.uint8), masks.numel(), p_drop, seed, offset,
@@ -263,8 +303,8 @@ class HipBackend:
 
     def colsum(self, x, out, rows, C, perm, beta):
         scratch = torch.empty(self.lib.mmdyn_colsum_chunks(rows) * C, device=x.device, dtype=torch.float32)
-        check(self.lib.mmdyn_colsum(_ptr(x), _ptr(out), _ptr(scratch), rows, C, perm, float(beta), _stream()),
-              "mmdyn_colsum")
+        check(self.lib.mmdyn_colsum(_ptr(x), _ptr(out), _ptr(scratch), rows, C, perm, float(beta), self._ticket(x),
+                                    _stream()), "mmdyn_colsum")
 
     def scale_dev(self, x, s, out):
         check(self.lib.mmdyn_scale_dev(_ptr(x), _ptr(s), _ptr(out), x.numel(), _stream()), "mmdyn_scale_dev")

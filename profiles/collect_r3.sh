@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collects the measurement set kept under profiles/r3 (run on the GPU box through gpurun; outputs under gpurun_out/r3p).
+# usage: bash profiles/collect_r3.sh [counts|part1|part2|others]
+set -eo pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r3p
+mkdir -p $O
+cd /tmp
+export TMPDIR=/tmp
+part=${1:-part1}
+if [ "$part" = counts ]; then
+  # launches per step by kernel (single lane, eager): fp32 bs 256 and bf16s bs 128
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f32 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --single-lane --no-graph > $O/single_f32.json 2> $O/single_f32.err
+  cp $(find $O/prof_f32 -name "*kernel_stats.csv" | head -1) $O/single_lane_f32_kernel_stats.csv
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b16 -- python3 $R/bench.py --dtype bf16s --batch 128 --steps 10 --warmup 3 --no-cpu-baseline --single-lane --no-graph > $O/single_b16.json 2> $O/single_b16.err
+  cp $(find $O/prof_b16 -name "*kernel_stats.csv" | head -1) $O/single_lane_bf16s_b128_kernel_stats.csv
+  rm -rf $O/prof_f32 $O/prof_b16
+  python3 $R/bench.py --dtype bf16s --batch 128 --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_c2_bf16s_b128.json 2> $O/bench_c2.err
+elif [ "$part" = part1 ]; then
+  python3 $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+  echo "bench done"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_graph -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_n1_under_rocprof.json 2> $O/rocprof_graph.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --single-lane --no-graph > $O/bench_n1_single_lane_under_rocprof.json 2> $O/rocprof_single.err
+  python3 $R/bench.py --breakdown --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2> $O/bench_n1_event_breakdown.txt
+  cp $(find $O/prof_graph -name "*kernel_stats.csv" | head -1) $O/bench_n1_kernel_stats.csv
+  cp $(find $O/prof_single -name "*kernel_stats.csv" | head -1) $O/bench_n1_single_lane_kernel_stats.csv
+  rm -rf $O/prof_graph $O/prof_single
+fi
+echo "collect $part done"

@@ -344,8 +344,14 @@ class EmuBackend:
     def dropout_expand(self, h, masks, out, P, B, H, p):
         out.reshape(P, B, H).copy_(h.reshape(1, B, H) * (masks.reshape(P, B, H).float() / (1 - p)))
 
-    def dropout_reduce(self, dout, masks, dh, P, B, H, p):
-        dh.reshape(B, H).copy_((dout.reshape(P, B, H) * (masks.reshape(P, B, H).float() / (1 - p))).sum(0))
+    def dropout_reduce(self, dout, masks, dh, P, B, H, p, u=None, act=0):
+        s = (dout.reshape(P, B, H) * (masks.reshape(P, B, H).float() / (1 - p))).sum(0)
+        dh.reshape(B, H).copy_(s if u is None else s * _act_grad(u.reshape(B, H), act))
+
+    def igemm_nt_dgrad_act(self, A, Bp, C, u, act, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset):
+        tmp = torch.empty(C.shape, dtype=torch.float32)
+        self.igemm_nt(A, Bp, None, tmp, None, None, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset, 0, 1)
+        C.reshape(-1).copy_((tmp.reshape(-1) * _act_grad(u.reshape(-1).float(), act)).to(C.dtype))
 
     def counter_add(self, counter, inc):
         counter += inc

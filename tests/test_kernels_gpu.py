@@ -116,6 +116,56 @@ def test_igemm_dgrad_bn_epilogue(case):
                                offset], [2, 3], post, tol=5e-5)
 
 
+@pytest.mark.parametrize("case", [IGEMM_CASES[2], IGEMM_CASES[3], IGEMM_CASES[5], IGEMM_CASES[6], IGEMM_CASES[8],
+                                  (TCONV_S2P1, 1, 3, 16, 64, 32, 32, 1, 0), (CONV, 1, 37, 8, 128, 5, 256, 1, 0)])
+@pytest.mark.parametrize("act", [1, 2])
+def test_igemm_dgrad_act_epilogue(case, act):
+    """Input-gradient GEMM with a plain activation backward in its epilogue (C = acc * act'(u)): the wave-specialised
+    kernels, the register-staged ones (N = 32) and the patch-resident transposed convolution."""
+    mode, G, Bg, Hi, Cin, Ho, N, stride, offset = case
+    Bt = G * Bg
+    taps = 1 if mode == DENSE else 16
+    A = rnd(Bt * Hi * Hi, Cin, seed=41)
+    Bp = rnd(taps, N, Cin, seed=42, scale=0.2)
+    rows = Bt * Ho * Ho
+    u = rnd(rows, N, seed=43) * 2.0
+    both("igemm_nt_dgrad_act", [A, Bp, torch.zeros(rows, N), u, act, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride, offset], [2],
+         tol=5e-5)
+
+
+def test_single_launch_finalize_equals_two_launches():
+    """The "last block finishes" forms (ticket counter; off by default, see ops._USE_TICKET) of the BatchNorm finalize,
+    the BatchNorm-backward finalize and the column sum are bit-identical to the two-launch forms, also when the same
+    counter slot is used again (the last block resets it)."""
+    G, T, C, rpg = 4, 300, 64, 4096
+    part = rnd(G, T, 2, C, seed=61).to(DEV)
+    outs = []
+    for tick in (False, True, True):
+        HIP.force_ticket = tick
+        try:
+            mean, rstd = torch.zeros(G, C, device=DEV), torch.zeros(G, C, device=DEV)
+            rm, rv, nbt = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+            scratch = torch.empty(32, G, 2, C, dtype=torch.float64, device=DEV)
+            HIP.bn_finalize(part, mean, rstd, rm, rv, nbt, scratch, G, T, C, rpg, 1e-5, 0.1, 2)
+            sums, dg, db = torch.zeros(G, 2, C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            HIP.bn_bwd_finalize(part, sums, dg, db, scratch, G, T, C, 0.0)
+            x, cs = rnd(1000, 512, seed=62).to(DEV), torch.zeros(512, device=DEV)
+            HIP.colsum(x, cs, 1000, 512, 0, 0.0)
+            torch.cuda.synchronize()
+            outs.append([t.clone() for t in (mean, rstd, rm, rv, nbt, sums, dg, db, cs)])
+        finally:
+            HIP.force_ticket = False
+    for a, b, c in zip(*outs):
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_dropout_reduce_with_activation_backward():
+    P, B, H = 4, 37, 512
+    dout, u = rnd(P * B, H, seed=51), rnd(B, H, seed=52) * 2
+    masks = (torch.rand(P, B, H, generator=torch.Generator().manual_seed(5)) > 0.1).to(torch.uint8)
+    both("dropout_reduce", [dout, masks, torch.zeros(B, H), P, B, H, 0.1, u, 1], [2])
+
+
 @pytest.fixture()
 def d16_tile(request, monkeypatch, lab):
     """Force one wave-tile shape of the direct-fragment fp32 kernels (igemm_d16.hip); without this the small test shapes
