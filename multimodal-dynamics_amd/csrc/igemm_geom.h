@@ -2,6 +2,7 @@
 // direct-fragment kernels (igemm_d16.hip).
 #pragma once
 #include "common.h"
+#include <cstdio>
 
 struct IgemmGeom {
   int mode;            // MMDYN_DENSE / MMDYN_CONV / MMDYN_TCONV_S2P1
@@ -58,5 +59,33 @@ int mmdyn_tconv_patch_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Ci
 
 // igemm_ws.hip: wave-specialised fp32 implicit GEMM (loader waves + LDS-DMA ring).  Same protocol as the hooks above.
 int mmdyn_igemm_ws_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
-                       const IgemmGeom& g, hipStream_t st);
+                       const IgemmGeom& g, bool bf16_ops, hipStream_t st);
 int mmdyn_igemm_ws_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
+
+// tile choice shared by the launcher and mmdyn_igemm_stat_tiles.  Measured on MI355X over every shape of the
+// bs=256 step (tests/microbench/sweep_tiles.py): the 64x64 tile (more resident blocks per CU to hide the
+// single-stage fetch latency) wins or ties everywhere except long-K problems that still fill the chip with
+// 128x128 tiles; N == 32 (mod 64) takes 128x32.
+// (rows_per_group, G) describe the row segments a tile may not straddle: groups, or (group, output pixel) pairs
+static inline void pick_tile(int N, int rows_per_group, int G, int ncls, int splitk, int ksteps, int* bm, int* bn) {
+  if (N % 64) {
+    *bm = 128;
+    *bn = 32;
+  } else {
+    *bm = 64;
+    *bn = 64;
+    if (N % 128 == 0 && splitk == 1 && ksteps >= 32 &&
+        (long)G * ceil_div(rows_per_group, 128) * (N / 128) * ncls >= 512) {
+      *bm = 128;
+      *bn = 128;
+    }
+  }
+  if (const char* ov = lab_env("MMDYN_IGEMM_TILE")) {   // kernel experiments only
+    int a = 0, b = 0;
+    if (sscanf(ov, "%d,%d", &a, &b) == 2 && N % b == 0) {
+      *bm = a;
+      *bn = b;
+    }
+  }
+}
+

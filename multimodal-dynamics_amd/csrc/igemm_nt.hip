@@ -599,33 +599,6 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
   }
 }
 
-// tile choice shared by the launcher and mmdyn_igemm_stat_tiles.  Measured on MI355X over every shape of the
-// bs=256 step (tests/microbench/sweep_tiles.py): the 64x64 tile (more resident blocks per CU to hide the
-// single-stage fetch latency) wins or ties everywhere except long-K problems that still fill the chip with
-// 128x128 tiles; N == 32 (mod 64) takes 128x32.
-// (rows_per_group, G) describe the row segments a tile may not straddle: groups, or (group, output pixel) pairs
-static void pick_tile(int N, int rows_per_group, int G, int ncls, int splitk, int ksteps, int* bm, int* bn) {
-  if (N % 64) {
-    *bm = 128;
-    *bn = 32;
-  } else {
-    *bm = 64;
-    *bn = 64;
-    if (N % 128 == 0 && splitk == 1 && ksteps >= 32 &&
-        (long)G * ceil_div(rows_per_group, 128) * (N / 128) * ncls >= 512) {
-      *bm = 128;
-      *bn = 128;
-    }
-  }
-  if (const char* ov = lab_env("MMDYN_IGEMM_TILE")) {   // kernel experiments only
-    int a = 0, b = 0;
-    if (sscanf(ov, "%d,%d", &a, &b) == 2 && N % b == 0) {
-      *bm = a;
-      *bn = b;
-    }
-  }
-}
-
 template <int MODE, int BM, int BN, int WM, int WN>
 static int launch_m(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats,
                     float* ws, IgemmGeom g, hipStream_t st, bool bf16) {
@@ -891,8 +864,8 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
     const int rc = mmdyn_igemm_d16_try(A, Bp, bias, C, C_act, stats, ws, g, stride, offset, st);
     if (rc != 1) return rc;
   }
-  if (!bf16 && ws_enabled()) {      // wave-specialised LDS-DMA ring kernels (igemm_ws.hip)
-    const int rc = mmdyn_igemm_ws_try(A, Bp, bias, C, C_act, stats, ws, g, st);
+  if (ws_enabled() && mode != MMDYN_IM2COL3 && mode != MMDYN_TCONV_S1P0) {   // wave-specialised LDS-DMA ring kernels (igemm_ws.hip)
+    const int rc = mmdyn_igemm_ws_try(A, Bp, bias, C, C_act, stats, ws, g, bf16, st);
     if (rc != 1) return rc;
   }
   int bm, bn;

@@ -45,7 +45,12 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds, unsi
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, int S>
+// B16: both operands are bf16 in HBM (the bf16-storage mode's convolution-level GEMMs with bf16 packed weights): a tile row
+// is 64 channels = the same 128 bytes, the loaders and the LDS image are unchanged, and a 16-byte fragment read feeds ONE
+// v_mfma_f32_16x16x32_bf16 (lane (row l&15, quarter l>>4) holds k = 8*(l>>4) .. +7 of each 32-deep half of the K-step).
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+
+template <int MODE, int BM, int BN, int WM, int WN, int S, bool B16>
 __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_kernel(
     const float* __restrict__ A, const float* __restrict__ Bp, const float* __restrict__ bias, float* __restrict__ C,
     float* __restrict__ C_act, float* __restrict__ stats, float* __restrict__ ws, const IgemmGeom g, const unsigned a_bytes,
@@ -59,6 +64,8 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
   constexpr int SLOT = (BM + BN) * RB;
   constexpr int TS = 16, MT = WM / TS, NT = WN / TS;
   constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
+  constexpr int ESZ = B16 ? 2 : 4;                 // operand element size
+  constexpr int KB = RB / ESZ;                     // channels per K-step (32 fp32 / 64 bf16)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* rowinfo = reinterpret_cast<int*>(smem + S * SLOT);      // [BM][4]: b, y0, x0, out offset (-1: none)
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
   }
   __syncthreads();
 
-  const int cin_steps = g.Cin / BK;
+  const int cin_steps = g.Cin / KB;
   const int total_steps = g.ntaps * cin_steps;
   const int per_split = (total_steps + g.splitk - 1) / g.splitk;
   const int s_begin = split * per_split;
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
 #pragma unroll
     for (int j = 0; j < PBL; ++j) {
       const int r = (wave + NL * j) * RPP + prow;
-      voffB[j] = (unsigned)(((n0 + r) * g.Cin) * 4 + ((lane & 7) ^ ((r >> 1) & 7)) * 16);
+      voffB[j] = (unsigned)(((n0 + r) * g.Cin) * ESZ + ((lane & 7) ^ ((r >> 1) & 7)) * 16);
     }
     int tap = s_begin / cin_steps;
     int cstep = s_begin - tap * cin_steps;
@@ -169,13 +176,13 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
         dw = pw - tw;
         wi = (1 - ph + 2 * th) * 4 + (1 - pw + 2 * tw);
       }
-      sB = (unsigned)wi * (unsigned)(g.N * g.Cin) * 4u;
+      sB = (unsigned)wi * (unsigned)(g.N * g.Cin) * (unsigned)ESZ;
 #pragma unroll
       for (int i = 0; i < PAL; ++i) {
         const int y = ry[i] + dh, x = rx[i] + dw;
         const bool ok = (rb[i] >= 0) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
         const unsigned pix = (unsigned)((rb[i] * g.Hi + y) * g.Wi + x);
-        voffA[i] = ok ? pix * (unsigned)(g.Cin * 4) + cslotA[i] : OOB;
+        voffA[i] = ok ? pix * (unsigned)(g.Cin * ESZ) + cslotA[i] : OOB;
       }
     };
     int issued = 0;
@@ -215,7 +222,10 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            yv[mt][e][nt] = g.bn_y[(size_t)max(ooff[mt][e], 0) + n0 + wn * WN + nt * TS + cl];
+          {
+            const size_t yo = (size_t)max(ooff[mt][e], 0) + n0 + wn * WN + nt * TS + cl;
+            yv[mt][e][nt] = (B16 && g.bny_b16) ? ld1<bf16_t>(reinterpret_cast<const bf16_t*>(g.bn_y) + yo) : g.bn_y[yo];
+          }
     }
     const int fr = (cl >> 1) & 7;
     const int foff0 = cl * RB + 16 * ((0 + h) ^ fr), foff1 = cl * RB + 16 * ((4 + h) ^ fr);
@@ -226,18 +236,31 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int fo = q ? foff1 : foff0;
-        f32x4v af[MT], bf[NT];
+        if constexpr (B16) {
+          bf16x8v af[MT], bf[NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4v*>(sl + abase + mt * TS * RB + fo);
+          for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const bf16x8v*>(sl + abase + mt * TS * RB + fo);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const f32x4v*>(sl + bbase + nt * TS * RB + fo);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const bf16x8v*>(sl + bbase + nt * TS * RB + fo);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+        } else {
+          f32x4v af[MT], bf[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4v*>(sl + abase + mt * TS * RB + fo);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const f32x4v*>(sl + bbase + nt * TS * RB + fo);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+        }
       }
     }
   }
@@ -284,8 +307,28 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
               ws[((size_t)split * g.rows_total + grow) * g.N + col] = v;
             } else {
               if (g.has_bias) v += bias[col];
-              C[(size_t)oo + col] = v;
-              if (g.want_act_out) C_act[(size_t)oo + col] = apply_act(v, g.act);
+              if (B16 && g.c_b16) {
+                // two adjacent columns live in adjacent lanes: the even lane stores both as one dword
+                const float vn = __shfl_down(v, 1, 64);
+                if (!(cl & 1)) {
+                  *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C) + (size_t)oo + col) = pack2_bf16(v, vn);
+                  if (g.want_act_out)
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C_act) + (size_t)oo + col) =
+                        pack2_bf16(apply_act(v, g.act), apply_act(vn, g.act));
+                }
+              } else {
+                C[(size_t)oo + col] = v;
+                if (g.want_act_out) {
+                  if (B16 && g.cact_b16) {      // fp32 pre-activation, bf16 activated output (FC level -> conv level)
+                    const float av = apply_act(v, g.act);
+                    const float an = __shfl_down(av, 1, 64);
+                    if (!(cl & 1))
+                      *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C_act) + (size_t)oo + col) = pack2_bf16(av, an);
+                  } else {
+                    C_act[(size_t)oo + col] = apply_act(v, g.act);
+                  }
+                }
+              }
             }
           }
         }
@@ -332,12 +375,24 @@ struct WsPick {
   int bm, bn;      // 0: not served
 };
 
-static WsPick ws_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr, int Cin, int N, int ncls, int splitk) {
+static WsPick ws_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr, int Cin, int N, int ncls, int splitk,
+                      bool b16 = false) {
   WsPick p{0, 0};
   if (mode != MMDYN_DENSE && mode != MMDYN_CONV && mode != MMDYN_TCONV_S2P1) return p;
-  if (Cin % BK || N % 64) return p;
+  if (Cin % (b16 ? 64 : BK) || N % 64) return p;
   // buffer descriptors carry 32-bit byte counts, and the out-of-range marker must stay beyond them
-  if ((int64_t)G * Bg * Hi * Wi * Cin * 4 >= MAX_BUFFER_BYTES || (int64_t)16 * N * Cin * 4 >= MAX_BUFFER_BYTES) return p;
+  const int esz = b16 ? 2 : 4;
+  if ((int64_t)G * Bg * Hi * Wi * Cin * esz >= MAX_BUFFER_BYTES || (int64_t)16 * N * Cin * esz >= MAX_BUFFER_BYTES) return p;
+  if (b16) {
+    // bf16 operands: the block tile follows the register-staged kernels' rule (igemm_geom.h pick_tile), so the number of
+    // BatchNorm partial-sum tiles a launch writes does not depend on which of the two kernels serves it
+    // (mmdyn_igemm_stat_tiles_bf16 knows the shape, not the storage types)
+    int bm, bn;
+    pick_tile(N, Bg * Hr * Wr, G, ncls, splitk, (mode == MMDYN_CONV ? 16 : (mode == MMDYN_TCONV_S2P1 ? 4 : 1)) * (Cin / BK), &bm,
+              &bn);
+    if (bm == bn && (bm == 64 || bm == 128)) p.bm = p.bn = bm;
+    return p;
+  }
   // Measured per shape against the register-staged kernels, each launch alone on the chip (tests/microbench/ab_ws.py,
   // profiles/r3/ab_ws_per_shape.txt):
   //   * 64x64 tiles (4 MFMA waves of 32x32, 49 KB of LDS: three blocks per CU) win or tie on every launch of the step but
@@ -363,7 +418,7 @@ static WsPick ws_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr, i
   return p;
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, int S>
+template <int MODE, int BM, int BN, int WM, int WN, int S, bool B16 = false>
 static int ws_launch(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
                      IgemmGeom g, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
   constexpr int NM = (BM / WM) * (BN / WN);
@@ -378,23 +433,36 @@ static int ws_launch(const float* A, const float* Bp, const float* bias, float* 
   const size_t smem = (size_t)S * (BM + BN) * RB + (size_t)BM * 16;
   static bool attr_set = false;        // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm_ws_kernel<MODE, BM, BN, WM, WN, S>,
+    hipError_t e = hipFuncSetAttribute((const void*)igemm_ws_kernel<MODE, BM, BN, WM, WN, S, B16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_ws_kernel<MODE, BM, BN, WM, WN, S>), grid, dim3(64 * (NM + NL)), smem, st, A, Bp, bias, C, C_act,
+  hipLaunchKernelGGL((igemm_ws_kernel<MODE, BM, BN, WM, WN, S, B16>), grid, dim3(64 * (NM + NL)), smem, st, A, Bp, bias, C, C_act,
                      stats, ws, g, a_bytes, b_bytes);
   MMDYN_LAUNCH_CHECK();
 }
 
-template <int MODE>
+template <int MODE, bool B16>
 static int ws_launch_mode(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
                           const IgemmGeom& g, WsPick p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
   if (p.bm == 128 && p.bn == 128)
-    return ws_launch<MODE, 128, 128, 64, 32, 3>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
-  if (p.bm == 128) return ws_launch<MODE, 128, 64, 32, 64, 3>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
-  return ws_launch<MODE, 64, 64, 32, 32, 3>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
+    return ws_launch<MODE, 128, 128, 64, 32, 3, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
+  if (p.bm == 128) return ws_launch<MODE, 128, 64, 32, 64, 3, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
+  return ws_launch<MODE, 64, 64, 32, 32, 3, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
+}
+
+template <bool B16>
+static int ws_dispatch(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
+                       const IgemmGeom& g, WsPick p, hipStream_t st) {
+  const int esz = B16 ? 2 : 4;
+  const unsigned a_bytes = (unsigned)((int64_t)g.G * g.Bg * g.Hi * g.Wi * g.Cin * esz);
+  const unsigned b_bytes = (unsigned)((int64_t)(g.mode == MMDYN_DENSE ? 1 : 16) * g.N * g.Cin * esz);
+  if (g.mode == MMDYN_DENSE)
+    return ws_launch_mode<MMDYN_DENSE, B16>(A, Bp, bias, C, C_act, stats, ws, g, p, a_bytes, b_bytes, st);
+  if (g.mode == MMDYN_CONV)
+    return ws_launch_mode<MMDYN_CONV, B16>(A, Bp, bias, C, C_act, stats, ws, g, p, a_bytes, b_bytes, st);
+  return ws_launch_mode<MMDYN_TCONV_S2P1, B16>(A, Bp, bias, C, C_act, stats, ws, g, p, a_bytes, b_bytes, st);
 }
 
 }  // namespace
@@ -410,15 +478,12 @@ int mmdyn_igemm_ws_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, 
   return p.bm ? ncls * ceil_div(Bg * Hr * Wr, p.bm) : 0;
 }
 
+// bf16_ops: the launch runs on the bf16 matrix cores; served here only when BOTH operands are bf16 in HBM (and not fp16 mode)
 int mmdyn_igemm_ws_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
-                       const IgemmGeom& g, hipStream_t st) {
-  const WsPick p = ws_pick(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Hr, g.Wr, g.Cin, g.N, g.nclasses, g.splitk);
+                       const IgemmGeom& g, bool bf16_ops, hipStream_t st) {
+  if (bf16_ops && (g.f16 || !g.a_b16 || !g.b_b16)) return 1;
+  const WsPick p = ws_pick(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Hr, g.Wr, g.Cin, g.N, g.nclasses, g.splitk, bf16_ops);
   if (!p.bm) return 1;
-  const int64_t a_bytes = (int64_t)g.G * g.Bg * g.Hi * g.Wi * g.Cin * 4;
-  const int64_t b_bytes = (int64_t)(g.mode == MMDYN_DENSE ? 1 : 16) * g.N * g.Cin * 4;
-  if (g.mode == MMDYN_DENSE)
-    return ws_launch_mode<MMDYN_DENSE>(A, Bp, bias, C, C_act, stats, ws, g, p, (unsigned)a_bytes, (unsigned)b_bytes, st);
-  if (g.mode == MMDYN_CONV)
-    return ws_launch_mode<MMDYN_CONV>(A, Bp, bias, C, C_act, stats, ws, g, p, (unsigned)a_bytes, (unsigned)b_bytes, st);
-  return ws_launch_mode<MMDYN_TCONV_S2P1>(A, Bp, bias, C, C_act, stats, ws, g, p, (unsigned)a_bytes, (unsigned)b_bytes, st);
+  if (bf16_ops) return ws_dispatch<true>(A, Bp, bias, C, C_act, stats, ws, g, p, st);
+  return ws_dispatch<false>(A, Bp, bias, C, C_act, stats, ws, g, p, st);
 }

@@ -65,7 +65,10 @@ def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch
     tiles = _cdiv(rows, 64) * _cdiv(N, 64)
     steps = K // 32
     splitk = max(1, min(256 // tiles, steps // 16)) if (N % 64 == 0 and out_dtype == torch.float32 and act_dtype is None) else 1
-    if _AB_OLDSPLITK and (N % 64 == 0 and out_dtype == torch.float32 and act_dtype is None):
+    if (_AB_OLDSPLITK or getattr(ops.B, "precision", "fp32") != "fp32") and \
+            (N % 64 == 0 and out_dtype == torch.float32 and act_dtype is None):
+        # 16-bit matrix-core modes: a K-step is latency, not arithmetic (a 512-row K = 512 GEMM unsplit: 26 us at 64 blocks),
+        # so the finer split of rounds 1-2 stays (without it bf16s bs 128 measured 2.45 vs 2.31 ms per step)
         splitk = max(1, min(512 // tiles, steps // 8))
     # (kept in the 16-bit matrix-core modes too: without it bf16s bs 128 measured 2.45 vs 2.31 ms per step)
     if splitk > 1:
