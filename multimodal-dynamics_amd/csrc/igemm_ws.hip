@@ -379,7 +379,14 @@ static WsPick ws_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr, i
                       bool b16 = false) {
   WsPick p{0, 0};
   if (mode != MMDYN_DENSE && mode != MMDYN_CONV && mode != MMDYN_TCONV_S2P1) return p;
-  if (Cin % (b16 ? 64 : BK) || N % 64) return p;
+  if (Cin % (b16 ? 64 : BK) || N % 32) return p;
+  if (N % 64) {                 // 32 (mod 64) output channels (the 32 -> 32 stages of the 128 / 256 pixel stacks): fp32, 128 x 32
+    if (b16 || splitk > 1) return p;
+    if ((int64_t)G * Bg * Hi * Wi * Cin * 4 >= MAX_BUFFER_BYTES) return p;
+    p.bm = 128;
+    p.bn = 32;
+    return p;
+  }
   // buffer descriptors carry 32-bit byte counts, and the out-of-range marker must stay beyond them
   const int esz = b16 ? 2 : 4;
   if ((int64_t)G * Bg * Hi * Wi * Cin * esz >= MAX_BUFFER_BYTES || (int64_t)16 * N * Cin * esz >= MAX_BUFFER_BYTES) return p;
@@ -446,6 +453,9 @@ static int ws_launch(const float* A, const float* Bp, const float* bias, float* 
 template <int MODE, bool B16>
 static int ws_launch_mode(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
                           const IgemmGeom& g, WsPick p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  if constexpr (!B16)
+    if (p.bm == 128 && p.bn == 32)
+      return ws_launch<MODE, 128, 32, 32, 32, 3, false>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
   if (p.bm == 128 && p.bn == 128)
     return ws_launch<MODE, 128, 128, 64, 32, 3, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
   if (p.bm == 128) return ws_launch<MODE, 128, 64, 32, 64, 3, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
