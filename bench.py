@@ -76,26 +76,38 @@ def _sha256(path):
         return None
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
-    the gfx950 correction + WRITE_SIZE).  PMC counters cannot be read from inside this process, so the value is the
-    last profiled one -- WITH its provenance: the profile records the sha-256 of the kernel source it was taken on, and
-    the value is reported as None (plus the reason) when the source has changed since.  Returns (bytes | None, note)."""
-    for rel in (("profiles", "r2", "igemm_traffic_pmc.json"), ("profiles", "r1", "igemm_traffic_pmc.json")):
-        path = os.path.join(ROOT, *rel)
-        try:
-            d = json.load(open(path))
-        except (OSError, ValueError):
-            continue
-        if not kernel.startswith(d.get("kernel", "?").split(" ")[0]):
-            continue
-        src = os.path.join(ROOT, "multimodal-dynamics_amd", "csrc", d.get("source", "igemm_nt.hip"))
-        note = {"profile": "/".join(rel), "collected": d.get("collected"), "source_sha256": d.get("source_sha256")}
-        if d.get("source_sha256") and d["source_sha256"] == _sha256(src):
-            return d["hbm_bytes_per_launch"], note
-        note["stale"] = "kernel source changed since the profile was collected (or the profile predates provenance)"
-        return None, note
-    return None, {"stale": "no PMC profile committed"}
+PEAK_HBM_BYTES_PER_S = 8.0e12       # MI355X_MICROARCH.md: HBM3E peak (spec); ~6.3 TB/s achievable
+
+
+def sources_sha256():
+    """sha-256 over the kernel sources (csrc/*.hip, *.h): the provenance key of the committed PMC profiles."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "multimodal-dynamics_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic(workload_key):
+    """HBM-side bytes of one step of this workload from the committed rocprofv3 PMC passes (profiles/r3/traffic_<key>.json:
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; profiles/collect_r3.sh traffic).  PMC counters cannot be
+    read from inside this process, so the values are the last profiled ones -- WITH their provenance: the profile records
+    the sha-256 of the kernel sources it was taken on, and the values are reported as None (plus the reason) when the
+    sources have changed since.  Returns (dict | None, note)."""
+    rel = ("profiles", "r3", f"traffic_{workload_key}.json")
+    path = os.path.join(ROOT, *rel)
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None, {"stale": f"no PMC profile committed for this workload ({'/'.join(rel)})"}
+    note = {"profile": "/".join(rel), "collected": d.get("collected"), "sources_sha256": d.get("sources_sha256")}
+    if d.get("sources_sha256") and d["sources_sha256"] == sources_sha256():
+        return d, note
+    note["stale"] = "kernel sources changed since the profile was collected"
+    return None, note
 
 
 def host_cpu_share():
@@ -397,9 +409,25 @@ def main():
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     total_ms = sum(d["ms"] for d in kern.values())
     peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else (PEAK_F16_MFMA_TFLOPS if args.dtype == "fp16" else PEAK_BF16_MFMA_TFLOPS)
-    # (the committed PMC passes were taken on the BASELINE workload: 64x64, bs 256, fp32, seq_modeling)
-    profiled = args.dtype == "f32" and S == 64 and args.batch == 256 and args.problem == "seq_modeling"
-    traffic, traffic_note = pmc_traffic(dom_name) if profiled else (None, {"stale": "profiled for the 64x64 bs 256 fp32 workload only"})
+    # byte side: the committed PMC passes of THIS workload (whole step + the implicit-GEMM launches)
+    wkey = f"s{S}_{args.dtype}_b{args.batch}_{args.problem}"
+    prof, traffic_note = pmc_traffic(wkey)
+    traffic = prof["hbm_bytes_per_launch"] if (prof and dom is ig) else None
+    step_bytes = (prof["whole_step"]["fetch_bytes"] + prof["whole_step"]["write_bytes"]) if prof else None
+    step_s = elapsed / args.steps
+    step_hbm_frac = step_bytes / step_s / PEAK_HBM_BYTES_PER_S if step_bytes else None
+    step_mfma_frac = sps / world * gflop_per_sample * 1e9 / 1e12 / peak
+    kern_hbm_frac = (traffic / (dom["ms"] / max(dom["calls"], 1) * 1e-3) / PEAK_HBM_BYTES_PER_S) if traffic and dom["ms"] > 0 else None
+    kern_mfma_frac = achieved / peak
+
+    def bound_of(mfma, hbm):
+        # the resource with the larger share of its peak; "launch" when neither reaches a fifth of its peak: the time then
+        # goes to the chain of dependent launches, not to a roofline resource
+        if hbm is None:
+            return "mfma"
+        if max(mfma, hbm) < 0.2:
+            return "launch"
+        return "hbm" if hbm > mfma else "mfma"
     arith = {"f32": "fp32", "bf16": "bf16 matrix-core operands (fp32 accumulate, storage and master weights)",
              "bf16s": "bf16 activation storage + bf16 matrix-core operands (fp32 accumulate and master weights)",
              "fp16": "fp16 matrix-core operands (fp32 accumulate, storage and master weights)"}[args.dtype]
@@ -419,16 +447,23 @@ def main():
                    "global_batch": global_batch, "parallelism": f"dp{world}", "bn": "sync" if (args.sync_bn and pg is not None) else "local",
                    "launch": "eager" if (args.no_graph or (args.sync_bn and pg is not None and dry)) else "hip_graph",
                    "final_loss": final_loss, "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps},
-        "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": peak,
+        "roofline": {"bound": bound_of(kern_mfma_frac, kern_hbm_frac),
+                     "kernel": dom_name + (" (all implicit-GEMM launches: igemm_ws_kernel + igemm_nt_kernel instances)"
+                                           if dom is ig else ""),
+                     "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": traffic, "traffic_provenance": traffic_note,
+                     "hbm_frac": kern_hbm_frac,
                      "algorithmic_flops_per_launch": dom["flops"] / max(dom["calls"], 1),
                      "operand_bytes_per_launch": dom["bytes"] / max(dom["calls"], 1),
                      "launches_per_step": dom["calls"], "avg_launch_ms": dom["ms"] / max(dom["calls"], 1),
                      "kernel_share_of_step": dom["ms"] / total_ms if total_ms else None,
                      "algorithmic_gflop_per_sample": gflop_per_sample,
                      "step_algorithmic_tflops": sps / world * gflop_per_sample * 1e9 / 1e12,
-                     "step_frac_of_peak": sps / world * gflop_per_sample * 1e9 / 1e12 / peak},
+                     "step_frac_of_peak": step_mfma_frac,
+                     "step_hbm_bytes": step_bytes, "step_hbm_frac_of_8TBps": step_hbm_frac,
+                     "step_launches": prof["whole_step"]["launches"] if prof else None,
+                     "step_bound": bound_of(step_mfma_frac, step_hbm_frac)},
     }
     if dry:
         out["dry_run"] = "CPU rehearsal with emulated kernels (MMDYN_BENCH_DRYRUN=emu): control flow only, numbers meaningless"

@@ -206,14 +206,32 @@ class Problem:
         perf = defaultdict(float)
         dev_loss = dev_acc = None        # fused path: loss and per-pass sums accumulate ON THE DEVICE, read once per epoch
         dev_n = dev_rows = 0             # (the reference's loss.item() per step, problems.py:156, would stall the replay)
+        try:
+            n_batches = len(self.train_loader)
+        except TypeError:
+            n_batches = -1
         for batch_idx, (data_input, data_target) in enumerate(self.train_loader):
             inputs, targets = self.parse_input(data_input, data_target)
             if self._step is not None and self._fused_applicable(inputs):
                 # on the GPU the step is replayed from HIP graphs (captured once per batch shape; the annealed KL weight
                 # is read from device memory); the emulation has no graphs
                 run = self._step.train_step_graphed if self._device.type == 'cuda' else self._step.train_step
-                loss = run(*self._fused_io(inputs, targets), self._kl_weight, loss_mask=self._fused_mask(targets),
-                           condition=inputs.get('shock') if self._conditional else None)
+                # Checkpoint fidelity: the LAST step of an epoch -- what the epoch's checkpoint sees -- also runs the image
+                # decoders on the subset passes whose reconstruction the reference computes and discards, so their BatchNorm
+                # running buffers receive the reference's 7 (3) EMA updates of that step, in pass order (eager launches:
+                # the captured graphs hold the 4-pass schedule).  With momentum 0.1 those updates carry 1 - 0.9**7 = 52 %
+                # of a buffer's weight; tests/test_model_emu.py measures the residual against the reference's buffers.
+                # --exact-running-stats does it on every step (identical buffers, ~1.4x the step time).
+                last_exact = (batch_idx == n_batches - 1 and not self._step.exact_running_stats and
+                              self.parameters.get('exact_last_step', True))
+                if last_exact:
+                    self._step.exact_running_stats, run = True, self._step.train_step
+                try:
+                    loss = run(*self._fused_io(inputs, targets), self._kl_weight, loss_mask=self._fused_mask(targets),
+                               condition=inputs.get('shock') if self._conditional else None)
+                finally:
+                    if last_exact:
+                        self._step.exact_running_stats = False
                 if dev_loss is None:
                     dev_loss, dev_acc = torch.zeros_like(loss, dtype=torch.float64), torch.zeros_like(self._step.acc)
                 dev_loss += loss.detach().to(torch.float64)
@@ -265,6 +283,13 @@ class Problem:
         if val_loss < self._best_loss:      # best-validation checkpoint, same dict keys as problems.py:580-586
             state = {'model': self._model.state_dict(), 'loss': val_loss, 'epoch': epoch}
             torch.save(state, self._checkpoint_dir + '/epoch_' + str(epoch) + '.ckpt')
+            if self._step is not None:
+                # the checkpoint keeps the reference's three keys (problems.py:751-757); how the image decoders' BatchNorm
+                # running buffers in 'model' were produced goes next to it
+                mode = ('exact' if self._step.exact_running_stats else
+                        'exact-on-last-step-of-epoch' if self.parameters.get('exact_last_step', True) else 'live-passes-only')
+                with open(self._checkpoint_dir + '/bn_running_stats_mode.txt', 'w') as f:
+                    f.write(mode + '\n')
             self._best_loss = val_loss
         return dict(perf)
 

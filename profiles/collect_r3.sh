@@ -25,5 +25,15 @@ elif [ "$part" = part1 ]; then
   cp $(find $O/prof_graph -name "*kernel_stats.csv" | head -1) $O/bench_n1_kernel_stats.csv
   cp $(find $O/prof_single -name "*kernel_stats.csv" | head -1) $O/bench_n1_single_lane_kernel_stats.csv
   rm -rf $O/prof_graph $O/prof_single
+elif [ "$part" = traffic ]; then
+  # whole-step HBM-side traffic of one bench.py workload: collect_r3.sh traffic <key> <bench args...>
+  # separate PMC passes, --kernel-trace only (MI355X_MICROARCH.md, HBM section)
+  key=$2; shift 2
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$key -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline "$@" > /dev/null 2> $O/pmc_fetch_$key.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$key -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline "$@" > /dev/null 2> $O/pmc_write_$key.err
+  python3 $R/tests/microbench/pmc_by_kernel.py $O/pmc_fetch_$key $O/pmc_write_$key 4 $O/hbm_traffic_by_kernel_$key.json > $O/hbm_traffic_by_kernel_$key.txt
+  python3 $R/profiles/make_traffic_json.py $O/hbm_traffic_by_kernel_$key.json $O/traffic_$key.json $key "$@" > /dev/null
+  rm -rf $O/pmc_fetch_$key $O/pmc_write_$key
+  tail -1 $O/hbm_traffic_by_kernel_$key.txt
 fi
 echo "collect $part done"

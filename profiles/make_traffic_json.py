@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""hbm_traffic_by_kernel.json (tests/microbench/pmc_by_kernel.py) -> igemm_traffic_pmc.json: the per-launch HBM-side
-bytes of the dominant kernel that bench.py's roofline.traffic reports, WITH its provenance (collection date and the
-sha-256 of the kernel source it was taken on: bench.py reports null once the source has changed).
-usage: make_traffic_json.py <hbm_traffic_by_kernel.json> <out.json>"""
+"""hbm_traffic_by_kernel.json (tests/microbench/pmc_by_kernel.py) -> traffic_<workload>.json: the HBM-side bytes of one
+train step of one bench.py workload -- whole step and the implicit-GEMM launches (the dominant kernel family) -- WITH
+provenance: collection date and the sha-256 over the kernel sources it was taken on (bench.py reports null once they
+have changed).
+usage: make_traffic_json.py <hbm_traffic_by_kernel.json> <out.json> <workload key> <bench args...>"""
 import datetime
 import hashlib
 import json
@@ -10,26 +11,40 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d = json.load(open(sys.argv[1]))
-rows = [r for r in d["kernels"] if r["kernel"].startswith("igemm_nt_kernel")]
-launches = sum(r["launches_per_step"] for r in rows)
-fetch = sum(r["fetch_MB_per_step"] for r in rows) * 1e6
-write = sum(r["write_MB_per_step"] for r in rows) * 1e6
-src = os.path.join(ROOT, "multimodal-dynamics_amd", "csrc", "igemm_nt.hip")
-out = {
-    "source_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1 "
-                   "--no-graph --no-cpu-baseline; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM section); KiB "
-                   "units; aggregated by tests/microbench/pmc_by_kernel.py (profiles/collect_r2.sh part2)",
-    "kernel": "igemm_nt_kernel (all template instances, incl. the dgrad+BatchNorm-backward launches; the 3-channel layers run "
-              "conv3_nt_kernel and are not counted)",
-    "source": "igemm_nt.hip",
-    "source_sha256": hashlib.sha256(open(src, "rb").read()).hexdigest(),
-    "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
-    "launches_per_step": launches,
-    "hbm_bytes_per_launch": (fetch + write) / max(launches, 1),
-    "fetch_bytes_per_step": fetch,
-    "write_bytes_per_step": write,
-    "whole_step": {"fetch_bytes": d["fetch_MB_per_step"] * 1e6, "write_bytes": d["write_MB_per_step"] * 1e6},
-}
-json.dump(out, open(sys.argv[2], "w"), indent=1)
-print(json.dumps(out, indent=1))
+
+
+def sources_sha256():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "multimodal-dynamics_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+if __name__ == "__main__":
+    d = json.load(open(sys.argv[1]))
+    fam = ("igemm_nt_kernel", "igemm_ws_kernel")
+    rows = [r for r in d["kernels"] if r["kernel"].startswith(fam)]
+    launches = sum(r["launches_per_step"] for r in rows)
+    fetch = sum(r["fetch_MB_per_step"] for r in rows) * 1e6
+    write = sum(r["write_MB_per_step"] for r in rows) * 1e6
+    out = {
+        "source_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 "
+                       "--warmup 1 --no-graph --no-cpu-baseline <args>; FETCH_SIZE doubled (gfx950 correction, "
+                       "MI355X_MICROARCH.md HBM section); KiB units; aggregated by tests/microbench/pmc_by_kernel.py "
+                       "(profiles/collect_r3.sh traffic)",
+        "workload": sys.argv[3],
+        "bench_args": sys.argv[4:],
+        "kernel": "igemm_ws_kernel + igemm_nt_kernel (every implicit-GEMM launch of the step; the 3-channel layers run "
+                  "conv3_nt_kernel, the 64 -> 32 channel transposed convolution tconv_patch_kernel: not counted)",
+        "sources_sha256": sources_sha256(),
+        "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+        "launches_per_step": launches,
+        "hbm_bytes_per_launch": (fetch + write) / max(launches, 1),
+        "whole_step": {"fetch_bytes": d["fetch_MB_per_step"] * 1e6, "write_bytes": d["write_MB_per_step"] * 1e6,
+                       "launches": sum(r["launches_per_step"] for r in d["kernels"])},
+    }
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
+    print(json.dumps(out, indent=1))
