@@ -21,11 +21,6 @@ from .ops import ACT_NONE, ACT_SWISH, ACT_RELU, DENSE, CONV, TCONV_S2P1, IM2COL3
 from .models.shapes import BN_EPS, BN_MOMENTUM, FEAT
 
 
-import os as _os
-_AB_OLDSPLITK = bool(_os.environ.get("MMDYN_AB_OLDSPLITK"))     # (A/B measurements of this round; see docs/LAB_NOTES.md)
-_AB_NODGRADACT = bool(_os.environ.get("MMDYN_AB_NODGRADACT"))
-
-
 def _new(like, *shape, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
@@ -65,8 +60,7 @@ def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch
     tiles = _cdiv(rows, 64) * _cdiv(N, 64)
     steps = K // 32
     splitk = max(1, min(256 // tiles, steps // 16)) if (N % 64 == 0 and out_dtype == torch.float32 and act_dtype is None) else 1
-    if (_AB_OLDSPLITK or getattr(ops.B, "precision", "fp32") != "fp32") and \
-            (N % 64 == 0 and out_dtype == torch.float32 and act_dtype is None):
+    if getattr(ops.B, "precision", "fp32") != "fp32" and (N % 64 == 0 and out_dtype == torch.float32 and act_dtype is None):
         # 16-bit matrix-core modes: a K-step is latency, not arithmetic (a 512-row K = 512 GEMM unsplit: 26 us at 64 blocks),
         # so the finer split of rounds 1-2 stays (without it bf16s bs 128 measured 2.45 vs 2.31 ms per step)
         splitk = max(1, min(512 // tiles, steps // 8))
@@ -96,9 +90,6 @@ def conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride=1, offset=0, stats=Fals
 def dgrad_act(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, u, act, stride=1, offset=0):
     """Input-gradient GEMM with the backward of the activation whose pre-activation is ``u`` in its epilogue:
     returns dL/du = (x (*) Wp) * act'(u), stored like ``u``."""
-    if _AB_NODGRADACT:
-        d, _, _ = conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride, offset, out_dtype=u.dtype)
-        return act_backward(d, u, act)
     du = torch.empty_like(u)
     ops.B.igemm_nt_dgrad_act(x, Wp, du, u, act, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride, offset)
     return du

@@ -18,6 +18,9 @@ def _canon(name, a):
     if name == "igemm_nt_dgrad_bn":
         A, Bp, C, stats, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset = a
         name, a = "igemm_nt", (A, Bp, y, C, None, stats, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset, 0, 1)
+    if name == "igemm_nt_dgrad_act":      # ... and the dgrad + activation-backward launch
+        A, Bp, C, u, act, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset = a
+        name, a = "igemm_nt", (A, Bp, u, C, None, None, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset, 0, 1)
     # the 3-channel layers run their own kernels (csrc/conv3.hip), not igemm_nt_kernel / wgrad_tn_kernel: booked apart so
     # that the launch counts and average durations of the MFMA families match what rocprofv3 reports per kernel name
     if name == "igemm_nt" and a[7] == ops.IM2COL3 and a[10] in (64, 128, 256) and \
@@ -89,6 +92,8 @@ class TimedBackend:
             sig = tuple(x for x in ca if isinstance(x, (int, bool))) if name in ("igemm_nt", "wgrad_tn", "conv3_nt", "conv3_wgrad", "tconv_patch") else ()
             if attr == "igemm_nt_dgrad_bn":
                 sig = sig + ("bn_bwd_epilogue",)
+            if attr == "igemm_nt_dgrad_act":
+                sig = sig + ("act_bwd_epilogue",)
             self.records.append((name, _flops(name, ca), _bytes(ca), s, e, sig))
             return r
         return wrapped

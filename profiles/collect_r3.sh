@@ -25,6 +25,24 @@ elif [ "$part" = part1 ]; then
   cp $(find $O/prof_graph -name "*kernel_stats.csv" | head -1) $O/bench_n1_kernel_stats.csv
   cp $(find $O/prof_single -name "*kernel_stats.csv" | head -1) $O/bench_n1_single_lane_kernel_stats.csv
   rm -rf $O/prof_graph $O/prof_single
+elif [ "$part" = others ]; then
+  # the other BASELINE configs' per-GPU shares (same JSON contract; config.workload names each)
+  python3 $R/bench.py --dtype bf16s --batch 128 --no-cpu-baseline > $O/bench_c2_bf16s_b128.json 2>> $O/others.err
+  python3 $R/bench.py --dtype bf16s --no-cpu-baseline > $O/bench_c2_bf16s_b256.json 2>> $O/others.err
+  python3 $R/bench.py --image-size 128 --problem dyn_modeling --batch 128 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_c3_dyn128_b128.json 2>> $O/others.err
+  python3 $R/bench.py --image-size 128 --problem dyn_modeling --batch 128 --dtype bf16s --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_c3_dyn128_b128_bf16s.json 2>> $O/others.err
+  python3 $R/bench.py --image-size 256 --dtype fp16 --batch 256 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c4_256_fp16_b256.json 2>> $O/others.err
+  python3 $R/bench.py --image-size 256 --dtype bf16s --batch 256 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c4_256_bf16s_b256.json 2>> $O/others.err
+  python3 $R/bench.py --image-size 256 --batch 64 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c4_256_f32_b64.json 2>> $O/others.err
+  python3 $R/bench.py --dtype fp16 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_c1_fp16.json 2>> $O/others.err
+  python3 $R/bench.py --infer --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_infer.json 2>> $O/others.err
+  python3 $R/bench.py --dtype bf16s --batch 128 --breakdown --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2> $O/bench_c2_event_breakdown.txt
+elif [ "$part" = alltraffic ]; then
+  bash $R/profiles/collect_r3.sh traffic s64_f32_b256_seq_modeling
+  bash $R/profiles/collect_r3.sh traffic s64_bf16s_b128_seq_modeling --dtype bf16s --batch 128
+  bash $R/profiles/collect_r3.sh traffic s128_f32_b128_dyn_modeling --image-size 128 --problem dyn_modeling --batch 128
+  bash $R/profiles/collect_r3.sh traffic s256_fp16_b256_seq_modeling --image-size 256 --dtype fp16 --batch 256
+  bash $R/profiles/collect_r3.sh traffic s256_bf16s_b256_seq_modeling --image-size 256 --dtype bf16s --batch 256
 elif [ "$part" = traffic ]; then
   # whole-step HBM-side traffic of one bench.py workload: collect_r3.sh traffic <key> <bench args...>
   # separate PMC passes, --kernel-trace only (MI355X_MICROARCH.md, HBM section)
