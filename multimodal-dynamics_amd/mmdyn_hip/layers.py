@@ -100,7 +100,9 @@ def tconv_s1p0(x, Wsp, G, Bg, Cin, N, stats=False):
     Large batches: the tap-skipping implicit GEMM (exactly the useful MACs, balanced pixel quads).  Small ones
     (too few blocks to fill 256 CUs): dense GEMM to a [rows][16*N] column matrix + col2im gather."""
     Bt = G * Bg
-    if G * 16 * _cdiv(Bg, 64) * (N // 64) >= 512 or ACT_DTYPE != torch.float32:      # (bf16 storage: no column matrix)
+    # (from 256 blocks on: the per-GPU share of a 4-group decoder at bs 128 -- the column-matrix route costs 2.5x the
+    # FLOPs plus a col2im pass: 0.55 vs ~0.15 ms there)
+    if G * 16 * _cdiv(Bg, 64) * (N // 64) >= 256 or ACT_DTYPE != torch.float32:      # (bf16 storage: no column matrix)
         return conv_like(x, Wsp, TCONV_S1P0, G, Bg, 5, Cin, 8, N, stats=stats)
     col, _ = dense(x, Wsp, None, Bt * 25, Cin, 16 * N)
     y = _new(x, Bt * 64, N)
