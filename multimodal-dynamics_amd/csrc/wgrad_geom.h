@@ -1,0 +1,23 @@
+// Geometry of one weight-gradient launch, shared by wgrad_tn.hip (register-staged kernels) and wgrad_ws.hip
+// (wave-specialised LDS-DMA ring kernels).
+#pragma once
+#include "common.h"
+
+struct WgradGeom {
+  int d_b16, g_b16;  // bf16 activation storage (bf16 matrix-core variants only): D / Gt are bf16 in HBM
+  int f16;           // 16-bit matrix-core mode with fp16 instead of bf16 operands (fp32 storage only)
+  int mode;  // MMDYN_DENSE or MMDYN_CONV
+  int rows;  // Bt*Hr*Wr
+  int Hr, Wr, Cd;
+  int Hi, Wi, Cg;
+  int rs, ro;
+  int ntaps, chunks, rows_per_chunk;
+};
+
+// wgrad_ws.hip (LAB build only: measured no faster than wgrad_tn.hip, see wgrad_entry): fp32 weight-gradient GEMM with loader
+// waves + LDS-DMA ring.  Returns MMDYN_OK / an error code, or 1 when the launch is not served.  Same partial-slab layout.
+#ifdef MMDYN_LAB
+int mmdyn_wgrad_ws_try(const float* D, const float* Gt, float* partial, const WgradGeom& g, hipStream_t st);
+#else
+static inline int mmdyn_wgrad_ws_try(const float*, const float*, float*, const WgradGeom&, hipStream_t) { return 1; }
+#endif

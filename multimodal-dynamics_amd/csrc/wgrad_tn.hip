@@ -16,19 +16,10 @@
 // slabs, no atomics); a second kernel sums the slabs and scatters into the canonical layout.
 #include <stdlib.h>
 #include "common.h"
+#include "wgrad_geom.h"
 
 namespace {
 
-struct WgradGeom {
-  int d_b16, g_b16;  // bf16 activation storage (bf16 matrix-core variants only): D / Gt are bf16 in HBM
-  int f16;           // 16-bit matrix-core mode with fp16 instead of bf16 operands (fp32 storage only)
-  int mode;  // MMDYN_DENSE or MMDYN_CONV
-  int rows;  // Bt*Hr*Wr
-  int Hr, Wr, Cd;
-  int Hi, Wi, Cg;
-  int rs, ro;
-  int ntaps, chunks, rows_per_chunk;
-};
 
 constexpr int RK = 32;  // rows per K-step
 
@@ -917,6 +908,16 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
     if (rc != 1) return rc;
   }
   const bool d64 = (Cd % 64 == 0), g64 = (Cg % 64 == 0);
+  if (!bf16 && mode != MMDYN_IM2COL3) {
+    // LAB build, MMDYN_WGRAD_WS=1: the wave-specialised LDS-DMA ring form of this GEMM (wgrad_ws.hip).  Measured per shape
+    // against the kernels below (profiles/r3/ab_ws_wgrad.txt): x0.97-1.10, one launch x0.69, sum +3 % -- unlike the implicit
+    // GEMM this kernel gains nothing from the ring, so the product keeps one code path and does not build it.
+    const char* e = lab_env("MMDYN_WGRAD_WS");
+    if (e && e[0] == '1') {
+      const int rc = mmdyn_wgrad_ws_try(D, Gt, partial, g, st);
+      if (rc != 1) return rc;
+    }
+  }
   if (bf16 && g.d_b16 && g.g_b16 && mode != MMDYN_IM2COL3) {
     // both operands bf16 in HBM: the transposing-LDS-read kernel (two waves share a 64x32 / 32x64 tile's rows)
     if (Cd % 128 == 0 && Cg % 128 == 0) return launch_b16<128, 128, 64, 64, 1>(D, Gt, partial, g, st);

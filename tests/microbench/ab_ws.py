@@ -95,6 +95,39 @@ def main():
         print(f"{str(sh):58s} regstage {m0 * 1e3:7.1f} us {fl / m0 / 1e9:6.1f} TF/s | ws {m1 * 1e3:7.1f} us {fl / m1 / 1e9:6.1f} TF/s "
               f"| x{m0 / m1:5.2f}  maxdiff {err:.1e}", flush=True)
     print(f"sum regstage {tot['0']:.3f} ms, ws {tot['1']:.3f} ms")
+    # ---- weight-gradient GEMMs (MMDYN_WGRAD_WS=1: the ring form, LAB build only) ----
+    WGRAD = [  # mode,Bt,Hr,Cd,Hi,Cg,stride,offset
+        (1, 1024, 5, 256, 8, 128, 1, 0), (1, 1024, 8, 128, 16, 64, 2, -1), (1, 256, 5, 256, 8, 128, 1, 0),
+        (1, 256, 8, 128, 16, 64, 2, -1), (0, 1024, 1, 6400, 1, 256, 1, 0), (0, 1024, 1, 512, 1, 512, 1, 0),
+        (0, 256, 1, 512, 1, 6400, 1, 0), (0, 1024, 1, 512, 1, 256, 1, 0)]
+    tot = {"0": 0.0, "1": 0.0}
+    for sh in WGRAD:
+        mode, Bt, Hr, Cd, Hi, Cg, stride, offset = sh
+        taps = 16 if mode == 1 else 1
+        rows = Bt * Hr * Hr
+        Dm = torch.randn(rows, Cd, device=dev)
+        Gm = torch.randn(Bt * Hi * Hi, Cg, device=dev)
+        chunks = HIP.wgrad_chunks(mode, rows, Cd, Cg)
+        part = torch.empty(chunks, taps, Cd, Cg, device=dev)
+        fn = lambda: HIP.wgrad_tn(Dm, Gm, part, mode, Bt, Hr, Hr, Cd, Hi, Hi, Cg, stride, offset, chunks)
+        times, res = {"0": [], "1": []}, {}
+        for rnd in range(5):
+            for flag in ("0", "1"):
+                os.environ["MMDYN_WGRAD_WS"] = flag
+                if rnd == 0:
+                    for _ in range(3):
+                        fn()
+                    torch.cuda.synchronize()
+                    res[flag] = part.sum(0)
+                times[flag].append(event_ms(fn, 10))
+        fl = 2.0 * rows * Cd * Cg * taps
+        m0, m1 = statistics.median(times["0"]), statistics.median(times["1"])
+        tot["0"] += m0
+        tot["1"] += m1
+        err = float((res["0"] - res["1"]).abs().max() / (res["0"].abs().max() + 1e-30))
+        print(f"wgrad {str(sh):44s} chunks {chunks:3d} regstage {m0 * 1e3:7.1f} us {fl / m0 / 1e9:6.1f} TF/s | ws {m1 * 1e3:7.1f} us "
+              f"{fl / m1 / 1e9:6.1f} TF/s | x{m0 / m1:5.2f}  maxdiff {err:.1e}", flush=True)
+    print(f"wgrad sum regstage {tot['0']:.3f} ms, ws {tot['1']:.3f} ms")
 
 
 if __name__ == "__main__":
