@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const TA* __restrict__ y
 // blockIdx.z (a 32-channel layer has only G x 1 channel blocks; the slices give the big layers 100+ blocks):
 // out[s][g][2][C] (double accumulate); the finish kernels add the S slices in a fixed order.
 constexpr int BN_MAX_SPLITS = 32;
+// single-launch ("last block finishes") form: every block arrives on ONE counter (~12 ns per arrival), so it runs with few,
+// fat slices -- at most 4 x groups x channel slabs <= 128 blocks -- instead of the 1024 the two-launch form spreads the sums over
+constexpr int TICKET_MAX_SPLITS = 4;
 static inline int bn_splits(int T) {
   int s = T / 128;
   return s < 1 ? 1 : (s > BN_MAX_SPLITS ? BN_MAX_SPLITS : s);
@@ -351,8 +354,9 @@ extern "C" int mmdyn_bn_finalize(const float* partial, float* mean, float* rstd,
   if (!partial || !mean || !rstd || !g_sums) return MMDYN_ERR_NULL;
   if (!bn_shape_ok(G, rows_per_group, C) || T <= 0) return MMDYN_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const int S = bn_splits(T);
+  int S = bn_splits(T);
   if (ticket) {           // one launch: the last-arriving block of the tile sums finishes the statistics
+    if (S > TICKET_MAX_SPLITS) S = TICKET_MAX_SPLITS;
     BnFinish f{};
     f.kind = 1;
     f.mean = mean;
@@ -481,8 +485,9 @@ extern "C" int mmdyn_bn_bwd_finalize(const float* partial, float* sums, float* d
   if (!partial || !sums || !g_sums) return MMDYN_ERR_NULL;
   if (!bn_shape_ok(G, 1, C) || T <= 0) return MMDYN_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const int S = bn_splits(T);
+  int S = bn_splits(T);
   if (ticket) {
+    if (S > TICKET_MAX_SPLITS) S = TICKET_MAX_SPLITS;
     BnFinish f{};
     f.kind = 2;
     f.sums_f = sums;
