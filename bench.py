@@ -249,11 +249,11 @@ def main():
                     help="dyn_modeling (configs[3]): the batch is --seq-length frames per sequence, targets are the next frames "
                          "(DynModeling.parse_input, problems.py:765-803); the step itself is the same computation")
     ap.add_argument("--seq-length", type=int, default=4)
-    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16s", "fp16"), default="f32",
+    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16s", "fp16", "fp16s"), default="f32",
                     help="f32: the BASELINE configs[1] line (default).  bf16s: bf16 activation storage + bf16 matrix "
                          "cores, fp32 accumulate / master weights = the per-GPU share of configs[2] (use --batch 128).  "
                          "bf16: bf16 matrix-core operands only (fp32 storage).  fp16: fp16 matrix-core operands, fp32 "
-                         "accumulate / storage / master weights (configs[4])")
+                         "accumulate / storage / master weights (configs[4]).  fp16s: fp16 + fp16 activation storage")
     ap.add_argument("--sync-bn", action="store_true",
                     help="BatchNorm statistics over the global batch (N > 1; one small all-reduce per BatchNorm layer and "
                          "direction, captured into the lanes' HIP graphs, each lane on its own RCCL communicator).  Default: "
@@ -311,7 +311,7 @@ def main():
 
     torch.manual_seed(0)
     S = args.image_size
-    PREC = {"f32": "fp32", "bf16": "bf16", "bf16s": "bf16s", "fp16": "fp16"}[args.dtype]
+    PREC = {"f32": "fp32", "bf16": "bf16", "bf16s": "bf16s", "fp16": "fp16", "fp16s": "fp16s"}[args.dtype]
     assert abs(algo_gflop_per_sample(64) - ALGO_GFLOP_PER_SAMPLE) < 1e-3
     gflop_per_sample = algo_gflop_per_sample(S)
     model = setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=S * S, architecture="cnn",
@@ -408,7 +408,7 @@ def main():
     dom_name = "igemm_nt_kernel" if dom is ig else "wgrad_tn_kernel"
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     total_ms = sum(d["ms"] for d in kern.values())
-    peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else (PEAK_F16_MFMA_TFLOPS if args.dtype == "fp16" else PEAK_BF16_MFMA_TFLOPS)
+    peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else (PEAK_F16_MFMA_TFLOPS if args.dtype in ("fp16", "fp16s") else PEAK_BF16_MFMA_TFLOPS)
     # byte side: the committed PMC passes of THIS workload (whole step + the implicit-GEMM launches)
     wkey = f"s{S}_{args.dtype}_b{args.batch}_{args.problem}"
     prof, traffic_note = pmc_traffic(wkey)
@@ -430,7 +430,9 @@ def main():
         return "hbm" if hbm > mfma else "mfma"
     arith = {"f32": "fp32", "bf16": "bf16 matrix-core operands (fp32 accumulate, storage and master weights)",
              "bf16s": "bf16 activation storage + bf16 matrix-core operands (fp32 accumulate and master weights)",
-             "fp16": "fp16 matrix-core operands (fp32 accumulate, storage and master weights)"}[args.dtype]
+             "fp16": "fp16 matrix-core operands (fp32 accumulate, storage and master weights)",
+             "fp16s": "fp16 activation storage + fp16 matrix-core operands (fp32 accumulate and master weights, loss scale 4B)"
+             }[args.dtype]
     which = ("BASELINE configs[1]" if (S == 64 and args.dtype == "f32" and args.problem == "seq_modeling") else
              "per-GPU share of BASELINE configs[2]" if (S == 64 and args.dtype in ("bf16", "bf16s")) else
              "per-GPU share of BASELINE configs[3] (extension: no reference architecture at this size)" if S == 128 else

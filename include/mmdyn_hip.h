@@ -148,11 +148,12 @@ int mmdyn_repack2d(const float* in, float* out, int rows_in, int cols_in, int ro
 /* mmdyn_repack2d writing a rows_out x cols_out block into a wider matrix (row stride ld_out >= cols_out) */
 int mmdyn_repack2d_ld(const float* in, float* out, int rows_in, int cols_in, int rows_out, int cols_out,
                       int ld_out, int mode, void* stream);
-/* the same two packs with a bf16 destination (RNE): in the bf16 precision modes the weights are packed straight to
- * the matrix cores' operand type, which halves the weight bytes every implicit-GEMM block pulls through L2 */
-int mmdyn_pack_conv_weight_b16(const float* Wc, void* P, int d0, int d1, int swap, void* stream);
+/* the same two packs with a 16-bit destination (RNE; half = 0: bf16, half = 1: IEEE half): in the 16-bit storage modes
+ * the weights are packed straight to the matrix cores' operand type, which halves the weight bytes every implicit-GEMM
+ * block pulls through L2 */
+int mmdyn_pack_conv_weight_b16(const float* Wc, void* P, int d0, int d1, int swap, int half, void* stream);
 int mmdyn_repack2d_ld_b16(const float* in, void* out, int rows_in, int cols_in, int rows_out, int cols_out,
-                          int ld_out, int mode, void* stream);
+                          int ld_out, int mode, int half, void* stream);
 /* A whole step's weight repacks in one launch.  `plan_dev` is a DEVICE array of n entries (built once: the
  * parameter storage of a training run does not move).  kind 0..5 = mmdyn_repack2d modes with an output leading
  * dimension ld_out (>= cols_out); kind 100 / 101 = mmdyn_pack_conv_weight with swap 0 / 1 (rows_in = d0,
@@ -161,7 +162,7 @@ typedef struct {
   const float* src;
   float* dst;
   int kind, rows_in, cols_in, rows_out, cols_out, ld_out;
-  int dst_bf16;   /* 1: dst is a bf16 tensor (ld_out in elements); the GEMM operands of the bf16 precision modes */
+  int dst_bf16;   /* 1: dst is a bf16 tensor (ld_out in elements), 2: an IEEE-half tensor; the GEMM operands of the 16-bit modes */
 } mmdyn_pack_entry;
 int mmdyn_pack_plan(const mmdyn_pack_entry* plan_dev, int n, void* stream);
 
@@ -356,9 +357,11 @@ int mmdyn_resize_u8_to_chw_f32(const uint8_t* src, const int* index, float* dst,
  *       (mmdyn_pack_conv_weight_b16 / mmdyn_repack2d_ld_b16 / a dst_bf16 plan entry), bit 6 C_act alone is bf16 (C stays
  *       fp32: the Linear layer whose activated output feeds the first transposed convolution, vae.py:264-271; not with
  *       bit 2 or split-K).  y == NULL: plain GEMM epilogue.  Split-K (fp32 workspace) is allowed with a bf16 A, not with a
- *       bf16 C.
- *   mmdyn_wgrad_tn_mx : bit 0 as above, bit 1 D is bf16, bit 2 Gt is bf16 (not IM2COL3).
- *   *_b16             : the element-wise kernels on bf16 activation tensors. */
+ *       bf16 C.  Bit 5 together with bit 0: every tensor the other bits mark is IEEE HALF instead of bf16 and the product
+ *       runs on the fp16 matrix cores (precision "fp16s": fp16 activation storage, BASELINE configs[4] arithmetic); bit 5
+ *       with no storage bit is mmdyn_igemm_nt_f16.
+ *   mmdyn_wgrad_tn_mx : bit 0 as above, bit 1 D is 16-bit, bit 2 Gt is 16-bit (not IM2COL3), bit 5 as above.
+ *   *_b16             : the element-wise kernels on 16-bit activation tensors (half = 0: bf16, half = 1: IEEE half). */
 int mmdyn_igemm_nt_mx(const void* A, const void* Bp, const float* bias, void* C, void* C_act, float* stats,
                       float* ws, const void* y, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
@@ -366,15 +369,16 @@ int mmdyn_igemm_nt_mx(const void* A, const void* Bp, const float* bias, void* C,
 int mmdyn_wgrad_tn_mx(const void* D, const void* Gt, float* partial, int mode, int Bt, int Hr, int Wr, int Cd, int Hi,
                       int Wi, int Cg, int stride, int offset, int chunks, int flags, void* stream);
 int mmdyn_bn_swish_fwd_b16(const uint16_t* y, const float* mean, const float* rstd, const float* gamma,
-                           const float* beta, uint16_t* a, int G, int rows_per_group, int C, void* stream);
+                           const float* beta, uint16_t* a, int G, int rows_per_group, int C, int half, void* stream);
 int mmdyn_bn_swish_bwd_reduce_b16(const uint16_t* da, const uint16_t* y, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, float* partial, int G, int rows_per_group,
-                                  int C, void* stream);
+                                  int C, int half, void* stream);
 int mmdyn_bn_swish_bwd_apply_b16(const uint16_t* da, const uint16_t* y, const float* mean, const float* rstd,
                                  const float* gamma, const float* beta, const float* sums, uint16_t* dy, int G,
-                                 int rows_per_group, int C, int da_is_du, void* stream);
-int mmdyn_act_bwd_b16(const uint16_t* dh, const uint16_t* u, uint16_t* du, int64_t n, int act, void* stream);
-int mmdyn_tconv_out3_fwd_b16(const uint16_t* a, const float* w, float* out, int Bt, int Hi, int Wi, void* stream);
+                                 int rows_per_group, int C, int da_is_du, int half, void* stream);
+int mmdyn_act_bwd_b16(const uint16_t* dh, const uint16_t* u, uint16_t* du, int64_t n, int act, int half, void* stream);
+int mmdyn_tconv_out3_fwd_b16(const uint16_t* a, const float* w, float* out, int Bt, int Hi, int Wi, int half,
+                             void* stream);
 
 /* ---- misc ------------------------------------------------------------------------------------- */
 int mmdyn_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, void* stream);

@@ -433,37 +433,50 @@ extern "C" int mmdyn_bn_swish_fwd(const float* y, const float* mean, const float
 /* bf16 activation storage (BASELINE configs[2]): same kernels, y / a / da / dy are bf16 in HBM (fp32 in registers);
  * statistics, affine parameters and sums stay fp32 */
 extern "C" int mmdyn_bn_swish_fwd_b16(const uint16_t* y, const float* mean, const float* rstd, const float* gamma,
-                                      const float* beta, uint16_t* a, int G, int rows_per_group, int C, void* stream) {
+                                      const float* beta, uint16_t* a, int G, int rows_per_group, int C, int half,
+                                      void* stream) {
   if (!y || !mean || !rstd || !gamma || !beta || !a) return MMDYN_ERR_NULL;
   if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
   BnParams bp{mean, rstd, gamma, beta};
   int64_t total4 = (int64_t)G * rows_per_group * (C / 4);
-  hipLaunchKernelGGL(bn_swish_fwd_kernel<bf16_t>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, bp, a,
-                     total4, rows_per_group, C);
+  if (half)
+    hipLaunchKernelGGL(bn_swish_fwd_kernel<half_t>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)y, bp, (half_t*)a, total4, rows_per_group, C);
+  else
+    hipLaunchKernelGGL(bn_swish_fwd_kernel<bf16_t>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, bp, a,
+                       total4, rows_per_group, C);
   MMDYN_LAUNCH_CHECK();
 }
 
 extern "C" int mmdyn_bn_swish_bwd_reduce_b16(const uint16_t* da, const uint16_t* y, const float* mean,
                                              const float* rstd, const float* gamma, const float* beta, float* partial,
-                                             int G, int rows_per_group, int C, void* stream) {
+                                             int G, int rows_per_group, int C, int half, void* stream) {
   if (!da || !y || !mean || !rstd || !gamma || !beta || !partial) return MMDYN_ERR_NULL;
   if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
   const int T = ceil_div(rows_per_group, TILE_ROWS);
   BnParams bp{mean, rstd, gamma, beta};
-  hipLaunchKernelGGL((colreduce_kernel<1, bf16_t>), dim3(T, G), dim3(256), 0, (hipStream_t)stream, y, da, bp, partial,
-                     rows_per_group, C, T);
+  if (half)
+    hipLaunchKernelGGL((colreduce_kernel<1, half_t>), dim3(T, G), dim3(256), 0, (hipStream_t)stream, (const half_t*)y,
+                       (const half_t*)da, bp, partial, rows_per_group, C, T);
+  else
+    hipLaunchKernelGGL((colreduce_kernel<1, bf16_t>), dim3(T, G), dim3(256), 0, (hipStream_t)stream, y, da, bp, partial,
+                       rows_per_group, C, T);
   MMDYN_LAUNCH_CHECK();
 }
 
 extern "C" int mmdyn_bn_swish_bwd_apply_b16(const uint16_t* da, const uint16_t* y, const float* mean, const float* rstd,
                                             const float* gamma, const float* beta, const float* sums, uint16_t* dy,
-                                            int G, int rows_per_group, int C, int da_is_du, void* stream) {
+                                            int G, int rows_per_group, int C, int da_is_du, int half, void* stream) {
   if (!da || !y || !mean || !rstd || !gamma || !beta || !sums || !dy) return MMDYN_ERR_NULL;
   if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
   BnParams bp{mean, rstd, gamma, beta};
   int64_t total4 = (int64_t)G * rows_per_group * (C / 4);
-  hipLaunchKernelGGL(bn_swish_bwd_apply_kernel<bf16_t>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, da,
-                     y, bp, sums, dy, total4, rows_per_group, C, da_is_du);
+  if (half)
+    hipLaunchKernelGGL(bn_swish_bwd_apply_kernel<half_t>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)da, (const half_t*)y, bp, sums, (half_t*)dy, total4, rows_per_group, C, da_is_du);
+  else
+    hipLaunchKernelGGL(bn_swish_bwd_apply_kernel<bf16_t>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, da,
+                       y, bp, sums, dy, total4, rows_per_group, C, da_is_du);
   MMDYN_LAUNCH_CHECK();
 }
 

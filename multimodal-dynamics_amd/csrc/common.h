@@ -32,6 +32,31 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
   r[1] = (__bf16)hi;
   return __builtin_bit_cast(uint32_t, r);
 }
+// Second 16-bit storage type: IEEE half (the fp16-storage mode, BASELINE configs[4]).  A distinct C++ type so that the
+// kernels templated on the storage type get their own instances; same size and alignment as bf16_t.
+struct half_t { uint16_t v; };
+__device__ __forceinline__ float h2f(uint32_t bits16) { return (float)__builtin_bit_cast(_Float16, (uint16_t)bits16); }
+__device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  h2 r;
+  r[0] = (_Float16)lo;
+  r[1] = (_Float16)hi;
+  return __builtin_bit_cast(uint32_t, r);
+}
+template <> __device__ __forceinline__ f32x4 ld4<half_t>(const half_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  f32x4 v;
+  v[0] = h2f(u.x & 0xffffu);
+  v[1] = h2f(u.x >> 16);
+  v[2] = h2f(u.y & 0xffffu);
+  v[3] = h2f(u.y >> 16);
+  return v;
+}
+template <> __device__ __forceinline__ float ld1<half_t>(const half_t* p) { return h2f(p->v); }
+// pack two values into one dword of the storage type T (bf16_t / half_t)
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack2_bf16(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<half_t>(float lo, float hi) { return pack2_f16(lo, hi); }
 template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
 template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f32x4 v) {
@@ -40,9 +65,16 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f32x4 v) {
   u.y = pack2_bf16(v[2], v[3]);
   *reinterpret_cast<uint2*>(p) = u;
 }
-// 16-byte accesses for both storage types: VECW<T> elements per access (4 floats or 8 bf16), as VECW/4 f32x4 groups
+template <> __device__ __forceinline__ void st4<half_t>(half_t* p, f32x4 v) {
+  uint2 u;
+  u.x = pack2_f16(v[0], v[1]);
+  u.y = pack2_f16(v[2], v[3]);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+// 16-byte accesses for all storage types: VECW<T> elements per access (4 floats or 8 16-bit values), as VECW/4 f32x4 groups
 template <typename T> struct vecw { static constexpr int n = 4; };
 template <> struct vecw<bf16_t> { static constexpr int n = 8; };
+template <> struct vecw<half_t> { static constexpr int n = 8; };
 template <typename T> __device__ __forceinline__ void ldv(const T* p, f32x4* v);
 template <> __device__ __forceinline__ void ldv<float>(const float* p, f32x4* v) { v[0] = *reinterpret_cast<const f32x4*>(p); }
 template <> __device__ __forceinline__ void ldv<bf16_t>(const bf16_t* p, f32x4* v) {
@@ -99,6 +131,40 @@ template <> __device__ __forceinline__ void stv_nt<bf16_t>(bf16_t* p, const f32x
 template <typename T> __device__ __forceinline__ void st1(T* p, float v);
 template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = (bf16_t)(pack2_bf16(v, 0.f) & 0xffffu); }
+template <> __device__ __forceinline__ void st1<half_t>(half_t* p, float v) { p->v = (uint16_t)(pack2_f16(v, 0.f) & 0xffffu); }
+__device__ __forceinline__ void unpack8_f16(const uint32_t* u, f32x4* v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i >> 1][(i & 1) * 2 + 0] = h2f(u[i] & 0xffffu);
+    v[i >> 1][(i & 1) * 2 + 1] = h2f(u[i] >> 16);
+  }
+}
+template <> __device__ __forceinline__ void ldv<half_t>(const half_t* p, f32x4* v) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+  unpack8_f16(w, v);
+}
+template <> __device__ __forceinline__ void stv<half_t>(half_t* p, const f32x4* v) {
+  uint4 u;
+  u.x = pack2_f16(v[0][0], v[0][1]);
+  u.y = pack2_f16(v[0][2], v[0][3]);
+  u.z = pack2_f16(v[1][0], v[1][1]);
+  u.w = pack2_f16(v[1][2], v[1][3]);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+template <> __device__ __forceinline__ void ldv_nt<half_t>(const half_t* p, f32x4* v) {
+  const u32x4 u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  const uint32_t w[4] = {u[0], u[1], u[2], u[3]};
+  unpack8_f16(w, v);
+}
+template <> __device__ __forceinline__ void stv_nt<half_t>(half_t* p, const f32x4* v) {
+  u32x4 u;
+  u[0] = pack2_f16(v[0][0], v[0][1]);
+  u[1] = pack2_f16(v[0][2], v[0][3]);
+  u[2] = pack2_f16(v[1][0], v[1][1]);
+  u[3] = pack2_f16(v[1][2], v[1][3]);
+  __builtin_nontemporal_store(u, reinterpret_cast<u32x4*>(p));
+}
 
 // Last-arriving block finishes (cdna_hip_programming.md section 5 "In-launch split-K reduction", Guideline 16 R1): every
 // block of a launch stores its partial result WRITE-THROUGH (st_wt: sc1 stores, so no release fence -- a fence would write

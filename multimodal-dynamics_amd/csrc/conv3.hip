@@ -46,6 +46,9 @@ template <> __device__ __forceinline__ float gld1<float>(gchar_p p) { return *(G
 template <> __device__ __forceinline__ float gld1<bf16_t>(gchar_p p) {
   return __uint_as_float((uint32_t)(*(GLOBAL_AS const bf16_t*)p) << 16);
 }
+template <> __device__ __forceinline__ float gld1<half_t>(gchar_p p) { return h2f(*(GLOBAL_AS const uint16_t*)p); }
+template <typename T> struct store16 { typedef bf16_t type; };      // (the 16-bit packing a store of type T uses)
+template <> struct store16<half_t> { typedef half_t type; };
 
 // slot j (0..23) of lane half h is the window element (ci, kh, kw) = (j>>3, (j>>1)&3, 2*(j&1)+h); MFMA j multiplies
 // slot j of A and B, so any bijection works as long as both operands use it.
@@ -65,8 +68,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: row / sample arithmetic stays scalar
   const int x = lane & 31, h = lane >> 5;
   for (int i = tid; i < 512; i += 256) {           // Wp: [32 n][64 k] (k >= 48 zero, never read), fp32 or bf16
-    const f32x4 v = g.w_b16 ? ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Wp) + 4 * i)
-                            : reinterpret_cast<const f32x4*>(Wp)[i];
+    const f32x4 v = g.w_b16 == 2 ? ld4<half_t>(reinterpret_cast<const half_t*>(Wp) + 4 * i)
+                    : g.w_b16 ? ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Wp) + 4 * i)
+                              : reinterpret_cast<const f32x4*>(Wp)[i];
     const int n = i >> 4, k = (i & 15) * 4;
     Ws[n * 65 + k + 0] = v[0];
     Ws[n * 65 + k + 1] = v[1];
@@ -185,8 +189,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // adjacent channels sit in adjacent lanes: the even lane stores both as one dword
         const float vn = __shfl_down(v, 1, 64);
         if (!(x & 1)) {
-          *(GLOBAL_AS uint32_t*)(cb + erow(e)) = pack2_bf16(v, vn);
-          if (ACT >= 0) *(GLOBAL_AS uint32_t*)(ab + erow(e)) = pack2_bf16(apply_act(v, ACT), apply_act(vn, ACT));
+          *(GLOBAL_AS uint32_t*)(cb + erow(e)) = pack2<typename store16<T>::type>(v, vn);
+          if (ACT >= 0)
+            *(GLOBAL_AS uint32_t*)(ab + erow(e)) = pack2<typename store16<T>::type>(apply_act(v, ACT), apply_act(vn, ACT));
         }
       } else {
         *(GLOBAL_AS float*)(cb + erow(e)) = v;
@@ -383,7 +388,11 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
   hipLaunchKernelGGL((conv3_nt_kernel<T_, BN_, ACT_, S_>), grid, dim3(256), 0, st, A, Bp, (T_*)C, (T_*)C_act, stats, g)
 #define CONV3_CASE(V, BN_, ACT_)                                                                                   \
   if (variant == (V)) {                                                                                            \
-    if (c_b16) {                                                                                                   \
+    if (c_b16 == 2) {                                                                                              \
+      if (segs == 1) CONV3_LAUNCH(half_t, BN_, ACT_, 1);                                                           \
+      else if (segs == 2) CONV3_LAUNCH(half_t, BN_, ACT_, 2);                                                      \
+      else CONV3_LAUNCH(half_t, BN_, ACT_, 4);                                                                     \
+    } else if (c_b16) {                                                                                            \
       if (segs == 1) CONV3_LAUNCH(bf16_t, BN_, ACT_, 1);                                                           \
       else if (segs == 2) CONV3_LAUNCH(bf16_t, BN_, ACT_, 2);                                                      \
       else CONV3_LAUNCH(bf16_t, BN_, ACT_, 4);                                                                     \
@@ -418,7 +427,11 @@ int mmdyn_conv3_wgrad_try(const void* D, const float* Gt, float* partial, int Bt
   g.rows_per_chunk = ceil_div(g.img_rows, chunks);
 #define CONV3_WG(T_, S_) \
   hipLaunchKernelGGL((conv3_wgrad_kernel<T_, S_>), dim3(chunks), dim3(256), 0, st, (const T_*)D, Gt, partial, g)
-  if (d_b16) {
+  if (d_b16 == 2) {
+    if (segs == 1) CONV3_WG(half_t, 1);
+    else if (segs == 2) CONV3_WG(half_t, 2);
+    else CONV3_WG(half_t, 4);
+  } else if (d_b16) {
     if (segs == 1) CONV3_WG(bf16_t, 1);
     else if (segs == 2) CONV3_WG(bf16_t, 2);
     else CONV3_WG(bf16_t, 4);

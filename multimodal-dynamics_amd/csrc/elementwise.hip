@@ -367,10 +367,14 @@ extern "C" int mmdyn_act_bwd(const float* dh, const float* u, float* du, int64_t
   hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, dh, u, du, n, act);
   MMDYN_LAUNCH_CHECK();
 }
-extern "C" int mmdyn_act_bwd_b16(const uint16_t* dh, const uint16_t* u, uint16_t* du, int64_t n, int act,
+extern "C" int mmdyn_act_bwd_b16(const uint16_t* dh, const uint16_t* u, uint16_t* du, int64_t n, int act, int half,
                                  void* stream) {
   if (!dh || !u || !du) return MMDYN_ERR_NULL;
-  hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, dh, u, du, n, act);
+  if (half)
+    hipLaunchKernelGGL(act_bwd_kernel<half_t>, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, (const half_t*)dh, (const half_t*)u,
+                       (half_t*)du, n, act);
+  else
+    hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, dh, u, du, n, act);
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_dropout_expand(const float* h, const uint8_t* masks, float* out, int P, int B, int H,

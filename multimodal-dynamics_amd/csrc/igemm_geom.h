@@ -33,7 +33,7 @@ struct IgemmGeom {
   // bf16 activation storage (bf16 matrix-core variants only): which of the activation tensors are bf16 in HBM
   int a_b16, c_b16, bny_b16;
   int cact_b16;   // the second (activated) output is bf16 while C itself is fp32
-  int f16;     // 16-bit matrix-core mode uses fp16 operands (v_mfma_f32_32x32x16_f16) instead of bf16; fp32 storage only
+  int f16;     // the 16-bit format is IEEE half instead of bf16 (v_mfma_*_f16): operands, and every tensor the *_b16 fields mark
   int b_b16;   // packed weights are bf16 (written so by the pack kernels in the bf16 modes: half the L2 -> LDS traffic)
 };
 

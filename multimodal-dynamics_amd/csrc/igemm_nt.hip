@@ -21,6 +21,7 @@
 #include "igemm_geom.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -49,13 +50,6 @@ __device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {
 // F16 (with BF16, fp32 storage on both sides): the 16-bit operands are IEEE half (RNE) and the product runs on
 // v_mfma_f32_32x32x16_f16 -- BASELINE configs[4] "MFMA fp16 conv with fp32 accumulate"; everything else as in the bf16 mode.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  h2 r;
-  r[0] = (_Float16)lo;
-  r[1] = (_Float16)hi;
-  return __builtin_bit_cast(uint32_t, r);
-}
 template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16, bool B16, bool WIDE = false, bool M16 = false,
           bool F16 = false, bool ONEPX = false>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__ A,
@@ -66,7 +60,10 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
                                                        const IgemmGeom g) {
   static_assert(!M16 || !BF16, "the 16x16x4 shape is the fp32 variant");
   static_assert(!ONEPX || MODE == MMDYN_TCONV_S1P0, "one output pixel per block is a variant of the k4 s1 p0 walk");
-  static_assert(!F16 || (BF16 && !A16 && !B16 && !WIDE), "fp16 operands: 16-bit matrix cores on fp32 storage");
+  static_assert(!F16 || BF16, "fp16 operands are a 16-bit matrix-core variant");
+  // (F16 with A16 / B16 / WIDE: the 16-bit STORAGE is IEEE half too -- precision "fp16s"; the raw granules go to LDS as they
+  // are, exactly like the bf16 ones, and the epilogue reads / writes half)
+  typedef typename std::conditional<F16, half_t, bf16_t>::type st16_t;
   constexpr int TS = M16 ? 16 : 32;                   // side of one MFMA output tile
   constexpr int NE = M16 ? 4 : 16;                    // accumulator registers per tile
   constexpr int LDS_LD = M16 ? BK + 8 : BK + 4;       // fp32 tile row stride (floats): conflict-free fragment reads
@@ -488,7 +485,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
         if (bnbwd) {
           float xh = 0.f;
           if (ooff >= 0) {
-            const float yv = (BF16 && g.bny_b16) ? ld1<bf16_t>(reinterpret_cast<const bf16_t*>(g.bn_y) + (size_t)ooff + col)
+            const float yv = (BF16 && g.bny_b16) ? ld1<st16_t>(reinterpret_cast<const st16_t*>(g.bn_y) + (size_t)ooff + col)
                                                  : g.bn_y[(size_t)ooff + col];
             xh = (yv - bn_m[nt]) * bn_r[nt];
             v *= act_grad(bn_g[nt] * xh + bn_b[nt], g.bwd_act);
@@ -510,10 +507,10 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
               // stores; ooff + col is even there, so the address is 4-byte aligned)
               const float vn = __shfl_down(v, 1, 64);
               if (!(cl & 1)) {
-                *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C) + (size_t)ooff + col) = pack2_bf16(v, vn);
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C) + (size_t)ooff + col) = pack2<st16_t>(v, vn);
                 if (g.want_act_out)
                   *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C_act) + (size_t)ooff + col) =
-                      pack2_bf16(apply_act(v, g.act), apply_act(vn, g.act));
+                      pack2<st16_t>(apply_act(v, g.act), apply_act(vn, g.act));
               }
             } else {
               C[(size_t)ooff + col] = v;
@@ -522,7 +519,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
                   const float av = apply_act(v, g.act);
                   const float an = __shfl_down(av, 1, 64);
                   if (!(cl & 1))
-                    *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C_act) + (size_t)ooff + col) = pack2_bf16(av, an);
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C_act) + (size_t)ooff + col) = pack2<st16_t>(av, an);
                 } else {
                   C_act[(size_t)ooff + col] = apply_act(v, g.act);
                 }
@@ -654,9 +651,17 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
     hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, false, false, false, false, M16_TILE>), grid, dim3(256), smem, st, A,
                        Bp, bias, C, C_act, stats, ws, g);
   else if (!bf16) IGEMM_LAUNCH(false, false, false);
-  else if (g.f16)
-    hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, false, false, false, false, true>), grid, dim3(256), smem, st,
-                       A, Bp, bias, C, C_act, stats, ws, g);
+  else if (g.f16) {
+#define IGEMM_LAUNCH_F16(A16_, B16_, WIDE_)                                                                             \
+  hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, A16_, B16_, WIDE_, false, true>), grid, dim3(256), smem, st, \
+                     A, Bp, bias, C, C_act, stats, ws, g)
+    if (g.a_b16 && g.b_b16 && CAN_A16 && g.Cin % 64 == 0) IGEMM_LAUNCH_F16(CAN_A16, true, CAN_A16);
+    else if (g.a_b16 && g.b_b16) IGEMM_LAUNCH_F16(CAN_A16, true, false);
+    else if (g.a_b16) IGEMM_LAUNCH_F16(CAN_A16, false, false);
+    else if (g.b_b16) IGEMM_LAUNCH_F16(false, true, false);
+    else IGEMM_LAUNCH_F16(false, false, false);
+#undef IGEMM_LAUNCH_F16
+  }
   else if (g.a_b16 && g.b_b16 && CAN_A16 && g.Cin % 64 == 0)
     hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, true, CAN_A16, true, CAN_A16>), grid, dim3(256), smem, st, A, Bp,
                        bias, C, C_act, stats, ws, g);
@@ -799,7 +804,7 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   g.b_b16 = (storage_flags & 16) != 0;
   g.f16 = (storage_flags & 32) != 0;
   g.cact_b16 = (storage_flags & 64) != 0;
-  if (g.f16 && (storage_flags & ~32)) return MMDYN_ERR_SHAPE;          // fp16 operands: fp32 storage on both sides
+  // (f16 alone: fp16 operands on fp32 storage; f16 with storage bits: those 16-bit tensors are IEEE half -- "fp16s")
   if (g.cact_b16 && (g.c_b16 || !C_act || splitk > 1 || (N & 1))) return MMDYN_ERR_SHAPE;
   if (storage_flags && (!bf16 || (g.c_b16 && splitk > 1) || (g.a_b16 && mode == MMDYN_IM2COL3))) return MMDYN_ERR_SHAPE;
   g.want_act_out = C_act != nullptr;
@@ -853,7 +858,8 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   hipStream_t st = (hipStream_t)stream;
   if (mode == MMDYN_IM2COL3) {     // the 3-channel layers have their own direct kernel (conv3.hip)
     const int rc = mmdyn_conv3_nt_try(A, Bp, bias, C, C_act, stats, G, Bg, Hi, Wi, Ho, Wo, N, ldc, act, splitk, bn_y,
-                                      bn_mean, bn_rstd, bn_gamma, bn_beta, g.c_b16, g.bny_b16, g.b_b16, st);
+                                      bn_mean, bn_rstd, bn_gamma, bn_beta, g.c_b16 << g.f16, g.bny_b16 << g.f16, g.b_b16 << g.f16,
+                                      st);
     if (rc != 1) return rc;
   }
   if (!bf16 && mode == MMDYN_TCONV_S2P1) {     // the 64 -> 32 channel up-sampling layer has a patch-resident kernel (tconv_patch.hip)

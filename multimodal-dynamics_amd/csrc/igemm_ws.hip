@@ -23,6 +23,7 @@
 #include "common.h"
 #include "igemm_geom.h"
 #include <cstdio>
+#include <type_traits>
 
 namespace {
 
@@ -49,8 +50,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds, unsi
 // is 64 channels = the same 128 bytes, the loaders and the LDS image are unchanged, and a 16-byte fragment read feeds ONE
 // v_mfma_f32_16x16x32_bf16 (lane (row l&15, quarter l>>4) holds k = 8*(l>>4) .. +7 of each 32-deep half of the K-step).
 typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));     // B16 == 2: the 16-bit storage is IEEE half ("fp16s")
 
-template <int MODE, int BM, int BN, int WM, int WN, int S, bool B16>
+template <int MODE, int BM, int BN, int WM, int WN, int S, int B16>
 __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_kernel(
     const float* __restrict__ A, const float* __restrict__ Bp, const float* __restrict__ bias, float* __restrict__ C,
     float* __restrict__ C_act, float* __restrict__ stats, float* __restrict__ ws, const IgemmGeom g, const unsigned a_bytes,
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
   constexpr int SLOT = (BM + BN) * RB;
   constexpr int TS = 16, MT = WM / TS, NT = WN / TS;
   constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
+  typedef typename std::conditional<B16 == 2, half_t, bf16_t>::type st16_t;
   constexpr int ESZ = B16 ? 2 : 4;                 // operand element size
   constexpr int KB = RB / ESZ;                     // channels per K-step (32 fp32 / 64 bf16)
 
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
           for (int nt = 0; nt < NT; ++nt)
           {
             const size_t yo = (size_t)max(ooff[mt][e], 0) + n0 + wn * WN + nt * TS + cl;
-            yv[mt][e][nt] = (B16 && g.bny_b16) ? ld1<bf16_t>(reinterpret_cast<const bf16_t*>(g.bn_y) + yo) : g.bn_y[yo];
+            yv[mt][e][nt] = (B16 && g.bny_b16) ? ld1<st16_t>(reinterpret_cast<const st16_t*>(g.bn_y) + yo) : g.bn_y[yo];
           }
     }
     const int fr = (cl >> 1) & 7;
@@ -246,7 +249,11 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+              if constexpr (B16 == 2)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8v, af[mt]),
+                                                                     __builtin_bit_cast(f16x8v, bf[nt]), acc[mt][nt], 0, 0, 0);
+              else
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
         } else {
           f32x4v af[MT], bf[NT];
 #pragma unroll
@@ -311,10 +318,10 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
                 // two adjacent columns live in adjacent lanes: the even lane stores both as one dword
                 const float vn = __shfl_down(v, 1, 64);
                 if (!(cl & 1)) {
-                  *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C) + (size_t)oo + col) = pack2_bf16(v, vn);
+                  *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C) + (size_t)oo + col) = pack2<st16_t>(v, vn);
                   if (g.want_act_out)
                     *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C_act) + (size_t)oo + col) =
-                        pack2_bf16(apply_act(v, g.act), apply_act(vn, g.act));
+                        pack2<st16_t>(apply_act(v, g.act), apply_act(vn, g.act));
                 }
               } else {
                 C[(size_t)oo + col] = v;
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
                     const float av = apply_act(v, g.act);
                     const float an = __shfl_down(av, 1, 64);
                     if (!(cl & 1))
-                      *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C_act) + (size_t)oo + col) = pack2_bf16(av, an);
+                      *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(C_act) + (size_t)oo + col) = pack2<st16_t>(av, an);
                   } else {
                     C_act[(size_t)oo + col] = apply_act(v, g.act);
                   }
@@ -425,7 +432,7 @@ static WsPick ws_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr, i
   return p;
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, int S, bool B16 = false>
+template <int MODE, int BM, int BN, int WM, int WN, int S, int B16 = 0>
 static int ws_launch(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
                      IgemmGeom g, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
   constexpr int NM = (BM / WM) * (BN / WN);
@@ -450,7 +457,7 @@ static int ws_launch(const float* A, const float* Bp, const float* bias, float* 
   MMDYN_LAUNCH_CHECK();
 }
 
-template <int MODE, bool B16>
+template <int MODE, int B16>
 static int ws_launch_mode(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
                           const IgemmGeom& g, WsPick p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
   if constexpr (!B16)
@@ -462,7 +469,7 @@ static int ws_launch_mode(const float* A, const float* Bp, const float* bias, fl
   return ws_launch<MODE, 64, 64, 32, 32, 3, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
 }
 
-template <bool B16>
+template <int B16>
 static int ws_dispatch(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
                        const IgemmGeom& g, WsPick p, hipStream_t st) {
   const int esz = B16 ? 2 : 4;
@@ -488,12 +495,14 @@ int mmdyn_igemm_ws_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, 
   return p.bm ? ncls * ceil_div(Bg * Hr * Wr, p.bm) : 0;
 }
 
-// bf16_ops: the launch runs on the bf16 matrix cores; served here only when BOTH operands are bf16 in HBM (and not fp16 mode)
+// bf16_ops: the launch runs on the 16-bit matrix cores; served here only when BOTH operands are 16-bit in HBM (bf16, or IEEE
+// half when g.f16 is set too)
 int mmdyn_igemm_ws_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
                        const IgemmGeom& g, bool bf16_ops, hipStream_t st) {
-  if (bf16_ops && (g.f16 || !g.a_b16 || !g.b_b16)) return 1;
+  if (bf16_ops && (!g.a_b16 || !g.b_b16)) return 1;
   const WsPick p = ws_pick(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Hr, g.Wr, g.Cin, g.N, g.nclasses, g.splitk, bf16_ops);
   if (!p.bm) return 1;
-  if (bf16_ops) return ws_dispatch<true>(A, Bp, bias, C, C_act, stats, ws, g, p, st);
-  return ws_dispatch<false>(A, Bp, bias, C, C_act, stats, ws, g, p, st);
+  if (bf16_ops && g.f16) return ws_dispatch<2>(A, Bp, bias, C, C_act, stats, ws, g, p, st);
+  if (bf16_ops) return ws_dispatch<1>(A, Bp, bias, C, C_act, stats, ws, g, p, st);
+  return ws_dispatch<0>(A, Bp, bias, C, C_act, stats, ws, g, p, st);
 }

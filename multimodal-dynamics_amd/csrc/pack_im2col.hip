@@ -235,7 +235,9 @@ __device__ __forceinline__ void pack_plan_entry(const mmdyn_pack_entry& e, float
 __global__ __launch_bounds__(256) void pack_plan_kernel(const mmdyn_pack_entry* __restrict__ plan) {
   __shared__ __attribute__((aligned(16))) float lds[PACK_LDS_FLOATS];
   const mmdyn_pack_entry e = plan[blockIdx.y];
-  if (e.dst_bf16)
+  if (e.dst_bf16 == 2)            // (2: IEEE half, the fp16-storage mode)
+    pack_plan_entry<half_t>(e, lds);
+  else if (e.dst_bf16)
     pack_plan_entry<bf16_t>(e, lds);
   else
     pack_plan_entry<float>(e, lds);
@@ -356,11 +358,15 @@ extern "C" int mmdyn_pack_conv_weight(const float* Wc, float* P, int d0, int d1,
   MMDYN_LAUNCH_CHECK();
 }
 
-extern "C" int mmdyn_pack_conv_weight_b16(const float* Wc, void* P, int d0, int d1, int swap, void* stream) {
+extern "C" int mmdyn_pack_conv_weight_b16(const float* Wc, void* P, int d0, int d1, int swap, int half, void* stream) {
   if (!Wc || !P) return MMDYN_ERR_NULL;
   if (d0 <= 0 || d1 <= 0) return MMDYN_ERR_SHAPE;
-  hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, dim3(ew_grid((int64_t)16 * d0 * d1)), dim3(256), 0,
-                     (hipStream_t)stream, Wc, (bf16_t*)P, d0, d1, swap);
+  if (half)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<half_t>, dim3(ew_grid((int64_t)16 * d0 * d1)), dim3(256), 0,
+                       (hipStream_t)stream, Wc, (half_t*)P, d0, d1, swap);
+  else
+    hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, dim3(ew_grid((int64_t)16 * d0 * d1)), dim3(256), 0,
+                       (hipStream_t)stream, Wc, (bf16_t*)P, d0, d1, swap);
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -383,11 +389,15 @@ extern "C" int mmdyn_repack2d_ld(const float* in, float* out, int rows_in, int c
 }
 
 extern "C" int mmdyn_repack2d_ld_b16(const float* in, void* out, int rows_in, int cols_in, int rows_out, int cols_out,
-                                     int ld_out, int mode, void* stream) {
+                                     int ld_out, int mode, int half, void* stream) {
   if (!in || !out) return MMDYN_ERR_NULL;
   if (mode < 0 || mode > 5 || rows_out <= 0 || cols_out <= 0 || ld_out < cols_out) return MMDYN_ERR_SHAPE;
-  hipLaunchKernelGGL(repack2d_ld_kernel<bf16_t>, dim3(ew_grid((int64_t)rows_out * cols_out)), dim3(256), 0,
-                     (hipStream_t)stream, in, (bf16_t*)out, rows_in, cols_in, rows_out, cols_out, ld_out, mode);
+  if (half)
+    hipLaunchKernelGGL(repack2d_ld_kernel<half_t>, dim3(ew_grid((int64_t)rows_out * cols_out)), dim3(256), 0,
+                       (hipStream_t)stream, in, (half_t*)out, rows_in, cols_in, rows_out, cols_out, ld_out, mode);
+  else
+    hipLaunchKernelGGL(repack2d_ld_kernel<bf16_t>, dim3(ew_grid((int64_t)rows_out * cols_out)), dim3(256), 0,
+                       (hipStream_t)stream, in, (bf16_t*)out, rows_in, cols_in, rows_out, cols_out, ld_out, mode);
   MMDYN_LAUNCH_CHECK();
 }
 

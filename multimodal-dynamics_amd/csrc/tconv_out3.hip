@@ -105,13 +105,16 @@ extern "C" int mmdyn_tconv_out3_fwd(const float* a, const float* w, float* out, 
 }
 
 /* bf16 activation storage: the input activations are bf16, weights and logits stay fp32 */
-extern "C" int mmdyn_tconv_out3_fwd_b16(const uint16_t* a, const float* w, float* out, int Bt, int Hi, int Wi,
+extern "C" int mmdyn_tconv_out3_fwd_b16(const uint16_t* a, const float* w, float* out, int Bt, int Hi, int Wi, int half,
                                         void* stream) {
   if (!a || !w || !out) return MMDYN_ERR_NULL;
   if (Bt <= 0 || Hi % TI || Wi % TI || Bt > 65535) return MMDYN_ERR_SHAPE;
   if ((int64_t)Bt * Hi * Wi * 32 >= (1LL << 31)) return MMDYN_ERR_RANGE;
   dim3 grid((Hi / TI) * (Wi / TI), Bt);
   size_t smem = (size_t)TH * TH * PIX_LD * sizeof(float);
-  hipLaunchKernelGGL(tconv_out3_kernel<bf16_t>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi);
+  if (half)
+    hipLaunchKernelGGL(tconv_out3_kernel<half_t>, grid, dim3(256), smem, (hipStream_t)stream, (const half_t*)a, w, out, Hi, Wi);
+  else
+    hipLaunchKernelGGL(tconv_out3_kernel<bf16_t>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi);
   MMDYN_LAUNCH_CHECK();
 }

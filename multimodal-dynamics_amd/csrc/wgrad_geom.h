@@ -5,7 +5,7 @@
 
 struct WgradGeom {
   int d_b16, g_b16;  // bf16 activation storage (bf16 matrix-core variants only): D / Gt are bf16 in HBM
-  int f16;           // 16-bit matrix-core mode with fp16 instead of bf16 operands (fp32 storage only)
+  int f16;           // the 16-bit format is IEEE half instead of bf16: operands, and D / Gt where d_b16 / g_b16 say 16-bit
   int mode;  // MMDYN_DENSE or MMDYN_CONV
   int rows;  // Bt*Hr*Wr
   int Hr, Wr, Cd;

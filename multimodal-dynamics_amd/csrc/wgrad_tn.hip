@@ -44,6 +44,7 @@ __device__ __forceinline__ s16x4 pack4_bf16(float a, float b, float c, float d) 
 // ST: operand storage, always a compile-time constant (a run-time test inside the fetch puts every load in its own
 // branch and the loads then wait for one another): 0 = D and Gt fp32, 1 = both bf16, 2 = D bf16 / Gt fp32,
 // 3 = D fp32 / Gt bf16, 4 = both fp32 in HBM, fragments rounded to fp16 (v_mfma_f32_32x32x8_f16: BASELINE configs[4])
+// 5 / 6 / 7 = as 1 / 2 / 3 with IEEE half in place of bf16, in HBM and on the matrix cores (precision "fp16s")
 // MODE (DENSE / CONV / IM2COL3) is a template parameter: with a run-time mode test inside the fetch each gathered load
 // sat in its own branch, and because the two sides of the branch write the same registers the compiler put
 // s_waitcnt vmcnt(0) in front of every one of them -- five serial memory round trips per K-step instead of one
@@ -99,6 +100,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
       const bool ok = row < row_end;
       if constexpr (BF16 && (ST == 1 || ST == 2))
         rd[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
+      else if constexpr (BF16 && (ST == 5 || ST == 6))
+        rd[i] = ld4<half_t>(reinterpret_cast<const half_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       else
         rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       okd = ok ? (okd | (1u << i)) : (okd & ~(1u << i));
@@ -140,6 +143,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
       }
       if constexpr (BF16 && (ST == 1 || ST == 3))
         rg[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
+      else if constexpr (BF16 && (ST == 5 || ST == 7))
+        rg[i] = ld4<half_t>(reinterpret_cast<const half_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       else
         rg[i] = *reinterpret_cast<const f32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       okg = ok ? (okg | (0xFu << (4 * i))) : (okg & ~(0xFu << (4 * i)));
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
       if constexpr (BF16) {
 #pragma unroll
         for (int r8 = wk * 2 * KPW; r8 < (wk + 1) * 2 * KPW; r8 += 8) {     // 8 rows per bf16 MFMA: lane half h -> 4 rows
-          if constexpr (ST == 4) {
+          if constexpr (ST >= 4) {
             f16x4 pa[DT], pb[GT];
 #pragma unroll
             for (int a = 0; a < DT; ++a) {
@@ -261,11 +266,20 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
 // MFMA) this is 4x fewer LDS cycles per k, no conversion VALU work and half the MFMA issues.
 // Row stride of a tile: bytes = 64 (mod 256), so the four rows of a transposed read (64 B each) fill all 64 banks.
 typedef __bf16 wb16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wf16x8 __attribute__((ext_vector_type(8)));
+typedef float wacc16_t __attribute__((ext_vector_type(16)));
+// H16: the 16-bit operands are IEEE half instead of bf16 (precision "fp16s") -- same bytes, same data path, other MFMA
+template <bool H16> __device__ __forceinline__ wacc16_t mfma16(wb16x8 a, wb16x8 b, wacc16_t c) {
+  if constexpr (H16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, a), __builtin_bit_cast(wf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 template <int BX> struct b16_ld { static constexpr int v = (BX == 32) ? 32 : BX + 32; };   // in elements
 
 // (waves_per_eu: without the hint the register allocator aims at eight waves per SIMD and spills the prefetched
 //  granules to scratch right after loading them)
-template <int MODE, int BD, int BG, int WD, int WG, int WK>
+template <int MODE, int BD, int BG, int WD, int WG, int WK, bool H16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void wgrad_b16_kernel(const bf16_t* __restrict__ D, const bf16_t* __restrict__ Gt,
                                                         float* __restrict__ partial, const WgradGeom g) {
   constexpr int DT = WD / 32, GT = WG / 32;
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         for (int a = 0; a < DT; ++a)
 #pragma unroll
           for (int b = 0; b < GT; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a], pb[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = mfma16<H16>(pa[a], pb[b], acc[a][b]);
       }
       __builtin_amdgcn_sched_barrier(0);   // the masking selects of lds_store (which wait for the loads) stay behind the MFMAs
       __syncthreads();
@@ -426,7 +440,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 // All-bf16 four-taps-per-block variant (narrow channel tiles of the k4 convolutions, see wgrad_tn4_kernel below for the
 // idea): the four waves own the four kw taps of kernel row kh = blockIdx.y and share one D tile; each wave stages its own
 // tap's gathered G tile.  Operand path as in wgrad_b16_kernel (16-byte granules, bf16 LDS tiles, transposing reads).
-template <int BD, int BG>
+template <int BD, int BG, bool H16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void wgrad_b16_tn4_kernel(
     const bf16_t* __restrict__ D, const bf16_t* __restrict__ Gt, float* __restrict__ partial, const WgradGeom g) {
   constexpr int DT = BD / 32, GT = BG / 32;
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         for (int a = 0; a < DT; ++a)
 #pragma unroll
           for (int b = 0; b < GT; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a], pb[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = mfma16<H16>(pa[a], pb[b], acc[a][b]);
       }
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
@@ -608,6 +622,8 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       const bool ok = (D_ALL || idx < RK * DV) & (row < row_end);
       if constexpr (BF16 && (ST == 1 || ST == 2))
         rd[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
+      else if constexpr (BF16 && (ST == 5 || ST == 6))
+        rd[i] = ld4<half_t>(reinterpret_cast<const half_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       else
         rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       okd = ok ? (okd | (1u << i)) : (okd & ~(1u << i));
@@ -625,6 +641,8 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       const int pix = (bb * g.Hi + y) * g.Wi + x;
       if constexpr (BF16 && (ST == 1 || ST == 3))
         rg[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
+      else if constexpr (BF16 && (ST == 5 || ST == 7))
+        rg[i] = ld4<half_t>(reinterpret_cast<const half_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       else
         rg[i] = *reinterpret_cast<const f32x4*>(Gt + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       okg = ok ? (okg | (1u << i)) : (okg & ~(1u << i));
@@ -659,7 +677,7 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       if constexpr (BF16) {
 #pragma unroll
         for (int r8 = 0; r8 < RK; r8 += 8) {
-          if constexpr (ST == 4) {
+          if constexpr (ST >= 4) {
             f16x4 pa[DT], pb[GT];
 #pragma unroll
             for (int a = 0; a < DT; ++a) {
@@ -732,9 +750,16 @@ static int launch4(const float* D, const float* Gt, float* partial, WgradGeom g,
   g.rows_per_chunk = ceil_div(rpc, RK) * RK;
   dim3 grid((g.Cd / BD) * (g.Cg / BG), 4, g.chunks);
   size_t smem = (size_t)RK * (BD + 4 * BG) * sizeof(float);
-  if (bf16 && g.d_b16 && g.g_b16)      // both operands bf16: transposing-LDS-read variant
-    hipLaunchKernelGGL((wgrad_b16_tn4_kernel<BD, BG>), grid, dim3(256), 0, st, reinterpret_cast<const bf16_t*>(D),
+  if (bf16 && g.d_b16 && g.g_b16 && g.f16)      // both operands IEEE half
+    hipLaunchKernelGGL((wgrad_b16_tn4_kernel<BD, BG, true>), grid, dim3(256), 0, st, reinterpret_cast<const bf16_t*>(D),
                        reinterpret_cast<const bf16_t*>(Gt), partial, g);
+  else if (bf16 && g.d_b16 && g.g_b16)      // both operands bf16: transposing-LDS-read variant
+    hipLaunchKernelGGL((wgrad_b16_tn4_kernel<BD, BG, false>), grid, dim3(256), 0, st, reinterpret_cast<const bf16_t*>(D),
+                       reinterpret_cast<const bf16_t*>(Gt), partial, g);
+  else if (bf16 && g.d_b16 && g.f16)
+    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 6>), grid, dim3(256), smem, st, D, Gt, partial, g);
+  else if (bf16 && g.g_b16 && g.f16)
+    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 7>), grid, dim3(256), smem, st, D, Gt, partial, g);
   else if (bf16 && g.d_b16)
     hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, true, 2>), grid, dim3(256), smem, st, D, Gt, partial, g);
   else if (bf16 && g.g_b16)
@@ -836,12 +861,17 @@ static int launch_b16(const float* D, const float* Gt, float* partial, WgradGeom
   int rpc = ceil_div(g.rows, zblocks);
   g.rows_per_chunk = ceil_div(rpc, RK) * RK;
   dim3 grid((unsigned)((g.Cd / BD) * (g.Cg / BG) * g.ntaps) * (unsigned)((zblocks + 7) / 8 * 8));
-  if (g.mode == MMDYN_CONV)
-    hipLaunchKernelGGL((wgrad_b16_kernel<MMDYN_CONV, BD, BG, WD, WG, WK>), grid, dim3(256), 0, st,
-                       reinterpret_cast<const bf16_t*>(D), reinterpret_cast<const bf16_t*>(Gt), partial, g);
-  else
-    hipLaunchKernelGGL((wgrad_b16_kernel<MMDYN_DENSE, BD, BG, WD, WG, WK>), grid, dim3(256), 0, st,
-                       reinterpret_cast<const bf16_t*>(D), reinterpret_cast<const bf16_t*>(Gt), partial, g);
+#define WGRAD_B16(M, H)                                                                                    \
+  hipLaunchKernelGGL((wgrad_b16_kernel<M, BD, BG, WD, WG, WK, H>), grid, dim3(256), 0, st,                 \
+                     reinterpret_cast<const bf16_t*>(D), reinterpret_cast<const bf16_t*>(Gt), partial, g)
+  if (g.mode == MMDYN_CONV) {
+    if (g.f16) WGRAD_B16(MMDYN_CONV, true);
+    else WGRAD_B16(MMDYN_CONV, false);
+  } else {
+    if (g.f16) WGRAD_B16(MMDYN_DENSE, true);
+    else WGRAD_B16(MMDYN_DENSE, false);
+  }
+#undef WGRAD_B16
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -856,7 +886,10 @@ static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, 
   hipLaunchKernelGGL((wgrad_tn_kernel<M, BD, BG, WD, WG, WK, BF, ST_>), grid, dim3(256), smem, st, D, Gt, partial, g)
 #define WGRAD_MODE(M)                                                  \
   do {                                                                 \
-    if (bf16 && g.d_b16 && g.g_b16) WGRAD_LAUNCH(M, true, 1);          \
+    if (bf16 && g.f16 && g.d_b16 && g.g_b16) WGRAD_LAUNCH(M, true, 5); \
+    else if (bf16 && g.f16 && g.d_b16) WGRAD_LAUNCH(M, true, 6);       \
+    else if (bf16 && g.f16 && g.g_b16) WGRAD_LAUNCH(M, true, 7);       \
+    else if (bf16 && g.d_b16 && g.g_b16) WGRAD_LAUNCH(M, true, 1);     \
     else if (bf16 && g.d_b16) WGRAD_LAUNCH(M, true, 2);                \
     else if (bf16 && g.g_b16) WGRAD_LAUNCH(M, true, 3);                \
     else if (bf16 && g.f16) WGRAD_LAUNCH(M, true, 4);                  \
@@ -885,7 +918,6 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
   g.d_b16 = (storage_flags & 2) != 0;
   g.g_b16 = (storage_flags & 4) != 0;
   g.f16 = (storage_flags & 32) != 0;
-  if (g.f16 && (storage_flags & ~32)) return MMDYN_ERR_SHAPE;
   if (storage_flags && (!bf16 || (g.g_b16 && mode == MMDYN_IM2COL3))) return MMDYN_ERR_SHAPE;
   g.mode = mode;
   const int64_t rows = (int64_t)Bt * Hr * Wr;
@@ -904,7 +936,7 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
   g.chunks = chunks;
   hipStream_t st = (hipStream_t)stream;
   if (mode == MMDYN_IM2COL3) {     // the 3-channel layers have their own direct kernel (conv3.hip)
-    const int rc = mmdyn_conv3_wgrad_try(D, Gt, partial, Bt, Hr, Wr, Cd, Hi, Wi, Cg, chunks, g.d_b16, st);
+    const int rc = mmdyn_conv3_wgrad_try(D, Gt, partial, Bt, Hr, Wr, Cd, Hi, Wi, Cg, chunks, g.d_b16 << g.f16, st);
     if (rc != 1) return rc;
   }
   const bool d64 = (Cd % 64 == 0), g64 = (Cg % 64 == 0);
@@ -946,7 +978,8 @@ extern "C" int mmdyn_wgrad_tn(const float* D, const float* Gt, float* partial, i
   return wgrad_entry(D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks, stream, false);
 }
 
-/* mixed storage: flags bit 0 = bf16 matrix cores (required), bit 1 = D is bf16 in HBM, bit 2 = Gt is bf16 */
+/* mixed storage: flags bit 0 = 16-bit matrix cores (required), bit 1 = D is 16-bit in HBM, bit 2 = Gt is 16-bit,
+ * bit 5 = the 16-bit format is IEEE half instead of bf16 (storage and matrix cores) */
 extern "C" int mmdyn_wgrad_tn_mx(const void* D, const void* Gt, float* partial, int mode, int Bt, int Hr, int Wr,
                                  int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks, int flags,
                                  void* stream) {

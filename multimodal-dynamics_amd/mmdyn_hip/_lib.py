@@ -44,8 +44,8 @@ _SIGNATURES = {
     "mmdyn_pack_conv_weight": "pp" + "iii" + "p",
     "mmdyn_repack2d": "pp" + "iiiii" + "p",
     "mmdyn_repack2d_ld": "pp" + "iiiiii" + "p",
-    "mmdyn_pack_conv_weight_b16": "pp" + "iii" + "p",
-    "mmdyn_repack2d_ld_b16": "pp" + "iiiiii" + "p",
+    "mmdyn_pack_conv_weight_b16": "pp" + "iiii" + "p",
+    "mmdyn_repack2d_ld_b16": "pp" + "iiiiiii" + "p",
     "mmdyn_pack_plan": "p" + "i" + "p",
     "mmdyn_im2col_nchw3": "pp" + "iii" + "p",
     "mmdyn_col2im_k4": "pp" + "iiiiiiiiii" + "p",
@@ -87,11 +87,11 @@ _SIGNATURES = {
     "mmdyn_sgd_step": "ppp" + "l" + "ffff" + "i" + "p",
     "mmdyn_igemm_nt_mx": "pppppppppppp" + "iiiiiiiiiiiiii" + "i" + "p",
     "mmdyn_wgrad_tn_mx": "ppp" + "iiiiiiiiiii" + "i" + "p",
-    "mmdyn_bn_swish_fwd_b16": "pppppp" + "iii" + "p",
-    "mmdyn_bn_swish_bwd_reduce_b16": "ppppppp" + "iii" + "p",
-    "mmdyn_bn_swish_bwd_apply_b16": "pppppppp" + "iiii" + "p",
-    "mmdyn_act_bwd_b16": "ppp" + "l" + "i" + "p",
-    "mmdyn_tconv_out3_fwd_b16": "ppp" + "iii" + "p",
+    "mmdyn_bn_swish_fwd_b16": "pppppp" + "iiii" + "p",
+    "mmdyn_bn_swish_bwd_reduce_b16": "ppppppp" + "iiii" + "p",
+    "mmdyn_bn_swish_bwd_apply_b16": "pppppppp" + "iiiii" + "p",
+    "mmdyn_act_bwd_b16": "ppp" + "l" + "ii" + "p",
+    "mmdyn_tconv_out3_fwd_b16": "ppp" + "iiii" + "p",
     "mmdyn_resize_ksize": "ii",
     "mmdyn_resize_plan": "ii" + "pp",
     "mmdyn_resize_u8_to_chw_f32": "ppp" + "iiiii" + "pppp" + "p",

@@ -25,7 +25,18 @@ from .models.shapes import DROPOUT_P
 
 SUBSETS_POSE = [(1, 1, 0), (1, 0, 0), (0, 1, 0), (1, 1, 1), (1, 0, 1), (0, 1, 1), (0, 0, 1)]
 SUBSETS_NOPOSE = SUBSETS_POSE[:3]
-PRECISIONS = ("fp32", "bf16", "bf16s", "fp16")
+PRECISIONS = ("fp32", "bf16", "bf16s", "fp16", "fp16s")
+
+
+def act_dtype(precision):
+    """Storage type of the convolution-level activations (and their gradients) of a precision mode."""
+    return {"bf16s": torch.bfloat16, "fp16s": torch.float16}.get(precision, torch.float32)
+
+
+def w_dtype(precision):
+    """Type the packed GEMM operands (weights) are written in: the matrix cores' operand type where the storage is 16-bit
+    anyway ("bf16" packs bf16 too: the kernels round fp32 weights to bf16 on their way in, packing does it once)."""
+    return {"bf16": torch.bfloat16, "bf16s": torch.bfloat16, "fp16s": torch.float16}.get(precision, torch.float32)
 
 _PREFIX_ORDER = ["pose_decoder", "visual_decoder", "tactile_decoder",         # bucket 0: ready first
                  "heads", "pose_encoder", "encoder_fc",                      # bucket 1: heads, pose encoder and the image
@@ -149,8 +160,8 @@ def _with_precision(fn):
         prev, prev_sync, prev_act, prev_w = getattr(ops.B, "precision", "fp32"), layers.SYNC, layers.ACT_DTYPE, layers.W_DTYPE
         ops.B.precision = self.precision
         layers.SYNC = self._sync
-        layers.ACT_DTYPE = torch.bfloat16 if self.precision == "bf16s" else torch.float32
-        layers.W_DTYPE = torch.float32 if self.precision in ("fp32", "fp16") else torch.bfloat16
+        layers.ACT_DTYPE = act_dtype(self.precision)
+        layers.W_DTYPE = w_dtype(self.precision)
         try:
             return fn(self, *a, **k)
         finally:
@@ -172,8 +183,8 @@ class MVAEStep:
         if precision not in PRECISIONS:
             raise ValueError("precision must be 'fp32' (the reference's arithmetic), 'bf16s' (bf16 activation storage + "
                              "bf16 matrix cores, fp32 accumulate / master weights: BASELINE configs[2]), 'bf16' (bf16 matrix-core "
-                             "operands only, fp32 storage) or 'fp16' (fp16 matrix-core operands, fp32 accumulate / storage: "
-                             "BASELINE configs[4])")
+                             "operands only, fp32 storage), 'fp16' (fp16 matrix-core operands, fp32 accumulate / storage: "
+                             "BASELINE configs[4]) or 'fp16s' (fp16 + fp16 activation storage)")
         self.precision = precision
         # Loss scale of the fp16 modes: every loss gradient entering the backward (BCE / MSE / KL) is multiplied by
         # 4 * B and Adam divides it out again (the backward is linear in the loss gradient, BatchNorm included).  Unscaled,
@@ -253,7 +264,7 @@ class MVAEStep:
             # what the encoder forward reads goes first (critical path); the transposed / decoder packs are launched
             # next to the encoder phase (run_late) and are ready long before the decoders start
             self.plan = layers.PackPlan(specs, early=("W1p", "W2k", "W3k", "W4k", "W5k", "W6k", "Wf", "Wh", "bh"),
-                                        w_dtype=torch.float32 if precision in ("fp32", "fp16") else torch.bfloat16)
+                                        w_dtype=w_dtype(precision))
         self._capturing = False
         self._graph = None
         self._static_mask = self._static_cond = None
@@ -777,9 +788,9 @@ class MVAEInference:
         from .models.vae import NoiseSource
         if getattr(model, "conditional", False):
             raise NotImplementedError("mmdyn_hip: MVAEInference is built for the unconditional cnn-mvae")
-        if precision not in ("fp32", "bf16", "bf16s", "fp16"):
-            raise ValueError("precision must be 'fp32', 'bf16' / 'fp16' (matrix-core operands) or 'bf16s' (+ bf16 activation "
-                             "storage)")
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be 'fp32', 'bf16' / 'fp16' (matrix-core operands) or 'bf16s' / 'fp16s' (+ 16-bit "
+                             "activation storage)")
         self.model, self.precision, self.use_graph = model, precision, use_graph
         self.use_pose = bool(model._use_pose)
         self.L = model.latent_size
@@ -788,7 +799,7 @@ class MVAEInference:
         self.noise = NoiseSource(seed)
         self._sync = None
         self._graphs = {}
-        self._w_dtype = torch.float32 if precision in ("fp32", "fp16") else torch.bfloat16     # packed GEMM operands
+        self._w_dtype = w_dtype(precision)     # packed GEMM operands
         self.refresh()
 
     def _P(self, name, keys):
@@ -884,7 +895,7 @@ class MVAEInference:
     def _run(self, key, fn, static_inputs, new_inputs):
         prev, prev_act, prev_w = getattr(ops.B, "precision", "fp32"), layers.ACT_DTYPE, layers.W_DTYPE
         ops.B.precision = self.precision
-        layers.ACT_DTYPE = torch.bfloat16 if self.precision == "bf16s" else torch.float32
+        layers.ACT_DTYPE = act_dtype(self.precision)
         layers.W_DTYPE = self._w_dtype
         try:
             if not (self.use_graph and self.dev.type == "cuda"):

@@ -407,7 +407,7 @@ class PackPlan:
                     r0, c0, ld = s["part"] if s["part"] is not None else (0, 0, s["cout"])
                     e.dst = dst.data_ptr() + dst.element_size() * (r0 * ld + c0)
                     e.rows_out, e.cols_out, e.ld_out = s["rout"], s["cout"], ld
-                e.dst_bf16 = int(dst.dtype == torch.bfloat16)
+                e.dst_bf16 = {torch.bfloat16: 1, torch.float16: 2}.get(dst.dtype, 0)
                 entries.append(e)
         self.n = len(entries)
         arr = (PackEntry * self.n)(*entries)

@@ -34,12 +34,27 @@ def _ptr(t, dtype=torch.float32):
 
 
 def _aptr(t):
-    """Pointer of an ACTIVATION tensor: fp32, or bf16 in the bf16-storage mode.  Returns (pointer, is_bf16)."""
+    """Pointer of an ACTIVATION (or packed-weight) tensor: fp32, or 16-bit in the storage modes.  Returns (pointer, fmt):
+    fmt 0 = fp32, 1 = bf16 ("bf16s"), 2 = IEEE half ("fp16s") -- truthy exactly for the 16-bit formats."""
     if t is None:
-        return None, False
+        return None, 0
     if t.dtype == torch.bfloat16:
-        return _ptr(t, torch.bfloat16), True
-    return _ptr(t), False
+        return _ptr(t, torch.bfloat16), 1
+    if t.dtype == torch.float16:
+        return _ptr(t, torch.float16), 2
+    return _ptr(t), 0
+
+
+def _is16(t):
+    return t.dtype in (torch.bfloat16, torch.float16)
+
+
+def _half(*fmts):
+    """1 when the 16-bit tensors of one call are IEEE half, 0 when bf16 (or none); the two never mix in one call."""
+    kinds = {f for f in fmts if f}
+    if len(kinds) > 1:
+        raise TypeError("mmdyn_hip: bf16 and fp16 tensors in one call")
+    return int(2 in kinds)
 
 
 def _stream():
@@ -62,7 +77,8 @@ class HipBackend:
         self.force_ticket = False
         # "fp32": v_mfma_f32_32x32x2_f32 (the reference's arithmetic, the default and the BASELINE configs[1] path);
         # "bf16": operands rounded to bf16 on their way into the matrix cores, fp32 accumulate (configs[2]);
-        # "fp16": the same with IEEE-half operands (configs[4]); "bf16s": bf16 + bf16 activation storage
+        # "fp16": the same with IEEE-half operands (configs[4]); "bf16s": bf16 + bf16 activation storage;
+        # "fp16s": fp16 + fp16 activation storage
         self.precision = "fp32"
 
     TICKET_SLOTS, TICKET_STRIDE = 4096, 16             # one 64-byte line per slot
@@ -105,21 +121,31 @@ class HipBackend:
         return r
 
     # ---- GEMMs ----
+    def _mx(self, *fmts):
+        """Base flags of the mixed-storage GEMM entry points: bit 0 (16-bit matrix cores), bit 5 when the 16-bit tensors of
+        the call are IEEE half.  The storage format has to be the precision mode's: bf16 tensors with "bf16" / "bf16s",
+        half tensors with "fp16s"."""
+        half = _half(*fmts)
+        ok = ("fp16s",) if half else ("bf16", "bf16s")
+        if self.precision not in ok:
+            raise ValueError(f"mmdyn_hip: {'fp16' if half else 'bf16'} tensors need precision {' / '.join(ok)} "
+                             f"(current: {self.precision})")
+        return 1 | (32 if half else 0)
+
     def igemm_nt(self, A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride,
                  offset, act, splitk):
         (pa, a16), (pc, c16), (pca, ca16), (pb, b16) = _aptr(A), _aptr(C), _aptr(C_act), _aptr(Bp)
         if a16 or c16 or ca16 or b16:      # bf16 activation storage / bf16 packed weights: the mixed-storage entry point
             mixed_out = C_act is not None and ca16 and not c16       # fp32 pre-activation + bf16 activated output
-            if self.precision == "fp32" or ((c16 or mixed_out) and splitk != 1) or (C_act is not None and c16 and not ca16):
-                raise ValueError("mmdyn_hip: bf16 tensors need a bf16 precision mode, no split-K into a "
-                                 "bf16 output, and a bf16 C only with a bf16 C_act")
+            if ((c16 or mixed_out) and splitk != 1) or (C_act is not None and c16 and not ca16):
+                raise ValueError("mmdyn_hip: no split-K into a 16-bit output, and a 16-bit C only with a 16-bit C_act")
             check(self.lib.mmdyn_igemm_nt_mx(pa, pb, _ptr(bias), pc, pca, _ptr(stats), _ptr(ws), None, None, None,
                                              None, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act,
-                                             splitk, 1 | (2 if a16 else 0) | (4 if c16 else 0) | (16 if b16 else 0) |
-                                             (64 if mixed_out else 0), _stream()), "mmdyn_igemm_nt_mx")
+                                             splitk, self._mx(a16, c16, ca16, b16) | (2 if a16 else 0) | (4 if c16 else 0) |
+                                             (16 if b16 else 0) | (64 if mixed_out else 0), _stream()), "mmdyn_igemm_nt_mx")
             return
-        fn = {"fp32": self.lib.mmdyn_igemm_nt, "fp16": self.lib.mmdyn_igemm_nt_f16}.get(self.precision,
-                                                                                         self.lib.mmdyn_igemm_nt_bf16)
+        fn = {"fp32": self.lib.mmdyn_igemm_nt, "fp16": self.lib.mmdyn_igemm_nt_f16,
+              "fp16s": self.lib.mmdyn_igemm_nt_f16}.get(self.precision, self.lib.mmdyn_igemm_nt_bf16)
         check(fn(pa, _ptr(Bp), _ptr(bias), pc, pca, _ptr(stats), _ptr(ws),
                  mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, _stream()), "mmdyn_igemm_nt")
 
@@ -127,24 +153,22 @@ class HipBackend:
                           stride, offset):
         (pa, a16), (pc, c16), (py, y16), (pb, b16) = _aptr(A), _aptr(C), _aptr(y), _aptr(Bp)
         if a16 or c16 or y16 or b16:
-            if self.precision == "fp32":
-                raise ValueError("mmdyn_hip: bf16 tensors need a bf16 precision mode")
             check(self.lib.mmdyn_igemm_nt_mx(pa, pb, None, pc, None, _ptr(stats), None, py, _ptr(mean), _ptr(rstd),
                                              _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride,
-                                             offset, ACT_NONE, 1, 1 | (2 if a16 else 0) | (4 if c16 else 0) |
+                                             offset, ACT_NONE, 1, self._mx(a16, c16, y16, b16) | (2 if a16 else 0) | (4 if c16 else 0) |
                                              (8 if y16 else 0) | (16 if b16 else 0), _stream()), "mmdyn_igemm_nt_mx")
             return
         check(self.lib.mmdyn_igemm_nt_dgrad_bn(pa, _ptr(Bp), pc, _ptr(stats), py, _ptr(mean), _ptr(rstd),
                                                _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride,
-                                               offset, {"fp32": 0, "fp16": 2}.get(self.precision, 1), _stream()),
+                                               offset, {"fp32": 0, "fp16": 2, "fp16s": 2}.get(self.precision, 1), _stream()),
               "mmdyn_igemm_nt_dgrad_bn")
 
     def igemm_nt_dgrad_act(self, A, Bp, C, u, act, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset):
         """C = (A x Bp) * act'(u): input-gradient GEMM with the activation backward in its epilogue."""
         (pa, a16), (pc, c16), (pu, u16), (pb, b16) = _aptr(A), _aptr(C), _aptr(u), _aptr(Bp)
-        if (a16 or c16 or u16 or b16) and self.precision in ("fp32", "fp16"):
-            raise ValueError("mmdyn_hip: bf16 tensors need a bf16 precision mode")
-        flags = {"fp32": 0, "fp16": 32}.get(self.precision, 1)
+        flags = {"fp32": 0, "fp16": 32, "fp16s": 32}.get(self.precision, 1)
+        if a16 or c16 or u16 or b16:
+            flags = self._mx(a16, c16, u16, b16)
         flags |= (2 if a16 else 0) | (4 if c16 else 0) | (8 if u16 else 0) | (16 if b16 else 0)
         check(self.lib.mmdyn_igemm_nt_dgrad_act(pa, pb, pc, pu, int(act), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset,
                                                 flags, _stream()), "mmdyn_igemm_nt_dgrad_act")
@@ -156,13 +180,12 @@ class HipBackend:
     def wgrad_tn(self, D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks):
         (pd, d16), (pg, g16) = _aptr(D), _aptr(Gt)
         if d16 or g16:
-            if self.precision == "fp32":
-                raise ValueError("mmdyn_hip: bf16 activation tensors need a bf16 precision mode")
             check(self.lib.mmdyn_wgrad_tn_mx(pd, pg, _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks,
-                                             1 | (2 if d16 else 0) | (4 if g16 else 0), _stream()), "mmdyn_wgrad_tn_mx")
+                                             self._mx(d16, g16) | (2 if d16 else 0) | (4 if g16 else 0), _stream()),
+                  "mmdyn_wgrad_tn_mx")
             return
-        fn = {"fp32": self.lib.mmdyn_wgrad_tn, "fp16": self.lib.mmdyn_wgrad_tn_f16}.get(self.precision,
-                                                                                         self.lib.mmdyn_wgrad_tn_bf16)
+        fn = {"fp32": self.lib.mmdyn_wgrad_tn, "fp16": self.lib.mmdyn_wgrad_tn_f16,
+              "fp16s": self.lib.mmdyn_wgrad_tn_f16}.get(self.precision, self.lib.mmdyn_wgrad_tn_bf16)
         check(fn(pd, pg, _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks,
                  _stream()), "mmdyn_wgrad_tn")
 
@@ -172,22 +195,28 @@ class HipBackend:
 
     # ---- packing / layout ----
     def pack_conv_weight(self, Wc, P, d0, d1, swap):
-        pp, p16 = _aptr(P)                 # a bf16 destination: the GEMM operand type of the bf16 precision modes
-        fn = self.lib.mmdyn_pack_conv_weight_b16 if p16 else self.lib.mmdyn_pack_conv_weight
-        check(fn(_ptr(Wc), pp, d0, d1, int(swap), _stream()), "mmdyn_pack_conv_weight")
+        pp, p16 = _aptr(P)                 # a 16-bit destination: the GEMM operand type of the 16-bit precision modes
+        if p16:
+            check(self.lib.mmdyn_pack_conv_weight_b16(_ptr(Wc), pp, d0, d1, int(swap), _half(p16), _stream()),
+                  "mmdyn_pack_conv_weight_b16")
+            return
+        check(self.lib.mmdyn_pack_conv_weight(_ptr(Wc), pp, d0, d1, int(swap), _stream()), "mmdyn_pack_conv_weight")
 
     def repack2d(self, src, dst, rows_in, cols_in, rows_out, cols_out, mode):
-        if dst.dtype == torch.bfloat16:
+        if _is16(dst):
             return self.repack2d_ld(src, dst, rows_in, cols_in, rows_out, cols_out, cols_out, mode)
         check(self.lib.mmdyn_repack2d(_ptr(src), _ptr(dst), rows_in, cols_in, rows_out, cols_out, mode, _stream()),
               "mmdyn_repack2d")
 
     def repack2d_ld(self, src, dst, rows_in, cols_in, rows_out, cols_out, ld_out, mode):
-        """dst: any fp32 (or bf16) view whose first element is the block's top-left corner (row stride ld_out)."""
-        _aptr(dst)                         # device / contiguity / dtype check
-        fn = self.lib.mmdyn_repack2d_ld_b16 if dst.dtype == torch.bfloat16 else self.lib.mmdyn_repack2d_ld
-        check(fn(_ptr(src), dst.data_ptr(), rows_in, cols_in, rows_out, cols_out, ld_out, mode, _stream()),
-              "mmdyn_repack2d_ld")
+        """dst: any fp32 (or 16-bit) view whose first element is the block's top-left corner (row stride ld_out)."""
+        _, d16 = _aptr(dst)                # device / contiguity / dtype check
+        if d16:
+            check(self.lib.mmdyn_repack2d_ld_b16(_ptr(src), dst.data_ptr(), rows_in, cols_in, rows_out, cols_out, ld_out, mode,
+                                                 _half(d16), _stream()), "mmdyn_repack2d_ld_b16")
+            return
+        check(self.lib.mmdyn_repack2d_ld(_ptr(src), dst.data_ptr(), rows_in, cols_in, rows_out, cols_out, ld_out, mode,
+                                         _stream()), "mmdyn_repack2d_ld")
 
     def pack_plan(self, plan_dev, n):
         """plan_dev: uint8 device tensor holding n mmdyn_pack_entry structs (see layers.PackPlan)."""
@@ -202,8 +231,11 @@ class HipBackend:
 
     def tconv_out3_fwd(self, a, w, out, Bt, Hi, Wi):
         pa, a16 = _aptr(a)
-        fn = self.lib.mmdyn_tconv_out3_fwd_b16 if a16 else self.lib.mmdyn_tconv_out3_fwd
-        check(fn(pa, _ptr(w), _ptr(out), Bt, Hi, Wi, _stream()), "mmdyn_tconv_out3_fwd")
+        if a16:
+            check(self.lib.mmdyn_tconv_out3_fwd_b16(pa, _ptr(w), _ptr(out), Bt, Hi, Wi, _half(a16), _stream()),
+                  "mmdyn_tconv_out3_fwd_b16")
+            return
+        check(self.lib.mmdyn_tconv_out3_fwd(pa, _ptr(w), _ptr(out), Bt, Hi, Wi, _stream()), "mmdyn_tconv_out3_fwd")
 
     def nchw_to_nhwc(self, src, dst, B, C, HW):
         check(self.lib.mmdyn_nchw_to_nhwc(_ptr(src), _ptr(dst), B, C, HW, _stream()), "mmdyn_nchw_to_nhwc")
@@ -226,17 +258,24 @@ class HipBackend:
         (py, y16), (pa, a16) = _aptr(y), _aptr(a)
         if y16 != a16:
             raise TypeError("mmdyn_hip: bn_swish_fwd input and output must share the storage type")
-        fn = self.lib.mmdyn_bn_swish_fwd_b16 if y16 else self.lib.mmdyn_bn_swish_fwd
-        check(fn(py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), pa, G, rows_per_group, C, _stream()),
-              "mmdyn_bn_swish_fwd")
+        if y16:
+            check(self.lib.mmdyn_bn_swish_fwd_b16(py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), pa, G, rows_per_group, C,
+                                                  _half(y16), _stream()), "mmdyn_bn_swish_fwd_b16")
+            return
+        check(self.lib.mmdyn_bn_swish_fwd(py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), pa, G, rows_per_group, C,
+                                          _stream()), "mmdyn_bn_swish_fwd")
 
     def bn_swish_bwd_reduce(self, da, y, mean, rstd, gamma, beta, partial, G, rows_per_group, C):
         (pd, d16), (py, y16) = _aptr(da), _aptr(y)
         if d16 != y16:
             raise TypeError("mmdyn_hip: bn_swish_bwd_reduce operands must share the storage type")
-        fn = self.lib.mmdyn_bn_swish_bwd_reduce_b16 if y16 else self.lib.mmdyn_bn_swish_bwd_reduce
-        check(fn(pd, py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(partial), G, rows_per_group, C, _stream()),
-              "mmdyn_bn_swish_bwd_reduce")
+        if y16:
+            check(self.lib.mmdyn_bn_swish_bwd_reduce_b16(pd, py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(partial),
+                                                         G, rows_per_group, C, _half(y16), _stream()),
+                  "mmdyn_bn_swish_bwd_reduce_b16")
+            return
+        check(self.lib.mmdyn_bn_swish_bwd_reduce(pd, py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(partial), G,
+                                                 rows_per_group, C, _stream()), "mmdyn_bn_swish_bwd_reduce")
 
     def bn_bwd_finalize(self, partial, sums, dgamma, dbeta, scratch, G, T, C, beta_acc):
         check(self.lib.mmdyn_bn_bwd_finalize(_ptr(partial), _ptr(sums), _ptr(dgamma), _ptr(dbeta),
@@ -266,9 +305,13 @@ class HipBackend:
         (pd, d16), (py, y16), (po, o16) = _aptr(da), _aptr(y), _aptr(dy)
         if not (d16 == y16 == o16):
             raise TypeError("mmdyn_hip: bn_swish_bwd_apply tensors must share the storage type")
-        fn = self.lib.mmdyn_bn_swish_bwd_apply_b16 if y16 else self.lib.mmdyn_bn_swish_bwd_apply
-        check(fn(pd, py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums), po, G, rows_per_group, C,
-                 int(da_is_du), _stream()), "mmdyn_bn_swish_bwd_apply")
+        if y16:
+            check(self.lib.mmdyn_bn_swish_bwd_apply_b16(pd, py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums), po,
+                                                        G, rows_per_group, C, int(da_is_du), _half(y16), _stream()),
+                  "mmdyn_bn_swish_bwd_apply_b16")
+            return
+        check(self.lib.mmdyn_bn_swish_bwd_apply(pd, py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums), po, G,
+                                                rows_per_group, C, int(da_is_du), _stream()), "mmdyn_bn_swish_bwd_apply")
 
     # ---- element-wise ----
     def act_fwd(self, u, h, act):
@@ -278,8 +321,10 @@ class HipBackend:
         (pd, d16), (pu, u16), (po, o16) = _aptr(dh), _aptr(u), _aptr(du)
         if not (d16 == u16 == o16):
             raise TypeError("mmdyn_hip: act_bwd tensors must share the storage type")
-        fn = self.lib.mmdyn_act_bwd_b16 if u16 else self.lib.mmdyn_act_bwd
-        check(fn(pd, pu, po, u.numel(), act, _stream()), "mmdyn_act_bwd")
+        if u16:
+            check(self.lib.mmdyn_act_bwd_b16(pd, pu, po, u.numel(), act, _half(u16), _stream()), "mmdyn_act_bwd_b16")
+            return
+        check(self.lib.mmdyn_act_bwd(pd, pu, po, u.numel(), act, _stream()), "mmdyn_act_bwd")
 
     def dropout_expand(self, h, masks, out, P, B, H, p_drop):
         check(self.lib.mmdyn_dropout_expand(_ptr(h), _ptr(masks, torch.uint8), _ptr(out), P, B, H, p_drop,

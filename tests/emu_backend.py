@@ -53,10 +53,11 @@ class EmuBackend:
     @staticmethod
     def _with_bf16(fn):
         def wrapped(*args):
-            conv = [a.float() if torch.is_tensor(a) and a.dtype == torch.bfloat16 else a for a in args]
+            h16 = (torch.bfloat16, torch.float16)           # ("bf16s" / "fp16s": the storage type of the mode)
+            conv = [a.float() if torch.is_tensor(a) and a.dtype in h16 else a for a in args]
             r = fn(*conv)
             for o, c in zip(args, conv):
-                if torch.is_tensor(o) and o.dtype == torch.bfloat16:
+                if torch.is_tensor(o) and o.dtype in h16:
                     o.copy_(c)
             return r
         return wrapped
@@ -98,7 +99,7 @@ class EmuBackend:
         # operands rounded to bf16 (RNE), fp32 accumulate -- except on the HBM-bound 3-channel layers, whose kernels
         # (conv3.hip) keep fp32 matrix cores in every precision mode
         if getattr(self, "precision", "fp32") != "fp32" and mode != IM2COL3:
-            h = torch.float16 if self.precision == "fp16" else torch.bfloat16
+            h = torch.float16 if self.precision in ("fp16", "fp16s") else torch.bfloat16
             A, Bp = A.to(h).to(torch.float32), Bp.to(h).to(torch.float32)
         if mode == IM2COL3:
             assert Cin == 64
@@ -161,7 +162,7 @@ class EmuBackend:
         assert chunks % 4 == 0 and Cd % 32 == 0 and Cg % 32 == 0
         rows = Bt * Hr * Wr
         if getattr(self, "precision", "fp32") != "fp32" and mode != IM2COL3:
-            h = torch.float16 if self.precision == "fp16" else torch.bfloat16
+            h = torch.float16 if self.precision in ("fp16", "fp16s") else torch.bfloat16
             D, Gt = D.to(h).to(torch.float32), Gt.to(h).to(torch.float32)
         Dm = D.reshape(-1)[: rows * Cd].reshape(rows, Cd)
         partial.zero_()

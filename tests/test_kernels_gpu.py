@@ -330,12 +330,27 @@ def test_wgrad_bf16(case, bf16_mode):
     test_wgrad(case)
 
 
+S16 = torch.bfloat16          # 16-bit storage type of the running storage test (set by the store16 fixture)
+
+
+@pytest.fixture(params=["bf16s", "fp16s"])
+def store16(request):
+    """The two 16-bit storage modes: bf16 ("bf16s") and IEEE half ("fp16s") activations / packed weights; the matrix cores
+    run in the same format.  The emulation widens, computes with operands rounded to the format and rounds what it stores."""
+    global S16
+    S16 = torch.float16 if request.param == "fp16s" else torch.bfloat16
+    HIP.precision = EMU.precision = request.param
+    yield request.param
+    HIP.precision = EMU.precision = "fp32"
+    S16 = torch.bfloat16
+
+
 def bf(t):
-    return t.to(torch.bfloat16)
+    return t.to(S16)
 
 
 @pytest.mark.parametrize("case", [IGEMM_CASES[1], IGEMM_CASES[4], IGEMM_CASES[6], IGEMM_CASES[9], IGEMM_CASES[13]])
-def test_igemm_bf16_storage(case, bf16_mode):
+def test_igemm_bf16_storage(case, store16):
     """bf16 activation storage: A and / or C (+ the activated copy, + the BatchNorm-backward operand) are bf16 in HBM.
     The emulation widens, computes in fp32 and rounds the outputs, so agreement is to one bf16 ulp of the outputs
     (a value on a rounding boundary may fall either way after fp32 summation-order differences)."""
@@ -348,35 +363,35 @@ def test_igemm_bf16_storage(case, bf16_mode):
     rows = Bt * Ho * Ho
     T = HIP.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
     post = lambda i, t: (t.sum(1) if t.dim() == 4 else t.float())
-    for c_dtype in (torch.bfloat16, torch.float32):
+    for c_dtype in (S16, torch.float32):
         C, Ca, stats = torch.zeros(rows, N, dtype=c_dtype), torch.zeros(rows, N, dtype=c_dtype), torch.zeros(G, T, 2, N)
         both("igemm_nt", [A, Bp, None, C, None, stats, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1],
-             [3, 5], post, tol=4e-3 if c_dtype == torch.bfloat16 else 2e-5)
+             [3, 5], post, tol=4e-3 if c_dtype == S16 else 2e-5)
         both("igemm_nt", [A, Bp, bias, C, Ca, None, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 1, 1],
-             [3, 4], post, tol=4e-3 if c_dtype == torch.bfloat16 else 2e-5)
+             [3, 4], post, tol=4e-3 if c_dtype == S16 else 2e-5)
     y = bf(rnd(rows, N, seed=44) * 1.5 + 0.2)
     mean, rstd = rnd(G, N, seed=45) * 0.3, rnd(G, N, seed=46).abs() + 0.5
     gamma, beta = rnd(N, seed=47) + 1.2, rnd(N, seed=48)
-    C, stats = torch.zeros(rows, N, dtype=torch.bfloat16), torch.zeros(G, T, 2, N)
+    C, stats = torch.zeros(rows, N, dtype=S16), torch.zeros(G, T, 2, N)
     both("igemm_nt_dgrad_bn", [A, Bp, C, stats, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride,
                                offset], [2, 3], post, tol=4e-3)
 
 
-def test_elementwise_bf16_storage(bf16_mode):
+def test_elementwise_bf16_storage(store16):
     G, rpg, C = 3, 1000, 64
     y, da = bf(rnd(G * rpg, C, seed=51) * 2 + 0.3), bf(rnd(G * rpg, C, seed=52))
     mean, rstd = rnd(G, C, seed=53) * 0.2, rnd(G, C, seed=54).abs() + 0.6
     gamma, beta = rnd(C, seed=55) + 1.5, rnd(C, seed=56)
     f32 = lambda i, t: t.float()
-    both("bn_swish_fwd", [y, mean, rstd, gamma, beta, torch.zeros(G * rpg, C, dtype=torch.bfloat16), G, rpg, C], [5], f32,
+    both("bn_swish_fwd", [y, mean, rstd, gamma, beta, torch.zeros(G * rpg, C, dtype=S16), G, rpg, C], [5], f32,
          tol=4e-3)
     T = HIP.colstats_tiles(rpg)
     ga, ca = both("bn_swish_bwd_reduce", [da, y, mean, rstd, gamma, beta, torch.zeros(G, T, 2, C), G, rpg, C], [6],
                   lambda i, t: t.sum(1), tol=1e-4)
     sums = ca[6].sum(1)
-    both("bn_swish_bwd_apply", [da, y, mean, rstd, gamma, beta, sums, torch.zeros(G * rpg, C, dtype=torch.bfloat16), G, rpg,
+    both("bn_swish_bwd_apply", [da, y, mean, rstd, gamma, beta, sums, torch.zeros(G * rpg, C, dtype=S16), G, rpg,
                                 C, False], [7], f32, tol=4e-3)
-    both("act_bwd", [da, y, torch.zeros(G * rpg, C, dtype=torch.bfloat16), 1], [2], f32, tol=4e-3)
+    both("act_bwd", [da, y, torch.zeros(G * rpg, C, dtype=S16), 1], [2], f32, tol=4e-3)
     a = bf(rnd(2 * 32 * 32, 32, seed=57))
     both("tconv_out3_fwd", [a, rnd(32, 3, 4, 4, seed=58, scale=0.2), torch.zeros(2, 3, 64, 64), 2, 32, 32], [2], tol=2e-5)
     # wgrad with bf16 operands (dense, conv and the im2col mode with a bf16 dense operand)
@@ -646,27 +661,27 @@ def test_conv3_direct_kernels(G, Bg):
              lambda i, t: t.sum(0), tol=5e-5)
 
 
-def test_bf16_packed_weights(bf16_mode):
+def test_bf16_packed_weights(store16):
     """bf16 precision modes pack the GEMM operands straight to bf16 (pack kernels with a bf16 destination) and the
     implicit GEMM reads them as such: same products as rounding fp32 packed weights inside the kernel."""
     f32 = lambda i, t: t.float()
     Wc = rnd(128, 64, 4, 4, seed=101, scale=0.2)
     for swap in (0, 1):
-        both("pack_conv_weight", [Wc, torch.zeros(16, 64 if swap else 128, 128 if swap else 64, dtype=torch.bfloat16), 128, 64, swap],
+        both("pack_conv_weight", [Wc, torch.zeros(16, 64 if swap else 128, 128 if swap else 64, dtype=S16), 128, 64, swap],
              [1], f32, tol=0.0)
     W = rnd(40, 500, seed=102)
-    out = torch.zeros(64, 512, dtype=torch.bfloat16)
+    out = torch.zeros(64, 512, dtype=S16)
     both("repack2d_ld", [W, out.view(-1)[512 * 8:], 40, 500, 40, 512, 512, 0], [1], f32, tol=0.0)
     for mode, G, Bg, Hi, Cin, Ho, N, stride, offset in ((CONV, 2, 3, 16, 64, 8, 128, 2, -1), (TCONV_S2P1, 1, 5, 8, 128, 16, 64, 1, 0),
                                                        (DENSE, 1, 300, 1, 512, 1, 512, 1, 0), (TCONV_S1P0, 2, 70, 5, 256, 8, 128, 1, 0)):
         Bt, taps = G * Bg, 16 if mode != DENSE else 1
         Bp = bf(rnd(taps, N, Cin, seed=103, scale=0.2))
-        for a_dtype in (torch.float32, torch.bfloat16):
+        for a_dtype in (torch.float32, S16):
             A = rnd(Bt * Hi * Hi, Cin, seed=104)
-            A = bf(A) if a_dtype == torch.bfloat16 else A
+            A = bf(A) if a_dtype == S16 else A
             C = torch.zeros(Bt * Ho * Ho, N, dtype=a_dtype)
             both("igemm_nt", [A, Bp, None, C, None, None, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1],
-                 [3], f32, tol=4e-3 if a_dtype == torch.bfloat16 else 2e-5)
+                 [3], f32, tol=4e-3 if a_dtype == S16 else 2e-5)
     # the 3-channel layer's kernel takes the bf16 [32][64] operand too
     x = rnd(3, 3, 64, 64, seed=105)
     Bp = bf(rnd(1, 32, 64, seed=106, scale=0.2))
@@ -674,20 +689,19 @@ def test_bf16_packed_weights(bf16_mode):
                       32, 32, 32, 1, 0, 1, 1], [3, 4])
 
 
-def test_igemm_bf16_mixed_output_and_one_pixel_walk(monkeypatch, lab):
+def test_igemm_bf16_mixed_output_and_one_pixel_walk(monkeypatch, lab, store16):
     """(i) A Linear layer whose activated output alone is bf16 (fp32 pre-activation for the backward, bf16 operand for the
     convolution behind it: storage flag bit 6).  (ii) The k4 s1 p0 transposed convolution on all-bf16 operands in its three
     block walks -- pairs of pixels (default below 2048 blocks), one pixel per block (default from 2048 blocks on, forced
     here on a small launch too) -- with bias, BatchNorm partial sums and ragged sample counts."""
     f32 = lambda i, t: t.float()
-    HIP.precision = EMU.precision = "bf16s"
     try:
         for rows, K, N in ((300, 256, 6400), (37, 288, 640)):
             A, Bp, bias = rnd(rows, K, seed=120), bf(rnd(1, N, K, seed=121, scale=0.2)), rnd(N, seed=122)
-            both("igemm_nt", [A, Bp, bias, torch.zeros(rows, N), torch.zeros(rows, N, dtype=torch.bfloat16), None, None, DENSE, 1,
+            both("igemm_nt", [A, Bp, bias, torch.zeros(rows, N), torch.zeros(rows, N, dtype=S16), None, None, DENSE, 1,
                               rows, 1, 1, K, 1, 1, N, N, 1, 0, 1, 1], [3, 4], f32, tol=4e-3)
         with pytest.raises(ValueError):      # a bf16 pre-activation next to an fp32 activated output is not a storage layout
-            HIP.igemm_nt(A.to(DEV), Bp.to(DEV), None, torch.zeros(rows, N, dtype=torch.bfloat16, device=DEV),
+            HIP.igemm_nt(A.to(DEV), Bp.to(DEV), None, torch.zeros(rows, N, dtype=S16, device=DEV),
                          torch.zeros(rows, N, device=DEV), None, None, DENSE, 1, rows, 1, 1, K, 1, 1, N, N, 1, 0, 1, 1)
         post = lambda i, t: t.float().sum(1) if t.dim() == 4 else t.float()
         for forced, G, Bg in ((None, 4, 256), ("2", 4, 256), ("4", 2, 70), (None, 2, 70), ("4", 1, 5)):
@@ -698,10 +712,10 @@ def test_igemm_bf16_mixed_output_and_one_pixel_walk(monkeypatch, lab):
             Bt = G * Bg
             A, Bp, bias = bf(rnd(Bt * 25, 256, seed=123)), bf(rnd(16, 128, 256, seed=124, scale=0.1)), rnd(128, seed=125)
             T = HIP.igemm_stat_tiles(TCONV_S1P0, G, Bg, 5, 5, 256, 8, 8, 128)
-            both("igemm_nt", [A, Bp, bias, torch.zeros(Bt * 64, 128, dtype=torch.bfloat16), None, torch.zeros(G, T, 2, 128), None,
+            both("igemm_nt", [A, Bp, bias, torch.zeros(Bt * 64, 128, dtype=S16), None, torch.zeros(G, T, 2, 128), None,
                               TCONV_S1P0, G, Bg, 5, 5, 256, 8, 8, 128, 128, 1, 0, 0, 1], [3, 5], post, tol=4e-3)
     finally:
-        HIP.precision = EMU.precision = "fp32"
+        monkeypatch.delenv("MMDYN_S1P0_SPLIT", raising=False)
 
 
 @pytest.mark.parametrize("H,Cin,G,Bg", [(16, 64, 2, 3), (16, 64, 1, 1), (16, 64, 4, 37), (32, 32, 2, 3), (32, 32, 1, 5), (64, 32, 2, 2),

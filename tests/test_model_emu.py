@@ -283,6 +283,23 @@ def test_fp16_precision_plumbing():
     check_extended_size_vs_oracle("cpu", 64, 3, True, n_steps=1, precision="fp16", loss_tol=2e-3, grad_tol=1e-1)
 
 
+def test_fp16s_precision_plumbing():
+    """precision="fp16s": as "fp16" with the convolution-level activations, their gradients and the packed weights stored
+    in IEEE half (3 more mantissa bits than the bf16 of "bf16s" at the same bytes); FC level, logits and losses stay fp32."""
+    from mmdyn_hip import layers, ops
+    worst16s = check_extended_size_vs_oracle("cpu", 64, 3, True, n_steps=1, precision="fp16s", loss_tol=2e-3, grad_tol=1e-1)
+    worstb = check_extended_size_vs_oracle("cpu", 64, 3, True, n_steps=1, precision="bf16s", loss_tol=5e-3, grad_tol=2e-1)
+    assert worst16s < worstb, (worst16s, worstb)          # half storage is the more accurate of the two 16-bit storage modes
+    assert ops.B.precision == "fp32" and layers.ACT_DTYPE == torch.float32 and layers.W_DTYPE == torch.float32
+    inputs, targets = seeded_batch(2, 5)
+    eps, masks = seeded_noise(2, 256, 7, 8, 6)
+    step = MVAEStep(build("cnn-mvae", True, True, "cpu"), noise=InjectedNoise(eps, masks), precision="fp16s")
+    step.forward(inputs, targets, 0.02)
+    assert step.ctx["ev"]["stages"][0]["a"].dtype == torch.float16 and step.ctx["dv"]["stages"][2]["y"].dtype == torch.float16
+    assert step.ctx["lgv"].dtype == torch.float32 and step.ctx["ov"].dtype == torch.float32
+    assert step.loss_scale == 8.0
+
+
 def test_extended_size_module_api_and_checks():
     """MVAE.forward / inference of a 128-pixel model, and the input-size check of a 64-pixel one."""
     from oracle import mvae_oracle as O

@@ -378,7 +378,18 @@ def test_fp16_engine_vs_oracle(size, B):
     print(f"fp16 size {size} B {B}: worst gradient rel-L2 {worst:.2e}")
 
 
-@pytest.mark.parametrize("size,B,precision", [(128, 128, "fp32"), (256, 32, "fp16"), (64, 128, "bf16s"), (256, 256, "fp16")])
+@pytest.mark.parametrize("size,B", [(64, 32), (64, 37), (128, 8), (256, 4)])
+def test_fp16_storage_engine_vs_oracle(size, B):
+    """precision="fp16s": fp16 matrix cores AND fp16 storage of the convolution-level activations, their gradients and the
+    packed weights (the bytes of "bf16s" with three more mantissa bits; loss scale 4 * B as in "fp16") against the fp32 CPU
+    oracle.  Stated tolerance: ELBO and partials 2e-3 relative, gradients 1e-1 relative L2 per tensor (between "fp16", whose
+    storage is fp32, and "bf16s": 1.5e-1).  B = 37: ragged against every tile."""
+    worst = T.check_extended_size_vs_oracle(DEV, size, B, True, n_steps=1, precision="fp16s", loss_tol=2e-3, grad_tol=1e-1)
+    print(f"fp16s size {size} B {B}: worst gradient rel-L2 {worst:.2e}")
+
+
+@pytest.mark.parametrize("size,B,precision", [(128, 128, "fp32"), (256, 32, "fp16"), (64, 128, "bf16s"), (256, 256, "fp16"),
+                                              (64, 128, "fp16s"), (256, 256, "fp16s")])
 def test_extended_sizes_full_batch_properties(size, B, precision):
     """Per-GPU shares of BASELINE configs[3] (bs 512 / 4 GPUs at 128x128), configs[2] (bs 1024 / 8 GPUs, bf16 storage) and
     configs[4] (256x256, fp16: bs 2048 / 8 GPUs = 256 per GPU, and a 32-sample slice):
