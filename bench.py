@@ -467,6 +467,14 @@ def main():
                      "step_launches": prof["whole_step"]["launches"] if prof else None,
                      "step_bound": bound_of(step_mfma_frac, step_hbm_frac)},
     }
+    if args.dtype == "f32" and dom is ig:
+        # The resource the fp32 implicit GEMM actually saturates (LAB_NOTES D.f; cycle counters inside the kernel):
+        # the CU's LDS fill path.  A 64x64 fp32 tile fills 16 KB of operands per 2*64*64*32 flop = 16 flop per filled byte, and
+        # LDS fills served from L2 / Infinity Cache run at 7.2-8 TB/s chip-wide -> ~120 TFLOP/s for this tile.
+        out["roofline"]["fill_bound"] = {
+            "flop_per_filled_byte": 16.0, "fill_rate_TBps": 7.5, "ceiling_tflops": 120.0,
+            "frac_of_fill_ceiling": achieved / 120.0,
+            "source": "profiles/r3/ws_ring_diag_stall_fractions.txt; MI355X_MICROARCH.md 'Indexed rows: gather into LDS'"}
     if dry:
         out["dry_run"] = "CPU rehearsal with emulated kernels (MMDYN_BENCH_DRYRUN=emu): control flow only, numbers meaningless"
     if args.breakdown:

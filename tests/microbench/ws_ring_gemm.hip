@@ -20,9 +20,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),               \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+__device__ unsigned long long g_stall[8];   // ... [4] loader in s_barrier, [5] loader issuing, [6] MFMA wave NM-1 in s_barrier   // DIAG 4: [0] cycles MFMA waves spent in s_barrier, [1] their K-loop cycles, [2] loader vmcnt-wait cycles, [3] loader loop cycles
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int BK, int S, int NL, bool M16>
+// DIAG (timing diagnostics, results are wrong for DIAG != 0): 1 = no s_barrier in the K loops (loader and MFMA waves run free),
+// 2 = no s_barrier and no DMA (LDS read + MFMA only: the ceiling of the consumer side), 3 = barriers kept, no DMA
+template <int BM, int BN, int WM, int WN, int BK, int S, int NL, bool M16, int DIAG = 0>
 __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void ws_gemm(const float* __restrict__ A,
                                                                              const float* __restrict__ B,
                                                                              float* __restrict__ C, int M, int N, int K) {
@@ -71,16 +74,30 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void ws_gemm(con
   auto issue = [&](int ks) {
     const int t = ks % S;
 #pragma unroll
-    for (int i = 0; i < PPL; ++i) GLDS16(gbase[i] + (size_t)ks * RB + voff[i], smem + t * SLOT + loff[i]);
+    for (int i = 0; i < PPL; ++i)
+      if (DIAG < 2 || DIAG == 4) GLDS16(gbase[i] + (size_t)ks * RB + voff[i], smem + t * SLOT + loff[i]);
   };
 
   if (NL > 0 && wave < NL) {
     // ================= loader wave =================
     for (int ks = 0; ks < S - 1 && ks < nk; ++ks) issue(ks);
+    long long t_wait = 0, t_loop = 0, t_lbar = 0, t_iss = 0;
+    if (DIAG == 4) t_loop = -(long long)__builtin_readcyclecounter();
     for (int k = 0; k < nk; ++k) {
+      if (DIAG == 4) t_wait -= (long long)__builtin_readcyclecounter();
       if (k + S - 1 <= nk) wait_vmcnt<PPL*(S - 2)>(); else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
+      if (DIAG == 4) { const long long c = (long long)__builtin_readcyclecounter(); t_wait += c; t_lbar -= c; }
+      if (DIAG == 0 || DIAG >= 3) __builtin_amdgcn_s_barrier();
+      if (DIAG == 4) { const long long c = (long long)__builtin_readcyclecounter(); t_lbar += c; t_iss -= c; }
       if (k + S - 1 < nk) issue(k + S - 1);
+      if (DIAG == 4) t_iss += (long long)__builtin_readcyclecounter();
+    }
+    if (DIAG == 4 && wave == 0 && lane == 0) {
+      t_loop += (long long)__builtin_readcyclecounter();
+      atomicAdd(&g_stall[2], (unsigned long long)t_wait);
+      atomicAdd(&g_stall[3], (unsigned long long)t_loop);
+      atomicAdd(&g_stall[4], (unsigned long long)t_lbar);
+      atomicAdd(&g_stall[5], (unsigned long long)t_iss);
     }
     return;
   }
@@ -103,9 +120,13 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void ws_gemm(con
   const int abase = (wm * WM) * RB, bbase = BM * RB + (wn * WN) * RB;
 
   if (NL == 0) for (int ks = 0; ks < S - 1 && ks < nk; ++ks) issue(ks);
+  long long t_bar = 0, t_all = 0;
+  if (DIAG == 4) t_all = -(long long)__builtin_readcyclecounter();
   for (int k = 0; k < nk; ++k) {
     if (NL == 0) { if (k + S - 1 <= nk) wait_vmcnt<PPL*(S - 2)>(); else wait_vmcnt<0>(); }
-    __builtin_amdgcn_s_barrier();
+    if (DIAG == 4) t_bar -= (long long)__builtin_readcyclecounter();
+    if (DIAG == 0 || DIAG >= 3) __builtin_amdgcn_s_barrier();
+    if (DIAG == 4) t_bar += (long long)__builtin_readcyclecounter();
     if (NL == 0) { if (k + S - 1 < nk) issue(k + S - 1); }
     const char* sl = smem + (k % S) * SLOT;
 #pragma unroll
@@ -126,6 +147,12 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void ws_gemm(con
           }
     }
   }
+  if (DIAG == 4 && mw == 0 && lane == 0) {
+    t_all += (long long)__builtin_readcyclecounter();
+    atomicAdd(&g_stall[0], (unsigned long long)t_bar);
+    atomicAdd(&g_stall[1], (unsigned long long)t_all);
+  }
+  if (DIAG == 4 && mw == NM - 1 && lane == 0) atomicAdd(&g_stall[6], (unsigned long long)t_bar);
   if constexpr (M16) {
     const int g = lane >> 4;
 #pragma unroll
@@ -289,7 +316,44 @@ int main(int argc, char** argv) {
     report("ws " #BM "x" #BN " w" #WM "x" #WN " bk" #BK_ " s" #S_ " nl" #NL_ " m16=" #M16_, time_ms([&] {            \
       hipLaunchKernelGGL((ws_gemm<BM, BN, WM, WN, BK_, S_, NL_, M16_>), dim3((s.M / BM) * (s.N / BN)), dim3(thr), smem, 0, A, B, C, s.M, s.N, s.K); }, 20)); \
   }
-      if (quick) {
+#define RUNDIAG(BM, BN, WM, WN, S_, D_)                                                                               \
+  if (s.M % (BM * 8) == 0 && s.N % BN == 0) {                                                                         \
+    const size_t smem = (size_t)(BM + BN) * 32 * 4 * S_;                                                              \
+    constexpr int thr = 64 * ((BM / WM) * (BN / WN) + 2);                                                             \
+    CK(hipFuncSetAttribute((const void*)ws_gemm<BM, BN, WM, WN, 32, S_, 2, true, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+    report("ws " #BM "x" #BN " w" #WM "x" #WN " s" #S_ " nl2 DIAG " #D_, time_ms([&] {                                 \
+      hipLaunchKernelGGL((ws_gemm<BM, BN, WM, WN, 32, S_, 2, true, D_>), dim3((s.M / BM) * (s.N / BN)), dim3(thr), smem, 0, A, B, C, s.M, s.N, s.K); }, 20)); \
+  }
+      if (argc > 2 && argv[2][0] == 'd') {
+        RUNDIAG(64, 64, 32, 32, 3, 0)
+        RUNDIAG(64, 64, 32, 32, 3, 1)
+        RUNDIAG(64, 64, 32, 32, 3, 2)
+        RUNDIAG(64, 64, 32, 32, 3, 3)
+        {
+          unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hst[8];
+          CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stall), z, sizeof(z)));
+          RUNDIAG(64, 64, 32, 32, 3, 4)
+          CK(hipMemcpyFromSymbol(hst, HIP_SYMBOL(g_stall), sizeof(hst)));
+          printf("    64x64 s3: MFMA wave 0 / 3 in s_barrier %.1f / %.1f %% of the K loop; loader 0: vmcnt wait %.1f %%, s_barrier %.1f %%, issuing %.1f %% (mean loop %.0f cycles per K-step)\n",
+                 100.0 * hst[0] / hst[1], 100.0 * hst[6] / hst[1], 100.0 * hst[2] / hst[3], 100.0 * hst[4] / hst[3], 100.0 * hst[5] / hst[3],
+                 (double)hst[3] / ((s.M / 64) * (s.N / 64)) / (s.K / 32) / 23.0);
+          CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stall), z, sizeof(z)));
+          RUNDIAG(64, 64, 32, 32, 5, 4)
+          CK(hipMemcpyFromSymbol(hst, HIP_SYMBOL(g_stall), sizeof(hst)));
+          printf("    64x64 s5: MFMA wave in s_barrier %.1f %% of its K loop; loader in vmcnt wait %.1f %% of its loop\n",
+                 100.0 * hst[0] / hst[1], 100.0 * hst[2] / hst[3]);
+        }
+        RUNDIAG(64, 64, 32, 32, 4, 0)
+        RUNDIAG(64, 64, 32, 32, 5, 0)
+        RUNDIAG(64, 64, 32, 32, 3, 0)
+        RUNDIAG(64, 64, 32, 32, 4, 0)
+        RUNDIAG(64, 64, 32, 32, 5, 0)
+        RUNDIAG(64, 64, 32, 32, 3, 0)
+        RUNDIAG(128, 128, 64, 32, 3, 0)
+        RUNDIAG(128, 128, 64, 32, 3, 1)
+        RUNDIAG(128, 128, 64, 32, 3, 2)
+        RUNDIAG(128, 128, 64, 32, 3, 3)
+      } else if (quick) {
         RUNREF(64, 64, 32, 32)
         RUNWS(64, 64, 32, 32, 32, 3, 2, true)
         RUNWS(64, 64, 32, 32, 32, 4, 2, true)
