@@ -33,6 +33,8 @@ elif [ "$part" = others ]; then
   python3 $R/bench.py --image-size 128 --problem dyn_modeling --batch 128 --dtype bf16s --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_c3_dyn128_b128_bf16s.json 2>> $O/others.err
   python3 $R/bench.py --image-size 256 --dtype fp16 --batch 256 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c4_256_fp16_b256.json 2>> $O/others.err
   python3 $R/bench.py --image-size 256 --dtype bf16s --batch 256 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c4_256_bf16s_b256.json 2>> $O/others.err
+  python3 $R/bench.py --image-size 256 --dtype fp16s --batch 256 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c4_256_fp16s_b256.json 2>> $O/others.err
+  python3 $R/bench.py --dtype fp16s --batch 128 --no-cpu-baseline > $O/bench_c2_fp16s_b128.json 2>> $O/others.err
   python3 $R/bench.py --image-size 256 --batch 64 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c4_256_f32_b64.json 2>> $O/others.err
   python3 $R/bench.py --dtype fp16 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_c1_fp16.json 2>> $O/others.err
   python3 $R/bench.py --infer --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_infer.json 2>> $O/others.err
@@ -43,6 +45,7 @@ elif [ "$part" = alltraffic ]; then
   bash $R/profiles/collect_r3.sh traffic s128_f32_b128_dyn_modeling --image-size 128 --problem dyn_modeling --batch 128
   bash $R/profiles/collect_r3.sh traffic s256_fp16_b256_seq_modeling --image-size 256 --dtype fp16 --batch 256
   bash $R/profiles/collect_r3.sh traffic s256_bf16s_b256_seq_modeling --image-size 256 --dtype bf16s --batch 256
+  bash $R/profiles/collect_r3.sh traffic s256_fp16s_b256_seq_modeling --image-size 256 --dtype fp16s --batch 256
 elif [ "$part" = traffic ]; then
   # whole-step HBM-side traffic of one bench.py workload: collect_r3.sh traffic <key> <bench args...>
   # separate PMC passes, --kernel-trace only (MI355X_MICROARCH.md, HBM section)
