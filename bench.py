@@ -467,6 +467,12 @@ def main():
                      "step_launches": prof["whole_step"]["launches"] if prof else None,
                      "step_bound": bound_of(step_mfma_frac, step_hbm_frac)},
     }
+    if args.dtype in ("bf16s", "fp16s") and dom is ig:
+        # 16-bit operands: a 64x64 tile fills 16 KB per K-step of 64 channels = 2*64*64*64 flop: 32 flop per filled byte
+        out["roofline"]["fill_bound"] = {
+            "flop_per_filled_byte": 32.0, "fill_rate_TBps": 7.5, "ceiling_tflops": 240.0,
+            "frac_of_fill_ceiling": achieved / 240.0,
+            "source": "profiles/r3/ws_ring_diag_stall_fractions.txt (fill rate); tile arithmetic in DESIGN 4.9"}
     if args.dtype == "f32" and dom is ig:
         # The resource the fp32 implicit GEMM actually saturates (LAB_NOTES D.f; cycle counters inside the kernel):
         # the CU's LDS fill path.  A 64x64 fp32 tile fills 16 KB of operands per 2*64*64*32 flop = 16 flop per filled byte, and
