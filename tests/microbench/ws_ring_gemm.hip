@@ -19,13 +19,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GLDS16(gptr, lptr)                                                                              \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),               \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+// the same with a cache-policy immediate (gfx940+: 1 = sc0, 2 = nt, 16 = sc1) -- fill-rate experiments
+#define GLDS16_AUX(gptr, lptr, AUX_)                                                                    \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),               \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, AUX_)
 
 __device__ unsigned long long g_stall[8];   // ... [4] loader in s_barrier, [5] loader issuing, [6] MFMA wave NM-1 in s_barrier   // DIAG 4: [0] cycles MFMA waves spent in s_barrier, [1] their K-loop cycles, [2] loader vmcnt-wait cycles, [3] loader loop cycles
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // DIAG (timing diagnostics, results are wrong for DIAG != 0): 1 = no s_barrier in the K loops (loader and MFMA waves run free),
 // 2 = no s_barrier and no DMA (LDS read + MFMA only: the ceiling of the consumer side), 3 = barriers kept, no DMA
-template <int BM, int BN, int WM, int WN, int BK, int S, int NL, bool M16, int DIAG = 0>
+template <int BM, int BN, int WM, int WN, int BK, int S, int NL, bool M16, int DIAG = 0, int AUXA = 0, int AUXB = 0>
 __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void ws_gemm(const float* __restrict__ A,
                                                                              const float* __restrict__ B,
                                                                              float* __restrict__ C, int M, int N, int K) {
@@ -75,7 +79,11 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void ws_gemm(con
     const int t = ks % S;
 #pragma unroll
     for (int i = 0; i < PPL; ++i)
-      if (DIAG < 2 || DIAG == 4) GLDS16(gbase[i] + (size_t)ks * RB + voff[i], smem + t * SLOT + loff[i]);
+      if (DIAG < 2 || DIAG == 4) {
+        // (piece index lw + i * NLW < PA: an A piece -- compile-time for NLW | PA)
+        if ((i * NLW) < PA) GLDS16_AUX(gbase[i] + (size_t)ks * RB + voff[i], smem + t * SLOT + loff[i], AUXA);
+        else GLDS16_AUX(gbase[i] + (size_t)ks * RB + voff[i], smem + t * SLOT + loff[i], AUXB);
+      }
   };
 
   if (NL > 0 && wave < NL) {
@@ -324,7 +332,26 @@ int main(int argc, char** argv) {
     report("ws " #BM "x" #BN " w" #WM "x" #WN " s" #S_ " nl2 DIAG " #D_, time_ms([&] {                                 \
       hipLaunchKernelGGL((ws_gemm<BM, BN, WM, WN, 32, S_, 2, true, D_>), dim3((s.M / BM) * (s.N / BN)), dim3(thr), smem, 0, A, B, C, s.M, s.N, s.K); }, 20)); \
   }
-      if (argc > 2 && argv[2][0] == 'd') {
+#define RUNAUX(AA, AB)                                                                                                \
+  if (s.M % 512 == 0 && s.N % 64 == 0) {                                                                              \
+    const size_t smem = (size_t)(64 + 64) * 32 * 4 * 3;                                                               \
+    CK(hipFuncSetAttribute((const void*)ws_gemm<64, 64, 32, 32, 32, 3, 2, true, 0, AA, AB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+    report("ws 64x64 s3 nl2 cache policy A=" #AA " B=" #AB, time_ms([&] {                                              \
+      hipLaunchKernelGGL((ws_gemm<64, 64, 32, 32, 32, 3, 2, true, 0, AA, AB>), dim3((s.M / 64) * (s.N / 64)), dim3(384), smem, 0, A, B, C, s.M, s.N, s.K); }, 20)); \
+  }
+      if (argc > 2 && argv[2][0] == 'c') {
+        RUNAUX(0, 0)
+        RUNAUX(0, 0)
+        RUNAUX(2, 0)
+        RUNAUX(2, 2)
+        RUNAUX(1, 0)
+        RUNAUX(1, 1)
+        RUNAUX(16, 0)
+        RUNAUX(16, 16)
+        RUNAUX(17, 0)
+        RUNAUX(3, 0)
+        RUNAUX(0, 0)
+      } else if (argc > 2 && argv[2][0] == 'd') {
         RUNDIAG(64, 64, 32, 32, 3, 0)
         RUNDIAG(64, 64, 32, 32, 3, 1)
         RUNDIAG(64, 64, 32, 32, 3, 2)
