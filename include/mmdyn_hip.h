@@ -129,6 +129,8 @@ int mmdyn_wgrad_tn_f16(const float* D, const float* Gt, float* partial, int mode
                        int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks, void* stream);
 /* recommended `chunks` (a multiple of 4) for mmdyn_wgrad_tn; partial must hold chunks*taps*Cd*Cg floats */
 int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg);
+/* ... for the kernel the storage flags of mmdyn_wgrad_tn_mx select (both operands 16-bit in HBM: the all-16-bit kernels' tiles) */
+int mmdyn_wgrad_chunks_mx(int mode, int rows, int Cd, int Cg, int flags);
 int mmdyn_wgrad_reduce(const float* partial, float* canon, int chunks, int taps, int Cd, int Cg,
                        int cg_canon, int perm, float beta, void* stream);
 

@@ -907,6 +907,12 @@ static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, 
 
 }  // namespace
 
+// (LAB build: MMDYN_WGRAD_128x64=0 puts the 128 x 64 channel layers back on 64x64 tiles -- step A/B)
+static bool tile_128x64() {
+  const char* e = lab_env("MMDYN_WGRAD_128x64");
+  return !(e && e[0] == '0');
+}
+
 static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr,
                        int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
                        void* stream, bool bf16, int storage_flags = 0) {
@@ -960,6 +966,10 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
     }
   }
   if (Cd % 128 == 0 && Cg % 128 == 0) return launch<128, 128, 64, 64, 1>(D, Gt, partial, g, st, bf16);
+  // 128 x 64 channel layers: one 128x64 tile instead of two 64x64 ones -- the gathered operand is filled once for all 128
+  // output channels (21 instead of 16 flop per filled byte): x1.10-1.16 with twice the partial slabs (mmdyn_wgrad_chunks),
+  // profiles/r3/ab_wgrad_tile_128x64.txt
+  if (Cd % 128 == 0 && g64 && tile_128x64()) return launch<128, 64, 64, 32, 1>(D, Gt, partial, g, st, bf16);
   if (mode == MMDYN_CONV && !(d64 && g64)) {   // narrow channel tiles: four kw taps per block share the dense
     if (d64) return launch4<64, 32>(D, Gt, partial, g, st, bf16);   // operand (measured +11 %; 64x64 tiles are faster
                                                               // on the one-tap kernel, so they stay there)
@@ -1001,10 +1011,12 @@ extern "C" int mmdyn_wgrad_tn_f16(const float* D, const float* Gt, float* partia
 }
 
 // recommended number of partial slabs: ~768 blocks in flight, at least 128 rows per block
-extern "C" int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg) {
+// b16_storage: both operands are 16-bit in HBM (the wgrad_b16 kernels: their own tiles)
+static int wgrad_chunks_impl(int mode, int rows, int Cd, int Cg, bool b16_storage) {
   if (Cd % 32 || Cg % 32 || rows <= 0) return MMDYN_ERR_SHAPE;
   int bd, bg, wk;
   if (Cd % 128 == 0 && Cg % 128 == 0) { bd = 128; bg = 128; wk = 1; }
+  else if (Cd % 128 == 0 && Cg % 64 == 0 && !b16_storage && tile_128x64()) { bd = 128; bg = 64; wk = 1; }
   else if (Cd % 64 == 0 && Cg % 64 == 0) { bd = 64; bg = 64; wk = 1; }
   else if (Cd % 64 == 0) { bd = 64; bg = 32; wk = 2; }
   else if (Cg % 64 == 0) { bd = 32; bg = 64; wk = 2; }
@@ -1028,6 +1040,12 @@ extern "C" int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg) {
   long chunks = z * wk;
   chunks = (chunks + 3) / 4 * 4;
   return (int)chunks;
+}
+
+extern "C" int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg) { return wgrad_chunks_impl(mode, rows, Cd, Cg, false); }
+/* flags as mmdyn_wgrad_tn_mx: the count for the kernel those storage flags select */
+extern "C" int mmdyn_wgrad_chunks_mx(int mode, int rows, int Cd, int Cg, int flags) {
+  return wgrad_chunks_impl(mode, rows, Cd, Cg, (flags & 6) == 6);
 }
 
 extern "C" int mmdyn_wgrad_reduce(const float* partial, float* canon, int chunks, int taps, int Cd, int Cg,

@@ -40,6 +40,7 @@ _SIGNATURES = {
     "mmdyn_wgrad_tn_bf16": "ppp" + "iiiiiiiiiii" + "p",
     "mmdyn_wgrad_tn_f16": "ppp" + "iiiiiiiiiii" + "p",
     "mmdyn_wgrad_chunks": "iiii",
+    "mmdyn_wgrad_chunks_mx": "iiiii",
     "mmdyn_wgrad_reduce": "pp" + "iiiiii" + "f" + "p",
     "mmdyn_pack_conv_weight": "pp" + "iii" + "p",
     "mmdyn_repack2d": "pp" + "iiiii" + "p",

@@ -70,7 +70,7 @@ class EmuBackend:
         return self.lib.mmdyn_colstats_tiles(r)
 
     def wgrad_chunks(self, mode, rows, Cd, Cg):
-        return self.lib.mmdyn_wgrad_chunks(mode, rows, Cd, Cg)
+        return self.lib.mmdyn_wgrad_chunks_mx(mode, rows, Cd, Cg, 7 if self.precision in ("bf16s", "fp16s") else 0)
 
     # ---- GEMMs ----
     @staticmethod

@@ -339,7 +339,20 @@ int main(int argc, char** argv) {
     report("ws 64x64 s3 nl2 cache policy A=" #AA " B=" #AB, time_ms([&] {                                              \
       hipLaunchKernelGGL((ws_gemm<64, 64, 32, 32, 32, 3, 2, true, 0, AA, AB>), dim3((s.M / 64) * (s.N / 64)), dim3(384), smem, 0, A, B, C, s.M, s.N, s.K); }, 20)); \
   }
-      if (argc > 2 && argv[2][0] == 'c') {
+      if (argc > 2 && argv[2][0] == 't') {          // tile shapes at warm clocks: three interleaved rounds after a long warm-up
+        // (the kernels' block order deals M-tiles in groups of eight: same guard as RUNREF / RUNWS)
+        for (int w = 0; w < 150 && s.M % 512 == 0 && s.N % 64 == 0; ++w)
+          hipLaunchKernelGGL((lds_gemm_ref<64, 64, 32, 32>), dim3((s.M / 64) * (s.N / 64)), dim3(256), (size_t)128 * 40 * 4, 0, A, B, C, s.M, s.N, s.K);
+        CK(hipDeviceSynchronize());
+        for (int rep = 0; rep < 3 && s.M % 512 == 0; ++rep) {
+          RUNWS(64, 64, 32, 32, 32, 3, 2, true)
+          RUNWS(128, 64, 64, 32, 32, 3, 2, true)
+          RUNWS(128, 64, 32, 64, 32, 3, 2, true)
+          RUNWS(64, 128, 32, 64, 32, 3, 2, true)
+          RUNWS(64, 128, 64, 32, 32, 3, 2, true)
+          RUNWS(128, 128, 64, 32, 32, 3, 2, true)
+        }
+      } else if (argc > 2 && argv[2][0] == 'c') {
         RUNAUX(0, 0)
         RUNAUX(0, 0)
         RUNAUX(2, 0)

@@ -700,7 +700,7 @@ def check_inference_engine(golden_dir, device):
     assert v_only[2] is not None and tuple(v_only[0].shape) == (B, 3, 64, 64)
     a, b = eng.inference(5), None
     assert tuple(a[0].shape) == (5, 3, 64, 64)
-    for prec, tol in (("bf16", 2e-2), ("bf16s", 3e-2)):            # reduced-precision serving: close to the fp32 result
+    for prec, tol in (("bf16", 2e-2), ("bf16s", 3e-2), ("fp16", 5e-3), ("fp16s", 5e-3)):   # reduced-precision serving: close to fp32
         e2 = MVAEInference(m, precision=prec, seed=5)
         o2 = e2([inputs[0], inputs[1]], pose=inputs[2])
         np.testing.assert_allclose(o2[3].cpu().numpy(), g["mvae/means"], rtol=tol, atol=tol)
