@@ -603,6 +603,9 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   if (MODE == MMDYN_TCONV_S1P0) {
     g.tiles_per_pixel = ceil_div(g.Bg, BM);
     g.s1p0_split = bf16 ? 2 : 1;
+    if (const char* e = lab_env("MMDYN_S1P0_SPLIT_F32")) {      // LAB: the pair walk for fp32 too (tests/microbench/ab_s1p0.py)
+      if (!bf16 && e[0] == '2') g.s1p0_split = 2;
+    }
     g.tiles_per_group = 16 * g.tiles_per_pixel * g.s1p0_split;   // 16 pixel quads per group, 4 pixels walked per block (pair)
   }
   // all-bf16 operands (the 64-channel K-step variant) with >= 2048 blocks: ONE output pixel per block (ONEPX at the kernel).

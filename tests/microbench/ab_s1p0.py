@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Diagnostic (LAB build): the fp32 k4 s1 p0 transposed convolution (the step's largest launch pair) -- balanced quad walk (product)
+against the pair walk (MMDYN_S1P0_SPLIT_F32=2: twice the blocks, 8..17 taps each); interleaved rounds after a clock warm-up."""
+import os
+import statistics
+import sys
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-dynamics_amd"))
+from mmdyn_hip import ops, _lib  # noqa: E402
+
+HIP = ops.HipBackend(lib_path=_lib.LAB_LIB_PATH)
+TCONV_S1P0 = 4
+
+
+def event_ms(fn, reps):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def main():
+    dev = "cuda"
+    x = torch.randn(8192, 8192, device=dev)
+    for _ in range(40):
+        x @ x
+    torch.cuda.synchronize()
+    for G, Bg in ((4, 256), (1, 256), (4, 128)):
+        Bt = G * Bg
+        A = torch.randn(Bt * 25, 256, device=dev)
+        Bp = torch.randn(16, 128, 256, device=dev) * 0.1
+        bias = torch.randn(128, device=dev)
+        C = torch.empty(Bt * 64, 128, device=dev)
+        T = HIP.igemm_stat_tiles(TCONV_S1P0, G, Bg, 5, 5, 256, 8, 8, 128)
+        stats = torch.zeros(G, T, 2, 128, device=dev)
+        fn = lambda: HIP.igemm_nt(A, Bp, bias, C, None, stats, None, TCONV_S1P0, G, Bg, 5, 5, 256, 8, 8, 128, 128, 1, 0, 0, 1)
+        times, res = {"1": [], "2": []}, {}
+        for rnd in range(6):
+            for flag in ("1", "2"):
+                os.environ["MMDYN_S1P0_SPLIT_F32"] = flag
+                if rnd == 0:
+                    fn()
+                    torch.cuda.synchronize()
+                    res[flag] = (C.clone(), stats.sum(1))
+                times[flag].append(event_ms(fn, 10))
+        fl = 2.0 * Bt * 400 * 256 * 128
+        for flag in ("1", "2"):
+            m = statistics.median(times[flag])
+            dc = float((res[flag][0] - res["1"][0]).abs().max())
+            ds = float((res[flag][1] - res["1"][1]).abs().max() / res["1"][1].abs().max())
+            print(f"s1p0 G={G} Bg={Bg}  {'quad walk' if flag == '1' else 'pair walk'}  {m * 1e3:7.1f} us {fl / m / 1e9:6.1f} TF/s  maxdiff C {dc:.1e} stats {ds:.1e}",
+                  flush=True)
+
+
+if __name__ == "__main__":
+    main()
