@@ -424,7 +424,7 @@ static WsPick ws_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr, i
   if (N % 128 == 0 && ksteps >= 32 && tiles128 >= 512) p.bm = p.bn = 128;
   if (const char* e = lab_env("MMDYN_WS_TILE")) {          // LAB build: force one tile (kernel experiments)
     int a = 0, b = 0;
-    if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 64 || (b == 128 && a == 128)) && N % b == 0) {
+    if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 64 || b == 128) && N % b == 0) {
       p.bm = a;
       p.bn = b;
     }
@@ -466,6 +466,10 @@ static int ws_launch_mode(const float* A, const float* Bp, const float* bias, fl
   if (p.bm == 128 && p.bn == 128)
     return ws_launch<MODE, 128, 128, 64, 32, 3, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
   if (p.bm == 128) return ws_launch<MODE, 128, 64, 32, 64, 3, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
+#ifdef MMDYN_LAB
+  if constexpr (!B16)         // LAB: 64 rows x 128 channels (the gathered operand filled once per 128 output channels)
+    if (p.bn == 128) return ws_launch<MODE, 64, 128, 32, 64, 3, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
+#endif
   return ws_launch<MODE, 64, 64, 32, 32, 3, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
 }
 
