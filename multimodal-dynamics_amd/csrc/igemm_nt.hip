@@ -602,9 +602,13 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   g.tiles_per_group = ceil_div(g.Bg * g.Hr * g.Wr, BM);
   if (MODE == MMDYN_TCONV_S1P0) {
     g.tiles_per_pixel = ceil_div(g.Bg, BM);
-    g.s1p0_split = bf16 ? 2 : 1;
-    if (const char* e = lab_env("MMDYN_S1P0_SPLIT_F32")) {      // LAB: the pair walk for fp32 too (tests/microbench/ab_s1p0.py)
-      if (!bf16 && e[0] == '2') g.s1p0_split = 2;
+    // fp32: the balanced quad walk while it gives every CU two blocks (4 x 256 samples: 512 blocks, 295 us against 346 for the
+    // pair walk); below that the pair walk's extra blocks win (4 x 128 samples: 199 vs 214 us; 256 samples: 130 vs 188 us) --
+    // tests/microbench/ab_s1p0.py, profiles/r3/ab_s1p0_pair_walk_fp32.txt
+    const long quad_blocks = (long)g.G * 16 * g.tiles_per_pixel * (g.N / BN);
+    g.s1p0_split = (bf16 || quad_blocks < 512) ? 2 : 1;
+    if (const char* e = lab_env("MMDYN_S1P0_SPLIT_F32")) {      // LAB: force one walk for fp32
+      if (!bf16 && (e[0] == '1' || e[0] == '2')) g.s1p0_split = e[0] - '0';
     }
     g.tiles_per_group = 16 * g.tiles_per_pixel * g.s1p0_split;   // 16 pixel quads per group, 4 pixels walked per block (pair)
   }
