@@ -254,6 +254,9 @@ def main():
                          "cores, fp32 accumulate / master weights = the per-GPU share of configs[2] (use --batch 128).  "
                          "bf16: bf16 matrix-core operands only (fp32 storage).  fp16: fp16 matrix-core operands, fp32 "
                          "accumulate / storage / master weights (configs[4]).  fp16s: fp16 + fp16 activation storage")
+    ap.add_argument("--defer-wgrad", choices=("auto", "on", "off"), default="auto",
+                    help="decoder weight-gradient GEMMs on two extra streams next to the encoder backward (auto: the engine's rule, "
+                         "on in the 16-bit storage modes)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="BatchNorm statistics over the global batch (N > 1; one small all-reduce per BatchNorm layer and "
                          "direction, captured into the lanes' HIP graphs, each lane on its own RCCL communicator).  Default: "
@@ -343,7 +346,7 @@ def main():
         return
     step = MVAEStep(model, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), process_group=pg,
                     world_size=world, two_lanes=not args.single_lane,
-                    precision=PREC,
+                    precision=PREC, defer_wgrad={"auto": None, "on": True, "off": False}[args.defer_wgrad],
                     sync_bn=args.sync_bn and pg is not None)
     inputs, targets = seeded_batch(args.batch, 1234 + rank, size=S)
     inputs, targets = [x.to(dev) for x in inputs], [x.to(dev) for x in targets]

@@ -328,6 +328,12 @@ int mmdyn_elbo_assemble(const double* bce, const double* mse, const double* kl, 
  * (graph-replay safe); p/g/m/v: flat fp32 buffers of n elements; g is multiplied by grad_scale first */
 int mmdyn_adam_step(float* p, const float* g, float* m, float* v, double* state, int64_t n, float lr,
                     float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* The same step behind an overflow guard (the fp16 precision modes: loss-scaled gradients can overflow fp16 on their way
+ * through the matrix cores).  state: SIX doubles {step count, step size, sqrt(bias_correction2), flag, skipped steps, skip};
+ * a gradient buffer that holds an inf or NaN leaves parameters, moments and step count untouched and adds one to state[4]
+ * -- the behaviour of torch.cuda.amp.GradScaler.step on such a step (the reference itself trains in fp32: problems.py:150-155). */
+int mmdyn_adam_step_guarded(float* p, const float* g, float* m, float* v, double* state, int64_t n, float lr,
+                            float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* torch.optim.SGD with momentum / weight decay as configured by problems.py:132-136 (momentum 0.9, wd 5e-4);
  * first != 0 on the first step (momentum buffer := gradient, like torch) */

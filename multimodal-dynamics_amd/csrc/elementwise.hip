@@ -308,9 +308,42 @@ __global__ void adam_tick_kernel(double* __restrict__ state, float lr, float bet
   }
 }
 
+// Guarded form (the fp16 modes, whose scaled gradients can overflow on their way through the matrix cores): state has six
+// doubles -- {step count, step size, sqrt(bias_correction2), "gradient holds inf / NaN" flag, skipped steps, skip this step}.
+// grad_nonfinite_kernel raises the flag, the tick turns it into "skip" (no step count, no moment or parameter update: what
+// torch.cuda.amp.GradScaler does with such a step) and counts it.
+__global__ void grad_nonfinite_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ state) {
+  const int64_t n4 = n >> 2;
+  float s = 0.f;                        // x - x is 0 for finite x and NaN otherwise
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    s += (v[0] - v[0]) + (v[1] - v[1]) + (v[2] - v[2]) + (v[3] - v[3]);
+  }
+  for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    s += g[i] - g[i];
+  if (!(s == 0.f)) state[3] = 1.0;      // (every writer stores the same value)
+}
+
+__global__ void adam_tick_guarded_kernel(double* __restrict__ state, float lr, float beta1, float beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (state[3] != 0.0) {
+      state[3] = 0.0;
+      state[4] += 1.0;
+      state[5] = 1.0;
+    } else {
+      const double t = state[0] + 1.0;
+      state[0] = t;
+      state[1] = (double)lr / (1.0 - pow((double)beta1, t));
+      state[2] = sqrt(1.0 - pow((double)beta2, t));
+      state[5] = 0.0;
+    }
+  }
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, const double* __restrict__ state, int64_t n, float beta1,
-                            float beta2, float eps, float grad_scale) {
+                            float beta2, float eps, float grad_scale, int guarded) {
+  if (guarded && state[5] != 0.0) return;
   const float step_size = (float)state[1], bc2s = (float)state[2];
   const int64_t n4 = n >> 2;
   auto upd = [&](float& pp, float gg, float& mm, float& vv) {
@@ -476,6 +509,16 @@ extern "C" int mmdyn_adam_step(float* p, const float* g, float* m, float* v, dou
   if (!p || !g || !m || !v || !state) return MMDYN_ERR_NULL;
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, ST, state, lr, beta1, beta2);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, p, g, m, v, state, n, beta1,
-                     beta2, eps, grad_scale);
+                     beta2, eps, grad_scale, 0);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_adam_step_guarded(float* p, const float* g, float* m, float* v, double* state, int64_t n,
+                                       float lr, float beta1, float beta2, float eps, float grad_scale,
+                                       void* stream) {
+  if (!p || !g || !m || !v || !state) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, g, n, state);
+  hipLaunchKernelGGL(adam_tick_guarded_kernel, dim3(1), dim3(64), 0, ST, state, lr, beta1, beta2);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, ST, p, g, m, v, state, n, beta1,
+                     beta2, eps, grad_scale, 1);
   MMDYN_LAUNCH_CHECK();
 }

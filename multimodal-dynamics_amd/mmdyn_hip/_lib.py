@@ -85,6 +85,7 @@ _SIGNATURES = {
     "mmdyn_mse": "pppp" + "l" + "f" + "p",
     "mmdyn_elbo_assemble": "ppppp" + "ii" + "ff" + "pp",
     "mmdyn_adam_step": "ppppp" + "l" + "fffff" + "p",
+    "mmdyn_adam_step_guarded": "ppppp" + "l" + "fffff" + "p",
     "mmdyn_sgd_step": "ppp" + "l" + "ffff" + "i" + "p",
     "mmdyn_igemm_nt_mx": "pppppppppppp" + "iiiiiiiiiiiiii" + "i" + "p",
     "mmdyn_wgrad_tn_mx": "ppp" + "iiiiiiiiiii" + "i" + "p",

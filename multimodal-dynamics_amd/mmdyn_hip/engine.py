@@ -176,7 +176,8 @@ class MVAEStep:
     """Fused train / eval step for an :class:`mmdyn_hip.models.MVAE` on one GPU (one rank)."""
 
     def __init__(self, model, lr=1e-3, pose_multiplier=1000.0, betas=(0.9, 0.999), eps=1e-8, noise=None,
-                 process_group=None, world_size=1, two_lanes=True, precision="fp32", exact_running_stats=False, sync_bn=False):
+                 process_group=None, world_size=1, two_lanes=True, precision="fp32", exact_running_stats=False, sync_bn=False,
+                 defer_wgrad=None):
         # --conditional (vae.py:231-237, 286-291): the condition joins the 512 features in front of the image encoders' heads
         # and the latent in front of the image decoders' first layer; the pose MLPs are built unconditional (vae.py:117-123)
         self.conditional = bool(getattr(model, "conditional", False))
@@ -192,9 +193,17 @@ class MVAEStep:
         # smallest normal (6.1e-5) once it has passed a few layers and is rounded away on its way into the matrix cores.
         # Scaled, dlogit = 4 (sigmoid - t) whatever the batch; the largest operand is the pose gradient 8000 * |error|
         # (fp16 maximum 65504: pose targets and predictions live in [0, 1]).  ``params.grad`` holds the scaled gradients
-        # between backward() and optimizer_step(): divide by ``loss_scale`` to read them.  Set per batch in _begin();
-        # data-parallel ranks must run equal local batches in these modes (bench.py does), the all-reduce adds the ranks.
+        # between backward() and optimizer_step(): divide by ``loss_scale`` to read them.  Set per batch in _begin()
+        # (4 * B * (64 / image side)^2: see there); data-parallel ranks must run equal local batches in these modes (bench.py
+        # does), the all-reduce adds the ranks.  The scale is static; what a static scale cannot rule out -- an overflow to
+        # inf somewhere in the backward -- is caught by the guarded Adam step (mmdyn_adam_step_guarded): such a step is
+        # skipped, counted in ``skipped_steps``, and leaves parameters and moments as they were.
         self._scale_per_sample = 4.0 if precision in ("fp16", "fp16s") else 0.0
+        # The decoders' weight-gradient GEMMs (nothing on the backward chain reads them) are queued during the decoder
+        # backward and run on two more streams next to the encoder backward: the replayed step then has four chains in
+        # flight instead of two.  None: the measured rule (on in the 16-bit storage modes, whose launches are latency-bound and
+        # leave most of the chip idle; off in fp32, where the chip is busy and the move changes nothing).
+        self.defer_wgrad = (precision in ("bf16s", "fp16s")) if defer_wgrad is None else bool(defer_wgrad)
         self.loss_scale = 1.0
         # False (default): each image decoder runs only on the passes whose reconstruction enters the loss, so its
         # BatchNorm running buffers see 4 EMA updates per step (2 without pose) where the reference applies 7 (3).
@@ -232,7 +241,7 @@ class MVAEStep:
         dev = self.params.flat.device
         self.adam_m = torch.zeros_like(self.params.flat)
         self.adam_v = torch.zeros_like(self.params.flat)
-        self.adam_state = torch.zeros(3, dtype=torch.float64, device=dev)
+        self.adam_state = torch.zeros(6, dtype=torch.float64, device=dev)     # (six: the guarded step of the fp16 modes)
         self.acc = torch.zeros(4, 8, dtype=torch.float64, device=dev)   # bce / mse / kl per pass (+ unmasked bce: --mask-loss)
         self.loss = torch.zeros(1, device=dev)
         self.partials = torch.zeros(8, device=dev)
@@ -346,7 +355,9 @@ class MVAEStep:
                                "construct MVAEStep after moving the model")
         v = inputs[0].contiguous()
         if self._scale_per_sample:
-            self.loss_scale = self._scale_per_sample * v.shape[0]
+            # (the latent gradient is a sum over the pixels of the reconstructions: the encoder-side gradients grow with the
+            #  image area, the scale shrinks with it -- 256x256 at 4 * B overflowed fp16 in the first encoder layers)
+            self.loss_scale = self._scale_per_sample * v.shape[0] * (64.0 / v.shape[-1]) ** 2
         self.ctx = {"B": v.shape[0], "dev": v.device, "x": {"v": v, "t": inputs[1].contiguous()},
                     "tg": {"v": targets[0].contiguous(), "t": targets[1].contiguous()},
                     "pose": inputs[2].contiguous() if self.use_pose else None,
@@ -444,7 +455,12 @@ class MVAEStep:
     def _ph_dec_bwd_steps(self, m):
         c, FP = self.ctx, self.params
         dec = self._MOD[m][1]
-        c["dz" + m] = yield from layers.decoder_backward_steps(FP.sub(dec), c["d" + m], c["dl" + m], FP.sub(dec, "G"))
+        wq = c.setdefault("wq" + m, []) if self.defer_wgrad else None
+        c["dz" + m] = yield from layers.decoder_backward_steps(FP.sub(dec), c["d" + m], c["dl" + m], FP.sub(dec, "G"), defer=wq)
+
+    def _ph_dec_wgrad(self, m):
+        """The decoder's queued weight-gradient GEMMs (defer_wgrad), on whatever stream is current."""
+        layers.run_deferred_wgrads(self.ctx.get("wq" + m) or [])
 
     def _ph_pose_dec_bwd(self):
         c, FP = self.ctx, self.params
@@ -557,6 +573,9 @@ class MVAEStep:
         self._ph_pose_dec_bwd()
         LN.fork()
         self._two(self._ph_dec_bwd_steps)
+        for i, m in enumerate("vt"):          # (eager launches: the queued weight gradients follow on their lane)
+            with LN.lane(i):
+                self._ph_dec_wgrad(m)
         LN.join()
         handles += self._reduce_bucket(0)
         self._ph_poe_bwd()
@@ -583,7 +602,13 @@ class MVAEStep:
         for h in handles:
             h.wait()
         ops.B.adam_step(self.params.flat, self.params.grad, self.adam_m, self.adam_v, self.adam_state, self.lr,
-                        self.betas[0], self.betas[1], self.eps, 1.0 / (self.world * self.loss_scale))
+                        self.betas[0], self.betas[1], self.eps, 1.0 / (self.world * self.loss_scale),
+                        guarded=bool(self._scale_per_sample))
+
+    @property
+    def skipped_steps(self):
+        """Optimiser steps the overflow guard of the fp16 modes has skipped so far (a gradient held inf / NaN)."""
+        return int(self.adam_state[4])
 
     @_with_precision
     def train_step(self, inputs, targets, kl_weight, loss_mask=None, condition=None):
@@ -690,9 +715,10 @@ class MVAEStep:
              ("main", lambda: (self._ph_pose_dec_fwd(), self._ph_pose_dec_bwd()))],
             [("main", lambda: (self._ph_assemble(), self._ph_poe_bwd()))],
         ]
+        wq = [("w0", lambda: self._ph_dec_wgrad("v")), ("w1", lambda: self._ph_dec_wgrad("t"))] if self.defer_wgrad else []
         if self.pg is None:
             stages.append([("l0", lambda: run(self._ph_enc_bwd_steps("v"))), ("l1", lambda: run(self._ph_enc_bwd_steps("t"))),
-                           ("main", lambda: self._ph_pose_enc_bwd())])
+                           ("main", lambda: self._ph_pose_enc_bwd())] + wq)
             stages.append([("main", lambda: self.optimizer_step(()))])
         else:
             # data parallel: the encoder backward is cut after the heads + FC layer (gradient bucket 1: 31 MB of the 37 MB
@@ -708,9 +734,11 @@ class MVAEStep:
                 for _ in gens.pop(m):
                     pass
 
-            stages.append([("l0", lambda: head("v")), ("l1", lambda: head("t")), ("main", lambda: self._ph_pose_enc_bwd())])
+            stages.append([("l0", lambda: head("v")), ("l1", lambda: head("t")), ("main", lambda: self._ph_pose_enc_bwd())] + wq)
             stages.append([("l0", lambda: tail("v")), ("l1", lambda: tail("t"))])
-        cap_stream = {"main": torch.cuda.Stream(), "l0": LN.side[0], "l1": LN.side[1]}
+        if getattr(self, "_wstreams", None) is None:
+            self._wstreams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        cap_stream = {"main": torch.cuda.Stream(), "l0": LN.side[0], "l1": LN.side[1], "w0": self._wstreams[0], "w1": self._wstreams[1]}
         pools = {k: torch.cuda.graph_pool_handle() for k in cap_stream}
         self._capturing = True
         lanes_on, LN.on = LN.on, False            # inside a lane graph everything stays on the capture stream ...
@@ -742,12 +770,16 @@ class MVAEStep:
         LN = self.lanes
         main = torch.cuda.current_stream()
         side = {"l0": LN.side[0], "l1": LN.side[1]}
+        if self.defer_wgrad:
+            side.update({"w0": self._wstreams[0], "w1": self._wstreams[1]})
         handles = []
         for ri, row in enumerate(captured):
-            if ri == self.DEC_STAGE + 1:
+            if ri == self.DEC_STAGE + 1 and not self.defer_wgrad:
                 handles += self._reduce_bucket(0)          # decoders done: reduce them under the encoder backward
             if ri == self.DEC_STAGE + 3 and self.pg is not None:
-                handles += self._reduce_bucket(1)          # heads / pose encoder / encoder FC: under the conv stacks' backward
+                # heads / pose encoder / encoder FC: under the conv stacks' backward (with deferred decoder weight gradients,
+                # which finish next to the heads: the decoders' bucket too)
+                handles += self._reduce_bucket(0, last=1) if self.defer_wgrad else self._reduce_bucket(1)
             if len(row) == 1:
                 row[0][1].replay()
                 continue

@@ -222,14 +222,25 @@ def dgrad_bn_swish_backward(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride, offset, 
     return dy
 
 
-def wgrad(D, Gt, canon, mode, Bt, Hr, Cd, Hi, Cg, stride=1, offset=0, cg_canon=None, perm=0):
-    """canon[cd][cg][taps] = sum_rows D[row][cd] * G_tap[row][cg]  (reference weight-gradient layout)."""
+def wgrad(D, Gt, canon, mode, Bt, Hr, Cd, Hi, Cg, stride=1, offset=0, cg_canon=None, perm=0, defer=None):
+    """canon[cd][cg][taps] = sum_rows D[row][cd] * G_tap[row][cg]  (reference weight-gradient layout).
+    ``defer`` (a list): do not launch -- queue the call (nothing on the backward chain depends on a weight gradient); the
+    engine runs the queue on another stream next to the following phase (run_deferred_wgrads)."""
+    if defer is not None:
+        defer.append((D, Gt, canon, mode, Bt, Hr, Cd, Hi, Cg, stride, offset, cg_canon, perm))
+        return
     rows = Bt * Hr * Hr
     taps = 16 if mode == CONV else 1
     chunks = ops.B.wgrad_chunks(mode, rows, Cd, Cg)
     partial = _new(D, chunks, taps, Cd, Cg)
     ops.B.wgrad_tn(D, Gt, partial, mode, Bt, Hr, Hr, Cd, Hi, Hi, Cg, stride, offset, chunks)
     ops.B.wgrad_reduce(partial, canon, chunks, taps, Cd, Cg, Cg if cg_canon is None else cg_canon, perm, 0.0)
+
+
+def run_deferred_wgrads(queue):
+    """Launch (and forget) the weight-gradient GEMMs queued with ``wgrad(..., defer=queue)`` on the current stream."""
+    while queue:
+        wgrad(*queue.pop(0))
 
 
 def pack_conv(W, swap):
@@ -650,8 +661,8 @@ def decoder_backward(*a, **k):
     return run(decoder_backward_steps(*a, **k))
 
 
-def decoder_backward_steps(P, c, dlogits, grads, need_dz=True):
-    """dlogits: NCHW [Bt,3,S,S] -> dz [Bt, L]; weight gradients into ``grads``."""
+def decoder_backward_steps(P, c, dlogits, grads, need_dz=True, defer=None):
+    """dlogits: NCHW [Bt,3,S,S] -> dz [Bt, L]; weight gradients into ``grads`` (``defer``: queued, see wgrad)."""
     Bt, G, Bg, L, pk, S, st = c["Bt"], c["G"], c["Bg"], c["L"], c["pk"], c["S"], c["stages"]
     n = len(st)
 
@@ -660,23 +671,24 @@ def decoder_backward_steps(P, c, dlogits, grads, need_dz=True):
 
     # last layer backward: both GEMMs gather the k4 s2 p1 window of the NCHW logit gradient on the fly
     t = st[n - 1]
-    wgrad(t["a"], dlogits, grads[f"hallucinate.{c['last']}.weight"], IM2COL3, Bt, S // 2, 32, S, 64, cg_canon=48)
+    wgrad(t["a"], dlogits, grads[f"hallucinate.{c['last']}.weight"], IM2COL3, Bt, S // 2, 32, S, 64, cg_canon=48, defer=defer)
     # the input-gradient GEMM of every layer carries the BatchNorm+Swish backward of the layer below in its epilogue
     dy = dgrad_bn_swish_backward(dlogits, pk[f"W{n + 1}p"], IM2COL3, G, Bg, S, 64, S // 2, 32, 1, 0, t["y"], t["m"], t["r"],
                                  t["bn"], *bn_keys(t))
     yield
     for k in range(n - 1, 0, -1):
         up, t = st[k], st[k - 1]
-        wgrad(up["a_in"], dy, grads[f"hallucinate.{up['i']}.weight"], CONV, Bt, up["Hi"], up["cin"], up["Ho"], up["cout"], 2, -1)
+        wgrad(up["a_in"], dy, grads[f"hallucinate.{up['i']}.weight"], CONV, Bt, up["Hi"], up["cin"], up["Ho"], up["cout"], 2, -1,
+              defer=defer)
         dy = dgrad_bn_swish_backward(dy, pk[f"W{k + 1}k"], CONV, G, Bg, up["Ho"], up["cout"], up["Hi"], up["cin"], 2, -1,
                                      t["y"], t["m"], t["r"], t["bn"], *bn_keys(t))
         yield
     t = st[0]
-    wgrad(c["h0"], dy, grads[f"hallucinate.{t['i']}.weight"], CONV, Bt, 5, t["cin"], 8, t["cout"], 1, 0)
+    wgrad(c["h0"], dy, grads[f"hallucinate.{t['i']}.weight"], CONV, Bt, 5, t["cin"], 8, t["cout"], 1, 0, defer=defer)
     # input gradient of the k4 s1 p0 layer with the FC layer's Swish backward in its epilogue (FC level: fp32)
     du0 = dgrad_act(dy, pk["W1k"], CONV, 1, Bt, 8, t["cout"], 5, t["cin"], c["u0"], ACT_SWISH, 1, 0)
     yield
-    wgrad(du0, c["z"], grads["upsample.0.weight"], DENSE, Bt, 1, FEAT, 1, L, cg_canon=c["Lc"], perm=2)
+    wgrad(du0, c["z"], grads["upsample.0.weight"], DENSE, Bt, 1, FEAT, 1, L, cg_canon=c["Lc"], perm=2, defer=defer)
     ops.B.colsum(du0, grads["upsample.0.bias"], Bt, FEAT, 2, 0.0)
     if not need_dz:
         return None

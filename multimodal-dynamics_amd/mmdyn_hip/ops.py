@@ -447,9 +447,13 @@ class HipBackend:
                                            float(kl_weight), float(pose_multiplier), _ptr(kl_weight_dev), _stream()),
               "mmdyn_elbo_assemble")
 
-    def adam_step(self, p, g, m, v, state, lr, beta1, beta2, eps, grad_scale):
-        check(self.lib.mmdyn_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(state, torch.float64), p.numel(),
-                                       lr, beta1, beta2, eps, grad_scale, _stream()), "mmdyn_adam_step")
+    def adam_step(self, p, g, m, v, state, lr, beta1, beta2, eps, grad_scale, guarded=False):
+        """guarded: ``state`` has six doubles and a gradient holding inf / NaN skips the step (counted in state[4])."""
+        if guarded and state.numel() < 6:
+            raise ValueError("mmdyn_hip: the guarded Adam step keeps six doubles of state")
+        fn = self.lib.mmdyn_adam_step_guarded if guarded else self.lib.mmdyn_adam_step
+        check(fn(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(state, torch.float64), p.numel(), lr, beta1, beta2, eps, grad_scale,
+                 _stream()), "mmdyn_adam_step")
 
 
     def sgd_step(self, p, g, buf, lr, momentum, weight_decay, grad_scale, first):

@@ -523,7 +523,13 @@ class EmuBackend:
             tot += v
         loss[0] = tot
 
-    def adam_step(self, p, g, m, v, state, lr, beta1, beta2, eps, grad_scale):
+    def adam_step(self, p, g, m, v, state, lr, beta1, beta2, eps, grad_scale, guarded=False):
+        if guarded and not bool(torch.isfinite(g).all()):
+            state[4] += 1
+            state[5] = 1
+            return
+        if guarded:
+            state[5] = 0
         state[0] += 1
         t = float(state[0])
         state[1] = lr / (1 - beta1 ** t)

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Step-level A/B on one box: decoder weight gradients on two extra streams (--defer-wgrad on) against in-chain (off)
+mkdir -p gpurun_out/dw
+set -o pipefail
+run() {  # name, args...
+  name=$1; shift
+  timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > gpurun_out/dw/$name.json 2> gpurun_out/dw/$name.err || { tail -8 gpurun_out/dw/$name.err; exit 1; }
+}
+for i in 1 2 3; do
+  for v in off on; do
+    run b16_${v}_$i --dtype bf16s --batch 128 --steps 200 --warmup 20 --defer-wgrad $v
+    run f32_${v}_$i --steps 100 --warmup 10 --defer-wgrad $v
+  done
+done
+for v in off on; do
+  run b16b256_${v} --dtype bf16s --batch 256 --steps 100 --warmup 10 --defer-wgrad $v
+  run f16s256_${v} --dtype fp16s --batch 256 --image-size 256 --steps 20 --warmup 5 --defer-wgrad $v
+  run dyn128_${v} --image-size 128 --problem dyn_modeling --batch 128 --steps 50 --warmup 5 --defer-wgrad $v
+done
+python3 - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/dw/*.json')):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], round(d['value']), round(d['ms_per_step'],4), d['config']['final_loss'])
+PY

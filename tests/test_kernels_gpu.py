@@ -525,6 +525,31 @@ def test_adam_matches_torch():
     torch.testing.assert_close(p.cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
 
 
+def test_guarded_adam_skips_a_step_whose_gradient_overflowed():
+    """mmdyn_adam_step_guarded (the fp16 modes): a gradient buffer holding an inf or a NaN leaves parameters, moments and the
+    step count untouched and is counted; finite gradients step exactly like mmdyn_adam_step."""
+    n = 100003
+    p0, g = rnd(n, seed=33), rnd(n, seed=34) * 0.01
+    p, pr = p0.clone().to(DEV), p0.clone().to(DEV)
+    m, v, mr, vr = (torch.zeros(n, device=DEV) for _ in range(4))
+    state, ref_state = torch.zeros(6, dtype=torch.float64, device=DEV), torch.zeros(3, dtype=torch.float64, device=DEV)
+    bad = g.clone()
+    bad[n - 2] = float("inf")
+    nan = g.clone()
+    nan[7] = float("nan")
+    for gg, finite in ((g, True), (bad, False), (g * 2, True), (nan, False), (g * 3, True)):
+        before = (p.clone(), m.clone(), v.clone())
+        HIP.adam_step(p, gg.to(DEV), m, v, state, 1e-3, 0.9, 0.999, 1e-8, 1.0, guarded=True)
+        if finite:
+            HIP.adam_step(pr, gg.to(DEV), mr, vr, ref_state, 1e-3, 0.9, 0.999, 1e-8, 1.0)
+            assert torch.equal(p, pr) and torch.equal(m, mr) and torch.equal(v, vr)
+        else:
+            assert torch.equal(p, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2])
+    assert float(state[0]) == 3.0 and float(state[4]) == 2.0 and float(ref_state[0]) == 3.0
+    with pytest.raises(ValueError):
+        HIP.adam_step(p, g.to(DEV), m, v, ref_state, 1e-3, 0.9, 0.999, 1e-8, 1.0, guarded=True)
+
+
 def test_latent_and_loss_kernels():
     B, L, P = 5, 256, 3
     heads = [rnd(B, 2 * L, seed=40 + i) for i in range(3)]

@@ -283,6 +283,45 @@ def test_fp16_precision_plumbing():
     check_extended_size_vs_oracle("cpu", 64, 3, True, n_steps=1, precision="fp16", loss_tol=2e-3, grad_tol=1e-1)
 
 
+def test_fp16_overflow_guard_skips_the_step():
+    """fp16 modes: a backward that overflowed (inf / NaN in the gradient buffer) does not reach the parameters -- the guarded Adam
+    step skips it and counts it; the loss scale shrinks with the image area (4 * B at 64x64, B / 4 at 256x256)."""
+    inputs, targets = seeded_batch(2, 5)
+    eps, masks = seeded_noise(2, 256, 14, 16, 6)
+    m = build("cnn-mvae", True, True, "cpu")
+    step = MVAEStep(m, noise=InjectedNoise(eps, masks), precision="fp16")
+    step.forward(inputs, targets, 0.02)
+    h = step.backward()
+    before = step.params.flat.clone()
+    step.params.grad[5] = float("inf")
+    step.optimizer_step(h)
+    assert torch.equal(step.params.flat, before) and step.skipped_steps == 1
+    step.forward(inputs, targets, 0.02)
+    step.optimizer_step(step.backward())
+    assert not torch.equal(step.params.flat, before) and step.skipped_steps == 1 and torch.isfinite(step.params.flat).all()
+    assert step.loss_scale == 8.0
+    i256, t256 = seeded_batch(1, 5, size=256)
+    s256 = MVAEStep(build("cnn-mvae", True, True, "cpu", size=256), precision="fp16s")
+    s256.forward(i256, t256, 0.02)
+    assert s256.loss_scale == 0.25
+
+
+def test_deferred_decoder_weight_gradients_equal_inline():
+    """defer_wgrad: the decoders' weight-gradient GEMMs are queued during the decoder backward and launched afterwards (on
+    their own streams in the replayed step) -- same calls, same operands: the gradient buffer is bit-identical."""
+    inputs, targets = seeded_batch(3, 5)
+    eps, masks = seeded_noise(3, 256, 7, 8, 6)
+    grads = []
+    for defer in (False, True):
+        step = MVAEStep(build("cnn-mvae", True, True, "cpu"), noise=InjectedNoise(eps, masks), defer_wgrad=defer)
+        step.forward(inputs, targets, 0.02)
+        step.backward()
+        grads.append(step.params.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert MVAEStep(build("cnn-mvae", True, True, "cpu"), precision="bf16s").defer_wgrad
+    assert not MVAEStep(build("cnn-mvae", True, True, "cpu")).defer_wgrad
+
+
 def test_fp16s_precision_plumbing():
     """precision="fp16s": as "fp16" with the convolution-level activations, their gradients and the packed weights stored
     in IEEE half (3 more mantissa bits than the bf16 of "bf16s" at the same bytes); FC level, logits and losses stay fp32."""
