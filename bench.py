@@ -256,7 +256,7 @@ def main():
                          "accumulate / storage / master weights (configs[4]).  fp16s: fp16 + fp16 activation storage")
     ap.add_argument("--defer-wgrad", choices=("auto", "on", "off"), default="auto",
                     help="decoder weight-gradient GEMMs on two extra streams next to the encoder backward (auto: the engine's rule, "
-                         "on in the 16-bit storage modes)")
+                         "on in fp32 on one GPU)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="BatchNorm statistics over the global batch (N > 1; one small all-reduce per BatchNorm layer and "
                          "direction, captured into the lanes' HIP graphs, each lane on its own RCCL communicator).  Default: "

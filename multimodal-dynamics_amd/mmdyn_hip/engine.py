@@ -201,9 +201,10 @@ class MVAEStep:
         self._scale_per_sample = 4.0 if precision in ("fp16", "fp16s") else 0.0
         # The decoders' weight-gradient GEMMs (nothing on the backward chain reads them) are queued during the decoder
         # backward and run on two more streams next to the encoder backward: the replayed step then has four chains in
-        # flight instead of two.  None: the measured rule (on in the 16-bit storage modes, whose launches are latency-bound and
-        # leave most of the chip idle; off in fp32, where the chip is busy and the move changes nothing).
-        self.defer_wgrad = (precision in ("bf16s", "fp16s")) if defer_wgrad is None else bool(defer_wgrad)
+        # flight instead of two.  None: the measured rule (tests/microbench/run_ab_defer_wgrad.sh, same box, alternating runs:
+        # fp32 bs 256 6.70 -> 6.64 ms, 128x128 fp32 7.04 -> 6.91; the 16-bit storage modes 0 .. -2 %) -- on in fp32 on one GPU.
+        # Data parallel: off, the decoders' gradient bucket would start its all-reduce a phase later.
+        self.defer_wgrad = (precision == "fp32" and process_group is None) if defer_wgrad is None else bool(defer_wgrad)
         self.loss_scale = 1.0
         # False (default): each image decoder runs only on the passes whose reconstruction enters the loss, so its
         # BatchNorm running buffers see 4 EMA updates per step (2 without pose) where the reference applies 7 (3).
