@@ -202,7 +202,8 @@ class MVAEStep:
         # The decoders' weight-gradient GEMMs (nothing on the backward chain reads them) are queued during the decoder
         # backward and run on two more streams next to the encoder backward: the replayed step then has four chains in
         # flight instead of two.  None: the measured rule (tests/microbench/run_ab_defer_wgrad.sh, same box, alternating runs:
-        # fp32 bs 256 6.70 -> 6.64 ms, 128x128 fp32 7.04 -> 6.91; the 16-bit storage modes 0 .. -2 %) -- on in fp32 on one GPU.
+        # fp32 bs 256 +0.3 .. 0.9 % over three boxes, 128x128 fp32 7.0 -> 6.85 ms (+2 %), 256x256 fp32 +0.5 .. 5 %; the 16-bit
+        # storage modes 0 .. -2 %) -- on in fp32 on one GPU.
         # Data parallel: off, the decoders' gradient bucket would start its all-reduce a phase later.
         self.defer_wgrad = (precision == "fp32" and process_group is None) if defer_wgrad is None else bool(defer_wgrad)
         self.loss_scale = 1.0
@@ -461,7 +462,11 @@ class MVAEStep:
 
     def _ph_dec_wgrad(self, m):
         """The decoder's queued weight-gradient GEMMs (defer_wgrad), on whatever stream is current."""
-        layers.run_deferred_wgrads(self.ctx.get("wq" + m) or [])
+        q = self.ctx.get("wq" + m) or []
+        # (graph capture: the operands stay referenced until the step's context goes, so that no later capture into the
+        #  producing lane's pool can be handed their memory while this queue's graph may still be reading it at replay)
+        self.ctx["wkeep" + m] = list(q)
+        layers.run_deferred_wgrads(q)
 
     def _ph_pose_dec_bwd(self):
         c, FP = self.ctx, self.params
@@ -716,6 +721,8 @@ class MVAEStep:
              ("main", lambda: (self._ph_pose_dec_fwd(), self._ph_pose_dec_bwd()))],
             [("main", lambda: (self._ph_assemble(), self._ph_poe_bwd()))],
         ]
+        # deferred decoder weight gradients: two more streams next to the encoder backward, joined in front of the optimiser
+        # (_replay).  Forking them one phase earlier, next to the serial latent backward, measured no better: 6.69 vs 6.68 ms.
         wq = [("w0", lambda: self._ph_dec_wgrad("v")), ("w1", lambda: self._ph_dec_wgrad("t"))] if self.defer_wgrad else []
         if self.pg is None:
             stages.append([("l0", lambda: run(self._ph_enc_bwd_steps("v"))), ("l1", lambda: run(self._ph_enc_bwd_steps("t"))),
@@ -773,14 +780,22 @@ class MVAEStep:
         side = {"l0": LN.side[0], "l1": LN.side[1]}
         if self.defer_wgrad:
             side.update({"w0": self._wstreams[0], "w1": self._wstreams[1]})
-        handles = []
+        handles, loose = [], []
         for ri, row in enumerate(captured):
             if ri == self.DEC_STAGE + 1 and not self.defer_wgrad:
                 handles += self._reduce_bucket(0)          # decoders done: reduce them under the encoder backward
             if ri == self.DEC_STAGE + 3 and self.pg is not None:
-                # heads / pose encoder / encoder FC: under the conv stacks' backward (with deferred decoder weight gradients,
-                # which finish next to the heads: the decoders' bucket too)
-                handles += self._reduce_bucket(0, last=1) if self.defer_wgrad else self._reduce_bucket(1)
+                if self.defer_wgrad:                       # (the decoders' bucket waits for their deferred weight gradients)
+                    for lane in loose:
+                        main.wait_event(side[lane].record_event())
+                    loose = []
+                    handles += self._reduce_bucket(0, last=1)
+                else:
+                    handles += self._reduce_bucket(1)      # heads / pose encoder / encoder FC: under the conv stacks' backward
+            if ri == len(captured) - 1:                    # the last row (optimiser, or the data-parallel tail) needs every gradient
+                for lane in loose:
+                    main.wait_event(side[lane].record_event())
+                loose = []
             if len(row) == 1:
                 row[0][1].replay()
                 continue
@@ -794,8 +809,12 @@ class MVAEStep:
                 if lane == "main":
                     g.replay()
             for lane, g in row:
-                if lane != "main":
+                if lane.startswith("w"):
+                    loose.append(lane)                     # joined in front of the optimiser, not at the end of this row
+                elif lane != "main":
                     main.wait_event(side[lane].record_event())
+        for lane in loose:
+            main.wait_event(side[lane].record_event())
         return handles
 
     @torch.no_grad()

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Step-level A/B on one box: decoder weight gradients on two extra streams (--defer-wgrad on) against in-chain (off)
 mkdir -p gpurun_out/dw
+rm -f gpurun_out/dw/*.json
 set -o pipefail
 run() {  # name, args...
   name=$1; shift
@@ -8,14 +9,13 @@ run() {  # name, args...
 }
 for i in 1 2 3; do
   for v in off on; do
-    run b16_${v}_$i --dtype bf16s --batch 128 --steps 200 --warmup 20 --defer-wgrad $v
     run f32_${v}_$i --steps 100 --warmup 10 --defer-wgrad $v
   done
 done
 for v in off on; do
-  run b16b256_${v} --dtype bf16s --batch 256 --steps 100 --warmup 10 --defer-wgrad $v
-  run f16s256_${v} --dtype fp16s --batch 256 --image-size 256 --steps 20 --warmup 5 --defer-wgrad $v
+  run b16_${v} --dtype bf16s --batch 128 --steps 200 --warmup 20 --defer-wgrad $v
   run dyn128_${v} --image-size 128 --problem dyn_modeling --batch 128 --steps 50 --warmup 5 --defer-wgrad $v
+  run f32b64s256_${v} --image-size 256 --batch 64 --steps 20 --warmup 5 --defer-wgrad $v
 done
 python3 - <<'PY'
 import json,glob
