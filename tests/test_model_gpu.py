@@ -403,11 +403,14 @@ def test_extended_sizes_full_batch_properties(size, B, precision):
         m = T.build("cnn-mvae", True, True, DEV, size=size)
         step = MVAEStep(m, noise=NoiseSource(7), precision=precision)
         run = []
-        for s in range(4):
+        # (the fp16 modes at 256x256: round 2's loss scale overflowed in the fourth step with bench.py's batch -- more steps,
+        #  and the overflow guard must not have fired)
+        for s in range(10 if (size == 256 and precision.startswith("fp16")) else 4):
             loss = step.train_step_graphed(gi, gt, klw) if graphed else step.train_step(gi, gt, klw)
             assert abs(float(step.partials[:7].sum()) - float(loss)) <= 1e-4 * abs(float(loss))
             assert torch.isfinite(step.params.grad).all()
             run.append(float(loss))
+        assert step.skipped_steps == 0
         runs.append(run)
     assert runs[0] == runs[1]
     assert runs[2] == pytest.approx(runs[0], rel=1e-6)
