@@ -612,7 +612,9 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
     }
     g.tiles_per_group = 16 * g.tiles_per_pixel * g.s1p0_split;   // 16 pixel quads per group, 4 pixels walked per block (pair)
   }
-  // all-bf16 operands (the 64-channel K-step variant) with >= 2048 blocks: ONE output pixel per block (ONEPX at the kernel).
+  // all-bf16 operands (the 64-channel K-step variant) with >= 2048 or <= 512 one-pixel blocks: ONE output pixel per block (ONEPX at
+  // the kernel) -- round 3, tests/microbench/ab_s1p0_b16.py: 1 x 128 samples 40 vs 46 us, 4 x 64 47 vs 57, 1 x 256 40 vs 46; only
+  // the 1024-block case (4 x 128) prefers the pair walk (63 vs 67 us).
   // Measured on 4 x 256 samples, 256 -> 128 channels: 79 us against 96 us for the pair walk (4 x 128 samples, 1024 blocks:
   // 65 vs 59 us, stays on the pair walk).  fp32: the balanced quad walk wins (325 vs 376 us).  MMDYN_S1P0_SPLIT=2 / 4 force
   // the pair walk / one pixel per block for the bf16 variants (kernel experiments).
@@ -621,7 +623,7 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
     const char* e = lab_env("MMDYN_S1P0_SPLIT");
     const int forced = e ? atoi(e) : 0;
     const long blocks1 = (long)g.G * 64 * g.tiles_per_pixel * (g.N / BN);
-    if (forced == 4 || (forced == 0 && blocks1 >= 2048)) {
+    if (forced == 4 || (forced == 0 && (blocks1 >= 2048 || blocks1 <= 512))) {
       onepx = true;
       g.s1p0_split = 4;
       g.tiles_per_group = 64 * g.tiles_per_pixel;
