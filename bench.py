@@ -279,6 +279,7 @@ def main():
     # barriers, max-over-ranks timing, the JSON line -- on CPU with gloo and the kernels replaced by the test suite's
     # emulation.  The numbers are meaningless and the line says so; the product path below never takes this branch.
     dry = os.environ.get("MMDYN_BENCH_DRYRUN") == "emu"
+    rehearse = False
     if dry:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from emu_backend import EmuBackend
@@ -290,6 +291,11 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+        # MMDYN_BENCH_REHEARSE_ONE_GPU=1 (rehearsal on a one-GPU box): every rank on cuda:0, collectives over gloo -- the real
+        # kernels, HIP graphs and the data-parallel schedule (buckets between the graph rows), without RCCL.  The line says so.
+        rehearse = os.environ.get("MMDYN_BENCH_REHEARSE_ONE_GPU") == "1"
+        if rehearse:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     sync = (lambda: None) if dry else torch.cuda.synchronize
@@ -298,7 +304,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if dry:
+        if dry or rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -484,6 +490,8 @@ def main():
             "flop_per_filled_byte": 16.0, "fill_rate_TBps": 7.5, "ceiling_tflops": 120.0,
             "frac_of_fill_ceiling": achieved / 120.0,
             "source": "profiles/r3/ws_ring_diag_stall_fractions.txt; MI355X_MICROARCH.md 'Indexed rows: gather into LDS'"}
+    if rehearse:
+        out["rehearsal"] = "all ranks on ONE GPU, collectives over gloo (MMDYN_BENCH_REHEARSE_ONE_GPU=1): schedule check, not a scaling number"
     if dry:
         out["dry_run"] = "CPU rehearsal with emulated kernels (MMDYN_BENCH_DRYRUN=emu): control flow only, numbers meaningless"
     if args.breakdown:
