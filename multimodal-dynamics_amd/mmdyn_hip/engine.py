@@ -119,7 +119,7 @@ class _Lanes:
 
     def __init__(self, device, enabled=True):
         self.on = enabled and device.type == "cuda"
-        if self.on:
+        if device.type == "cuda":        # (the graph path replays its lane graphs on these even when eager launches stay on one stream)
             self.side = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
 
     def fork(self):

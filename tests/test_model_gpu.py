@@ -501,3 +501,16 @@ def test_data_parallel_schedule_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["launch"] == "hip_graph" and "rehearsal" in d
     assert np.isfinite(d["config"]["final_loss"]) and d["config"]["final_loss"] < 90000.0
+
+
+def test_single_lane_engine_replays_graphs_too():
+    """MVAEStep(two_lanes=False) -- the diagnostic form bench.py --single-lane builds -- captures and replays its step like the
+    two-lane engine (it used to fail in the capture: no side streams) and trains identically."""
+    B, klw = 8, 0.02
+    inputs, targets = seeded_batch(B, 5)
+    gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+    runs = []
+    for two in (True, False):
+        step = MVAEStep(T.build("cnn-mvae", True, True, DEV), noise=NoiseSource(11), two_lanes=two)
+        runs.append([float(step.train_step_graphed(gi, gt, klw)) for _ in range(4)])
+    assert runs[0] == pytest.approx(runs[1], rel=1e-6) and runs[0][-1] < runs[0][0]
