@@ -14,70 +14,94 @@ namespace {
 
 constexpr int TI = 16;          // input tile edge
 constexpr int TH = TI + 2;      // with halo
-constexpr int PIX_LD = 36;      // floats per staged pixel (32 channels + 16-byte pad)
+constexpr int PX_LD = 20;       // floats per staged pixel ROW of one channel (18 + pad)
+constexpr int CH_LD = TH * PX_LD;   // floats per channel plane
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Round 3: the arithmetic is packed.  The two output columns (2j, 2j+1) of an input pixel j read the input pixels
+// (j+1-tw, j+2-tw) and the ADJACENT weights (kw = 1+2tw, 2tw), so one v_pk_fma_f32 serves both -- IF the two input pixels sit
+// in one register pair.  The tile is therefore staged channel-major, [32 ch][18 rows][18 px]: a pixel pair of one channel
+// is two neighbouring floats.  768 packed FMAs per thread and no register shuffles, against 1536 + ~1000 v_mov when the pairs
+// had to be assembled from pixel-major 16-byte reads (82 -> 5x us per launch on 4 x 256 samples).
 template <typename TA>
 __global__ __launch_bounds__(256) void tconv_out3_kernel(const TA* __restrict__ a,         // [Bt][Hi][Wi][32]
                                                          const float* __restrict__ w,      // [32][3][4][4]
                                                          float* __restrict__ out,          // [Bt][3][2Hi][2Wi]
                                                          int Hi, int Wi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* tile = reinterpret_cast<float*>(smem);           // [TH*TH][PIX_LD]
+  float* tile = reinterpret_cast<float*>(smem);           // [32][TH][PX_LD]
   const int tid = threadIdx.x;
   const int tiles_x = Wi / TI;
   const int b = blockIdx.y;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * TI - 1, x0 = tx * TI - 1;           // top-left of the halo tile
 
-  // stage: TH*TH pixels x 8 float4
-  for (int idx = tid; idx < TH * TH * 8; idx += 256) {
+  // stage: TH*TH pixels x 8 float4, transposed to channel planes.  All of a thread's loads are issued before the first
+  // store: as a load -> store loop the eleven round trips were serial and the launch latency-bound (10 us of a block's 13)
+  constexpr int NLD = (TH * TH * 8 + 255) / 256;
+  f32x4 val[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int idx = tid + 256 * k;
     const int p = idx >> 3, v = idx & 7;
     const int py = p / TH, px = p - py * TH;
     const int y = y0 + py, x = x0 + px;
-    f32x4 val = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi)
-      val = ld4<TA>(a + ((size_t)(b * Hi + y) * Wi + x) * 32 + v * 4);
-    *reinterpret_cast<f32x4*>(&tile[p * PIX_LD + v * 4]) = val;
+    const bool ok = idx < TH * TH * 8 && (unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    // (masked lanes read a valid dummy address: a predicated load would be sunk into its own branch)
+    const f32x4 r = ld4<TA>(a + (ok ? ((size_t)(b * Hi + y) * Wi + x) * 32 + v * 4 : (size_t)0));
+    val[k] = ok ? r : z;
+  }
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < TH * TH * 8) {
+      const int p = idx >> 3, v = idx & 7;
+      const int py = p / TH, px = p - py * TH;
+      float* dst = tile + (size_t)(v * 4) * CH_LD + py * PX_LD + px;
+      dst[0] = val[k][0];
+      dst[CH_LD] = val[k][1];
+      dst[2 * CH_LD] = val[k][2];
+      dst[3 * CH_LD] = val[k][3];
+    }
   }
   __syncthreads();
 
   const int li = tid >> 4, lj = tid & 15;                 // input pixel inside the tile
-  float acc[2][2][3];
+  f32x2 acc[2][3];                                        // [ph][co] = (output column 2j, 2j+1)
 #pragma unroll
   for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-    for (int pw = 0; pw < 2; ++pw)
-#pragma unroll
-      for (int co = 0; co < 3; ++co) acc[ph][pw][co] = 0.f;
+    for (int co = 0; co < 3; ++co) acc[ph][co] = (f32x2){0.f, 0.f};
 
-  // output (2i+ph, 2j+pw) <- input (i+ph-th, j+pw-tw), kernel tap (1-ph+2th, 1-pw+2tw)
+  // output (2i+ph, 2j+pw) <- input (i+ph-th, j+pw-tw), kernel tap (kh, kw) = (1-ph+2th, 1-pw+2tw):
+  // for a fixed tw the pair pw = (0, 1) reads the input pair (j+1-tw, j+2-tw) [tile columns lj+1-tw, lj+2-tw] and the weight
+  // pair (kw = 1+2tw, kw = 2tw)
+  const float* base = tile + li * PX_LD + lj;
+#pragma unroll 4
+  for (int ci = 0; ci < 32; ++ci) {
+    const float* pc = base + ci * CH_LD;
+    f32x2 in[3][2];                                       // [dy][tw]: tw = 0 -> columns (lj+1, lj+2), tw = 1 -> (lj, lj+1)
 #pragma unroll
-  for (int c4 = 0; c4 < 8; ++c4) {
-    f32x4 nb[3][3];
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx)
-        nb[dy][dx] = *reinterpret_cast<const f32x4*>(&tile[((li + dy) * TH + (lj + dx)) * PIX_LD + c4 * 4]);
+    for (int dy = 0; dy < 3; ++dy) {
+      const float c0 = pc[dy * PX_LD], c1 = pc[dy * PX_LD + 1], c2 = pc[dy * PX_LD + 2];
+      in[dy][0] = (f32x2){c1, c2};
+      in[dy][1] = (f32x2){c0, c1};
+    }
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-      for (int th = 0; th < 2; ++th)
+      for (int th = 0; th < 2; ++th) {
+        const int dy = 1 + ph - th, kh = 1 - ph + 2 * th;
 #pragma unroll
-        for (int pw = 0; pw < 2; ++pw)
+        for (int tw = 0; tw < 2; ++tw)
 #pragma unroll
-          for (int tw = 0; tw < 2; ++tw) {
-            const int dy = 1 + ph - th, dx = 1 + pw - tw;          // neighbour index 0..2
-            const int kh = 1 - ph + 2 * th, kw = 1 - pw + 2 * tw;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int ci = c4 * 4 + k;
-              const float v = nb[dy][dx][k];
-#pragma unroll
-              for (int co = 0; co < 3; ++co)
-                acc[ph][pw][co] = fmaf(v, w[((ci * 3 + co) * 4 + kh) * 4 + kw], acc[ph][pw][co]);
-            }
+          for (int co = 0; co < 3; ++co) {
+            const float* wp = w + ((ci * 3 + co) * 4 + kh) * 4 + 2 * tw;       // (kw = 2tw, 2tw+1): (pw = 1, pw = 0)
+            const f32x2 w2 = {wp[1], wp[0]};
+            acc[ph][co] = __builtin_elementwise_fma(in[dy][tw], w2, acc[ph][co]);
           }
+      }
   }
 
   const int Ho = 2 * Hi, Wo = 2 * Wi;
@@ -85,10 +109,8 @@ __global__ __launch_bounds__(256) void tconv_out3_kernel(const TA* __restrict__ 
 #pragma unroll
   for (int co = 0; co < 3; ++co)
 #pragma unroll
-    for (int ph = 0; ph < 2; ++ph) {
-      float2 v2 = make_float2(acc[ph][0][co], acc[ph][1][co]);
-      *reinterpret_cast<float2*>(out + (((size_t)b * 3 + co) * Ho + oy + ph) * Wo + ox) = v2;
-    }
+    for (int ph = 0; ph < 2; ++ph)
+      *reinterpret_cast<f32x2*>(out + (((size_t)b * 3 + co) * Ho + oy + ph) * Wo + ox) = acc[ph][co];
 }
 
 }  // namespace
@@ -99,7 +121,7 @@ extern "C" int mmdyn_tconv_out3_fwd(const float* a, const float* w, float* out, 
   if (Bt <= 0 || Hi % TI || Wi % TI || Bt > 65535) return MMDYN_ERR_SHAPE;
   if ((int64_t)Bt * Hi * Wi * 32 >= (1LL << 31)) return MMDYN_ERR_RANGE;
   dim3 grid((Hi / TI) * (Wi / TI), Bt);
-  size_t smem = (size_t)TH * TH * PIX_LD * sizeof(float);
+  size_t smem = (size_t)32 * CH_LD * sizeof(float);
   hipLaunchKernelGGL(tconv_out3_kernel<float>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi);
   MMDYN_LAUNCH_CHECK();
 }
@@ -111,7 +133,7 @@ extern "C" int mmdyn_tconv_out3_fwd_b16(const uint16_t* a, const float* w, float
   if (Bt <= 0 || Hi % TI || Wi % TI || Bt > 65535) return MMDYN_ERR_SHAPE;
   if ((int64_t)Bt * Hi * Wi * 32 >= (1LL << 31)) return MMDYN_ERR_RANGE;
   dim3 grid((Hi / TI) * (Wi / TI), Bt);
-  size_t smem = (size_t)TH * TH * PIX_LD * sizeof(float);
+  size_t smem = (size_t)32 * CH_LD * sizeof(float);
   if (half)
     hipLaunchKernelGGL(tconv_out3_kernel<half_t>, grid, dim3(256), smem, (hipStream_t)stream, (const half_t*)a, w, out, Hi, Wi);
   else

@@ -72,14 +72,27 @@ __global__ __launch_bounds__(512) void tconv_patch_kernel(const float* __restric
   for (int u = blockIdx.x; u < Bt * K::TILES; u += gridDim.x) {
     const int b = u / K::TILES, y0 = (u - b * K::TILES) * TH;          // image, first input row of the tile
     __syncthreads();                           // the previous tile's LDS reads are done
-    for (int i = tid; i < PH2 * PW2 * (CIN / 4); i += 512) {
+    // (all of a thread's patch loads are issued before its first LDS store: as a load -> store loop the ten round trips
+    //  were serial -- ~10 us of a block's ~70 at one block per CU)
+    constexpr int NPIECE = PH2 * PW2 * (CIN / 4), NLD = (NPIECE + 511) / 512;
+    f32x4 pv[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + 512 * k;
       const int c4 = i % (CIN / 4), p = i / (CIN / 4);
       const int py = p / PW2, px = p - py * PW2;
       const int iy = y0 + py - 1, ix = px - 1;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-        v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(X + (((size_t)b * H + iy) * W + ix) * CIN + c4 * 4));
-      *reinterpret_cast<f32x4*>(patch + (size_t)p * CP + c4 * 4) = v;
+      const bool ok = i < NPIECE && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      // (masked lanes read a valid dummy address: a predicated load would be sunk into its own branch)
+      const f32x4 r = __builtin_nontemporal_load(
+          reinterpret_cast<const f32x4*>(X + (ok ? (((size_t)b * H + iy) * W + ix) * CIN + c4 * 4 : (size_t)0)));
+      pv[k] = ok ? r : z;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + 512 * k;
+      if (i < NPIECE) *reinterpret_cast<f32x4*>(patch + (size_t)(i / (CIN / 4)) * CP + (i % (CIN / 4)) * 4) = pv[k];
     }
     bload(0, rb[0]);
     bload(1, rb[1]);
