@@ -171,39 +171,18 @@ __device__ __forceinline__ void block_atomic_add(double v, double* dst) {
   if (threadIdx.x == 0) atomicAdd(dst, red[0] + red[1] + red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ logits,
-                                                         const float* __restrict__ target,
-                                                         const float* __restrict__ mask,
-                                                         float* __restrict__ dlogit, double* __restrict__ loss,
-                                                         int64_t n, int chw, int hw, int mask_c, float grad_scale) {
-  double acc = 0.0;
-  const int64_t n4 = n >> 2;  // n is a multiple of 4 for image tensors (checked by the caller)
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    f32x4 x = reinterpret_cast<const f32x4*>(logits)[i], t = reinterpret_cast<const f32x4*>(target)[i];
-    f32x4 mk = {1.f, 1.f, 1.f, 1.f};
-    if (mask) {
-      const int64_t e0 = i * 4;
-      // mask is [B][mask_c][H][W] with mask_c == 1 (broadcast over the channels) or == C (the dataset's 3-channel
-      // segmentation mask, elementwise): torch.mul(recon_i, loss_mask) of problems.py:445-447
-      const int64_t b = e0 / chw;
-      const int rem = (int)(e0 - b * chw);
-      const int ch = rem / hw, pix = rem - ch * hw;
-      mk = *reinterpret_cast<const f32x4*>(mask + (b * mask_c + (mask_c == 1 ? 0 : ch)) * hw + pix);
-    }
-    f32x4 d;
-    float part = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float xm = x[k] * mk[k], tm = t[k] * mk[k];
-      // max(x,0) - x*t + log(1 + exp(-|x|))
-      part += fmaxf(xm, 0.f) - xm * tm + log1pf(expf(-fabsf(xm)));
-      d[k] = mk[k] * (1.f / (1.f + expf(-xm)) - tm) * grad_scale;
-    }
-    acc += (double)part;
-    if (dlogit) reinterpret_cast<f32x4*>(dlogit)[i] = d;
-  }
-  block_atomic_add(acc, loss);
+// One element of BCE-with-logits (torch.nn.functional.binary_cross_entropy_with_logits, problems.py:421-428) and its
+// derivative from ONE exponential: e = exp(-|x|) in (0, 1]; loss = max(x, 0) - x t + log(1 + e); sigmoid(x) = 1 / (1 + e) for
+// x >= 0 and e / (1 + e) below.  Hardware exp / log / reciprocal (v_exp_f32, v_log_f32, v_rcp_f32: ~1 ulp on these ranges; log
+// of 1 + e loses at most 6e-8 absolute, against terms of 0.3-0.7): the library log1pf + two expf + a division made this
+// 113 MB pass VALU-bound at 2.1 TB/s.
+__device__ __forceinline__ void bce_elem(float x, float t, float& loss, float& sig) {
+  const float e = __expf(-fabsf(x));
+  const float inv = __frcp_rn(__fadd_rn(1.f, e));
+  // (explicitly rounded products and sums: every kernel that inlines this evaluates the same expression tree, whatever
+  //  contraction the compiler would pick around it)
+  loss = __fadd_rn(__fsub_rn(fmaxf(x, 0.f), __fmul_rn(x, t)), __logf(__fadd_rn(1.f, e)));
+  sig = x >= 0.f ? inv : __fmul_rn(e, inv);
 }
 
 // The same reconstruction term for several decoder passes that share ONE target (the live passes of a modality in the
@@ -236,7 +215,7 @@ __global__ __launch_bounds__(256) void bce_logits_groups_kernel(const float* __r
     f32x4 d;
     float part = 0.f;
     if constexpr (MASKED) {
-      // the loss mask multiplies logits and target (problems.py:445-447): [B][1 or C][H][W], as in bce_logits_kernel
+      // the loss mask multiplies logits and target (problems.py:445-447): [B][1 or C][H][W] (mask_c == 1: broadcast over channels)
       const int64_t e0 = i * 4, b = e0 / chw;
       const int rem = (int)(e0 - b * chw);
       const int ch = rem / hw, pix = rem - ch * hw;
@@ -245,16 +224,21 @@ __global__ __launch_bounds__(256) void bce_logits_groups_kernel(const float* __r
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float xm = xv[k] * mk[k], tm = t[k] * mk[k];
-        part += fmaxf(xm, 0.f) - xm * tm + log1pf(expf(-fabsf(xm)));
-        d[k] = mk[k] * (1.f / (1.f + expf(-xm)) - tm) * grad_scale;
-        part_u += fmaxf(xv[k], 0.f) - xv[k] * t[k] + log1pf(expf(-fabsf(xv[k])));
+        float l, sg, lu, su;
+        bce_elem(xm, tm, l, sg);
+        bce_elem(xv[k], t[k], lu, su);
+        part += l;
+        d[k] = mk[k] * (sg - tm) * grad_scale;
+        part_u += lu;
       }
       acc_u += (double)part_u;
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        part += fmaxf(xv[k], 0.f) - xv[k] * t[k] + log1pf(expf(-fabsf(xv[k])));
-        d[k] = (1.f / (1.f + expf(-xv[k])) - t[k]) * grad_scale;
+        float l, sg;
+        bce_elem(xv[k], t[k], l, sg);
+        part += l;
+        d[k] = (sg - t[k]) * grad_scale;
       }
     }
     acc += (double)part;
@@ -366,17 +350,17 @@ extern "C" int mmdyn_reparam_bwd(const float* mu, const float* lv, const float* 
   MMDYN_LAUNCH_CHECK();
 }
 
+static int bce_groups_launch(const float* logits, const float* target, const float* mask, float* dlogit,
+                             double* loss_slots, double* unmasked_slots, const int* slot_of_group, int G, int64_t n,
+                             int chw, int hw, int mask_channels, float grad_scale, void* stream);
+
+/* one pass: the grouped kernel with a single group (the same arithmetic, to the last bit, as a multi-pass launch) */
 extern "C" int mmdyn_bce_logits(const float* logits, const float* target, const float* mask, float* dlogit,
                                 double* loss_sum, int64_t n, int chw, int hw, int mask_channels, float grad_scale,
                                 void* stream) {
-  if (!logits || !target || !loss_sum) return MMDYN_ERR_NULL;
-  if (n % 4 || (mask && (hw <= 0 || hw % 4 || chw % hw || n % chw || (mask_channels != 1 && mask_channels != chw / hw))))
-    return MMDYN_ERR_SHAPE;
-  int g = ew_grid(n / 4);
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(bce_logits_kernel, dim3(g), dim3(256), 0, ST, logits, target, mask, dlogit, loss_sum, n,
-                     chw, hw, mask_channels, grad_scale);
-  MMDYN_LAUNCH_CHECK();
+  const int slot0 = 0;
+  return bce_groups_launch(logits, target, mask, dlogit, loss_sum, nullptr, &slot0, 1, n, chw, hw, mask_channels, grad_scale,
+                           stream);
 }
 
 static int bce_groups_launch(const float* logits, const float* target, const float* mask, float* dlogit,
