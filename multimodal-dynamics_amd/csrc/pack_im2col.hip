@@ -320,6 +320,40 @@ __global__ void col2im_k4_kernel(const float* __restrict__ col, float* __restric
   }
 }
 
+// The same sum for the NHWC / tap-major form with C % 4 == 0 (the fused step's k4 s1 p0 decoder layer on small batches):
+// four channels per thread as 16-byte accesses, 32-bit index arithmetic (the element-wise kernel above spends its time in
+// 64-bit divisions and 4-byte loads: 52 us for 60 MB).
+__global__ __launch_bounds__(256) void col2im_k4_nhwc_vec_kernel(const float* __restrict__ col, float* __restrict__ out,
+                                                                 int total4, int Hi, int Wi, int Ho, int Wo, int C, int ldcol,
+                                                                 int s, int p) {
+  const int C4 = C >> 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+    const int c4 = i % C4;
+    int t = i / C4;
+    const int wo = t % Wo;
+    t /= Wo;
+    const int ho = t % Ho, b = t / Ho;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+      const int ty = ho + p - kh;
+      if (ty < 0 || (ty % s) != 0) continue;
+      const int hi = ty / s;
+      if (hi >= Hi) continue;
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw) {
+        const int tx = wo + p - kw;
+        if (tx < 0 || (tx % s) != 0) continue;
+        const int wi = tx / s;
+        if (wi >= Wi) continue;
+        const size_t row = (size_t)(b * Hi + hi) * Wi + wi;
+        acc += *reinterpret_cast<const f32x4*>(col + row * ldcol + (kh * 4 + kw) * C + c4 * 4);
+      }
+    }
+    reinterpret_cast<f32x4*>(out)[i] = acc;
+  }
+}
+
 // [B][C][HW] <-> [B][HW][C]; small tensors only (3-channel images), simple gather
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C,
                                     int HW) {
@@ -424,6 +458,11 @@ extern "C" int mmdyn_col2im_k4(const float* col, float* out, int Bt, int Hi, int
       ldcol < 16 * C)
     return MMDYN_ERR_SHAPE;
   int64_t total = (int64_t)Bt * Ho * Wo * C;
+  if (tap_major && C % 4 == 0 && ldcol % 4 == 0 && total < (1LL << 31) && (int64_t)Bt * Hi * Wi * ldcol < (1LL << 40)) {
+    hipLaunchKernelGGL(col2im_k4_nhwc_vec_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream, col, out,
+                       (int)(total / 4), Hi, Wi, Ho, Wo, C, ldcol, stride, pad);
+    MMDYN_LAUNCH_CHECK();
+  }
   if (tap_major)
     hipLaunchKernelGGL(col2im_k4_kernel<true>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, col,
                        out, Bt, Hi, Wi, Ho, Wo, C, ldcol, stride, pad);
