@@ -8,7 +8,13 @@
 
 namespace {
 
-constexpr int TILE_ROWS = 512;
+// Rows per block of the column reductions: 512 for large tensors; small ones (the encoder's last two BatchNorm layers: 6400 and
+// 16384 rows) get tiles that still give the launch ~200+ blocks -- at 512 rows they ran on 13 / 32 blocks (35 us for 13 MB).
+// ONE function for the launchers and for mmdyn_colstats_tiles (the size of the partial-sum buffer).
+static int tile_rows_for(int rows_per_group) {
+  int t = rows_per_group / 256 / 32 * 32;
+  return t < 32 ? 32 : (t > 512 ? 512 : t);
+}
 
 struct BnParams {
   const float* mean;
@@ -23,15 +29,15 @@ template <int MODE, typename TA>
 __global__ __launch_bounds__(256) void colreduce_kernel(const TA* __restrict__ y,
                                                         const TA* __restrict__ da, BnParams bp,
                                                         float* __restrict__ partial, int rows_per_group,
-                                                        int C, int T) {
+                                                        int C, int T, int tile_rows) {
   __shared__ float red[256 * 8];
   const int tid = threadIdx.x;
   const int g = blockIdx.y, t = blockIdx.x;
   const int CV = C >> 2;        // float4 columns (8..64)
   const int RL = 256 / CV;      // row lanes
   const int rl = tid / CV, cv = tid - rl * CV;
-  const int r_begin = t * TILE_ROWS;
-  const int r_end = min(rows_per_group, r_begin + TILE_ROWS);
+  const int r_begin = t * tile_rows;
+  const int r_end = min(rows_per_group, r_begin + tile_rows);
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
   f32x4 mean4, rstd4, gam4, bet4;
   if (MODE == 1 && rl < RL) {
@@ -331,7 +337,7 @@ __global__ void bn_swish_bwd_apply_kernel(const T* __restrict__ da, const T* __r
 
 }  // namespace
 
-extern "C" int mmdyn_colstats_tiles(int rows_per_group) { return ceil_div(rows_per_group, TILE_ROWS); }
+extern "C" int mmdyn_colstats_tiles(int rows_per_group) { return ceil_div(rows_per_group, tile_rows_for(rows_per_group)); }
 
 static bool bn_shape_ok(int G, int rows_per_group, int C) {
   return G > 0 && rows_per_group > 0 && C >= 32 && C <= 256 && (C % 32) == 0 && (256 % (C / 4)) == 0 &&
@@ -341,10 +347,10 @@ static bool bn_shape_ok(int G, int rows_per_group, int C) {
 extern "C" int mmdyn_colstats(const float* y, float* partial, int G, int rows_per_group, int C, void* stream) {
   if (!y || !partial) return MMDYN_ERR_NULL;
   if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
-  const int T = ceil_div(rows_per_group, TILE_ROWS);
+  const int TR = tile_rows_for(rows_per_group), T = ceil_div(rows_per_group, TR);
   BnParams bp{};
   hipLaunchKernelGGL((colreduce_kernel<0, float>), dim3(T, G), dim3(256), 0, (hipStream_t)stream, y,
-                     (const float*)nullptr, bp, partial, rows_per_group, C, T);
+                     (const float*)nullptr, bp, partial, rows_per_group, C, T, TR);
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -453,14 +459,14 @@ extern "C" int mmdyn_bn_swish_bwd_reduce_b16(const uint16_t* da, const uint16_t*
                                              int G, int rows_per_group, int C, int half, void* stream) {
   if (!da || !y || !mean || !rstd || !gamma || !beta || !partial) return MMDYN_ERR_NULL;
   if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
-  const int T = ceil_div(rows_per_group, TILE_ROWS);
+  const int TR = tile_rows_for(rows_per_group), T = ceil_div(rows_per_group, TR);
   BnParams bp{mean, rstd, gamma, beta};
   if (half)
     hipLaunchKernelGGL((colreduce_kernel<1, half_t>), dim3(T, G), dim3(256), 0, (hipStream_t)stream, (const half_t*)y,
-                       (const half_t*)da, bp, partial, rows_per_group, C, T);
+                       (const half_t*)da, bp, partial, rows_per_group, C, T, TR);
   else
     hipLaunchKernelGGL((colreduce_kernel<1, bf16_t>), dim3(T, G), dim3(256), 0, (hipStream_t)stream, y, da, bp, partial,
-                       rows_per_group, C, T);
+                       rows_per_group, C, T, TR);
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -486,10 +492,10 @@ extern "C" int mmdyn_bn_swish_bwd_reduce(const float* da, const float* y, const 
                                          float* partial, int G, int rows_per_group, int C, void* stream) {
   if (!da || !y || !mean || !rstd || !gamma || !beta || !partial) return MMDYN_ERR_NULL;
   if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
-  const int T = ceil_div(rows_per_group, TILE_ROWS);
+  const int TR = tile_rows_for(rows_per_group), T = ceil_div(rows_per_group, TR);
   BnParams bp{mean, rstd, gamma, beta};
   hipLaunchKernelGGL((colreduce_kernel<1, float>), dim3(T, G), dim3(256), 0, (hipStream_t)stream, y, da, bp, partial,
-                     rows_per_group, C, T);
+                     rows_per_group, C, T, TR);
   MMDYN_LAUNCH_CHECK();
 }
 
