@@ -785,16 +785,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int64_t ntiles = (slab + 31) / 32;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t i = tile * 32 + il;
-    float s0 = 0.f, s1 = 0.f;
+    // four independent loads per round (two made the 24 rounds of a 192-slab layer a chain of memory latencies: 12 us)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < slab) {
       int c = cl;
-      for (; c + 8 < chunks; c += 16) {
+      for (; c + 24 < chunks; c += 32) {
         s0 += partial[(size_t)c * slab + i];
         s1 += partial[(size_t)(c + 8) * slab + i];
+        s2 += partial[(size_t)(c + 16) * slab + i];
+        s3 += partial[(size_t)(c + 24) * slab + i];
       }
-      if (c < chunks) s0 += partial[(size_t)c * slab + i];
+      for (; c < chunks; c += 8) s0 += partial[(size_t)c * slab + i];
     }
-    red[cl][il] = s0 + s1;
+    red[cl][il] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (cl == 0 && i < slab) {
       float s = 0.f;
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-// Few slabs (<= 32: every layer with many weights): one thread sums ALL slabs of four consecutive elements --
+// Few slabs (<= 64: every layer with many weights): one thread sums ALL slabs of four consecutive elements --
 // `chunks` independent 16-byte loads in flight, no LDS, no barrier -- in slab order (deterministic).
 __global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __restrict__ partial,
                                                                float* __restrict__ canon, int chunks, int taps,
@@ -1055,7 +1058,7 @@ extern "C" int mmdyn_wgrad_reduce(const float* partial, float* canon, int chunks
   if (perm == 1 && (Cg % 256 || Cg / 256 != 25)) return MMDYN_ERR_SHAPE;
   if (perm == 2 && (Cd % 256 || Cd / 256 != 25)) return MMDYN_ERR_SHAPE;
   int64_t slab = (int64_t)taps * Cd * Cg;
-  if (chunks <= 32 && slab >= 65536) {
+  if (chunks <= 64 && slab >= 65536) {
     hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(ew_grid(slab >> 2)), dim3(256), 0, (hipStream_t)stream, partial,
                        canon, chunks, taps, Cd, Cg, cg_canon, perm, beta);
     MMDYN_LAUNCH_CHECK();
