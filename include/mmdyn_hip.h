@@ -256,6 +256,11 @@ int mmdyn_colsum(const float* x, float* out, float* scratch, int rows, int C, in
 int mmdyn_colsum_chunks(int rows);
 /* out = x * s[0], s in device memory (chain rule through a scalar loss term without a host sync) */
 int mmdyn_scale_dev(const float* x, const float* s, float* out, int64_t n, void* stream);
+/* Gradient buckets on the wire in bf16 (data parallel, 16-bit storage modes; the reference has no
+ * counterpart: problems.py:52, 388 train on one device): round the fp32 bucket to bf16 (RNE) in front of the all-reduce,
+ * widen it back behind it.  src / dst 16-byte (fp32 side) and 8-byte (bf16 side) aligned. */
+int mmdyn_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int mmdyn_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* sum of P row blocks: out[b][:] = sum_p x[p][b][:] */
 int mmdyn_sum_blocks(const float* x, float* out, int P, int64_t n, void* stream);
 /* tiny Linear layers of the 7-DoF pose MLP (K or N == 7; vae.py:117-123): y = x W^T + b */

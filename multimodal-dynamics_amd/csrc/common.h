@@ -201,6 +201,25 @@ __device__ __forceinline__ bool last_block_arrives(unsigned* counter, unsigned n
     return MMDYN_OK;                              \
   } while (0)
 
+// Opt-in for more than 64 KiB of dynamic LDS.  The attribute belongs to one kernel instance ON ONE DEVICE, so a launcher
+// keeps one of these per instance (a function-local static) and asks before every launch; a racing second thread only
+// repeats an idempotent call.
+struct LdsOptIn {
+  static constexpr int MAX_DEVICES = 64;
+  bool done[MAX_DEVICES] = {};
+  int ensure(const void* kernel, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= MAX_DEVICES) return MMDYN_ERR_RANGE;
+    if (done[dev]) return MMDYN_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done[dev] = true;
+    return MMDYN_OK;
+  }
+};
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -299,6 +299,22 @@ __global__ void scale_dev_kernel(const float* __restrict__ x, const float* __res
     out[i] = x[i] * k;
 }
 
+// Gradient buckets on the wire in bf16 (16-bit storage modes, SURVEY section 8e: 28.1 instead of 56.2 MB per step): the
+// flat fp32 gradient bucket is rounded (RNE, v_cvt_pk_bf16_f32) into a bf16 staging buffer in front of the all-reduce and
+// widened back (exact) behind it; Adam keeps reading fp32.  16 bytes per lane on the fp32 side.
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    st4<bf16_t>(dst + 4 * i, ld4<float>(src + 4 * i));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) st1<bf16_t>(dst + 4 * n4 + threadIdx.x, src[4 * n4 + threadIdx.x]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    st4<float>(dst + 4 * i, ld4<bf16_t>(src + 4 * i));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[4 * n4 + threadIdx.x] = ld1<bf16_t>(src + 4 * n4 + threadIdx.x);
+}
+
 __global__ void adam_tick_kernel(double* __restrict__ state, float lr, float beta1, float beta2) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double t = state[0] + 1.0;
@@ -494,6 +510,20 @@ extern "C" int mmdyn_linear_small_bwd(const float* dy, const float* x, const flo
 extern "C" int mmdyn_scale_dev(const float* x, const float* s, float* out, int64_t n, void* stream) {
   if (!x || !s || !out) return MMDYN_ERR_NULL;
   hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, x, s, out, n);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst) return MMDYN_ERR_NULL;
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return MMDYN_ERR_SHAPE;       // 16-byte / 8-byte accesses
+  if (n <= 0) return MMDYN_OK;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, ST, src, (bf16_t*)dst, n);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+  if (!src || !dst) return MMDYN_ERR_NULL;
+  if (((uintptr_t)dst & 15) || ((uintptr_t)src & 7)) return MMDYN_ERR_SHAPE;
+  if (n <= 0) return MMDYN_OK;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, ST, (const bf16_t*)src, dst, n);
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,

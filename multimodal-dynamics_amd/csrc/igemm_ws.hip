@@ -6,7 +6,7 @@
 // reference path (/root/reference/mmdyn/pytorch/models/vae.py:198-216, 264-277) for the fp32 launches it serves; every
 // other launch keeps the register-staged kernel of igemm_nt.hip.
 //
-// Why a second structure (profiles/r3/ws_ring_microbench.txt; docs/LAB_NOTES.md): in the register-staged kernel every
+// Why a second structure (profiles/r3/ws_ring_microbench_*.txt; docs/LAB_NOTES.md D): in the register-staged kernel every
 // wave gathers, loads, waits, writes LDS and multiplies; its one exposed resource is the operand fetch (+20 % without it).
 // Here a block is TWO loader waves + 4 (or 8) MFMA waves:
 //   * loader waves own the gather arithmetic.  They issue buffer_load_dwordx4 ... lds (LDS-DMA: no VGPR round trip, no
@@ -445,13 +445,8 @@ static int ws_launch(const float* A, const float* Bp, const float* bias, float* 
     grid = dim3((unsigned)8 * ((s_inner + nparts - 1) / nparts) * g.splitk);
   }
   const size_t smem = (size_t)S * (BM + BN) * RB + (size_t)BM * 16;
-  static bool attr_set = false;        // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm_ws_kernel<MODE, BM, BN, WM, WN, S, B16>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;        // (per kernel instance; per device inside)
+  if (int e = lds_opt_in.ensure((const void*)igemm_ws_kernel<MODE, BM, BN, WM, WN, S, B16>, (int)smem)) return e;
   hipLaunchKernelGGL((igemm_ws_kernel<MODE, BM, BN, WM, WN, S, B16>), grid, dim3(64 * (NM + NL)), smem, st, A, Bp, bias, C, C_act,
                      stats, ws, g, a_bytes, b_bytes);
   MMDYN_LAUNCH_CHECK();

@@ -239,11 +239,8 @@ int patch_tiles(int mode, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
 template <int H, int W, int CIN, int N, int TH>
 int patch_launch(const float* A, const float* Bp, float* C, float* stats, const IgemmGeom& g, const PatchEpi& ep, hipStream_t st) {
   using K = PatchCfg<H, W, CIN, N, TH>;
-  static const bool attr_ok = [] {
-    return hipFuncSetAttribute((const void*)tconv_patch_kernel<H, W, CIN, N, TH>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)K::SMEM) == hipSuccess;
-  }();
-  if (!attr_ok) return MMDYN_ERR_SHAPE;                     // (never observed: ~105 KB of the CU's 160 KB)
+  static LdsOptIn lds_opt_in;                               // (~105 KB of the CU's 160 KB)
+  if (int e = lds_opt_in.ensure((const void*)tconv_patch_kernel<H, W, CIN, N, TH>, (int)K::SMEM)) return e;
   const int Bt = g.G * g.Bg;
   hipLaunchKernelGGL((tconv_patch_kernel<H, W, CIN, N, TH>), dim3(Bt * K::TILES), dim3(512), K::SMEM, st, A, Bp, C, stats, Bt, g.Bg,
                      g.ldc, ep);

@@ -166,13 +166,8 @@ static int ws_launch(const float* D, const float* Gt, float* partial, WgradGeom 
   g.rows_per_chunk = ceil_div(rpc, RK) * RK;
   dim3 grid((unsigned)((g.Cd / BD) * (g.Cg / BG) * g.ntaps) * (unsigned)((g.chunks + 7) / 8 * 8));
   const size_t smem = (size_t)S * RK * (BD + BG) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_ws_kernel<MODE, BD, BG, WD, WG, RK, S>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;
+  if (int e = lds_opt_in.ensure((const void*)wgrad_ws_kernel<MODE, BD, BG, WD, WG, RK, S>, (int)smem)) return e;
   hipLaunchKernelGGL((wgrad_ws_kernel<MODE, BD, BG, WD, WG, RK, S>), grid, dim3(64 * (4 + NL)), smem, st, D, Gt, partial, g,
                      d_bytes, g_bytes);
   MMDYN_LAUNCH_CHECK();

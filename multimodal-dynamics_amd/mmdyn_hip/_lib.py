@@ -73,6 +73,8 @@ _SIGNATURES = {
     "mmdyn_colsum_chunks": "i",
     "mmdyn_scale_dev": "ppp" + "l" + "p",
     "mmdyn_sum_blocks": "pp" + "i" + "l" + "p",
+    "mmdyn_cast_f32_to_bf16": "pp" + "l" + "p",
+    "mmdyn_cast_bf16_to_f32": "pp" + "l" + "p",
     "mmdyn_linear_small_fwd": "pppp" + "iiii" + "p",
     "mmdyn_linear_small_bwd": "pppppp" + "iii" + "f" + "p",
     "mmdyn_poe_fwd": "pppppp" + "iiii" + "p",

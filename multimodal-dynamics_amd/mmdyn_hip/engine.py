@@ -112,6 +112,22 @@ class FlatParams:
         return {k[len(prefix) + 1:]: v for k, v in src.items() if k.startswith(prefix + ".")}
 
 
+class _Bf16Bucket:
+    """Handle of one gradient bucket that travels in bf16: ``wait()`` orders the current stream behind the all-reduce (like
+    the Work it wraps) and widens the reduced bucket back into the fp32 gradient buffer there."""
+
+    def __init__(self, work, engine, lo, hi):
+        self.work, self.engine, self.lo, self.hi = work, engine, lo, hi
+
+    def wait(self):
+        self.work.wait()
+        e = self.engine
+        ops.B.cast_bf16_to_f32(e._grad16[self.lo:self.hi], e.params.grad[self.lo:self.hi])
+
+    def is_completed(self):
+        return self.work.is_completed()
+
+
 class _Lanes:
     """Two side streams for the independent visual / tactile halves of the schedule (HIP streams on the GPU,
     no-ops on the CPU emulation).  Every fork starts from the main stream's current point and every join
@@ -177,7 +193,7 @@ class MVAEStep:
 
     def __init__(self, model, lr=1e-3, pose_multiplier=1000.0, betas=(0.9, 0.999), eps=1e-8, noise=None,
                  process_group=None, world_size=1, two_lanes=True, precision="fp32", exact_running_stats=False, sync_bn=False,
-                 defer_wgrad=None):
+                 defer_wgrad=None, grad_reduce_bf16=None):
         # --conditional (vae.py:231-237, 286-291): the condition joins the 512 features in front of the image encoders' heads
         # and the latent in front of the image decoders' first layer; the pose MLPs are built unconditional (vae.py:117-123)
         self.conditional = bool(getattr(model, "conditional", False))
@@ -241,6 +257,13 @@ class MVAEStep:
         self.pg, self.world = process_group, world_size
         self.params = FlatParams(model)
         dev = self.params.flat.device
+        # Gradient buckets on the wire: fp32 by default; in the 16-bit storage modes the buckets are
+        # rounded to bf16 in front of the all-reduce and widened back behind it (28.1 instead of 56.2 MB per step against a
+        # ~2 ms step; bf16 rather than fp16 also for "fp16s": the loss-scaled gradients keep fp32's range).  Adam, its
+        # moments and the master weights stay fp32.  ``grad_reduce_bf16`` overrides the rule.
+        use16 = (precision in ("bf16s", "fp16s")) if grad_reduce_bf16 is None else bool(grad_reduce_bf16)
+        self._grad16 = torch.empty(self.params.total, device=dev, dtype=torch.bfloat16) if (use16 and process_group is not None) else None
+        self._warm_works = None      # list while the warm-up step in front of a graph capture runs: its collectives' Work handles
         self.adam_m = torch.zeros_like(self.params.flat)
         self.adam_v = torch.zeros_like(self.params.flat)
         self.adam_state = torch.zeros(6, dtype=torch.float64, device=dev)     # (six: the guarded step of the fp16 modes)
@@ -602,13 +625,23 @@ class MVAEStep:
         import torch.distributed as dist
         lo = 0 if i == 0 else self.params.bucket_bounds[i - 1]
         hi = self.params.bucket_bounds[i if last is None else last]
-        return [dist.all_reduce(self.params.grad[lo:hi], group=self.pg, async_op=True)]
+        if self._grad16 is not None:
+            ops.B.cast_f32_to_bf16(self.params.grad[lo:hi], self._grad16[lo:hi])
+            h = _Bf16Bucket(dist.all_reduce(self._grad16[lo:hi], group=self.pg, async_op=True), self, lo, hi)
+        else:
+            h = dist.all_reduce(self.params.grad[lo:hi], group=self.pg, async_op=True)
+        if self._warm_works is not None:
+            self._warm_works.append(h)
+        return [h]
 
-    def optimizer_step(self, handles=()):
+    def optimizer_step(self, handles=(), loss_scale=None):
+        """``loss_scale``: the scale the gradients in the flat buffer were produced with, when that is not the one of the
+        latest ``_begin`` (a graph replay: the captured backward keeps the scale of its capture)."""
         for h in handles:
             h.wait()
+        scale = self.loss_scale if loss_scale is None else loss_scale
         ops.B.adam_step(self.params.flat, self.params.grad, self.adam_m, self.adam_v, self.adam_state, self.lr,
-                        self.betas[0], self.betas[1], self.eps, 1.0 / (self.world * self.loss_scale),
+                        self.betas[0], self.betas[1], self.eps, 1.0 / (self.world * scale),
                         guarded=bool(self._scale_per_sample))
 
     @property
@@ -653,12 +686,18 @@ class MVAEStep:
             side.wait_stream(torch.cuda.current_stream())
             if self._sync is not None:
                 self._sync.pending = []                        # keep the Work handles of the warm-up's collectives
+            if self.pg is not None:
+                self._warm_works = []                          # (gradient buckets: _reduce_bucket)
             with torch.cuda.stream(side):                      # warm-up outside capture (allocator, lazy init)
                 self.train_step(self._static_in, self._static_tg, kl_weight, self._static_mask, self._static_cond)
             torch.cuda.current_stream().wait_stream(side)
             if self.pg is not None:
                 self._drain_before_capture(key)
-            self._graph = (key, self._capture(kl_weight))
+            captured = self._capture(kl_weight)
+            # the loss scale baked into the captured backward: an eval_step or an eager step on another batch size in
+            # between rewrites self.loss_scale, the replayed gradients keep this one (the eager Adam of the data-parallel
+            # replay divides by it)
+            self._graph = (key, captured, self.loss_scale)
             return self.loss             # the warm-up above WAS this call's optimiser step
         for dst, src in zip(self._static_in + self._static_tg, list(inputs) + list(targets)):
             if dst.data_ptr() != src.data_ptr():
@@ -671,24 +710,29 @@ class MVAEStep:
         if self.pg is not None:
             # buckets 0 and 1 were reduced under the encoder backward graphs; the conv stacks' gradients go now
             handles += self._reduce_bucket(2)
-            self.optimizer_step(handles)
+            self.optimizer_step(handles, loss_scale=self._graph[2])
         return self.loss
 
     WATCHDOG_SWEEP_S = 0.1       # ProcessGroupNCCL's watchdog thread looks at its list of un-retired Work objects every 100 ms
+    DRAIN_TIMEOUT_S = 60.0
 
     def _drain_before_capture(self, key):
         """Everything a captured step with RCCL collectives relies on, made explicit before the capture starts.
 
         (1) Every rank must be about to capture the SAME step (a capture on one rank only would leave the lane
         communicators waiting for collectives nobody issues): the capture keys are compared across ranks, a mismatch is an
-        error on every rank instead of a hang.  (2) The warm-up's collectives must be finished AND retired: their Work
-        handles (gradient buckets: waited on in optimizer_step; SyncBN statistics: layers.SyncBN.pending) are waited on,
-        the device is synchronised, and one barrier per communicator proves that every rank got that far.  (3) The process
-        group's watchdog THREAD polls the events of un-retired Work objects; a poll that lands while a communicator's
-        stream is capturing fails ("operation not permitted on an event last recorded in a capturing stream") and aborts
-        the process.  With (2) done every Work is complete, so the next watchdog sweep retires them all; the sweep interval
-        is the documented 100 ms (WATCHDOG_SWEEP_S; TORCH_NCCL_* settings do not change it), we wait 2.5 of them.  The
-        capture itself runs with capture_error_mode="thread_local", so API calls of other threads cannot invalidate it."""
+        error on every rank instead of a hang.  (2) The warm-up's collectives must be finished: their Work handles (gradient
+        buckets: kept by _reduce_bucket; SyncBN statistics: layers.SyncBN.pending) are polled with ``is_completed()`` until
+        every one answers True (bounded by DRAIN_TIMEOUT_S: a Work that never completes is an error, not a hang), the device
+        is synchronised, and one barrier per communicator proves that every rank got that far.  (3) The process group's
+        watchdog THREAD polls the events of Work objects it has not retired yet; a poll that lands while a communicator's
+        stream is capturing fails ("operation not permitted on an event last recorded in a capturing stream") and aborts the
+        process.  Retirement itself cannot be observed from Python -- the ProcessGroupNCCL / Work bindings of torch 2.10 expose
+        ``is_completed()``, which answers for the GPU side of a Work, and nothing about the watchdog's list -- but it follows
+        from (2): every Work is complete on every rank, so the watchdog's NEXT sweep retires them all, and a sweep starts
+        every WATCHDOG_SWEEP_S (the documented 100 ms; TORCH_NCCL_* settings do not change it).  One sweep interval plus a
+        fifth is therefore waited after the last barrier (round 3 slept 2.5 intervals without knowing the Works' state).
+        The capture itself runs with capture_error_mode="thread_local", so API calls of other threads cannot invalidate it."""
         import time
         import torch.distributed as dist
         keys = [None] * self.world
@@ -697,16 +741,22 @@ class MVAEStep:
             raise RuntimeError(f"mmdyn_hip: ranks are about to capture different steps {keys}: every rank must see the same "
                                "batch shapes (shard evenly, drop the last partial batch)")
         groups = [self.pg]
+        works = list(self._warm_works or [])
+        self._warm_works = None
         if self._sync is not None:
-            for w in self._sync.pending or []:
-                w.wait()
+            works += list(self._sync.pending or [])
             self._sync.pending = None
             groups += list(self._sync.lane_groups or [])
+        deadline = time.monotonic() + self.DRAIN_TIMEOUT_S
+        while not all(w.is_completed() for w in works):
+            if time.monotonic() > deadline:
+                raise RuntimeError("mmdyn_hip: a collective of the warm-up step did not complete before the graph capture")
+            time.sleep(0.001)
         torch.cuda.synchronize()
         for g in groups:
             dist.barrier(group=g)
         torch.cuda.synchronize()
-        time.sleep(2.5 * self.WATCHDOG_SWEEP_S)
+        time.sleep(1.2 * self.WATCHDOG_SWEEP_S)
 
     def _capture(self, kl_weight):
         LN = self.lanes

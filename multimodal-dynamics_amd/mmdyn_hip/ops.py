@@ -85,19 +85,30 @@ class HipBackend:
 
     def _ticket(self, like):
         """Address of a zero-initialised arrival counter for ONE launch (the "last block finishes" kernels:
-        mmdyn_bn_finalize, mmdyn_bn_bwd_finalize, mmdyn_colsum).  Slots are handed out round-robin: a slot comes up again
-        only after 4096 such launches -- far more than a train step issues -- so no two launches in flight (the two lanes
-        of the engine, or the nodes of one captured HIP graph) ever share one; the kernel that used a slot leaves it zero."""
+        mmdyn_bn_finalize, mmdyn_bn_bwd_finalize, mmdyn_colsum); the kernel that used a slot leaves it zero.
+        A launch recorded into a HIP graph keeps its slot for every replay, so captured launches draw from the lower half
+        of the pool and a slot handed out there is NEVER reissued (a process that captures more than 2048 such launches is
+        told so).  Eager launches cycle through the upper half: a slot comes up again only after 2048 eager launches of
+        this kind -- far more than a train step issues -- so no two launches in flight share one, and none can meet a
+        slot that a replaying graph owns."""
         if not (_USE_TICKET or self.force_ticket):
             return None
         dev = like.device
         ent = self._tickets.get(dev)
         if ent is None:
-            ent = [torch.zeros(self.TICKET_SLOTS * self.TICKET_STRIDE, dtype=torch.int32, device=dev), 0]
+            ent = [torch.zeros(self.TICKET_SLOTS * self.TICKET_STRIDE, dtype=torch.int32, device=dev), 0, 0]
             self._tickets[dev] = ent
-        pool, nxt = ent
-        ent[1] = (nxt + 1) % self.TICKET_SLOTS
-        return pool.data_ptr() + 4 * self.TICKET_STRIDE * nxt
+        pool, nxt_eager, nxt_graph = ent
+        half = self.TICKET_SLOTS // 2
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            if nxt_graph >= half:
+                raise RuntimeError("mmdyn_hip: ticket slots for captured launches exhausted (2048 per device)")
+            ent[2] = nxt_graph + 1
+            slot = nxt_graph
+        else:
+            ent[1] = (nxt_eager + 1) % half
+            slot = half + nxt_eager
+        return pool.data_ptr() + 4 * self.TICKET_STRIDE * slot
 
     @property
     def lib(self):
@@ -357,6 +368,15 @@ class HipBackend:
 
     def sum_blocks(self, x, out, P, n):
         check(self.lib.mmdyn_sum_blocks(_ptr(x), _ptr(out), P, n, _stream()), "mmdyn_sum_blocks")
+
+    def cast_f32_to_bf16(self, src, dst):
+        """dst (bf16, same element count) = RNE(src): the gradient bucket on its way to the all-reduce."""
+        check(self.lib.mmdyn_cast_f32_to_bf16(_ptr(src), _ptr(dst, torch.bfloat16), src.numel(), _stream()),
+              "mmdyn_cast_f32_to_bf16")
+
+    def cast_bf16_to_f32(self, src, dst):
+        check(self.lib.mmdyn_cast_bf16_to_f32(_ptr(src, torch.bfloat16), _ptr(dst), src.numel(), _stream()),
+              "mmdyn_cast_bf16_to_f32")
 
     def linear_small_fwd(self, x, W, b, y, rows, K, N, act):
         check(self.lib.mmdyn_linear_small_fwd(_ptr(x), _ptr(W), _ptr(b), _ptr(y), rows, K, N, act, _stream()),

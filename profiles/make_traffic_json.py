@@ -34,7 +34,7 @@ if __name__ == "__main__":
         "source_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 "
                        "--warmup 1 --no-graph --no-cpu-baseline <args>; FETCH_SIZE doubled (gfx950 correction, "
                        "MI355X_MICROARCH.md HBM section); KiB units; aggregated by tests/microbench/pmc_by_kernel.py "
-                       "(profiles/collect_r3.sh traffic)",
+                       "(profiles/collect_r4.sh traffic)",
         "workload": sys.argv[3],
         "bench_args": sys.argv[4:],
         "kernel": "igemm_ws_kernel + igemm_nt_kernel (every implicit-GEMM launch of the step; the 3-channel layers run "

@@ -379,6 +379,12 @@ class EmuBackend:
     def sum_blocks(self, x, out, P, n):
         out.reshape(-1).copy_(x.reshape(P, n).sum(0))
 
+    def cast_f32_to_bf16(self, src, dst):
+        dst.copy_(src.to(torch.bfloat16))
+
+    def cast_bf16_to_f32(self, src, dst):
+        dst.copy_(src.to(torch.float32))
+
     def linear_small_fwd(self, x, W, b, y, rows, K, N, act):
         o = x.reshape(rows, K) @ W.reshape(N, K).t()
         if b is not None:

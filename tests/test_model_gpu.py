@@ -256,6 +256,34 @@ def test_graphed_step_with_process_group_equals_single(tmp_path, nccl_group):
     assert float((out[0][1] - out[1][1]).norm() / out[0][1].norm()) < 1e-6
 
 
+def test_fp16_graph_replay_with_process_group_keeps_its_loss_scale(nccl_group):
+    """in the fp16 modes the loss scale is 4 * B of the LATEST _begin(); the data-parallel graph replay
+    runs Adam eagerly, so an eval_step on another batch size between two replays must not change the scale Adam divides
+    by.  Train (graphed, B = 8), evaluate B = 4, train again == train, train."""
+    B, klw = 8, 0.02
+    inputs, targets = seeded_batch(B, 95)
+    gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+    out = []
+    for with_eval in (False, True):
+        m = T.build("cnn-mvae", True, True, DEV)
+        step = MVAEStep(m, noise=NoiseSource(96), process_group=nccl_group, world_size=1, precision="fp16")
+        step.train_step_graphed(gi, gt, klw)               # warm-up + capture
+        step.train_step_graphed(gi, gt, klw)               # first replay
+        if with_eval:
+            step.eval_step([x[:4] for x in gi], [x[:4] for x in gt], klw)
+            assert step.loss_scale == 4.0 * 4 and step._graph[2] == 4.0 * B
+        loss = float(step.train_step_graphed(gi, gt, klw))
+        torch.cuda.synchronize()
+        out.append((loss, step.params.flat.clone(), step.adam_m.clone()))
+        assert step.skipped_steps == 0
+        step.close()
+        del step
+    # (the evaluation draws from the device-side noise stream, so the step after it sees other noise: compare the moments'
+    #  magnitude, which a gradient scaled by 2 would double, and the parameters, which must have moved equally far)
+    assert float(out[1][2].norm() / out[0][2].norm()) == pytest.approx(1.0, rel=0.15)     # (stale scale: 1.37)
+    assert out[0][0] == pytest.approx(out[1][0], rel=2e-2)
+
+
 def test_sync_bn_inside_the_phase_graphs(tmp_path, nccl_group):
     """SyncBN statistics all-reduces captured INTO the lanes' HIP graphs (each lane on its own RCCL communicator, so the
     two concurrently replayed graphs never interleave collectives of one communicator): graph replay == eager launches,
