@@ -70,10 +70,11 @@ int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C,
  * x * act'(u) pass of loss.backward() through Swish / ReLU, vae.py:14-19, 215, 267, 331-334):
  *     C = (A x Bp) * act'(u),   u = the layer's saved pre-activation at the C positions (row stride N),
  * act = MMDYN_ACT_SWISH or MMDYN_ACT_RELU (for ReLU u may be the activated output: same sign).  No bias, second output,
- * statistics or split-K.  flags: 0 = fp32 everywhere; otherwise as mmdyn_igemm_nt_mx (bit 3: u is bf16). */
+ * statistics or split-K.  flags: 0 = fp32 everywhere; otherwise as mmdyn_igemm_nt_mx (bit 3: u is bf16).
+ * ws: workspace of mmdyn_igemm_slab_floats(...) floats (NULL when that is 0). */
 int mmdyn_igemm_nt_dgrad_act(const void* A, const void* Bp, void* C, const void* u, int act, int mode, int G, int Bg,
                              int Hi, int Wi, int Cin, int Ho, int Wo, int N, int stride, int offset, int flags,
-                             void* stream);
+                             float* ws, void* stream);
 /* Input-gradient GEMM with the BatchNorm+Swish backward of the PRECEDING layer fused into its epilogue.
  * The tile of dL/d(activation) never reaches HBM as such: with y the layer's saved pre-BatchNorm output (same
  * rows/columns as C) and xhat = (y - mean[g]) * rstd[g], the kernel writes
@@ -81,11 +82,16 @@ int mmdyn_igemm_nt_dgrad_act(const void* A, const void* Bp, void* C, const void*
  * and the per-tile column sums (du, du*xhat) into stats[G][T][2][N] (T = mmdyn_igemm_stat_tiles), which feed
  * mmdyn_bn_bwd_finalize directly -- the separate reduction pass (mmdyn_bn_swish_bwd_reduce: one more read of da
  * and y) disappears; mmdyn_bn_swish_bwd_apply(da_is_du = 1) finishes the layer.  bf16: 0 = fp32 matrix cores,
- * 1 = bf16, 2 = fp16 operands (T = mmdyn_igemm_stat_tiles_bf16 for both).  No bias / activation / split-K here. */
+ * 1 = bf16, 2 = fp16 operands (T = mmdyn_igemm_stat_tiles_bf16 for both).  No bias / activation / split-K here.
+ * ws: workspace of mmdyn_igemm_slab_floats(...) floats (NULL when that is 0). */
 int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C, float* stats, const float* y,
                             const float* mean, const float* rstd, const float* gamma, const float* beta,
                             int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
-                            int stride, int offset, int bf16, void* stream);
+                            int stride, int offset, int bf16, float* ws, void* stream);
+/* Workspace (floats) the fp32 launch of a shape wants in its `ws` argument when it is not split over K: the persistent,
+ * stream-K-scheduled ring kernel (csrc/igemm_wsp.hip) accumulates a tile whose K range straddles two blocks in pieces and
+ * parks the pieces there for its fix-up launch.  0 = none (ws may be NULL). */
+int mmdyn_igemm_slab_floats(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
 
 /* Same contract, bf16 matrix cores: the fp32 operands are rounded to bf16 (round-to-nearest-even) on their way
  * into the MFMA (v_mfma_f32_32x32x16_bf16), products are accumulated in fp32, everything in HBM stays fp32.
@@ -105,6 +111,15 @@ int mmdyn_igemm_nt_f16(const float* A, const float* Bp, const float* bias, float
 int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
 /* ... and what the bf16 matrix-core variants (mmdyn_igemm_nt_bf16, mmdyn_igemm_nt_mx, dgrad_bn(bf16 = 1)) write */
 int mmdyn_igemm_stat_tiles_bf16(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
+/* Grouped dense GEMM (round 4): G independent problems of ONE shape in one launch,
+ *   C_g[rows][N] = A_g[rows][K] . Bp_g[N][K]^T (+ bias_g),   g = 0 .. G-1,
+ * group g at A + g*rows*K, Bp + g*N*K, bias + g*N, C / C_act / u + g*rows*N.  Replaces the three nn.Linear pairs
+ * linear_means | linear_log_var (vae.py:211-216, 239-240) of the visual, tactile and pose encoders at the product-of-experts
+ * join, forward and input gradient: 1024 x 512 x 512 each, half a chip's worth of tiles when launched alone.
+ * u != NULL: C = (A . Bp^T) * act'(u) (activation backward in the epilogue; bias and C_act must be NULL).
+ * flags: as mmdyn_igemm_nt_mx (0 = fp32 everywhere).  K % 32 == 0, N % 32 == 0. */
+int mmdyn_igemm_nt_grouped(const void* A, const void* Bp, const float* bias, void* C, void* C_act, const void* u, int G,
+                           int rows, int K, int N, int act, int flags, void* stream);
 int mmdyn_splitk_reduce(const float* ws, const float* bias, float* C, float* C_act, int splitk,
                         int rows, int N, int act, void* stream);
 
@@ -128,6 +143,12 @@ int mmdyn_wgrad_tn_bf16(const float* D, const float* Gt, float* partial, int mod
 int mmdyn_wgrad_tn_f16(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr, int Wr,
                        int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks, void* stream);
 /* recommended `chunks` (a multiple of 4) for mmdyn_wgrad_tn; partial must hold chunks*taps*Cd*Cg floats */
+/* Grouped weight gradient (round 4; DENSE): group g owns rows [g*rows, (g+1)*rows) of D [G*rows][Cd] and Gt [G*rows][Cg];
+ * partial is [chunks][G][Cd][Cg], so ONE mmdyn_wgrad_reduce(partial, canon, chunks, 1, G*Cd, Cg, Cg, 0, beta) writes the G
+ * gradients [G][Cd][Cg] (the fused engine keeps the heads' weights of the three encoders adjacent).  chunks as
+ * mmdyn_wgrad_chunks_mx(DENSE, rows, Cd, Cg, flags); flags as mmdyn_wgrad_tn_mx (not both operands 16-bit). */
+int mmdyn_wgrad_tn_grouped(const void* D, const void* Gt, float* partial, int G, int rows, int Cd, int Cg, int chunks,
+                           int flags, void* stream);
 int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg);
 /* ... for the kernel the storage flags of mmdyn_wgrad_tn_mx select (both operands 16-bit in HBM: the all-16-bit kernels' tiles) */
 int mmdyn_wgrad_chunks_mx(int mode, int rows, int Cd, int Cg, int flags);

@@ -35,6 +35,9 @@ struct IgemmGeom {
   int cact_b16;   // the second (activated) output is bf16 while C itself is fp32
   int f16;     // the 16-bit format is IEEE half instead of bf16 (v_mfma_*_f16): operands, and every tensor the *_b16 fields mark
   int b_b16;   // packed weights are bf16 (written so by the pack kernels in the bf16 modes: half the L2 -> LDS traffic)
+  // Grouped launch (mmdyn_igemm_nt_grouped): every group multiplies its OWN weights -- group grp reads Bp + grp * b_group_stride
+  // and bias + grp * bias_group_stride (elements; 0 = one weight matrix shared by all groups, the BatchNorm-group form)
+  int b_group_stride, bias_group_stride;
 };
 
 // igemm_d16.hip: fp32 implicit GEMM on v_mfma_f32_16x16x4_f32 with operand fragments loaded straight from global
@@ -61,6 +64,13 @@ int mmdyn_tconv_patch_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Ci
 int mmdyn_igemm_ws_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
                        const IgemmGeom& g, bool bf16_ops, hipStream_t st);
 int mmdyn_igemm_ws_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
+
+// igemm_wsp.hip: the persistent, stream-K-scheduled form of the ring kernel for the large launches.  Same protocol as the
+// hooks above; `slabs` is the workspace for the pieces of split tiles (mmdyn_igemm_wsp_slab_bytes; may be null when that is 0).
+int mmdyn_igemm_wsp_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
+                        const IgemmGeom& g, bool bf16_ops, hipStream_t st);
+int mmdyn_igemm_wsp_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, bool b16);
+int64_t mmdyn_igemm_wsp_slab_bytes(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, bool b16);
 
 // tile choice shared by the launcher and mmdyn_igemm_stat_tiles.  Measured on MI355X over every shape of the
 // bs=256 step (tests/microbench/sweep_tiles.py): the 64x64 tile (more resident blocks per CU to hide the

@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   const int cls = inner / NY;
   const int n0 = (inner - cls * NY) * BN;
   const int ph = cls >> 1, pw = cls & 1;
+  // grouped launch: this group's own weights and bias (strides are 0 when the groups share them)
+  Bp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bp) + (size_t)grp * g.b_group_stride * (B16 ? 2 : 4));
+  if (bias) bias += (size_t)grp * g.bias_group_stride;
 
   // TCONV_S1P0: rows are ordered (output pixel, sample) so that a tile sees ONE output pixel and multiplies only
   // the kernel taps that reach the input for it (1..16 of them for k4 s1 p0).  To balance the blocks, each block
@@ -766,8 +769,18 @@ extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, i
   if (tp > 0) return tp;
   int t = mmdyn_igemm_d16_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   if (t > 0) return t;
+  t = ws_enabled() ? mmdyn_igemm_wsp_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, false) : 0;
+  if (t > 0) return t;
   t = ws_enabled() ? mmdyn_igemm_ws_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) : 0;
   return t > 0 ? t : lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+}
+/* Floats of workspace the fp32 launch of this shape wants in `ws` (with splitk == 1): the slabs of the persistent kernel's
+ * split tiles (igemm_wsp.hip).  0: none. */
+extern "C" int mmdyn_igemm_slab_floats(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+  if (!ws_enabled()) return 0;
+  if (mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) > 0) return 0;
+  if (mmdyn_igemm_d16_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) > 0) return 0;
+  return (int)(mmdyn_igemm_wsp_slab_bytes(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, false) / 4);
 }
 extern "C" int mmdyn_igemm_stat_tiles_bf16(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   return lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
@@ -778,7 +791,8 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
                        int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
                        void* stream, bool bf16, const float* bn_y = nullptr, const float* bn_mean = nullptr,
                        const float* bn_rstd = nullptr, const float* bn_gamma = nullptr,
-                       const float* bn_beta = nullptr, int storage_flags = 0) {
+                       const float* bn_beta = nullptr, int storage_flags = 0, int b_group_stride = 0,
+                       int bias_group_stride = 0) {
   if (!A || !Bp || !C) return MMDYN_ERR_NULL;
   if (Cin <= 0 || N <= 0 || Cin % BK || N % 32 || G <= 0 || Bg <= 0 || ldc < N) return MMDYN_ERR_SHAPE;
   if (splitk < 1) splitk = 1;
@@ -817,6 +831,8 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   if (g.cact_b16 && (g.c_b16 || !C_act || splitk > 1 || (N & 1))) return MMDYN_ERR_SHAPE;
   if (storage_flags && (!bf16 || (g.c_b16 && splitk > 1) || (g.a_b16 && mode == MMDYN_IM2COL3))) return MMDYN_ERR_SHAPE;
   g.want_act_out = C_act != nullptr;
+  g.b_group_stride = b_group_stride;
+  g.bias_group_stride = bias_group_stride;
   g.splitk = splitk;
   g.nclasses = 1;
   g.os = 1;
@@ -875,8 +891,12 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
     const int rc = mmdyn_tconv_patch_try(A, Bp, bias, C, C_act, stats, ws, g, st);
     if (rc != 1) return rc;
   }
-  if (!bf16 && mode != MMDYN_IM2COL3) {
+  if (!bf16 && mode != MMDYN_IM2COL3 && !b_group_stride) {
     const int rc = mmdyn_igemm_d16_try(A, Bp, bias, C, C_act, stats, ws, g, stride, offset, st);
+    if (rc != 1) return rc;
+  }
+  if (ws_enabled() && !bf16 && mode != MMDYN_IM2COL3 && mode != MMDYN_TCONV_S1P0) {   // persistent ring kernel (igemm_wsp.hip)
+    const int rc = mmdyn_igemm_wsp_try(A, Bp, bias, C, C_act, stats, ws, g, false, st);
     if (rc != 1) return rc;
   }
   if (ws_enabled() && mode != MMDYN_IM2COL3 && mode != MMDYN_TCONV_S1P0) {   // wave-specialised LDS-DMA ring kernels (igemm_ws.hip)
@@ -907,10 +927,10 @@ extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias
 extern "C" int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C, float* stats, const float* y,
                                        const float* mean, const float* rstd, const float* gamma, const float* beta,
                                        int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
-                                       int stride, int offset, int bf16, void* stream) {
+                                       int stride, int offset, int bf16, float* ws, void* stream) {
   if (!stats || !y || !mean || !rstd || !gamma || !beta) return MMDYN_ERR_NULL;
   if (bf16 < 0 || bf16 > 2) return MMDYN_ERR_SHAPE;
-  return igemm_entry(A, Bp, nullptr, C, nullptr, stats, nullptr, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset,
+  return igemm_entry(A, Bp, nullptr, C, nullptr, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset,
                      MMDYN_ACT_NONE, 1, stream, bf16 != 0, y, mean, rstd, gamma, beta, bf16 == 2 ? 32 : 0);
 }
 
@@ -918,10 +938,10 @@ extern "C" int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C
  * pre-activation, same rows / columns as C.  flags as mmdyn_igemm_nt_mx (bit 3: u is bf16); 0 = fp32 everywhere. */
 extern "C" int mmdyn_igemm_nt_dgrad_act(const void* A, const void* Bp, void* C, const void* u, int act, int mode, int G, int Bg,
                                         int Hi, int Wi, int Cin, int Ho, int Wo, int N, int stride, int offset, int flags,
-                                        void* stream) {
+                                        float* ws, void* stream) {
   if (!u) return MMDYN_ERR_NULL;
   if (act != MMDYN_ACT_SWISH && act != MMDYN_ACT_RELU) return MMDYN_ERR_SHAPE;
-  return igemm_entry((const float*)A, (const float*)Bp, nullptr, (float*)C, nullptr, nullptr, nullptr, mode, G, Bg, Hi, Wi, Cin,
+  return igemm_entry((const float*)A, (const float*)Bp, nullptr, (float*)C, nullptr, nullptr, ws, mode, G, Bg, Hi, Wi, Cin,
                      Ho, Wo, N, N, stride, offset, act, 1, stream, (flags & 1) != 0 || (flags & 32) != 0, (const float*)u, nullptr,
                      nullptr, nullptr, nullptr, flags & ~1);
 }
@@ -947,6 +967,22 @@ extern "C" int mmdyn_igemm_nt_mx(const void* A, const void* Bp, const float* bia
   return igemm_entry((const float*)A, (const float*)Bp, bias, (float*)C, (float*)C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho,
                      Wo, N, ldc, stride, offset, act, splitk, stream, (flags & 1) != 0, (const float*)bn_y, bn_mean,
                      bn_rstd, bn_gamma, bn_beta, flags & ~1);
+}
+
+/* Grouped dense GEMM: G independent problems of ONE shape in one launch -- C_g[rows][N] = A_g[rows][K] . Bp_g[N][K]^T (+ bias_g),
+ * group g at A + g*rows*K, Bp + g*N*K, bias + g*N, C (and C_act, u) + g*rows*N.  The heads / pose GEMMs at the product-of-experts
+ * join of the fused step (vae.py:211-216, 239-240: linear_means | linear_log_var of the visual, tactile and pose encoders) are
+ * three such problems of 1024 x 512 x 512 that fill half the chip each when launched one by one.
+ * u != NULL: the activation-backward epilogue C = (A . Bp^T) * act'(u) (then bias / C_act must be NULL).
+ * flags as mmdyn_igemm_nt_mx (0 = fp32 everywhere). */
+extern "C" int mmdyn_igemm_nt_grouped(const void* A, const void* Bp, const float* bias, void* C, void* C_act, const void* u,
+                                      int G, int rows, int K, int N, int act, int flags, void* stream) {
+  if (G < 1 || rows < 1) return MMDYN_ERR_SHAPE;
+  if (u && (bias || C_act || (act != MMDYN_ACT_SWISH && act != MMDYN_ACT_RELU))) return MMDYN_ERR_SHAPE;
+  if ((int64_t)G * N * K >= (1LL << 31)) return MMDYN_ERR_RANGE;
+  return igemm_entry((const float*)A, (const float*)Bp, bias, (float*)C, (float*)C_act, nullptr, nullptr, MMDYN_DENSE, G, rows, 1, 1,
+                     K, 1, 1, N, N, 1, 0, act, 1, stream, (flags & 1) != 0 || (flags & 32) != 0, (const float*)u, nullptr, nullptr,
+                     nullptr, nullptr, flags & ~1, N * K, N);
 }
 
 extern "C" int mmdyn_igemm_nt_bf16(const float* A, const float* Bp, const float* bias, float* C, float* C_act,

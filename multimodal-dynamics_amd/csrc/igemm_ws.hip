@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
 #pragma unroll
     for (int j = 0; j < PBL; ++j) {
       const int r = (wave + NL * j) * RPP + prow;
-      voffB[j] = (unsigned)(((n0 + r) * g.Cin) * ESZ + ((lane & 7) ^ ((r >> 1) & 7)) * 16);
+      voffB[j] = (unsigned)((grp * g.b_group_stride + (n0 + r) * g.Cin) * ESZ + ((lane & 7) ^ ((r >> 1) & 7)) * 16);
     }
     int tap = s_begin / cin_steps;
     int cstep = s_begin - tap * cin_steps;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
               const int grow = grp * Mg + tile * BM + wm * WM + mt * TS + 4 * h + e;   // dense row id (DENSE mode only)
               ws[((size_t)split * g.rows_total + grow) * g.N + col] = v;
             } else {
-              if (g.has_bias) v += bias[col];
+              if (g.has_bias) v += bias[grp * g.bias_group_stride + col];
               if (B16 && g.c_b16) {
                 // two adjacent columns live in adjacent lanes: the even lane stores both as one dword
                 const float vn = __shfl_down(v, 1, 64);
@@ -473,7 +473,8 @@ static int ws_dispatch(const float* A, const float* Bp, const float* bias, float
                        const IgemmGeom& g, WsPick p, hipStream_t st) {
   const int esz = B16 ? 2 : 4;
   const unsigned a_bytes = (unsigned)((int64_t)g.G * g.Bg * g.Hi * g.Wi * g.Cin * esz);
-  const unsigned b_bytes = (unsigned)((int64_t)(g.mode == MMDYN_DENSE ? 1 : 16) * g.N * g.Cin * esz);
+  const unsigned b_bytes = (unsigned)(((int64_t)(g.mode == MMDYN_DENSE ? 1 : 16) * g.N * g.Cin +
+                                       (int64_t)(g.G - 1) * g.b_group_stride) * esz);
   if (g.mode == MMDYN_DENSE)
     return ws_launch_mode<MMDYN_DENSE, B16>(A, Bp, bias, C, C_act, stats, ws, g, p, a_bytes, b_bytes, st);
   if (g.mode == MMDYN_CONV)
@@ -499,6 +500,7 @@ int mmdyn_igemm_ws_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, 
 int mmdyn_igemm_ws_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
                        const IgemmGeom& g, bool bf16_ops, hipStream_t st) {
   if (bf16_ops && (!g.a_b16 || !g.b_b16)) return 1;
+  if ((int64_t)g.G * g.b_group_stride * 4 >= MAX_BUFFER_BYTES) return 1;      // (grouped weights: one buffer descriptor)
   const WsPick p = ws_pick(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Hr, g.Wr, g.Cin, g.N, g.nclasses, g.splitk, bf16_ops);
   if (!p.bm) return 1;
   if (bf16_ops && g.f16) return ws_dispatch<2>(A, Bp, bias, C, C_act, stats, ws, g, p, st);

@@ -1,0 +1,704 @@
+// Persistent, stream-K-scheduled form of the wave-specialised implicit GEMM (igemm_ws.hip) for the LARGE launches of the
+// step (v_mfma_f32_16x16x4_f32 / v_mfma_f32_16x16x32_{bf16,f16}, gfx950).
+//
+//   C[row][n] = sum_{tap, ci} A_tap[row][ci] * Bp[widx(tap)][n][ci]        (same contract as igemm_nt.hip / igemm_ws.hip)
+//
+// Replaces the ATen kernels behind nn.Conv2d / nn.ConvTranspose2d forward and input-gradient on the reference path
+// (/root/reference/mmdyn/pytorch/models/vae.py:198-216, 264-277) for the launches it serves (wsp_pick below).
+//
+// Why a third structure (docs/LAB_NOTES.md D.c, E): 128-row tiles do 21-32 flop per filled LDS byte
+// against 16 for the 64x64 tile and measure 122-134 TFLOP/s as a dense GEMM, but one block per tile hands that back:
+// a lone 98 KB block per CU exposes its row decode, its first DMA round trip and its epilogue, and 200-400 tiles over 256
+// CUs leave a wave of CUs idle at the end.  Here a launch is ONE resident block per CU slot that walks a contiguous range
+// of (tile, K-step) units:
+//   * the loader waves run the DMA ring STRAIGHT THROUGH the tile boundary: the first S-1 K-steps of tile t+1 land
+//     while the MFMA waves are still in the epilogue of tile t; the per-tile row decode (sample, y, x of every gathered
+//     row) is done by the LOADER lanes for their own 8 rows each, in the shadow of the DMA queue, with a float-reciprocal
+//     division -- no integer division on any MFMA lane, no block barrier at the tile boundary.  The MFMA waves get the
+//     output offsets of their rows through a four-deep LDS table the loaders fill one segment ahead;
+//   * the unit ranges are equal for all blocks (stream-K): a tile whose K range straddles two blocks is accumulated in
+//     pieces; each piece goes to a private slab (the accumulator fragments as they sit in registers, 16 bytes per lane)
+//     and a second, tiny launch (igemm_wsp_fixup_kernel) sums the pieces of each split tile in piece order and runs the
+//     SAME epilogue -- deterministic, no atomics, no in-kernel inter-block hand-off (the kernel boundary is the fence);
+//   * BatchNorm partial sums are written per (tile, wave row): no cross-wave reduction, hence no block barrier in the
+//     epilogue (mmdyn_igemm_wsp_stat_tiles tells the host how many partial tiles a launch writes).
+// The ring itself (LDS-DMA pieces of 8 rows x 128 B, XOR swizzle on the DMA source address and on the fragment read,
+// counted vmcnt, ONE raw s_barrier per K-step, out-of-range offsets for padding rows) is igemm_ws.hip's.
+#include "common.h"
+#include "igemm_geom.h"
+#include <cstdio>
+#include <type_traits>
+
+namespace {
+
+constexpr int BK = 32;          // K-step: 32 fp32 channels (64 16-bit ones) = one 128-byte row segment
+constexpr int RB = 128;         // bytes per tile row
+constexpr int RPP = 8;          // rows per DMA piece (1 KiB per wave instruction)
+constexpr int NL = 2;           // loader waves per block
+constexpr int NRO = 4;          // depth of the row-offset table (segments the loaders may be ahead of the MFMA waves: <= S-1)
+constexpr unsigned OOB = 0x80000000u;
+constexpr int64_t MAX_BUFFER_BYTES = 0x7FFFFF00LL;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// raw block barrier (no vmcnt drain: LDS-DMA stays in flight across it); the loaders' LDS stores (row offsets) are complete
+__device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// LAB build only (MMDYN_WSP_DIAG=1): cycle stamps of wave 0 (loader) and of the first MFMA wave of every block, summed over the
+// launch -- where a K-step's time goes.  [0] MFMA wave: cycles waiting in the ring barrier, [1] in K loops (barrier included),
+// [2] in epilogues / slab stores, [3] whole kernel; [4] loader: cycles in its counted vmcnt wait, [5] in the ring barrier,
+// [6] issuing (row decode of the next segment included), [7] whole loop.  The stamps cost ~10 % themselves.
+#ifdef MMDYN_LAB
+__device__ unsigned long long wsp_diag[8];
+#define WSP_STAMP() ((long long)__builtin_readcyclecounter())
+#else
+#define WSP_STAMP() 0LL
+#endif
+
+// Schedule of one launch: units = tiles x K-steps, block b owns units [b * per, (b + 1) * per).
+struct WspSched {
+  int tiles;       // M-tiles x N-tiles x parity classes
+  int ksteps;      // K-steps per tile
+  int per;         // units per block (the last block may get fewer)
+  int si, ny;      // inner tiles per M-tile (N-tiles x classes), N-tiles
+  float inv_hw, inv_w;
+};
+
+// quotient and remainder by a launch constant through a float reciprocal, exact for 0 <= n < 2^23 (checked by the launcher)
+__device__ __forceinline__ void fdiv(int n, int d, float inv, int& q, int& r) {
+  q = (int)((float)n * inv);
+  r = n - q * d;
+  if (r < 0) { q -= 1; r += d; }
+  if (r >= d) { q += 1; r -= d; }
+}
+
+struct TileId {
+  int grp, tile, cls, n0, ph, pw;
+};
+__device__ __forceinline__ TileId tile_of(int t, const IgemmGeom& g, const WspSched& sc, int BN) {
+  TileId id;
+  const int mx = t / sc.si, inner = t - mx * sc.si;
+  id.grp = mx / g.tiles_per_group;
+  id.tile = mx - id.grp * g.tiles_per_group;
+  id.cls = inner / sc.ny;
+  id.n0 = (inner - id.cls * sc.ny) * BN;
+  id.ph = id.cls >> 1;
+  id.pw = id.cls & 1;
+  return id;
+}
+
+// row `ml` of group `grp` (class ph, pw) -> sample index, gather base (y0, x0), output offset (-1: the row does not exist)
+__device__ __forceinline__ void decode_row(int ml, int Mg, const TileId& id, const IgemmGeom& g, const WspSched& sc, int& ib,
+                                           int& y0, int& x0, int& ooff) {
+  ib = -1;
+  y0 = x0 = 0;
+  ooff = -1;
+  if (ml < Mg) {
+    int s, p, rr, cc;
+    fdiv(ml, g.Hr * g.Wr, sc.inv_hw, s, p);
+    fdiv(p, g.Wr, sc.inv_w, rr, cc);
+    ib = id.grp * g.Bg + s;
+    y0 = rr * g.rs + g.ro;
+    x0 = cc * g.rs + g.ro;
+    ooff = ((ib * g.Ho + rr * g.os + id.ph) * g.Wo + cc * g.os + id.pw) * g.ldc;
+  }
+}
+
+// ---- epilogue of one finished tile, shared by the main kernel and the fix-up kernel (MFMA-wave lanes only) ----
+// An accumulator register holds, over the wave, 4 rows x 16 columns of a 16x16 tile (element e: row 4*(l>>4) + e, column
+// l&15): stored as it sits that is 32 global_store_dword per lane and tile, and the epilogue of a 128x128 tile took 15 000
+// cycles -- store ISSUE, not bytes (cycle stamps: docs/LAB_NOTES.md E; cdna_hip_programming.md T21).  Every 16x16 tile
+// therefore goes through a wave-private LDS patch ([16][TRLD] floats) and comes back ROW-major: lane l holds row l>>2,
+// columns 4*(l&3) .. +3 -- one 16-byte store (and, for the BatchNorm / activation backward, one 16-byte load of the saved
+// pre-activation) per tile and lane, 4x fewer memory instructions, the same bytes.
+constexpr int TRLD = 20;        // patch row stride (floats): 16-byte aligned rows; the 4 rows of a store group 2-way conflict only
+
+// the tile's saved pre-BN / pre-activation values in the transposed layout: yq[mt][nt] = row (l>>2) of tile (mt, nt), 4 columns
+template <int MT, int NT, int B16>
+__device__ __forceinline__ void wsp_fetch_y(f32x4v (&yq)[MT][NT], const int (&ooff)[MT], const IgemmGeom& g, int col0) {
+  typedef typename std::conditional<B16 == 2, half_t, bf16_t>::type st16_t;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const size_t yo = (size_t)max(ooff[mt], 0) + col0 + nt * 16;
+      if (B16 && g.bny_b16) yq[mt][nt] = ld4<st16_t>(reinterpret_cast<const st16_t*>(g.bn_y) + yo);
+      else yq[mt][nt] = *reinterpret_cast<const f32x4v*>(g.bn_y + yo);
+    }
+}
+
+// ooff[mt]: output offset of row (l>>2) of the wave's mt-th 16-row tile (-1: no such row); tr: this wave's LDS patch
+template <int BM, int BN, int WM, int WN, int B16>
+__device__ __forceinline__ void wsp_epilogue(f32x4v (&acc)[WM / 16][WN / 16], const int (&ooff)[WM / 16],
+                                             const f32x4v (&yq)[WM / 16][WN / 16], const TileId& id, const IgemmGeom& g,
+                                             const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ C_act,
+                                             float* __restrict__ stats, int wm, int wn, int lane, float* tr) {
+  constexpr int TS = 16, MT = WM / TS, NT = WN / TS, WAVES_M = BM / WM;
+  typedef typename std::conditional<B16 == 2, half_t, bf16_t>::type st16_t;
+  const int h = lane >> 4, cl = lane & 15;
+  const int trow = lane >> 2, c4 = (lane & 3) * 4;       // transposed layout: row inside the 16-row tile, first of 4 columns
+  const bool bnbwd = g.bn_y != nullptr;
+  const bool bn = bnbwd && g.bn_mean != nullptr;         // (activation-only backward: xhat = u, gamma = 1, beta = 0)
+  f32x4v cs[NT], cq[NT], bn_m[NT], bn_r[NT], bn_g[NT], bn_b[NT], bia[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = id.n0 + wn * WN + nt * TS + c4;
+    cs[nt] = cq[nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    bn_m[nt] = bn ? *reinterpret_cast<const f32x4v*>(g.bn_mean + (size_t)id.grp * g.N + col) : f32x4v{0.f, 0.f, 0.f, 0.f};
+    bn_r[nt] = bn ? *reinterpret_cast<const f32x4v*>(g.bn_rstd + (size_t)id.grp * g.N + col) : f32x4v{1.f, 1.f, 1.f, 1.f};
+    bn_g[nt] = bn ? *reinterpret_cast<const f32x4v*>(g.bn_gamma + col) : f32x4v{1.f, 1.f, 1.f, 1.f};
+    bn_b[nt] = bn ? *reinterpret_cast<const f32x4v*>(g.bn_beta + col) : f32x4v{0.f, 0.f, 0.f, 0.f};
+    bia[nt] = g.has_bias ? *reinterpret_cast<const f32x4v*>(bias + id.grp * g.bias_group_stride + col) : f32x4v{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int oo = ooff[mt];
+    const bool live = oo >= 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = id.n0 + wn * WN + nt * TS + c4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tr[(4 * h + e) * TRLD + cl] = acc[mt][nt][e];
+      f32x4v v = *reinterpret_cast<const f32x4v*>(&tr[trow * TRLD + c4]);
+      if (bnbwd) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = live ? (yq[mt][nt][k] - bn_m[nt][k]) * bn_r[nt][k] : 0.f;
+          v[k] = live ? v[k] * act_grad(bn_g[nt][k] * xh + bn_b[nt][k], g.bwd_act) : v[k];
+          cs[nt][k] += v[k];
+          cq[nt][k] += v[k] * xh;
+        }
+      } else {
+        cs[nt] += v;
+        cq[nt] += v * v;
+      }
+      if (live) {
+        if (g.has_bias) v += bia[nt];
+        f32x4v a = v;
+        if (g.want_act_out) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a[k] = apply_act(v[k], g.act);
+        }
+        if (B16 && g.c_b16) {
+          st4<st16_t>(reinterpret_cast<st16_t*>(C) + (size_t)oo + col, v);
+          if (g.want_act_out) st4<st16_t>(reinterpret_cast<st16_t*>(C_act) + (size_t)oo + col, a);
+        } else {
+          *reinterpret_cast<f32x4v*>(C + (size_t)oo + col) = v;
+          if (g.want_act_out) {
+            if (B16 && g.cact_b16) st4<st16_t>(reinterpret_cast<st16_t*>(C_act) + (size_t)oo + col, a);
+            else *reinterpret_cast<f32x4v*>(C_act + (size_t)oo + col) = a;
+          }
+        }
+      }
+    }
+  }
+  if (g.want_stats) {
+    // one partial-sum tile per (M-tile, class, wave row): rows beyond the group are zero-filled operands -> contribute 0.
+    // A column's 64 rows: 4 tiles (summed above) x the 16 lanes with the same l&3
+    const int T = g.nclasses * g.tiles_per_group * WAVES_M;
+    const int slot = (id.cls * g.tiles_per_group + id.tile) * WAVES_M + wm;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float sv = cs[nt][k], qv = cq[nt][k];
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) {
+          sv += __shfl_xor(sv, m, 64);
+          qv += __shfl_xor(qv, m, 64);
+        }
+        cs[nt][k] = sv;
+        cq[nt][k] = qv;
+      }
+      if (lane < 4) {
+        const size_t base = ((size_t)(id.grp * T + slot) * 2) * g.N + id.n0 + wn * WN + nt * TS + c4;
+        *reinterpret_cast<f32x4v*>(stats + base) = cs[nt];
+        *reinterpret_cast<f32x4v*>(stats + base + g.N) = cq[nt];
+      }
+    }
+  }
+}
+
+template <int MODE, int BM, int BN, int WM, int WN, int S, int B16, bool DIAG = false>
+__global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_kernel(
+    const float* __restrict__ A, const float* __restrict__ Bp, const float* __restrict__ bias, float* __restrict__ C,
+    float* __restrict__ C_act, float* __restrict__ stats, float* __restrict__ slabs, const IgemmGeom g, const WspSched sc,
+    const unsigned a_bytes, const unsigned b_bytes) {
+  constexpr int NM = (BM / WM) * (BN / WN);        // MFMA waves
+  constexpr int PA = BM / RPP, PB = BN / RPP;      // DMA pieces per K-step
+  static_assert(PA % NL == 0 && PB % NL == 0, "pieces split evenly over the loader waves");
+  constexpr int PAL = PA / NL, PBL = PB / NL, PPL = PAL + PBL;
+  static_assert(PPL * (S - 2) <= 63, "vmcnt is a 6-bit counter");
+  static_assert(S - 1 < NRO, "row-offset table deep enough for the loaders' lead");
+  constexpr int SLOT = (BM + BN) * RB;
+  constexpr int TS = 16, MT = WM / TS, NT = WN / TS;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int ESZ = B16 ? 2 : 4;
+  constexpr int KB = RB / ESZ;                     // channels per K-step
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* rowoff = reinterpret_cast<int*>(smem + S * SLOT);       // [NRO][BM]: output offset of every tile row (-1: none)
+  float* trans = reinterpret_cast<float*>(rowoff + NRO * BM);  // [NM][16][TRLD]: the MFMA waves' epilogue patches
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Mg = g.Bg * g.Hr * g.Wr;
+  const int total_units = sc.tiles * sc.ksteps;
+  const int u0 = blockIdx.x * sc.per, u1 = min(total_units, u0 + sc.per);
+  if (u0 >= u1) return;
+  const int nsteps = u1 - u0;
+  const int cin_steps = g.Cin / KB;
+
+  if (wave < NL) {
+    // ===================================== loader wave =====================================
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (int)b_bytes, 0x00020000);
+    const int prow = lane >> 3;                          // row of this lane inside a piece
+    int rb[PAL], ry[PAL], rx[PAL];
+    unsigned voffA[PAL], voffB[PBL];
+    int su = u0, seg = -1, seg_end = u0;                 // next unit to issue; running segment; its last unit + 1
+    int tap = 0, cstep = 0, ph = 0, pw = 0;
+    unsigned sB = 0;
+    auto settap = [&]() {
+      int dh = 0, dw = 0, wi = 0;
+      if (MODE == MMDYN_CONV) {
+        dh = tap >> 2;
+        dw = tap & 3;
+        wi = tap;
+      } else if (MODE == MMDYN_TCONV_S2P1) {
+        const int th = tap >> 1, tw = tap & 1;
+        dh = ph - th;
+        dw = pw - tw;
+        wi = (1 - ph + 2 * th) * 4 + (1 - pw + 2 * tw);
+      }
+      sB = (unsigned)wi * (unsigned)(g.N * g.Cin) * (unsigned)ESZ;
+#pragma unroll
+      for (int i = 0; i < PAL; ++i) {
+        const int r = (wave + NL * i) * RPP + prow;
+        const int y = ry[i] + dh, x = rx[i] + dw;
+        const bool ok = (rb[i] >= 0) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
+        const unsigned pix = (unsigned)((rb[i] * g.Hi + y) * g.Wi + x);
+        voffA[i] = ok ? pix * (unsigned)(g.Cin * ESZ) + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16) : OOB;
+      }
+    };
+    auto next_segment = [&]() {
+      ++seg;
+      const int t = su / sc.ksteps, kb = su - t * sc.ksteps;
+      seg_end = min(u1, (t + 1) * sc.ksteps);
+      const TileId id = tile_of(t, g, sc, BN);
+      ph = id.ph;
+      pw = id.pw;
+#pragma unroll
+      for (int i = 0; i < PAL; ++i) {
+        const int r = (wave + NL * i) * RPP + prow;      // tile row
+        int oo;
+        decode_row(id.tile * BM + r, Mg, id, g, sc, rb[i], ry[i], rx[i], oo);
+        if ((lane & 7) == 0) rowoff[(seg & (NRO - 1)) * BM + r] = oo;
+      }
+#pragma unroll
+      for (int j = 0; j < PBL; ++j) {
+        const int r = (wave + NL * j) * RPP + prow;
+        voffB[j] = (unsigned)((id.grp * g.b_group_stride + (id.n0 + r) * g.Cin) * ESZ + ((lane & 7) ^ ((r >> 1) & 7)) * 16);
+      }
+      tap = kb / cin_steps;
+      cstep = kb - tap * cin_steps;
+      settap();
+    };
+    int islot = 0;                                       // ring slot of the next issue
+    auto issue = [&]() {
+      if (su == seg_end) next_segment();
+      char* slot = smem + islot * SLOT;
+      const unsigned so = (unsigned)cstep * RB;
+#pragma unroll
+      for (int i = 0; i < PAL; ++i) dma16(rsA, slot + (wave + NL * i) * 1024, voffA[i], so);
+#pragma unroll
+      for (int j = 0; j < PBL; ++j) dma16(rsB, slot + BM * RB + (wave + NL * j) * 1024, voffB[j], sB + so);
+      islot = islot + 1 == S ? 0 : islot + 1;
+      ++su;
+      if (++cstep == cin_steps) {
+        cstep = 0;
+        ++tap;
+        if (su < seg_end) settap();
+      }
+    };
+    for (int k = 0; k < S - 1 && k < nsteps; ++k) issue();
+    long long t_wait = 0, t_bar = 0, t_iss = 0, t_all = 0;
+    if (DIAG) t_all = -WSP_STAMP();
+    for (int k = 0; k < nsteps; ++k) {
+      if (DIAG) t_wait -= WSP_STAMP();
+      if (k + S - 1 <= nsteps) wait_vmcnt<PPL*(S - 2)>(); else wait_vmcnt<0>();
+      if (DIAG) { const long long c = WSP_STAMP(); t_wait += c; t_bar -= c; }
+      ring_barrier();                                    // slot k is complete; slot k-1 has been read by every MFMA wave
+      if (DIAG) { const long long c = WSP_STAMP(); t_bar += c; t_iss -= c; }
+      if (k + S - 1 < nsteps) issue();
+      if (DIAG) t_iss += WSP_STAMP();
+    }
+#ifdef MMDYN_LAB
+    if (DIAG && wave == 0 && lane == 0) {
+      t_all += WSP_STAMP();
+      atomicAdd(&wsp_diag[4], (unsigned long long)t_wait);
+      atomicAdd(&wsp_diag[5], (unsigned long long)t_bar);
+      atomicAdd(&wsp_diag[6], (unsigned long long)t_iss);
+      atomicAdd(&wsp_diag[7], (unsigned long long)t_all);
+    }
+#endif
+    return;
+  }
+
+  // ===================================== MFMA waves =====================================
+  const int mw = wave - NL;
+  const int wm = mw / WAVES_N, wn = mw - wm * WAVES_N;
+  const int h = lane >> 4, cl = lane & 15;
+  const bool bnbwd = g.bn_y != nullptr;
+  const int fr = (cl >> 1) & 7;
+  const int foff0 = cl * RB + 16 * ((0 + h) ^ fr), foff1 = cl * RB + 16 * ((4 + h) ^ fr);
+  const int abase = wm * WM * RB, bbase = BM * RB + wn * WN * RB;
+  int cslot = 0;                                         // ring slot of the next K-step
+  int seg = -1;
+  long long d_bar = 0, d_loop = 0, d_epi = 0, d_all = 0;
+  if (DIAG) d_all = -WSP_STAMP();
+  for (int cu = u0; cu < u1;) {
+    ++seg;
+    const int t = cu / sc.ksteps, kb = cu - t * sc.ksteps;
+    const int ke = min(sc.ksteps, kb + (u1 - cu));
+    const bool full = kb == 0 && ke == sc.ksteps;
+    const TileId id = tile_of(t, g, sc, BN);
+    f32x4v acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    int ooff[MT];                                        // output offset of row (lane >> 2) of each 16-row tile of the wave
+    f32x4v yq[MT][NT];                                   // BatchNorm / activation backward epilogue: the tile's saved values
+    if (DIAG) d_loop -= WSP_STAMP();
+    for (int k = kb; k < ke; ++k) {
+      if (DIAG) d_bar -= WSP_STAMP();
+      ring_barrier();
+      if (DIAG) d_bar += WSP_STAMP();
+      if (k == kb) {
+        // the loaders published this segment's row offsets before its first K-step; the epilogue's operand is requested NOW
+        // and lands under the K loop
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ooff[mt] = rowoff[(seg & (NRO - 1)) * BM + wm * WM + mt * TS + (lane >> 2)];
+        if (full && bnbwd) wsp_fetch_y<MT, NT, B16>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
+      }
+      const char* sl = smem + cslot * SLOT;
+      cslot = cslot + 1 == S ? 0 : cslot + 1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int fo = q ? foff1 : foff0;
+        if constexpr (B16 != 0) {
+          bf16x8v af[MT], bf[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const bf16x8v*>(sl + abase + mt * TS * RB + fo);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const bf16x8v*>(sl + bbase + nt * TS * RB + fo);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              if constexpr (B16 == 2)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8v, af[mt]),
+                                                                     __builtin_bit_cast(f16x8v, bf[nt]), acc[mt][nt], 0, 0, 0);
+              else
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+        } else {
+          f32x4v af[MT], bf[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4v*>(sl + abase + mt * TS * RB + fo);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const f32x4v*>(sl + bbase + nt * TS * RB + fo);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+    if (DIAG) { const long long c = WSP_STAMP(); d_loop += c; d_epi -= c; }
+    if (full) {
+      wsp_epilogue<BM, BN, WM, WN, B16>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
+    } else {
+      // a piece of a split tile: the accumulator fragments as they are, 16 bytes per lane (slot 0: the piece is this block's
+      // first segment, slot 1: its last); igemm_wsp_fixup_kernel sums the pieces and runs the epilogue
+      float* sb = slabs + ((size_t)(blockIdx.x * 2 + (cu == u0 ? 0 : 1)) * NM + mw) * (MT * NT * 256);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4v*>(sb + ((mt * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
+    }
+    if (DIAG) d_epi += WSP_STAMP();
+    cu += ke - kb;
+  }
+#ifdef MMDYN_LAB
+  if (DIAG && mw == 0 && lane == 0) {
+    d_all += WSP_STAMP();
+    atomicAdd(&wsp_diag[0], (unsigned long long)d_bar);
+    atomicAdd(&wsp_diag[1], (unsigned long long)d_loop);
+    atomicAdd(&wsp_diag[2], (unsigned long long)d_epi);
+    atomicAdd(&wsp_diag[3], (unsigned long long)d_all);
+  }
+#endif
+}
+
+// One block per tile; blocks of tiles that were computed whole return at once.  Sums the pieces of a split tile in piece
+// (= K) order and runs the epilogue of the main kernel.
+template <int MODE, int BM, int BN, int WM, int WN, int B16>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_wsp_fixup_kernel(
+    const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ C_act, float* __restrict__ stats,
+    const float* __restrict__ slabs, const IgemmGeom g, const WspSched sc) {
+  constexpr int NM = (BM / WM) * (BN / WN);
+  constexpr int TS = 16, MT = WM / TS, NT = WN / TS, WAVES_N = BN / WN;
+  const int t = blockIdx.x;
+  const int ub = t * sc.ksteps, ue = ub + sc.ksteps;
+  const int b0 = ub / sc.per;
+  if (ue <= (b0 + 1) * sc.per) return;                   // the tile lies inside one block's range: computed whole
+  const int lane = threadIdx.x & 63, mw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = mw / WAVES_N, wn = mw - wm * WAVES_N;
+  const int Mg = g.Bg * g.Hr * g.Wr;
+  const TileId id = tile_of(t, g, sc, BN);
+  f32x4v acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  for (int u = ub; u < ue;) {
+    const int b = u / sc.per;
+    const int pe = min(ue, (b + 1) * sc.per);            // end of this block's piece of the tile
+    const float* sb = slabs + ((size_t)(b * 2 + (u == b * sc.per ? 0 : 1)) * NM + mw) * (MT * NT * 256);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += *reinterpret_cast<const f32x4v*>(sb + ((mt * NT + nt) * 64 + lane) * 4);
+    u = pe;
+  }
+  __shared__ __attribute__((aligned(16))) float trans[NM * 16 * TRLD];
+  int ooff[MT];
+  f32x4v yq[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int ib, y0, x0;
+    decode_row(id.tile * BM + wm * WM + mt * TS + (lane >> 2), Mg, id, g, sc, ib, y0, x0, ooff[mt]);
+  }
+  if (g.bn_y != nullptr) wsp_fetch_y<MT, NT, B16>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
+  wsp_epilogue<BM, BN, WM, WN, B16>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
+}
+
+// ---- which launches this file serves, and how ----
+struct WspPick {
+  int bm, bn;      // 0: not served
+  int bpc;         // resident blocks per CU the grid is sized for
+};
+
+static int device_cus() {
+  static int cus[LdsOptIn::MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LdsOptIn::MAX_DEVICES) return 256;
+  if (!cus[dev]) {
+    hipDeviceProp_t p;
+    cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
+// Measured per shape against the one-tile-per-block ring kernels and the register-staged kernels, each launch alone on the
+// chip (tests/microbench/ab_ws.py, profiles/r4/ab_wsp_per_shape.txt).  Served: fp32 / all-16-bit CONV and TCONV_S2P1
+// launches with at least two 128-row tiles' worth of work per CU slot.
+static WspPick wsp_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr, int Cin, int N, int ncls, int splitk, bool b16,
+                        int b_group_stride) {
+  WspPick p{0, 0, 0};
+  if (const char* e = lab_env("MMDYN_WSP"))
+    if (e[0] == '0') return p;
+  if (mode != MMDYN_CONV && mode != MMDYN_TCONV_S2P1 && mode != MMDYN_DENSE) return p;
+  if (splitk > 1 || b_group_stride) return p;
+  const int kb = b16 ? 64 : BK;
+  if (Cin % kb || N % 64) return p;
+  const int esz = b16 ? 2 : 4;
+  if ((int64_t)G * Bg * Hi * Wi * Cin * esz >= MAX_BUFFER_BYTES || (int64_t)16 * N * Cin * esz >= MAX_BUFFER_BYTES) return p;
+  const long rows_g = (long)Bg * Hr * Wr;
+  if (rows_g >= (1L << 23)) return p;                    // float-reciprocal row decode
+  const int ksteps = (mode == MMDYN_CONV ? 16 : (mode == MMDYN_TCONV_S2P1 ? 4 : 1)) * (Cin / kb);
+  const int cus = device_cus();
+  // 128x128 tiles, one block per CU, where N allows: x1.03-1.15 against the one-tile-per-block kernels on the N = 128 / 256
+  // launches (more where the tile count does not divide the CUs: 400 tiles x1.07, 256 tiles x1.15).  The 128x64 tile (two
+  // blocks per CU) is built and tested but LOSES on the step's N = 64 launches (x0.86 / x0.98): their 16-K-step tiles spend
+  // 17-21 % of a block's time in the epilogue and keep the loaders 36-74 % busy issuing (cycle stamps: docs/LAB_NOTES.md E),
+  // so it is served only when forced (LAB build).
+  if (N % 128 == 0) {
+    p.bm = p.bn = 128;
+    p.bpc = 1;
+  } else {
+    if (!lab_env("MMDYN_WSP_TILE")) return p;
+    p.bm = 128;
+    p.bn = 64;
+    p.bpc = 2;
+  }
+  if (const char* e = lab_env("MMDYN_WSP_TILE")) {       // LAB build: force one tile (kernel experiments)
+    int a = 0, b = 0;
+    if (sscanf(e, "%d,%d", &a, &b) == 2 && a == 128 && (b == 64 || b == 128) && N % b == 0) {
+      p.bn = b;
+      p.bpc = b == 128 ? 1 : 2;
+    }
+  }
+  const long tiles = (long)G * ((rows_g + p.bm - 1) / p.bm) * (N / p.bn) * ncls;
+  if (tiles * ksteps >= (1L << 30)) return WspPick{0, 0, 0};
+  long min_units = 2L * 16 * cus * p.bpc;                // at least two 16-K-step tiles' worth per resident block
+  if (const char* e = lab_env("MMDYN_WSP_MIN_UNITS")) min_units = atol(e);
+  if (tiles * ksteps < min_units || mode == MMDYN_DENSE) {
+    if (!lab_env("MMDYN_WSP_TILE")) return WspPick{0, 0, 0};
+  }
+  return p;
+}
+
+static WspSched make_sched(const IgemmGeom& g, const WspPick& p, int ksteps) {
+  WspSched sc{};
+  const int tpg = ceil_div(g.Bg * g.Hr * g.Wr, p.bm);
+  sc.ny = g.N / p.bn;
+  sc.si = sc.ny * g.nclasses;
+  sc.tiles = g.G * tpg * sc.si;
+  sc.ksteps = ksteps;
+  const long units = (long)sc.tiles * ksteps;
+  const long nblk = (long)device_cus() * p.bpc;
+  sc.per = (int)((units + nblk - 1) / nblk);
+  if (const char* e = lab_env("MMDYN_WSP_UNITS_PER_BLOCK")) {      // LAB build: force the cut (kernel tests: split tiles)
+    const int v = atoi(e);
+    if (v > 0 && (units + v - 1) / v <= 65535L * 16) sc.per = v;
+  }
+  // (a block never starts inside the last S-1 K-steps of a tile for nothing: ranges are plain equal cuts; the ring does not care)
+  sc.inv_hw = 1.0f / (float)(g.Hr * g.Wr);
+  sc.inv_w = 1.0f / (float)g.Wr;
+  return sc;
+}
+
+static bool has_split_tiles(const WspSched& sc) { return sc.per % sc.ksteps != 0; }
+
+template <int MODE, int BM, int BN, int WM, int WN, int S, int B16>
+static int wsp_launch(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
+                      IgemmGeom g, const WspSched& sc, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  constexpr int NM = (BM / WM) * (BN / WN);
+  g.tiles_per_group = ceil_div(g.Bg * g.Hr * g.Wr, BM);
+  const long units = (long)sc.tiles * sc.ksteps;
+  const int nblk = (int)((units + sc.per - 1) / sc.per);
+  const size_t smem = (size_t)S * (BM + BN) * RB + (size_t)NRO * BM * sizeof(int) + (size_t)NM * 16 * TRLD * sizeof(float);
+  static LdsOptIn lds_opt_in;
+  if (int e = lds_opt_in.ensure((const void*)igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16>, (int)smem)) return e;
+  if (has_split_tiles(sc) && !slabs) return MMDYN_ERR_NULL;
+#ifdef MMDYN_LAB
+  if constexpr (B16 == 0 && MODE != MMDYN_DENSE) {
+    const char* e = lab_env("MMDYN_WSP_DIAG");
+    if (e && e[0] == '1') {
+      static LdsOptIn diag_opt_in;
+      if (int er = diag_opt_in.ensure((const void*)igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16, true>, (int)smem)) return er;
+      hipLaunchKernelGGL((igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16, true>), dim3(nblk), dim3(64 * (NM + NL)), smem, st, A, Bp,
+                         bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes);
+      if (has_split_tiles(sc))
+        hipLaunchKernelGGL((igemm_wsp_fixup_kernel<MODE, BM, BN, WM, WN, B16>), dim3(sc.tiles), dim3(64 * NM), 0, st, bias, C, C_act,
+                           stats, slabs, g, sc);
+      MMDYN_LAUNCH_CHECK();
+    }
+  }
+#endif
+  hipLaunchKernelGGL((igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16>), dim3(nblk), dim3(64 * (NM + NL)), smem, st, A, Bp, bias, C,
+                     C_act, stats, slabs, g, sc, a_bytes, b_bytes);
+  if (has_split_tiles(sc))
+    hipLaunchKernelGGL((igemm_wsp_fixup_kernel<MODE, BM, BN, WM, WN, B16>), dim3(sc.tiles), dim3(64 * NM), 0, st, bias, C, C_act,
+                       stats, slabs, g, sc);
+  MMDYN_LAUNCH_CHECK();
+}
+
+template <int MODE, int B16>
+static int wsp_launch_mode(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
+                           const IgemmGeom& g, const WspPick& p, const WspSched& sc, unsigned a_bytes, unsigned b_bytes,
+                           hipStream_t st) {
+  if (p.bn == 128) return wsp_launch<MODE, 128, 128, 64, 32, 3, B16>(A, Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
+  return wsp_launch<MODE, 128, 64, 64, 32, 3, B16>(A, Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
+}
+
+template <int B16>
+static int wsp_dispatch(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
+                        const IgemmGeom& g, const WspPick& p, const WspSched& sc, hipStream_t st) {
+  const int esz = B16 ? 2 : 4;
+  const unsigned a_bytes = (unsigned)((int64_t)g.G * g.Bg * g.Hi * g.Wi * g.Cin * esz);
+  const unsigned b_bytes = (unsigned)((int64_t)(g.mode == MMDYN_DENSE ? 1 : 16) * g.N * g.Cin * esz);
+  if (g.mode == MMDYN_DENSE) return wsp_launch_mode<MMDYN_DENSE, B16>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
+  if (g.mode == MMDYN_CONV) return wsp_launch_mode<MMDYN_CONV, B16>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
+  return wsp_launch_mode<MMDYN_TCONV_S2P1, B16>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
+}
+
+static int ksteps_of(int mode, int Cin, bool b16) {
+  return (mode == MMDYN_CONV ? 16 : (mode == MMDYN_TCONV_S2P1 ? 4 : 1)) * (Cin / (b16 ? 64 : BK));
+}
+
+}  // namespace
+
+// BatchNorm partial-sum tiles per group the persistent kernel writes for the shape (0: not served): one per M-tile, parity
+// class and wave row
+int mmdyn_igemm_wsp_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, bool b16) {
+  int Hr = Ho, Wr = Wo, ncls = 1;
+  if (mode == MMDYN_TCONV_S2P1) {
+    Hr = Hi;
+    Wr = Wi;
+    ncls = 4;
+  }
+  const WspPick p = wsp_pick(mode, G, Bg, Hi, Wi, Hr, Wr, Cin, N, ncls, 1, b16, 0);
+  if (!p.bm) return 0;
+  return ncls * ceil_div(Bg * Hr * Wr, p.bm) * 2;        // both tiles are cut into waves of 64 x 32: two wave rows
+}
+
+// bytes of slab workspace the launch needs for its split tiles (0: none, or not served)
+int64_t mmdyn_igemm_wsp_slab_bytes(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, bool b16) {
+  IgemmGeom g{};
+  g.mode = mode;
+  g.G = G;
+  g.Bg = Bg;
+  g.N = N;
+  g.Hr = Ho;
+  g.Wr = Wo;
+  g.nclasses = 1;
+  if (mode == MMDYN_TCONV_S2P1) {
+    g.Hr = Hi;
+    g.Wr = Wi;
+    g.nclasses = 4;
+  }
+  const WspPick p = wsp_pick(mode, G, Bg, Hi, Wi, g.Hr, g.Wr, Cin, N, g.nclasses, 1, b16, 0);
+  if (!p.bm) return 0;
+  const WspSched sc = make_sched(g, p, ksteps_of(mode, Cin, b16));
+  if (!has_split_tiles(sc)) return 0;
+  const long units = (long)sc.tiles * sc.ksteps;
+  const long nblk = (units + sc.per - 1) / sc.per;
+  return (int64_t)nblk * 2 * p.bm * p.bn * 4;
+}
+
+// bf16_ops: the launch runs on the 16-bit matrix cores; served only when BOTH operands are 16-bit in HBM
+int mmdyn_igemm_wsp_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
+                        const IgemmGeom& g, bool bf16_ops, hipStream_t st) {
+  if (bf16_ops && (!g.a_b16 || !g.b_b16)) return 1;
+  const WspPick p = wsp_pick(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Hr, g.Wr, g.Cin, g.N, g.nclasses, g.splitk, bf16_ops, g.b_group_stride);
+  if (!p.bm) return 1;
+  const WspSched sc = make_sched(g, p, ksteps_of(g.mode, g.Cin, bf16_ops));
+  if (bf16_ops && g.f16) return wsp_dispatch<2>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, st);
+  if (bf16_ops) return wsp_dispatch<1>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, st);
+  return wsp_dispatch<0>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, st);
+}
+
+#ifdef MMDYN_LAB
+// LAB build: read (and clear) the cycle stamps of the MMDYN_WSP_DIAG=1 launches since the last call (out: 8 x uint64, host)
+extern "C" int mmdyn_lab_wsp_diag(unsigned long long* out) {
+  if (!out) return MMDYN_ERR_NULL;
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(wsp_diag), sizeof(unsigned long long) * 8);
+  if (e != hipSuccess) return (int)e;
+  unsigned long long zero[8] = {};
+  e = hipMemcpyToSymbol(HIP_SYMBOL(wsp_diag), zero, sizeof(zero));
+  return e == hipSuccess ? MMDYN_OK : (int)e;
+}
+#endif

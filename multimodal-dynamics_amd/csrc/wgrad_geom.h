@@ -12,6 +12,10 @@ struct WgradGeom {
   int Hi, Wi, Cg;
   int rs, ro;
   int ntaps, chunks, rows_per_chunk;
+  // Grouped launch (mmdyn_wgrad_tn_grouped, DENSE only): `groups` independent problems whose rows follow one another in D
+  // and Gt (group g = rows [g*rows, (g+1)*rows)); each is cut into `chunks` slabs and the slabs are laid out
+  // [slab][group][Cd][Cg], so that ONE mmdyn_wgrad_reduce over Cd' = groups*Cd sums them all.  0 / 1 = a plain launch.
+  int groups;
 };
 
 // wgrad_ws.hip (LAB build only: measured no faster than wgrad_tn.hip, see wgrad_entry): fp32 weight-gradient GEMM with loader

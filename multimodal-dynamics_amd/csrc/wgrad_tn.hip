@@ -72,13 +72,17 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
   const int tiles_g = g.Cg / BG;
   const int td = blockIdx.x / tiles_g, tg = blockIdx.x - td * tiles_g;
   const int cd0 = td * BD, cg0 = tg * BG;
-  const int tap = blockIdx.y, chunk = blockIdx.z;
+  const int tap = blockIdx.y;
+  // grouped launch: blockIdx.z = group * zblocks + chunk (plain launch: one group)
+  const int ngrp = g.groups > 1 ? g.groups : 1;
+  const int zb = gridDim.z / ngrp;
+  const int grp = blockIdx.z / zb, chunk = blockIdx.z - grp * zb;
   const int dh = (MODE == MMDYN_CONV) ? (tap >> 2) : 0;
   const int dw = (MODE == MMDYN_CONV) ? (tap & 3) : 0;
   const int HWr = g.Hr * g.Wr;
 
-  const int row_begin = chunk * g.rows_per_chunk;
-  const int row_end = min(g.rows, row_begin + g.rows_per_chunk);
+  const int row_begin = grp * g.rows + chunk * g.rows_per_chunk;
+  const int row_end = min((grp + 1) * g.rows, row_begin + g.rows_per_chunk);
 
   // Branch-free fetch (same idea as igemm_nt): rows past the chunk or outside the image read a valid dummy
   // address and are zeroed when the tile is written to LDS; pixel decode uses a float reciprocal (rows < 2^23).
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
     }
   }
 
-  float* out = partial + ((size_t)((chunk * WK + wk) * g.ntaps + tap) * g.Cd) * g.Cg;
+  float* out = partial + ((size_t)(((chunk * WK + wk) * ngrp + grp) * g.ntaps + tap) * g.Cd) * g.Cg;
 #pragma unroll
   for (int a = 0; a < DT; ++a)
 #pragma unroll
@@ -883,7 +887,7 @@ static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, 
   const int zblocks = g.chunks / WK;  // chunks % 4 == 0 is checked by the caller
   int rpc = ceil_div(g.rows, zblocks);
   g.rows_per_chunk = ceil_div(rpc, RK) * RK;
-  dim3 grid((g.Cd / BD) * (g.Cg / BG), g.ntaps, zblocks);
+  dim3 grid((g.Cd / BD) * (g.Cg / BG), g.ntaps, zblocks * (g.groups > 1 ? g.groups : 1));
   size_t smem = (size_t)RK * (BD + BG) * sizeof(float);
 #define WGRAD_LAUNCH(M, BF, ST_)                                                                                      \
   hipLaunchKernelGGL((wgrad_tn_kernel<M, BD, BG, WD, WG, WK, BF, ST_>), grid, dim3(256), smem, st, D, Gt, partial, g)
@@ -918,8 +922,9 @@ static bool tile_128x64() {
 
 static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr,
                        int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
-                       void* stream, bool bf16, int storage_flags = 0) {
+                       void* stream, bool bf16, int storage_flags = 0, int groups = 1) {
   if (!D || !Gt || !partial) return MMDYN_ERR_NULL;
+  if (groups < 1 || (groups > 1 && mode != MMDYN_DENSE)) return MMDYN_ERR_SHAPE;
   if (Cd % 32 || Cg % 32 || Cd <= 0 || Cg <= 0 || chunks < 4 || chunks % 4) return MMDYN_ERR_SHAPE;
   if (mode != MMDYN_DENSE && mode != MMDYN_CONV && mode != MMDYN_IM2COL3) return MMDYN_ERR_SHAPE;
   if (mode == MMDYN_IM2COL3 && (Cg != 64 || Hi != 2 * Hr || Wi != 2 * Wr)) return MMDYN_ERR_SHAPE;
@@ -929,8 +934,9 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
   g.f16 = (storage_flags & 32) != 0;
   if (storage_flags && (!bf16 || (g.g_b16 && mode == MMDYN_IM2COL3))) return MMDYN_ERR_SHAPE;
   g.mode = mode;
+  g.groups = groups;
   const int64_t rows = (int64_t)Bt * Hr * Wr;
-  if (rows * Cd >= (1LL << 31) || (int64_t)Bt * Hi * Wi * (mode == MMDYN_IM2COL3 ? 3 : Cg) >= (1LL << 31))
+  if (groups * rows * Cd >= (1LL << 31) || groups * rows * Cg >= (1LL << 31) || (int64_t)Bt * Hi * Wi * (mode == MMDYN_IM2COL3 ? 3 : Cg) >= (1LL << 31))
     return MMDYN_ERR_RANGE;
   g.rows = (int)rows;
   g.Hr = Hr;
@@ -954,11 +960,12 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
     // against the kernels below (profiles/r3/ab_ws_wgrad.txt): x0.97-1.10, one launch x0.69, sum +3 % -- unlike the implicit
     // GEMM this kernel gains nothing from the ring, so the product keeps one code path and does not build it.
     const char* e = lab_env("MMDYN_WGRAD_WS");
-    if (e && e[0] == '1') {
+    if (e && e[0] == '1' && groups == 1) {
       const int rc = mmdyn_wgrad_ws_try(D, Gt, partial, g, st);
       if (rc != 1) return rc;
     }
   }
+  if (groups > 1 && g.d_b16 && g.g_b16) return MMDYN_ERR_SHAPE;     // (grouped: the register-staged kernel below only)
   if (bf16 && g.d_b16 && g.g_b16 && mode != MMDYN_IM2COL3) {
     // both operands bf16 in HBM: the transposing-LDS-read kernel (two waves share a 64x32 / 32x64 tile's rows)
     if (Cd % 128 == 0 && Cg % 128 == 0) return launch_b16<128, 128, 64, 64, 1>(D, Gt, partial, g, st);
@@ -1004,6 +1011,16 @@ extern "C" int mmdyn_wgrad_tn_bf16(const float* D, const float* Gt, float* parti
                                    int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
                                    void* stream) {
   return wgrad_entry(D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks, stream, true);
+}
+
+/* Grouped weight gradient (DENSE): G independent problems of one shape in one launch -- group g owns rows [g*rows, (g+1)*rows)
+ * of D [G*rows][Cd] and Gt [G*rows][Cg]; partial is laid out [chunks][G][Cd][Cg], so ONE mmdyn_wgrad_reduce(partial, canon,
+ * chunks, 1, G*Cd, Cg, ...) produces the G gradients [G][Cd][Cg] (the heads of the visual / tactile / pose encoders,
+ * vae.py:211-216, whose weights the fused engine keeps adjacent).  flags as mmdyn_wgrad_tn_mx (0 = fp32). */
+extern "C" int mmdyn_wgrad_tn_grouped(const void* D, const void* Gt, float* partial, int G, int rows, int Cd, int Cg, int chunks,
+                                      int flags, void* stream) {
+  return wgrad_entry((const float*)D, (const float*)Gt, partial, MMDYN_DENSE, rows, 1, 1, Cd, 1, 1, Cg, 1, 0, chunks, stream,
+                     (flags & 1) != 0 || (flags & 32) != 0, flags & ~1, G);
 }
 
 /* fp16 matrix cores (v_mfma_f32_32x32x8_f16), fp32 accumulate, fp32 storage: BASELINE configs[4] */

@@ -29,16 +29,19 @@ MAX_EXPERTS = 4
 # name -> argument type codes, in header order: p pointer, i int, l int64, f float, Q uint64
 _SIGNATURES = {
     "mmdyn_igemm_nt": "ppppppp" + "iiiiiiiiiiiiii" + "p",
-    "mmdyn_igemm_nt_dgrad_bn": "ppppppppp" + "iiiiiiiiiiii" + "p",
-    "mmdyn_igemm_nt_dgrad_act": "pppp" + "i" + "iiiiiiiiiii" + "i" + "p",
+    "mmdyn_igemm_nt_dgrad_bn": "ppppppppp" + "iiiiiiiiiiii" + "pp",
+    "mmdyn_igemm_nt_dgrad_act": "pppp" + "i" + "iiiiiiiiiii" + "i" + "pp",
+    "mmdyn_igemm_slab_floats": "iiiiiiiii",
     "mmdyn_igemm_nt_bf16": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_nt_f16": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_stat_tiles": "iiiiiiiii",
     "mmdyn_igemm_stat_tiles_bf16": "iiiiiiiii",
+    "mmdyn_igemm_nt_grouped": "pppppp" + "iiiiii" + "p",
     "mmdyn_splitk_reduce": "pppp" + "iiii" + "p",
     "mmdyn_wgrad_tn": "ppp" + "iiiiiiiiiii" + "p",
     "mmdyn_wgrad_tn_bf16": "ppp" + "iiiiiiiiiii" + "p",
     "mmdyn_wgrad_tn_f16": "ppp" + "iiiiiiiiiii" + "p",
+    "mmdyn_wgrad_tn_grouped": "ppp" + "iiiiii" + "p",
     "mmdyn_wgrad_chunks": "iiii",
     "mmdyn_wgrad_chunks_mx": "iiiii",
     "mmdyn_wgrad_reduce": "pp" + "iiiiii" + "f" + "p",

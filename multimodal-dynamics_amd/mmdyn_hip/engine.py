@@ -38,6 +38,8 @@ def w_dtype(precision):
     anyway ("bf16" packs bf16 too: the kernels round fp32 weights to bf16 on their way in, packing does it once)."""
     return {"bf16": torch.bfloat16, "bf16s": torch.bfloat16, "fp16s": torch.float16}.get(precision, torch.float32)
 
+HEAD_GROUP_ORDER = ("visual_encoder", "tactile_encoder", "pose_encoder")    # groups of the grouped heads launches
+
 _PREFIX_ORDER = ["pose_decoder", "visual_decoder", "tactile_decoder",         # bucket 0: ready first
                  "heads", "pose_encoder", "encoder_fc",                      # bucket 1: heads, pose encoder and the image
                  #                      encoders' FC layer (two thirds of the encoder parameters, first in their backward)
@@ -56,8 +58,13 @@ class FlatParams:
         named = dict(model.named_parameters())
         # the two heads of an encoder are ONE fused GEMM ([means | log_var] rows): keeping their weights adjacent (and
         # their biases adjacent) in the flat buffers lets the backward write both gradients as one [2L][K] / [2L] block
+        # ... and the heads of ALL encoders are one GROUPED launch each way (layers.heads_*_grouped): their weights follow
+        # one another in group order (visual, tactile, pose) -- [G][2L][K] --, their biases behind them
         rank = {"linear_means.weight": 0, "linear_log_var.weight": 1, "linear_means.bias": 2, "linear_log_var.bias": 3}
-        heads = sorted((k for k in named if ".linear_" in k), key=lambda k: (k.split(".", 1)[0], rank[k.split(".", 1)[1]]))
+        enc_order = {p: i for i, p in enumerate(HEAD_GROUP_ORDER)}
+        heads = sorted((k for k in named if ".linear_" in k),
+                       key=lambda k: (rank[k.split(".", 1)[1]] >= 2, enc_order.get(k.split(".", 1)[0], 99), k.split(".", 1)[0],
+                                      rank[k.split(".", 1)[1]]))
         groups = {p: [] for p in _PREFIX_ORDER}
         groups["heads"] = list(heads)
         for k in named:
@@ -106,6 +113,21 @@ class FlatParams:
             return None
         ow, ob = self.offsets[kw[0]], self.offsets[kb[0]]
         return self.grad[ow:ow + 2 * L * K].view(2 * L, K), self.grad[ob:ob + 2 * L]
+
+    def grouped_heads_grad(self, prefixes):
+        """(gW_all [G*2L][K], [gb_g [2L]]) views of the flat gradient buffer covering the heads of ``prefixes`` in that
+        order, or None when they are not laid out [G][2L][K] there (unequal head shapes)."""
+        views = [self.fused_heads_grad(p) for p in prefixes]
+        if any(v is None for v in views):
+            return None
+        L, K = self.P[f"{prefixes[0]}.linear_means.weight"].shape
+        o0 = self.offsets[f"{prefixes[0]}.linear_means.weight"]
+        for g, p in enumerate(prefixes):
+            if tuple(self.P[f"{p}.linear_means.weight"].shape) != (L, K) or \
+                    self.offsets[f"{p}.linear_means.weight"] != o0 + g * 2 * L * K:
+                return None
+        G = len(prefixes)
+        return self.grad[o0:o0 + G * 2 * L * K].view(G * 2 * L, K), [v[1] for v in views]
 
     def sub(self, prefix, which="P"):
         src = self.P if which == "P" else self.G
@@ -285,6 +307,15 @@ class MVAEStep:
         # every weight repack of a step (conv tap-major packs, FC permutations / transposes, fused heads) as ONE
         # kernel launch over a device-resident plan; the emulation backend packs per stack instead
         self.plan = None
+        # The fused heads of the visual / tactile (/ pose) encoders as ONE grouped launch each way at the product-of-experts
+        # join: equal head shapes (the unconditional models; a condition widens the image heads only)
+        # and gradients laid out [G][2L][K] in the flat buffer.  Otherwise each encoder launches its own heads.
+        self._head_prefixes = [p for p in HEAD_GROUP_ORDER if p != "pose_encoder" or self.use_pose]
+        self._hg_grad = None if self.conditional else self.params.grouped_heads_grad(self._head_prefixes)
+        self._hg_all, self._hg_views = None, None
+        if self._hg_grad is not None:
+            self._hg_all, self._hg_views = layers.heads_group_buffers([self.params.sub(p) for p in self._head_prefixes],
+                                                                      self.params.flat, w_dtype(precision))
         if ops.B.name == "hip":
             FP = self.params
             specs = {"ev": layers.encoder_pack_specs(FP.sub("visual_encoder")),
@@ -297,8 +328,11 @@ class MVAEStep:
                 specs["hp"] = layers.heads_pack_specs(FP.sub("pose_encoder"))
             # what the encoder forward reads goes first (critical path); the transposed / decoder packs are launched
             # next to the encoder phase (run_late) and are ready long before the decoders start
+            pre = None
+            if self._hg_views is not None:     # the grouped launches' operands: the plan packs straight into their slices
+                pre = {"h" + p[0]: v for p, v in zip(self._head_prefixes, self._hg_views)}
             self.plan = layers.PackPlan(specs, early=("W1p", "W2k", "W3k", "W4k", "W5k", "W6k", "Wf", "Wh", "bh"),
-                                        w_dtype=w_dtype(precision))
+                                        w_dtype=w_dtype(precision), prealloc=pre)
         self._capturing = False
         self._graph = None
         self._static_mask = self._static_cond = None
@@ -408,6 +442,17 @@ class MVAEStep:
         c["mask"] = {"v": mv, "t": mt}
         LN.join()
         self.acc.zero_()
+        if self._hg_grad is not None:
+            # operand of the grouped heads launch: the (dropped-out) features of every pass of every encoder, group-major
+            c["hg_rows"] = len(self.pass_v) * c["B"]
+            c["hd_all"] = torch.empty(len(self._head_prefixes) * c["hg_rows"], 512, device=c["dev"])
+            if self.plan is None:              # (emulation backend: no pack plan -- pack the heads into the group buffers here)
+                for p, v in zip(self._head_prefixes, self._hg_views):
+                    layers.pack_now(layers.heads_pack_specs(self.params.sub(p)), pre=v)
+
+    def _hd_slice(self, key, gi):
+        r = self.ctx["hg_rows"]
+        return self.ctx[key][gi * r:(gi + 1) * r]
 
     def _ph_pack_late(self):
         """Decoder and backward (transposed) weight packs: on the joint stream while the lanes run the encoders."""
@@ -421,6 +466,9 @@ class MVAEStep:
         n = len(self._passes_of(m))
         h, c["e" + m] = yield from layers.encoder_trunk_forward_steps(FP.sub(enc), self._buffers(enc), c["x"][m], 1, n,
                                                                      c["pk"].get("e" + m))
+        if self._hg_grad is not None:          # grouped heads: the launch follows the lanes' join (_ph_heads)
+            ops.B.dropout_expand(h, c["mask"][m], self._hd_slice("hd_all", self._MOD[m][2]), n, B, 512, DROPOUT_P)
+            return
         hd = torch.empty(n * B, 512, device=c["dev"])
         ops.B.dropout_expand(h, c["mask"][m], hd, n, B, 512, DROPOUT_P)
         cond = None if c["cond"] is None else c["cond"].repeat(n, 1)           # the same condition rows for every pass
@@ -431,8 +479,30 @@ class MVAEStep:
         c["op"] = None
         if self.use_pose:
             pose_rep = c["pose"].repeat(len(self.pass_p), 1)                  # same pose rows for each pass
+            if self._hg_grad is not None:
+                _, c["ep"] = layers.pose_encoder_trunk_forward(FP.sub("pose_encoder"), pose_rep, out=self._hd_slice("hd_all", 2))
+                return
             hp, c["ep"] = layers.pose_encoder_trunk_forward(FP.sub("pose_encoder"), pose_rep)
             c["op"], c["hp"] = layers.heads_forward(FP.sub("pose_encoder"), hp, c["pk"].get("hp"))
+
+    def _ph_heads(self):
+        """Grouped heads of every encoder, one launch (joint stream, after the lanes' join)."""
+        c = self.ctx
+        if self._hg_grad is None:
+            return
+        G = len(self._head_prefixes)
+        c["o_all"] = layers.heads_forward_grouped(c["hd_all"], self._hg_all, G, c["hg_rows"])
+        c["ov"], c["ot"] = self._hd_slice("o_all", 0), self._hd_slice("o_all", 1)
+        c["op"] = self._hd_slice("o_all", 2) if self.use_pose else None
+
+    def _ph_heads_bwd(self):
+        """Backward of the grouped heads: three grouped launches (weight gradients, their slab reduction, input gradients)."""
+        c = self.ctx
+        if self._hg_grad is None:
+            return
+        G = len(self._head_prefixes)
+        c["dhd_all"] = layers.heads_backward_grouped(c["hd_all"], c["do_all"], self._hg_all, self._hg_grad[0], self._hg_grad[1],
+                                                     G, c["hg_rows"])
 
     def _ph_poe(self):
         """Product of experts + reparametrisation + KL for every pass, one launch."""
@@ -510,15 +580,23 @@ class MVAEStep:
         if self.use_pose:
             for g, p in enumerate(self.pass_p):
                 blocks[p][2] = c["dzp"][g * B:(g + 1) * B]
-        c["dov"], c["dot"] = torch.empty_like(c["ov"]), torch.empty_like(c["ot"])
-        c["dop"] = torch.empty_like(c["op"]) if self.use_pose else None
+        if self._hg_grad is not None:
+            c["do_all"] = torch.empty_like(c["o_all"])
+            c["dov"], c["dot"] = self._hd_slice("do_all", 0), self._hd_slice("do_all", 1)
+            c["dop"] = self._hd_slice("do_all", 2) if self.use_pose else None
+        else:
+            c["dov"], c["dot"] = torch.empty_like(c["ov"]), torch.empty_like(c["ot"])
+            c["dop"] = torch.empty_like(c["op"]) if self.use_pose else None
         ops.B.poe_bwd(self._passes(c, B, [c["dov"], c["dot"], c["dop"]], blocks), c["eps"], c["mu"], c["lv"], None, None,
                       None, self.loss_scale / B, True, P, B, L, self.klw)
 
     def _ph_enc_bwd_steps(self, m):
         c, FP, B = self.ctx, self.params, self.ctx["B"]
         enc = self._MOD[m][0]
-        dhd = layers.heads_backward(c["h" + m], c["do" + m], FP.sub(enc, "G"), fused=FP.fused_heads_grad(enc))
+        if self._hg_grad is not None:
+            dhd = self._hd_slice("dhd_all", self._MOD[m][2])
+        else:
+            dhd = layers.heads_backward(c["h" + m], c["do" + m], FP.sub(enc, "G"), fused=FP.fused_heads_grad(enc))
         dh = torch.empty(B, 512, device=c["dev"])
         # (the FC layer's Swish backward rides along: dh is dL/du5)
         ops.B.dropout_reduce(dhd, c["mask"][m], dh, len(self._passes_of(m)), B, 512, DROPOUT_P, u=c["e" + m]["u5"],
@@ -529,8 +607,11 @@ class MVAEStep:
     def _ph_pose_enc_bwd(self):
         c, FP = self.ctx, self.params
         if self.use_pose:
-            dhp = layers.heads_backward(c["hp"], c["dop"], FP.sub("pose_encoder", "G"),
-                                        fused=FP.fused_heads_grad("pose_encoder"))
+            if self._hg_grad is not None:
+                dhp = self._hd_slice("dhd_all", 2)
+            else:
+                dhp = layers.heads_backward(c["hp"], c["dop"], FP.sub("pose_encoder", "G"),
+                                            fused=FP.fused_heads_grad("pose_encoder"))
             layers.pose_encoder_trunk_backward(FP.sub("pose_encoder"), c["ep"], dhp, FP.sub("pose_encoder", "G"))
 
     def _publish(self):
@@ -564,6 +645,7 @@ class MVAEStep:
         self._two(self._ph_enc_steps)
         self._ph_pose_enc()
         LN.join()
+        self._ph_heads()
         self._ph_poe()
         LN.fork()
         self._two(self._ph_dec_fwd_steps)
@@ -608,6 +690,7 @@ class MVAEStep:
         LN.join()
         handles += self._reduce_bucket(0)
         self._ph_poe_bwd()
+        self._ph_heads_bwd()
         LN.fork()
         self._two(self._ph_enc_bwd_steps)
         self._ph_pose_enc_bwd()
@@ -765,11 +848,11 @@ class MVAEStep:
             [("main", lambda: self._ph_pre())],
             [("l0", lambda: run(self._ph_enc_steps("v"))), ("l1", lambda: run(self._ph_enc_steps("t"))),
              ("main", lambda: (self._ph_pack_late(), self._ph_pose_enc()))],
-            [("main", lambda: self._ph_poe())],
+            [("main", lambda: (self._ph_heads(), self._ph_poe()))],
             [("l0", lambda: (run(self._ph_dec_fwd_steps("v")), run(self._ph_dec_bwd_steps("v")))),
              ("l1", lambda: (run(self._ph_dec_fwd_steps("t")), run(self._ph_dec_bwd_steps("t")))),
              ("main", lambda: (self._ph_pose_dec_fwd(), self._ph_pose_dec_bwd()))],
-            [("main", lambda: (self._ph_assemble(), self._ph_poe_bwd()))],
+            [("main", lambda: (self._ph_assemble(), self._ph_poe_bwd(), self._ph_heads_bwd()))],
         ]
         # deferred decoder weight gradients: two more streams next to the encoder backward, joined in front of the optimiser
         # (_replay).  Forking them one phase earlier, next to the serial latent backward, measured no better: 6.69 vs 6.68 ms.

@@ -47,11 +47,12 @@ def _cdiv(a, b):
 # ------------------------------------------------------------------------------------------------
 # primitive helpers
 # ------------------------------------------------------------------------------------------------
-def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch.float32, act_dtype=None):
+def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch.float32, act_dtype=None, out=None):
     """C = A[rows][K] . Bp[N][K]^T (+bias) on the MFMA GEMM; picks split-K for short, wide-K problems.
     Returns (pre_activation, activated or None).  ``act_dtype``: storage type of the activated output alone (bf16 when it
-    feeds a convolution of the bf16-storage mode; only without split-K)."""
-    C = _new(A, rows, N, dtype=out_dtype)
+    feeds a convolution of the bf16-storage mode; only without split-K).  ``out``: write the pre-activation there (a
+    contiguous [rows][N] view, e.g. one group's rows of a grouped launch's operand) instead of a fresh tensor."""
+    C = _new(A, rows, N, dtype=out_dtype) if out is None else out
     Ca = _new(A, rows, N, dtype=out_dtype if act_dtype is None else act_dtype) if want_act else None
     # split-K only when the 64x64 tiling leaves most of the 256 CUs idle AND K is long enough to amortise the
     # partial-sum pass and its second launch.  Re-measured with the wave-specialised kernels (tests/microbench/
@@ -364,18 +365,19 @@ def heads_pack_specs(P):
             _spec("WhT", Wl, 1, L, K, Kp, L, (Kp, 2 * L), (0, L, 2 * L))]
 
 
-def _alloc_packed(specs, like, w_dtype=None):
+def _alloc_packed(specs, like, w_dtype=None, pre=None):
+    """``pre``: {name: tensor} destinations that already exist (views into a grouped launch's contiguous operands)."""
     wd = W_DTYPE if w_dtype is None else w_dtype
-    out = {}
+    out = dict(pre or {})
     for s in specs:
         if s["name"] not in out:       # matrices are GEMM operands (W_DTYPE); vectors are biases (always fp32)
             out[s["name"]] = torch.zeros(s["shape"], device=like.device, dtype=wd if len(s["shape"]) >= 2 else torch.float32)
     return out
 
 
-def pack_now(specs):
+def pack_now(specs, pre=None):
     """One kernel per entry (module-API path)."""
-    out = _alloc_packed(specs, specs[0]["src"])
+    out = _alloc_packed(specs, specs[0]["src"], pre=pre)
     for s in specs:
         dst = out[s["name"]]
         if s["kind"] >= K_KEEP:
@@ -393,7 +395,7 @@ class PackPlan:
     """All repacks of the given spec lists as ONE kernel launch (mmdyn_pack_plan).  Source and destination
     storage must not move afterwards (the fused engine's flat parameter buffer and these outputs never do)."""
 
-    def __init__(self, named_specs, early=(), w_dtype=None):
+    def __init__(self, named_specs, early=(), w_dtype=None, prealloc=None):
         """``early``: names of the packed tensors the first phase of the step needs; they go to the front of the
         table so that :meth:`run_early` / :meth:`run_late` can launch the two halves at different points."""
         import ctypes
@@ -401,7 +403,7 @@ class PackPlan:
         self.packed, entries = {}, []
         order = []
         for key, specs in named_specs.items():
-            outs = _alloc_packed(specs, specs[0]["src"], w_dtype)
+            outs = _alloc_packed(specs, specs[0]["src"], w_dtype, (prealloc or {}).get(key))
             self.packed[key] = outs
             order += [(0 if s["name"] in early else 1, len(order) + i, outs, s) for i, s in enumerate(specs)]
         order.sort(key=lambda t: (t[0], t[1]))
@@ -444,13 +446,13 @@ class PackPlan:
 # ------------------------------------------------------------------------------------------------
 # generic Linear (MFMA when both dims are multiples of 32, the small kernel for the 7-wide pose ends)
 # ------------------------------------------------------------------------------------------------
-def linear_forward(x, W, b, act=ACT_NONE):
-    """y = act(x W^T + b).  Returns (pre_activation or None, y)."""
+def linear_forward(x, W, b, act=ACT_NONE, out=None):
+    """y = act(x W^T + b).  Returns (pre_activation or None, y).  ``out`` (act == ACT_NONE, MFMA path): destination of y."""
     rows, K = x.shape
     N = W.shape[0]
     if K % 32 == 0 and N % 32 == 0:
         if act == ACT_NONE:
-            u, _ = dense(x, W, b, rows, K, N)
+            u, _ = dense(x, W, b, rows, K, N, out=out)
             return None, u
         u, y = dense(x, W, b, rows, K, N, act, want_act=True)
         return u, y
@@ -734,16 +736,53 @@ def heads_backward(c, dout, grads, need_dx=True, fused=None):
     return dx if Kp == c["K0"] else crop_columns(dx, Kp, c["K0"])
 
 
+def heads_group_buffers(Ps, like, w_dtype=None):
+    """Contiguous packed operands of the fused heads of ``len(Ps)`` encoders with equal head shapes: ({"Wh": [G][2L][Kp],
+    "bh": [G][2L], "WhT": [G][Kp][2L]}, per-group views in the layout of heads_pack_specs) -- the weights of a grouped
+    launch (mmdyn_igemm_nt_grouped) follow one another at a fixed stride."""
+    L, K = Ps[0]["linear_means.weight"].shape
+    Kp, G = _pad32(K), len(Ps)
+    wd = W_DTYPE if w_dtype is None else w_dtype
+    allb = {"Wh": torch.zeros(G, 2 * L, Kp, device=like.device, dtype=wd), "bh": torch.zeros(G, 2 * L, device=like.device),
+            "WhT": torch.zeros(G, Kp, 2 * L, device=like.device, dtype=wd)}
+    return allb, [{k: v[g] for k, v in allb.items()} for g in range(G)]
+
+
+def heads_forward_grouped(hd_all, pk_all, G, rows):
+    """hd_all [G*rows][Kp] (group g = rows [g*rows, (g+1)*rows)) -> out [G*rows][2L], every group on its own heads: the
+    linear_means | linear_log_var pairs of the visual, tactile and pose encoders (vae.py:211-216, 239-240) as ONE launch."""
+    _, N, Kp = pk_all["Wh"].shape
+    out = _new(hd_all, G * rows, N)
+    ops.B.igemm_nt_grouped(hd_all, pk_all["Wh"], pk_all["bh"], out, None, None, G, rows, Kp, N, ACT_NONE)
+    return out
+
+
+def heads_backward_grouped(hd_all, dout_all, pk_all, gW_all, gb, G, rows):
+    """Backward of :func:`heads_forward_grouped`: the G weight gradients as one grouped GEMM + one slab reduction into
+    ``gW_all`` ([G*2L][Kp], the adjacent heads' gradients of the flat buffer), the bias gradients into ``gb[g]`` ([2L] each),
+    and the input gradients [G*rows][Kp] as one grouped GEMM."""
+    _, N, Kp = pk_all["Wh"].shape
+    chunks = ops.B.wgrad_chunks(DENSE, rows, N, Kp)
+    partial = _new(hd_all, chunks, G, N, Kp)
+    ops.B.wgrad_tn_grouped(dout_all, hd_all, partial, G, rows, N, Kp, chunks)
+    ops.B.wgrad_reduce(partial, gW_all, chunks, 1, G * N, Kp, Kp, 0, 0.0)
+    for g in range(G):
+        ops.B.colsum(dout_all[g * rows:(g + 1) * rows], gb[g], rows, N, 0, 0.0)
+    dx = _new(hd_all, G * rows, Kp)
+    ops.B.igemm_nt_grouped(dout_all, pk_all["WhT"], None, dx, None, None, G, rows, N, Kp, ACT_NONE)
+    return dx
+
+
 HEAD_KEYS = ["linear_means.weight", "linear_means.bias", "linear_log_var.weight", "linear_log_var.bias"]
 POSE_ENC_KEYS = ["fc_net.0.weight", "fc_net.0.bias", "fc_net.2.weight", "fc_net.2.bias"]
 POSE_DEC_KEYS = ["deconv_net.0.weight", "deconv_net.0.bias", "deconv_net.2.weight", "deconv_net.2.bias",
                  "deconv_net.4.weight", "deconv_net.4.bias"]
 
 
-def pose_encoder_trunk_forward(P, pose):
+def pose_encoder_trunk_forward(P, pose, out=None):
     """Linear(7,512) ReLU Linear(512,512) (Identity): vae.py:218-222 with layer_sizes [512,512]."""
     _, h1 = linear_forward(pose, P["fc_net.0.weight"], P["fc_net.0.bias"], ACT_RELU)
-    _, h2 = linear_forward(h1, P["fc_net.2.weight"], P["fc_net.2.bias"], ACT_NONE)
+    _, h2 = linear_forward(h1, P["fc_net.2.weight"], P["fc_net.2.bias"], ACT_NONE, out=out)
     return h2, {"x": pose, "h1": h1}
 
 

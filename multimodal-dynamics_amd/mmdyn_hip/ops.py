@@ -133,6 +133,13 @@ class HipBackend:
         return r
 
     # ---- GEMMs ----
+    def _slabs(self, like, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N):
+        """Workspace for the pieces of the persistent ring kernel's split tiles (fp32 launches not split over K), or None."""
+        if self.precision != "fp32":
+            return None
+        n = self.lib.mmdyn_igemm_slab_floats(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+        return torch.empty(n, device=like.device, dtype=torch.float32) if n > 0 else None
+
     def _mx(self, *fmts):
         """Base flags of the mixed-storage GEMM entry points: bit 0 (16-bit matrix cores), bit 5 when the 16-bit tensors of
         the call are IEEE half.  The storage format has to be the precision mode's: bf16 tensors with "bf16" / "bf16s",
@@ -158,6 +165,8 @@ class HipBackend:
             return
         fn = {"fp32": self.lib.mmdyn_igemm_nt, "fp16": self.lib.mmdyn_igemm_nt_f16,
               "fp16s": self.lib.mmdyn_igemm_nt_f16}.get(self.precision, self.lib.mmdyn_igemm_nt_bf16)
+        if ws is None and splitk == 1:
+            ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
         check(fn(pa, _ptr(Bp), _ptr(bias), pc, pca, _ptr(stats), _ptr(ws),
                  mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, _stream()), "mmdyn_igemm_nt")
 
@@ -170,9 +179,11 @@ class HipBackend:
                                              offset, ACT_NONE, 1, self._mx(a16, c16, y16, b16) | (2 if a16 else 0) | (4 if c16 else 0) |
                                              (8 if y16 else 0) | (16 if b16 else 0), _stream()), "mmdyn_igemm_nt_mx")
             return
+        ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
         check(self.lib.mmdyn_igemm_nt_dgrad_bn(pa, _ptr(Bp), pc, _ptr(stats), py, _ptr(mean), _ptr(rstd),
                                                _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride,
-                                               offset, {"fp32": 0, "fp16": 2, "fp16s": 2}.get(self.precision, 1), _stream()),
+                                               offset, {"fp32": 0, "fp16": 2, "fp16s": 2}.get(self.precision, 1), _ptr(ws),
+                                               _stream()),
               "mmdyn_igemm_nt_dgrad_bn")
 
     def igemm_nt_dgrad_act(self, A, Bp, C, u, act, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset):
@@ -182,8 +193,30 @@ class HipBackend:
         if a16 or c16 or u16 or b16:
             flags = self._mx(a16, c16, u16, b16)
         flags |= (2 if a16 else 0) | (4 if c16 else 0) | (8 if u16 else 0) | (16 if b16 else 0)
+        ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) if flags == 0 else None
         check(self.lib.mmdyn_igemm_nt_dgrad_act(pa, pb, pc, pu, int(act), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset,
-                                                flags, _stream()), "mmdyn_igemm_nt_dgrad_act")
+                                                flags, _ptr(ws), _stream()), "mmdyn_igemm_nt_dgrad_act")
+
+    def igemm_nt_grouped(self, A, Bp, bias, C, C_act, u, G, rows, K, N, act):
+        """G dense GEMMs of one shape in one launch: A [G*rows][K], Bp [G][N][K], bias [G][N] | None, C [G*rows][N];
+        u (same shape as C): C = (A . Bp^T) * act'(u)."""
+        (pa, a16), (pc, c16), (pca, ca16), (pb, b16), (pu, u16) = _aptr(A), _aptr(C), _aptr(C_act), _aptr(Bp), _aptr(u)
+        flags = {"fp32": 0, "fp16": 33, "fp16s": 33}.get(self.precision, 1)
+        if a16 or c16 or ca16 or b16 or u16:
+            flags = self._mx(a16, c16, ca16, b16, u16)
+        flags |= (2 if a16 else 0) | (4 if c16 else 0) | (8 if u16 else 0) | (16 if b16 else 0)
+        check(self.lib.mmdyn_igemm_nt_grouped(pa, pb, _ptr(bias), pc, pca, pu, G, rows, K, N, int(act), flags, _stream()),
+              "mmdyn_igemm_nt_grouped")
+
+    def wgrad_tn_grouped(self, D, Gt, partial, G, rows, Cd, Cg, chunks):
+        """partial [chunks][G][Cd][Cg] of G weight-gradient problems whose rows follow one another in D / Gt."""
+        (pd, d16), (pg, g16) = _aptr(D), _aptr(Gt)
+        flags = {"fp32": 0, "fp16": 33, "fp16s": 33}.get(self.precision, 1)
+        if d16 or g16:
+            flags = self._mx(d16, g16)
+        flags |= (2 if d16 else 0) | (4 if g16 else 0)
+        check(self.lib.mmdyn_wgrad_tn_grouped(pd, pg, _ptr(partial), G, rows, Cd, Cg, chunks, flags, _stream()),
+              "mmdyn_wgrad_tn_grouped")
 
     def splitk_reduce(self, ws, bias, C, C_act, splitk, rows, N, act):
         check(self.lib.mmdyn_splitk_reduce(_ptr(ws), _ptr(bias), _ptr(C), _ptr(C_act), splitk, rows, N, act,

@@ -21,6 +21,12 @@ def _canon(name, a):
     if name == "igemm_nt_dgrad_act":      # ... and the dgrad + activation-backward launch
         A, Bp, C, u, act, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset = a
         name, a = "igemm_nt", (A, Bp, u, C, None, None, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset, 0, 1)
+    if name == "igemm_nt_grouped":        # G dense GEMMs of one shape in one launch: the same kernels, G groups of `rows` rows
+        A, Bp, bias, C, C_act, u, G, rows, K, N, act = a
+        name, a = "igemm_nt", (A, Bp, bias if u is None else u, C, C_act, None, None, ops.DENSE, G, rows, 1, 1, K, 1, 1, N, N, 1, 0, act, 1)
+    if name == "wgrad_tn_grouped":
+        D, Gt, partial, G, rows, Cd, Cg, chunks = a
+        name, a = "wgrad_tn", (D, Gt, partial, ops.DENSE, G * rows, 1, 1, Cd, 1, 1, Cg, 1, 0, chunks)
     # the 3-channel layers run their own kernels (csrc/conv3.hip), not igemm_nt_kernel / wgrad_tn_kernel: booked apart so
     # that the launch counts and average durations of the MFMA families match what rocprofv3 reports per kernel name
     if name == "igemm_nt" and a[7] == ops.IM2COL3 and a[10] in (64, 128, 256) and \
@@ -94,6 +100,8 @@ class TimedBackend:
                 sig = sig + ("bn_bwd_epilogue",)
             if attr == "igemm_nt_dgrad_act":
                 sig = sig + ("act_bwd_epilogue",)
+            if attr in ("igemm_nt_grouped", "wgrad_tn_grouped"):
+                sig = sig + ("grouped",)
             self.records.append((name, _flops(name, ca), _bytes(ca), s, e, sig))
             return r
         return wrapped

@@ -150,6 +150,38 @@ class EmuBackend:
         if C_act is not None:
             C_act.reshape(-1, N).copy_(_act(out, act))
 
+    def igemm_nt_grouped(self, A, Bp, bias, C, C_act, u, G, rows, K, N, act):
+        """mmdyn_igemm_nt_grouped: G dense GEMMs of one shape, group g on its own weights / bias."""
+        self.calls.append("igemm_nt_grouped")
+        h16 = (torch.bfloat16, torch.float16)
+        Af, Bf = A.float().reshape(G, rows, K), Bp.float().reshape(G, N, K)
+        if getattr(self, "precision", "fp32") != "fp32":
+            h = torch.float16 if self.precision in ("fp16", "fp16s") else torch.bfloat16
+            Af, Bf = Af.to(h).to(torch.float32), Bf.to(h).to(torch.float32)
+        out = torch.einsum("grk,gnk->grn", Af, Bf)
+        if u is not None:
+            uf = u.float().reshape(G, rows, N)
+            out = out * (_act_grad(uf, act))
+            C.copy_(out.reshape(C.shape).to(C.dtype))
+            return
+        if bias is not None:
+            out = out + bias.reshape(G, 1, N)
+        C.copy_(out.reshape(C.shape).to(C.dtype))
+        if C_act is not None:
+            C_act.copy_(_act(out, act).reshape(C_act.shape).to(C_act.dtype))
+
+    def wgrad_tn_grouped(self, D, Gt, partial, G, rows, Cd, Cg, chunks):
+        """partial [chunks][G][Cd][Cg]; one wgrad_reduce over Cd' = G*Cd then sums the slabs of all groups."""
+        Df, Gf = D.float().reshape(G, rows, Cd), Gt.float().reshape(G, rows, Cg)
+        if getattr(self, "precision", "fp32") != "fp32":
+            h = torch.float16 if self.precision in ("fp16", "fp16s") else torch.bfloat16
+            Df, Gf = Df.to(h).to(torch.float32), Gf.to(h).to(torch.float32)
+        full = torch.einsum("grd,grc->gdc", Df, Gf)
+        partial.zero_()
+        p = partial.reshape(chunks, G, Cd, Cg)
+        p[0] = 0.5 * full
+        p[chunks - 1] += 0.5 * full
+
     def splitk_reduce(self, ws, bias, C, C_act, splitk, rows, N, act):
         out = ws.reshape(splitk, rows, N).sum(0)
         if bias is not None:

@@ -204,6 +204,62 @@ def test_igemm_nt_regstage(case, regstage):
     test_igemm_nt(case)
 
 
+@pytest.fixture(params=["128,64", "128,128"])
+def wsp(request, monkeypatch, lab):
+    """The persistent, stream-K-scheduled ring kernel (igemm_wsp.hip) forced onto the small test shapes: with a few hundred
+    (tile, K-step) units spread over 256 / 512 resident blocks every block gets one or two K-steps, so EVERY tile is split
+    into many pieces and goes through the slab + fix-up path; rows are not tile multiples."""
+    monkeypatch.setenv("MMDYN_WSP_TILE", request.param)
+    yield request.param
+
+
+WSP_CASES = [c for c in IGEMM_CASES if c[0] in (DENSE, CONV, TCONV_S2P1) and c[6] % 64 == 0] + [
+    (CONV, 4, 40, 16, 64, 8, 128, 2, -1), (TCONV_S2P1, 4, 33, 8, 128, 16, 64, 1, 0), (CONV, 1, 300, 8, 128, 5, 256, 1, 0)]
+
+
+@pytest.mark.parametrize("case", WSP_CASES)
+def test_igemm_nt_persistent(case, wsp):
+    if case[6] % int(wsp.split(",")[1]):
+        pytest.skip("N is not a multiple of the forced tile width")
+    test_igemm_nt(case)
+
+
+@pytest.mark.parametrize("case", [c for c in WSP_CASES if c[0] != DENSE])
+def test_igemm_dgrad_bn_epilogue_persistent(case, wsp):
+    if case[6] % int(wsp.split(",")[1]):
+        pytest.skip("N is not a multiple of the forced tile width")
+    test_igemm_dgrad_bn_epilogue(case)
+
+
+@pytest.mark.parametrize("case", [WSP_CASES[2], WSP_CASES[4], WSP_CASES[-1], WSP_CASES[-2]])
+@pytest.mark.parametrize("act", [1, 2])
+def test_igemm_dgrad_act_epilogue_persistent(case, act, wsp):
+    if case[6] % int(wsp.split(",")[1]):
+        pytest.skip("N is not a multiple of the forced tile width")
+    test_igemm_dgrad_act_epilogue(case, act)
+
+
+def test_persistent_kernel_whole_tiles_and_split_tiles_agree(lab, monkeypatch):
+    """The same launch cut two ways -- 512 tiles over 256 blocks (whole tiles only) and with MMDYN_WSP_UNITS_PER_BLOCK moved off
+    a tile multiple (split tiles + fix-up) -- and the one-tile-per-block ring kernel: equal to summation-order error."""
+    mode, G, Bg, Hi, Cin, Ho, N, stride, offset = CONV, 4, 128, 16, 64, 8, 128, 2, -1
+    Bt = G * Bg
+    A, Bp = rnd(Bt * Hi * Hi, Cin, seed=71).to(DEV), rnd(16, N, Cin, seed=72, scale=0.2).to(DEV)
+    outs = []
+    for env in ({"MMDYN_WSP": "0"}, {"MMDYN_WSP_TILE": "128,128"}, {"MMDYN_WSP_TILE": "128,128", "MMDYN_WSP_UNITS_PER_BLOCK": "19"}):
+        for k in ("MMDYN_WSP", "MMDYN_WSP_TILE", "MMDYN_WSP_UNITS_PER_BLOCK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        T = HIP.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
+        C, st = torch.zeros(Bt * Ho * Ho, N, device=DEV), torch.zeros(G, T, 2, N, device=DEV)
+        HIP.igemm_nt(A, Bp, None, C, None, st, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1)
+        torch.cuda.synchronize()
+        outs.append((C.cpu(), st.sum(1).cpu()))
+    for C, st in outs[1:]:
+        assert rel(C, outs[0][0]) < 2e-6 and rel(st, outs[0][1]) < 2e-5
+
+
 @pytest.mark.parametrize("case", [c for c in IGEMM_CASES if c[0] != DENSE][:6] + [IGEMM_CASES[0]])
 def test_igemm_dgrad_bn_epilogue_regstage(case, regstage):
     test_igemm_dgrad_bn_epilogue(case)
