@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--infer", action="store_true",
                     help="time forward-only inference instead (model.eval(): joint visual+tactile+pose pass through the "
                          "module API, running-estimate BatchNorm); prints its own JSON line, not the BASELINE metric")
+    ap.add_argument("--no-grouped-heads", action="store_true",
+                    help="A/B switch: launch the heads of the three encoders one by one instead of as grouped launches")
     ap.add_argument("--single-lane", action="store_true",
                     help="no visual/tactile stream overlap: per-kernel durations in a rocprofv3 trace then match "
                          "the roofline object's live HIP-event measurement")
@@ -357,7 +359,7 @@ def main():
     step = MVAEStep(model, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), process_group=pg,
                     world_size=world, two_lanes=not args.single_lane,
                     precision=PREC, defer_wgrad={"auto": None, "on": True, "off": False}[args.defer_wgrad],
-                    sync_bn=args.sync_bn and pg is not None)
+                    sync_bn=args.sync_bn and pg is not None, group_heads=not args.no_grouped_heads)
     inputs, targets = seeded_batch(args.batch, 1234 + rank, size=S)
     inputs, targets = [x.to(dev) for x in inputs], [x.to(dev) for x in targets]
     if args.problem == "dyn_modeling":

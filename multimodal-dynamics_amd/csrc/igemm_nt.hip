@@ -895,7 +895,7 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
     const int rc = mmdyn_igemm_d16_try(A, Bp, bias, C, C_act, stats, ws, g, stride, offset, st);
     if (rc != 1) return rc;
   }
-  if (ws_enabled() && !bf16 && mode != MMDYN_IM2COL3 && mode != MMDYN_TCONV_S1P0) {   // persistent ring kernel (igemm_wsp.hip)
+  if (ws_enabled() && !bf16 && mode != MMDYN_IM2COL3) {   // persistent ring kernel (igemm_wsp.hip)
     const int rc = mmdyn_igemm_wsp_try(A, Bp, bias, C, C_act, stats, ws, g, false, st);
     if (rc != 1) return rc;
   }

@@ -465,6 +465,15 @@ static int ws_launch_mode(const float* A, const float* Bp, const float* bias, fl
   if constexpr (!B16)         // LAB: 64 rows x 128 channels (the gathered operand filled once per 128 output channels)
     if (p.bn == 128) return ws_launch<MODE, 64, 128, 32, 64, 3, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
 #endif
+  if constexpr (MODE == MMDYN_DENSE) {
+    // Launches of at most two 64x64 blocks per CU (the heads / pose / FC-level GEMMs: K loops of 8-16 steps at one or two
+    // blocks per CU) are chains of DMA round trips, not matrix work: a four-slot ring keeps three K-steps in flight instead of
+    // two (65 KB of LDS: still two blocks per CU).  LAB build: MMDYN_WS_DENSE_S=3 switches it off (A/B).
+    const long blocks = (long)g.G * ceil_div(g.Bg * g.Hr * g.Wr, 64) * (g.N / 64) * g.splitk;
+    const char* e = lab_env("MMDYN_WS_DENSE_S");
+    if (blocks <= 2L * 256 && !(e && e[0] == '3'))
+      return ws_launch<MODE, 64, 64, 32, 32, 4, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
+  }
   return ws_launch<MODE, 64, 64, 32, 32, 3, B16>(A, Bp, bias, C, C_act, stats, ws, g, a_bytes, b_bytes, st);
 }
 

@@ -65,11 +65,54 @@ __device__ unsigned long long wsp_diag[8];
 // Schedule of one launch: units = tiles x K-steps, block b owns units [b * per, (b + 1) * per).
 struct WspSched {
   int tiles;       // M-tiles x N-tiles x parity classes
-  int ksteps;      // K-steps per tile
+  int ksteps;      // K-steps per tile (TCONV_S1P0: of the heaviest tile; the count varies with the output pixel)
+  int units;       // all (tile, K-step) units of the launch
   int per;         // units per block (the last block may get fewer)
   int si, ny;      // inner tiles per M-tile (N-tiles x classes), N-tiles
+  int cin_steps;   // K-steps per filter tap
+  int spg, ug;     // TCONV_S1P0: 128-sample tiles per group; units of one (group, sample tile): 400 taps x cin_steps
   float inv_hw, inv_w;
 };
+
+// TCONV_S1P0 (k4 s1 p0 transposed convolution, 5x5 -> 8x8): a tile is (group, 128 samples, ONE output pixel) and multiplies
+// only the taps that reach the input for that pixel: nk(py) * nk(px) of them, nk = 1 2 3 4 4 3 2 1 along each axis (400 per
+// sample tile in all).  The tiles are unequal, the unit ranges of the blocks are not: stream-K balances what the register-staged
+// kernel balances with its four-pixel walk.
+__device__ __forceinline__ int s1p0_nk(int i) { return min(i, 7 - i) + 1; }
+__device__ __forceinline__ int s1p0_cum(int i) { return i <= 4 ? i * (i + 1) / 2 : 20 - (8 - i) * (9 - i) / 2; }   // taps before i
+
+struct Seg {
+  int t, ub, kt;   // tile, its first unit, its K-steps
+};
+template <int MODE> __device__ __forceinline__ Seg seg_of_tile(int t, const WspSched& sc) {
+  Seg s;
+  s.t = t;
+  if constexpr (MODE == MMDYN_TCONV_S1P0) {
+    const int q = t >> 6, py = (t >> 3) & 7, px = t & 7;
+    s.ub = q * sc.ug + (20 * s1p0_cum(py) + s1p0_nk(py) * s1p0_cum(px)) * sc.cin_steps;
+    s.kt = s1p0_nk(py) * s1p0_nk(px) * sc.cin_steps;
+  } else {
+    s.ub = t * sc.ksteps;
+    s.kt = sc.ksteps;
+  }
+  return s;
+}
+template <int MODE> __device__ __forceinline__ Seg seg_at(int u, const WspSched& sc) {
+  if constexpr (MODE == MMDYN_TCONV_S1P0) {
+    const int q = u / sc.ug;
+    const int ts = (u - q * sc.ug) / sc.cin_steps;       // tap-step inside the (group, sample tile): 0 .. 399
+    int py = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) py = ts >= 20 * s1p0_cum(i) ? i : py;
+    const int rem = ts - 20 * s1p0_cum(py), nky = s1p0_nk(py);
+    int px = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) px = rem >= nky * s1p0_cum(i) ? i : px;
+    return seg_of_tile<MODE>(q * 64 + py * 8 + px, sc);
+  } else {
+    return seg_of_tile<MODE>(u / sc.ksteps, sc);
+  }
+}
 
 // quotient and remainder by a launch constant through a float reciprocal, exact for 0 <= n < 2^23 (checked by the launcher)
 __device__ __forceinline__ void fdiv(int n, int d, float inv, int& q, int& r) {
@@ -80,10 +123,23 @@ __device__ __forceinline__ void fdiv(int n, int d, float inv, int& q, int& r) {
 }
 
 struct TileId {
-  int grp, tile, cls, n0, ph, pw;
+  int grp, tile, cls, n0, ph, pw;      // TCONV_S1P0: tile = pixel * spg + sample tile (the partial-sum slot), ph / pw = the pixel
+  int stile;                           // TCONV_S1P0: 128-sample tile inside the group
 };
-__device__ __forceinline__ TileId tile_of(int t, const IgemmGeom& g, const WspSched& sc, int BN) {
+template <int MODE> __device__ __forceinline__ TileId tile_of(int t, const IgemmGeom& g, const WspSched& sc, int BN) {
   TileId id;
+  if constexpr (MODE == MMDYN_TCONV_S1P0) {
+    const int q = t >> 6, p = t & 63;
+    id.grp = q / sc.spg;
+    id.stile = q - id.grp * sc.spg;
+    id.tile = p * sc.spg + id.stile;
+    id.cls = 0;
+    id.n0 = 0;
+    id.ph = p >> 3;
+    id.pw = p & 7;
+    return id;
+  }
+  id.stile = 0;
   const int mx = t / sc.si, inner = t - mx * sc.si;
   id.grp = mx / g.tiles_per_group;
   id.tile = mx - id.grp * g.tiles_per_group;
@@ -95,11 +151,21 @@ __device__ __forceinline__ TileId tile_of(int t, const IgemmGeom& g, const WspSc
 }
 
 // row `ml` of group `grp` (class ph, pw) -> sample index, gather base (y0, x0), output offset (-1: the row does not exist)
+template <int MODE>
 __device__ __forceinline__ void decode_row(int ml, int Mg, const TileId& id, const IgemmGeom& g, const WspSched& sc, int& ib,
                                            int& y0, int& x0, int& ooff) {
   ib = -1;
   y0 = x0 = 0;
   ooff = -1;
+  if constexpr (MODE == MMDYN_TCONV_S1P0) {              // ml: sample index inside the group; the row's pixel is the tile's
+    if (ml < g.Bg) {
+      ib = id.grp * g.Bg + ml;
+      y0 = id.ph;
+      x0 = id.pw;
+      ooff = ((ib * g.Ho + id.ph) * g.Wo + id.pw) * g.ldc;
+    }
+    return;
+  }
   if (ml < Mg) {
     int s, p, rr, cc;
     fdiv(ml, g.Hr * g.Wr, sc.inv_hw, s, p);
@@ -250,11 +316,10 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Mg = g.Bg * g.Hr * g.Wr;
-  const int total_units = sc.tiles * sc.ksteps;
-  const int u0 = blockIdx.x * sc.per, u1 = min(total_units, u0 + sc.per);
+  const int u0 = blockIdx.x * sc.per, u1 = min(sc.units, u0 + sc.per);
   if (u0 >= u1) return;
   const int nsteps = u1 - u0;
-  const int cin_steps = g.Cin / KB;
+  const int cin_steps = sc.cin_steps;
 
   if (wave < NL) {
     // ===================================== loader wave =====================================
@@ -268,7 +333,15 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
     unsigned sB = 0;
     auto settap = [&]() {
       int dh = 0, dw = 0, wi = 0;
-      if (MODE == MMDYN_CONV) {
+      if (MODE == MMDYN_TCONV_S1P0) {                    // (ph, pw) = the tile's output pixel; tap counts its VALID taps
+        const int kh0 = max(0, ph - (g.Hi - 1)), kw0 = max(0, pw - (g.Wi - 1));
+        const int nkw = min(3, pw) - kw0 + 1;
+        const int a = tap / nkw;
+        const int kh = kh0 + a, kw = kw0 + (tap - a * nkw);
+        dh = -kh;
+        dw = -kw;
+        wi = kh * 4 + kw;
+      } else if (MODE == MMDYN_CONV) {
         dh = tap >> 2;
         dw = tap & 3;
         wi = tap;
@@ -290,16 +363,18 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
     };
     auto next_segment = [&]() {
       ++seg;
-      const int t = su / sc.ksteps, kb = su - t * sc.ksteps;
-      seg_end = min(u1, (t + 1) * sc.ksteps);
-      const TileId id = tile_of(t, g, sc, BN);
+      const Seg sg = seg_at<MODE>(su, sc);
+      const int kb = su - sg.ub;
+      seg_end = min(u1, sg.ub + sg.kt);
+      const TileId id = tile_of<MODE>(sg.t, g, sc, BN);
       ph = id.ph;
       pw = id.pw;
+      const int row0 = (MODE == MMDYN_TCONV_S1P0 ? id.stile : id.tile) * BM;
 #pragma unroll
       for (int i = 0; i < PAL; ++i) {
         const int r = (wave + NL * i) * RPP + prow;      // tile row
         int oo;
-        decode_row(id.tile * BM + r, Mg, id, g, sc, rb[i], ry[i], rx[i], oo);
+        decode_row<MODE>(row0 + r, Mg, id, g, sc, rb[i], ry[i], rx[i], oo);
         if ((lane & 7) == 0) rowoff[(seg & (NRO - 1)) * BM + r] = oo;
       }
 #pragma unroll
@@ -366,10 +441,11 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
   if (DIAG) d_all = -WSP_STAMP();
   for (int cu = u0; cu < u1;) {
     ++seg;
-    const int t = cu / sc.ksteps, kb = cu - t * sc.ksteps;
-    const int ke = min(sc.ksteps, kb + (u1 - cu));
-    const bool full = kb == 0 && ke == sc.ksteps;
-    const TileId id = tile_of(t, g, sc, BN);
+    const Seg sg = seg_at<MODE>(cu, sc);
+    const int kb = cu - sg.ub;
+    const int ke = min(sg.kt, kb + (u1 - cu));
+    const bool full = kb == 0 && ke == sg.kt;
+    const TileId id = tile_of<MODE>(sg.t, g, sc, BN);
     f32x4v acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -460,13 +536,14 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_wsp_fixup_ke
   constexpr int NM = (BM / WM) * (BN / WN);
   constexpr int TS = 16, MT = WM / TS, NT = WN / TS, WAVES_N = BN / WN;
   const int t = blockIdx.x;
-  const int ub = t * sc.ksteps, ue = ub + sc.ksteps;
+  const Seg sg = seg_of_tile<MODE>(t, sc);
+  const int ub = sg.ub, ue = sg.ub + sg.kt;
   const int b0 = ub / sc.per;
   if (ue <= (b0 + 1) * sc.per) return;                   // the tile lies inside one block's range: computed whole
   const int lane = threadIdx.x & 63, mw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = mw / WAVES_N, wn = mw - wm * WAVES_N;
   const int Mg = g.Bg * g.Hr * g.Wr;
-  const TileId id = tile_of(t, g, sc, BN);
+  const TileId id = tile_of<MODE>(t, g, sc, BN);
   f32x4v acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -488,7 +565,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_wsp_fixup_ke
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     int ib, y0, x0;
-    decode_row(id.tile * BM + wm * WM + mt * TS + (lane >> 2), Mg, id, g, sc, ib, y0, x0, ooff[mt]);
+    decode_row<MODE>((MODE == MMDYN_TCONV_S1P0 ? id.stile : id.tile) * BM + wm * WM + mt * TS + (lane >> 2), Mg, id, g, sc, ib, y0,
+                     x0, ooff[mt]);
   }
   if (g.bn_y != nullptr) wsp_fetch_y<MT, NT, B16>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
   wsp_epilogue<BM, BN, WM, WN, B16>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
@@ -512,23 +590,36 @@ static int device_cus() {
 }
 
 // Measured per shape against the one-tile-per-block ring kernels and the register-staged kernels, each launch alone on the
-// chip (tests/microbench/ab_ws.py, profiles/r4/ab_wsp_per_shape.txt).  Served: fp32 / all-16-bit CONV and TCONV_S2P1
-// launches with at least two 128-row tiles' worth of work per CU slot.
+// chip (tests/microbench/ab_wsp.py, profiles/r4/ab_wsp_per_shape.txt).  Served: fp32 (and all-16-bit) CONV / TCONV_S2P1 launches
+// with N % 128 == 0 and at least two 16-K-step tiles' worth of work per CU, and the k4 s1 p0 transposed convolution with N = 128.
 static WspPick wsp_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr, int Cin, int N, int ncls, int splitk, bool b16,
                         int b_group_stride) {
   WspPick p{0, 0, 0};
   if (const char* e = lab_env("MMDYN_WSP"))
     if (e[0] == '0') return p;
-  if (mode != MMDYN_CONV && mode != MMDYN_TCONV_S2P1 && mode != MMDYN_DENSE) return p;
+  if (mode != MMDYN_CONV && mode != MMDYN_TCONV_S2P1 && mode != MMDYN_DENSE && mode != MMDYN_TCONV_S1P0) return p;
   if (splitk > 1 || b_group_stride) return p;
   const int kb = b16 ? 64 : BK;
   if (Cin % kb || N % 64) return p;
   const int esz = b16 ? 2 : 4;
   if ((int64_t)G * Bg * Hi * Wi * Cin * esz >= MAX_BUFFER_BYTES || (int64_t)16 * N * Cin * esz >= MAX_BUFFER_BYTES) return p;
+  const int cus = device_cus();
+  if (mode == MMDYN_TCONV_S1P0) {
+    // tiles of 128 samples x ONE output pixel x all 128 channels, 1..16 taps each (stream-K balances them)
+    if (const char* e = lab_env("MMDYN_WSP_S1P0"))
+      if (e[0] == '0') return p;
+    if (N != 128 || Hi != 5 || Wi != 5 || Hr != 8 || Wr != 8) return p;
+    const long units = (long)G * ((Bg + 127) / 128) * 400 * (Cin / kb);
+    long min_units = 2L * 16 * cus;
+    if (const char* e = lab_env("MMDYN_WSP_MIN_UNITS")) min_units = atol(e);
+    if (units < min_units || units >= (1L << 30)) return p;
+    p.bm = p.bn = 128;
+    p.bpc = 1;
+    return p;
+  }
   const long rows_g = (long)Bg * Hr * Wr;
   if (rows_g >= (1L << 23)) return p;                    // float-reciprocal row decode
   const int ksteps = (mode == MMDYN_CONV ? 16 : (mode == MMDYN_TCONV_S2P1 ? 4 : 1)) * (Cin / kb);
-  const int cus = device_cus();
   // 128x128 tiles, one block per CU, where N allows: x1.03-1.15 against the one-tile-per-block kernels on the N = 128 / 256
   // launches (more where the tile count does not divide the CUs: 400 tiles x1.07, 256 tiles x1.15).  The 128x64 tile (two
   // blocks per CU) is built and tested but LOSES on the step's N = 64 launches (x0.86 / x0.98): their 16-K-step tiles spend
@@ -560,39 +651,50 @@ static WspPick wsp_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr,
   return p;
 }
 
-static WspSched make_sched(const IgemmGeom& g, const WspPick& p, int ksteps) {
+static WspSched make_sched(const IgemmGeom& g, const WspPick& p, bool b16) {
   WspSched sc{};
-  const int tpg = ceil_div(g.Bg * g.Hr * g.Wr, p.bm);
-  sc.ny = g.N / p.bn;
-  sc.si = sc.ny * g.nclasses;
-  sc.tiles = g.G * tpg * sc.si;
-  sc.ksteps = ksteps;
-  const long units = (long)sc.tiles * ksteps;
+  sc.cin_steps = g.Cin / (b16 ? 64 : BK);
+  if (g.mode == MMDYN_TCONV_S1P0) {
+    sc.spg = ceil_div(g.Bg, p.bm);
+    sc.ug = 400 * sc.cin_steps;
+    sc.ny = sc.si = 1;
+    sc.tiles = g.G * sc.spg * 64;
+    sc.ksteps = 16 * sc.cin_steps;
+    sc.units = g.G * sc.spg * sc.ug;
+  } else {
+    const int tpg = ceil_div(g.Bg * g.Hr * g.Wr, p.bm);
+    sc.ny = g.N / p.bn;
+    sc.si = sc.ny * g.nclasses;
+    sc.tiles = g.G * tpg * sc.si;
+    sc.ksteps = (g.mode == MMDYN_CONV ? 16 : (g.mode == MMDYN_TCONV_S2P1 ? 4 : 1)) * sc.cin_steps;
+    sc.units = sc.tiles * sc.ksteps;
+  }
   const long nblk = (long)device_cus() * p.bpc;
-  sc.per = (int)((units + nblk - 1) / nblk);
+  sc.per = (int)((sc.units + nblk - 1) / nblk);
   if (const char* e = lab_env("MMDYN_WSP_UNITS_PER_BLOCK")) {      // LAB build: force the cut (kernel tests: split tiles)
     const int v = atoi(e);
-    if (v > 0 && (units + v - 1) / v <= 65535L * 16) sc.per = v;
+    if (v > 0 && (sc.units + v - 1) / v <= 65535L * 16) sc.per = v;
   }
-  // (a block never starts inside the last S-1 K-steps of a tile for nothing: ranges are plain equal cuts; the ring does not care)
   sc.inv_hw = 1.0f / (float)(g.Hr * g.Wr);
   sc.inv_w = 1.0f / (float)g.Wr;
   return sc;
 }
 
-static bool has_split_tiles(const WspSched& sc) { return sc.per % sc.ksteps != 0; }
+// no tile straddles two blocks' ranges (then there are no slabs and no fix-up launch)
+static bool has_split_tiles(const IgemmGeom& g, const WspSched& sc) { return g.mode == MMDYN_TCONV_S1P0 || sc.per % sc.ksteps != 0; }
 
 template <int MODE, int BM, int BN, int WM, int WN, int S, int B16>
 static int wsp_launch(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
                       IgemmGeom g, const WspSched& sc, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
   constexpr int NM = (BM / WM) * (BN / WN);
-  g.tiles_per_group = ceil_div(g.Bg * g.Hr * g.Wr, BM);
-  const long units = (long)sc.tiles * sc.ksteps;
-  const int nblk = (int)((units + sc.per - 1) / sc.per);
+  // (partial-sum slots per group: M-tiles x classes; TCONV_S1P0: output pixels x sample tiles)
+  g.tiles_per_group = MODE == MMDYN_TCONV_S1P0 ? 64 * sc.spg : ceil_div(g.Bg * g.Hr * g.Wr, BM);
+  const int nblk = (sc.units + sc.per - 1) / sc.per;
   const size_t smem = (size_t)S * (BM + BN) * RB + (size_t)NRO * BM * sizeof(int) + (size_t)NM * 16 * TRLD * sizeof(float);
   static LdsOptIn lds_opt_in;
   if (int e = lds_opt_in.ensure((const void*)igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16>, (int)smem)) return e;
-  if (has_split_tiles(sc) && !slabs) return MMDYN_ERR_NULL;
+  const bool split = has_split_tiles(g, sc);
+  if (split && !slabs) return MMDYN_ERR_NULL;
 #ifdef MMDYN_LAB
   if constexpr (B16 == 0 && MODE != MMDYN_DENSE) {
     const char* e = lab_env("MMDYN_WSP_DIAG");
@@ -601,7 +703,7 @@ static int wsp_launch(const float* A, const float* Bp, const float* bias, float*
       if (int er = diag_opt_in.ensure((const void*)igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16, true>, (int)smem)) return er;
       hipLaunchKernelGGL((igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16, true>), dim3(nblk), dim3(64 * (NM + NL)), smem, st, A, Bp,
                          bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes);
-      if (has_split_tiles(sc))
+      if (split)
         hipLaunchKernelGGL((igemm_wsp_fixup_kernel<MODE, BM, BN, WM, WN, B16>), dim3(sc.tiles), dim3(64 * NM), 0, st, bias, C, C_act,
                            stats, slabs, g, sc);
       MMDYN_LAUNCH_CHECK();
@@ -610,7 +712,7 @@ static int wsp_launch(const float* A, const float* Bp, const float* bias, float*
 #endif
   hipLaunchKernelGGL((igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16>), dim3(nblk), dim3(64 * (NM + NL)), smem, st, A, Bp, bias, C,
                      C_act, stats, slabs, g, sc, a_bytes, b_bytes);
-  if (has_split_tiles(sc))
+  if (split)
     hipLaunchKernelGGL((igemm_wsp_fixup_kernel<MODE, BM, BN, WM, WN, B16>), dim3(sc.tiles), dim3(64 * NM), 0, st, bias, C, C_act,
                        stats, slabs, g, sc);
   MMDYN_LAUNCH_CHECK();
@@ -621,7 +723,9 @@ static int wsp_launch_mode(const float* A, const float* Bp, const float* bias, f
                            const IgemmGeom& g, const WspPick& p, const WspSched& sc, unsigned a_bytes, unsigned b_bytes,
                            hipStream_t st) {
   if (p.bn == 128) return wsp_launch<MODE, 128, 128, 64, 32, 3, B16>(A, Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
-  return wsp_launch<MODE, 128, 64, 64, 32, 3, B16>(A, Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
+  if constexpr (MODE != MMDYN_TCONV_S1P0)
+    return wsp_launch<MODE, 128, 64, 64, 32, 3, B16>(A, Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
+  return MMDYN_ERR_SHAPE;
 }
 
 template <int B16>
@@ -632,35 +736,23 @@ static int wsp_dispatch(const float* A, const float* Bp, const float* bias, floa
   const unsigned b_bytes = (unsigned)((int64_t)(g.mode == MMDYN_DENSE ? 1 : 16) * g.N * g.Cin * esz);
   if (g.mode == MMDYN_DENSE) return wsp_launch_mode<MMDYN_DENSE, B16>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
   if (g.mode == MMDYN_CONV) return wsp_launch_mode<MMDYN_CONV, B16>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
+  if (g.mode == MMDYN_TCONV_S1P0) {
+    if constexpr (B16 == 0)          // (fp32 only so far: the 16-bit modes keep their one-pixel-per-block walk)
+      return wsp_launch_mode<MMDYN_TCONV_S1P0, 0>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
+    return 1;
+  }
   return wsp_launch_mode<MMDYN_TCONV_S2P1, B16>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
 }
 
-static int ksteps_of(int mode, int Cin, bool b16) {
-  return (mode == MMDYN_CONV ? 16 : (mode == MMDYN_TCONV_S2P1 ? 4 : 1)) * (Cin / (b16 ? 64 : BK));
-}
-
-}  // namespace
-
-// BatchNorm partial-sum tiles per group the persistent kernel writes for the shape (0: not served): one per M-tile, parity
-// class and wave row
-int mmdyn_igemm_wsp_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, bool b16) {
-  int Hr = Ho, Wr = Wo, ncls = 1;
-  if (mode == MMDYN_TCONV_S2P1) {
-    Hr = Hi;
-    Wr = Wi;
-    ncls = 4;
-  }
-  const WspPick p = wsp_pick(mode, G, Bg, Hi, Wi, Hr, Wr, Cin, N, ncls, 1, b16, 0);
-  if (!p.bm) return 0;
-  return ncls * ceil_div(Bg * Hr * Wr, p.bm) * 2;        // both tiles are cut into waves of 64 x 32: two wave rows
-}
-
-// bytes of slab workspace the launch needs for its split tiles (0: none, or not served)
-int64_t mmdyn_igemm_wsp_slab_bytes(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, bool b16) {
+// geometry of a launch as the queries below know it (shape only)
+static IgemmGeom query_geom(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   IgemmGeom g{};
   g.mode = mode;
   g.G = G;
   g.Bg = Bg;
+  g.Hi = Hi;
+  g.Wi = Wi;
+  g.Cin = Cin;
   g.N = N;
   g.Hr = Ho;
   g.Wr = Wo;
@@ -670,12 +762,31 @@ int64_t mmdyn_igemm_wsp_slab_bytes(int mode, int G, int Bg, int Hi, int Wi, int 
     g.Wr = Wi;
     g.nclasses = 4;
   }
+  return g;
+}
+
+}  // namespace
+
+// BatchNorm partial-sum tiles per group the persistent kernel writes for the shape (0: not served): one per M-tile, parity
+// class and wave row (TCONV_S1P0: per output pixel, sample tile and wave row)
+int mmdyn_igemm_wsp_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, bool b16) {
+  if (mode == MMDYN_TCONV_S1P0 && b16) return 0;
+  const IgemmGeom g = query_geom(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   const WspPick p = wsp_pick(mode, G, Bg, Hi, Wi, g.Hr, g.Wr, Cin, N, g.nclasses, 1, b16, 0);
   if (!p.bm) return 0;
-  const WspSched sc = make_sched(g, p, ksteps_of(mode, Cin, b16));
-  if (!has_split_tiles(sc)) return 0;
-  const long units = (long)sc.tiles * sc.ksteps;
-  const long nblk = (units + sc.per - 1) / sc.per;
+  if (mode == MMDYN_TCONV_S1P0) return 64 * ceil_div(Bg, p.bm) * 2;
+  return g.nclasses * ceil_div(Bg * g.Hr * g.Wr, p.bm) * 2;        // both tiles are cut into waves of 64 x 32: two wave rows
+}
+
+// bytes of slab workspace the launch needs for its split tiles (0: none, or not served)
+int64_t mmdyn_igemm_wsp_slab_bytes(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, bool b16) {
+  if (mode == MMDYN_TCONV_S1P0 && b16) return 0;
+  const IgemmGeom g = query_geom(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  const WspPick p = wsp_pick(mode, G, Bg, Hi, Wi, g.Hr, g.Wr, Cin, N, g.nclasses, 1, b16, 0);
+  if (!p.bm) return 0;
+  const WspSched sc = make_sched(g, p, b16);
+  if (!has_split_tiles(g, sc)) return 0;
+  const long nblk = (sc.units + sc.per - 1) / sc.per;
   return (int64_t)nblk * 2 * p.bm * p.bn * 4;
 }
 
@@ -683,9 +794,10 @@ int64_t mmdyn_igemm_wsp_slab_bytes(int mode, int G, int Bg, int Hi, int Wi, int 
 int mmdyn_igemm_wsp_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
                         const IgemmGeom& g, bool bf16_ops, hipStream_t st) {
   if (bf16_ops && (!g.a_b16 || !g.b_b16)) return 1;
+  if (bf16_ops && g.mode == MMDYN_TCONV_S1P0) return 1;
   const WspPick p = wsp_pick(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Hr, g.Wr, g.Cin, g.N, g.nclasses, g.splitk, bf16_ops, g.b_group_stride);
   if (!p.bm) return 1;
-  const WspSched sc = make_sched(g, p, ksteps_of(g.mode, g.Cin, bf16_ops));
+  const WspSched sc = make_sched(g, p, bf16_ops);
   if (bf16_ops && g.f16) return wsp_dispatch<2>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, st);
   if (bf16_ops) return wsp_dispatch<1>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, st);
   return wsp_dispatch<0>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, st);

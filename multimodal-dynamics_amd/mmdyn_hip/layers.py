@@ -757,10 +757,18 @@ def heads_forward_grouped(hd_all, pk_all, G, rows):
     return out
 
 
-def heads_backward_grouped(hd_all, dout_all, pk_all, gW_all, gb, G, rows):
-    """Backward of :func:`heads_forward_grouped`: the G weight gradients as one grouped GEMM + one slab reduction into
-    ``gW_all`` ([G*2L][Kp], the adjacent heads' gradients of the flat buffer), the bias gradients into ``gb[g]`` ([2L] each),
-    and the input gradients [G*rows][Kp] as one grouped GEMM."""
+def heads_backward_grouped(dout_all, pk_all, G, rows):
+    """Input gradients of :func:`heads_forward_grouped`, [G*rows][Kp], as one grouped GEMM (what the backward chain waits for)."""
+    _, N, Kp = pk_all["Wh"].shape
+    dx = _new(dout_all, G * rows, Kp)
+    ops.B.igemm_nt_grouped(dout_all, pk_all["WhT"], None, dx, None, None, G, rows, N, Kp, ACT_NONE)
+    return dx
+
+
+def heads_wgrad_grouped(hd_all, dout_all, pk_all, gW_all, gb, G, rows):
+    """Parameter gradients of :func:`heads_forward_grouped` (nothing on the backward chain reads them): the G weight
+    gradients as one grouped GEMM + one slab reduction into ``gW_all`` ([G*2L][Kp], the adjacent heads' gradients of the flat
+    buffer), the bias gradients into ``gb[g]`` ([2L] each)."""
     _, N, Kp = pk_all["Wh"].shape
     chunks = ops.B.wgrad_chunks(DENSE, rows, N, Kp)
     partial = _new(hd_all, chunks, G, N, Kp)
@@ -768,9 +776,6 @@ def heads_backward_grouped(hd_all, dout_all, pk_all, gW_all, gb, G, rows):
     ops.B.wgrad_reduce(partial, gW_all, chunks, 1, G * N, Kp, Kp, 0, 0.0)
     for g in range(G):
         ops.B.colsum(dout_all[g * rows:(g + 1) * rows], gb[g], rows, N, 0, 0.0)
-    dx = _new(hd_all, G * rows, Kp)
-    ops.B.igemm_nt_grouped(dout_all, pk_all["WhT"], None, dx, None, None, G, rows, N, Kp, ACT_NONE)
-    return dx
 
 
 HEAD_KEYS = ["linear_means.weight", "linear_means.bias", "linear_log_var.weight", "linear_log_var.bias"]

@@ -15,6 +15,8 @@ from mmdyn_hip import ops, _lib  # noqa: E402
 HIP = ops.HipBackend(lib_path=_lib.LAB_LIB_PATH)
 # mode,G,Bg,Hi,Cin,Ho,N,stride,offset, kind ('plain' | 'stats' | 'bnbwd' | 'actbwd')
 SHAPES = [
+    (4, 4, 256, 5, 256, 8, 128, 1, 0, "stats"),         # decoder layer 1: the k4 s1 p0 transposed convolution (a)
+    (4, 4, 128, 5, 256, 8, 128, 1, 0, "stats"),         # ... at the bs 128 share
     (1, 1, 1024, 8, 128, 5, 256, 1, 0, "actbwd"),       # decoder layer-1 input gradient (b)
     (1, 4, 256, 32, 32, 16, 64, 2, -1, "bnbwd"),        # (c)
     (2, 4, 256, 8, 128, 16, 64, 1, 0, "stats"),         # (d)
@@ -80,7 +82,7 @@ def main():
                     torch.cuda.synchronize()
                     res[flag] = C.clone()
                 times[flag].append(event_ms(fn, 10))
-        fl = 2.0 * rows * N * Cin * (16 if mode == 1 else 4)
+        fl = 2.0 * rows * N * Cin * (16 if mode == 1 else 4) if mode != 4 else 2.0 * Bt * Hi * Hi * N * 16 * Cin
         m0, m1 = statistics.median(times["0"]), statistics.median(times["1"])
         tot["0"] += m0
         tot["1"] += m1

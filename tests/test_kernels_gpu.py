@@ -239,6 +239,16 @@ def test_igemm_dgrad_act_epilogue_persistent(case, act, wsp):
     test_igemm_dgrad_act_epilogue(case, act)
 
 
+@pytest.mark.parametrize("case", [(TCONV_S1P0, 4, 70, 5, 256, 8, 128, 1, 0), (TCONV_S1P0, 2, 200, 5, 256, 8, 128, 1, 0),
+                                  (TCONV_S1P0, 1, 5, 5, 256, 8, 128, 1, 0)])
+def test_s1p0_persistent(case, lab, monkeypatch):
+    """The k4 s1 p0 transposed convolution on the persistent kernel: tiles of one output pixel with 1..16 valid taps, every
+    one of them split between blocks (stream-K), sample counts that are not tile multiples; forced on for the small case."""
+    monkeypatch.setenv("MMDYN_WSP_MIN_UNITS", "0")
+    assert HIP.igemm_stat_tiles(case[0], case[1], case[2], 5, 5, 256, 8, 8, 128) == 64 * ((case[2] + 127) // 128) * 2
+    test_igemm_nt(case)
+
+
 def test_persistent_kernel_whole_tiles_and_split_tiles_agree(lab, monkeypatch):
     """The same launch cut two ways -- 512 tiles over 256 blocks (whole tiles only) and with MMDYN_WSP_UNITS_PER_BLOCK moved off
     a tile multiple (split tiles + fix-up) -- and the one-tile-per-block ring kernel: equal to summation-order error."""
