@@ -111,6 +111,11 @@ int mmdyn_igemm_nt_f16(const float* A, const float* Bp, const float* bias, float
 int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
 /* ... and what the bf16 matrix-core variants (mmdyn_igemm_nt_bf16, mmdyn_igemm_nt_mx, dgrad_bn(bf16 = 1)) write */
 int mmdyn_igemm_stat_tiles_bf16(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
+/* ... and of the mixed-storage entry point mmdyn_igemm_nt_mx for the given flags (launches whose two operands are both 16-bit
+ * in HBM may run the persistent ring kernel, csrc/igemm_wsp.hip, which writes one partial tile per wave row); flags == 0:
+ * mmdyn_igemm_stat_tiles.  mmdyn_igemm_slab_floats_mx: the `ws` workspace of such a launch (see mmdyn_igemm_slab_floats). */
+int mmdyn_igemm_stat_tiles_mx(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int flags);
+int mmdyn_igemm_slab_floats_mx(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int flags);
 /* Grouped dense GEMM (round 4): G independent problems of ONE shape in one launch,
  *   C_g[rows][N] = A_g[rows][K] . Bp_g[N][K]^T (+ bias_g),   g = 0 .. G-1,
  * group g at A + g*rows*K, Bp + g*N*K, bias + g*N, C / C_act / u + g*rows*N.  Replaces the three nn.Linear pairs

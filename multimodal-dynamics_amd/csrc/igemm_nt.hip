@@ -785,6 +785,21 @@ extern "C" int mmdyn_igemm_slab_floats(int mode, int G, int Bg, int Hi, int Wi, 
 extern "C" int mmdyn_igemm_stat_tiles_bf16(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   return lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
 }
+/* ... of the mixed-storage entry points, flags as mmdyn_igemm_nt_mx: launches whose operands are BOTH 16-bit in HBM (bits 1 and
+ * 4) may run the persistent ring kernel (igemm_wsp.hip), which writes one partial tile per wave row */
+extern "C" int mmdyn_igemm_stat_tiles_mx(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int flags) {
+  if (!(flags & 1) && !(flags & 32)) return mmdyn_igemm_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  if ((flags & 2) && (flags & 16) && ws_enabled()) {
+    const int t = mmdyn_igemm_wsp_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, true);
+    if (t > 0) return t;
+  }
+  return lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+}
+extern "C" int mmdyn_igemm_slab_floats_mx(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int flags) {
+  if (!(flags & 1) && !(flags & 32)) return mmdyn_igemm_slab_floats(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  if (!((flags & 2) && (flags & 16)) || !ws_enabled()) return 0;
+  return (int)(mmdyn_igemm_wsp_slab_bytes(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, true) / 4);
+}
 
 static int igemm_entry(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
                        float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
@@ -895,8 +910,8 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
     const int rc = mmdyn_igemm_d16_try(A, Bp, bias, C, C_act, stats, ws, g, stride, offset, st);
     if (rc != 1) return rc;
   }
-  if (ws_enabled() && !bf16 && mode != MMDYN_IM2COL3) {   // persistent ring kernel (igemm_wsp.hip)
-    const int rc = mmdyn_igemm_wsp_try(A, Bp, bias, C, C_act, stats, ws, g, false, st);
+  if (ws_enabled() && mode != MMDYN_IM2COL3 && (!bf16 || (g.a_b16 && g.b_b16))) {   // persistent ring kernel (igemm_wsp.hip)
+    const int rc = mmdyn_igemm_wsp_try(A, Bp, bias, C, C_act, stats, ws, g, bf16, st);
     if (rc != 1) return rc;
   }
   if (ws_enabled() && mode != MMDYN_IM2COL3 && mode != MMDYN_TCONV_S1P0) {   // wave-specialised LDS-DMA ring kernels (igemm_ws.hip)

@@ -599,6 +599,18 @@ static WspPick wsp_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr,
     if (e[0] == '0') return p;
   if (mode != MMDYN_CONV && mode != MMDYN_TCONV_S2P1 && mode != MMDYN_DENSE && mode != MMDYN_TCONV_S1P0) return p;
   if (splitk > 1 || b_group_stride) return p;
+  // All-16-bit operands: built and tested (tests/test_kernels_gpu.py::test_igemm_all16_persistent) but measured SLOWER in the
+  // 16-bit storage modes' steps (same box, profiles/r4/step_ab_wsp_configs.txt: bf16s bs 128 -0.6 %, bs 256 -2.6 %, 256 px -0.3 %):
+  // their K loops are DMA round trips at one block per CU, where three 64x64 blocks per CU hide more.  LAB build only
+  // (MMDYN_WSP_B16=1).
+#ifdef MMDYN_LAB
+  if (b16) {
+    const char* e = lab_env("MMDYN_WSP_B16");
+    if (!(e && e[0] == '1')) return p;
+  }
+#else
+  if (b16) return p;
+#endif
   const int kb = b16 ? 64 : BK;
   if (Cin % kb || N % 64) return p;
   const int esz = b16 ? 2 : 4;
@@ -610,7 +622,7 @@ static WspPick wsp_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr,
       if (e[0] == '0') return p;
     if (N != 128 || Hi != 5 || Wi != 5 || Hr != 8 || Wr != 8) return p;
     const long units = (long)G * ((Bg + 127) / 128) * 400 * (Cin / kb);
-    long min_units = 2L * 16 * cus;
+    long min_units = (b16 ? 1L : 2L) * 16 * cus;      // (16-bit: a K-step is latency, not arithmetic: even cuts pay earlier)
     if (const char* e = lab_env("MMDYN_WSP_MIN_UNITS")) min_units = atol(e);
     if (units < min_units || units >= (1L << 30)) return p;
     p.bm = p.bn = 128;
@@ -736,11 +748,8 @@ static int wsp_dispatch(const float* A, const float* Bp, const float* bias, floa
   const unsigned b_bytes = (unsigned)((int64_t)(g.mode == MMDYN_DENSE ? 1 : 16) * g.N * g.Cin * esz);
   if (g.mode == MMDYN_DENSE) return wsp_launch_mode<MMDYN_DENSE, B16>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
   if (g.mode == MMDYN_CONV) return wsp_launch_mode<MMDYN_CONV, B16>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
-  if (g.mode == MMDYN_TCONV_S1P0) {
-    if constexpr (B16 == 0)          // (fp32 only so far: the 16-bit modes keep their one-pixel-per-block walk)
-      return wsp_launch_mode<MMDYN_TCONV_S1P0, 0>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
-    return 1;
-  }
+  if (g.mode == MMDYN_TCONV_S1P0)
+    return wsp_launch_mode<MMDYN_TCONV_S1P0, B16>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
   return wsp_launch_mode<MMDYN_TCONV_S2P1, B16>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
 }
 
@@ -770,7 +779,6 @@ static IgemmGeom query_geom(int mode, int G, int Bg, int Hi, int Wi, int Cin, in
 // BatchNorm partial-sum tiles per group the persistent kernel writes for the shape (0: not served): one per M-tile, parity
 // class and wave row (TCONV_S1P0: per output pixel, sample tile and wave row)
 int mmdyn_igemm_wsp_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, bool b16) {
-  if (mode == MMDYN_TCONV_S1P0 && b16) return 0;
   const IgemmGeom g = query_geom(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   const WspPick p = wsp_pick(mode, G, Bg, Hi, Wi, g.Hr, g.Wr, Cin, N, g.nclasses, 1, b16, 0);
   if (!p.bm) return 0;
@@ -780,7 +788,6 @@ int mmdyn_igemm_wsp_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin,
 
 // bytes of slab workspace the launch needs for its split tiles (0: none, or not served)
 int64_t mmdyn_igemm_wsp_slab_bytes(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, bool b16) {
-  if (mode == MMDYN_TCONV_S1P0 && b16) return 0;
   const IgemmGeom g = query_geom(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   const WspPick p = wsp_pick(mode, G, Bg, Hi, Wi, g.Hr, g.Wr, Cin, N, g.nclasses, 1, b16, 0);
   if (!p.bm) return 0;
@@ -794,12 +801,13 @@ int64_t mmdyn_igemm_wsp_slab_bytes(int mode, int G, int Bg, int Hi, int Wi, int 
 int mmdyn_igemm_wsp_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
                         const IgemmGeom& g, bool bf16_ops, hipStream_t st) {
   if (bf16_ops && (!g.a_b16 || !g.b_b16)) return 1;
-  if (bf16_ops && g.mode == MMDYN_TCONV_S1P0) return 1;
   const WspPick p = wsp_pick(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Hr, g.Wr, g.Cin, g.N, g.nclasses, g.splitk, bf16_ops, g.b_group_stride);
   if (!p.bm) return 1;
   const WspSched sc = make_sched(g, p, bf16_ops);
+#ifdef MMDYN_LAB
   if (bf16_ops && g.f16) return wsp_dispatch<2>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, st);
   if (bf16_ops) return wsp_dispatch<1>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, st);
+#endif
   return wsp_dispatch<0>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, st);
 }
 

@@ -36,6 +36,8 @@ _SIGNATURES = {
     "mmdyn_igemm_nt_f16": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_stat_tiles": "iiiiiiiii",
     "mmdyn_igemm_stat_tiles_bf16": "iiiiiiiii",
+    "mmdyn_igemm_stat_tiles_mx": "iiiiiiiiii",
+    "mmdyn_igemm_slab_floats_mx": "iiiiiiiiii",
     "mmdyn_igemm_nt_grouped": "pppppp" + "iiiiii" + "p",
     "mmdyn_splitk_reduce": "pppp" + "iiii" + "p",
     "mmdyn_wgrad_tn": "ppp" + "iiiiiiiiiii" + "p",

@@ -117,10 +117,18 @@ class HipBackend:
         return self._l
 
     # ---- host-only helpers (no GPU needed) ----
-    def igemm_stat_tiles(self, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N):
-        """T of the per-tile BatchNorm partial sums the implicit GEMM of the current precision mode writes."""
-        fn = self.lib.mmdyn_igemm_stat_tiles if self.precision == "fp32" else self.lib.mmdyn_igemm_stat_tiles_bf16
-        return fn(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+    def _all16_flags(self):
+        """Flags of a launch whose two operands are both 16-bit in HBM, in the current storage mode."""
+        return 1 | 2 | 16 | (32 if self.precision == "fp16s" else 0)
+
+    def igemm_stat_tiles(self, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=False):
+        """T of the per-tile BatchNorm partial sums the implicit GEMM of the current precision mode writes.  ``all16``: both
+        operands of the launch are 16-bit in HBM (the convolution-level launches of the "bf16s" / "fp16s" modes)."""
+        if self.precision == "fp32":
+            return self.lib.mmdyn_igemm_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+        if all16 and self.precision in ("bf16s", "fp16s"):
+            return self.lib.mmdyn_igemm_stat_tiles_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, self._all16_flags())
+        return self.lib.mmdyn_igemm_stat_tiles_bf16(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
 
     def colstats_tiles(self, rows_per_group):
         return self.lib.mmdyn_colstats_tiles(rows_per_group)
@@ -133,11 +141,14 @@ class HipBackend:
         return r
 
     # ---- GEMMs ----
-    def _slabs(self, like, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N):
+    def _slabs(self, like, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=False):
         """Workspace for the pieces of the persistent ring kernel's split tiles (fp32 launches not split over K), or None."""
-        if self.precision != "fp32":
+        if self.precision == "fp32":
+            n = self.lib.mmdyn_igemm_slab_floats(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+        elif all16 and self.precision in ("bf16s", "fp16s"):
+            n = self.lib.mmdyn_igemm_slab_floats_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, self._all16_flags())
+        else:
             return None
-        n = self.lib.mmdyn_igemm_slab_floats(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
         return torch.empty(n, device=like.device, dtype=torch.float32) if n > 0 else None
 
     def _mx(self, *fmts):
@@ -151,13 +162,26 @@ class HipBackend:
                              f"(current: {self.precision})")
         return 1 | (32 if half else 0)
 
+    def _check_stat_tiles(self, stats, all16, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N):
+        """The partial-sum buffer must have the tile count the kernel that serves THIS launch writes (it depends on the
+        storage types of the operands: igemm_stat_tiles(..., all16)) -- a mismatch would be an out-of-bounds write."""
+        if stats is None:
+            return
+        T = self.igemm_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=all16)
+        if stats.dim() != 4 or tuple(stats.shape) != (G, T, 2, N):
+            raise ValueError(f"mmdyn_hip: stats must be [G={G}][T={T}][2][N={N}] for this launch (igemm_stat_tiles with "
+                             f"all16={all16}), got {tuple(stats.shape)}")
+
     def igemm_nt(self, A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride,
                  offset, act, splitk):
         (pa, a16), (pc, c16), (pca, ca16), (pb, b16) = _aptr(A), _aptr(C), _aptr(C_act), _aptr(Bp)
+        self._check_stat_tiles(stats, bool(a16 and b16), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
         if a16 or c16 or ca16 or b16:      # bf16 activation storage / bf16 packed weights: the mixed-storage entry point
             mixed_out = C_act is not None and ca16 and not c16       # fp32 pre-activation + bf16 activated output
             if ((c16 or mixed_out) and splitk != 1) or (C_act is not None and c16 and not ca16):
                 raise ValueError("mmdyn_hip: no split-K into a 16-bit output, and a 16-bit C only with a 16-bit C_act")
+            if ws is None and splitk == 1:
+                ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=bool(a16 and b16))
             check(self.lib.mmdyn_igemm_nt_mx(pa, pb, _ptr(bias), pc, pca, _ptr(stats), _ptr(ws), None, None, None,
                                              None, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act,
                                              splitk, self._mx(a16, c16, ca16, b16) | (2 if a16 else 0) | (4 if c16 else 0) |
@@ -173,8 +197,10 @@ class HipBackend:
     def igemm_nt_dgrad_bn(self, A, Bp, C, stats, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N,
                           stride, offset):
         (pa, a16), (pc, c16), (py, y16), (pb, b16) = _aptr(A), _aptr(C), _aptr(y), _aptr(Bp)
+        self._check_stat_tiles(stats, bool(a16 and b16), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
         if a16 or c16 or y16 or b16:
-            check(self.lib.mmdyn_igemm_nt_mx(pa, pb, None, pc, None, _ptr(stats), None, py, _ptr(mean), _ptr(rstd),
+            ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=bool(a16 and b16))
+            check(self.lib.mmdyn_igemm_nt_mx(pa, pb, None, pc, None, _ptr(stats), _ptr(ws), py, _ptr(mean), _ptr(rstd),
                                              _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride,
                                              offset, ACT_NONE, 1, self._mx(a16, c16, y16, b16) | (2 if a16 else 0) | (4 if c16 else 0) |
                                              (8 if y16 else 0) | (16 if b16 else 0), _stream()), "mmdyn_igemm_nt_mx")
@@ -193,7 +219,7 @@ class HipBackend:
         if a16 or c16 or u16 or b16:
             flags = self._mx(a16, c16, u16, b16)
         flags |= (2 if a16 else 0) | (4 if c16 else 0) | (8 if u16 else 0) | (16 if b16 else 0)
-        ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) if flags == 0 else None
+        ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=bool(a16 and b16)) if (flags == 0 or (a16 and b16)) else None
         check(self.lib.mmdyn_igemm_nt_dgrad_act(pa, pb, pc, pu, int(act), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset,
                                                 flags, _ptr(ws), _stream()), "mmdyn_igemm_nt_dgrad_act")
 

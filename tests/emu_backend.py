@@ -63,7 +63,7 @@ class EmuBackend:
         return wrapped
 
     # host helpers
-    def igemm_stat_tiles(self, *a):
+    def igemm_stat_tiles(self, *a, all16=False):
         return self.lib.mmdyn_igemm_stat_tiles(*a)
 
     def colstats_tiles(self, r):

@@ -249,6 +249,37 @@ def test_s1p0_persistent(case, lab, monkeypatch):
     test_igemm_nt(case)
 
 
+@pytest.mark.parametrize("case", [(CONV, 2, 3, 16, 64, 8, 128, 2, -1), (CONV, 1, 37, 8, 128, 5, 256, 1, 0), (TCONV_S2P1, 2, 5, 8, 128, 16, 64, 1, 0),
+                                  (TCONV_S1P0, 2, 70, 5, 256, 8, 128, 1, 0), (CONV, 4, 40, 16, 64, 8, 128, 2, -1)])
+def test_igemm_all16_persistent(case, wsp, store16, monkeypatch):
+    """Both operands 16-bit in HBM (the convolution-level launches of the storage modes) on the persistent kernel: 64-channel
+    K-steps on v_mfma_f32_16x16x32_{bf16,f16}, 16-bit outputs stored four columns per lane, the BatchNorm-backward operand
+    loaded likewise; every tile split (forced onto the small shapes)."""
+    mode, G, Bg, Hi, Cin, Ho, N, stride, offset = case
+    if N % int(wsp.split(",")[1]):
+        pytest.skip("N is not a multiple of the forced tile width")
+    monkeypatch.setenv("MMDYN_WSP_MIN_UNITS", "0")
+    monkeypatch.setenv("MMDYN_WSP_B16", "1")                 # (the product does not route 16-bit launches here: measured slower)
+    Bt, rows = G * Bg, G * Bg * Ho * Ho
+    A, Bp, bias = bf(rnd(Bt * Hi * Hi, Cin, seed=141)), bf(rnd(16, N, Cin, seed=142, scale=0.2)), rnd(N, seed=143)
+    T = HIP.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, all16=True)
+    post = lambda i, t: (t.sum(1) if t.dim() == 4 else t.float())
+    for c_dtype in (S16, torch.float32):
+        C, Ca, stats = torch.zeros(rows, N, dtype=c_dtype), torch.zeros(rows, N, dtype=c_dtype), torch.zeros(G, T, 2, N)
+        both("igemm_nt", [A, Bp, None, C, None, stats, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1],
+             [3, 5], post, tol=4e-3 if c_dtype == S16 else 2e-5)
+        both("igemm_nt", [A, Bp, bias, C, Ca, None, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 1, 1],
+             [3, 4], post, tol=4e-3 if c_dtype == S16 else 2e-5)
+    if mode != TCONV_S1P0:
+        y = bf(rnd(rows, N, seed=144) * 1.5 + 0.2)
+        mean, rstd = rnd(G, N, seed=145) * 0.3, rnd(G, N, seed=146).abs() + 0.5
+        gamma, beta = rnd(N, seed=147) + 1.2, rnd(N, seed=148)
+        both("igemm_nt_dgrad_bn", [A, Bp, torch.zeros(rows, N, dtype=S16), torch.zeros(G, T, 2, N), y, mean, rstd, gamma, beta, mode, G,
+                                   Bg, Hi, Hi, Cin, Ho, Ho, N, stride, offset], [2, 3], post, tol=4e-3)
+        both("igemm_nt_dgrad_act", [A, Bp, torch.zeros(rows, N, dtype=S16), y, 1, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride, offset],
+             [2], lambda i, t: t.float(), tol=4e-3)
+
+
 def test_persistent_kernel_whole_tiles_and_split_tiles_agree(lab, monkeypatch):
     """The same launch cut two ways -- 512 tiles over 256 blocks (whole tiles only) and with MMDYN_WSP_UNITS_PER_BLOCK moved off
     a tile multiple (split tiles + fix-up) -- and the one-tile-per-block ring kernel: equal to summation-order error."""
@@ -802,7 +833,7 @@ def test_igemm_bf16_mixed_output_and_one_pixel_walk(monkeypatch, lab, store16):
                 monkeypatch.setenv("MMDYN_S1P0_SPLIT", forced)
             Bt = G * Bg
             A, Bp, bias = bf(rnd(Bt * 25, 256, seed=123)), bf(rnd(16, 128, 256, seed=124, scale=0.1)), rnd(128, seed=125)
-            T = HIP.igemm_stat_tiles(TCONV_S1P0, G, Bg, 5, 5, 256, 8, 8, 128)
+            T = HIP.igemm_stat_tiles(TCONV_S1P0, G, Bg, 5, 5, 256, 8, 8, 128, all16=True)
             both("igemm_nt", [A, Bp, bias, torch.zeros(Bt * 64, 128, dtype=S16), None, torch.zeros(G, T, 2, 128), None,
                               TCONV_S1P0, G, Bg, 5, 5, 256, 8, 8, 128, 128, 1, 0, 0, 1], [3, 5], post, tol=4e-3)
     finally:
