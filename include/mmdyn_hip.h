@@ -154,6 +154,13 @@ int mmdyn_wgrad_tn_f16(const float* D, const float* Gt, float* partial, int mode
  * mmdyn_wgrad_chunks_mx(DENSE, rows, Cd, Cg, flags); flags as mmdyn_wgrad_tn_mx (not both operands 16-bit). */
 int mmdyn_wgrad_tn_grouped(const void* D, const void* Gt, float* partial, int G, int rows, int Cd, int Cg, int chunks,
                            int flags, void* stream);
+/* Round 4, SURVEY.md section 7 step 5 (BatchNorm-apply + Swish fused into the neighbouring kernels): the weight gradient of
+ * the decoder's last layer nn.ConvTranspose2d(32, 3, 4, 2, 1) (vae.py:277) with the BatchNorm2d + Swish in front of it
+ * (vae.py:275-276) recomputed on the operand fetch.  y [G*Bg][Hr][Hr][32]: the pre-BatchNorm tensor (fp32; y_b16 = 1 bf16,
+ * 2 IEEE half); mean / rstd [G][32]; Gt: the NCHW logit gradient [G*Bg][3][2Hr][2Hr]; partial [chunks][32][64] as
+ * mmdyn_wgrad_tn(MMDYN_IM2COL3) writes it (chunks = mmdyn_wgrad_chunks(MMDYN_IM2COL3, ...)).  Hr = 32, 64 or 128. */
+int mmdyn_wgrad_out3_bn(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        const float* Gt, float* partial, int G, int Bg, int Hr, int chunks, int y_b16, void* stream);
 int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg);
 /* ... for the kernel the storage flags of mmdyn_wgrad_tn_mx select (both operands 16-bit in HBM: the all-16-bit kernels' tiles) */
 int mmdyn_wgrad_chunks_mx(int mode, int rows, int Cd, int Cg, int flags);
@@ -208,6 +215,11 @@ int mmdyn_col2im_k4(const float* col, float* out, int Bt, int Hi, int Wi, int Ho
 /* nn.ConvTranspose2d(32, 3, 4, 2, 1) forward (vae.py:277) as a direct LDS-tiled VALU kernel: a is NHWC
  * [Bt][Hi][Wi][32], w the reference's [32][3][4][4], out NCHW logits [Bt][3][2Hi][2Wi]; Hi, Wi % 16 == 0. */
 int mmdyn_tconv_out3_fwd(const float* a, const float* w, float* out, int Bt, int Hi, int Wi, void* stream);
+/* ... fused with the BatchNorm2d + Swish in front of it (vae.py:275-277): y [G*Bg][Hi][Wi][32] is the pre-BatchNorm output of the
+ * layer below (fp32; b16 = 1 bf16, 2 IEEE half), mean / rstd [G][32] its batch statistics; the activation is applied while
+ * the input tile is staged, the activated tensor never exists in HBM. */
+int mmdyn_tconv_out3_bn_fwd(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            const float* w, float* out, int G, int Bg, int Hi, int Wi, int b16, void* stream);
 
 /* ---- train-mode BatchNorm2d + Swish, channels-last, per group (vae.py:201-208, 269-276) ----- */
 /* column sums of y and y*y over row chunks -> partial[G][T][2][C], T = mmdyn_colstats_tiles(rows_per_group) */

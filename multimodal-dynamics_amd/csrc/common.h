@@ -261,7 +261,9 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
                        const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
                        int c_b16, int bny_b16, int b_b16, hipStream_t st);
 int mmdyn_conv3_wgrad_try(const void* D, const float* Gt, float* partial, int Bt, int Hr, int Wr, int Cd, int Hi,
-                          int Wi, int Cg, int chunks, int d_b16, hipStream_t st);
+                          int Wi, int Cg, int chunks, int d_b16, hipStream_t st, const float* bn_mean = nullptr,
+                          const float* bn_rstd = nullptr, const float* bn_gamma = nullptr, const float* bn_beta = nullptr,
+                          int Bg = 0);
 
 // Kernel-experiment knobs (environment variables read by the library: docs/LAB_NOTES.md C) exist only in the LAB build
 // (make lab -> libmmdyn_hip_lab.so, -DMMDYN_LAB).  The product library has one code path per launch: lab_env() is

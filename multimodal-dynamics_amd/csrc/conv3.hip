@@ -228,6 +228,12 @@ struct Conv3WgradGeom {
   int Bt, Hr, Hi, Wi;       // Wr = Hr = 32 * SEGS
   int img_rows;             // Bt*Hr*SEGS units (32-pixel segments of output image rows) = K-blocks of 32 pixels
   int rows_per_chunk;       // units per block
+  // BNACT: the dense operand is swish(BatchNorm(D)) of the layer's pre-BatchNorm tensor, recomputed on the fetch
+  const float* bn_mean;     // [G][32]
+  const float* bn_rstd;
+  const float* bn_gamma;    // [32]
+  const float* bn_beta;
+  int Bg;                   // samples per BatchNorm group
 };
 
 constexpr int PATCH_LD = 76;                 // 3 pad + 1 (x = -1) + 64 + 1 (x = 64) + pad; 76 % 32 = 12 spreads the
@@ -236,7 +242,11 @@ constexpr int PATCH = PATCH_ROWS * PATCH_LD;
 
 // SEGS as in conv3_nt_kernel: images of 64 * SEGS pixels a side; a K-block is one 32-pixel segment of an output row, its
 // patch the 12 input rows x 64 columns under it plus one halo column on either side (zero at the image border)
-template <typename TD, int SEGS>
+// BNACT (round 4): D is the PRE-BatchNorm output y of the decoder's last BatchNorm layer and the kernel multiplies with
+// a = swish(gamma * ((y - mean[g]) * rstd[g]) + beta), recomputed as the fragments arrive (a lane always holds channel lane & 31:
+// four constants per lane and group; ~8 VALU instructions per element in the shadow of the 64-cycle MFMAs) -- the activated
+// tensor the forward no longer writes (tconv_out3.hip, FUSED) is not needed here either.
+template <typename TD, int SEGS, bool BNACT = false>
 __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const TD* __restrict__ D, const float* __restrict__ img,
                                                           float* __restrict__ partial, const Conv3WgradGeom g) {
   __shared__ __attribute__((aligned(16))) float smem[8192];       // 4 waves x 2 patches (7904 floats); reused as [4][32][64]
@@ -291,10 +301,26 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const TD* __restrict__
       if (lane < 24) p[(lane >> 1) * PATCH_LD + ((lane & 1) ? 68 : 3)] = rh;
     }
   };
+  float bn_m = 0.f, bn_r = 1.f, bn_g = 1.f, bn_b = 0.f;
+  int bn_grp = -1;
+  if constexpr (BNACT) {
+    bn_g = g.bn_gamma[n];
+    bn_b = g.bn_beta[n];
+  }
   auto load_d = [&](int it, float* d) {         // fragment order: lane (cd = n, pixel 2j + kk) = 64 consecutive elements
     const TD* p = D + (size_t)it * 32 * 32 + lane;
 #pragma unroll
     for (int j = 0; j < 16; ++j) d[j] = ld1<TD>(p + 64 * j);
+    if constexpr (BNACT) {
+      const int grp = (it / (g.Hr * SEGS)) / g.Bg;          // (wave-uniform; changes a handful of times per block)
+      if (grp != bn_grp) {
+        bn_grp = grp;
+        bn_m = g.bn_mean[grp * 32 + n];
+        bn_r = g.bn_rstd[grp * 32 + n];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) d[j] = swishf_(bn_g * ((d[j] - bn_m) * bn_r) + bn_b);
+    }
   };
 
   f32x16 acc[2];
@@ -413,8 +439,10 @@ int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void*
 }
 
 // chunks = partial slabs = blocks; 1 when the shape is not this file's
+// bn_mean != nullptr: D is the pre-BatchNorm tensor, the operand swish(BatchNorm(D)) (groups of Bg samples)
 int mmdyn_conv3_wgrad_try(const void* D, const float* Gt, float* partial, int Bt, int Hr, int Wr, int Cd, int Hi,
-                          int Wi, int Cg, int chunks, int d_b16, hipStream_t st) {
+                          int Wi, int Cg, int chunks, int d_b16, hipStream_t st, const float* bn_mean, const float* bn_rstd,
+                          const float* bn_gamma, const float* bn_beta, int Bg) {
   if (Cd != 32 || Cg != 64 || Wr != Hr || Wi != Hi || Hi != 2 * Hr || (Hi != 64 && Hi != 128 && Hi != 256)) return 1;
   const int segs = Hi / 64;
   if ((int64_t)Bt * Hr * segs >= (1LL << 30)) return 1;
@@ -425,8 +453,18 @@ int mmdyn_conv3_wgrad_try(const void* D, const float* Gt, float* partial, int Bt
   g.Wi = Wi;
   g.img_rows = Bt * Hr * segs;
   g.rows_per_chunk = ceil_div(g.img_rows, chunks);
-#define CONV3_WG(T_, S_) \
-  hipLaunchKernelGGL((conv3_wgrad_kernel<T_, S_>), dim3(chunks), dim3(256), 0, st, (const T_*)D, Gt, partial, g)
+  g.bn_mean = bn_mean;
+  g.bn_rstd = bn_rstd;
+  g.bn_gamma = bn_gamma;
+  g.bn_beta = bn_beta;
+  g.Bg = Bg > 0 ? Bg : Bt;
+#define CONV3_WG(T_, S_)                                                                                                  \
+  do {                                                                                                                    \
+    if (bn_mean)                                                                                                          \
+      hipLaunchKernelGGL((conv3_wgrad_kernel<T_, S_, true>), dim3(chunks), dim3(256), 0, st, (const T_*)D, Gt, partial, g); \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((conv3_wgrad_kernel<T_, S_>), dim3(chunks), dim3(256), 0, st, (const T_*)D, Gt, partial, g);     \
+  } while (0)
   if (d_b16 == 2) {
     if (segs == 1) CONV3_WG(half_t, 1);
     else if (segs == 2) CONV3_WG(half_t, 2);

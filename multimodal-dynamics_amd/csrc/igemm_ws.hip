@@ -170,9 +170,16 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
     auto settap = [&]() {
       int dh = 0, dw = 0, wi = 0;
       if (MODE == MMDYN_CONV) {
-        dh = tap >> 2;
-        dw = tap & 3;
-        wi = tap;
+        // Stride 2: the taps that touch the SAME input pixels are walked back to back -- (kh, kw), (kh, kw ^ 2), (kh ^ 2, kw),
+        // (kh ^ 2, kw ^ 2) read the same columns of the same input rows one output pixel apart -- so that a block's re-reads
+        // of a line follow its first touch by at most three K-steps instead of up to ten.  Order: class (kh & 1, kw & 1) major;
+        // the weight slice follows the tap.  Measured (profiles/r4/ab_taporder*.txt): L2 misses of the launch -18 %, hit rate
+        // 0.872 -> 0.894, time x1.01 -- the kernel is not bound by where its fills are served from (docs/LAB_NOTES.md E).
+        const int cls = tap >> 2, j = tap & 3;           // class (kh & 1, kw & 1); member (kh >> 1, kw >> 1)
+        const int t2 = g.tap_order ? ((cls >> 1) + 2 * (j >> 1)) * 4 + (cls & 1) + 2 * (j & 1) : tap;
+        dh = t2 >> 2;
+        dw = t2 & 3;
+        wi = t2;
       } else if (MODE == MMDYN_TCONV_S2P1) {
         const int th = tap >> 1, tw = tap & 1;
         dh = ph - th;
@@ -507,7 +514,10 @@ int mmdyn_igemm_ws_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, 
 // bf16_ops: the launch runs on the 16-bit matrix cores; served here only when BOTH operands are 16-bit in HBM (bf16, or IEEE
 // half when g.f16 is set too)
 int mmdyn_igemm_ws_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
-                       const IgemmGeom& g, bool bf16_ops, hipStream_t st) {
+                       const IgemmGeom& g_in, bool bf16_ops, hipStream_t st) {
+  IgemmGeom g = g_in;
+  g.tap_order = g.mode == MMDYN_CONV && g.rs == 2;
+  if (const char* e = lab_env("MMDYN_WS_TAPORDER")) g.tap_order = g.tap_order && e[0] != '0';      // LAB: raster order (A/B)
   if (bf16_ops && (!g.a_b16 || !g.b_b16)) return 1;
   if ((int64_t)g.G * g.b_group_stride * 4 >= MAX_BUFFER_BYTES) return 1;      // (grouped weights: one buffer descriptor)
   const WsPick p = ws_pick(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Hr, g.Wr, g.Cin, g.N, g.nclasses, g.splitk, bf16_ops);

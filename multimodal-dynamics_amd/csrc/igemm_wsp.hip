@@ -342,9 +342,12 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
         dw = -kw;
         wi = kh * 4 + kw;
       } else if (MODE == MMDYN_CONV) {
-        dh = tap >> 2;
-        dw = tap & 3;
-        wi = tap;
+        // (stride 2: the four taps of one input-pixel class back to back, as in igemm_ws.hip)
+        const int cls = tap >> 2, j = tap & 3;
+        const int t2 = g.tap_order ? ((cls >> 1) + 2 * (j >> 1)) * 4 + (cls & 1) + 2 * (j & 1) : tap;
+        dh = t2 >> 2;
+        dw = t2 & 3;
+        wi = t2;
       } else if (MODE == MMDYN_TCONV_S2P1) {
         const int th = tap >> 1, tw = tap & 1;
         dh = ph - th;
@@ -799,7 +802,10 @@ int64_t mmdyn_igemm_wsp_slab_bytes(int mode, int G, int Bg, int Hi, int Wi, int 
 
 // bf16_ops: the launch runs on the 16-bit matrix cores; served only when BOTH operands are 16-bit in HBM
 int mmdyn_igemm_wsp_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
-                        const IgemmGeom& g, bool bf16_ops, hipStream_t st) {
+                        const IgemmGeom& g_in, bool bf16_ops, hipStream_t st) {
+  IgemmGeom g = g_in;
+  g.tap_order = g.mode == MMDYN_CONV && g.rs == 2;
+  if (const char* e = lab_env("MMDYN_WS_TAPORDER")) g.tap_order = g.tap_order && e[0] != '0';
   if (bf16_ops && (!g.a_b16 || !g.b_b16)) return 1;
   const WspPick p = wsp_pick(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Hr, g.Wr, g.Cin, g.N, g.nclasses, g.splitk, bf16_ops, g.b_group_stride);
   if (!p.bm) return 1;

@@ -23,11 +23,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // in one register pair.  The tile is therefore staged channel-major, [32 ch][18 rows][18 px]: a pixel pair of one channel
 // is two neighbouring floats.  768 packed FMAs per thread and no register shuffles, against 1536 + ~1000 v_mov when the pairs
 // had to be assembled from pixel-major 16-byte reads (82 -> 5x us per launch on 4 x 256 samples).
-template <typename TA>
+// Round 4: FUSED = the input is the layer's pre-BatchNorm tensor y and the staging loop applies the preceding
+// BatchNorm2d + Swish (vae.py:275-276) on its way into LDS -- a = swish(gamma * ((y - mean[g]) * rstd[g]) + beta), the expression
+// of bn_swish_fwd_kernel, once per staged element (1.27x with the halo) -- so the activated tensor is never written to HBM and
+// the separate element-wise pass over the largest activation of the network disappears.
+struct Out3Bn {
+  const float* mean;      // [G][32]
+  const float* rstd;      // [G][32]
+  const float* gamma;     // [32]
+  const float* beta;      // [32]
+  int Bg;                 // samples per BatchNorm group
+};
+template <typename TA, bool FUSED = false>
 __global__ __launch_bounds__(256) void tconv_out3_kernel(const TA* __restrict__ a,         // [Bt][Hi][Wi][32]
                                                          const float* __restrict__ w,      // [32][3][4][4]
                                                          float* __restrict__ out,          // [Bt][3][2Hi][2Wi]
-                                                         int Hi, int Wi) {
+                                                         int Hi, int Wi, const Out3Bn bn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tile = reinterpret_cast<float*>(smem);           // [32][TH][PX_LD]
   const int tid = threadIdx.x;
@@ -40,6 +51,15 @@ __global__ __launch_bounds__(256) void tconv_out3_kernel(const TA* __restrict__ 
   // store: as a load -> store loop the eleven round trips were serial and the launch latency-bound (10 us of a block's 13)
   constexpr int NLD = (TH * TH * 8 + 255) / 256;
   f32x4 val[NLD];
+  // (a thread stages the same four channels in every round: 256 % 8 == 0)
+  f32x4 bm = {0.f, 0.f, 0.f, 0.f}, br = bm, bg = bm, bb = bm;
+  if constexpr (FUSED) {
+    const int c0 = (tid & 7) * 4, grp = b / bn.Bg;
+    bm = *reinterpret_cast<const f32x4*>(bn.mean + grp * 32 + c0);
+    br = *reinterpret_cast<const f32x4*>(bn.rstd + grp * 32 + c0);
+    bg = *reinterpret_cast<const f32x4*>(bn.gamma + c0);
+    bb = *reinterpret_cast<const f32x4*>(bn.beta + c0);
+  }
 #pragma unroll
   for (int k = 0; k < NLD; ++k) {
     const int idx = tid + 256 * k;
@@ -49,8 +69,12 @@ __global__ __launch_bounds__(256) void tconv_out3_kernel(const TA* __restrict__ 
     const bool ok = idx < TH * TH * 8 && (unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     // (masked lanes read a valid dummy address: a predicated load would be sunk into its own branch)
-    const f32x4 r = ld4<TA>(a + (ok ? ((size_t)(b * Hi + y) * Wi + x) * 32 + v * 4 : (size_t)0));
-    val[k] = ok ? r : z;
+    f32x4 r = ld4<TA>(a + (ok ? ((size_t)(b * Hi + y) * Wi + x) * 32 + v * 4 : (size_t)0));
+    if constexpr (FUSED) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[q] = swishf_(bg[q] * ((r[q] - bm[q]) * br[q]) + bb[q]);
+    }
+    val[k] = ok ? r : z;                                  // (padding is zero AFTER the activation, as in the unfused layer)
   }
 #pragma unroll
   for (int k = 0; k < NLD; ++k) {
@@ -122,7 +146,27 @@ extern "C" int mmdyn_tconv_out3_fwd(const float* a, const float* w, float* out, 
   if ((int64_t)Bt * Hi * Wi * 32 >= (1LL << 31)) return MMDYN_ERR_RANGE;
   dim3 grid((Hi / TI) * (Wi / TI), Bt);
   size_t smem = (size_t)32 * CH_LD * sizeof(float);
-  hipLaunchKernelGGL(tconv_out3_kernel<float>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi);
+  hipLaunchKernelGGL(tconv_out3_kernel<float>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi, Out3Bn{});
+  MMDYN_LAUNCH_CHECK();
+}
+
+/* The same layer fused with the BatchNorm2d + Swish in front of it: `y` is the pre-BatchNorm output of the layer below
+ * ([G*Bg][Hi][Wi][32]; fp32, or 16-bit with b16 = 1 (bf16) / 2 (IEEE half)), mean / rstd [G][32] its batch statistics. */
+extern "C" int mmdyn_tconv_out3_bn_fwd(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                       const float* w, float* out, int G, int Bg, int Hi, int Wi, int b16, void* stream) {
+  if (!y || !mean || !rstd || !gamma || !beta || !w || !out) return MMDYN_ERR_NULL;
+  const int64_t Bt = (int64_t)G * Bg;
+  if (G <= 0 || Bg <= 0 || Hi % TI || Wi % TI || Bt > 65535 || b16 < 0 || b16 > 2) return MMDYN_ERR_SHAPE;
+  if (Bt * Hi * Wi * 32 >= (1LL << 31)) return MMDYN_ERR_RANGE;
+  dim3 grid((Hi / TI) * (Wi / TI), (unsigned)Bt);
+  size_t smem = (size_t)32 * CH_LD * sizeof(float);
+  const Out3Bn bn{mean, rstd, gamma, beta, Bg};
+  if (b16 == 2)
+    hipLaunchKernelGGL((tconv_out3_kernel<half_t, true>), grid, dim3(256), smem, (hipStream_t)stream, (const half_t*)y, w, out, Hi, Wi, bn);
+  else if (b16 == 1)
+    hipLaunchKernelGGL((tconv_out3_kernel<bf16_t, true>), grid, dim3(256), smem, (hipStream_t)stream, (const bf16_t*)y, w, out, Hi, Wi, bn);
+  else
+    hipLaunchKernelGGL((tconv_out3_kernel<float, true>), grid, dim3(256), smem, (hipStream_t)stream, (const float*)y, w, out, Hi, Wi, bn);
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -135,8 +179,8 @@ extern "C" int mmdyn_tconv_out3_fwd_b16(const uint16_t* a, const float* w, float
   dim3 grid((Hi / TI) * (Wi / TI), Bt);
   size_t smem = (size_t)32 * CH_LD * sizeof(float);
   if (half)
-    hipLaunchKernelGGL(tconv_out3_kernel<half_t>, grid, dim3(256), smem, (hipStream_t)stream, (const half_t*)a, w, out, Hi, Wi);
+    hipLaunchKernelGGL(tconv_out3_kernel<half_t>, grid, dim3(256), smem, (hipStream_t)stream, (const half_t*)a, w, out, Hi, Wi, Out3Bn{});
   else
-    hipLaunchKernelGGL(tconv_out3_kernel<bf16_t>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi);
+    hipLaunchKernelGGL(tconv_out3_kernel<bf16_t>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi, Out3Bn{});
   MMDYN_LAUNCH_CHECK();
 }

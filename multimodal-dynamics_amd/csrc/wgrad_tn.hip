@@ -1023,6 +1023,19 @@ extern "C" int mmdyn_wgrad_tn_grouped(const void* D, const void* Gt, float* part
                      (flags & 1) != 0 || (flags & 32) != 0, flags & ~1, G);
 }
 
+/* Weight gradient of the decoder's LAST layer (nn.ConvTranspose2d(32, 3, 4, 2, 1), vae.py:277) with the BatchNorm2d + Swish in
+ * front of it recomputed on the operand fetch: y [G*Bg][Hr][Hr][32] is the pre-BatchNorm tensor (fp32, or 16-bit with y_b16 =
+ * 1 / 2), the dense operand swish(gamma * ((y - mean[g]) * rstd[g]) + beta); Gt the NCHW logit gradient [G*Bg][3][2Hr][2Hr]
+ * (im2col mode).  partial: [chunks][1][32][64] as mmdyn_wgrad_tn(MMDYN_IM2COL3).  Hr = 32, 64 or 128 (the direct kernel). */
+extern "C" int mmdyn_wgrad_out3_bn(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                   const float* Gt, float* partial, int G, int Bg, int Hr, int chunks, int y_b16, void* stream) {
+  if (!y || !mean || !rstd || !gamma || !beta || !Gt || !partial) return MMDYN_ERR_NULL;
+  if (G <= 0 || Bg <= 0 || chunks < 1 || y_b16 < 0 || y_b16 > 2) return MMDYN_ERR_SHAPE;
+  const int rc = mmdyn_conv3_wgrad_try(y, Gt, partial, G * Bg, Hr, Hr, 32, 2 * Hr, 2 * Hr, 64, chunks, y_b16, (hipStream_t)stream,
+                                       mean, rstd, gamma, beta, Bg);
+  return rc == 1 ? MMDYN_ERR_SHAPE : rc;
+}
+
 /* fp16 matrix cores (v_mfma_f32_32x32x8_f16), fp32 accumulate, fp32 storage: BASELINE configs[4] */
 extern "C" int mmdyn_wgrad_tn_f16(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr,
                                   int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,

@@ -56,6 +56,8 @@ _SIGNATURES = {
     "mmdyn_im2col_nchw3": "pp" + "iii" + "p",
     "mmdyn_col2im_k4": "pp" + "iiiiiiiiii" + "p",
     "mmdyn_tconv_out3_fwd": "ppp" + "iii" + "p",
+    "mmdyn_tconv_out3_bn_fwd": "ppppppp" + "iiiii" + "p",
+    "mmdyn_wgrad_out3_bn": "ppppppp" + "iiiii" + "p",
     "mmdyn_colstats": "pp" + "iii" + "p",
     "mmdyn_colstats_tiles": "i",
     "mmdyn_bn_finalize": "ppppppp" + "iiii" + "ff" + "i" + "pp",
