@@ -241,7 +241,39 @@ def wgrad(D, Gt, canon, mode, Bt, Hr, Cd, Hi, Cg, stride=1, offset=0, cg_canon=N
 def run_deferred_wgrads(queue):
     """Launch (and forget) the weight-gradient GEMMs queued with ``wgrad(..., defer=queue)`` on the current stream."""
     while queue:
-        wgrad(*queue.pop(0))
+        item = queue.pop(0)
+        if item and callable(item[0]):          # (fn, *args): a weight gradient with its own launcher (wgrad_out3_bn)
+            item[0](*item[1:])
+        else:
+            wgrad(*item)
+
+
+def bn_stats_only(y, partial, T, bn, G, rows_per_group, C, repeat=1):
+    """mean / rstd of a BatchNorm layer WITHOUT the apply pass (the consumer applies BatchNorm + Swish on its operand fetch)."""
+    if partial is None:             # eval mode: running estimates
+        mean, rstd = _new(y, G, C), _new(y, G, C)
+        ops.B.bn_eval_stats(bn.rm, bn.rv, mean, rstd, G, C, BN_EPS)
+        return mean, rstd
+    return _bn_forward_stats(y, partial, T, bn, G, rows_per_group, C, repeat)
+
+
+def fuses_last_bn(S):
+    """The decoder's last BatchNorm + Swish rides on its two consumers (tconv_out3.hip FUSED, conv3_wgrad_kernel BNACT) for the
+    image sizes those direct kernels serve (local and synchronised statistics alike: the consumers only need mean / rstd)."""
+    return S in (64, 128, 256)
+
+
+def wgrad_out3_bn(y, mean, rstd, bn, dlogits, canon, G, Bg, Hr, defer=None):
+    """Weight gradient of the last decoder layer (canonical [32][3][4][4]) from the pre-BatchNorm tensor y of the stage below:
+    swish(BatchNorm(y)) is recomputed on the operand fetch (the activated tensor was never stored)."""
+    if defer is not None:
+        defer.append((wgrad_out3_bn, y, mean, rstd, bn, dlogits, canon, G, Bg, Hr))
+        return
+    rows = G * Bg * Hr * Hr
+    chunks = ops.B.wgrad_chunks(IM2COL3, rows, 32, 64)
+    partial = _new(y, chunks, 1, 32, 64)
+    ops.B.wgrad_out3_bn(y, mean, rstd, bn.gamma, bn.beta, dlogits, partial, G, Bg, Hr, chunks)
+    ops.B.wgrad_reduce(partial, canon, chunks, 1, 32, 64, 48, 0, 0.0)
 
 
 def pack_conv(W, swap):
@@ -647,14 +679,25 @@ def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, co
         else:
             Ho = 2 * H
             y, st, T = conv_like(a, pk[f"W{j + 1}s"], TCONV_S2P1, G, Bg, H, cin, Ho, cout, stats=training)
-        an, m, r = bn_swish_from_partials(y, st, T, bn, G, Bg * Ho * Ho, cout, repeat)
+        if j == len(convs) - 1 and fuses_last_bn(S) and cout == 32:
+            # last BatchNorm + Swish: statistics only -- the two consumers of the activated tensor (the 3-channel output layer
+            # below, the last layer's weight gradient) apply it on their operand fetch, the tensor itself is never written
+            m, r = bn_stats_only(y, st, T, bn, G, Bg * Ho * Ho, cout, repeat)
+            an = None
+        else:
+            an, m, r = bn_swish_from_partials(y, st, T, bn, G, Bg * Ho * Ho, cout, repeat)
         stages.append(dict(i=i, Hi=H, Ho=Ho, cin=cin, cout=cout, a_in=a, y=y, a=an, m=m, r=r, bn=bn))
         a, H = an, Ho
         yield
     out = None
     if logits:
         out = _new(z, Bt, 3, S, S)
-        ops.B.tconv_out3_fwd(a, P[f"hallucinate.{last}.weight"], out, Bt, H, H)     # direct kernel, canonical weights
+        t = stages[-1]
+        if t["a"] is None:
+            ops.B.tconv_out3_bn_fwd(t["y"], t["m"], t["r"], t["bn"].gamma, t["bn"].beta, P[f"hallucinate.{last}.weight"], out, G, Bg,
+                                    H, H)
+        else:
+            ops.B.tconv_out3_fwd(a, P[f"hallucinate.{last}.weight"], out, Bt, H, H)     # direct kernel, canonical weights
     c.update(u0=u0, h0=h0, stages=stages)
     return out, c
 
@@ -673,7 +716,10 @@ def decoder_backward_steps(P, c, dlogits, grads, need_dz=True, defer=None):
 
     # last layer backward: both GEMMs gather the k4 s2 p1 window of the NCHW logit gradient on the fly
     t = st[n - 1]
-    wgrad(t["a"], dlogits, grads[f"hallucinate.{c['last']}.weight"], IM2COL3, Bt, S // 2, 32, S, 64, cg_canon=48, defer=defer)
+    if t["a"] is None:            # (the activated tensor of the last BatchNorm was never stored: recomputed on the fetch)
+        wgrad_out3_bn(t["y"], t["m"], t["r"], t["bn"], dlogits, grads[f"hallucinate.{c['last']}.weight"], G, Bg, S // 2, defer=defer)
+    else:
+        wgrad(t["a"], dlogits, grads[f"hallucinate.{c['last']}.weight"], IM2COL3, Bt, S // 2, 32, S, 64, cg_canon=48, defer=defer)
     # the input-gradient GEMM of every layer carries the BatchNorm+Swish backward of the layer below in its epilogue
     dy = dgrad_bn_swish_backward(dlogits, pk[f"W{n + 1}p"], IM2COL3, G, Bg, S, 64, S // 2, 32, 1, 0, t["y"], t["m"], t["r"],
                                  t["bn"], *bn_keys(t))

@@ -308,6 +308,18 @@ class HipBackend:
             return
         check(self.lib.mmdyn_tconv_out3_fwd(pa, _ptr(w), _ptr(out), Bt, Hi, Wi, _stream()), "mmdyn_tconv_out3_fwd")
 
+    def tconv_out3_bn_fwd(self, y, mean, rstd, gamma, beta, w, out, G, Bg, Hi, Wi):
+        """The last decoder layer on the PRE-BatchNorm tensor y: BatchNorm2d + Swish applied while the input tile is staged."""
+        py, y16 = _aptr(y)
+        check(self.lib.mmdyn_tconv_out3_bn_fwd(py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(w), _ptr(out), G, Bg, Hi, Wi,
+                                               y16, _stream()), "mmdyn_tconv_out3_bn_fwd")
+
+    def wgrad_out3_bn(self, y, mean, rstd, gamma, beta, Gt, partial, G, Bg, Hr, chunks):
+        """Weight gradient of the last decoder layer with swish(BatchNorm(y)) recomputed on the operand fetch."""
+        py, y16 = _aptr(y)
+        check(self.lib.mmdyn_wgrad_out3_bn(py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(Gt), _ptr(partial), G, Bg, Hr,
+                                           chunks, y16, _stream()), "mmdyn_wgrad_out3_bn")
+
     def nchw_to_nhwc(self, src, dst, B, C, HW):
         check(self.lib.mmdyn_nchw_to_nhwc(_ptr(src), _ptr(dst), B, C, HW, _stream()), "mmdyn_nchw_to_nhwc")
 

@@ -27,6 +27,11 @@ def _canon(name, a):
     if name == "wgrad_tn_grouped":
         D, Gt, partial, G, rows, Cd, Cg, chunks = a
         name, a = "wgrad_tn", (D, Gt, partial, ops.DENSE, G * rows, 1, 1, Cd, 1, 1, Cg, 1, 0, chunks)
+    if name == "wgrad_out3_bn":           # the last decoder layer's weight gradient with the fused BatchNorm + Swish (conv3_wgrad_kernel)
+        y, mean, rstd, gamma, beta, Gt, partial, G, Bg, Hr, chunks = a
+        return "conv3_wgrad", (y, Gt, partial, ops.IM2COL3, G * Bg, Hr, Hr, 32, 2 * Hr, 2 * Hr, 64, 1, 0, chunks)
+    if name == "tconv_out3_bn_fwd":
+        return "tconv_out3_fwd", a
     # the 3-channel layers run their own kernels (csrc/conv3.hip), not igemm_nt_kernel / wgrad_tn_kernel: booked apart so
     # that the launch counts and average durations of the MFMA families match what rocprofv3 reports per kernel name
     if name == "igemm_nt" and a[7] == ops.IM2COL3 and a[10] in (64, 128, 256) and \

@@ -279,6 +279,21 @@ class EmuBackend:
         x = a.reshape(Bt, Hi, Wi, 32).permute(0, 3, 1, 2)
         out.reshape(-1).copy_(F.conv_transpose2d(x, w.reshape(32, 3, 4, 4), stride=2, padding=1).reshape(-1))
 
+    def tconv_out3_bn_fwd(self, y, mean, rstd, gamma, beta, w, out, G, Bg, Hi, Wi):
+        """mmdyn_tconv_out3_bn_fwd: the activation is applied in fp32 on the (possibly 16-bit) y and never rounded to storage."""
+        a = torch.empty(y.shape, dtype=torch.float32)
+        EmuBackend.bn_swish_fwd(self, y.float(), mean, rstd, gamma, beta, a, G, Bg * Hi * Wi, 32)
+        EmuBackend.tconv_out3_fwd(self, a, w, out, G * Bg, Hi, Wi)
+
+    def wgrad_out3_bn(self, y, mean, rstd, gamma, beta, Gt, partial, G, Bg, Hr, chunks):
+        a = torch.empty(y.shape, dtype=torch.float32)
+        EmuBackend.bn_swish_fwd(self, y.float(), mean, rstd, gamma, beta, a, G, Bg * Hr * Hr, 32)
+        prev, self.precision = self.precision, "fp32"            # (the 3-channel layers keep fp32 matrix cores in every mode)
+        try:
+            EmuBackend.wgrad_tn(self, a, Gt, partial, IM2COL3, G * Bg, Hr, Hr, 32, 2 * Hr, 2 * Hr, 64, 1, 0, chunks)
+        finally:
+            self.precision = prev
+
     def nchw_to_nhwc(self, src, dst, B, C, HW):
         dst.reshape(-1).copy_(src.reshape(B, C, HW).permute(0, 2, 1).reshape(-1))
 

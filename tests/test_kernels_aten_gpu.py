@@ -326,3 +326,38 @@ def test_wgrad_reduce_vs_torch(chunks, taps, Cd, Cg, cgc, perm):
     assert rel(canon, want) < 1e-6
     ops.B.wgrad_reduce(part.to(DEV), canon, chunks, taps, Cd, Cg, cgc, perm, 1.0)
     assert rel(canon, 2 * want) < 1e-6
+
+
+@pytest.mark.parametrize("G,Bg,H,dtype", [(2, 3, 32, torch.float32), (1, 2, 64, torch.float32), (4, 5, 32, torch.bfloat16), (2, 1, 128, torch.float16)])
+def test_last_decoder_layer_with_fused_batchnorm_swish(G, Bg, H, dtype):
+    """mmdyn_tconv_out3_bn_fwd and mmdyn_wgrad_out3_bn: nn.BatchNorm2d(32) (train-mode statistics given) -> Swish ->
+    nn.ConvTranspose2d(32, 3, 4, 2, 1) (vae.py:275-277), forward and the transposed convolution's weight gradient, with the
+    activation applied on the operand fetch of both kernels -- against ATen on the same (possibly 16-bit) pre-BatchNorm tensor."""
+    from mmdyn_hip.engine import act_dtype
+    B = G * Bg
+    prec = {torch.float32: "fp32", torch.bfloat16: "bf16s", torch.float16: "fp16s"}[dtype]
+    y = (rnd(B, 32, H, H, seed=40) * 2 + 0.3).to(dtype)
+    mean, rstd = rnd(G, 32, seed=41) * 0.3, rnd(G, 32, seed=42).abs() + 0.5
+    gamma, beta = rnd(32, seed=43) + 1.2, rnd(32, seed=44)
+    W = rnd(32, 3, 4, 4, seed=45, scale=0.2)
+    yd = y.double()
+    xh = (yd.reshape(G, Bg, 32, H, H) - mean.double().reshape(G, 1, 32, 1, 1)) * rstd.double().reshape(G, 1, 32, 1, 1)
+    u = (xh * gamma.double().reshape(1, 1, 32, 1, 1) + beta.double().reshape(1, 1, 32, 1, 1)).reshape(B, 32, H, H)
+    a = u * torch.sigmoid(u)
+    Wd = W.double().requires_grad_(True)
+    ref = F.conv_transpose2d(a, Wd, stride=2, padding=1)
+    prev = ops.B.precision
+    ops.B.precision = prec
+    try:
+        out = torch.empty(B, 3, 2 * H, 2 * H, device=DEV)
+        rows = nhwc_rows(y).to(DEV)
+        ops.B.tconv_out3_bn_fwd(rows, mean.to(DEV), rstd.to(DEV), gamma.to(DEV), beta.to(DEV), W.to(DEV), out, G, Bg, H, H)
+        assert rel(out, ref) < 3e-6
+        dl = rnd(B, 3, 2 * H, 2 * H, seed=46)
+        (gW,) = torch.autograd.grad(ref, Wd, dl.double())
+        gW_hip = torch.zeros(32, 3, 4, 4, device=DEV)
+        bn = layers.BNState(gamma.to(DEV), beta.to(DEV))
+        layers.wgrad_out3_bn(rows, mean.to(DEV), rstd.to(DEV), bn, dl.to(DEV), gW_hip, G, Bg, H)
+        assert rel(gW_hip, gW) < 1e-5
+    finally:
+        ops.B.precision = prev
