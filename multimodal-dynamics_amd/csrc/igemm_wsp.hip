@@ -737,6 +737,13 @@ template <int MODE, int B16>
 static int wsp_launch_mode(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
                            const IgemmGeom& g, const WspPick& p, const WspSched& sc, unsigned a_bytes, unsigned b_bytes,
                            hipStream_t st) {
+#ifdef MMDYN_LAB
+  if constexpr (B16 == 0) {        // LAB experiment: a four-slot ring (three K-steps in flight, 140 KB of LDS)
+    const char* e = lab_env("MMDYN_WSP_S");
+    if (e && e[0] == '4' && p.bn == 128)
+      return wsp_launch<MODE, 128, 128, 64, 32, 4, B16>(A, Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
+  }
+#endif
   if (p.bn == 128) return wsp_launch<MODE, 128, 128, 64, 32, 3, B16>(A, Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
   if constexpr (MODE != MMDYN_TCONV_S1P0)
     return wsp_launch<MODE, 128, 64, 64, 32, 3, B16>(A, Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);

@@ -40,7 +40,9 @@ def event_ms(fn, reps):
     return s.elapsed_time(e) / reps
 
 
-TILE = sys.argv[1] if len(sys.argv) > 1 else ""
+TILE = sys.argv[1] if len(sys.argv) > 1 and "," in sys.argv[1] else ""
+if len(sys.argv) > 1 and sys.argv[1].startswith("S"):       # "S4": the persistent side with a four-slot ring (LAB experiment)
+    os.environ["MMDYN_WSP_S"] = sys.argv[1][1:]
 
 
 def main():
