@@ -495,7 +495,7 @@ def main():
         # observation, not as a roofline.
         fpb = 16.0 if args.dtype == "f32" else 32.0
         out["roofline"]["lds_fill_path"] = {
-            "tile": "64x64 (36 of the 40 implicit-GEMM launches of the fp32 step)", "flop_per_filled_byte": fpb,
+            "tile": "64x64 one-tile-per-block ring kernel (most implicit-GEMM launches of the step; the six largest run 128x128 persistent tiles at 32 flop per filled byte)", "flop_per_filled_byte": fpb,
             "observed_fill_rate_TBps": 7.3, "l2_hit_rate_of_fills": [0.87, 0.93],
             "avg_l1_to_l2_read_latency_cycles": [170, 250],
             "tflops_at_observed_fill_rate": fpb * 7.3, "achieved_over_that": achieved / (fpb * 7.3),

@@ -316,7 +316,14 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Mg = g.Bg * g.Hr * g.Wr;
-  const int u0 = blockIdx.x * sc.per, u1 = min(sc.units, u0 + sc.per);
+  // XCD-aware range order for the k4 s1 p0 layer (speed only): workgroups are dealt round-robin over the 8 XCDs, each with its
+  // own L2; block b takes range (b & 7) * (blocks / 8) + (b >> 3), so the 32 blocks of one XCD walk 32 CONSECUTIVE ranges = one
+  // (group, 128-sample tile), whose 3.2 MB of input then stay in that XCD's L2 instead of 25.6 MB passing through all eight:
+  // HBM-side fetch of the launch 868 -> 438 MB per pair (PMC), time unchanged.  The convolution launches keep the plain order
+  // (their ranges share nothing but the weights; the same remap measured 689 -> 930 MB there).
+  const int rb = (MODE == MMDYN_TCONV_S1P0 && (gridDim.x & 7) == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3))
+                                                                    : (int)blockIdx.x;
+  const int u0 = rb * sc.per, u1 = min(sc.units, u0 + sc.per);
   if (u0 >= u1) return;
   const int nsteps = u1 - u0;
   const int cin_steps = sc.cin_steps;
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
     } else {
       // a piece of a split tile: the accumulator fragments as they are, 16 bytes per lane (slot 0: the piece is this block's
       // first segment, slot 1: its last); igemm_wsp_fixup_kernel sums the pieces and runs the epilogue
-      float* sb = slabs + ((size_t)(blockIdx.x * 2 + (cu == u0 ? 0 : 1)) * NM + mw) * (MT * NT * 256);
+      float* sb = slabs + ((size_t)(rb * 2 + (cu == u0 ? 0 : 1)) * NM + mw) * (MT * NT * 256);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
