@@ -38,6 +38,7 @@ struct IgemmGeom {
   // Grouped launch (mmdyn_igemm_nt_grouped): every group multiplies its OWN weights -- group grp reads Bp + grp * b_group_stride
   // and bias + grp * bias_group_stride (elements; 0 = one weight matrix shared by all groups, the BatchNorm-group form)
   int b_group_stride, bias_group_stride;
+  int x3;          // fp32 launch on the bf16 matrix cores through the exact three-term operand split (igemm_nt.hip, X3)
   int tap_order;   // ring kernels, stride-2 CONV: the four taps of one input-pixel class back to back (0 = raster order)
 };
 

@@ -50,8 +50,24 @@ __device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {
 // F16 (with BF16, fp32 storage on both sides): the 16-bit operands are IEEE half (RNE) and the product runs on
 // v_mfma_f32_32x32x16_f16 -- BASELINE configs[4] "MFMA fp16 conv with fp32 accumulate"; everything else as in the bf16 mode.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// X3 (fp32 operands, fp32 results): the product runs on the bf16 matrix cores through an EXACT three-term split of every fp32
+// operand, x = hi + mid + lo with hi, mid, lo bf16 (8 + 8 + 8 significant bits; truncation, so the three have one sign), and six
+// of the nine cross products -- hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi; the dropped three are <= 2^-23 |a||b| together --
+// accumulated in fp32, smallest terms first.  v_mfma_f32_32x32x16_bf16 runs 16x the rate of the fp32 shapes, so the six products
+// cost 6/16 of the native matrix time; the split is VALU work on the store side (once per element per block) and the tiles take
+// three bf16 planes in LDS.  Error against fp64 on the same data: relative L2 4.9e-7, native fp32 MFMA 5.7e-7
+// (tests/microbench/x3_gemm.hip, profiles/r3/x3_split_gemm_microbench.txt; docs/LAB_NOTES.md D.g and F).
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+  hi = __builtin_amdgcn_perm(u1, u0, 0x07060302);                 // (u0 >> 16) | (u1 & 0xffff0000)
+  const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+  const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+  mid = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+  const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
+}
 template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16, bool B16, bool WIDE = false, bool M16 = false,
-          bool F16 = false, bool ONEPX = false>
+          bool F16 = false, bool ONEPX = false, bool X3 = false>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__ A,
                                                        const float* __restrict__ Bp,
                                                        const float* __restrict__ bias,
@@ -61,6 +77,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   static_assert(!M16 || !BF16, "the 16x16x4 shape is the fp32 variant");
   static_assert(!ONEPX || MODE == MMDYN_TCONV_S1P0, "one output pixel per block is a variant of the k4 s1 p0 walk");
   static_assert(!F16 || BF16, "fp16 operands are a 16-bit matrix-core variant");
+  static_assert(!X3 || (!BF16 && !M16 && MODE != MMDYN_IM2COL3), "the three-term split is a variant of the fp32 kernel");
   // (F16 with A16 / B16 / WIDE: the 16-bit STORAGE is IEEE half too -- precision "fp16s"; the raw granules go to LDS as they
   // are, exactly like the bf16 ones, and the epilogue reads / writes half)
   typedef typename std::conditional<F16, half_t, bf16_t>::type st16_t;
@@ -79,7 +96,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* As = reinterpret_cast<float*>(smem);            // [BM][LDS_LD] then [BN][LDS_LD]
   float* Bs = As + BM * LDS_LD;
-  int* rowinfo = reinterpret_cast<int*>(As + (BM + BN) * LDS_LD);  // [BM][4]: b, y0, x0, out offset (-1: none)
+  // [BM][4]: b, y0, x0, out offset (-1: none); behind the tiles (X3: three bf16 planes of 80-byte rows)
+  int* rowinfo = X3 ? reinterpret_cast<int*>(smem + (size_t)3 * (BM + BN) * (BK + 8) * 2) : reinterpret_cast<int*>(As + (BM + BN) * LDS_LD);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -205,8 +223,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   // bf16 matrix-core variants keep the tiles in LDS as bf16 ([row][40] halves: 32 + one 16-byte pad slot): half the
   // LDS bytes, one ds_read_b128 per operand and 16-deep MFMA, conversion once per element on the store side
   constexpr int LDH = KB + 8;
-  bf16_t* As16 = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Bs16 = As16 + BM * LDH;
+  bf16_t* As16 = reinterpret_cast<bf16_t*>(smem);            // (X3: [plane][BM][LDH], then [plane][BN][LDH])
+  bf16_t* Bs16 = As16 + (X3 ? 3 : 1) * BM * LDH;
   int tap = s_begin / cin_steps;            // running (tap, channel-step) position of the NEXT fetch
   int cstep = s_begin - tap * cin_steps;
   auto gload = [&](f32x4 (&ra)[A_LOADS], f32x4 (&rbv)[B_LOADS], unsigned& okmask) {
@@ -281,6 +299,30 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
     tap = last ? tap : ntap;
   };
   auto lds_store = [&](const f32x4 (&ra)[A_LOADS], const f32x4 (&rbv)[B_LOADS], const unsigned okmask) {
+    if constexpr (X3) {
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        const unsigned m = okmask >> (4 * i);
+        uint2 h, md, l;
+        split3((m & 1u) ? ra[i][0] : 0.f, (m & 2u) ? ra[i][1] : 0.f, h.x, md.x, l.x);
+        split3((m & 4u) ? ra[i][2] : 0.f, (m & 8u) ? ra[i][3] : 0.f, h.y, md.y, l.y);
+        const int o = (lrow + ROWS_PER_PASS * i) * LDH + gran * 4;
+        *reinterpret_cast<uint2*>(&As16[o]) = h;
+        *reinterpret_cast<uint2*>(&As16[BM * LDH + o]) = md;
+        *reinterpret_cast<uint2*>(&As16[2 * BM * LDH + o]) = l;
+      }
+#pragma unroll
+      for (int j = 0; j < B_LOADS; ++j) {
+        uint2 h, md, l;
+        split3(rbv[j][0], rbv[j][1], h.x, md.x, l.x);
+        split3(rbv[j][2], rbv[j][3], h.y, md.y, l.y);
+        const int o = (lrow + ROWS_PER_PASS * j) * LDH + gran * 4;
+        *reinterpret_cast<uint2*>(&Bs16[o]) = h;
+        *reinterpret_cast<uint2*>(&Bs16[BN * LDH + o]) = md;
+        *reinterpret_cast<uint2*>(&Bs16[2 * BN * LDH + o]) = l;
+      }
+      return;
+    }
     if constexpr (WIDE) {
       const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -365,7 +407,30 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
   auto mfma_step = [&]() {
       const float* Ac = As;
     const float* Bc = Bs;
-    if constexpr (BF16) {
+    if constexpr (X3) {
+      const int frag16 = (lane & 31) * LDH + (lane >> 5) * 8;      // lane (row i, half h): k = 16m + 8h .. +7
+#pragma unroll
+      for (int m = 0; m < BK / 16; ++m) {
+        bf16x8 pa[3][MT], pb[3][NT];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            pa[p][mt] = *reinterpret_cast<const bf16x8*>(&As16[(p * BM + wm * WM + mt * 32) * LDH + frag16 + m * 16]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            pb[p][nt] = *reinterpret_cast<const bf16x8*>(&Bs16[(p * BN + wn * WN + nt * 32) * LDH + frag16 + m * 16]);
+        }
+        constexpr int order[6][2] = {{0, 2}, {2, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 0}};      // (plane of A, plane of B)
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[order[t][0]][mt], pb[order[t][1]][nt], acc[mt][nt], 0, 0, 0);
+      }
+    } else if constexpr (BF16) {
       const int frag16 = (lane & 31) * LDH + (lane >> 5) * 8;      // lane (row i, half h): k = 16m + 8h .. +7
 #pragma unroll
       for (int m = 0; m < KB / 16; ++m) {
@@ -651,6 +716,16 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   const bool m16 = !bf16 && M16_TILE && !force_m32 && (force_m16 || (big_tile_m16 && nblocks >= 2048 && ksteps >= 8) ||
                                                        (BM == 128 && BN == 128 && lab_env("MMDYN_IGEMM_M16_128") != nullptr));
   size_t smem = (size_t)(BM + BN) * (m16 ? BK + 8 : LDS_LD32) * sizeof(float) + (size_t)BM * 4 * sizeof(int);
+  if constexpr (MODE != MMDYN_IM2COL3 && BM * BN >= 64 * 64 && BN >= 64) {
+    if (g.x3 && !bf16) {        // fp32 through the bf16 matrix cores (three-term split, see X3 at the kernel)
+      smem = (size_t)3 * (BM + BN) * (BK + 8) * 2 + (size_t)BM * 4 * sizeof(int);
+      static LdsOptIn optin;
+      auto k = igemm_nt_kernel<MODE, BM, BN, WM, WN, false, false, false, false, false, false, false, true>;
+      if (int rc = optin.ensure(reinterpret_cast<const void*>(k), smem)) return rc;
+      hipLaunchKernelGGL(k, grid, dim3(256), smem, st, A, Bp, bias, C, C_act, stats, ws, g);
+      MMDYN_LAUNCH_CHECK();
+    }
+  }
 #define IGEMM_LAUNCH(BF, A16_, B16_)                                                                                     \
   hipLaunchKernelGGL((igemm_nt_kernel<MODE, BM, BN, WM, WN, BF, A16_, B16_>), grid, dim3(256), smem, st, A, Bp, bias, C, \
                      C_act, stats, ws, g)
@@ -743,6 +818,48 @@ static bool ws_enabled() {
   return !(e && e[0] == '0');
 }
 
+// fp32 launches that take the three-term split (X3 at the kernel) and their block tile.  `allowed`: the caller asked for it (flag
+// bit 7 of the entry points: the "fp32x3" mode of the host side).  LAB: MMDYN_X3=1 / 0 overrides the flag, MMDYN_X3_TILE=BM,BN
+// forces one tile, MMDYN_X3_MIN_BLOCKS moves the size threshold.
+static bool x3_pick(bool allowed, int mode, int G, int rows_per_group, int N, int splitk, int* bm, int* bn) {
+  if (const char* on = lab_env("MMDYN_X3")) allowed = on[0] == '1';
+  if (!allowed) return false;
+  if (mode == MMDYN_IM2COL3 || splitk != 1 || N % 64) return false;
+  const int ncls = mode == MMDYN_TCONV_S2P1 ? 4 : 1;
+  // measured per shape alone on the chip (tests/microbench/ab_x3.py, profiles/r4/ab_x3_*.txt): 128x128 tiles (four waves of
+  // 64x64) where they give >= 384 blocks, the k4 s1 p0 layer and the other launches on 64x64 tiles from 512 blocks on
+  const long b128 = (long)G * ceil_div(rows_per_group, 128) * (N / 128) * ncls;
+  const long b64 = (long)G * ceil_div(rows_per_group, 64) * (N / 64) * ncls;
+  long min_blocks = 512;
+  if (const char* e = lab_env("MMDYN_X3_MIN_BLOCKS")) min_blocks = atol(e);
+  if (mode != MMDYN_TCONV_S1P0 && N % 128 == 0 && b128 >= 384) {
+    *bm = 128;
+    *bn = 128;
+  } else if (mode == MMDYN_TCONV_S2P1 && N == 64 && b64 >= 2 * min_blocks) {
+    *bm = 128;
+    *bn = 64;
+  } else if (b64 >= min_blocks) {
+    *bm = 64;
+    *bn = 64;
+  } else {
+    return false;
+  }
+  if (const char* e = lab_env("MMDYN_X3_TILE")) {
+    int a = 0, b = 0;
+    if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 64 || b == 128) && N % b == 0) {
+      *bm = a;
+      *bn = b;
+    }
+  }
+  return true;
+}
+static int x3_stat_tiles(bool allowed, int mode, int G, int Bg, int Hi, int Wi, int Ho, int Wo, int N) {
+  int bm, bn;
+  if (mode == MMDYN_TCONV_S1P0) return x3_pick(allowed, mode, G, Bg * Ho * Wo, N, 1, &bm, &bn) ? Ho * Wo * ceil_div(Bg, bm) : 0;
+  const int Hr = mode == MMDYN_TCONV_S2P1 ? Hi : Ho, Wr = mode == MMDYN_TCONV_S2P1 ? Wi : Wo, ncls = mode == MMDYN_TCONV_S2P1 ? 4 : 1;
+  return x3_pick(allowed, mode, G, Bg * Hr * Wr, N, 1, &bm, &bn) ? ncls * ceil_div(Bg * Hr * Wr, bm) : 0;
+}
+
 static int lds_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   if (mode == MMDYN_TCONV_S1P0) {
     int bm, bn;
@@ -764,23 +881,32 @@ static int lds_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int 
 
 // fp32 launches go to the wave-independent kernels of igemm_d16.hip where those serve the shape; the bf16 matrix-core
 // modes always take the LDS-tiled kernels of this file.  The number of partial-sum tiles follows the kernel.
-extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+static int f32_stat_tiles(bool x3, int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   const int tp = mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   if (tp > 0) return tp;
   int t = mmdyn_igemm_d16_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  if (t > 0) return t;
+  t = x3_stat_tiles(x3, mode, G, Bg, Hi, Wi, Ho, Wo, N);
   if (t > 0) return t;
   t = ws_enabled() ? mmdyn_igemm_wsp_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, false) : 0;
   if (t > 0) return t;
   t = ws_enabled() ? mmdyn_igemm_ws_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) : 0;
   return t > 0 ? t : lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
 }
+extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+  return f32_stat_tiles(false, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+}
 /* Floats of workspace the fp32 launch of this shape wants in `ws` (with splitk == 1): the slabs of the persistent kernel's
  * split tiles (igemm_wsp.hip).  0: none. */
-extern "C" int mmdyn_igemm_slab_floats(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+static int f32_slab_floats(bool x3, int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   if (!ws_enabled()) return 0;
   if (mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) > 0) return 0;
   if (mmdyn_igemm_d16_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) > 0) return 0;
+  if (x3_stat_tiles(x3, mode, G, Bg, Hi, Wi, Ho, Wo, N) > 0) return 0;
   return (int)(mmdyn_igemm_wsp_slab_bytes(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, false) / 4);
+}
+extern "C" int mmdyn_igemm_slab_floats(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+  return f32_slab_floats(false, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
 }
 extern "C" int mmdyn_igemm_stat_tiles_bf16(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   return lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
@@ -788,7 +914,7 @@ extern "C" int mmdyn_igemm_stat_tiles_bf16(int mode, int G, int Bg, int Hi, int 
 /* ... of the mixed-storage entry points, flags as mmdyn_igemm_nt_mx: launches whose operands are BOTH 16-bit in HBM (bits 1 and
  * 4) may run the persistent ring kernel (igemm_wsp.hip), which writes one partial tile per wave row */
 extern "C" int mmdyn_igemm_stat_tiles_mx(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int flags) {
-  if (!(flags & 1) && !(flags & 32)) return mmdyn_igemm_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  if (!(flags & 1) && !(flags & 32)) return f32_stat_tiles((flags & 128) != 0, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   if ((flags & 2) && (flags & 16) && ws_enabled()) {
     const int t = mmdyn_igemm_wsp_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, true);
     if (t > 0) return t;
@@ -796,7 +922,7 @@ extern "C" int mmdyn_igemm_stat_tiles_mx(int mode, int G, int Bg, int Hi, int Wi
   return lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
 }
 extern "C" int mmdyn_igemm_slab_floats_mx(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int flags) {
-  if (!(flags & 1) && !(flags & 32)) return mmdyn_igemm_slab_floats(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  if (!(flags & 1) && !(flags & 32)) return f32_slab_floats((flags & 128) != 0, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   if (!((flags & 2) && (flags & 16)) || !ws_enabled()) return 0;
   return (int)(mmdyn_igemm_wsp_slab_bytes(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, true) / 4);
 }
@@ -836,6 +962,9 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
     if (stats || C_act || bias || splitk > 1 || mode == MMDYN_IM2COL3 || ldc != N) return MMDYN_ERR_SHAPE;
     g.act = MMDYN_ACT_NONE;
   }
+  const bool x3_allowed = (storage_flags & 128) != 0;      // fp32 launch that may take the three-term split
+  storage_flags &= ~128;
+  if (x3_allowed && (bf16 || storage_flags)) return MMDYN_ERR_SHAPE;
   g.a_b16 = (storage_flags & 2) != 0;
   g.c_b16 = (storage_flags & 4) != 0;
   g.bny_b16 = (storage_flags & 8) != 0;
@@ -910,6 +1039,16 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
     const int rc = mmdyn_igemm_d16_try(A, Bp, bias, C, C_act, stats, ws, g, stride, offset, st);
     if (rc != 1) return rc;
   }
+  if (!bf16) {        // fp32 through the bf16 matrix cores (three-term operand split)
+    int bm, bn;
+    if (x3_pick(x3_allowed, mode, G, mode == MMDYN_TCONV_S1P0 ? Bg * Ho * Wo : Bg * g.Hr * g.Wr, N, splitk, &bm, &bn)) {
+      g.x3 = 1;
+      if (bn == 128 && bm == 128) return mmdyn_igemm_tile0(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+      if (bn == 128 && bm == 64) return mmdyn_igemm_tile1(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+      if (bn == 64 && bm == 128) return mmdyn_igemm_tile2(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+      return mmdyn_igemm_tile3(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+    }
+  }
   if (ws_enabled() && mode != MMDYN_IM2COL3 && (!bf16 || (g.a_b16 && g.b_b16))) {   // persistent ring kernel (igemm_wsp.hip)
     const int rc = mmdyn_igemm_wsp_try(A, Bp, bias, C, C_act, stats, ws, g, bf16, st);
     if (rc != 1) return rc;
@@ -944,9 +1083,10 @@ extern "C" int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C
                                        int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
                                        int stride, int offset, int bf16, float* ws, void* stream) {
   if (!stats || !y || !mean || !rstd || !gamma || !beta) return MMDYN_ERR_NULL;
-  if (bf16 < 0 || bf16 > 2) return MMDYN_ERR_SHAPE;
+  if (bf16 < 0 || bf16 > 3) return MMDYN_ERR_SHAPE;        // (3: fp32 arithmetic, the three-term split allowed)
   return igemm_entry(A, Bp, nullptr, C, nullptr, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset,
-                     MMDYN_ACT_NONE, 1, stream, bf16 != 0, y, mean, rstd, gamma, beta, bf16 == 2 ? 32 : 0);
+                     MMDYN_ACT_NONE, 1, stream, bf16 == 1 || bf16 == 2, y, mean, rstd, gamma, beta,
+                     bf16 == 2 ? 32 : bf16 == 3 ? 128 : 0);
 }
 
 /* Input-gradient GEMM with the backward of a plain ACTIVATION in its epilogue: C = (A x Bp) * act'(u), u the layer's saved

@@ -16,6 +16,7 @@ struct WgradGeom {
   // and Gt (group g = rows [g*rows, (g+1)*rows)); each is cut into `chunks` slabs and the slabs are laid out
   // [slab][group][Cd][Cg], so that ONE mmdyn_wgrad_reduce over Cd' = groups*Cd sums them all.  0 / 1 = a plain launch.
   int groups;
+  int x3;      // fp32 launch on the bf16 matrix cores through the exact three-term operand split (wgrad_tn_kernel X3)
 };
 
 // wgrad_ws.hip (LAB build only: measured no faster than wgrad_tn.hip, see wgrad_entry): fp32 weight-gradient GEMM with loader

@@ -49,10 +49,25 @@ __device__ __forceinline__ s16x4 pack4_bf16(float a, float b, float c, float d) 
 // sat in its own branch, and because the two sides of the branch write the same registers the compiler put
 // s_waitcnt vmcnt(0) in front of every one of them -- five serial memory round trips per K-step instead of one
 // (found in the ISA; the comment "branch-free fetch" below was only true of the source).
-template <int MODE, int BD, int BG, int WD, int WG, int WK, bool BF16, int ST>
+// X3 (fp32 operands in HBM, ST = 0): the product runs on the bf16 matrix cores through the exact three-term split of every fp32
+// operand (x = hi + mid + lo, all bf16; six of the nine cross products, fp32 accumulate -- see X3 at igemm_nt_kernel).  The split
+// is done once per element as the tile is written to LDS (three bf16 planes per operand); the k-strided fragments (the reduction
+// index is the tile ROW) come from the transposing read ds_read_b64_tr_b16, as in wgrad_b16_kernel below.
+template <int BX> struct x3_ld { static constexpr int v = (BX == 32) ? 32 : BX + 32; };   // plane row stride in elements
+__device__ __forceinline__ void wsplit3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+  hi = __builtin_amdgcn_perm(u1, u0, 0x07060302);                 // (u0 >> 16) | (u1 & 0xffff0000)
+  const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+  const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+  mid = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+  const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
+}
+template <int MODE, int BD, int BG, int WD, int WG, int WK, bool BF16, int ST, bool X3 = false>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__ D,
                                                        const float* __restrict__ Gt,
                                                        float* __restrict__ partial, const WgradGeom g) {
+  static_assert(!X3 || (!BF16 && ST == 0 && WK == 1 && MODE != MMDYN_IM2COL3), "the three-term split is a variant of the fp32 kernel");
   constexpr int DT = WD / 32, GT = WG / 32;
   constexpr int WAVES_G = BG / WG;
   constexpr int WAVES_DG = (BD / WD) * WAVES_G;
@@ -65,6 +80,9 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Ds = reinterpret_cast<float*>(smem);  // [RK][BD]
   float* Gs = Ds + RK * BD;                    // [RK][BG]
+  constexpr int LDD = x3_ld<BD>::v, LDG = x3_ld<BG>::v;
+  bf16_t* Ds16 = reinterpret_cast<bf16_t*>(smem);     // X3: [plane][RK][LDD], then [plane][RK][LDG]
+  bf16_t* Gs16 = Ds16 + 3 * RK * LDD;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / WAVES_DG, wdg = wave % WAVES_DG;
@@ -156,6 +174,35 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
   };
   auto lds_store = [&]() {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (X3) {
+#pragma unroll
+      for (int i = 0; i < D_LOADS; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx / DV, v = idx - r * DV;
+        const f32x4 x = ((okd >> i) & 1u) ? rd[i] : zero;
+        uint2 hh, mm, ll;
+        wsplit3(x[0], x[1], hh.x, mm.x, ll.x);
+        wsplit3(x[2], x[3], hh.y, mm.y, ll.y);
+        const int o = r * LDD + v * 4;
+        *reinterpret_cast<uint2*>(&Ds16[o]) = hh;
+        *reinterpret_cast<uint2*>(&Ds16[RK * LDD + o]) = mm;
+        *reinterpret_cast<uint2*>(&Ds16[2 * RK * LDD + o]) = ll;
+      }
+#pragma unroll
+      for (int i = 0; i < G_LOADS; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx / GV, v = idx - r * GV;
+        const f32x4 x = ((okg >> (4 * i)) & 1u) ? rg[i] : zero;        // (all four mask bits are equal outside IM2COL3)
+        uint2 hh, mm, ll;
+        wsplit3(x[0], x[1], hh.x, mm.x, ll.x);
+        wsplit3(x[2], x[3], hh.y, mm.y, ll.y);
+        const int o = r * LDG + v * 4;
+        *reinterpret_cast<uint2*>(&Gs16[o]) = hh;
+        *reinterpret_cast<uint2*>(&Gs16[RK * LDG + o]) = mm;
+        *reinterpret_cast<uint2*>(&Gs16[2 * RK * LDG + o]) = ll;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < D_LOADS; ++i)
       reinterpret_cast<f32x4*>(Ds)[tid + 256 * i] = ((okd >> i) & 1u) ? rd[i] : zero;
@@ -187,7 +234,40 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
     for (int r0 = row_begin; r0 < row_end; r0 += RK) {
       gload(r0 + RK);                      // past the chunk end every row is masked: a harmless dummy fetch
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (BF16) {
+      if constexpr (X3) {
+        // transposed-read lane roles as in wgrad_b16_kernel: group gq = lane>>4 (columns 16*(gq&1).., k half gq>>1), lane 4q+p of
+        // the group supplies the address of row q, columns 4p..4p+3 of its block
+        const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+        const int trow = 8 * (gq >> 1) + tq, tcol = 16 * (gq & 1) + 4 * tp;
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+        typedef __bf16 xb16x8 __attribute__((ext_vector_type(8)));
+        auto frag = [&](const bf16_t* tile, int ld, int col0, int k0) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(&tile[(k0 + trow) * ld + col0 + tcol]));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(&tile[(k0 + trow + 4) * ld + col0 + tcol]));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          return __builtin_bit_cast(xb16x8, v);
+        };
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {          // 16 rows per MFMA
+          xb16x8 pa[3][DT], pb[3][GT];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int a = 0; a < DT; ++a) pa[p][a] = frag(Ds16 + p * RK * LDD, LDD, wd * WD + a * 32, kc * 16);
+#pragma unroll
+            for (int b = 0; b < GT; ++b) pb[p][b] = frag(Gs16 + p * RK * LDG, LDG, wg * WG + b * 32, kc * 16);
+          }
+          constexpr int order[6][2] = {{0, 2}, {2, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 0}};      // smallest terms first
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int a = 0; a < DT; ++a)
+#pragma unroll
+              for (int b = 0; b < GT; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[order[t][0]][a], pb[order[t][1]][b], acc[a][b], 0, 0, 0);
+        }
+      } else if constexpr (BF16) {
 #pragma unroll
         for (int r8 = wk * 2 * KPW; r8 < (wk + 1) * 2 * KPW; r8 += 8) {     // 8 rows per bf16 MFMA: lane half h -> 4 rows
           if constexpr (ST >= 4) {
@@ -889,6 +969,16 @@ static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, 
   g.rows_per_chunk = ceil_div(rpc, RK) * RK;
   dim3 grid((g.Cd / BD) * (g.Cg / BG), g.ntaps, zblocks * (g.groups > 1 ? g.groups : 1));
   size_t smem = (size_t)RK * (BD + BG) * sizeof(float);
+  if constexpr (WK == 1) {
+    if (g.x3 && !bf16 && g.mode != MMDYN_IM2COL3) {       // fp32 through the bf16 matrix cores (three-term split)
+      smem = (size_t)3 * RK * (x3_ld<BD>::v + x3_ld<BG>::v) * 2;
+      if (g.mode == MMDYN_CONV)
+        hipLaunchKernelGGL((wgrad_tn_kernel<MMDYN_CONV, BD, BG, WD, WG, WK, false, 0, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
+      else
+        hipLaunchKernelGGL((wgrad_tn_kernel<MMDYN_DENSE, BD, BG, WD, WG, WK, false, 0, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
+      MMDYN_LAUNCH_CHECK();
+    }
+  }
 #define WGRAD_LAUNCH(M, BF, ST_)                                                                                      \
   hipLaunchKernelGGL((wgrad_tn_kernel<M, BD, BG, WD, WG, WK, BF, ST_>), grid, dim3(256), smem, st, D, Gt, partial, g)
 #define WGRAD_MODE(M)                                                  \
@@ -929,6 +1019,11 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
   if (mode != MMDYN_DENSE && mode != MMDYN_CONV && mode != MMDYN_IM2COL3) return MMDYN_ERR_SHAPE;
   if (mode == MMDYN_IM2COL3 && (Cg != 64 || Hi != 2 * Hr || Wi != 2 * Wr)) return MMDYN_ERR_SHAPE;
   WgradGeom g{};
+  bool x3 = (storage_flags & 128) != 0;        // fp32 launch that may take the three-term split ("fp32x3" on the host side)
+  storage_flags &= ~128;
+  if (x3 && (bf16 || storage_flags)) return MMDYN_ERR_SHAPE;
+  if (const char* e = lab_env("MMDYN_X3_WGRAD")) x3 = e[0] == '1';      // (LAB: override)
+  g.x3 = x3 && !bf16;
   g.d_b16 = (storage_flags & 2) != 0;
   g.g_b16 = (storage_flags & 4) != 0;
   g.f16 = (storage_flags & 32) != 0;
