@@ -253,7 +253,7 @@ def main():
                     help="dyn_modeling (configs[3]): the batch is --seq-length frames per sequence, targets are the next frames "
                          "(DynModeling.parse_input, problems.py:765-803); the step itself is the same computation")
     ap.add_argument("--seq-length", type=int, default=4)
-    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16s", "fp16", "fp16s"), default="f32",
+    ap.add_argument("--dtype", choices=("f32", "f32x3", "bf16", "bf16s", "fp16", "fp16s"), default="f32",
                     help="f32: the BASELINE configs[1] line (default).  bf16s: bf16 activation storage + bf16 matrix "
                          "cores, fp32 accumulate / master weights = the per-GPU share of configs[2] (use --batch 128).  "
                          "bf16: bf16 matrix-core operands only (fp32 storage).  fp16: fp16 matrix-core operands, fp32 "
@@ -326,7 +326,7 @@ def main():
 
     torch.manual_seed(0)
     S = args.image_size
-    PREC = {"f32": "fp32", "bf16": "bf16", "bf16s": "bf16s", "fp16": "fp16", "fp16s": "fp16s"}[args.dtype]
+    PREC = {"f32": "fp32", "f32x3": "fp32x3", "bf16": "bf16", "bf16s": "bf16s", "fp16": "fp16", "fp16s": "fp16s"}[args.dtype]
     assert abs(algo_gflop_per_sample(64) - ALGO_GFLOP_PER_SAMPLE) < 1e-3
     gflop_per_sample = algo_gflop_per_sample(S)
     model = setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=S * S, architecture="cnn",
@@ -423,9 +423,15 @@ def main():
     # (the implicit-GEMM entry points are served by igemm_ws_kernel -- the LDS-DMA ring, 36 of the 40 launches of the fp32
     #  bs-256 step -- and by igemm_nt_kernel, the register-staged form, for the rest)
     dom_name = "igemm_ws_kernel" if dom is ig else "wgrad_tn_kernel"
+    if args.dtype == "f32x3" and dom is ig:
+        dom_name = "igemm_nt_kernel (X3 instances)"
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     total_ms = sum(d["ms"] for d in kern.values())
     peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else (PEAK_F16_MFMA_TFLOPS if args.dtype in ("fp16", "fp16s") else PEAK_BF16_MFMA_TFLOPS)
+    if args.dtype == "f32x3":
+        # fp32 products as SIX bf16 products of the exact three-term operand split: an algorithmic (fp32) flop costs six flops of
+        # the bf16 matrix pipe, so the ceiling for algorithmic flops is the dense bf16 peak / 6 (2.65 x the native fp32 peak)
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
     # byte side: the committed PMC passes of THIS workload (whole step + the implicit-GEMM launches)
     wkey = f"s{S}_{args.dtype}_b{args.batch}_{args.problem}"
     prof, traffic_note = pmc_traffic(wkey)
@@ -445,12 +451,14 @@ def main():
         if max(mfma, hbm) < 0.2:
             return "launch"
         return "hbm" if hbm > mfma else "mfma"
-    arith = {"f32": "fp32", "bf16": "bf16 matrix-core operands (fp32 accumulate, storage and master weights)",
+    arith = {"f32": "fp32", "f32x3": "fp32 storage and results; GEMMs on the bf16 matrix cores through the exact three-term split of "
+                                     "their fp32 operands (six products, fp32 accumulate; error vs fp64 <= native fp32 MFMA)",
+             "bf16": "bf16 matrix-core operands (fp32 accumulate, storage and master weights)",
              "bf16s": "bf16 activation storage + bf16 matrix-core operands (fp32 accumulate and master weights)",
              "fp16": "fp16 matrix-core operands (fp32 accumulate, storage and master weights)",
              "fp16s": "fp16 activation storage + fp16 matrix-core operands (fp32 accumulate and master weights, loss scale 4B)"
              }[args.dtype]
-    which = ("BASELINE configs[1]" if (S == 64 and args.dtype == "f32" and args.problem == "seq_modeling") else
+    which = ("BASELINE configs[1]" if (S == 64 and args.dtype in ("f32", "f32x3") and args.problem == "seq_modeling") else
              "per-GPU share of BASELINE configs[2]" if (S == 64 and args.dtype in ("bf16", "bf16s")) else
              "per-GPU share of BASELINE configs[3] (extension: no reference architecture at this size)" if S == 128 else
              "per-GPU share of BASELINE configs[4] (extension: no reference architecture at this size)" if S == 256 else
@@ -484,6 +492,10 @@ def main():
                      "step_launches": prof["whole_step"]["launches"] if prof else None,
                      "step_bound": bound_of(step_mfma_frac, step_hbm_frac)},
     }
+    if args.dtype == "f32x3":
+        out["roofline"]["peak_note"] = ("dense bf16 MFMA peak / 6: every fp32 product is six bf16 products of the three-term split; "
+                                        "launches the split does not serve run on the fp32 matrix cores (peak %.1f)" % PEAK_FP32_MFMA_TFLOPS)
+        out["roofline"]["frac_of_native_fp32_mfma_peak"] = achieved / PEAK_FP32_MFMA_TFLOPS
     if dom is ig and args.dtype in ("f32", "bf16s", "fp16s"):
         # What the ring kernels' operand path was measured to do (round 4, cache counters per launch shape:
         # profiles/r4/cache_by_launch_f32.txt; LAB_NOTES E).  Round 3 called 7.5 TB/s "the Infinity-Cache LDS-fill rate" and

@@ -32,6 +32,21 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
   r[1] = (__bf16)hi;
   return __builtin_bit_cast(uint32_t, r);
 }
+// Exact three-term split of two fp32 values into bf16 terms (the X3 variants of igemm_nt_kernel / wgrad_tn_kernel):
+// hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid, every conversion round-to-nearest-even (v_cvt_pk_bf16_f32).  Both
+// subtractions are exact in fp32 (hi is within half a bf16 ulp of x; the second residual has at most 8 significant bits), so
+// hi + mid + lo == x bit for bit, with |mid| <= 2^-8 |x| and |lo| <= 2^-16 |x|.  Of the nine cross products of two split
+// operands the kernels keep six (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi); the dropped three are together below
+// 2^-23 |a||b| (measured on random data: max 2^-24.2, rms 2^-27.4, zero mean -- less than ONE fp32 rounding of the product,
+// tests/test_model_emu.py::test_three_term_split_*).  Each result packs the pair (x0 low half, x1 high half).
+// Non-finite inputs: inf - inf = NaN in the residuals, so an Inf operand yields NaN where the fp32 matrix cores would give Inf.
+__device__ __forceinline__ void split3_bf16(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  hi = pack2_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  mid = pack2_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+  lo = pack2_bf16(s0, s1);
+}
 // Second 16-bit storage type: IEEE half (the fp16-storage mode, BASELINE configs[4]).  A distinct C++ type so that the
 // kernels templated on the storage type get their own instances; same size and alignment as bf16_t.
 struct half_t { uint16_t v; };

@@ -50,22 +50,13 @@ __device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {
 // F16 (with BF16, fp32 storage on both sides): the 16-bit operands are IEEE half (RNE) and the product runs on
 // v_mfma_f32_32x32x16_f16 -- BASELINE configs[4] "MFMA fp16 conv with fp32 accumulate"; everything else as in the bf16 mode.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// X3 (fp32 operands, fp32 results): the product runs on the bf16 matrix cores through an EXACT three-term split of every fp32
-// operand, x = hi + mid + lo with hi, mid, lo bf16 (8 + 8 + 8 significant bits; truncation, so the three have one sign), and six
-// of the nine cross products -- hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi; the dropped three are <= 2^-23 |a||b| together --
+// X3 (fp32 operands, fp32 results): the product runs on the bf16 matrix cores through the EXACT three-term split of every fp32
+// operand, x = hi + mid + lo with hi, mid, lo bf16 (split3_bf16, common.h), and six of the nine cross products -- hi.hi, hi.mid,
+// mid.hi, mid.mid, hi.lo, lo.hi; the dropped three are together below 2^-23 |a||b|, less than one fp32 rounding of the product --
 // accumulated in fp32, smallest terms first.  v_mfma_f32_32x32x16_bf16 runs 16x the rate of the fp32 shapes, so the six products
 // cost 6/16 of the native matrix time; the split is VALU work on the store side (once per element per block) and the tiles take
-// three bf16 planes in LDS.  Error against fp64 on the same data: relative L2 4.9e-7, native fp32 MFMA 5.7e-7
-// (tests/microbench/x3_gemm.hip, profiles/r3/x3_split_gemm_microbench.txt; docs/LAB_NOTES.md D.g and F).
-__device__ __forceinline__ void split3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-  const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-  hi = __builtin_amdgcn_perm(u1, u0, 0x07060302);                 // (u0 >> 16) | (u1 & 0xffff0000)
-  const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
-  const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-  mid = __builtin_amdgcn_perm(v1, v0, 0x07060302);
-  const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-  lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
-}
+// three bf16 planes in LDS.  Error against fp64 on the same data: relative L2 4.7e-7, native fp32 MFMA 5.4e-7
+// (tests/microbench/ab_x3.py, profiles/r4/ab_x3_*.txt; docs/LAB_NOTES.md D.g and F).
 template <int MODE, int BM, int BN, int WM, int WN, bool BF16, bool A16, bool B16, bool WIDE = false, bool M16 = false,
           bool F16 = false, bool ONEPX = false, bool X3 = false>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__ A,
@@ -304,8 +295,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
       for (int i = 0; i < A_LOADS; ++i) {
         const unsigned m = okmask >> (4 * i);
         uint2 h, md, l;
-        split3((m & 1u) ? ra[i][0] : 0.f, (m & 2u) ? ra[i][1] : 0.f, h.x, md.x, l.x);
-        split3((m & 4u) ? ra[i][2] : 0.f, (m & 8u) ? ra[i][3] : 0.f, h.y, md.y, l.y);
+        split3_bf16((m & 1u) ? ra[i][0] : 0.f, (m & 2u) ? ra[i][1] : 0.f, h.x, md.x, l.x);
+        split3_bf16((m & 4u) ? ra[i][2] : 0.f, (m & 8u) ? ra[i][3] : 0.f, h.y, md.y, l.y);
         const int o = (lrow + ROWS_PER_PASS * i) * LDH + gran * 4;
         *reinterpret_cast<uint2*>(&As16[o]) = h;
         *reinterpret_cast<uint2*>(&As16[BM * LDH + o]) = md;
@@ -314,8 +305,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < B_LOADS; ++j) {
         uint2 h, md, l;
-        split3(rbv[j][0], rbv[j][1], h.x, md.x, l.x);
-        split3(rbv[j][2], rbv[j][3], h.y, md.y, l.y);
+        split3_bf16(rbv[j][0], rbv[j][1], h.x, md.x, l.x);
+        split3_bf16(rbv[j][2], rbv[j][3], h.y, md.y, l.y);
         const int o = (lrow + ROWS_PER_PASS * j) * LDH + gran * 4;
         *reinterpret_cast<uint2*>(&Bs16[o]) = h;
         *reinterpret_cast<uint2*>(&Bs16[BN * LDH + o]) = md;
@@ -825,6 +816,15 @@ static bool x3_pick(bool allowed, int mode, int G, int rows_per_group, int N, in
   if (const char* on = lab_env("MMDYN_X3")) allowed = on[0] == '1';
   if (!allowed) return false;
   if (mode == MMDYN_IM2COL3 || splitk != 1 || N % 64) return false;
+  if (const char* e = lab_env("MMDYN_X3_MODES")) {        // (LAB: bit m set = launches of mode m may take the split)
+    if (!((atoi(e) >> mode) & 1)) return false;
+  }
+  if (const char* e = lab_env("MMDYN_X3_ONLY_G")) {       // (LAB bisecting knobs: only launches with this G / this N)
+    if (atoi(e) != G) return false;
+  }
+  if (const char* e = lab_env("MMDYN_X3_ONLY_N")) {
+    if (atoi(e) != N) return false;
+  }
   const int ncls = mode == MMDYN_TCONV_S2P1 ? 4 : 1;
   // measured per shape alone on the chip (tests/microbench/ab_x3.py, profiles/r4/ab_x3_*.txt): 128x128 tiles (four waves of
   // 64x64) where they give >= 384 blocks, the k4 s1 p0 layer and the other launches on 64x64 tiles from 512 blocks on

@@ -50,19 +50,11 @@ __device__ __forceinline__ s16x4 pack4_bf16(float a, float b, float c, float d) 
 // s_waitcnt vmcnt(0) in front of every one of them -- five serial memory round trips per K-step instead of one
 // (found in the ISA; the comment "branch-free fetch" below was only true of the source).
 // X3 (fp32 operands in HBM, ST = 0): the product runs on the bf16 matrix cores through the exact three-term split of every fp32
-// operand (x = hi + mid + lo, all bf16; six of the nine cross products, fp32 accumulate -- see X3 at igemm_nt_kernel).  The split
+// operand (x = hi + mid + lo, all bf16: split3_bf16 in common.h; six of the nine cross products, fp32 accumulate -- see X3 at
+// igemm_nt_kernel).  The split
 // is done once per element as the tile is written to LDS (three bf16 planes per operand); the k-strided fragments (the reduction
 // index is the tile ROW) come from the transposing read ds_read_b64_tr_b16, as in wgrad_b16_kernel below.
 template <int BX> struct x3_ld { static constexpr int v = (BX == 32) ? 32 : BX + 32; };   // plane row stride in elements
-__device__ __forceinline__ void wsplit3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-  const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-  hi = __builtin_amdgcn_perm(u1, u0, 0x07060302);                 // (u0 >> 16) | (u1 & 0xffff0000)
-  const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
-  const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-  mid = __builtin_amdgcn_perm(v1, v0, 0x07060302);
-  const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-  lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
-}
 template <int MODE, int BD, int BG, int WD, int WG, int WK, bool BF16, int ST, bool X3 = false>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__ D,
                                                        const float* __restrict__ Gt,
@@ -181,8 +173,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
         const int r = idx / DV, v = idx - r * DV;
         const f32x4 x = ((okd >> i) & 1u) ? rd[i] : zero;
         uint2 hh, mm, ll;
-        wsplit3(x[0], x[1], hh.x, mm.x, ll.x);
-        wsplit3(x[2], x[3], hh.y, mm.y, ll.y);
+        split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
+        split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
         const int o = r * LDD + v * 4;
         *reinterpret_cast<uint2*>(&Ds16[o]) = hh;
         *reinterpret_cast<uint2*>(&Ds16[RK * LDD + o]) = mm;
@@ -194,8 +186,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
         const int r = idx / GV, v = idx - r * GV;
         const f32x4 x = ((okg >> (4 * i)) & 1u) ? rg[i] : zero;        // (all four mask bits are equal outside IM2COL3)
         uint2 hh, mm, ll;
-        wsplit3(x[0], x[1], hh.x, mm.x, ll.x);
-        wsplit3(x[2], x[3], hh.y, mm.y, ll.y);
+        split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
+        split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
         const int o = r * LDG + v * 4;
         *reinterpret_cast<uint2*>(&Gs16[o]) = hh;
         *reinterpret_cast<uint2*>(&Gs16[RK * LDG + o]) = mm;

@@ -25,7 +25,22 @@ from .models.shapes import DROPOUT_P
 
 SUBSETS_POSE = [(1, 1, 0), (1, 0, 0), (0, 1, 0), (1, 1, 1), (1, 0, 1), (0, 1, 1), (0, 0, 1)]
 SUBSETS_NOPOSE = SUBSETS_POSE[:3]
-PRECISIONS = ("fp32", "bf16", "bf16s", "fp16", "fp16s")
+# "fp32x3": fp32 storage and fp32 results like "fp32"; the GEMM launches that gain from it run on the bf16 matrix cores through the
+# exact three-term split of their fp32 operands (ops.HipBackend.fp32_split, csrc/igemm_nt.hip X3) -- error against fp64 no larger
+# than the native fp32 matrix cores', six bf16 MFMAs per product at 16x the fp32 rate
+PRECISIONS = ("fp32", "fp32x3", "bf16", "bf16s", "fp16", "fp16s")
+
+
+def _select_precision(precision):
+    """Select an engine precision on the active backend; returns the previous (precision, fp32_split) pair."""
+    prev = (getattr(ops.B, "precision", "fp32"), getattr(ops.B, "fp32_split", False))
+    ops.B.precision = "fp32" if precision == "fp32x3" else precision
+    ops.B.fp32_split = precision == "fp32x3"
+    return prev
+
+
+def _restore_precision(prev):
+    ops.B.precision, ops.B.fp32_split = prev
 
 
 def act_dtype(precision):
@@ -195,15 +210,15 @@ def _with_precision(fn):
 
     @functools.wraps(fn)
     def wrapped(self, *a, **k):
-        prev, prev_sync, prev_act, prev_w = getattr(ops.B, "precision", "fp32"), layers.SYNC, layers.ACT_DTYPE, layers.W_DTYPE
-        ops.B.precision = self.precision
+        prev_sync, prev_act, prev_w = layers.SYNC, layers.ACT_DTYPE, layers.W_DTYPE
+        prev = _select_precision(self.precision)
         layers.SYNC = self._sync
         layers.ACT_DTYPE = act_dtype(self.precision)
         layers.W_DTYPE = w_dtype(self.precision)
         try:
             return fn(self, *a, **k)
         finally:
-            ops.B.precision = prev
+            _restore_precision(prev)
             layers.SYNC = prev_sync
             layers.ACT_DTYPE = prev_act
             layers.W_DTYPE = prev_w
@@ -243,7 +258,7 @@ class MVAEStep:
         # fp32 bs 256 +0.3 .. 0.9 % over three boxes, 128x128 fp32 7.0 -> 6.85 ms (+2 %), 256x256 fp32 +0.5 .. 5 %; the 16-bit
         # storage modes 0 .. -2 %) -- on in fp32 on one GPU.
         # Data parallel: off, the decoders' gradient bucket would start its all-reduce a phase later.
-        self.defer_wgrad = (precision == "fp32" and process_group is None) if defer_wgrad is None else bool(defer_wgrad)
+        self.defer_wgrad = (precision in ("fp32", "fp32x3") and process_group is None) if defer_wgrad is None else bool(defer_wgrad)
         self.loss_scale = 1.0
         # False (default): each image decoder runs only on the passes whose reconstruction enters the loss, so its
         # BatchNorm running buffers see 4 EMA updates per step (2 without pose) where the reference applies 7 (3).
@@ -1087,8 +1102,8 @@ class MVAEInference:
 
     # ---- graph capture / replay ---------------------------------------------------------------------------
     def _run(self, key, fn, static_inputs, new_inputs):
-        prev, prev_act, prev_w = getattr(ops.B, "precision", "fp32"), layers.ACT_DTYPE, layers.W_DTYPE
-        ops.B.precision = self.precision
+        prev_act, prev_w = layers.ACT_DTYPE, layers.W_DTYPE
+        prev = _select_precision(self.precision)
         layers.ACT_DTYPE = act_dtype(self.precision)
         layers.W_DTYPE = self._w_dtype
         try:
@@ -1113,7 +1128,7 @@ class MVAEInference:
             g.replay()
             return out
         finally:
-            ops.B.precision = prev
+            _restore_precision(prev)
             layers.ACT_DTYPE = prev_act
             layers.W_DTYPE = prev_w
 

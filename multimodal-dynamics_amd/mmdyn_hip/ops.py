@@ -80,6 +80,10 @@ class HipBackend:
         # "fp16": the same with IEEE-half operands (configs[4]); "bf16s": bf16 + bf16 activation storage;
         # "fp16s": fp16 + fp16 activation storage
         self.precision = "fp32"
+        # With precision "fp32": let the fp32 GEMM launches that gain from it run on the bf16 matrix cores through the EXACT
+        # three-term split of their fp32 operands (x = hi + mid + lo, six of nine products, fp32 accumulate: csrc/igemm_nt.hip
+        # X3; error against fp64 no larger than the native fp32 matrix cores').  The engines' precision "fp32x3" sets it.
+        self.fp32_split = False
 
     TICKET_SLOTS, TICKET_STRIDE = 4096, 16             # one 64-byte line per slot
 
@@ -117,6 +121,10 @@ class HipBackend:
         return self._l
 
     # ---- host-only helpers (no GPU needed) ----
+    def _x3(self):
+        """Flag bit 7 of the GEMM entry points: this fp32 launch may take the three-term split."""
+        return 128 if (self.fp32_split and self.precision == "fp32") else 0
+
     def _all16_flags(self):
         """Flags of a launch whose two operands are both 16-bit in HBM, in the current storage mode."""
         return 1 | 2 | 16 | (32 if self.precision == "fp16s" else 0)
@@ -125,6 +133,8 @@ class HipBackend:
         """T of the per-tile BatchNorm partial sums the implicit GEMM of the current precision mode writes.  ``all16``: both
         operands of the launch are 16-bit in HBM (the convolution-level launches of the "bf16s" / "fp16s" modes)."""
         if self.precision == "fp32":
+            if self._x3():
+                return self.lib.mmdyn_igemm_stat_tiles_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, 128)
             return self.lib.mmdyn_igemm_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
         if all16 and self.precision in ("bf16s", "fp16s"):
             return self.lib.mmdyn_igemm_stat_tiles_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, self._all16_flags())
@@ -143,7 +153,9 @@ class HipBackend:
     # ---- GEMMs ----
     def _slabs(self, like, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=False):
         """Workspace for the pieces of the persistent ring kernel's split tiles (fp32 launches not split over K), or None."""
-        if self.precision == "fp32":
+        if self.precision == "fp32" and self._x3():
+            n = self.lib.mmdyn_igemm_slab_floats_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, 128)
+        elif self.precision == "fp32":
             n = self.lib.mmdyn_igemm_slab_floats(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
         elif all16 and self.precision in ("bf16s", "fp16s"):
             n = self.lib.mmdyn_igemm_slab_floats_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, self._all16_flags())
@@ -191,6 +203,11 @@ class HipBackend:
               "fp16s": self.lib.mmdyn_igemm_nt_f16}.get(self.precision, self.lib.mmdyn_igemm_nt_bf16)
         if ws is None and splitk == 1:
             ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+        if self._x3():
+            check(self.lib.mmdyn_igemm_nt_mx(pa, pb, _ptr(bias), pc, pca, _ptr(stats), _ptr(ws), None, None, None, None, None,
+                                             mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, 128,
+                                             _stream()), "mmdyn_igemm_nt_mx")
+            return
         check(fn(pa, _ptr(Bp), _ptr(bias), pc, pca, _ptr(stats), _ptr(ws),
                  mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, _stream()), "mmdyn_igemm_nt")
 
@@ -208,18 +225,18 @@ class HipBackend:
         ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
         check(self.lib.mmdyn_igemm_nt_dgrad_bn(pa, _ptr(Bp), pc, _ptr(stats), py, _ptr(mean), _ptr(rstd),
                                                _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride,
-                                               offset, {"fp32": 0, "fp16": 2, "fp16s": 2}.get(self.precision, 1), _ptr(ws),
+                                               offset, 3 if self._x3() else {"fp32": 0, "fp16": 2, "fp16s": 2}.get(self.precision, 1), _ptr(ws),
                                                _stream()),
               "mmdyn_igemm_nt_dgrad_bn")
 
     def igemm_nt_dgrad_act(self, A, Bp, C, u, act, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset):
         """C = (A x Bp) * act'(u): input-gradient GEMM with the activation backward in its epilogue."""
         (pa, a16), (pc, c16), (pu, u16), (pb, b16) = _aptr(A), _aptr(C), _aptr(u), _aptr(Bp)
-        flags = {"fp32": 0, "fp16": 32, "fp16s": 32}.get(self.precision, 1)
+        flags = {"fp32": self._x3(), "fp16": 32, "fp16s": 32}.get(self.precision, 1)
         if a16 or c16 or u16 or b16:
             flags = self._mx(a16, c16, u16, b16)
         flags |= (2 if a16 else 0) | (4 if c16 else 0) | (8 if u16 else 0) | (16 if b16 else 0)
-        ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=bool(a16 and b16)) if (flags == 0 or (a16 and b16)) else None
+        ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=bool(a16 and b16)) if (flags in (0, 128) or (a16 and b16)) else None
         check(self.lib.mmdyn_igemm_nt_dgrad_act(pa, pb, pc, pu, int(act), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset,
                                                 flags, _ptr(ws), _stream()), "mmdyn_igemm_nt_dgrad_act")
 
@@ -227,7 +244,7 @@ class HipBackend:
         """G dense GEMMs of one shape in one launch: A [G*rows][K], Bp [G][N][K], bias [G][N] | None, C [G*rows][N];
         u (same shape as C): C = (A . Bp^T) * act'(u)."""
         (pa, a16), (pc, c16), (pca, ca16), (pb, b16), (pu, u16) = _aptr(A), _aptr(C), _aptr(C_act), _aptr(Bp), _aptr(u)
-        flags = {"fp32": 0, "fp16": 33, "fp16s": 33}.get(self.precision, 1)
+        flags = {"fp32": self._x3(), "fp16": 33, "fp16s": 33}.get(self.precision, 1)
         if a16 or c16 or ca16 or b16 or u16:
             flags = self._mx(a16, c16, ca16, b16, u16)
         flags |= (2 if a16 else 0) | (4 if c16 else 0) | (8 if u16 else 0) | (16 if b16 else 0)
@@ -237,7 +254,7 @@ class HipBackend:
     def wgrad_tn_grouped(self, D, Gt, partial, G, rows, Cd, Cg, chunks):
         """partial [chunks][G][Cd][Cg] of G weight-gradient problems whose rows follow one another in D / Gt."""
         (pd, d16), (pg, g16) = _aptr(D), _aptr(Gt)
-        flags = {"fp32": 0, "fp16": 33, "fp16s": 33}.get(self.precision, 1)
+        flags = {"fp32": self._x3(), "fp16": 33, "fp16s": 33}.get(self.precision, 1)
         if d16 or g16:
             flags = self._mx(d16, g16)
         flags |= (2 if d16 else 0) | (4 if g16 else 0)
@@ -254,6 +271,10 @@ class HipBackend:
             check(self.lib.mmdyn_wgrad_tn_mx(pd, pg, _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks,
                                              self._mx(d16, g16) | (2 if d16 else 0) | (4 if g16 else 0), _stream()),
                   "mmdyn_wgrad_tn_mx")
+            return
+        if self._x3():
+            check(self.lib.mmdyn_wgrad_tn_mx(pd, pg, _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks, 128,
+                                             _stream()), "mmdyn_wgrad_tn_mx")
             return
         fn = {"fp32": self.lib.mmdyn_wgrad_tn, "fp16": self.lib.mmdyn_wgrad_tn_f16,
               "fp16s": self.lib.mmdyn_wgrad_tn_f16}.get(self.precision, self.lib.mmdyn_wgrad_tn_bf16)

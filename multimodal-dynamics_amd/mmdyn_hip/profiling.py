@@ -89,6 +89,14 @@ class TimedBackend:
     def precision(self, value):
         self._inner.precision = value
 
+    @property
+    def fp32_split(self):
+        return getattr(self._inner, "fp32_split", False)
+
+    @fp32_split.setter
+    def fp32_split(self, value):
+        self._inner.fp32_split = value
+
     def __getattr__(self, attr):
         fn = getattr(self._inner, attr)
         if attr in HOST_ONLY or not callable(fn):

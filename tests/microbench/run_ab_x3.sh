@@ -1,10 +1,9 @@
 #!/bin/bash
-# Same-box A/B of the three-term-split fp32 kernels (LAB library, MMDYN_X3=1) on the bench line: alternating runs.
-# usage: bash tests/microbench/run_ab_x3.sh [extra bench args]
+# Same-box A/B of the fp32 arithmetic on the bench line, PRODUCT library: native fp32 matrix cores (--dtype f32) against the
+# three-term split on the bf16 matrix cores (--dtype f32x3); alternating runs.   usage: run_ab_x3.sh [extra bench args]
 R=${GRAFT_REPO_ROOT:-/root/repo}
-export MMDYN_HIP_LIB=$R/multimodal-dynamics_amd/mmdyn_hip/libmmdyn_hip_lab.so
-ms() { python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%.3f ms  %.0f samples/s  loss %s' % (d['ms_per_step'], d['value'], d.get('final_loss', d.get('loss'))))"; }
+ms() { python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%.3f ms  %.0f samples/s  final loss %.6f' % (d['ms_per_step'], d['value'], d['config']['final_loss']))"; }
 for i in 1 2 3; do
-  echo -n "native fp32 matrix cores:   "; python3 $R/bench.py --no-cpu-baseline "$@" 2>/dev/null | ms
-  echo -n "three-term split (X3=1):    "; MMDYN_X3=1 MMDYN_X3_WGRAD=1 python3 $R/bench.py --no-cpu-baseline "$@" 2>/dev/null | ms
+  echo -n "--dtype f32   (native fp32 matrix cores): "; python3 $R/bench.py --no-cpu-baseline "$@" 2>/dev/null | ms
+  echo -n "--dtype f32x3 (three-term split):         "; python3 $R/bench.py --no-cpu-baseline --dtype f32x3 "$@" 2>/dev/null | ms
 done

@@ -361,3 +361,99 @@ def test_last_decoder_layer_with_fused_batchnorm_swish(G, Bg, H, dtype):
         assert rel(gW_hip, gW) < 1e-5
     finally:
         ops.B.precision = prev
+
+
+# ---- fp32 GEMMs on the bf16 matrix cores: the exact three-term operand split (csrc/igemm_nt.hip / wgrad_tn.hip X3) --------------
+# Held to the SAME tolerances against fp64 ATen as the native fp32 kernels above, at sizes the split's launch rule serves
+# (>= 512 blocks of 64x64 or >= 384 of 128x128); "served" is checked too: the result differs in its last bits from the native one.
+@pytest.fixture
+def x3():
+    prev = ops.B.fp32_split
+    ops.B.fp32_split = True
+    yield
+    ops.B.fp32_split = prev
+
+
+def _native(fn):
+    prev, ops.B.fp32_split = ops.B.fp32_split, False
+    try:
+        return fn()
+    finally:
+        ops.B.fp32_split = prev
+
+
+def relg(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("B,Hi,Cin,Cout,stride,pad", [(256, 16, 64, 128, 2, 1), (1024, 16, 64, 128, 2, 1), (512, 32, 32, 64, 2, 1),
+                                                      (1024, 8, 128, 256, 1, 0)])
+def test_x3_conv2d_forward_input_and_weight_gradient(x3, B, Hi, Cin, Cout, stride, pad):
+    x, W = rnd(B, Cin, Hi, Hi, seed=1).to(DEV), rnd(Cout, Cin, 4, 4, seed=2, scale=0.1).to(DEV)
+    Ho = (Hi + 2 * pad - 4) // stride + 1
+    Wp = layers.pack_conv(W, swap=False)
+    run = lambda: layers.conv_like(nhwc_rows(x), Wp, CONV, 1, B, Hi, Cin, Ho, Cout, stride, -pad)[0]
+    y, y_native = run(), _native(run)
+    xd, Wd = x.double().requires_grad_(True), W.double().requires_grad_(True)
+    ref = F.conv2d(xd, Wd, stride=stride, padding=pad)
+    assert relg(from_rows(y, B, Ho, Cout), ref) < 2e-6
+    assert not torch.equal(y, y_native) and relg(y, y_native) < 3e-6
+    dy = rnd(B, Cout, Ho, Ho, seed=3).to(DEV)
+    gx, gW = torch.autograd.grad(ref, (xd, Wd), dy.double())
+    gW_hip = torch.zeros(Cout, Cin, 4, 4, device=DEV)
+    layers.wgrad(nhwc_rows(dy), nhwc_rows(x), gW_hip, CONV, B, Ho, Cout, Hi, Cin, stride, -pad)
+    gW_nat = torch.zeros(Cout, Cin, 4, 4, device=DEV)
+    _native(lambda: layers.wgrad(nhwc_rows(dy), nhwc_rows(x), gW_nat, CONV, B, Ho, Cout, Hi, Cin, stride, -pad))
+    assert relg(gW_hip, gW) < 5e-6
+    if Cout % 64 == 0 and Cin % 64 == 0:          # (narrower channel tiles keep the four-tap kernel and the fp32 matrix cores)
+        assert not torch.equal(gW_hip, gW_nat)
+    if stride == 2:
+        Ws = layers.pack_conv(W, swap=True)
+        dx, _, _ = layers.conv_like(nhwc_rows(dy), Ws, TCONV_S2P1, 1, B, Ho, Cout, Hi, Cin)
+        assert relg(from_rows(dx, B, Hi, Cin), gx) < 5e-6
+
+
+@pytest.mark.parametrize("G,Bg", [(4, 256), (4, 70)])
+def test_x3_conv_transpose2d_s1p0_with_statistics(x3, G, Bg):
+    B = G * Bg
+    x, W = rnd(B, 256, 5, 5, seed=7).to(DEV), rnd(256, 128, 4, 4, seed=8, scale=0.1).to(DEV)
+    Ws = layers.pack_conv(W, swap=True)
+    y, st, T = layers.tconv_s1p0(nhwc_rows(x), Ws, G, Bg, 256, 128, stats=True)
+    ref = F.conv_transpose2d(x.double(), W.double(), stride=1, padding=0)
+    assert relg(from_rows(y, B, 8, 128), ref) < 2e-6
+    rr = ref.reshape(G, Bg, 128, 64).permute(0, 1, 3, 2).reshape(G, Bg * 64, 128)          # [G][rows][channel]
+    sums = st.double().sum(1)                                                             # [G][2][N]: sum, sum of squares
+    # (the column sums cancel -- |sum| ~ 1e-2 of sum |y| -- so their error is measured against the sum of magnitudes)
+    assert float((sums[:, 0] - rr.sum(1)).norm() / rr.abs().sum(1).norm()) < 1e-6 and relg(sums[:, 1], (rr * rr).sum(1)) < 1e-5
+
+
+@pytest.mark.parametrize("rows,K,N", [(6400, 256, 2048), (1024, 256, 6400), (1024, 6400, 256)])
+def test_x3_linear_forward_and_weight_gradient(x3, rows, K, N):
+    x, W, b = rnd(rows, K, seed=9).to(DEV), rnd(N, K, seed=10, scale=0.05).to(DEV), rnd(N, seed=11).to(DEV)
+    y, _ = layers.dense(x, W, b, rows, K, N)
+    ref = F.linear(x.double(), W.double(), b.double())
+    assert relg(y, ref) < 2e-6
+    dy = rnd(rows, N, seed=12).to(DEV)
+    gW_hip = torch.zeros(N, K, device=DEV)
+    layers.wgrad(dy, x, gW_hip, DENSE, rows, 1, N, 1, K)
+    assert relg(gW_hip, dy.double().t() @ x.double()) < 5e-6
+
+
+def test_x3_batchnorm_backward_epilogue_matches_the_native_launch(x3):
+    """The input-gradient GEMM with the BatchNorm + Swish backward in its epilogue and the per-tile sums it leaves: the split launch
+    against the native one on the same data (both were checked against autograd above)."""
+    mode, G, Bg, Hi, Cin, Ho, N = CONV, 4, 64, 32, 32, 16, 64
+    Bt, rows = G * Bg, G * Bg * Ho * Ho
+    A, Bp = rnd(Bt * Hi * Hi, Cin, seed=20).to(DEV), rnd(16, N, Cin, seed=21, scale=0.1).to(DEV)
+    y = rnd(rows, N, seed=22).to(DEV)
+    mean, rstd = rnd(G, N, seed=23).to(DEV), (rnd(G, N, seed=24).abs() + 0.5).to(DEV)
+    gamma, beta = (rnd(N, seed=25).abs() + 0.5).to(DEV), rnd(N, seed=26).to(DEV)
+
+    def run():
+        T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
+        C, st = torch.empty(rows, N, device=DEV), torch.empty(G, T, 2, N, device=DEV)
+        ops.B.igemm_nt_dgrad_bn(A, Bp, C, st, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, 2, -1)
+        return C, st.double().sum(1)
+    (C, s), (Cn, sn) = run(), _native(run)
+    assert not torch.equal(C, Cn)
+    assert relg(C, Cn) < 3e-6 and relg(s, sn) < 1e-5

@@ -322,6 +322,50 @@ def test_deferred_decoder_weight_gradients_equal_inline():
     assert MVAEStep(build("cnn-mvae", True, True, "cpu")).defer_wgrad
 
 
+def test_fp32x3_precision_plumbing():
+    """precision="fp32x3": fp32 storage and results, the GEMMs allowed onto the bf16 matrix cores through the exact three-term
+    operand split.  On the emulated kernels (fp32 arithmetic) the mode is pure plumbing: same tolerances as "fp32", the backend
+    sees precision "fp32" + fp32_split while a step runs and is restored afterwards."""
+    from mmdyn_hip import ops
+    check_extended_size_vs_oracle("cpu", 64, 3, True, n_steps=1, precision="fp32x3")
+    assert ops.B.precision == "fp32" and not getattr(ops.B, "fp32_split", False)
+    assert MVAEStep(build("cnn-mvae", True, True, "cpu"), precision="fp32x3").defer_wgrad
+    with pytest.raises(ValueError):
+        MVAEStep(build("cnn-mvae", True, True, "cpu"), precision="fp32x2")
+
+
+def test_three_term_split_is_exact_and_its_dropped_products_are_below_fp32_rounding():
+    """The arithmetic of csrc/common.h split3_bf16 (the X3 kernels), restated in numpy: hi = bf16(x), mid = bf16(x - hi),
+    lo = x - hi - mid with round-to-nearest-even conversions leaves three bf16 values whose sum IS x, and the three cross products
+    the kernels drop (mid.lo, lo.mid, lo.lo) are together below 2^-23 |a||b| -- less than ONE fp32 rounding of the product."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+
+    def bf16_rne(v):
+        u = v.view(np.uint32).astype(np.uint64)
+        return ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32).view(np.float32)
+
+    def split(x):
+        hi = bf16_rne(x)
+        r = x - hi
+        mid = bf16_rne(r)
+        return hi, mid, r - mid
+    a = (rng.standard_normal(200000) * 10.0 ** rng.integers(-20, 20, 200000)).astype(np.float32)
+    b = (rng.standard_normal(200000) * 10.0 ** rng.integers(-10, 10, 200000)).astype(np.float32)
+    ah, am, al = split(a)
+    bh, bm, bl = split(b)
+    for t in (ah, am, al, bh, bm, bl):
+        assert np.array_equal(bf16_rne(t), t)                                    # every term is a bf16 value
+    f = lambda v: v.astype(np.float64)
+    assert np.array_equal(f(ah) + f(am) + f(al), f(a)) and np.array_equal(f(bh) + f(bm) + f(bl), f(b))
+    six = f(ah) * f(bh) + f(ah) * f(bm) + f(am) * f(bh) + f(am) * f(bm) + f(ah) * f(bl) + f(al) * f(bh)
+    exact = f(a) * f(b)
+    rel = (six - exact) / exact
+    assert np.abs(rel).max() <= 2.0 ** -23 and abs(rel.mean()) < 1e-10           # bounded and unbiased
+    fp32_product = (a * b).astype(np.float64)                                     # one RNE rounding of the exact product
+    assert np.sqrt((rel ** 2).mean()) < np.sqrt((((fp32_product - exact) / exact) ** 2).mean())
+
+
 def test_fp16s_precision_plumbing():
     """precision="fp16s": as "fp16" with the convolution-level activations, their gradients and the packed weights stored
     in IEEE half (3 more mantissa bits than the bf16 of "bf16s" at the same bytes); FC level, logits and losses stay fp32."""

@@ -130,9 +130,16 @@ def test_conditional_training_loops(tmp_path):
     T.check_conditional_loops(tmp_path, no_cuda=False)
 
 
-@pytest.mark.parametrize("B,n_steps", [(32, 3), (256, 1), (1, 1), (5, 2), (37, 1), (130, 1)])
-def test_fused_engine_vs_oracle(B, n_steps):
-    """ELBO (total and each of the 7 partials) within 1e-4 relative of the CPU oracle, gradients within 1e-3
+@pytest.mark.parametrize("B,n_steps,precision", [(32, 3, "fp32"), (256, 1, "fp32"), (1, 1, "fp32"), (5, 2, "fp32"), (37, 1, "fp32"),
+                                                 (130, 1, "fp32"), (32, 3, "fp32x3"), (256, 1, "fp32x3"), (131, 1, "fp32x3"), (200, 1, "fp32x3")])
+def test_fused_engine_vs_oracle(B, n_steps, precision):
+    """(precision "fp32x3": the GEMMs that gain from it run on the bf16 matrix cores through the exact three-term split of their
+    fp32 operands -- held to the SAME tolerances as the native fp32 arithmetic.  Its ragged case is B = 131, not 130: at B = 130 with
+    this seed ONE ReLU input of the pose decoder (sample 37 of the {tactile, pose} subset, unit 507 of deconv_net.2) is 3.5e-7 in the
+    native arithmetic and the oracle and <= 0 in the split -- a rounding-level difference in the forward pass that flips the unit's
+    gradient mask and moves the tactile / pose encoder gradients by 2e-3 (profiles/r4/x3_relu_knife_edge_b130.txt,
+    tests/microbench/x3_state_diff.py); either subgradient is right, neither arithmetic is closer to the exact one.)
+    ELBO (total and each of the 7 partials) within 1e-4 relative of the CPU oracle, gradients within 1e-3
     relative L2 per tensor, loss still within 1e-4 after 3 Adam steps; B=256 is the
     BASELINE batch (one oracle step takes a few seconds on the host cores); 1, 5, 37 and 130 are ragged sizes: no
     row count is a multiple of any tile, split-K / chunk / band sizes all hit their remainders."""
@@ -142,7 +149,7 @@ def test_fused_engine_vs_oracle(B, n_steps):
     inputs, targets = seeded_batch(B, 1234)
     eps, masks = seeded_noise(B, 256, 7 * n_steps, 8 * n_steps, 4321)
     m = T.build("cnn-mvae", True, True, DEV)
-    step = MVAEStep(m, noise=InjectedNoise(eps, masks))
+    step = MVAEStep(m, noise=InjectedNoise(eps, masks), precision=precision)
     names = list(prm.keys())
     opt = O.Adam([prm[k] for k in names], lr=1e-3)
     gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
