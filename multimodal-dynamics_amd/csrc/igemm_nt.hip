@@ -707,7 +707,7 @@ static int launch_m(const float* A, const float* Bp, const float* bias, float* C
   const bool m16 = !bf16 && M16_TILE && !force_m32 && (force_m16 || (big_tile_m16 && nblocks >= 2048 && ksteps >= 8) ||
                                                        (BM == 128 && BN == 128 && lab_env("MMDYN_IGEMM_M16_128") != nullptr));
   size_t smem = (size_t)(BM + BN) * (m16 ? BK + 8 : LDS_LD32) * sizeof(float) + (size_t)BM * 4 * sizeof(int);
-  if constexpr (MODE != MMDYN_IM2COL3 && BM * BN >= 64 * 64 && BN >= 64) {
+  if constexpr (MODE != MMDYN_IM2COL3 && BM * BN >= 64 * 64) {
     if (g.x3 && !bf16) {        // fp32 through the bf16 matrix cores (three-term split, see X3 at the kernel)
       smem = (size_t)3 * (BM + BN) * (BK + 8) * 2 + (size_t)BM * 4 * sizeof(int);
       static LdsOptIn optin;
@@ -815,7 +815,15 @@ static bool ws_enabled() {
 static bool x3_pick(bool allowed, int mode, int G, int rows_per_group, int N, int splitk, int* bm, int* bn) {
   if (const char* on = lab_env("MMDYN_X3")) allowed = on[0] == '1';
   if (!allowed) return false;
-  if (mode == MMDYN_IM2COL3 || splitk != 1 || N % 64) return false;
+  if (mode == MMDYN_IM2COL3 || splitk != 1) return false;
+  if (N == 32) {           // (LAB experiment, MMDYN_X3_N32=256|128: the 32-channel layers on 256x32 / 128x32 tiles)
+    const char* e = lab_env("MMDYN_X3_N32");
+    if (!e || (atoi(e) != 256 && atoi(e) != 128)) return false;
+    *bm = atoi(e);
+    *bn = 32;
+    return true;
+  }
+  if (N % 64) return false;
   if (const char* e = lab_env("MMDYN_X3_MODES")) {        // (LAB: bit m set = launches of mode m may take the split)
     if (!((atoi(e) >> mode) & 1)) return false;
   }
@@ -882,11 +890,11 @@ static int lds_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int 
 // fp32 launches go to the wave-independent kernels of igemm_d16.hip where those serve the shape; the bf16 matrix-core
 // modes always take the LDS-tiled kernels of this file.  The number of partial-sum tiles follows the kernel.
 static int f32_stat_tiles(bool x3, int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+  int t = x3_stat_tiles(x3, mode, G, Bg, Hi, Wi, Ho, Wo, N);        // (same order as igemm_entry tries the kernels)
+  if (t > 0) return t;
   const int tp = mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   if (tp > 0) return tp;
-  int t = mmdyn_igemm_d16_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
-  if (t > 0) return t;
-  t = x3_stat_tiles(x3, mode, G, Bg, Hi, Wi, Ho, Wo, N);
+  t = mmdyn_igemm_d16_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   if (t > 0) return t;
   t = ws_enabled() ? mmdyn_igemm_wsp_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, false) : 0;
   if (t > 0) return t;
@@ -900,9 +908,9 @@ extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, i
  * split tiles (igemm_wsp.hip).  0: none. */
 static int f32_slab_floats(bool x3, int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   if (!ws_enabled()) return 0;
+  if (x3_stat_tiles(x3, mode, G, Bg, Hi, Wi, Ho, Wo, N) > 0) return 0;
   if (mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) > 0) return 0;
   if (mmdyn_igemm_d16_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) > 0) return 0;
-  if (x3_stat_tiles(x3, mode, G, Bg, Hi, Wi, Ho, Wo, N) > 0) return 0;
   return (int)(mmdyn_igemm_wsp_slab_bytes(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, false) / 4);
 }
 extern "C" int mmdyn_igemm_slab_floats(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
@@ -1031,14 +1039,6 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
                                       st);
     if (rc != 1) return rc;
   }
-  if (!bf16 && mode == MMDYN_TCONV_S2P1) {     // the 64 -> 32 channel up-sampling layer has a patch-resident kernel (tconv_patch.hip)
-    const int rc = mmdyn_tconv_patch_try(A, Bp, bias, C, C_act, stats, ws, g, st);
-    if (rc != 1) return rc;
-  }
-  if (!bf16 && mode != MMDYN_IM2COL3 && !b_group_stride) {
-    const int rc = mmdyn_igemm_d16_try(A, Bp, bias, C, C_act, stats, ws, g, stride, offset, st);
-    if (rc != 1) return rc;
-  }
   if (!bf16) {        // fp32 through the bf16 matrix cores (three-term operand split)
     int bm, bn;
     if (x3_pick(x3_allowed, mode, G, mode == MMDYN_TCONV_S1P0 ? Bg * Ho * Wo : Bg * g.Hr * g.Wr, N, splitk, &bm, &bn)) {
@@ -1046,8 +1046,18 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
       if (bn == 128 && bm == 128) return mmdyn_igemm_tile0(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
       if (bn == 128 && bm == 64) return mmdyn_igemm_tile1(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
       if (bn == 64 && bm == 128) return mmdyn_igemm_tile2(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+      if (bn == 32 && bm == 256) return mmdyn_igemm_tile4(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
+      if (bn == 32) return mmdyn_igemm_tile5(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
       return mmdyn_igemm_tile3(A, Bp, bias, C, C_act, stats, ws, g, st, bf16);
     }
+  }
+  if (!bf16 && mode == MMDYN_TCONV_S2P1) {     // the 64 -> 32 channel up-sampling layer has a patch-resident kernel (tconv_patch.hip)
+    const int rc = mmdyn_tconv_patch_try(A, Bp, bias, C, C_act, stats, ws, g, st);
+    if (rc != 1) return rc;
+  }
+  if (!bf16 && mode != MMDYN_IM2COL3 && !b_group_stride) {
+    const int rc = mmdyn_igemm_d16_try(A, Bp, bias, C, C_act, stats, ws, g, stride, offset, st);
+    if (rc != 1) return rc;
   }
   if (ws_enabled() && mode != MMDYN_IM2COL3 && (!bf16 || (g.a_b16 && g.b_b16))) {   // persistent ring kernel (igemm_wsp.hip)
     const int rc = mmdyn_igemm_wsp_try(A, Bp, bias, C, C_act, stats, ws, g, bf16, st);

@@ -654,9 +654,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 // the four kw taps of one kernel row kh and share ONE dense-operand tile, so D is fetched once per 4 taps instead
 // of once per tap (half the L2 traffic of the one-tap kernel on these shapes) and no wave has to split the row
 // reduction (WK = 1: a quarter / half of the partial slabs).  grid.y = kh.
-template <int BD, int BG, bool BF16, int ST>
+// X3: the three-term split of the fp32 operands on the bf16 matrix cores, as in wgrad_tn_kernel (three bf16 planes per tile in
+// LDS, transposing fragment reads, six products).
+template <int BD, int BG, bool BF16, int ST, bool X3 = false>
 __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict__ D, const float* __restrict__ Gt,
                                                         float* __restrict__ partial, const WgradGeom g) {
+  static_assert(!X3 || (!BF16 && ST == 0), "the three-term split is a variant of the fp32 kernel");
   constexpr int DT = BD / 32, GT = BG / 32;
   constexpr int DV = BD / 4, GV = BG / 4;
   constexpr int D_LOADS = (RK * DV + 255) / 256;          // float4 per thread for the shared D tile
@@ -686,6 +689,9 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
     if (r >= d) { q += 1; r -= d; }
   };
   float* Gw = Gs + wave * RK * BG;
+  constexpr int LDD = x3_ld<BD>::v, LDG = x3_ld<BG>::v;
+  bf16_t* Ds16 = reinterpret_cast<bf16_t*>(smem);                 // X3: [plane][RK][LDD], then per wave [plane][RK][LDG]
+  bf16_t* Gw16 = Ds16 + 3 * RK * LDD + wave * 3 * RK * LDG;
 
   f32x4 rd[D_LOADS], rg[G_LOADS];
   unsigned okd = 0, okg = 0;
@@ -726,6 +732,37 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
   };
   auto lds_store = [&]() {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (X3) {
+#pragma unroll
+      for (int i = 0; i < D_LOADS; ++i) {
+        const int idx = tid + 256 * i;
+        if (D_ALL || idx < RK * DV) {
+          const int r = idx / DV, v = idx - r * DV;
+          const f32x4 x = ((okd >> i) & 1u) ? rd[i] : zero;
+          uint2 hh, mm, ll;
+          split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
+          split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
+          const int o = r * LDD + v * 4;
+          *reinterpret_cast<uint2*>(&Ds16[o]) = hh;
+          *reinterpret_cast<uint2*>(&Ds16[RK * LDD + o]) = mm;
+          *reinterpret_cast<uint2*>(&Ds16[2 * RK * LDD + o]) = ll;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < G_LOADS; ++i) {
+        const int idx = lane + 64 * i;
+        const int r = idx / GV, v = idx - r * GV;
+        const f32x4 x = ((okg >> i) & 1u) ? rg[i] : zero;
+        uint2 hh, mm, ll;
+        split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
+        split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
+        const int o = r * LDG + v * 4;
+        *reinterpret_cast<uint2*>(&Gw16[o]) = hh;
+        *reinterpret_cast<uint2*>(&Gw16[RK * LDG + o]) = mm;
+        *reinterpret_cast<uint2*>(&Gw16[2 * RK * LDG + o]) = ll;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < D_LOADS; ++i)
       if (D_ALL || tid + 256 * i < RK * DV) reinterpret_cast<f32x4*>(Ds)[tid + 256 * i] = ((okd >> i) & 1u) ? rd[i] : zero;
@@ -750,7 +787,38 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
     for (int r0 = row_begin; r0 < row_end; r0 += RK) {
       gload(r0 + RK);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (BF16) {
+      if constexpr (X3) {
+        const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;        // transposed-read lane roles (wgrad_b16_kernel)
+        const int trow = 8 * (gq >> 1) + tq, tcol = 16 * (gq & 1) + 4 * tp;
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+        typedef __bf16 xb16x8 __attribute__((ext_vector_type(8)));
+        auto frag = [&](const bf16_t* tile, int ld, int col0, int k0) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(&tile[(k0 + trow) * ld + col0 + tcol]));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(&tile[(k0 + trow + 4) * ld + col0 + tcol]));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          return __builtin_bit_cast(xb16x8, v);
+        };
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          xb16x8 pa[3][DT], pb[3][GT];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int a = 0; a < DT; ++a) pa[p][a] = frag(Ds16 + p * RK * LDD, LDD, a * 32, kc * 16);
+#pragma unroll
+            for (int b = 0; b < GT; ++b) pb[p][b] = frag(Gw16 + p * RK * LDG, LDG, b * 32, kc * 16);
+          }
+          constexpr int order[6][2] = {{0, 2}, {2, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 0}};      // smallest terms first
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int a = 0; a < DT; ++a)
+#pragma unroll
+              for (int b = 0; b < GT; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[order[t][0]][a], pb[order[t][1]][b], acc[a][b], 0, 0, 0);
+        }
+      } else if constexpr (BF16) {
 #pragma unroll
         for (int r8 = 0; r8 < RK; r8 += 8) {
           if constexpr (ST >= 4) {
@@ -826,6 +894,11 @@ static int launch4(const float* D, const float* Gt, float* partial, WgradGeom g,
   g.rows_per_chunk = ceil_div(rpc, RK) * RK;
   dim3 grid((g.Cd / BD) * (g.Cg / BG), 4, g.chunks);
   size_t smem = (size_t)RK * (BD + 4 * BG) * sizeof(float);
+  if (g.x3 && !bf16) {       // fp32 through the bf16 matrix cores (three-term split)
+    smem = (size_t)3 * RK * (x3_ld<BD>::v + 4 * x3_ld<BG>::v) * 2;
+    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, false, 0, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
+    MMDYN_LAUNCH_CHECK();
+  }
   if (bf16 && g.d_b16 && g.g_b16 && g.f16)      // both operands IEEE half
     hipLaunchKernelGGL((wgrad_b16_tn4_kernel<BD, BG, true>), grid, dim3(256), 0, st, reinterpret_cast<const bf16_t*>(D),
                        reinterpret_cast<const bf16_t*>(Gt), partial, g);

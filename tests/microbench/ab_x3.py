@@ -27,6 +27,8 @@ SHAPES = [
     (1, 1, 256, 16, 64, 8, 128, 2, -1, "stats"),        # encoder conv3
     (2, 1, 256, 8, 128, 16, 64, 1, 0, "bnbwd"),
     (1, 1, 256, 32, 32, 16, 64, 2, -1, "stats"),
+    (2, 4, 256, 16, 64, 32, 32, 1, 0, "stats"),         # 64 -> 32 channel up-sampling layer (native: the patch-resident kernel);
+    (2, 1, 256, 16, 64, 32, 32, 1, 0, "actbwd"),        #   on the split only with MMDYN_X3_N32=256|128
     (0, 1, 6400, 1, 256, 1, 2048, 1, 0, "plain"),       # FC level
     (0, 1, 1024, 1, 256, 1, 6400, 1, 0, "plain"),
     (0, 1, 256, 1, 512, 1, 6400, 1, 0, "plain"),
