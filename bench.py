@@ -265,6 +265,8 @@ def main():
                     help="BatchNorm statistics over the global batch (N > 1; one small all-reduce per BatchNorm layer and "
                          "direction, captured into the lanes' HIP graphs, each lane on its own RCCL communicator).  Default: "
                          "local statistics")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="skip the extra timed run in the fp32x3 arithmetic that a default (f32, one GPU) run reports next to its value")
     ap.add_argument("--infer", action="store_true",
                     help="time forward-only inference instead (model.eval(): joint visual+tactile+pose pass through the "
                          "module API, running-estimate BatchNorm); prints its own JSON line, not the BASELINE metric")
@@ -529,6 +531,35 @@ def main():
         for k, d in sorted(profile_step.by_shape.items(), key=lambda kv: -kv[1]["ms"]):
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
             print(f"  {k[0]:9s} {str(k[1:]):70s} x{d['calls']:2d} {d['ms']:7.3f} ms {tf:6.1f} TF/s", file=sys.stderr)
+    if world == 1 and args.dtype == "f32" and not args.no_alt and not dry and not args.no_graph:
+        # The same workload, same seeds, in the engine's "fp32x3" arithmetic (fp32 storage and results; the GEMMs on the bf16 matrix
+        # cores through the exact three-term operand split, csrc/igemm_nt.hip X3) -- timed like `value` (W warm-up + K graph-replayed
+        # steps between synchronisations), reported NEXT to it: `value` above is the native fp32 matrix-core arithmetic.
+        del step
+        torch.cuda.empty_cache()
+        torch.manual_seed(0)
+        model3 = setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=S * S, architecture="cnn",
+                             conditional=False, categorical_conditions=False, latent_size=256, use_pose=True).to(dev).train()
+        step3 = MVAEStep(model3, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), two_lanes=not args.single_lane,
+                         precision="fp32x3", defer_wgrad={"auto": None, "on": True, "off": False}[args.defer_wgrad],
+                         group_heads=not args.no_grouped_heads)
+        for _ in range(args.warmup):
+            step3.train_step_graphed(inputs, targets, KL_WEIGHT)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss3 = step3.train_step_graphed(inputs, targets, KL_WEIGHT)
+        sync()
+        dt3 = time.perf_counter() - t0
+        out["alt_arithmetic"] = {
+            "name": "fp32x3", "value": args.batch * args.steps / dt3, "unit": "samples/s", "ms_per_step": 1e3 * dt3 / args.steps,
+            "final_loss": float(loss3), "final_loss_native_fp32": final_loss,
+            "what": "fp32 operands split exactly into three bf16 terms (round-to-nearest), six of the nine cross products on "
+                    "v_mfma_f32_32x32x16_bf16, fp32 accumulate; dropped terms < 2^-23 |a||b| per product (less than one fp32 rounding); "
+                    "error against fp64 no larger than the native fp32 matrix cores' (profiles/r4/ab_x3_*.txt); same oracle "
+                    "tolerances (tests/test_model_gpu.py::test_fused_engine_vs_oracle[*-fp32x3]); python bench.py --dtype f32x3 "
+                    "makes it the measured arithmetic"}
+        del step3, model3
     if world == 1 and not args.no_cpu_baseline:
         # torch.set_num_threads(os.cpu_count()).  On a box whose CPU share is smaller than the
         # machine (the one-GPU box: 16 of 256 hardware threads, no visible quota) the figure at the documented share is

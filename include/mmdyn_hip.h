@@ -82,7 +82,8 @@ int mmdyn_igemm_nt_dgrad_act(const void* A, const void* Bp, void* C, const void*
  * and the per-tile column sums (du, du*xhat) into stats[G][T][2][N] (T = mmdyn_igemm_stat_tiles), which feed
  * mmdyn_bn_bwd_finalize directly -- the separate reduction pass (mmdyn_bn_swish_bwd_reduce: one more read of da
  * and y) disappears; mmdyn_bn_swish_bwd_apply(da_is_du = 1) finishes the layer.  bf16: 0 = fp32 matrix cores,
- * 1 = bf16, 2 = fp16 operands (T = mmdyn_igemm_stat_tiles_bf16 for both).  No bias / activation / split-K here.
+ * 1 = bf16, 2 = fp16 operands (T = mmdyn_igemm_stat_tiles_bf16 for both), 3 = fp32 arithmetic with the three-term split allowed
+ * (flag bit 7 of mmdyn_igemm_nt_mx; T = mmdyn_igemm_stat_tiles_mx(..., 128)).  No bias / activation / split-K here.
  * ws: workspace of mmdyn_igemm_slab_floats(...) floats (NULL when that is 0). */
 int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C, float* stats, const float* y,
                             const float* mean, const float* rstd, const float* gamma, const float* beta,
@@ -411,7 +412,17 @@ int mmdyn_resize_u8_to_chw_f32(const uint8_t* src, const int* index, float* dst,
  *       bf16 C.  Bit 5 together with bit 0: every tensor the other bits mark is IEEE HALF instead of bf16 and the product
  *       runs on the fp16 matrix cores (precision "fp16s": fp16 activation storage, BASELINE configs[4] arithmetic); bit 5
  *       with no storage bit is mmdyn_igemm_nt_f16.
- *   mmdyn_wgrad_tn_mx : bit 0 as above, bit 1 D is 16-bit, bit 2 Gt is 16-bit (not IM2COL3), bit 5 as above.
+ *       Bit 7 ALONE (flags == 128; also accepted by mmdyn_igemm_nt_dgrad_act / _grouped, mmdyn_wgrad_tn_mx / _grouped and the
+ *       *_stat_tiles_mx / *_slab_floats_mx queries): an fp32 launch -- fp32 operands, fp32 results, every tensor fp32 in HBM --
+ *       that MAY run on the bf16 matrix cores through the exact three-term split of its fp32 operands (precision "fp32x3" of the
+ *       host side): x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid (round-to-nearest, both
+ *       subtractions exact), six of the nine cross products (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi) on
+ *       v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped products are below 2^-23 |a||b| together, less than one fp32
+ *       rounding of the product, and the error against fp64 is no larger than the fp32 matrix cores' (csrc/common.h split3_bf16,
+ *       csrc/igemm_nt.hip / wgrad_tn.hip X3; profiles/r4/ab_x3_*.txt).  The library decides per launch (shapes with >= 512 blocks
+ *       of 64x64 or >= 384 of 128x128 outputs; every weight-gradient GEMM); the rest of such a step runs the fp32 matrix cores.
+ *       An Inf operand gives NaN (inf - inf in the split) where the fp32 matrix cores would give Inf.
+ *   mmdyn_wgrad_tn_mx : bit 0 as above, bit 1 D is 16-bit, bit 2 Gt is 16-bit (not IM2COL3), bit 5 as above, bit 7 alone as above.
  *   *_b16             : the element-wise kernels on 16-bit activation tensors (half = 0: bf16, half = 1: IEEE half). */
 int mmdyn_igemm_nt_mx(const void* A, const void* Bp, const float* bias, void* C, void* C_act, float* stats,
                       float* ws, const void* y, const float* mean, const float* rstd, const float* gamma,
