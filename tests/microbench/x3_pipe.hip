@@ -136,6 +136,114 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void x3_gemm(const floa
     }
 }
 
+// WS: producer / consumer waves.  NPW producer waves load the next K-step to registers, split it and write the three planes of the
+// other LDS buffer; the MFMA waves only read fragments and issue.  One raw s_barrier per K-step (no vmcnt wait in it: the producers'
+// global loads stay in flight across it).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int BM, int BN, int WM, int WN, int NPW>
+__global__ __launch_bounds__(64 * (NPW + (BM / WM) * (BN / WN))) void x3_ws(const float* __restrict__ A, const float* __restrict__ B,
+                                                                            float* __restrict__ C, int M, int N, int K) {
+  constexpr int WAVES_N = BN / WN;
+  constexpr int RPP = NPW * 64 / GRANS;
+  constexpr int A_LOADS = BM / RPP, B_LOADS = BN / RPP;
+  constexpr int MT = WM / 32, NT = WN / 32;
+  constexpr int STAGE = 3 * (BM + BN) * LDH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint16_t* S = reinterpret_cast<uint16_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntn = N / BN;
+  const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+  const int nsteps = K / BK;
+  if (wave < NPW) {
+    const int lrow = tid / GRANS, gran = tid % GRANS;
+    f32x4 ra[2][A_LOADS], rb[2][B_LOADS];
+    auto gload = [&](int set, int k0) {
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i)
+        ra[set][i] = *reinterpret_cast<const f32x4*>(A + (size_t)(tm * BM + lrow + RPP * i) * K + k0 + gran * 4);
+#pragma unroll
+      for (int j = 0; j < B_LOADS; ++j)
+        rb[set][j] = *reinterpret_cast<const f32x4*>(B + (size_t)(tn * BN + lrow + RPP * j) * K + k0 + gran * 4);
+    };
+    auto store_split = [&](uint16_t* T, int rows, int row, f32x4 v) {
+      uint2 h, m, l;
+      split3(v[0], v[1], h.x, m.x, l.x);
+      split3(v[2], v[3], h.y, m.y, l.y);
+      *reinterpret_cast<uint2*>(&T[row * LDH + gran * 4]) = h;
+      *reinterpret_cast<uint2*>(&T[(rows + row) * LDH + gran * 4]) = m;
+      *reinterpret_cast<uint2*>(&T[(2 * rows + row) * LDH + gran * 4]) = l;
+    };
+    auto lds_store = [&](int set, uint16_t* As) {
+      uint16_t* Bs = As + 3 * BM * LDH;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) store_split(As, BM, lrow + RPP * i, ra[set][i]);
+#pragma unroll
+      for (int j = 0; j < B_LOADS; ++j) store_split(Bs, BN, lrow + RPP * j, rb[set][j]);
+    };
+    auto kk = [&](int st) { return st < nsteps ? st * BK : 0; };
+    gload(0, 0);
+    gload(1, kk(1));
+    lds_store(0, S);                      // step 0
+    gload(0, kk(2));
+    lds_barrier();
+    for (int s = 0; s < nsteps; s += 2) {      // (nsteps is even here)
+      lds_store(1, S + STAGE);            // step s + 1 (set 1), loads of step s + 2 (set 0) in flight
+      gload(1, kk(s + 3));
+      lds_barrier();
+      lds_store(0, S);                    // step s + 2
+      gload(0, kk(s + 4));
+      lds_barrier();
+    }
+    return;
+  }
+  const int cw = wave - NPW;
+  const int wm = cw / WAVES_N, wn = cw % WAVES_N;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+  const int frag = (lane & 31) * LDH + (lane >> 5) * 8;
+  lds_barrier();
+  for (int s = 0; s < nsteps; ++s) {
+    const uint16_t* As = S + (s & 1) * STAGE;
+    const uint16_t* Bs = As + 3 * BM * LDH;
+#pragma unroll
+    for (int m = 0; m < BK / 16; ++m) {
+      bf16x8 pa[3][MT], pb[3][NT];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          pa[p][mt] = *reinterpret_cast<const bf16x8*>(&As[(p * BM + wm * WM + mt * 32) * LDH + frag + m * 16]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          pb[p][nt] = *reinterpret_cast<const bf16x8*>(&Bs[(p * BN + wn * WN + nt * 32) * LDH + frag + m * 16]);
+      }
+      constexpr int order[6][2] = {{0, 2}, {2, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 0}};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[order[t][0]][mt], pb[order[t][1]][nt], acc[mt][nt], 0, 0, 0);
+    }
+    lds_barrier();
+  }
+  const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = tm * BM + wm * WM + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) C[(size_t)r * N + tn * BN + wn * WN + nt * 32 + cl] = acc[mt][nt][e];
+    }
+}
+
 static double rel_err(const std::vector<float>& A, const std::vector<float>& B, const std::vector<float>& C, int M, int N, int K) {
   double num = 0, den = 0;
   for (int r = 0; r < M; r += M / 32) {
@@ -184,6 +292,16 @@ static void run(const char* name, F launch, float* dC, const std::vector<float>&
         dC, A, B, M, N, K);                                                                                           \
   } while (0)
 
+#define WS(BM, BN, WM, WN, NPW)                                                                                       \
+  do {                                                                                                                \
+    const size_t smem = (size_t)2 * 3 * (BM + BN) * LDH * 2;                                                           \
+    constexpr int NTHR = 64 * (NPW + (BM / WM) * (BN / WN));                                                          \
+    CK(hipFuncSetAttribute((const void*)x3_ws<BM, BN, WM, WN, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+    run("x3 " #BM "x" #BN " consumers " #WM "x" #WN " + " #NPW " producer waves",                                      \
+        [&] { hipLaunchKernelGGL((x3_ws<BM, BN, WM, WN, NPW>), dim3((M / BM) * (N / BN)), dim3(NTHR), smem, 0, dA, dB, dC, M, N, K); }, \
+        dC, A, B, M, N, K);                                                                                           \
+  } while (0)
+
 int main() {
   const int shapes[][3] = {{65536, 128, 1024}, {262144, 64, 512}, {16384, 128, 1024}};
   for (auto& s : shapes) {
@@ -205,7 +323,15 @@ int main() {
     X3(128, 64, 64, 32, 1);
     X3(128, 64, 32, 32, 0);
     X3(128, 64, 32, 32, 1);
+    WS(64, 64, 32, 32, 2);
+    WS(64, 64, 32, 32, 4);
+    WS(128, 64, 64, 32, 4);
+    WS(128, 64, 32, 32, 4);
     if (N % 128 == 0) {
+      WS(128, 128, 64, 64, 4);
+      WS(128, 128, 64, 32, 4);
+      WS(128, 128, 64, 64, 2);
+      WS(128, 128, 64, 32, 2);
       X3(128, 128, 64, 64, 0);
       X3(128, 128, 64, 64, 1);
       X3(128, 128, 64, 32, 0);
