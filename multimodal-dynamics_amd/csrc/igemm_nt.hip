@@ -804,17 +804,34 @@ int mmdyn_igemm_tile5(IGEMM_TILE_ARGS) { return launch<128, 32, 32, 32>(A, Bp, b
 
 
 // LAB build: MMDYN_IGEMM_WS=0 sends every launch back to the register-staged kernels (A/B measurements, kernel tests)
-static bool ws_enabled() {
-  const char* e = lab_env("MMDYN_IGEMM_WS");
-  return !(e && e[0] == '0');
-}
 
 // fp32 launches that take the three-term split (X3 at the kernel) and their block tile.  `allowed`: the caller asked for it (flag
 // bit 7 of the entry points: the "fp32x3" mode of the host side).  LAB: MMDYN_X3=1 / 0 overrides the flag, MMDYN_X3_TILE=BM,BN
 // forces one tile, MMDYN_X3_MIN_BLOCKS moves the size threshold.
-static bool x3_pick(bool allowed, int mode, int G, int rows_per_group, int N, int splitk, int* bm, int* bn) {
+static bool ws_enabled() {
+  const char* e = lab_env("MMDYN_IGEMM_WS");
+  return !(e && e[0] == '0');
+}
+static bool x3_on(bool allowed) {
   if (const char* on = lab_env("MMDYN_X3")) allowed = on[0] == '1';
-  if (!allowed) return false;
+  return allowed;
+}
+// the launches the persistent ring kernel serves keep it in the split arithmetic (its MFMA waves split their fragments in registers;
+// LAB: MMDYN_X3_WSP=0 sends them to the register-staged split kernels below instead)
+static bool x3_wsp(bool allowed) {
+  if (!x3_on(allowed) || !ws_enabled()) return false;
+  const char* e = lab_env("MMDYN_X3_WSP");
+  return !(e && e[0] == '0');
+}
+// (LAB experiment, MMDYN_X3_WS=1: every launch the one-tile ring kernels serve runs them in the split arithmetic -- ahead of the
+//  register-staged split kernels)
+static bool x3_ws(bool allowed) {
+  if (!x3_on(allowed) || !ws_enabled()) return false;
+  const char* e = lab_env("MMDYN_X3_WS");
+  return e && e[0] == '1';
+}
+static bool x3_pick(bool allowed, int mode, int G, int rows_per_group, int N, int splitk, int* bm, int* bn) {
+  if (!x3_on(allowed)) return false;
   if (mode == MMDYN_IM2COL3 || splitk != 1) return false;
   if (N == 32) {           // (LAB experiment, MMDYN_X3_N32=256|128: the 32-channel layers on 256x32 / 128x32 tiles)
     const char* e = lab_env("MMDYN_X3_N32");
@@ -890,7 +907,11 @@ static int lds_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int 
 // fp32 launches go to the wave-independent kernels of igemm_d16.hip where those serve the shape; the bf16 matrix-core
 // modes always take the LDS-tiled kernels of this file.  The number of partial-sum tiles follows the kernel.
 static int f32_stat_tiles(bool x3, int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
-  int t = x3_stat_tiles(x3, mode, G, Bg, Hi, Wi, Ho, Wo, N);        // (same order as igemm_entry tries the kernels)
+  int t = x3_wsp(x3) ? mmdyn_igemm_wsp_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, false) : 0;   // (same order as igemm_entry)
+  if (t > 0) return t;
+  t = (x3_ws(x3) && mode != MMDYN_TCONV_S1P0) ? mmdyn_igemm_ws_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) : 0;
+  if (t > 0 && mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) == 0) return t;
+  t = x3_stat_tiles(x3, mode, G, Bg, Hi, Wi, Ho, Wo, N);
   if (t > 0) return t;
   const int tp = mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   if (tp > 0) return tp;
@@ -908,6 +929,11 @@ extern "C" int mmdyn_igemm_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, i
  * split tiles (igemm_wsp.hip).  0: none. */
 static int f32_slab_floats(bool x3, int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   if (!ws_enabled()) return 0;
+  if (x3_wsp(x3) && mmdyn_igemm_wsp_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, false) > 0)
+    return (int)(mmdyn_igemm_wsp_slab_bytes(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, false) / 4);
+  if (x3_ws(x3) && mode != MMDYN_TCONV_S1P0 && mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) == 0 &&
+      mmdyn_igemm_ws_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) > 0)
+    return 0;
   if (x3_stat_tiles(x3, mode, G, Bg, Hi, Wi, Ho, Wo, N) > 0) return 0;
   if (mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) > 0) return 0;
   if (mmdyn_igemm_d16_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) > 0) return 0;
@@ -1037,6 +1063,19 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
     const int rc = mmdyn_conv3_nt_try(A, Bp, bias, C, C_act, stats, G, Bg, Hi, Wi, Ho, Wo, N, ldc, act, splitk, bn_y,
                                       bn_mean, bn_rstd, bn_gamma, bn_beta, g.c_b16 << g.f16, g.bny_b16 << g.f16, g.b_b16 << g.f16,
                                       st);
+    if (rc != 1) return rc;
+  }
+  if (!bf16 && mode != MMDYN_IM2COL3 && x3_wsp(x3_allowed)) {     // the persistent ring kernel in the split arithmetic
+    IgemmGeom gx = g;
+    gx.x3 = 1;
+    const int rc = mmdyn_igemm_wsp_try(A, Bp, bias, C, C_act, stats, ws, gx, false, st);
+    if (rc != 1) return rc;
+  }
+  if (!bf16 && mode != MMDYN_IM2COL3 && mode != MMDYN_TCONV_S1P0 && x3_ws(x3_allowed) &&
+      mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) == 0) {      // (LAB experiment: see x3_ws)
+    IgemmGeom gx = g;
+    gx.x3 = 1;
+    const int rc = mmdyn_igemm_ws_try(A, Bp, bias, C, C_act, stats, ws, gx, false, st);
     if (rc != 1) return rc;
   }
   if (!bf16) {        // fp32 through the bf16 matrix cores (three-term operand split)

@@ -52,7 +52,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds, unsi
 typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));     // B16 == 2: the 16-bit storage is IEEE half ("fp16s")
 
-template <int MODE, int BM, int BN, int WM, int WN, int S, int B16>
+// X3 (B16 = 0): the MFMA waves split their fp32 fragments in registers into three bf16 terms and multiply six plane pairs on
+// v_mfma_f32_16x16x32_bf16 (see X3 at igemm_wsp_kernel / igemm_nt_kernel); loaders, ring and epilogue are the fp32 kernel's.
+template <int MODE, int BM, int BN, int WM, int WN, int S, int B16, bool X3 = false>
 __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_kernel(
     const float* __restrict__ A, const float* __restrict__ Bp, const float* __restrict__ bias, float* __restrict__ C,
     float* __restrict__ C_act, float* __restrict__ stats, float* __restrict__ ws, const IgemmGeom g, const unsigned a_bytes,
@@ -243,6 +245,35 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_ws_ke
     for (int k = 0; k < nsteps; ++k) {
       ring_barrier();
       const char* sl = smem + (k % S) * SLOT;
+      if constexpr (X3) {
+        static_assert(B16 == 0, "the three-term split is a variant of the fp32 kernel");
+        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+        bf16x8v ap[3][MT], bp[3][NT];
+        auto split_frag = [&](const char* base, bf16x8v& hi, bf16x8v& mid, bf16x8v& lo) {
+          const f32x4v x0 = *reinterpret_cast<const f32x4v*>(base + foff0);
+          const f32x4v x1 = *reinterpret_cast<const f32x4v*>(base + foff1);
+          uint32_t h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+          split3_bf16(x0[0], x0[1], h0, m0, l0);
+          split3_bf16(x0[2], x0[3], h1, m1, l1);
+          split3_bf16(x1[0], x1[1], h2, m2, l2);
+          split3_bf16(x1[2], x1[3], h3, m3, l3);
+          hi = __builtin_bit_cast(bf16x8v, (u32x4v){h0, h1, h2, h3});
+          mid = __builtin_bit_cast(bf16x8v, (u32x4v){m0, m1, m2, m3});
+          lo = __builtin_bit_cast(bf16x8v, (u32x4v){l0, l1, l2, l3});
+        };
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) split_frag(sl + bbase + nt * TS * RB, bp[0][nt], bp[1][nt], bp[2][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) split_frag(sl + abase + mt * TS * RB, ap[0][mt], ap[1][mt], ap[2][mt]);
+        constexpr int order[6][2] = {{0, 2}, {2, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 0}};      // (plane of A, plane of B), smallest first
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[order[t][0]][mt], bp[order[t][1]][nt], acc[mt][nt], 0, 0, 0);
+      } else
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int fo = q ? foff1 : foff0;
@@ -452,6 +483,19 @@ static int ws_launch(const float* A, const float* Bp, const float* bias, float* 
     grid = dim3((unsigned)8 * ((s_inner + nparts - 1) / nparts) * g.splitk);
   }
   const size_t smem = (size_t)S * (BM + BN) * RB + (size_t)BM * 16;
+#ifdef MMDYN_LAB
+  // (LAB experiment, MMDYN_X3_WS=1 at igemm_entry: measured no better than the register-staged split kernels on the step -- the
+  //  64x64 ring is balanced against its loaders, which the split does not speed up; docs/LAB_NOTES.md F.g)
+  if constexpr (B16 == 0) {
+    if (g.x3) {            // fp32 on the bf16 matrix cores (three-term split in the MFMA waves)
+      static LdsOptIn x3_opt_in;
+      if (int e = x3_opt_in.ensure((const void*)igemm_ws_kernel<MODE, BM, BN, WM, WN, S, 0, true>, (int)smem)) return e;
+      hipLaunchKernelGGL((igemm_ws_kernel<MODE, BM, BN, WM, WN, S, 0, true>), grid, dim3(64 * (NM + NL)), smem, st, A, Bp, bias, C,
+                         C_act, stats, ws, g, a_bytes, b_bytes);
+      MMDYN_LAUNCH_CHECK();
+    }
+  }
+#endif
   static LdsOptIn lds_opt_in;        // (per kernel instance; per device inside)
   if (int e = lds_opt_in.ensure((const void*)igemm_ws_kernel<MODE, BM, BN, WM, WN, S, B16>, (int)smem)) return e;
   hipLaunchKernelGGL((igemm_ws_kernel<MODE, BM, BN, WM, WN, S, B16>), grid, dim3(64 * (NM + NL)), smem, st, A, Bp, bias, C, C_act,

@@ -292,7 +292,12 @@ __device__ __forceinline__ void wsp_epilogue(f32x4v (&acc)[WM / 16][WN / 16], co
   }
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, int S, int B16, bool DIAG = false>
+// X3 (B16 = 0: fp32 operands in HBM and in the ring): the MFMA waves split their fp32 fragments in registers into three bf16
+// terms (split3_bf16, common.h) and multiply six of the nine plane pairs on v_mfma_f32_16x16x32_bf16 -- the fp32 product at 6/16 of
+// the fp32 matrix time (see X3 at igemm_nt_kernel).  The fragment reads are the fp32 kernel's own: lane (row l&15, quarter h)
+// holds the granules h and 4 + h of its row, i.e. eight channels of the 32-deep K-step, and the bf16 MFMA only needs A and B lanes
+// of equal h to hold the SAME eight channels in the same order.  Loaders, ring, scheduling and epilogue are unchanged.
+template <int MODE, int BM, int BN, int WM, int WN, int S, int B16, bool DIAG = false, bool X3 = false>
 __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_kernel(
     const float* __restrict__ A, const float* __restrict__ Bp, const float* __restrict__ bias, float* __restrict__ C,
     float* __restrict__ C_act, float* __restrict__ stats, float* __restrict__ slabs, const IgemmGeom g, const WspSched sc,
@@ -306,6 +311,7 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
   constexpr int SLOT = (BM + BN) * RB;
   constexpr int TS = 16, MT = WM / TS, NT = WN / TS;
   constexpr int WAVES_N = BN / WN;
+  static_assert(!X3 || B16 == 0, "the three-term split is a variant of the fp32 kernel");
   constexpr int ESZ = B16 ? 2 : 4;
   constexpr int KB = RB / ESZ;                     // channels per K-step
 
@@ -477,6 +483,34 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
       }
       const char* sl = smem + cslot * SLOT;
       cslot = cslot + 1 == S ? 0 : cslot + 1;
+      if constexpr (X3) {
+        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+        bf16x8v ap[3][MT], bp[3][NT];
+        auto split_frag = [&](const char* base, bf16x8v& hi, bf16x8v& mid, bf16x8v& lo) {
+          const f32x4v x0 = *reinterpret_cast<const f32x4v*>(base + foff0);
+          const f32x4v x1 = *reinterpret_cast<const f32x4v*>(base + foff1);
+          uint32_t h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+          split3_bf16(x0[0], x0[1], h0, m0, l0);
+          split3_bf16(x0[2], x0[3], h1, m1, l1);
+          split3_bf16(x1[0], x1[1], h2, m2, l2);
+          split3_bf16(x1[2], x1[3], h3, m3, l3);
+          hi = __builtin_bit_cast(bf16x8v, (u32x4v){h0, h1, h2, h3});
+          mid = __builtin_bit_cast(bf16x8v, (u32x4v){m0, m1, m2, m3});
+          lo = __builtin_bit_cast(bf16x8v, (u32x4v){l0, l1, l2, l3});
+        };
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) split_frag(sl + bbase + nt * TS * RB, bp[0][nt], bp[1][nt], bp[2][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) split_frag(sl + abase + mt * TS * RB, ap[0][mt], ap[1][mt], ap[2][mt]);
+        constexpr int order[6][2] = {{0, 2}, {2, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 0}};      // (plane of A, plane of B), smallest first
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[order[t][0]][mt], bp[order[t][1]][nt], acc[mt][nt], 0, 0, 0);
+      } else
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int fo = q ? foff1 : foff0;
@@ -708,6 +742,24 @@ static bool has_split_tiles(const IgemmGeom& g, const WspSched& sc) { return g.m
 template <int MODE, int BM, int BN, int WM, int WN, int S, int B16>
 static int wsp_launch(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
                       IgemmGeom g, const WspSched& sc, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  if constexpr (B16 == 0 && S == 3) {
+    if (g.x3) {            // fp32 on the bf16 matrix cores (three-term split in the MFMA waves)
+      constexpr int NMx = (BM / WM) * (BN / WN);
+      g.tiles_per_group = MODE == MMDYN_TCONV_S1P0 ? 64 * sc.spg : ceil_div(g.Bg * g.Hr * g.Wr, BM);
+      const int nblkx = (sc.units + sc.per - 1) / sc.per;
+      const size_t smemx = (size_t)S * (BM + BN) * RB + (size_t)NRO * BM * sizeof(int) + (size_t)NMx * 16 * TRLD * sizeof(float);
+      static LdsOptIn x3_opt_in;
+      if (int e = x3_opt_in.ensure((const void*)igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, 0, false, true>, (int)smemx)) return e;
+      const bool splitx = has_split_tiles(g, sc);
+      if (splitx && !slabs) return MMDYN_ERR_NULL;
+      hipLaunchKernelGGL((igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, 0, false, true>), dim3(nblkx), dim3(64 * (NMx + NL)), smemx, st, A,
+                         Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes);
+      if (splitx)
+        hipLaunchKernelGGL((igemm_wsp_fixup_kernel<MODE, BM, BN, WM, WN, 0>), dim3(sc.tiles), dim3(64 * NMx), 0, st, bias, C, C_act,
+                           stats, slabs, g, sc);
+      MMDYN_LAUNCH_CHECK();
+    }
+  }
   constexpr int NM = (BM / WM) * (BN / WN);
   // (partial-sum slots per group: M-tiles x classes; TCONV_S1P0: output pixels x sample tiles)
   g.tiles_per_group = MODE == MMDYN_TCONV_S1P0 ? 64 * sc.spg : ceil_div(g.Bg * g.Hr * g.Wr, BM);

@@ -439,10 +439,12 @@ def test_x3_linear_forward_and_weight_gradient(x3, rows, K, N):
     assert relg(gW_hip, dy.double().t() @ x.double()) < 5e-6
 
 
-def test_x3_batchnorm_backward_epilogue_matches_the_native_launch(x3):
+@pytest.mark.parametrize("G,Bg,Hi,Cin,Ho,N", [(4, 64, 32, 32, 16, 64), (4, 256, 16, 64, 8, 128)])
+def test_x3_batchnorm_backward_epilogue_matches_the_native_launch(x3, G, Bg, Hi, Cin, Ho, N):
     """The input-gradient GEMM with the BatchNorm + Swish backward in its epilogue and the per-tile sums it leaves: the split launch
-    against the native one on the same data (both were checked against autograd above)."""
-    mode, G, Bg, Hi, Cin, Ho, N = CONV, 4, 64, 32, 32, 16, 64
+    against the native one on the same data (both were checked against autograd above).  First shape: the register-staged split
+    kernel; second: the persistent ring kernel with the split in its MFMA waves."""
+    mode = CONV
     Bt, rows = G * Bg, G * Bg * Ho * Ho
     A, Bp = rnd(Bt * Hi * Hi, Cin, seed=20).to(DEV), rnd(16, N, Cin, seed=21, scale=0.1).to(DEV)
     y = rnd(rows, N, seed=22).to(DEV)
