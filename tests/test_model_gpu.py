@@ -349,7 +349,8 @@ def test_bf16_storage_engine_vs_oracle(B):
     assert float(l) < loss0
 
 
-def test_full_size_properties_b256():
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_full_size_properties_b256(precision):
     """BASELINE batch (256): properties that need no CPU run of the same size --
     (i) the total equals the sum of the 7 partial ELBOs; (ii) replaying the same step from the same state and
     noise is bit-reproducible (no atomics on the data path except the fp64 loss sums); (iii) gradients are
@@ -361,7 +362,7 @@ def test_full_size_properties_b256():
     losses = []
     for rep in range(2):
         m = T.build("cnn-mvae", True, True, DEV)
-        step = MVAEStep(m, noise=NoiseSource(7))
+        step = MVAEStep(m, noise=NoiseSource(7), precision=precision)
         run = []
         for s in range(4):
             loss = step.train_step(gi, gt, klw)
@@ -373,16 +374,19 @@ def test_full_size_properties_b256():
     assert losses[0][-1] < losses[0][0]
 
 
-def test_graph_replay_equals_eager_steps():
+@pytest.mark.parametrize("B,precision", [(16, "fp32"), (256, "fp32x3")])
+def test_graph_replay_equals_eager_steps(B, precision):
     """The HIP-graph replay of the fused step is the same computation as the eager launches: identical losses over
-    several optimiser steps from the same state and the same Philox stream, and fresh noise on every replay."""
-    B, klw = 16, 0.02
+    several optimiser steps from the same state and the same Philox stream, and fresh noise on every replay.
+    (fp32x3 at the BASELINE batch: the split kernels -- persistent, register-staged and weight-gradient -- inside captured graphs on
+    three streams.)"""
+    klw = 0.02
     inputs, targets = seeded_batch(B, 5)
     gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
     runs = []
     for graphed in (False, True):
         m = T.build("cnn-mvae", True, True, DEV)
-        step = MVAEStep(m, noise=NoiseSource(11))
+        step = MVAEStep(m, noise=NoiseSource(11), precision=precision)
         losses = []
         for s in range(5):
             loss = step.train_step_graphed(gi, gt, klw) if graphed else step.train_step(gi, gt, klw)
