@@ -485,7 +485,7 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
       cslot = cslot + 1 == S ? 0 : cslot + 1;
       if constexpr (X3) {
         typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-        bf16x8v ap[3][MT], bp[3][NT];
+        bf16x8v bp[3][NT];
         auto split_frag = [&](const char* base, bf16x8v& hi, bf16x8v& mid, bf16x8v& lo) {
           const f32x4v x0 = *reinterpret_cast<const f32x4v*>(base + foff0);
           const f32x4v x1 = *reinterpret_cast<const f32x4v*>(base + foff1);
@@ -500,16 +500,18 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
         };
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) split_frag(sl + bbase + nt * TS * RB, bp[0][nt], bp[1][nt], bp[2][nt]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) split_frag(sl + abase + mt * TS * RB, ap[0][mt], ap[1][mt], ap[2][mt]);
+        // one A fragment's planes live at a time (all of them at once: 256 registers and a spill on the 64x64 wave tile)
         constexpr int order[6][2] = {{0, 2}, {2, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 0}};      // (plane of A, plane of B), smallest first
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int mt = 0; mt < MT; ++mt) {
+          bf16x8v ap[3];
+          split_frag(sl + abase + mt * TS * RB, ap[0], ap[1], ap[2]);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
+          for (int t = 0; t < 6; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[order[t][0]][mt], bp[order[t][1]][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[order[t][0]], bp[order[t][1]][nt], acc[mt][nt], 0, 0, 0);
+        }
       } else
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -803,6 +805,14 @@ static int wsp_launch_mode(const float* A, const float* Bp, const float* bias, f
       return wsp_launch<MODE, 128, 128, 64, 32, 4, B16>(A, Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
   }
 #endif
+  if constexpr (B16 == 0) {
+    // the split arithmetic runs FOUR MFMA waves of 64x64 instead of eight of 64x32: a wave then splits 64 fragment values for 96
+    // MFMAs instead of 48 for 48 (3.7 instead of 5.5 VALU operations per MFMA; one MFMA wave per SIMD): x1.06-1.09 on the launches it
+    // serves, step 5.81 -> 5.74 ms on one box (profiles/r4/step_ab_x3_persistent_wave_tile.txt).  LAB: MMDYN_X3_WSP_W64=0 = eight waves.
+    const char* e = lab_env("MMDYN_X3_WSP_W64");
+    if (g.x3 && p.bn == 128 && !(e && e[0] == '0'))
+      return wsp_launch<MODE, 128, 128, 64, 64, 3, B16>(A, Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
+  }
   if (p.bn == 128) return wsp_launch<MODE, 128, 128, 64, 32, 3, B16>(A, Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
   if constexpr (MODE != MMDYN_TCONV_S1P0)
     return wsp_launch<MODE, 128, 64, 64, 32, 3, B16>(A, Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
