@@ -163,7 +163,8 @@ int mmdyn_wgrad_tn_grouped(const void* D, const void* Gt, float* partial, int G,
 int mmdyn_wgrad_out3_bn(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                         const float* Gt, float* partial, int G, int Bg, int Hr, int chunks, int y_b16, void* stream);
 int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg);
-/* ... for the kernel the storage flags of mmdyn_wgrad_tn_mx select (both operands 16-bit in HBM: the all-16-bit kernels' tiles) */
+/* ... for the kernel the flags of mmdyn_wgrad_tn_mx select (both operands 16-bit in HBM: the all-16-bit kernels' tiles; bit 7
+ * alone: the three-term-split kernels, whose LDS planes let fewer blocks share a CU) */
 int mmdyn_wgrad_chunks_mx(int mode, int rows, int Cd, int Cg, int flags);
 int mmdyn_wgrad_reduce(const float* partial, float* canon, int chunks, int taps, int Cd, int Cg,
                        int cg_canon, int perm, float beta, void* stream);

@@ -1205,7 +1205,8 @@ extern "C" int mmdyn_wgrad_tn_f16(const float* D, const float* Gt, float* partia
 
 // recommended number of partial slabs: ~768 blocks in flight, at least 128 rows per block
 // b16_storage: both operands are 16-bit in HBM (the wgrad_b16 kernels: their own tiles)
-static int wgrad_chunks_impl(int mode, int rows, int Cd, int Cg, bool b16_storage) {
+// x3: the launch may take the three-term split (flag bit 7): its tiles hold three bf16 planes in LDS, so fewer blocks fit a CU
+static int wgrad_chunks_impl(int mode, int rows, int Cd, int Cg, bool b16_storage, bool x3 = false) {
   if (Cd % 32 || Cg % 32 || rows <= 0) return MMDYN_ERR_SHAPE;
   int bd, bg, wk;
   if (Cd % 128 == 0 && Cg % 128 == 0) { bd = 128; bg = 128; wk = 1; }
@@ -1221,6 +1222,12 @@ static int wgrad_chunks_impl(int mode, int rows, int Cd, int Cg, bool b16_storag
     wk = 1;
   }
   long target = 768;      // blocks in flight (whole-step sweep after the fetch fixes: 768 beats 512 / 1024 in all three precisions)
+  if (x3 && mode != MMDYN_IM2COL3) {
+    // the split kernels: 61 KB of LDS per 128x128 tile = two blocks per CU, so 768 blocks would run as one and a half rounds;
+    // step sweep in that arithmetic (profiles/r4/step_ab_x3_wgrad_blocks.txt): 512 beats 384 / 768 / 1024 / 1536 (5.67 against
+    // 5.78 ms at 768; 256 x the blocks per CU of each tile: 5.67), and the slab reduction has a third less to read
+    target = 512;
+  }
   if (const char* ov = lab_env("MMDYN_WGRAD_BLOCKS")) target = atol(ov);   // kernel experiments only
   if (mode == MMDYN_IM2COL3) {            // conv3_wgrad: one block (four waves, one slab) per chunk
     tiles = 1;
@@ -1238,7 +1245,7 @@ static int wgrad_chunks_impl(int mode, int rows, int Cd, int Cg, bool b16_storag
 extern "C" int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg) { return wgrad_chunks_impl(mode, rows, Cd, Cg, false); }
 /* flags as mmdyn_wgrad_tn_mx: the count for the kernel those storage flags select */
 extern "C" int mmdyn_wgrad_chunks_mx(int mode, int rows, int Cd, int Cg, int flags) {
-  return wgrad_chunks_impl(mode, rows, Cd, Cg, (flags & 6) == 6);
+  return wgrad_chunks_impl(mode, rows, Cd, Cg, (flags & 6) == 6, (flags & 128) != 0 && !(flags & 1));
 }
 
 extern "C" int mmdyn_wgrad_reduce(const float* partial, float* canon, int chunks, int taps, int Cd, int Cg,

@@ -145,7 +145,7 @@ class HipBackend:
 
     def wgrad_chunks(self, mode, rows, Cd, Cg):
         # (16-bit storage modes: the all-16-bit weight-gradient kernels keep their own tile rule)
-        r = self.lib.mmdyn_wgrad_chunks_mx(mode, rows, Cd, Cg, 7 if self.precision in ("bf16s", "fp16s") else 0)
+        r = self.lib.mmdyn_wgrad_chunks_mx(mode, rows, Cd, Cg, 7 if self.precision in ("bf16s", "fp16s") else self._x3())
         if r < 0:
             check(r, "mmdyn_wgrad_chunks_mx")
         return r
