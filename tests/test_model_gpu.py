@@ -404,6 +404,13 @@ def test_extended_image_sizes_vs_oracle(size, B, use_pose):
     T.check_extended_size_vs_oracle(DEV, size, B, use_pose, n_steps=2)
 
 
+@pytest.mark.parametrize("size,B", [(128, 48), (256, 16)])
+def test_fp32x3_extended_sizes_vs_oracle(size, B):
+    """The 128 / 256 pixel stacks in the "fp32x3" arithmetic (their 128 x 128 and 256 x 256 layers are where the split's launch rule
+    bites at these batch sizes), at the fp32 mode's tolerances."""
+    T.check_extended_size_vs_oracle(DEV, size, B, True, n_steps=1, precision="fp32x3")
+
+
 @pytest.mark.parametrize("size,B", [(64, 32), (256, 4), (64, 256)])
 def test_fp16_engine_vs_oracle(size, B):
     """fp16 matrix-core operands (v_mfma_f32_32x32x16_f16 / 32x32x8_f16), fp32 accumulate, storage and master weights
