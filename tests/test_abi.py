@@ -57,3 +57,25 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.mmdyn_igemm_nt(None, None, None, None, None, None, None, 0, 1, 1, 1, 1, 32, 1, 1, 32, 32, 1, 0, 0, 1, None) == -2
     assert lib.mmdyn_wgrad_chunks(0, 128, 33, 32) == -1
     assert lib.mmdyn_igemm_stat_tiles(2, 4, 256, 8, 8, 128, 16, 16, 64) > 0
+
+
+def test_split_arithmetic_host_queries_without_a_gpu():
+    """Flag bit 7 ("this fp32 launch may take the three-term split") at the shape queries: host arithmetic only.
+    The weight-gradient cut aims at 512 blocks in flight instead of 768 (the split kernels' LDS planes: two 128x128 blocks per CU);
+    the partial-sum tile count of a launch follows the kernel the flag selects, and a launch the split does not serve answers as
+    the plain fp32 query does."""
+    lib = _lib.load()
+    CONV, TCONV_S2P1, DENSE = 1, 2, 0
+    # conv 128 -> 256 channels on 1024 x 5x5 rows: 2 x 1 tiles x 16 taps = 32 tiles -> 24 slabs natively, 16 with the split
+    assert lib.mmdyn_wgrad_chunks_mx(CONV, 1024 * 25, 256, 128, 0) == 24
+    assert lib.mmdyn_wgrad_chunks_mx(CONV, 1024 * 25, 256, 128, 128) == 16
+    assert lib.mmdyn_wgrad_chunks_mx(CONV, 1024 * 25, 256, 128, 7) == lib.mmdyn_wgrad_chunks_mx(CONV, 1024 * 25, 256, 128, 6)
+    # the persistent kernel keeps its launches (and its tile count) in the split arithmetic
+    native = lib.mmdyn_igemm_stat_tiles(CONV, 4, 256, 16, 16, 64, 8, 8, 128)
+    assert lib.mmdyn_igemm_stat_tiles_mx(CONV, 4, 256, 16, 16, 64, 8, 8, 128, 128) == native
+    assert lib.mmdyn_igemm_slab_floats_mx(CONV, 4, 256, 16, 16, 64, 8, 8, 128, 128) == lib.mmdyn_igemm_slab_floats(CONV, 4, 256, 16, 16, 64, 8, 8, 128)
+    # a large N = 64 launch: the register-staged split kernel on 128x64 tiles (one partial-sum tile per 128 rows and class), no slabs
+    assert lib.mmdyn_igemm_stat_tiles_mx(TCONV_S2P1, 4, 256, 8, 8, 128, 16, 16, 64, 128) == 4 * (256 * 64 // 128)
+    assert lib.mmdyn_igemm_slab_floats_mx(TCONV_S2P1, 4, 256, 8, 8, 128, 16, 16, 64, 128) == 0
+    # too small for the split's launch rule: the plain answer
+    assert lib.mmdyn_igemm_stat_tiles_mx(DENSE, 1, 256, 1, 1, 512, 1, 1, 512, 128) == lib.mmdyn_igemm_stat_tiles(DENSE, 1, 256, 1, 1, 512, 1, 1, 512)
