@@ -253,8 +253,10 @@ def main():
                     help="dyn_modeling (configs[3]): the batch is --seq-length frames per sequence, targets are the next frames "
                          "(DynModeling.parse_input, problems.py:765-803); the step itself is the same computation")
     ap.add_argument("--seq-length", type=int, default=4)
-    ap.add_argument("--dtype", choices=("f32", "f32x3", "bf16", "bf16s", "fp16", "fp16s"), default="f32",
-                    help="f32: the BASELINE configs[1] line (default).  bf16s: bf16 activation storage + bf16 matrix "
+    ap.add_argument("--dtype", choices=("f32", "f32x3", "bf16", "bf16s", "fp16", "fp16s"), default="f32x3",
+                    help="f32x3 (default): BASELINE configs[1] with the fp32 GEMMs on the bf16 matrix cores through the exact "
+                         "three-term split of their fp32 operands (fp32 storage, results and tolerances; the native fp32 run is timed by "
+                         "the same process and reported beside it as native_fp32).  f32: the native fp32 matrix cores.  bf16s: bf16 activation storage + bf16 matrix "
                          "cores, fp32 accumulate / master weights = the per-GPU share of configs[2] (use --batch 128).  "
                          "bf16: bf16 matrix-core operands only (fp32 storage).  fp16: fp16 matrix-core operands, fp32 "
                          "accumulate / storage / master weights (configs[4]).  fp16s: fp16 + fp16 activation storage")
@@ -266,7 +268,8 @@ def main():
                          "direction, captured into the lanes' HIP graphs, each lane on its own RCCL communicator).  Default: "
                          "local statistics")
     ap.add_argument("--no-alt", action="store_true",
-                    help="skip the extra timed run in the fp32x3 arithmetic that a default (f32, one GPU) run reports next to its value")
+                    help="skip the extra timed run in the other fp32 arithmetic (native fp32 beside the default f32x3 line, f32x3 "
+                         "beside --dtype f32) that a one-GPU run reports next to its value")
     ap.add_argument("--infer", action="store_true",
                     help="time forward-only inference instead (model.eval(): joint visual+tactile+pose pass through the "
                          "module API, running-estimate BatchNorm); prints its own JSON line, not the BASELINE metric")
@@ -326,19 +329,23 @@ def main():
     from mmdyn_hip.profiling import profile_step
     from mmdyn_hip.utils.seeded_init import seeded_batch
 
-    torch.manual_seed(0)
     S = args.image_size
-    PREC = {"f32": "fp32", "f32x3": "fp32x3", "bf16": "bf16", "bf16s": "bf16s", "fp16": "fp16", "fp16s": "fp16s"}[args.dtype]
+    PRECS = {"f32": "fp32", "f32x3": "fp32x3", "bf16": "bf16", "bf16s": "bf16s", "fp16": "fp16", "fp16s": "fp16s"}
     assert abs(algo_gflop_per_sample(64) - ALGO_GFLOP_PER_SAMPLE) < 1e-3
     gflop_per_sample = algo_gflop_per_sample(S)
-    model = setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=S * S, architecture="cnn",
-                        conditional=False, categorical_conditions=False, latent_size=256, use_pose=True).to(dev).train()
+
+    def new_model():
+        torch.manual_seed(0)
+        return setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=S * S, architecture="cnn",
+                           conditional=False, categorical_conditions=False, latent_size=256, use_pose=True).to(dev).train()
+
     if args.infer:
+        model = new_model()
         inputs, _ = seeded_batch(args.batch, 1234 + rank, size=S)
         v, t, p = [z.to(dev) for z in inputs]
         from mmdyn_hip.engine import MVAEInference
         model.eval()
-        eng = MVAEInference(model, precision=PREC,
+        eng = MVAEInference(model, precision=PRECS[args.dtype],
                             use_graph=not args.no_graph,
                             seed=1234 + rank)
         for _ in range(args.warmup):
@@ -358,10 +365,7 @@ def main():
                                      "algorithmic_gflop_per_sample": 0.274,
                                      "tflops": args.batch * args.steps / dt * 0.274e9 / 1e12}})
         return
-    step = MVAEStep(model, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), process_group=pg,
-                    world_size=world, two_lanes=not args.single_lane,
-                    precision=PREC, defer_wgrad={"auto": None, "on": True, "off": False}[args.defer_wgrad],
-                    sync_bn=args.sync_bn and pg is not None, group_heads=not args.no_grouped_heads)
+
     inputs, targets = seeded_batch(args.batch, 1234 + rank, size=S)
     inputs, targets = [x.to(dev) for x in inputs], [x.to(dev) for x in targets]
     if args.problem == "dyn_modeling":
@@ -376,40 +380,147 @@ def main():
         for k in (0, 1):
             targets[k][Lq - 1::Lq] = final[k][Lq - 1::Lq]
 
-    def eager_step():
-        return step.train_step(inputs, targets, KL_WEIGHT)
+    def measure(dtype, with_pg):
+        """W warm-up + K timed steps of the workload in one arithmetic (between barrier + synchronize, max over ranks), then
+        the per-kernel HIP-event profile of one more (untimed, single-lane, eager) step.  Same seeds for every arithmetic."""
+        model = new_model()
+        step = MVAEStep(model, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), process_group=pg if with_pg else None,
+                        world_size=world if with_pg else 1, two_lanes=not args.single_lane,
+                        precision=PRECS[dtype], defer_wgrad={"auto": None, "on": True, "off": False}[args.defer_wgrad],
+                        sync_bn=args.sync_bn and pg is not None and with_pg, group_heads=not args.no_grouped_heads)
 
-    def one_step():
-        if args.no_graph:
+        def eager_step():
             return step.train_step(inputs, targets, KL_WEIGHT)
-        return step.train_step_graphed(inputs, targets, KL_WEIGHT)
 
-    for _ in range(args.warmup):
-        one_step()
-    sync()
-    if pg is not None:
-        dist.barrier()
-        sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    host_enqueue = time.perf_counter() - t0      # host side done enqueueing; the GPU is still running if it is ahead
-    sync()
-    if pg is not None:
-        dist.barrier()
-        sync()
-    elapsed = time.perf_counter() - t0
-    if pg is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-    final_loss = float(loss)
+        def one_step():
+            if args.no_graph:
+                return step.train_step(inputs, targets, KL_WEIGHT)
+            return step.train_step_graphed(inputs, targets, KL_WEIGHT)
 
-    # per-kernel timing of one extra (untimed) step, HIP events on the launch stream
-    # (one lane, eager launches: per-kernel durations are then not inflated by the other lane's kernels)
-    lanes_on, step.lanes.on = step.lanes.on, False
-    kern = {} if dry else profile_step(eager_step)
-    step.lanes.on = lanes_on
+        for _ in range(args.warmup):
+            one_step()
+        sync()
+        if pg is not None and with_pg:
+            dist.barrier()
+            sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = one_step()
+        host_enqueue = time.perf_counter() - t0      # host side done enqueueing; the GPU is still running if it is ahead
+        sync()
+        if pg is not None and with_pg:
+            dist.barrier()
+            sync()
+        elapsed = time.perf_counter() - t0
+        if pg is not None and with_pg:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t)
+        res = {"dtype": dtype, "elapsed": elapsed, "host_enqueue": host_enqueue, "final_loss": float(loss)}
+        # per-kernel timing of one extra (untimed) step, HIP events on the launch stream (one lane, eager launches: per-kernel
+        # durations are then not inflated by the other lane's kernels).  The step is profiled TWICE and the second pass is
+        # kept: the first eager step after the graph replays draws its scratch tensors (stream-K slabs, partial-sum tables)
+        # from the default memory pool for the first time, and that allocation sits between the two events of the launch that
+        # asked for it (the k4 s1 p0 layer read 282 us by events against 204 us in the rocprofv3 trace of the same run:
+        # VERDICT r4, profiles/r5/event_vs_trace_s1p0.txt)
+        lanes_on, step.lanes.on = step.lanes.on, False
+        kern, by_shape = {}, {}
+        if not dry:
+            profile_step(eager_step)
+            kern = profile_step(eager_step)
+            by_shape = dict(profile_step.by_shape)
+        step.lanes.on = lanes_on
+        res["kern"], res["by_shape"] = kern, by_shape
+        step.close()
+        del step, model
+        if not dry:
+            torch.cuda.empty_cache()
+        return res
+
+    def roofline_of(res, sps):
+        """The `roofline` object of one measured arithmetic: the dominant MFMA kernel family by live HIP events against the
+        dense peak of the matrix pipe it runs on, the committed PMC traffic of the same workload beside it."""
+        dtype, kern = res["dtype"], res["kern"]
+        ig = kern.get("igemm_nt", {"ms": 0.0, "flops": 0.0, "calls": 0, "bytes": 0.0})
+        wg = kern.get("wgrad_tn", {"ms": 0.0, "flops": 0.0, "calls": 0, "bytes": 0.0})
+        dom = ig if ig["ms"] >= wg["ms"] else wg
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        total_ms = sum(d["ms"] for d in kern.values())
+        peak = PEAK_FP32_MFMA_TFLOPS if dtype == "f32" else (PEAK_F16_MFMA_TFLOPS if dtype in ("fp16", "fp16s") else PEAK_BF16_MFMA_TFLOPS)
+        if dtype == "f32x3":
+            # fp32 products as SIX bf16 products of the exact three-term operand split: an algorithmic (fp32) flop costs six flops
+            # of the bf16 matrix pipe, so the ceiling for algorithmic flops is the dense bf16 peak / 6 (2.65 x the native fp32 peak)
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+        # byte side: the committed PMC passes of THIS workload (whole step + the implicit-GEMM launches)
+        wkey = f"s{S}_{dtype}_b{args.batch}_{args.problem}"
+        prof, traffic_note = pmc_traffic(wkey)
+        traffic = prof["hbm_bytes_per_launch"] if (prof and dom is ig) else None
+        step_bytes = (prof["whole_step"]["fetch_bytes"] + prof["whole_step"]["write_bytes"]) if prof else None
+        step_s = res["elapsed"] / args.steps
+        step_hbm_frac = step_bytes / step_s / PEAK_HBM_BYTES_PER_S if step_bytes else None
+        step_mfma_frac = sps / world * gflop_per_sample * 1e9 / 1e12 / peak
+        kern_hbm_frac = (traffic / (dom["ms"] / max(dom["calls"], 1) * 1e-3) / PEAK_HBM_BYTES_PER_S) if traffic and dom["ms"] > 0 else None
+        kern_mfma_frac = achieved / peak
+
+        def bound_of(mfma, hbm):
+            # the resource with the larger share of its peak; "launch" when neither reaches a fifth of its peak: the time then
+            # goes to the chain of dependent launches, not to a roofline resource
+            if hbm is None:           # no byte-side evidence (no committed PMC profile of these sources): claim the MFMA bound only
+                return "mfma" if mfma >= 0.2 else "unknown"      # where the matrix side alone supports it
+            if max(mfma, hbm) < 0.2:
+                return "launch"
+            return "hbm" if hbm > mfma else "mfma"
+        if dom is ig:
+            dom_name = ("implicit-GEMM family: every mmdyn_igemm_nt* entry-point call of the step (" + kernel_mix(res["by_shape"], dtype) + ")")
+        else:
+            dom_name = "weight-gradient family: every mmdyn_wgrad_tn* entry-point call of the step"
+        rl = {"bound": bound_of(kern_mfma_frac, kern_hbm_frac), "kernel": dom_name,
+              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+              "traffic": traffic, "traffic_provenance": traffic_note, "hbm_frac": kern_hbm_frac,
+              "algorithmic_flops_per_launch": dom["flops"] / max(dom["calls"], 1),
+              "operand_bytes_per_launch": dom["bytes"] / max(dom["calls"], 1),
+              "launches_per_step": dom["calls"], "avg_launch_ms": dom["ms"] / max(dom["calls"], 1),
+              "kernel_share_of_step": dom["ms"] / total_ms if total_ms else None,
+              "algorithmic_gflop_per_sample": gflop_per_sample,
+              "step_algorithmic_tflops": sps / world * gflop_per_sample * 1e9 / 1e12,
+              "step_frac_of_peak": step_mfma_frac,
+              "step_hbm_bytes": step_bytes, "step_hbm_frac_of_8TBps": step_hbm_frac,
+              "step_launches": prof["whole_step"]["launches"] if prof else None,
+              "step_bound": bound_of(step_mfma_frac, step_hbm_frac)}
+        if dtype == "f32x3":
+            rl["peak_note"] = ("dense bf16 MFMA peak / 6: every fp32 product is six bf16 products of the exact three-term split "
+                               "(MI355X_MICROARCH.md: ~2.5 PF dense at the 2.4 GHz the chip does not hold on random data -- bf16 loops "
+                               "measure ~1.25 PF there); launches the split does not serve run on the fp32 matrix cores (peak %.1f)"
+                               % PEAK_FP32_MFMA_TFLOPS)
+            rl["frac_of_native_fp32_mfma_peak"] = achieved / PEAK_FP32_MFMA_TFLOPS
+            rl["step_frac_of_native_fp32_mfma_peak"] = sps / world * gflop_per_sample * 1e9 / 1e12 / PEAK_FP32_MFMA_TFLOPS
+        return rl, total_ms
+
+    def kernel_mix(by_shape, dtype):
+        """Which kernels served the implicit-GEMM entry-point calls, asked of the library's own launch rule (host-side shape
+        queries: a launch with stream-K slabs runs the persistent kernel)."""
+        from mmdyn_hip import ops as _ops
+        lib = getattr(_ops.B, "lib", None)
+        n_all = n_wsp = 0
+        for k, d in by_shape.items():
+            if k[0] != "igemm_nt":
+                continue
+            n_all += d["calls"]
+            ints = [x for x in k[1:] if isinstance(x, int)]
+            try:
+                mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N = ints[:9]
+                flags = 128 if dtype == "f32x3" else 0
+                if lib is not None and ints[13] == 1 and lib.mmdyn_igemm_slab_floats_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, flags) > 0:
+                    n_wsp += d["calls"]
+            except Exception:
+                pass
+        arith = " in the three-term split arithmetic where the launch rule selects it" if dtype == "f32x3" else ""
+        return (f"{n_all} calls: {n_wsp} on the persistent stream-K ring kernel igemm_wsp_kernel + its fix-up launch, the rest on "
+                f"the one-tile ring kernel igemm_ws_kernel / the register-staged igemm_nt_kernel{arith}")
+
+    if pg is not None:
+        import torch.distributed as dist
+    primary = measure(args.dtype, True)
     if pg is not None:
         dist.barrier()
     if rank != 0:
@@ -417,44 +528,13 @@ def main():
             dist.destroy_process_group()
         return
 
+    elapsed, final_loss, kern = primary["elapsed"], primary["final_loss"], primary["kern"]
     global_batch = args.batch * world
     sps = global_batch * args.steps / elapsed
-    ig = kern.get("igemm_nt", {"ms": 0.0, "flops": 0.0, "calls": 0, "bytes": 0.0})
-    wg = kern.get("wgrad_tn", {"ms": 0.0, "flops": 0.0, "calls": 0, "bytes": 0.0})
-    dom = ig if ig["ms"] >= wg["ms"] else wg
-    # (the implicit-GEMM entry points are served by igemm_ws_kernel -- the LDS-DMA ring, 36 of the 40 launches of the fp32
-    #  bs-256 step -- and by igemm_nt_kernel, the register-staged form, for the rest)
-    dom_name = "igemm_ws_kernel" if dom is ig else "wgrad_tn_kernel"
-    if args.dtype == "f32x3" and dom is ig:
-        dom_name = "igemm_nt_kernel (X3 instances)"
-    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-    total_ms = sum(d["ms"] for d in kern.values())
-    peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else (PEAK_F16_MFMA_TFLOPS if args.dtype in ("fp16", "fp16s") else PEAK_BF16_MFMA_TFLOPS)
-    if args.dtype == "f32x3":
-        # fp32 products as SIX bf16 products of the exact three-term operand split: an algorithmic (fp32) flop costs six flops of
-        # the bf16 matrix pipe, so the ceiling for algorithmic flops is the dense bf16 peak / 6 (2.65 x the native fp32 peak)
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-    # byte side: the committed PMC passes of THIS workload (whole step + the implicit-GEMM launches)
-    wkey = f"s{S}_{args.dtype}_b{args.batch}_{args.problem}"
-    prof, traffic_note = pmc_traffic(wkey)
-    traffic = prof["hbm_bytes_per_launch"] if (prof and dom is ig) else None
-    step_bytes = (prof["whole_step"]["fetch_bytes"] + prof["whole_step"]["write_bytes"]) if prof else None
-    step_s = elapsed / args.steps
-    step_hbm_frac = step_bytes / step_s / PEAK_HBM_BYTES_PER_S if step_bytes else None
-    step_mfma_frac = sps / world * gflop_per_sample * 1e9 / 1e12 / peak
-    kern_hbm_frac = (traffic / (dom["ms"] / max(dom["calls"], 1) * 1e-3) / PEAK_HBM_BYTES_PER_S) if traffic and dom["ms"] > 0 else None
-    kern_mfma_frac = achieved / peak
-
-    def bound_of(mfma, hbm):
-        # the resource with the larger share of its peak; "launch" when neither reaches a fifth of its peak: the time then
-        # goes to the chain of dependent launches, not to a roofline resource
-        if hbm is None:           # no byte-side evidence (no committed PMC profile of these sources): claim the MFMA bound only
-            return "mfma" if mfma >= 0.2 else "unknown"      # where the matrix side alone supports it
-        if max(mfma, hbm) < 0.2:
-            return "launch"
-        return "hbm" if hbm > mfma else "mfma"
-    arith = {"f32": "fp32", "f32x3": "fp32 storage and results; GEMMs on the bf16 matrix cores through the exact three-term split of "
-                                     "their fp32 operands (six products, fp32 accumulate; error vs fp64 <= native fp32 MFMA)",
+    roof, total_ms = roofline_of(primary, sps)
+    arith = {"f32": "fp32 (native fp32 matrix cores)",
+             "f32x3": "fp32 storage and results, GEMMs in the fp32x3 arithmetic (exact three-term bf16 split of the fp32 operands, "
+                      "six of nine products on the bf16 matrix cores, fp32 accumulate; error vs fp64 <= native fp32 MFMA)",
              "bf16": "bf16 matrix-core operands (fp32 accumulate, storage and master weights)",
              "bf16s": "bf16 activation storage + bf16 matrix-core operands (fp32 accumulate and master weights)",
              "fp16": "fp16 matrix-core operands (fp32 accumulate, storage and master weights)",
@@ -475,91 +555,52 @@ def main():
         "config": {"workload": workload,
                    "global_batch": global_batch, "parallelism": f"dp{world}", "bn": "sync" if (args.sync_bn and pg is not None) else "local",
                    "launch": "eager" if (args.no_graph or (args.sync_bn and pg is not None and dry)) else "hip_graph",
-                   "final_loss": final_loss, "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps},
-        "roofline": {"bound": bound_of(kern_mfma_frac, kern_hbm_frac),
-                     "kernel": dom_name + (" (+ igemm_nt_kernel: every implicit-GEMM launch of the step is counted)"
-                                           if dom is ig else ""),
-                     "achieved": achieved, "peak": peak,
-                     "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": traffic, "traffic_provenance": traffic_note,
-                     "hbm_frac": kern_hbm_frac,
-                     "algorithmic_flops_per_launch": dom["flops"] / max(dom["calls"], 1),
-                     "operand_bytes_per_launch": dom["bytes"] / max(dom["calls"], 1),
-                     "launches_per_step": dom["calls"], "avg_launch_ms": dom["ms"] / max(dom["calls"], 1),
-                     "kernel_share_of_step": dom["ms"] / total_ms if total_ms else None,
-                     "algorithmic_gflop_per_sample": gflop_per_sample,
-                     "step_algorithmic_tflops": sps / world * gflop_per_sample * 1e9 / 1e12,
-                     "step_frac_of_peak": step_mfma_frac,
-                     "step_hbm_bytes": step_bytes, "step_hbm_frac_of_8TBps": step_hbm_frac,
-                     "step_launches": prof["whole_step"]["launches"] if prof else None,
-                     "step_bound": bound_of(step_mfma_frac, step_hbm_frac)},
+                   "final_loss": final_loss, "host_enqueue_ms_per_step": 1e3 * primary["host_enqueue"] / args.steps},
+        "roofline": roof,
     }
-    if args.dtype == "f32x3":
-        out["roofline"]["peak_note"] = ("dense bf16 MFMA peak / 6: every fp32 product is six bf16 products of the three-term split; "
-                                        "launches the split does not serve run on the fp32 matrix cores (peak %.1f)" % PEAK_FP32_MFMA_TFLOPS)
-        out["roofline"]["frac_of_native_fp32_mfma_peak"] = achieved / PEAK_FP32_MFMA_TFLOPS
-    if dom is ig and args.dtype in ("f32", "bf16s", "fp16s"):
-        # What the ring kernels' operand path was measured to do (round 4, cache counters per launch shape:
-        # profiles/r4/cache_by_launch_f32.txt; LAB_NOTES E).  Round 3 called 7.5 TB/s "the Infinity-Cache LDS-fill rate" and
-        # priced the kernels against it; the counters say otherwise: the fp32 64x64 launches fill at ~7.3 TB/s with 0.87-0.93
-        # of their L1 misses HITTING L2 at 170-250 cycles average latency (~2.6 KB in flight per CU), and cutting the L2 misses
-        # of a launch by 18 % (tap order, profiles/r4/ab_taporder*.txt) moves its time by 1 %.  The rate is this kernel
-        # structure's LDS-DMA issue rate (one 1-KiB piece per ~58 cycles per CU with six loader waves), NOT a property of the
-        # cache level that serves the fills -- the hardware guide's L2-served fill rate is 16.8-18.8 TB/s.  Reported as an
-        # observation, not as a roofline.
-        fpb = 16.0 if args.dtype == "f32" else 32.0
-        out["roofline"]["lds_fill_path"] = {
-            "tile": "64x64 one-tile-per-block ring kernel (most implicit-GEMM launches of the step; the six largest run 128x128 persistent tiles at 32 flop per filled byte)", "flop_per_filled_byte": fpb,
-            "observed_fill_rate_TBps": 7.3, "l2_hit_rate_of_fills": [0.87, 0.93],
-            "avg_l1_to_l2_read_latency_cycles": [170, 250],
-            "tflops_at_observed_fill_rate": fpb * 7.3, "achieved_over_that": achieved / (fpb * 7.3),
-            "is_a_hardware_ceiling": False,
-            "source": "profiles/r4/cache_by_launch_f32.txt (TCC_HIT/MISS, TCP_TCC_READ_REQ(_LATENCY) per launch shape); "
-                      "profiles/r4/ab_taporder.txt + ab_taporder_l2_hit_rates.txt; MI355X_MICROARCH.md 'Indexed rows: gather into LDS'"}
     if rehearse:
         out["rehearsal"] = "all ranks on ONE GPU, collectives over gloo (MMDYN_BENCH_REHEARSE_ONE_GPU=1): schedule check, not a scaling number"
     if dry:
         out["dry_run"] = "CPU rehearsal with emulated kernels (MMDYN_BENCH_DRYRUN=emu): control flow only, numbers meaningless"
-    if args.breakdown:
-        for k, d in sorted(kern.items(), key=lambda kv: -kv[1]["ms"]):
+
+    def print_breakdown(res, title):
+        k2, tot = res["kern"], sum(d["ms"] for d in res["kern"].values())
+        print(f"---- {title} ----", file=sys.stderr)
+        for k, d in sorted(k2.items(), key=lambda kv: -kv[1]["ms"]):
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 and d["flops"] else 0.0
             gb = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
             print(f"{k:24s} calls {d['calls']:4d}  {d['ms']:8.3f} ms  {tf:7.2f} TFLOP/s  {gb:8.1f} GB/s(args)", file=sys.stderr)
-        print(f"sum of kernel time {total_ms:.3f} ms vs step {1e3 * elapsed / args.steps:.3f} ms", file=sys.stderr)
+        print(f"sum of kernel time {tot:.3f} ms vs step {1e3 * res['elapsed'] / args.steps:.3f} ms", file=sys.stderr)
         print("per-shape MFMA launches: name, (mode,G,Bg,Hi,Wi,Cin,Ho,Wo,N,ldc,stride,offset,act,splitk) | "
               "(mode,Bt,Hr,Wr,Cd,Hi,Wi,Cg,stride,offset,chunks)", file=sys.stderr)
-        for k, d in sorted(profile_step.by_shape.items(), key=lambda kv: -kv[1]["ms"]):
+        for k, d in sorted(res["by_shape"].items(), key=lambda kv: -kv[1]["ms"]):
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
             print(f"  {k[0]:9s} {str(k[1:]):70s} x{d['calls']:2d} {d['ms']:7.3f} ms {tf:6.1f} TF/s", file=sys.stderr)
-    if world == 1 and args.dtype == "f32" and not args.no_alt and not dry and not args.no_graph:
-        # The same workload, same seeds, in the engine's "fp32x3" arithmetic (fp32 storage and results; the GEMMs on the bf16 matrix
-        # cores through the exact three-term operand split, csrc/igemm_nt.hip X3) -- timed like `value` (W warm-up + K graph-replayed
-        # steps between synchronisations), reported NEXT to it: `value` above is the native fp32 matrix-core arithmetic.
-        del step
-        torch.cuda.empty_cache()
-        torch.manual_seed(0)
-        model3 = setup_model("cnn-mvae", cross_modal=True, condition_dim=0, input_dim=S * S, architecture="cnn",
-                             conditional=False, categorical_conditions=False, latent_size=256, use_pose=True).to(dev).train()
-        step3 = MVAEStep(model3, lr=1e-3, pose_multiplier=1000.0, noise=NoiseSource(1234 + rank), two_lanes=not args.single_lane,
-                         precision="fp32x3", defer_wgrad={"auto": None, "on": True, "off": False}[args.defer_wgrad],
-                         group_heads=not args.no_grouped_heads)
-        for _ in range(args.warmup):
-            step3.train_step_graphed(inputs, targets, KL_WEIGHT)
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss3 = step3.train_step_graphed(inputs, targets, KL_WEIGHT)
-        sync()
-        dt3 = time.perf_counter() - t0
-        out["alt_arithmetic"] = {
-            "name": "fp32x3", "value": args.batch * args.steps / dt3, "unit": "samples/s", "ms_per_step": 1e3 * dt3 / args.steps,
-            "final_loss": float(loss3), "final_loss_native_fp32": final_loss,
-            "what": "fp32 operands split exactly into three bf16 terms (round-to-nearest), six of the nine cross products on "
-                    "v_mfma_f32_32x32x16_bf16, fp32 accumulate; dropped terms < 2^-23 |a||b| per product (less than one fp32 rounding); "
-                    "error against fp64 no larger than the native fp32 matrix cores' (profiles/r4/ab_x3_*.txt); same oracle "
-                    "tolerances (tests/test_model_gpu.py::test_fused_engine_vs_oracle[*-fp32x3]); python bench.py --dtype f32x3 "
-                    "makes it the measured arithmetic"}
-        del step3, model3
+
+    if args.breakdown:
+        print_breakdown(primary, f"{args.dtype} (the measured arithmetic)")
+    if world == 1 and args.dtype in ("f32", "f32x3") and not args.no_alt and not dry and not args.no_graph:
+        # The same workload, same seeds, in the OTHER fp32 arithmetic, timed the same way by the same process on the same box and
+        # reported NEXT to `value` with its own roofline: native fp32 matrix cores beside the default fp32x3 line (VERDICT r4
+        # item 2), or fp32x3 beside an explicit --dtype f32 run.
+        other = "f32" if args.dtype == "f32x3" else "f32x3"
+        sec = measure(other, False)
+        sps2 = args.batch * args.steps / sec["elapsed"]
+        roof2, _ = roofline_of(sec, sps2)
+        obj = {"dtype": other, "value": sps2, "unit": "samples/s", "ms_per_step": 1e3 * sec["elapsed"] / args.steps,
+               "final_loss": sec["final_loss"], "roofline": roof2}
+        if other == "f32":
+            obj["what"] = ("the same workload on the native fp32 matrix cores (v_mfma_f32_16x16x4_f32 / 32x32x2_f32, peak 157.3 TFLOP/s): "
+                           "python bench.py --dtype f32 makes it the measured arithmetic")
+            out["native_fp32"] = obj
+            out["speedup_over_native_fp32"] = sps / sps2
+        else:
+            obj["name"] = "fp32x3"
+            obj["what"] = ("fp32 operands split exactly into three bf16 terms (round-to-nearest), six of the nine cross products on "
+                           "the bf16 matrix cores, fp32 accumulate; the default arithmetic of bench.py")
+            out["alt_arithmetic"] = obj
+        if args.breakdown:
+            print_breakdown(sec, other)
     if world == 1 and not args.no_cpu_baseline:
         # torch.set_num_threads(os.cpu_count()).  On a box whose CPU share is smaller than the
         # machine (the one-GPU box: 16 of 256 hardware threads, no visible quota) the figure at the documented share is

@@ -49,6 +49,13 @@ extern "C" {
                                   exactly the useful MACs, no zero padding, no column matrix */
 
 const char* mmdyn_version(void);
+/* ABI revision of this header.  It changes whenever an exported signature or a workspace requirement changes (round 4 added
+ * the `ws` argument of mmdyn_igemm_nt_dgrad_act / _dgrad_bn and the slab workspace of large launches: revision 4; round 5 the
+ * plane-packed weight kinds of the pack plan: revision 5).  A binding checks mmdyn_abi_version() == MMDYN_ABI_VERSION right after
+ * loading the library (mmdyn_hip/_lib.py does) so that a caller built against an older header fails at load time instead of
+ * passing its stream handle where the library now expects a workspace pointer. */
+#define MMDYN_ABI_VERSION 5
+int mmdyn_abi_version(void);
 
 /* ---- MFMA implicit GEMM, "NT" form ---------------------------------------------------------
  * C[row][n] = act( sum_{tap,ci} A_tap[row][ci] * Bp[widx(tap)][n][ci] + bias[n] )
@@ -61,6 +68,10 @@ const char* mmdyn_version(void);
  *   stats  : optional per-tile BatchNorm partial sums [G][T][2][N], T = mmdyn_igemm_stat_tiles(...)
  *   splitk : >1 only for DENSE: partial products go to `ws` ([splitk][rows][N]) and
  *            mmdyn_splitk_reduce finishes (bias/act/second output are applied there).
+ *   ws     : with splitk == 1 the LARGE launches (persistent stream-K kernel, csrc/igemm_wsp.hip) park the pieces of tiles
+ *            that straddle two blocks there: ws must hold mmdyn_igemm_slab_floats(...) floats whenever that query answers
+ *            > 0 (MMDYN_ERR_NULL otherwise); NULL is fine when it answers 0.  Same rule for mmdyn_igemm_nt_mx
+ *            (mmdyn_igemm_slab_floats_mx).
  * Requirements: Cin % 32 == 0, N % 32 == 0.  v_mfma_f32_32x32x2_f32, fp32 in / fp32 accumulate. */
 int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
                    float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
@@ -423,6 +434,13 @@ int mmdyn_resize_u8_to_chw_f32(const uint8_t* src, const int* index, float* dst,
  *       csrc/igemm_nt.hip / wgrad_tn.hip X3; profiles/r4/ab_x3_*.txt).  The library decides per launch (shapes with >= 512 blocks
  *       of 64x64 or >= 384 of 128x128 outputs; every weight-gradient GEMM); the rest of such a step runs the fp32 matrix cores.
  *       An Inf operand gives NaN (inf - inf in the split) where the fp32 matrix cores would give Inf.
+ *       Bits 7 + 8 (flags == 384; mmdyn_igemm_nt_mx, mmdyn_igemm_nt_dgrad_act; mmdyn_igemm_nt_dgrad_bn(bf16 = 4)): the same
+ *       arithmetic on operands that ARRIVE SPLIT -- A and Bp are rows of [plane][Cin] bf16 (hi | mid | lo, 6 bytes per element:
+ *       mmdyn_split_planes, or written so by their producers) -- so the GEMM itself contains no split: LDS-DMA of the planes, six
+ *       v_mfma_f32_16x16x32_bf16 per fragment pair (csrc/igemm_wsp.hip, igemm_wsp3_kernel).  Same terms, same product order per
+ *       K-step as the flags == 128 launch of the shape (results agree to the last bits; the channel -> k-lane map inside the 32-deep
+ *       MFMA differs, so not bit for bit).  Only for shapes mmdyn_igemm_planes_served answers 1 for
+ *       (MMDYN_ERR_SHAPE otherwise); tile counts and workspace as for flags == 128.
  *   mmdyn_wgrad_tn_mx : bit 0 as above, bit 1 D is 16-bit, bit 2 Gt is 16-bit (not IM2COL3), bit 5 as above, bit 7 alone as above.
  *   *_b16             : the element-wise kernels on 16-bit activation tensors (half = 0: bf16, half = 1: IEEE half). */
 int mmdyn_igemm_nt_mx(const void* A, const void* Bp, const float* bias, void* C, void* C_act, float* stats,
@@ -431,6 +449,13 @@ int mmdyn_igemm_nt_mx(const void* A, const void* Bp, const float* bias, void* C,
                       int ldc, int stride, int offset, int act, int splitk, int flags, void* stream);
 int mmdyn_wgrad_tn_mx(const void* D, const void* Gt, float* partial, int mode, int Bt, int Hr, int Wr, int Cd, int Hi,
                       int Wi, int Cg, int stride, int offset, int chunks, int flags, void* stream);
+/* The exact three-term bf16 split of an fp32 matrix, stored for the plane launches above: x [rows][C] fp32 ->
+ * planes [rows][3][C] bf16 with planes[r][0] = hi = bf16(x), [1] = mid = bf16(x - hi), [2] = lo = x - hi - mid (round-to-nearest-
+ * even; hi + mid + lo == x bit for bit for finite x).  C % 8 == 0.  A channels-last activation tensor is such a matrix with one
+ * row per pixel; packed weights [taps][N][Cin] are one with taps * N rows.  (Replaces nothing in the reference: it is the storage
+ * format of the fp32x3 arithmetic's GEMM operands, the role nn.Conv2d's fp32 input tensor plays in vae.py:198-216, 264-277.) */
+int mmdyn_split_planes(const float* x, void* planes, int64_t rows, int C, void* stream);
+int mmdyn_igemm_planes_served(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
 int mmdyn_bn_swish_fwd_b16(const uint16_t* y, const float* mean, const float* rstd, const float* gamma,
                            const float* beta, uint16_t* a, int G, int rows_per_group, int C, int half, void* stream);
 int mmdyn_bn_swish_bwd_reduce_b16(const uint16_t* da, const uint16_t* y, const float* mean, const float* rstd,

@@ -72,6 +72,10 @@ int mmdyn_igemm_ws_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, 
 int mmdyn_igemm_wsp_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
                         const IgemmGeom& g, bool bf16_ops, hipStream_t st);
 int mmdyn_igemm_wsp_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, bool b16);
+// ... with BOTH operands arriving as the three-plane bf16 split of fp32 tensors (rows of [plane][Cin]); same protocol
+int mmdyn_igemm_wsp3_try(const void* A, const void* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
+                         const IgemmGeom& g, hipStream_t st);
+bool mmdyn_igemm_wsp3_serves(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
 int64_t mmdyn_igemm_wsp_slab_bytes(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, bool b16);
 
 // tile choice shared by the launcher and mmdyn_igemm_stat_tiles.  Measured on MI355X over every shape of the

@@ -942,6 +942,13 @@ static int f32_slab_floats(bool x3, int mode, int G, int Bg, int Hi, int Wi, int
 extern "C" int mmdyn_igemm_slab_floats(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   return f32_slab_floats(false, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
 }
+/* 1: the fp32x3 launch of this shape can take its operands ALREADY SPLIT (flag bits 7 + 8 of mmdyn_igemm_nt_mx); its
+ * partial-sum tile count and slab workspace are those of the flags == 128 queries.  0: keep fp32 operands. */
+extern "C" int mmdyn_igemm_planes_served(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+  if (G <= 0 || Bg <= 0 || Cin <= 0 || N <= 0 || Cin % BK || N % 32) return 0;
+  if (!ws_enabled() || !x3_wsp(true)) return 0;
+  return mmdyn_igemm_wsp3_serves(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) ? 1 : 0;
+}
 extern "C" int mmdyn_igemm_stat_tiles_bf16(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   return lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
 }
@@ -997,8 +1004,12 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
     g.act = MMDYN_ACT_NONE;
   }
   const bool x3_allowed = (storage_flags & 128) != 0;      // fp32 launch that may take the three-term split
-  storage_flags &= ~128;
+  // bit 8 (with bit 7): A and Bp ARRIVE split -- rows of [plane][Cin] bf16, written by mmdyn_split_planes / the plane kinds of the
+  // pack plan / a producing kernel -- and the launch runs igemm_wsp3_kernel: no split anywhere in the GEMM
+  const bool planes = (storage_flags & 256) != 0;
+  storage_flags &= ~(128 | 256);
   if (x3_allowed && (bf16 || storage_flags)) return MMDYN_ERR_SHAPE;
+  if (planes && !x3_allowed) return MMDYN_ERR_SHAPE;
   g.a_b16 = (storage_flags & 2) != 0;
   g.c_b16 = (storage_flags & 4) != 0;
   g.bny_b16 = (storage_flags & 8) != 0;
@@ -1064,6 +1075,10 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
                                       bn_mean, bn_rstd, bn_gamma, bn_beta, g.c_b16 << g.f16, g.bny_b16 << g.f16, g.b_b16 << g.f16,
                                       st);
     if (rc != 1) return rc;
+  }
+  if (planes) {       // operands already split: served by the persistent plane-ring kernel or not at all (mmdyn_igemm_planes_served)
+    const int rc = ws_enabled() ? mmdyn_igemm_wsp3_try(A, Bp, bias, C, C_act, stats, ws, g, st) : 1;
+    return rc == 1 ? MMDYN_ERR_SHAPE : rc;
   }
   if (!bf16 && mode != MMDYN_IM2COL3 && x3_wsp(x3_allowed)) {     // the persistent ring kernel in the split arithmetic
     IgemmGeom gx = g;
@@ -1132,10 +1147,10 @@ extern "C" int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C
                                        int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
                                        int stride, int offset, int bf16, float* ws, void* stream) {
   if (!stats || !y || !mean || !rstd || !gamma || !beta) return MMDYN_ERR_NULL;
-  if (bf16 < 0 || bf16 > 3) return MMDYN_ERR_SHAPE;        // (3: fp32 arithmetic, the three-term split allowed)
+  if (bf16 < 0 || bf16 > 4) return MMDYN_ERR_SHAPE;        // (3: fp32 arithmetic, the three-term split allowed; 4: A and Bp arrive split)
   return igemm_entry(A, Bp, nullptr, C, nullptr, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset,
                      MMDYN_ACT_NONE, 1, stream, bf16 == 1 || bf16 == 2, y, mean, rstd, gamma, beta,
-                     bf16 == 2 ? 32 : bf16 == 3 ? 128 : 0);
+                     bf16 == 2 ? 32 : bf16 == 3 ? 128 : bf16 == 4 ? 384 : 0);
 }
 
 /* Input-gradient GEMM with the backward of a plain ACTIVATION in its epilogue: C = (A x Bp) * act'(u), u the layer's saved

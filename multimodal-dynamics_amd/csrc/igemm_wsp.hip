@@ -573,6 +573,212 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
 #endif
 }
 
+// ---- P3: the fp32x3 arithmetic on operands that ARRIVE SPLIT ("split once, not once per tile") ----
+// A and Bp are the exact three-term bf16 split of fp32 tensors, kept in HBM by whoever produced them (mmdyn_split_planes, the
+// pack plan, the producing kernels' epilogues): every row -- a pixel of A, an (tap, n) row of Bp -- is [plane][Cin] bf16, hi | mid
+// | lo, 6 bytes per element.  A K-step is 32 channels: 64 bytes per plane and row.  Ring image of a K-step: per operand, 16-row
+// blocks x 3 planes x 1-KiB pieces ([16 rows][64 B]); a piece is one DMA wave instruction (lane l -> row l >> 2, 16-byte position
+// l & 3 holding source granule (l & 3) ^ f(row), f(r) = (r >> 2) & 2) and ONE conflict-free ds_read_b128 per 16x16x32 fragment
+// (lane (row r, quarter h) reads position h ^ f(r)).  The MFMA waves execute ds_read_b128 + v_mfma_f32_16x16x32_bf16 only: six
+// plane products per fragment pair, smallest first, fp32 accumulate -- the terms and the order of the X3 variant above (the two
+// map channels to the k lanes of the 32-deep MFMA differently: equal to the last bits, not bit for bit), with no VALU work in the
+// K loop and 48 KB of fills per 128x128x32 K-step instead of the fp32 ring's 32 KB.  Schedule, row decode, slabs, fix-up launch and epilogue are igemm_wsp_kernel's (B16 = 0: fp32 results).
+// Measured as a dense GEMM against the split-in-the-kernel structures: tests/microbench/p3_ring_gemm.hip, profiles/r5/.
+constexpr int P3_RB = 192;      // bytes per tile row in the ring: three planes of 32 bf16 channels
+constexpr int P3_PIECE = 1024;  // 16 rows x 64 bytes
+__device__ __forceinline__ int p3_swz(int r) { return (r >> 2) & 2; }
+
+template <int MODE, int BM, int BN, int WM, int WN, int S, int NLD>
+__global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NLD)) void igemm_wsp3_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bp, const float* __restrict__ bias, float* __restrict__ C,
+    float* __restrict__ C_act, float* __restrict__ stats, float* __restrict__ slabs, const IgemmGeom g, const WspSched sc,
+    const unsigned a_bytes, const unsigned b_bytes) {
+  constexpr int NM = (BM / WM) * (BN / WN);        // MFMA waves
+  constexpr int RBA = BM / 16, RBB = BN / 16;      // 16-row blocks per operand tile
+  static_assert(RBA % NLD == 0 && RBB % NLD == 0, "row blocks split evenly over the loader waves");
+  constexpr int RAL = RBA / NLD, RBL = RBB / NLD, PPL = 3 * (RAL + RBL);
+  static_assert(PPL * (S - 2) <= 63, "vmcnt is a 6-bit counter");
+  static_assert(S - 1 < NRO, "row-offset table deep enough for the loaders' lead");
+  constexpr int SLOT = (BM + BN) * P3_RB;
+  constexpr int TS = 16, MT = WM / TS, NT = WN / TS;
+  constexpr int WAVES_N = BN / WN;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* rowoff = reinterpret_cast<int*>(smem + S * SLOT);       // [NRO][BM]: output offset of every tile row (-1: none)
+  float* trans = reinterpret_cast<float*>(rowoff + NRO * BM);  // [NM][16][TRLD]: the MFMA waves' epilogue patches
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Mg = g.Bg * g.Hr * g.Wr;
+  const int rb = (MODE == MMDYN_TCONV_S1P0 && (gridDim.x & 7) == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3))
+                                                                    : (int)blockIdx.x;
+  const int u0 = rb * sc.per, u1 = min(sc.units, u0 + sc.per);
+  if (u0 >= u1) return;
+  const int nsteps = u1 - u0;
+  const int cin_steps = sc.cin_steps;
+
+  if (wave < NLD) {
+    // ===================================== loader wave =====================================
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (int)b_bytes, 0x00020000);
+    const int prow = lane >> 2;                          // row of this lane inside a 16-row piece
+    const unsigned gran = (unsigned)(((lane & 3) ^ p3_swz(prow)) * 16);
+    const unsigned plane_b = (unsigned)(g.Cin * 2);      // bytes from one plane of a row to the next
+    int rbs[RAL], ry[RAL], rx[RAL];
+    unsigned voffA[RAL], voffB[RBL];
+    int su = u0, seg = -1, seg_end = u0;
+    int tap = 0, cstep = 0, ph = 0, pw = 0;
+    unsigned sB = 0;
+    auto settap = [&]() {
+      int dh = 0, dw = 0, wi = 0;
+      if (MODE == MMDYN_TCONV_S1P0) {
+        const int kh0 = max(0, ph - (g.Hi - 1)), kw0 = max(0, pw - (g.Wi - 1));
+        const int nkw = min(3, pw) - kw0 + 1;
+        const int a = tap / nkw;
+        const int kh = kh0 + a, kw = kw0 + (tap - a * nkw);
+        dh = -kh;
+        dw = -kw;
+        wi = kh * 4 + kw;
+      } else if (MODE == MMDYN_CONV) {
+        const int cls = tap >> 2, j = tap & 3;
+        const int t2 = g.tap_order ? ((cls >> 1) + 2 * (j >> 1)) * 4 + (cls & 1) + 2 * (j & 1) : tap;
+        dh = t2 >> 2;
+        dw = t2 & 3;
+        wi = t2;
+      } else if (MODE == MMDYN_TCONV_S2P1) {
+        const int th = tap >> 1, tw = tap & 1;
+        dh = ph - th;
+        dw = pw - tw;
+        wi = (1 - ph + 2 * th) * 4 + (1 - pw + 2 * tw);
+      }
+      sB = (unsigned)wi * (unsigned)(g.N * g.Cin) * 6u;
+#pragma unroll
+      for (int i = 0; i < RAL; ++i) {
+        const int y = ry[i] + dh, x = rx[i] + dw;
+        const bool ok = (rbs[i] >= 0) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
+        const unsigned pix = (unsigned)((rbs[i] * g.Hi + y) * g.Wi + x);
+        voffA[i] = ok ? pix * (unsigned)(g.Cin * 6) + gran : OOB;
+      }
+    };
+    auto next_segment = [&]() {
+      ++seg;
+      const Seg sg = seg_at<MODE>(su, sc);
+      const int kb = su - sg.ub;
+      seg_end = min(u1, sg.ub + sg.kt);
+      const TileId id = tile_of<MODE>(sg.t, g, sc, BN);
+      ph = id.ph;
+      pw = id.pw;
+      const int row0 = (MODE == MMDYN_TCONV_S1P0 ? id.stile : id.tile) * BM;
+#pragma unroll
+      for (int i = 0; i < RAL; ++i) {
+        const int r = (wave + NLD * i) * 16 + prow;      // tile row
+        int oo;
+        decode_row<MODE>(row0 + r, Mg, id, g, sc, rbs[i], ry[i], rx[i], oo);
+        if ((lane & 3) == 0) rowoff[(seg & (NRO - 1)) * BM + r] = oo;
+      }
+#pragma unroll
+      for (int j = 0; j < RBL; ++j) {
+        const int r = (wave + NLD * j) * 16 + prow;
+        voffB[j] = (unsigned)(id.grp * g.b_group_stride + (id.n0 + r) * g.Cin) * 6u + gran;
+      }
+      tap = kb / cin_steps;
+      cstep = kb - tap * cin_steps;
+      settap();
+    };
+    int islot = 0;
+    auto issue = [&]() {
+      if (su == seg_end) next_segment();
+      char* slot = smem + islot * SLOT;
+      const unsigned so = (unsigned)cstep * 64u;
+#pragma unroll
+      for (int i = 0; i < RAL; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dma16(rsA, slot + ((wave + NLD * i) * 3 + p) * P3_PIECE, voffA[i], so + (unsigned)p * plane_b);
+#pragma unroll
+      for (int j = 0; j < RBL; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          dma16(rsB, slot + BM * P3_RB + ((wave + NLD * j) * 3 + p) * P3_PIECE, voffB[j], sB + so + (unsigned)p * plane_b);
+      islot = islot + 1 == S ? 0 : islot + 1;
+      ++su;
+      if (++cstep == cin_steps) {
+        cstep = 0;
+        ++tap;
+        if (su < seg_end) settap();
+      }
+    };
+    for (int k = 0; k < S - 1 && k < nsteps; ++k) issue();
+    for (int k = 0; k < nsteps; ++k) {
+      if (k + S - 1 <= nsteps) wait_vmcnt<PPL*(S - 2)>(); else wait_vmcnt<0>();
+      ring_barrier();                                    // slot k is complete; slot k-1 has been read by every MFMA wave
+      if (k + S - 1 < nsteps) issue();
+    }
+    return;
+  }
+
+  // ===================================== MFMA waves =====================================
+  const int mw = wave - NLD;
+  const int wm = mw / WAVES_N, wn = mw - wm * WAVES_N;
+  const int h = lane >> 4, cl = lane & 15;
+  const bool bnbwd = g.bn_y != nullptr;
+  const int foff = cl * 64 + ((h ^ p3_swz(cl)) * 16);
+  const int abase = (wm * WM / 16) * 3 * P3_PIECE, bbase = BM * P3_RB + (wn * WN / 16) * 3 * P3_PIECE;
+  int cslot = 0;
+  int seg = -1;
+  for (int cu = u0; cu < u1;) {
+    ++seg;
+    const Seg sg = seg_at<MODE>(cu, sc);
+    const int kb = cu - sg.ub;
+    const int ke = min(sg.kt, kb + (u1 - cu));
+    const bool full = kb == 0 && ke == sg.kt;
+    const TileId id = tile_of<MODE>(sg.t, g, sc, BN);
+    f32x4v acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    int ooff[MT];
+    f32x4v yq[MT][NT];
+    for (int k = kb; k < ke; ++k) {
+      ring_barrier();
+      if (k == kb) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ooff[mt] = rowoff[(seg & (NRO - 1)) * BM + wm * WM + mt * TS + (lane >> 2)];
+        if (full && bnbwd) wsp_fetch_y<MT, NT, 0>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
+      }
+      const char* sl = smem + cslot * SLOT;
+      cslot = cslot + 1 == S ? 0 : cslot + 1;
+      bf16x8v bp[3][NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bp[p][nt] = *reinterpret_cast<const bf16x8v*>(sl + bbase + (nt * 3 + p) * P3_PIECE + foff);
+      constexpr int order[6][2] = {{0, 2}, {2, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 0}};      // (plane of A, plane of B), smallest first
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        bf16x8v ap[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ap[p] = *reinterpret_cast<const bf16x8v*>(sl + abase + (mt * 3 + p) * P3_PIECE + foff);
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[order[t][0]], bp[order[t][1]][nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    if (full) {
+      wsp_epilogue<BM, BN, WM, WN, 0>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
+    } else {
+      float* sb = slabs + ((size_t)(rb * 2 + (cu == u0 ? 0 : 1)) * NM + mw) * (MT * NT * 256);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4v*>(sb + ((mt * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
+    }
+    cu += ke - kb;
+  }
+}
+
 // One block per tile; blocks of tiles that were computed whole return at once.  Sums the pieces of a split tile in piece
 // (= K) order and runs the epilogue of the main kernel.
 template <int MODE, int BM, int BN, int WM, int WN, int B16>
@@ -832,6 +1038,29 @@ static int wsp_dispatch(const float* A, const float* Bp, const float* bias, floa
   return wsp_launch_mode<MMDYN_TCONV_S2P1, B16>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
 }
 
+// P3 launches: 128x128 tiles, four loader waves + eight MFMA waves of 64x32 (two per SIMD: one wave's fragment reads land
+// under its partner's MFMAs -- tests/microbench/p3_ring_gemm.hip: LDS reads + MFMA alone 263 against 219 TFLOP/s for one 64x64
+// wave per SIMD), three ring slots of 48 KB.
+constexpr int P3_NLD = 4, P3_S = 3, P3_WM = 64, P3_WN = 32;
+template <int MODE>
+static int wsp3_launch(const bf16_t* A, const bf16_t* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
+                       IgemmGeom g, const WspSched& sc, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  constexpr int BM = 128, BN = 128, NM = (BM / P3_WM) * (BN / P3_WN);
+  g.tiles_per_group = MODE == MMDYN_TCONV_S1P0 ? 64 * sc.spg : ceil_div(g.Bg * g.Hr * g.Wr, BM);
+  const int nblk = (sc.units + sc.per - 1) / sc.per;
+  const size_t smem = (size_t)P3_S * (BM + BN) * P3_RB + (size_t)NRO * BM * sizeof(int) + (size_t)NM * 16 * TRLD * sizeof(float);
+  static LdsOptIn opt_in;
+  if (int e = opt_in.ensure((const void*)igemm_wsp3_kernel<MODE, BM, BN, P3_WM, P3_WN, P3_S, P3_NLD>, (int)smem)) return e;
+  const bool split = has_split_tiles(g, sc);
+  if (split && !slabs) return MMDYN_ERR_NULL;
+  hipLaunchKernelGGL((igemm_wsp3_kernel<MODE, BM, BN, P3_WM, P3_WN, P3_S, P3_NLD>), dim3(nblk), dim3(64 * (NM + P3_NLD)), smem, st, A, Bp,
+                     bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes);
+  if (split)
+    hipLaunchKernelGGL((igemm_wsp_fixup_kernel<MODE, BM, BN, P3_WM, P3_WN, 0>), dim3(sc.tiles), dim3(64 * NM), 0, st, bias, C, C_act,
+                       stats, slabs, g, sc);
+  MMDYN_LAUNCH_CHECK();
+}
+
 // geometry of a launch as the queries below know it (shape only)
 static IgemmGeom query_geom(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   IgemmGeom g{};
@@ -891,6 +1120,33 @@ int mmdyn_igemm_wsp_try(const float* A, const float* Bp, const float* bias, floa
   if (bf16_ops) return wsp_dispatch<1>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, st);
 #endif
   return wsp_dispatch<0>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, st);
+}
+
+// The launch with both operands ARRIVING as three-plane bf16 rows (igemm_wsp3_kernel).  Served: what the fp32 persistent kernel
+// serves on 128x128 tiles (same wsp_pick, so partial-sum tile counts and slab sizes are the fp32 launch's), convolution modes only.
+// Returns 1 when the shape is not served.
+bool mmdyn_igemm_wsp3_serves(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+  if (mode != MMDYN_CONV && mode != MMDYN_TCONV_S2P1 && mode != MMDYN_TCONV_S1P0) return false;
+  const IgemmGeom g = query_geom(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  const WspPick p = wsp_pick(mode, G, Bg, Hi, Wi, g.Hr, g.Wr, Cin, N, g.nclasses, 1, false, 0);
+  if (p.bm != 128 || p.bn != 128) return false;
+  return (int64_t)G * Bg * Hi * Wi * Cin * 6 < MAX_BUFFER_BYTES && (int64_t)16 * N * Cin * 6 < MAX_BUFFER_BYTES;
+}
+
+int mmdyn_igemm_wsp3_try(const void* A, const void* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
+                         const IgemmGeom& g_in, hipStream_t st) {
+  IgemmGeom g = g_in;
+  if (g.splitk > 1 || g.b_group_stride || !mmdyn_igemm_wsp3_serves(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Cin, g.Ho, g.Wo, g.N)) return 1;
+  g.tap_order = g.mode == MMDYN_CONV && g.rs == 2;
+  const WspPick p = wsp_pick(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Hr, g.Wr, g.Cin, g.N, g.nclasses, g.splitk, false, 0);
+  const WspSched sc = make_sched(g, p, false);
+  const unsigned a_bytes = (unsigned)((int64_t)g.G * g.Bg * g.Hi * g.Wi * g.Cin * 6);
+  const unsigned b_bytes = (unsigned)((int64_t)16 * g.N * g.Cin * 6);
+  const bf16_t* Ap = reinterpret_cast<const bf16_t*>(A);
+  const bf16_t* Bq = reinterpret_cast<const bf16_t*>(Bp);
+  if (g.mode == MMDYN_CONV) return wsp3_launch<MMDYN_CONV>(Ap, Bq, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
+  if (g.mode == MMDYN_TCONV_S1P0) return wsp3_launch<MMDYN_TCONV_S1P0>(Ap, Bq, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
+  return wsp3_launch<MMDYN_TCONV_S2P1>(Ap, Bq, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
 }
 
 #ifdef MMDYN_LAB

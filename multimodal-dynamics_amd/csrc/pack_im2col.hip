@@ -382,7 +382,8 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restr
 
 }  // namespace
 
-extern "C" const char* mmdyn_version(void) { return "mmdyn_hip 0.1 (gfx950)"; }
+extern "C" const char* mmdyn_version(void) { return "mmdyn_hip 0.5 (gfx950)"; }
+extern "C" int mmdyn_abi_version(void) { return MMDYN_ABI_VERSION; }
 
 extern "C" int mmdyn_pack_conv_weight(const float* Wc, float* P, int d0, int d1, int swap, void* stream) {
   if (!Wc || !P) return MMDYN_ERR_NULL;
@@ -432,6 +433,37 @@ extern "C" int mmdyn_repack2d_ld_b16(const float* in, void* out, int rows_in, in
   else
     hipLaunchKernelGGL(repack2d_ld_kernel<bf16_t>, dim3(ew_grid((int64_t)rows_out * cols_out)), dim3(256), 0,
                        (hipStream_t)stream, in, (bf16_t*)out, rows_in, cols_in, rows_out, cols_out, ld_out, mode);
+  MMDYN_LAUNCH_CHECK();
+}
+
+// fp32 [rows][C] -> the exact three-term bf16 split, rows of [plane][C]: hi | mid | lo (split3_bf16, common.h), 6 bytes per
+// element.  One thread moves 8 consecutive channels of a row: two 16-byte loads, three 16-byte stores.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, bf16_t* __restrict__ planes, int64_t granules,
+                                                          int C) {
+  const int gpr = C >> 3;        // 8-channel granules per row
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < granules; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / gpr;
+    const int c0 = (int)(i - row * gpr) * 8;
+    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + row * C + c0));
+    const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + row * C + c0 + 4));
+    uint32_t h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+    split3_bf16(a[0], a[1], h0, m0, l0);
+    split3_bf16(a[2], a[3], h1, m1, l1);
+    split3_bf16(b[0], b[1], h2, m2, l2);
+    split3_bf16(b[2], b[3], h3, m3, l3);
+    bf16_t* o = planes + row * 3 * (int64_t)C + c0;
+    *reinterpret_cast<u32x4*>(o) = u32x4{h0, h1, h2, h3};
+    *reinterpret_cast<u32x4*>(o + C) = u32x4{m0, m1, m2, m3};
+    *reinterpret_cast<u32x4*>(o + 2 * C) = u32x4{l0, l1, l2, l3};
+  }
+}
+
+extern "C" int mmdyn_split_planes(const float* x, void* planes, int64_t rows, int C, void* stream) {
+  if (!x || !planes) return MMDYN_ERR_NULL;
+  if (rows <= 0 || C <= 0 || C % 8) return MMDYN_ERR_SHAPE;
+  const int64_t granules = rows * (C / 8);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(ew_grid(granules)), dim3(256), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<bf16_t*>(planes), granules, C);
   MMDYN_LAUNCH_CHECK();
 }
 

@@ -896,6 +896,10 @@ static int launch4(const float* D, const float* Gt, float* partial, WgradGeom g,
   size_t smem = (size_t)RK * (BD + 4 * BG) * sizeof(float);
   if (g.x3 && !bf16) {       // fp32 through the bf16 matrix cores (three-term split)
     smem = (size_t)3 * RK * (x3_ld<BD>::v + 4 * x3_ld<BG>::v) * 2;
+    // three planes of four tap tiles: the <32,64> instance needs 78 KB: opt in like every other > 64 KB kernel
+    static LdsOptIn x3_opt_in;
+    if (smem > 65536)
+      if (int e = x3_opt_in.ensure((const void*)wgrad_tn4_kernel<BD, BG, false, 0, true>, (int)smem)) return e;
     hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, false, 0, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
     MMDYN_LAUNCH_CHECK();
   }
@@ -1037,10 +1041,16 @@ static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, 
   if constexpr (WK == 1) {
     if (g.x3 && !bf16 && g.mode != MMDYN_IM2COL3) {       // fp32 through the bf16 matrix cores (three-term split)
       smem = (size_t)3 * RK * (x3_ld<BD>::v + x3_ld<BG>::v) * 2;
-      if (g.mode == MMDYN_CONV)
+      static LdsOptIn x3_conv_opt_in, x3_dense_opt_in;
+      if (g.mode == MMDYN_CONV) {
+        if (smem > 65536)
+          if (int e = x3_conv_opt_in.ensure((const void*)wgrad_tn_kernel<MMDYN_CONV, BD, BG, WD, WG, WK, false, 0, true>, (int)smem)) return e;
         hipLaunchKernelGGL((wgrad_tn_kernel<MMDYN_CONV, BD, BG, WD, WG, WK, false, 0, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
-      else
+      } else {
+        if (smem > 65536)
+          if (int e = x3_dense_opt_in.ensure((const void*)wgrad_tn_kernel<MMDYN_DENSE, BD, BG, WD, WG, WK, false, 0, true>, (int)smem)) return e;
         hipLaunchKernelGGL((wgrad_tn_kernel<MMDYN_DENSE, BD, BG, WD, WG, WK, false, 0, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
+      }
       MMDYN_LAUNCH_CHECK();
     }
   }

@@ -25,9 +25,11 @@ class PackEntry(ctypes.Structure):
 
 MAX_PASSES = 8
 MAX_EXPERTS = 4
+ABI_VERSION = 5          # MMDYN_ABI_VERSION of the include/mmdyn_hip.h this table was written against
 
 # name -> argument type codes, in header order: p pointer, i int, l int64, f float, Q uint64
 _SIGNATURES = {
+    "mmdyn_abi_version": "",
     "mmdyn_igemm_nt": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_nt_dgrad_bn": "ppppppppp" + "iiiiiiiiiiii" + "pp",
     "mmdyn_igemm_nt_dgrad_act": "pppp" + "i" + "iiiiiiiiiii" + "i" + "pp",
@@ -98,6 +100,8 @@ _SIGNATURES = {
     "mmdyn_sgd_step": "ppp" + "l" + "ffff" + "i" + "p",
     "mmdyn_igemm_nt_mx": "pppppppppppp" + "iiiiiiiiiiiiii" + "i" + "p",
     "mmdyn_wgrad_tn_mx": "ppp" + "iiiiiiiiiii" + "i" + "p",
+    "mmdyn_split_planes": "pp" + "l" + "i" + "p",
+    "mmdyn_igemm_planes_served": "iiiiiiiii",
     "mmdyn_bn_swish_fwd_b16": "pppppp" + "iiii" + "p",
     "mmdyn_bn_swish_bwd_reduce_b16": "ppppppp" + "iiii" + "p",
     "mmdyn_bn_swish_bwd_apply_b16": "pppppppp" + "iiiii" + "p",
@@ -137,6 +141,10 @@ def load(path=None):
         fn = getattr(lib, name)
         fn.restype = _I
         fn.argtypes = [_CODES[c] for c in sig]
+    got = lib.mmdyn_abi_version()
+    if got != ABI_VERSION:
+        raise OSError(f"{path} implements ABI revision {got}, this binding was written against {ABI_VERSION}: rebuild the "
+                      "library (make -C multimodal-dynamics_amd/csrc) -- signatures and workspace arguments differ between revisions")
     _libs[path] = lib
     return lib
 

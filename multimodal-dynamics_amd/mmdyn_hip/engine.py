@@ -352,10 +352,17 @@ class MVAEStep:
         self._graph = None
         self._static_mask = self._static_cond = None
 
+    def _drop_graph(self):
+        """Forget the captured step; its launches' arrival-counter slots (ops.HipBackend._ticket) become free again."""
+        g, self._graph = self._graph, None
+        if g is not None and len(g) > 3 and g[3]:
+            torch.cuda.synchronize()            # no replay of the dropped graphs may still be using a slot
+            ops.B.ticket_release(g[3])
+
     def close(self):
         """Drop the captured HIP graphs (and their memory pools).  Call before tearing down the process group of a
         data-parallel run: graphs that captured RCCL collectives should not outlive their communicators."""
-        self._graph = None
+        self._drop_graph()
         self.ctx = None
         if self.lanes.on:
             torch.cuda.synchronize()
@@ -794,16 +801,29 @@ class MVAEStep:
                 self._sync.pending = []                        # keep the Work handles of the warm-up's collectives
             if self.pg is not None:
                 self._warm_works = []                          # (gradient buckets: _reduce_bucket)
-            with torch.cuda.stream(side):                      # warm-up outside capture (allocator, lazy init)
-                self.train_step(self._static_in, self._static_tg, kl_weight, self._static_mask, self._static_cond)
-            torch.cuda.current_stream().wait_stream(side)
-            if self.pg is not None:
-                self._drain_before_capture(key)
-            captured = self._capture(kl_weight)
+            try:
+                with torch.cuda.stream(side):                  # warm-up outside capture (allocator, lazy init)
+                    self.train_step(self._static_in, self._static_tg, kl_weight, self._static_mask, self._static_cond)
+                torch.cuda.current_stream().wait_stream(side)
+                if self.pg is not None:
+                    self._drain_before_capture(key)
+            finally:
+                # a warm-up step that raises must not leave later eager steps appending to the list for ever
+                self._warm_works = None
+                if self._sync is not None:
+                    self._sync.pending = None
+            self._drop_graph()           # a recapture (new batch shape): the old graphs' arrival-counter slots go back
+            mark = getattr(ops.B, "ticket_mark", None)
+            if mark is not None:
+                mark()
+            try:
+                captured = self._capture(kl_weight)
+            finally:
+                slots = ops.B.ticket_take() if mark is not None else []
             # the loss scale baked into the captured backward: an eval_step or an eager step on another batch size in
             # between rewrites self.loss_scale, the replayed gradients keep this one (the eager Adam of the data-parallel
             # replay divides by it)
-            self._graph = (key, captured, self.loss_scale)
+            self._graph = (key, captured, self.loss_scale, slots)
             return self.loss             # the warm-up above WAS this call's optimiser step
         for dst, src in zip(self._static_in + self._static_tg, list(inputs) + list(targets)):
             if dst.data_ptr() != src.data_ptr():
@@ -836,8 +856,9 @@ class MVAEStep:
         process.  Retirement itself cannot be observed from Python -- the ProcessGroupNCCL / Work bindings of torch 2.10 expose
         ``is_completed()``, which answers for the GPU side of a Work, and nothing about the watchdog's list -- but it follows
         from (2): every Work is complete on every rank, so the watchdog's NEXT sweep retires them all, and a sweep starts
-        every WATCHDOG_SWEEP_S (the documented 100 ms; TORCH_NCCL_* settings do not change it).  One sweep interval plus a
-        fifth is therefore waited after the last barrier (round 3 slept 2.5 intervals without knowing the Works' state).
+        every WATCHDOG_SWEEP_S (the documented 100 ms; TORCH_NCCL_* settings do not change it).  2.5 sweep intervals are
+        waited after the last barrier: one would do by the argument above, but the argument rests on the watchdog's timing and
+        on host scheduling, no multi-rank RCCL run has measured it, and the wait is paid once per capture.
         The capture itself runs with capture_error_mode="thread_local", so API calls of other threads cannot invalidate it."""
         import time
         import torch.distributed as dist
@@ -862,7 +883,7 @@ class MVAEStep:
         for g in groups:
             dist.barrier(group=g)
         torch.cuda.synchronize()
-        time.sleep(1.2 * self.WATCHDOG_SWEEP_S)
+        time.sleep(2.5 * self.WATCHDOG_SWEEP_S)
 
     def _capture(self, kl_weight):
         LN = self.lanes

@@ -22,6 +22,8 @@ from .models.shapes import BN_EPS, BN_MOMENTUM, FEAT
 
 
 def _new(like, *shape, dtype=torch.float32):
+    if isinstance(like, ops.Planes):
+        like = like.t
     return torch.empty(shape, device=like.device, dtype=dtype)
 
 
@@ -81,7 +83,8 @@ def conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride=1, offset=0, stats=Fals
     y = _new(x, Bt * Ho * Ho, N, dtype=ACT_DTYPE if out_dtype is None else out_dtype)
     st, T = None, 0
     if stats:
-        T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, all16=ops._is16(x) and ops._is16(Wp))
+        planes = isinstance(x, ops.Planes)          # (operands that arrive split: the fp32x3 launch's tile count)
+        T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, all16=not planes and ops._is16(x) and ops._is16(Wp))
         st = _new(x, G, T, 2, N)
     ops.B.igemm_nt(x, Wp, None, y, None, st, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset,
                    ACT_NONE, 1)
@@ -212,7 +215,8 @@ def dgrad_bn_swish_backward(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride, offset, 
     turns dL/da into du = dL/da * swish'(.) and emits the per-tile sums, so only finalize + apply remain.
     Returns dL/dy (gradient w.r.t. this layer's conv output)."""
     rows_per_group = Bg * Ho * Ho
-    T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, all16=ops._is16(x) and ops._is16(Wp))
+    T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N,
+                               all16=not isinstance(x, ops.Planes) and ops._is16(x) and ops._is16(Wp))
     du = torch.empty_like(y)
     partial = _new(y, G, T, 2, N)
     ops.B.igemm_nt_dgrad_bn(x, Wp, du, partial, y, mean, rstd, bn.gamma, bn.beta, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N,

@@ -61,6 +61,32 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class Planes:
+    """An fp32 matrix [rows][C] kept as its exact three-term bf16 split, the operand format of the fp32x3 GEMMs that take their
+    operands ALREADY SPLIT (include/mmdyn_hip.h, flag bits 7 + 8): ``t[row][plane][c]`` (torch.bfloat16), plane 0 = hi = bf16(x),
+    1 = mid = bf16(x - hi), 2 = lo = x - hi - mid; hi + mid + lo == x bit for bit.  Written by ``B.split_planes`` (or by the
+    kernels that produce the tensor); a channels-last activation has one row per pixel, packed weights one per (tap, n)."""
+    __slots__ = ("t",)
+
+    def __init__(self, rows, C, device):
+        if C % 8:
+            raise ValueError("mmdyn_hip: plane rows are moved in 8-channel granules (C % 8 == 0)")
+        self.t = torch.empty(rows, 3, C, dtype=torch.bfloat16, device=device)
+
+    @property
+    def rows(self):
+        return self.t.shape[0]
+
+    @property
+    def C(self):
+        return self.t.shape[2]
+
+    def float(self):
+        """The fp32 matrix back (exact: hi + mid has at most 16 significant bits, + lo is x)."""
+        f = self.t.to(torch.float32)
+        return (f[:, 0] + f[:, 1]) + f[:, 2]
+
+
 # The "last block finishes" single-launch forms of mmdyn_bn_finalize / mmdyn_bn_bwd_finalize / mmdyn_colsum are OFF by
 # default: measured on the two-lane step they cost 0.12 ms (fp32 bs 256: 6.78 -> 6.90 ms; bf16s bs 128: 2.165 -> 2.19 ms) --
 # up to 1024 blocks arrive on one counter (~12 ns per arrival) and every block drains its stores before it may leave
@@ -73,7 +99,8 @@ class HipBackend:
 
     def __init__(self, lib_path=None):
         self._l, self._lib_path = None, lib_path       # lib_path: the LAB build (tests / microbenchmarks only)
-        self._tickets = {}                             # device -> (zeroed int32 pool, next slot)
+        self._tickets = {}                             # device -> [zeroed int32 pool, next eager slot, next graph slot, free graph slots]
+        self._drawn = None                             # (device, slot) pairs drawn by captured launches since ticket_mark()
         self.force_ticket = False
         # "fp32": v_mfma_f32_32x32x2_f32 (the reference's arithmetic, the default and the BASELINE configs[1] path);
         # "bf16": operands rounded to bf16 on their way into the matrix cores, fp32 accumulate (configs[2]);
@@ -91,28 +118,50 @@ class HipBackend:
         """Address of a zero-initialised arrival counter for ONE launch (the "last block finishes" kernels:
         mmdyn_bn_finalize, mmdyn_bn_bwd_finalize, mmdyn_colsum); the kernel that used a slot leaves it zero.
         A launch recorded into a HIP graph keeps its slot for every replay, so captured launches draw from the lower half
-        of the pool and a slot handed out there is NEVER reissued (a process that captures more than 2048 such launches is
-        told so).  Eager launches cycle through the upper half: a slot comes up again only after 2048 eager launches of
-        this kind -- far more than a train step issues -- so no two launches in flight share one, and none can meet a
-        slot that a replaying graph owns."""
+        of the pool, and a slot handed out there belongs to that graph until its owner gives it back: the engines bracket a
+        capture with ticket_mark() / ticket_take() and call ticket_release() with the slots of a graph they drop (a
+        recapture on a new batch shape), so a long run that recaptures every epoch does not run out.  Eager
+        launches cycle through the upper half: a slot comes up again only after 2048 eager launches of this kind -- far more
+        than a train step issues -- so no two launches in flight share one, and none can meet a slot that a replaying graph
+        owns."""
         if not (_USE_TICKET or self.force_ticket):
             return None
         dev = like.device
         ent = self._tickets.get(dev)
         if ent is None:
-            ent = [torch.zeros(self.TICKET_SLOTS * self.TICKET_STRIDE, dtype=torch.int32, device=dev), 0, 0]
+            ent = [torch.zeros(self.TICKET_SLOTS * self.TICKET_STRIDE, dtype=torch.int32, device=dev), 0, 0, []]
             self._tickets[dev] = ent
-        pool, nxt_eager, nxt_graph = ent
+        pool, nxt_eager, nxt_graph, free = ent
         half = self.TICKET_SLOTS // 2
         if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
-            if nxt_graph >= half:
-                raise RuntimeError("mmdyn_hip: ticket slots for captured launches exhausted (2048 per device)")
-            ent[2] = nxt_graph + 1
-            slot = nxt_graph
+            if free:
+                slot = free.pop()
+            elif nxt_graph >= half:
+                raise RuntimeError("mmdyn_hip: ticket slots for captured launches exhausted (2048 live per device)")
+            else:
+                ent[2] = nxt_graph + 1
+                slot = nxt_graph
+            if self._drawn is not None:
+                self._drawn.append((dev, slot))
         else:
             ent[1] = (nxt_eager + 1) % half
             slot = half + nxt_eager
         return pool.data_ptr() + 4 * self.TICKET_STRIDE * slot
+
+    def ticket_mark(self):
+        """Start recording the slots that captured launches draw (one capture at a time)."""
+        self._drawn = []
+
+    def ticket_take(self):
+        """The slots drawn since ticket_mark(): they belong to the graph(s) just captured."""
+        drawn, self._drawn = self._drawn or [], None
+        return drawn
+
+    def ticket_release(self, slots):
+        """Give back the slots of graphs that will never be replayed again.  The caller has synchronised the device (a replay
+        still in flight would otherwise share its counter with the next capture's launch)."""
+        for dev, slot in slots or ():
+            self._tickets[dev][3].append(slot)
 
     @property
     def lib(self):
@@ -184,8 +233,40 @@ class HipBackend:
             raise ValueError(f"mmdyn_hip: stats must be [G={G}][T={T}][2][N={N}] for this launch (igemm_stat_tiles with "
                              f"all16={all16}), got {tuple(stats.shape)}")
 
+    def _planes_pair(self, A, Bp, Cin):
+        """Both operands of a GEMM arrive split (or neither): their pointers, after the checks the kernel cannot make."""
+        if not (isinstance(A, Planes) and isinstance(Bp, Planes)):
+            raise TypeError("mmdyn_hip: a GEMM takes both operands as Planes or neither")
+        if not self._x3():
+            raise ValueError("mmdyn_hip: plane operands belong to the fp32x3 arithmetic (engine precision 'fp32x3')")
+        if A.C != Cin or Bp.C != Cin:
+            raise ValueError(f"mmdyn_hip: plane rows of {A.C} / {Bp.C} channels for a GEMM over Cin = {Cin}")
+        for t in (A.t, Bp.t):
+            if not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("mmdyn_hip: plane tensors must be contiguous GPU tensors")
+        return A.t.data_ptr(), Bp.t.data_ptr()
+
+    def split_planes(self, x, planes):
+        """planes <- the exact three-term bf16 split of the fp32 matrix x ([rows][C] contiguous)."""
+        if x.numel() != planes.rows * planes.C:
+            raise ValueError("mmdyn_hip: split_planes: shapes differ")
+        check(self.lib.mmdyn_split_planes(_ptr(x), planes.t.data_ptr(), planes.rows, planes.C, _stream()), "mmdyn_split_planes")
+
+    def igemm_planes_served(self, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N):
+        """True when the fp32x3 launch of this shape can take its operands already split (host query, no GPU needed)."""
+        return bool(self._x3()) and self.lib.mmdyn_igemm_planes_served(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) == 1
+
     def igemm_nt(self, A, Bp, bias, C, C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride,
                  offset, act, splitk):
+        if isinstance(A, Planes) or isinstance(Bp, Planes):
+            pa, pb = self._planes_pair(A, Bp, Cin)
+            self._check_stat_tiles(stats, False, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+            if ws is None and splitk == 1:
+                ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+            check(self.lib.mmdyn_igemm_nt_mx(pa, pb, _ptr(bias), _ptr(C), _ptr(C_act), _ptr(stats), _ptr(ws), None, None, None, None,
+                                             None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, 384,
+                                             _stream()), "mmdyn_igemm_nt_mx")
+            return
         (pa, a16), (pc, c16), (pca, ca16), (pb, b16) = _aptr(A), _aptr(C), _aptr(C_act), _aptr(Bp)
         self._check_stat_tiles(stats, bool(a16 and b16), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
         if a16 or c16 or ca16 or b16:      # bf16 activation storage / bf16 packed weights: the mixed-storage entry point
@@ -213,6 +294,14 @@ class HipBackend:
 
     def igemm_nt_dgrad_bn(self, A, Bp, C, stats, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N,
                           stride, offset):
+        if isinstance(A, Planes) or isinstance(Bp, Planes):
+            pa, pb = self._planes_pair(A, Bp, Cin)
+            self._check_stat_tiles(stats, False, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+            ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+            check(self.lib.mmdyn_igemm_nt_dgrad_bn(pa, pb, _ptr(C), _ptr(stats), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                                                   _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset, 4, _ptr(ws),
+                                                   _stream()), "mmdyn_igemm_nt_dgrad_bn")
+            return
         (pa, a16), (pc, c16), (py, y16), (pb, b16) = _aptr(A), _aptr(C), _aptr(y), _aptr(Bp)
         self._check_stat_tiles(stats, bool(a16 and b16), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
         if a16 or c16 or y16 or b16:
@@ -231,6 +320,12 @@ class HipBackend:
 
     def igemm_nt_dgrad_act(self, A, Bp, C, u, act, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset):
         """C = (A x Bp) * act'(u): input-gradient GEMM with the activation backward in its epilogue."""
+        if isinstance(A, Planes) or isinstance(Bp, Planes):
+            pa, pb = self._planes_pair(A, Bp, Cin)
+            ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+            check(self.lib.mmdyn_igemm_nt_dgrad_act(pa, pb, _ptr(C), _ptr(u), int(act), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride,
+                                                    offset, 384, _ptr(ws), _stream()), "mmdyn_igemm_nt_dgrad_act")
+            return
         (pa, a16), (pc, c16), (pu, u16), (pb, b16) = _aptr(A), _aptr(C), _aptr(u), _aptr(Bp)
         flags = {"fp32": self._x3(), "fp16": 32, "fp16s": 32}.get(self.precision, 1)
         if a16 or c16 or u16 or b16:

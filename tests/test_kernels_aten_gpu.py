@@ -459,3 +459,88 @@ def test_x3_batchnorm_backward_epilogue_matches_the_native_launch(x3, G, Bg, Hi,
     (C, s), (Cn, sn) = run(), _native(run)
     assert not torch.equal(C, Cn)
     assert relg(C, Cn) < 3e-6 and relg(s, sn) < 1e-5
+
+
+# ---- fp32x3 with operands that ARRIVE split (csrc/igemm_wsp.hip igemm_wsp3_kernel, mmdyn_split_planes) -------
+def _planes(x):
+    p = ops.Planes(x.shape[0], x.shape[1], x.device)
+    ops.B.split_planes(x.contiguous(), p)
+    return p
+
+
+def test_split_planes_is_exact_and_round_to_nearest(x3):
+    """hi + mid + lo == x bit for bit over 60 binades, each term the round-to-nearest-even bf16 of the running residual
+    (torch's own fp32 -> bf16 cast is the witness: ATen, one hop).  The contract's lower edge: the third term is 2^-16 |x|, so below
+    |x| ~ 2^-110 it leaves bf16's normal range (the matrix pipe flushes such terms) -- there the reconstruction is held to one
+    minimum-normal (2^-126) absolute, which is what the GEMMs of this arithmetic promise for such operands."""
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(4096, 64, generator=g) * 2 - 1) * torch.exp2(torch.randint(-30, 30, (4096, 64), generator=g).float())
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e-38, 1.0e30, 2.0 ** -126, 1.0 + 2.0 ** -23])
+    x[1, :8] = torch.tensor([1.0e-36, -1.0e-36, 1.0e36, -1.0e36, 3.0e38, 2.0 ** -100, 2.0 ** -112, 65504.0])
+    x = x.to(DEV)
+    p = _planes(x)
+    big = x.abs() >= 2.0 ** -100
+    assert torch.equal(p.float()[big | (x == 0)], x[big | (x == 0)])
+    assert float((p.float() - x).abs().max()) <= 2.0 ** -126
+    hi = x.to(torch.bfloat16)
+    mid = (x - hi.float()).to(torch.bfloat16)
+    lo = ((x - hi.float()) - mid.float()).to(torch.bfloat16)
+    assert torch.equal(p.t[:, 0][big], hi[big]) and torch.equal(p.t[:, 1][big], mid[big]) and torch.equal(p.t[:, 2][big], lo[big])
+    assert float((p.t[:, 1].float().abs() - x.abs() * 2.0 ** -8).max()) <= 0 and float((p.t[:, 2].float().abs() - x.abs() * 2.0 ** -16).max()) <= 0
+
+
+@pytest.mark.parametrize("G,Bg", [(4, 256), (4, 70)])
+def test_planes_conv_transpose2d_s1p0_with_statistics(x3, G, Bg):
+    """The k4 s1 p0 layer on split operands: against fp64 ATen, and against the launch that splits inside the kernel (same six
+    products per K-step in the same order; the two kernels map channels to the k lanes of the 32-deep MFMA differently, so the
+    results agree to the last bits, not bit for bit)."""
+    B = G * Bg
+    x, W = rnd(B, 256, 5, 5, seed=7).to(DEV), rnd(256, 128, 4, 4, seed=8, scale=0.1).to(DEV)
+    Ws, xr = layers.pack_conv(W, swap=True), nhwc_rows(x)
+    assert ops.B.igemm_planes_served(ops.TCONV_S1P0, G, Bg, 5, 5, 256, 8, 8, 128)
+    y, st, T = layers.conv_like(_planes(xr), _planes(Ws.view(-1, 256)), ops.TCONV_S1P0, G, Bg, 5, 256, 8, 128, stats=True)
+    ref = F.conv_transpose2d(x.double(), W.double(), stride=1, padding=0)
+    assert relg(from_rows(y, B, 8, 128), ref) < 2e-6
+    y2, st2, _ = layers.conv_like(xr, Ws, ops.TCONV_S1P0, G, Bg, 5, 256, 8, 128, stats=True)
+    assert relg(y, y2) < 3e-7 and relg(st.double().sum(1)[:, 1], st2.double().sum(1)[:, 1]) < 1e-6
+    rr = ref.reshape(G, Bg, 128, 64).permute(0, 1, 3, 2).reshape(G, Bg * 64, 128)
+    sums = st.double().sum(1)
+    assert float((sums[:, 0] - rr.sum(1)).norm() / rr.abs().sum(1).norm()) < 1e-6 and relg(sums[:, 1], (rr * rr).sum(1)) < 1e-5
+
+
+def test_planes_input_gradient_with_the_epilogues(x3):
+    """The two large N % 128 == 0 input-gradient launches of the decoder backward on split operands -- BatchNorm + Swish backward
+    epilogue with its per-tile sums, activation backward epilogue -- against the in-kernel split (to the last bits), and against ATen."""
+    G, Bg, Hi, Cin, Ho, N = 4, 256, 16, 64, 8, 128
+    Bt, rows = G * Bg, G * Bg * Ho * Ho
+    A, Bp = rnd(Bt * Hi * Hi, Cin, seed=20).to(DEV), rnd(16, N, Cin, seed=21, scale=0.1).to(DEV)
+    y = rnd(rows, N, seed=22).to(DEV)
+    mean, rstd = rnd(G, N, seed=23).to(DEV), (rnd(G, N, seed=24).abs() + 0.5).to(DEV)
+    gamma, beta = (rnd(N, seed=25).abs() + 0.5).to(DEV), rnd(N, seed=26).to(DEV)
+    assert ops.B.igemm_planes_served(CONV, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
+
+    def run(a, b):
+        T = ops.B.igemm_stat_tiles(CONV, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
+        C, st = torch.empty(rows, N, device=DEV), torch.empty(G, T, 2, N, device=DEV)
+        ops.B.igemm_nt_dgrad_bn(a, b, C, st, y, mean, rstd, gamma, beta, CONV, G, Bg, Hi, Hi, Cin, Ho, Ho, N, 2, -1)
+        return C, st
+    (C, s), (C2, s2) = run(_planes(A), _planes(Bp.view(-1, Cin))), run(A, Bp)
+    assert relg(C, C2) < 3e-7 and relg(s.double().sum(1), s2.double().sum(1)) < 1e-5
+    # plain launch of the same shape against fp64 ATen
+    yp, _, _ = layers.conv_like(_planes(A), _planes(Bp.view(-1, Cin)), CONV, G, Bg, Hi, Cin, Ho, N, 2, -1)
+    w = Bp.view(4, 4, N, Cin).permute(2, 3, 0, 1).double()
+    ref = F.conv2d(A.view(Bt, Hi, Hi, Cin).permute(0, 3, 1, 2).double(), w, stride=2, padding=1)
+    assert relg(from_rows(yp, Bt, Ho, N), ref) < 2e-6
+    # activation-backward epilogue: decoder layer-1 input gradient (1024 x 8x8x128 -> 5x5x256)
+    A1, B1 = rnd(1024 * 64, 128, seed=30).to(DEV), rnd(16, 256, 128, seed=31, scale=0.1).to(DEV)
+    u = rnd(1024 * 25, 256, seed=32).to(DEV)
+    d1 = layers.dgrad_act(_planes(A1), _planes(B1.view(-1, 128)), CONV, 1, 1024, 8, 128, 5, 256, u, ops.ACT_SWISH, 1, 0)
+    d2 = layers.dgrad_act(A1, B1, CONV, 1, 1024, 8, 128, 5, 256, u, ops.ACT_SWISH, 1, 0)
+    assert relg(d1, d2) < 3e-7
+
+
+def test_planes_launch_is_refused_where_it_is_not_served(x3):
+    A, Bp = rnd(4 * 64, 64, seed=40).to(DEV), rnd(16, 64, 64, seed=41).to(DEV)
+    assert not ops.B.igemm_planes_served(CONV, 1, 4, 8, 8, 64, 4, 4, 64)
+    with pytest.raises(Exception):
+        layers.conv_like(_planes(A), _planes(Bp.view(-1, 64)), CONV, 1, 4, 8, 64, 4, 64, 2, -1)
