@@ -275,6 +275,9 @@ def main():
                          "module API, running-estimate BatchNorm); prints its own JSON line, not the BASELINE metric")
     ap.add_argument("--no-grouped-heads", action="store_true",
                     help="A/B switch: launch the heads of the three encoders one by one instead of as grouped launches")
+    ap.add_argument("--no-planes", action="store_true",
+                    help="A/B switch (f32x3): every GEMM splits its fp32 operands inside the kernel (the round-4 structure) instead of "
+                         "taking them already split where the plane-ring kernel serves the launch")
     ap.add_argument("--single-lane", action="store_true",
                     help="no visual/tactile stream overlap: per-kernel durations in a rocprofv3 trace then match "
                          "the roofline object's live HIP-event measurement")
@@ -327,6 +330,9 @@ def main():
     from mmdyn_hip.engine import MVAEStep
     from mmdyn_hip.models import setup_model, NoiseSource
     from mmdyn_hip.profiling import profile_step
+    if args.no_planes:
+        from mmdyn_hip import layers as _layers
+        _layers.PLANES = False
     from mmdyn_hip.utils.seeded_init import seeded_batch
 
     S = args.image_size

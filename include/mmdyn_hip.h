@@ -210,7 +210,9 @@ typedef struct {
   const float* src;
   float* dst;
   int kind, rows_in, cols_in, rows_out, cols_out, ld_out;
-  int dst_bf16;   /* 1: dst is a bf16 tensor (ld_out in elements), 2: an IEEE-half tensor; the GEMM operands of the 16-bit modes */
+  int dst_bf16;   /* 1: dst is a bf16 tensor (ld_out in elements), 2: an IEEE-half tensor; the GEMM operands of the 16-bit modes;
+                     3 (kinds 100 / 101 only): dst is a PLANE tensor, rows (tap, x) of [plane][y] bf16 -- the exact three-term split
+                     of the packed weight (mmdyn_split_planes of the kind's fp32 output), the Bp of the plane launches */
 } mmdyn_pack_entry;
 int mmdyn_pack_plan(const mmdyn_pack_entry* plan_dev, int n, void* stream);
 
@@ -456,6 +458,14 @@ int mmdyn_wgrad_tn_mx(const void* D, const void* Gt, float* partial, int mode, i
  * format of the fp32x3 arithmetic's GEMM operands, the role nn.Conv2d's fp32 input tensor plays in vae.py:198-216, 264-277.) */
 int mmdyn_split_planes(const float* x, void* planes, int64_t rows, int C, void* stream);
 int mmdyn_igemm_planes_served(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
+/* mmdyn_bn_swish_fwd / mmdyn_bn_swish_bwd_apply (train-mode nn.BatchNorm2d + Swish forward, vae.py:200-208, 268-276, and the apply
+ * pass of their backward) with the result ALSO (a / dy non-null) or ONLY (a / dy NULL) written as a plane tensor -- the split
+ * rides on a pass that exists anyway, so the GEMMs that consume the tensor find their operand already split. */
+int mmdyn_bn_swish_fwd_planes(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              float* a, void* a_planes, int G, int rows_per_group, int C, void* stream);
+int mmdyn_bn_swish_bwd_apply_planes(const float* da, const float* y, const float* mean, const float* rstd, const float* gamma,
+                                    const float* beta, const float* sums, float* dy, void* dy_planes, int G, int rows_per_group,
+                                    int C, int da_is_du, void* stream);
 int mmdyn_bn_swish_fwd_b16(const uint16_t* y, const float* mean, const float* rstd, const float* gamma,
                            const float* beta, uint16_t* a, int G, int rows_per_group, int C, int half, void* stream);
 int mmdyn_bn_swish_bwd_reduce_b16(const uint16_t* da, const uint16_t* y, const float* mean, const float* rstd,

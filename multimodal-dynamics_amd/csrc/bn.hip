@@ -335,6 +335,77 @@ __global__ void bn_swish_bwd_apply_kernel(const T* __restrict__ da, const T* __r
   }
 }
 
+// The same two passes writing their result as a PLANE tensor (rows of [plane][C] bf16: the exact three-term split, common.h) for
+// the fp32x3 GEMMs that take their operands already split -- the split rides on a pass that exists anyway (VERDICT r4 items 1 and
+// 3a).  One thread = 8 channels of a row: two 16-byte loads per input, three 16-byte plane stores; the fp32 result is written as
+// well when `a` / `dy` is not null (a consumer that still wants fp32).
+__global__ void bn_swish_fwd_planes_kernel(const float* __restrict__ y, BnParams bp, float* __restrict__ a, bf16_t* __restrict__ ap,
+                                           int64_t total8, int rows_per_group, int C) {
+  const int CV = C / 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const int64_t row = i / CV;
+    const int g = (int)(row / rows_per_group);
+    f32x4 v[2], o[2];
+    ldv_nt<float>(y + i * 8, v);
+    ldv_nt<float>(y + i * 8 + 4, v + 1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c0 = cv * 8 + q * 4;
+      f32x4 m = *reinterpret_cast<const f32x4*>(bp.mean + (size_t)g * C + c0);
+      f32x4 r = *reinterpret_cast<const f32x4*>(bp.rstd + (size_t)g * C + c0);
+      f32x4 ga = *reinterpret_cast<const f32x4*>(bp.gamma + c0);
+      f32x4 be = *reinterpret_cast<const f32x4*>(bp.beta + c0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[q][k] = swishf_(ga[k] * ((v[q][k] - m[k]) * r[k]) + be[k]);
+    }
+    if (a) {
+      stv_nt<float>(a + i * 8, o);
+      stv_nt<float>(a + i * 8 + 4, o + 1);
+    }
+    store_planes8(ap + row * 3 * (int64_t)C + cv * 8, C, o[0], o[1]);
+  }
+}
+
+__global__ void bn_swish_bwd_apply_planes_kernel(const float* __restrict__ da, const float* __restrict__ y, BnParams bp,
+                                                 const float* __restrict__ sums, float* __restrict__ dy, bf16_t* __restrict__ dyp,
+                                                 int64_t total8, int rows_per_group, int C, int da_is_du) {
+  const int CV = C / 8;
+  const float inv_n = 1.f / (float)rows_per_group;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const int64_t row = i / CV;
+    const int g = (int)(row / rows_per_group);
+    f32x4 v[2], d[2], o[2];
+    ldv_nt<float>(y + i * 8, v);
+    ldv_nt<float>(y + i * 8 + 4, v + 1);
+    ldv_nt<float>(da + i * 8, d);
+    ldv_nt<float>(da + i * 8 + 4, d + 1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c0 = cv * 8 + q * 4;
+      f32x4 m = *reinterpret_cast<const f32x4*>(bp.mean + (size_t)g * C + c0);
+      f32x4 r = *reinterpret_cast<const f32x4*>(bp.rstd + (size_t)g * C + c0);
+      f32x4 ga = *reinterpret_cast<const f32x4*>(bp.gamma + c0);
+      f32x4 be = *reinterpret_cast<const f32x4*>(bp.beta + c0);
+      f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + ((size_t)g * 2 + 0) * C + c0);
+      f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + ((size_t)g * 2 + 1) * C + c0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float xh = (v[q][k] - m[k]) * r[k];
+        float u = ga[k] * xh + be[k];
+        float du = da_is_du ? d[q][k] : d[q][k] * swish_gradf_(u);
+        o[q][k] = ga[k] * r[k] * (du - s0[k] * inv_n - xh * (s1[k] * inv_n));
+      }
+    }
+    if (dy) {
+      stv_nt<float>(dy + i * 8, o);
+      stv_nt<float>(dy + i * 8 + 4, o + 1);
+    }
+    store_planes8(dyp + row * 3 * (int64_t)C + cv * 8, C, o[0], o[1]);
+  }
+}
+
 }  // namespace
 
 extern "C" int mmdyn_colstats_tiles(int rows_per_group) { return ceil_div(rows_per_group, tile_rows_for(rows_per_group)); }
@@ -533,5 +604,31 @@ extern "C" int mmdyn_bn_swish_bwd_apply(const float* da, const float* y, const f
   int64_t total4 = (int64_t)G * rows_per_group * (C / 4);
   hipLaunchKernelGGL(bn_swish_bwd_apply_kernel<float>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, da,
                      y, bp, sums, dy, total4, rows_per_group, C, da_is_du);
+  MMDYN_LAUNCH_CHECK();
+}
+
+/* mmdyn_bn_swish_fwd / mmdyn_bn_swish_bwd_apply with the result written as a PLANE tensor (rows of [plane][C] bf16, the exact
+ * three-term split: mmdyn_split_planes) for the fp32x3 GEMMs that take their operands already split; `a` / `dy` may be NULL when no
+ * consumer wants the fp32 tensor.  The fp32 values are bit-identical to the plain entry points'. */
+extern "C" int mmdyn_bn_swish_fwd_planes(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                         float* a, void* a_planes, int G, int rows_per_group, int C, void* stream) {
+  if (!y || !mean || !rstd || !gamma || !beta || !a_planes) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
+  BnParams bp{mean, rstd, gamma, beta};
+  const int64_t total8 = (int64_t)G * rows_per_group * (C / 8);
+  hipLaunchKernelGGL(bn_swish_fwd_planes_kernel, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, bp, a,
+                     reinterpret_cast<bf16_t*>(a_planes), total8, rows_per_group, C);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_bn_swish_bwd_apply_planes(const float* da, const float* y, const float* mean, const float* rstd,
+                                               const float* gamma, const float* beta, const float* sums, float* dy, void* dy_planes,
+                                               int G, int rows_per_group, int C, int da_is_du, void* stream) {
+  if (!da || !y || !mean || !rstd || !gamma || !beta || !sums || !dy_planes) return MMDYN_ERR_NULL;
+  if (!bn_shape_ok(G, rows_per_group, C)) return MMDYN_ERR_SHAPE;
+  BnParams bp{mean, rstd, gamma, beta};
+  const int64_t total8 = (int64_t)G * rows_per_group * (C / 8);
+  hipLaunchKernelGGL(bn_swish_bwd_apply_planes_kernel, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, da, y, bp, sums, dy,
+                     reinterpret_cast<bf16_t*>(dy_planes), total8, rows_per_group, C, da_is_du);
   MMDYN_LAUNCH_CHECK();
 }

@@ -47,6 +47,32 @@ __device__ __forceinline__ void split3_bf16(float x0, float x1, uint32_t& hi, ui
   const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
   lo = pack2_bf16(s0, s1);
 }
+// Eight consecutive channels of one row of a PLANE tensor (rows of [plane][C] bf16: hi | mid | lo, the operand format of the GEMMs
+// that take their fp32x3 operands already split): three 16-byte stores.  `row_c0` points at channel c0 of the row's first plane.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_planes8(bf16_t* row_c0, int C, const f32x4& a, const f32x4& b) {
+  uint32_t h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+  split3_bf16(a[0], a[1], h0, m0, l0);
+  split3_bf16(a[2], a[3], h1, m1, l1);
+  split3_bf16(b[0], b[1], h2, m2, l2);
+  split3_bf16(b[2], b[3], h3, m3, l3);
+  *reinterpret_cast<u32x4_t*>(row_c0) = u32x4_t{h0, h1, h2, h3};
+  *reinterpret_cast<u32x4_t*>(row_c0 + C) = u32x4_t{m0, m1, m2, m3};
+  *reinterpret_cast<u32x4_t*>(row_c0 + 2 * C) = u32x4_t{l0, l1, l2, l3};
+}
+// ... and back: the fp32 values of eight consecutive channels (exact: hi + mid has at most 16 significant bits, + lo is x)
+__device__ __forceinline__ void load_planes8(const bf16_t* row_c0, int C, f32x4& a, f32x4& b) {
+  const u32x4_t h = *reinterpret_cast<const u32x4_t*>(row_c0);
+  const u32x4_t m = *reinterpret_cast<const u32x4_t*>(row_c0 + C);
+  const u32x4_t l = *reinterpret_cast<const u32x4_t*>(row_c0 + 2 * C);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    a[2 * k] = (__uint_as_float(h[k] << 16) + __uint_as_float(m[k] << 16)) + __uint_as_float(l[k] << 16);
+    a[2 * k + 1] = (__uint_as_float(h[k] & 0xffff0000u) + __uint_as_float(m[k] & 0xffff0000u)) + __uint_as_float(l[k] & 0xffff0000u);
+    b[2 * k] = (__uint_as_float(h[2 + k] << 16) + __uint_as_float(m[2 + k] << 16)) + __uint_as_float(l[2 + k] << 16);
+    b[2 * k + 1] = (__uint_as_float(h[2 + k] & 0xffff0000u) + __uint_as_float(m[2 + k] & 0xffff0000u)) + __uint_as_float(l[2 + k] & 0xffff0000u);
+  }
+}
 // Second 16-bit storage type: IEEE half (the fp16-storage mode, BASELINE configs[4]).  A distinct C++ type so that the
 // kernels templated on the storage type get their own instances; same size and alignment as bf16_t.
 struct half_t { uint16_t v; };

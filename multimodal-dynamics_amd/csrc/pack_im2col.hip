@@ -83,7 +83,16 @@ __global__ void repack2d_ld_kernel(const float* __restrict__ in, TO* __restrict_
 constexpr int PACK_LDS_FLOATS = 6912;           // 27 KB (5 blocks per CU): the largest tiles below are 32 x 201 and 400 x 17 floats
 
 // conv weight: Wc[d0][d1][16] -> P[tap][x][y], (x, y) = (a, b) or swapped: tile = TA values of a x TB values of b x 16 taps
-template <typename TO>
+// PLANES (TO = bf16_t): the destination is a plane tensor -- rows (tap, x) of [plane][ny] bf16, the exact three-term split of the
+// packed weight (the Bp operand of the fp32x3 launches that take their operands already split, igemm_wsp3_kernel)
+__device__ __forceinline__ void st1_planes(bf16_t* row_y, int ny, float v) {
+  uint32_t h, m, l;
+  split3_bf16(v, 0.f, h, m, l);
+  row_y[0] = (bf16_t)(h & 0xffffu);
+  row_y[ny] = (bf16_t)(m & 0xffffu);
+  row_y[2 * ny] = (bf16_t)(l & 0xffffu);
+}
+template <typename TO, bool PLANES = false>
 __device__ __forceinline__ void pack_conv_tiled(const float* __restrict__ src, TO* __restrict__ dst, int d0, int d1, int swap,
                                                 float* lds) {
   // runs on the destination are along y: b for the keep form, a for the swapped one
@@ -110,7 +119,10 @@ __device__ __forceinline__ void pack_conv_tiled(const float* __restrict__ src, T
       const int iy = i % TY, r = i / TY, ix = r % TX, tap = r / TX;
       const int ia = swap ? iy : ix, ib = swap ? ix : iy;
       const int x = (swap ? b0 : a0) + ix, y = (swap ? a0 : b0) + iy;
-      if (x < nx && y < ny) st1<TO>(dst + ((size_t)tap * nx + x) * ny + y, lds[(ia * TB + ib) * LDT + tap]);
+      if (x < nx && y < ny) {
+        if constexpr (PLANES) st1_planes(reinterpret_cast<bf16_t*>(dst) + ((size_t)tap * nx + x) * 3 * ny + y, ny, lds[(ia * TB + ib) * LDT + tap]);
+        else st1<TO>(dst + ((size_t)tap * nx + x) * ny + y, lds[(ia * TB + ib) * LDT + tap]);
+      }
     }
   }
 }
@@ -235,7 +247,9 @@ __device__ __forceinline__ void pack_plan_entry(const mmdyn_pack_entry& e, float
 __global__ __launch_bounds__(256) void pack_plan_kernel(const mmdyn_pack_entry* __restrict__ plan) {
   __shared__ __attribute__((aligned(16))) float lds[PACK_LDS_FLOATS];
   const mmdyn_pack_entry e = plan[blockIdx.y];
-  if (e.dst_bf16 == 2)            // (2: IEEE half, the fp16-storage mode)
+  if (e.dst_bf16 == 3) {          // (3: plane tensor -- conv-weight kinds only, checked by mmdyn_pack_plan's caller side)
+    if (e.kind >= 100) pack_conv_tiled<bf16_t, true>(e.src, reinterpret_cast<bf16_t*>(e.dst), e.rows_in, e.cols_in, e.kind - 100, lds);
+  } else if (e.dst_bf16 == 2)     // (2: IEEE half, the fp16-storage mode)
     pack_plan_entry<half_t>(e, lds);
   else if (e.dst_bf16)
     pack_plan_entry<bf16_t>(e, lds);

@@ -102,6 +102,8 @@ _SIGNATURES = {
     "mmdyn_wgrad_tn_mx": "ppp" + "iiiiiiiiiii" + "i" + "p",
     "mmdyn_split_planes": "pp" + "l" + "i" + "p",
     "mmdyn_igemm_planes_served": "iiiiiiiii",
+    "mmdyn_bn_swish_fwd_planes": "ppppppp" + "iii" + "p",
+    "mmdyn_bn_swish_bwd_apply_planes": "ppppppppp" + "iiii" + "p",
     "mmdyn_bn_swish_fwd_b16": "pppppp" + "iiii" + "p",
     "mmdyn_bn_swish_bwd_reduce_b16": "ppppppp" + "iiii" + "p",
     "mmdyn_bn_swish_bwd_apply_b16": "pppppppp" + "iiiii" + "p",

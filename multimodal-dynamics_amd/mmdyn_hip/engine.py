@@ -347,7 +347,7 @@ class MVAEStep:
             if self._hg_views is not None:     # the grouped launches' operands: the plan packs straight into their slices
                 pre = {"h" + p[0]: v for p, v in zip(self._head_prefixes, self._hg_views)}
             self.plan = layers.PackPlan(specs, early=("W1p", "W2k", "W3k", "W4k", "W5k", "W6k", "Wf", "Wh", "bh"),
-                                        w_dtype=w_dtype(precision), prealloc=pre)
+                                        w_dtype=w_dtype(precision), prealloc=pre, plane_twins=precision == "fp32x3")
         self._capturing = False
         self._graph = None
         self._static_mask = self._static_cond = None

@@ -14,6 +14,8 @@ Reference structure restated here (file:line relative to /root/reference/mmdyn/p
   pose MLPs      :117-123, 14-19        the flatten order c*25+hw of :227/:295 is absorbed into the
   packed FC weights (hw*256+c), so no activation is ever transposed.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -77,9 +79,59 @@ def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch
     return C, Ca
 
 
+# fp32x3: hand the plane-ring kernel its operands already split where it serves the launch (False: A/B measurements only --
+# every launch then splits inside the kernel, the round-4 structure)
+PLANES = True
+# packed fp32 weight (by data pointer) -> (weak reference to that tensor, the Planes twin a PackPlan writes next to it every step).
+# The plan's outputs never move; the weak reference guards against a dead plan's address being handed to another tensor.
+PLANE_TWIN = {}
+
+
+def _plane_twin(Wp):
+    ent = PLANE_TWIN.get(Wp.data_ptr())
+    if ent is None:
+        return None
+    if ent[0]() is not Wp:
+        if ent[0]() is None:
+            del PLANE_TWIN[Wp.data_ptr()]
+        return None
+    return ent[1]
+
+
+def planes_served(mode, G, Bg, Hi, Cin, Ho, N):
+    """True when the fp32x3 launch of this shape takes its operands already split (plane-ring kernel, host-side query)."""
+    served = getattr(ops.B, "igemm_planes_served", None) if PLANES else None
+    return bool(served is not None and ACT_DTYPE == torch.float32 and served(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N))
+
+
+def split_operands(x, Wp, mode, G, Bg, Hi, Cin, Ho, N):
+    """fp32x3: where the plane-ring kernel serves the launch (the large N % 128 == 0 convolution-level GEMMs), hand it its two
+    operands ALREADY SPLIT -- (Planes(x), Planes(Wp)) -- so that the GEMM contains no split; everything else gets (x, Wp) back.
+    An activation that arrives as Planes was written so by its producer (bn_swish_*(planes=...)); the packed weight's twin comes
+    from the pack plan (PLANE_TWIN); whatever is still fp32 is split here by its own launch (mmdyn_split_planes)."""
+    if isinstance(Wp, ops.Planes):
+        return x, Wp
+    xin = x.t if isinstance(x, ops.Planes) else x
+    if xin.dtype not in (torch.float32, torch.bfloat16) or Wp.dtype != torch.float32 or not planes_served(mode, G, Bg, Hi, Cin, Ho, N):
+        if isinstance(x, ops.Planes):
+            raise ValueError("mmdyn_hip: a plane operand for a launch the plane-ring kernel does not serve")
+        return x, Wp
+    if not isinstance(x, ops.Planes):
+        xp = ops.Planes(x.numel() // Cin, Cin, x.device)
+        ops.B.split_planes(x, xp)
+        x = xp
+    wp = _plane_twin(Wp)
+    if wp is None or wp.C != Cin or wp.rows * Cin != Wp.numel():
+        wp = ops.Planes(Wp.numel() // Cin, Cin, Wp.device)
+        ops.B.split_planes(Wp, wp)
+    return x, wp
+
+
 def conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride=1, offset=0, stats=False, out_dtype=None):
     """Implicit-GEMM conv / transposed conv on NHWC rows; optional per-tile BatchNorm partial sums."""
     Bt = G * Bg
+    if out_dtype in (None, torch.float32) and ACT_DTYPE == torch.float32:
+        x, Wp = split_operands(x, Wp, mode, G, Bg, Hi, Cin, Ho, N)
     y = _new(x, Bt * Ho * Ho, N, dtype=ACT_DTYPE if out_dtype is None else out_dtype)
     st, T = None, 0
     if stats:
@@ -95,6 +147,8 @@ def dgrad_act(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, u, act, stride=1, offset=0):
     """Input-gradient GEMM with the backward of the activation whose pre-activation is ``u`` in its epilogue:
     returns dL/du = (x (*) Wp) * act'(u), stored like ``u``."""
     du = torch.empty_like(u)
+    if u.dtype == torch.float32:
+        x, Wp = split_operands(x, Wp, mode, G, Bg, Hi, Cin, Ho, N)
     ops.B.igemm_nt_dgrad_act(x, Wp, du, u, act, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride, offset)
     return du
 
@@ -210,11 +264,15 @@ def bn_swish_backward(da, y, mean, rstd, bn, dgamma, dbeta, G, rows_per_group, C
     return dy
 
 
-def dgrad_bn_swish_backward(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride, offset, y, mean, rstd, bn, dgamma, dbeta):
+def dgrad_bn_swish_backward(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride, offset, y, mean, rstd, bn, dgamma, dbeta, planes_out=None):
     """Input-gradient GEMM of the layer ABOVE fused with this layer's BatchNorm+Swish backward: the GEMM epilogue
     turns dL/da into du = dL/da * swish'(.) and emits the per-tile sums, so only finalize + apply remain.
-    Returns dL/dy (gradient w.r.t. this layer's conv output)."""
+    Returns dL/dy (gradient w.r.t. this layer's conv output).  ``planes_out`` (True / False instead of None): returns the pair
+    (dL/dy, the same tensor as Planes or None) -- with True the apply pass writes the operand of the next plane launch already
+    split."""
     rows_per_group = Bg * Ho * Ho
+    if y.dtype == torch.float32 and mode != IM2COL3:
+        x, Wp = split_operands(x, Wp, mode, G, Bg, Hi, Cin, Ho, N)
     T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N,
                                all16=not isinstance(x, ops.Planes) and ops._is16(x) and ops._is16(Wp))
     du = torch.empty_like(y)
@@ -223,8 +281,12 @@ def dgrad_bn_swish_backward(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride, offset, 
                             stride, offset)
     sums = _bn_backward_sums(y, partial, T, dgamma, dbeta, G, N)
     dy = torch.empty_like(y)
+    if planes_out and y.dtype == torch.float32:
+        dyp = ops.Planes(y.shape[0], N, y.device)
+        ops.B.bn_swish_bwd_apply(du, y, mean, rstd, bn.gamma, bn.beta, sums, dy, G, rows_per_group, N, True, planes=dyp)
+        return dy, dyp
     ops.B.bn_swish_bwd_apply(du, y, mean, rstd, bn.gamma, bn.beta, sums, dy, G, rows_per_group, N, True)
-    return dy
+    return dy if planes_out is None else (dy, None)
 
 
 def wgrad(D, Gt, canon, mode, Bt, Hr, Cd, Hi, Cg, stride=1, offset=0, cg_canon=None, perm=0, defer=None):
@@ -411,6 +473,12 @@ def _alloc_packed(specs, like, w_dtype=None, pre=None):
     return out
 
 
+def wants_plane_twin(s):
+    """Conv-weight packs [16][N][Cin] whose launches the plane-ring kernel can serve (N % 128 == 0, Cin % 32 == 0) also get a
+    Planes twin from the plan in the fp32x3 arithmetic (whether a given batch's launch takes it: planes_served)."""
+    return s["kind"] >= K_KEEP and len(s["shape"]) == 3 and s["shape"][1] % 128 == 0 and s["shape"][2] % 32 == 0
+
+
 def pack_now(specs, pre=None):
     """One kernel per entry (module-API path)."""
     out = _alloc_packed(specs, specs[0]["src"], pre=pre)
@@ -431,9 +499,11 @@ class PackPlan:
     """All repacks of the given spec lists as ONE kernel launch (mmdyn_pack_plan).  Source and destination
     storage must not move afterwards (the fused engine's flat parameter buffer and these outputs never do)."""
 
-    def __init__(self, named_specs, early=(), w_dtype=None, prealloc=None):
+    def __init__(self, named_specs, early=(), w_dtype=None, prealloc=None, plane_twins=False):
         """``early``: names of the packed tensors the first phase of the step needs; they go to the front of the
-        table so that :meth:`run_early` / :meth:`run_late` can launch the two halves at different points."""
+        table so that :meth:`run_early` / :meth:`run_late` can launch the two halves at different points.
+        ``plane_twins`` (fp32x3): the conv-weight packs the plane-ring kernel can use are ALSO written as Planes by the same
+        launch (one more table entry each, dst_bf16 = 3) and registered in PLANE_TWIN under their fp32 pack."""
         import ctypes
         from ._lib import PackEntry
         self.packed, entries = {}, []
@@ -444,12 +514,22 @@ class PackPlan:
             order += [(0 if s["name"] in early else 1, len(order) + i, outs, s) for i, s in enumerate(specs)]
         order.sort(key=lambda t: (t[0], t[1]))
         self.n_early = sum(1 for t in order if t[0] == 0)
+        self.twins = []
         for _, _, outs, s in order:
-            for s in (s,):
+            for twin in ((False, True) if (plane_twins and wants_plane_twin(s) and outs[s["name"]].dtype == torch.float32) else (False,)):
                 dst = outs[s["name"]]
                 e = PackEntry()
                 e.src = s["src"].data_ptr()
                 e.kind, e.rows_in, e.cols_in = s["kind"], s["rin"], s["cin"]
+                if twin:
+                    pl = ops.Planes(16 * s["shape"][1], s["shape"][2], dst.device)
+                    PLANE_TWIN[dst.data_ptr()] = (weakref.ref(dst), pl)
+                    self.twins.append((dst.data_ptr(), pl))
+                    e.dst, e.rows_out, e.cols_out, e.ld_out, e.dst_bf16 = pl.t.data_ptr(), 0, 0, 0, 3
+                    if s["name"] in early:
+                        self.n_early += 1
+                    entries.append(e)
+                    continue
                 if s["kind"] >= K_KEEP:
                     e.dst, e.rows_out, e.cols_out, e.ld_out = dst.data_ptr(), 0, 0, 0
                 else:
@@ -725,20 +805,28 @@ def decoder_backward_steps(P, c, dlogits, grads, need_dz=True, defer=None):
     else:
         wgrad(t["a"], dlogits, grads[f"hallucinate.{c['last']}.weight"], IM2COL3, Bt, S // 2, 32, S, 64, cg_canon=48, defer=defer)
     # the input-gradient GEMM of every layer carries the BatchNorm+Swish backward of the layer below in its epilogue
-    dy = dgrad_bn_swish_backward(dlogits, pk[f"W{n + 1}p"], IM2COL3, G, Bg, S, 64, S // 2, 32, 1, 0, t["y"], t["m"], t["r"],
-                                 t["bn"], *bn_keys(t))
+    def next_takes_planes(k):
+        """the input-gradient launch that consumes stage k's dL/dy: of stage k (k >= 1), or the k4 s1 p0 layer's (k = 0)"""
+        if k >= 1:
+            u = st[k]
+            return planes_served(CONV, G, Bg, u["Ho"], u["cout"], u["Hi"], u["cin"])
+        return planes_served(CONV, 1, Bt, 8, st[0]["cout"], 5, st[0]["cin"])
+
+    dy, dyp = dgrad_bn_swish_backward(dlogits, pk[f"W{n + 1}p"], IM2COL3, G, Bg, S, 64, S // 2, 32, 1, 0, t["y"], t["m"], t["r"],
+                                      t["bn"], *bn_keys(t), planes_out=next_takes_planes(n - 1))
     yield
     for k in range(n - 1, 0, -1):
         up, t = st[k], st[k - 1]
         wgrad(up["a_in"], dy, grads[f"hallucinate.{up['i']}.weight"], CONV, Bt, up["Hi"], up["cin"], up["Ho"], up["cout"], 2, -1,
               defer=defer)
-        dy = dgrad_bn_swish_backward(dy, pk[f"W{k + 1}k"], CONV, G, Bg, up["Ho"], up["cout"], up["Hi"], up["cin"], 2, -1,
-                                     t["y"], t["m"], t["r"], t["bn"], *bn_keys(t))
+        dy, dyp = dgrad_bn_swish_backward(dy if dyp is None else dyp, pk[f"W{k + 1}k"], CONV, G, Bg, up["Ho"], up["cout"], up["Hi"],
+                                          up["cin"], 2, -1, t["y"], t["m"], t["r"], t["bn"], *bn_keys(t),
+                                          planes_out=next_takes_planes(k - 1))
         yield
     t = st[0]
     wgrad(c["h0"], dy, grads[f"hallucinate.{t['i']}.weight"], CONV, Bt, 5, t["cin"], 8, t["cout"], 1, 0, defer=defer)
     # input gradient of the k4 s1 p0 layer with the FC layer's Swish backward in its epilogue (FC level: fp32)
-    du0 = dgrad_act(dy, pk["W1k"], CONV, 1, Bt, 8, t["cout"], 5, t["cin"], c["u0"], ACT_SWISH, 1, 0)
+    du0 = dgrad_act(dy if dyp is None else dyp, pk["W1k"], CONV, 1, Bt, 8, t["cout"], 5, t["cin"], c["u0"], ACT_SWISH, 1, 0)
     yield
     wgrad(du0, c["z"], grads["upsample.0.weight"], DENSE, Bt, 1, FEAT, 1, L, cg_canon=c["Lc"], perm=2, defer=defer)
     ops.B.colsum(du0, grads["upsample.0.bias"], Bt, FEAT, 2, 0.0)

@@ -453,7 +453,14 @@ class HipBackend:
                                          G, T, C, rows_per_group, eps, momentum, repeat, self._ticket(partial), _stream()),
               "mmdyn_bn_finalize")
 
-    def bn_swish_fwd(self, y, mean, rstd, gamma, beta, a, G, rows_per_group, C):
+    def bn_swish_fwd(self, y, mean, rstd, gamma, beta, a, G, rows_per_group, C, planes=None):
+        """``planes`` (a Planes): the activated tensor is ALSO written already split (``a`` may then be None: planes only)."""
+        if planes is not None:
+            if planes.rows != G * rows_per_group or planes.C != C:
+                raise ValueError("mmdyn_hip: bn_swish_fwd: plane tensor of the wrong shape")
+            check(self.lib.mmdyn_bn_swish_fwd_planes(_ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(a),
+                                                     planes.t.data_ptr(), G, rows_per_group, C, _stream()), "mmdyn_bn_swish_fwd_planes")
+            return
         (py, y16), (pa, a16) = _aptr(y), _aptr(a)
         if y16 != a16:
             raise TypeError("mmdyn_hip: bn_swish_fwd input and output must share the storage type")
@@ -500,7 +507,15 @@ class HipBackend:
                                                   float(sums_scale), float(beta_acc), _stream()),
               "mmdyn_bn_bwd_finalize_sums")
 
-    def bn_swish_bwd_apply(self, da, y, mean, rstd, gamma, beta, sums, dy, G, rows_per_group, C, da_is_du=False):
+    def bn_swish_bwd_apply(self, da, y, mean, rstd, gamma, beta, sums, dy, G, rows_per_group, C, da_is_du=False, planes=None):
+        """``planes`` (a Planes): dL/dy is ALSO written already split (``dy`` may then be None: planes only)."""
+        if planes is not None:
+            if planes.rows != G * rows_per_group or planes.C != C:
+                raise ValueError("mmdyn_hip: bn_swish_bwd_apply: plane tensor of the wrong shape")
+            check(self.lib.mmdyn_bn_swish_bwd_apply_planes(_ptr(da), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums),
+                                                           _ptr(dy), planes.t.data_ptr(), G, rows_per_group, C, int(da_is_du), _stream()),
+                  "mmdyn_bn_swish_bwd_apply_planes")
+            return
         (pd, d16), (py, y16), (po, o16) = _aptr(da), _aptr(y), _aptr(dy)
         if not (d16 == y16 == o16):
             raise TypeError("mmdyn_hip: bn_swish_bwd_apply tensors must share the storage type")

@@ -9,7 +9,7 @@ import torch
 
 from . import ops
 
-HOST_ONLY = {"igemm_stat_tiles", "colstats_tiles", "wgrad_chunks"}
+HOST_ONLY = {"igemm_stat_tiles", "colstats_tiles", "wgrad_chunks", "igemm_planes_served"}
 
 
 def _canon(name, a):

@@ -493,7 +493,7 @@ def test_split_planes_is_exact_and_round_to_nearest(x3):
 def test_planes_conv_transpose2d_s1p0_with_statistics(x3, G, Bg):
     """The k4 s1 p0 layer on split operands: against fp64 ATen, and against the launch that splits inside the kernel (same six
     products per K-step in the same order; the two kernels map channels to the k lanes of the 32-deep MFMA differently, so the
-    results agree to the last bits, not bit for bit)."""
+    results carry independent fp32 accumulation roundings: equal to ~1e-6 relative, not bit for bit)."""
     B = G * Bg
     x, W = rnd(B, 256, 5, 5, seed=7).to(DEV), rnd(256, 128, 4, 4, seed=8, scale=0.1).to(DEV)
     Ws, xr = layers.pack_conv(W, swap=True), nhwc_rows(x)
@@ -502,7 +502,7 @@ def test_planes_conv_transpose2d_s1p0_with_statistics(x3, G, Bg):
     ref = F.conv_transpose2d(x.double(), W.double(), stride=1, padding=0)
     assert relg(from_rows(y, B, 8, 128), ref) < 2e-6
     y2, st2, _ = layers.conv_like(xr, Ws, ops.TCONV_S1P0, G, Bg, 5, 256, 8, 128, stats=True)
-    assert relg(y, y2) < 3e-7 and relg(st.double().sum(1)[:, 1], st2.double().sum(1)[:, 1]) < 1e-6
+    assert relg(y, y2) < 1.5e-6 and relg(st.double().sum(1)[:, 1], st2.double().sum(1)[:, 1]) < 1e-6
     rr = ref.reshape(G, Bg, 128, 64).permute(0, 1, 3, 2).reshape(G, Bg * 64, 128)
     sums = st.double().sum(1)
     assert float((sums[:, 0] - rr.sum(1)).norm() / rr.abs().sum(1).norm()) < 1e-6 and relg(sums[:, 1], (rr * rr).sum(1)) < 1e-5
@@ -525,7 +525,7 @@ def test_planes_input_gradient_with_the_epilogues(x3):
         ops.B.igemm_nt_dgrad_bn(a, b, C, st, y, mean, rstd, gamma, beta, CONV, G, Bg, Hi, Hi, Cin, Ho, Ho, N, 2, -1)
         return C, st
     (C, s), (C2, s2) = run(_planes(A), _planes(Bp.view(-1, Cin))), run(A, Bp)
-    assert relg(C, C2) < 3e-7 and relg(s.double().sum(1), s2.double().sum(1)) < 1e-5
+    assert relg(C, C2) < 1.5e-6 and relg(s.double().sum(1), s2.double().sum(1)) < 1e-5
     # plain launch of the same shape against fp64 ATen
     yp, _, _ = layers.conv_like(_planes(A), _planes(Bp.view(-1, Cin)), CONV, G, Bg, Hi, Cin, Ho, N, 2, -1)
     w = Bp.view(4, 4, N, Cin).permute(2, 3, 0, 1).double()
@@ -536,7 +536,7 @@ def test_planes_input_gradient_with_the_epilogues(x3):
     u = rnd(1024 * 25, 256, seed=32).to(DEV)
     d1 = layers.dgrad_act(_planes(A1), _planes(B1.view(-1, 128)), CONV, 1, 1024, 8, 128, 5, 256, u, ops.ACT_SWISH, 1, 0)
     d2 = layers.dgrad_act(A1, B1, CONV, 1, 1024, 8, 128, 5, 256, u, ops.ACT_SWISH, 1, 0)
-    assert relg(d1, d2) < 3e-7
+    assert relg(d1, d2) < 1.5e-6
 
 
 def test_planes_launch_is_refused_where_it_is_not_served(x3):
@@ -544,3 +544,47 @@ def test_planes_launch_is_refused_where_it_is_not_served(x3):
     assert not ops.B.igemm_planes_served(CONV, 1, 4, 8, 8, 64, 4, 4, 64)
     with pytest.raises(Exception):
         layers.conv_like(_planes(A), _planes(Bp.view(-1, 64)), CONV, 1, 4, 8, 64, 4, 64, 2, -1)
+
+
+def test_batchnorm_passes_write_their_result_already_split(x3):
+    """mmdyn_bn_swish_fwd_planes / _bwd_apply_planes: the fp32 result is the plain entry point's bit for bit, the plane tensor is its
+    exact split -- with and without the fp32 copy."""
+    G, Bg, H, C = 4, 6, 16, 64
+    rpg = Bg * H * H
+    y, da = rnd(G * rpg, C, seed=50).to(DEV), rnd(G * rpg, C, seed=51).to(DEV)
+    mean, rstd = rnd(G, C, seed=52).to(DEV), (rnd(G, C, seed=53).abs() + 0.5).to(DEV)
+    gamma, beta = (rnd(C, seed=54).abs() + 0.5).to(DEV), rnd(C, seed=55).to(DEV)
+    sums = rnd(G, 2, C, seed=56).to(DEV)
+    a0 = torch.empty_like(y)
+    ops.B.bn_swish_fwd(y, mean, rstd, gamma, beta, a0, G, rpg, C)
+    for keep in (True, False):
+        a1, p = (torch.empty_like(y) if keep else None), ops.Planes(G * rpg, C, DEV)
+        ops.B.bn_swish_fwd(y, mean, rstd, gamma, beta, a1, G, rpg, C, planes=p)
+        assert torch.equal(p.float(), a0) and (a1 is None or torch.equal(a1, a0))
+    for is_du in (False, True):
+        d0 = torch.empty_like(y)
+        ops.B.bn_swish_bwd_apply(da, y, mean, rstd, gamma, beta, sums, d0, G, rpg, C, is_du)
+        for keep in (True, False):
+            d1, p = (torch.empty_like(y) if keep else None), ops.Planes(G * rpg, C, DEV)
+            ops.B.bn_swish_bwd_apply(da, y, mean, rstd, gamma, beta, sums, d1, G, rpg, C, is_du, planes=p)
+            # (two kernels, two instruction schedules: the compiler contracts the apply expression's multiply-adds differently, so the
+            #  plain entry point agrees to an ulp; the plane tensor is the exact split of THIS launch's fp32 result)
+            assert relg(p.float(), d0) < 2e-7 and (d1 is None or torch.equal(p.float(), d1))
+
+
+def test_pack_plan_writes_plane_twins(x3):
+    """A conv-weight entry with dst_bf16 = 3: the plan's Planes twin is the exact split of the fp32 pack it stands next to."""
+    W = {"hallucinate.0.weight": rnd(256, 128, 4, 4, seed=60, scale=0.1).to(DEV), "conv": rnd(128, 64, 4, 4, seed=61, scale=0.1).to(DEV)}
+    specs = [layers._spec("W1s", W["hallucinate.0.weight"], layers.K_SWAP, 256, 128, 0, 0, (16, 128, 256)),
+             layers._spec("W3k", W["conv"], layers.K_KEEP, 128, 64, 0, 0, (16, 128, 64)),
+             layers._spec("W9k", W["conv"][:64].contiguous(), layers.K_KEEP, 64, 64, 0, 0, (16, 64, 64))]
+    plan = layers.PackPlan({"d": specs}, early=("W3k",), plane_twins=True)
+    plan.run()
+    pk = plan.packed["d"]
+    assert len(plan.twins) == 2 and plan.n == 5 and plan.n_early == 2
+    for name in ("W1s", "W3k"):
+        tw = layers._plane_twin(pk[name])
+        assert tw is not None and torch.equal(tw.float().view_as(pk[name]), pk[name])
+    assert layers._plane_twin(pk["W9k"]) is None
+    ref = layers.pack_conv(W["hallucinate.0.weight"], swap=True)
+    assert torch.equal(ref, pk["W1s"])
