@@ -1038,27 +1038,84 @@ static int wsp_dispatch(const float* A, const float* Bp, const float* bias, floa
   return wsp_launch_mode<MMDYN_TCONV_S2P1, B16>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, a_bytes, b_bytes, st);
 }
 
-// P3 launches: 128x128 tiles, four loader waves + eight MFMA waves of 64x32 (two per SIMD: one wave's fragment reads land
-// under its partner's MFMAs -- tests/microbench/p3_ring_gemm.hip: LDS reads + MFMA alone 263 against 219 TFLOP/s for one 64x64
-// wave per SIMD), three ring slots of 48 KB.
-constexpr int P3_NLD = 4, P3_S = 3, P3_WM = 64, P3_WN = 32;
-template <int MODE>
+// P3 launch configurations (block tile, MFMA-wave tile, ring slots, resident blocks per CU the grid is sized for).  Four loader
+// waves everywhere.  128x128: eight MFMA waves of 64x32 (two per SIMD: one wave's fragment reads land under its partner's MFMAs --
+// tests/microbench/p3_ring_gemm.hip: LDS reads + MFMA alone 263 against 219 TFLOP/s for one 64x64 wave per SIMD), three ring slots
+// of 48 KB.  N % 128 == 64 layers: 128x64 (36 KB per K-step: 14 flop per filled byte against 21) -- variants measured per shape in
+// tests/microbench/ab_p3.py (profiles/r5/ab_p3_*.txt).
+constexpr int P3_NLD = 4;
+struct Wsp3Cfg {
+  int bm, bn, s, bpc;    // bm == 0: not served
+};
+template <int MODE, int BM, int BN, int WM, int WN, int S>
 static int wsp3_launch(const bf16_t* A, const bf16_t* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
                        IgemmGeom g, const WspSched& sc, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
-  constexpr int BM = 128, BN = 128, NM = (BM / P3_WM) * (BN / P3_WN);
+  constexpr int NM = (BM / WM) * (BN / WN);
   g.tiles_per_group = MODE == MMDYN_TCONV_S1P0 ? 64 * sc.spg : ceil_div(g.Bg * g.Hr * g.Wr, BM);
   const int nblk = (sc.units + sc.per - 1) / sc.per;
-  const size_t smem = (size_t)P3_S * (BM + BN) * P3_RB + (size_t)NRO * BM * sizeof(int) + (size_t)NM * 16 * TRLD * sizeof(float);
+  const size_t smem = (size_t)S * (BM + BN) * P3_RB + (size_t)NRO * BM * sizeof(int) + (size_t)NM * 16 * TRLD * sizeof(float);
   static LdsOptIn opt_in;
-  if (int e = opt_in.ensure((const void*)igemm_wsp3_kernel<MODE, BM, BN, P3_WM, P3_WN, P3_S, P3_NLD>, (int)smem)) return e;
+  if (int e = opt_in.ensure((const void*)igemm_wsp3_kernel<MODE, BM, BN, WM, WN, S, P3_NLD>, (int)smem)) return e;
   const bool split = has_split_tiles(g, sc);
   if (split && !slabs) return MMDYN_ERR_NULL;
-  hipLaunchKernelGGL((igemm_wsp3_kernel<MODE, BM, BN, P3_WM, P3_WN, P3_S, P3_NLD>), dim3(nblk), dim3(64 * (NM + P3_NLD)), smem, st, A, Bp,
+  hipLaunchKernelGGL((igemm_wsp3_kernel<MODE, BM, BN, WM, WN, S, P3_NLD>), dim3(nblk), dim3(64 * (NM + P3_NLD)), smem, st, A, Bp,
                      bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes);
   if (split)
-    hipLaunchKernelGGL((igemm_wsp_fixup_kernel<MODE, BM, BN, P3_WM, P3_WN, 0>), dim3(sc.tiles), dim3(64 * NM), 0, st, bias, C, C_act,
+    hipLaunchKernelGGL((igemm_wsp_fixup_kernel<MODE, BM, BN, WM, WN, 0>), dim3(sc.tiles), dim3(64 * NM), 0, st, bias, C, C_act,
                        stats, slabs, g, sc);
   MMDYN_LAUNCH_CHECK();
+}
+
+// Which launches take their operands already split, and on which tile.  Every (tile, wave tile) pair has BM / WM = 2 wave rows, so
+// a launch writes two partial-sum tiles per M-tile and class whatever the configuration (wsp3_stat_tiles).
+static Wsp3Cfg wsp3_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr, int Cin, int N, int ncls, int splitk,
+                         int b_group_stride) {
+  Wsp3Cfg c{0, 0, 0, 0};
+  if (mode != MMDYN_CONV && mode != MMDYN_TCONV_S2P1 && mode != MMDYN_TCONV_S1P0) return c;
+  if (splitk > 1 || b_group_stride || Cin % BK || N % 64) return c;
+  if ((int64_t)G * Bg * Hi * Wi * Cin * 6 >= MAX_BUFFER_BYTES || (int64_t)16 * N * Cin * 6 >= MAX_BUFFER_BYTES) return c;
+  const int cus = device_cus();
+  const int cin_steps = Cin / BK;
+  // Threshold (in 128x128x32 K-step units): 8 per CU.  Measured per shape against the kernels that split inside the GEMM
+  // (tests/microbench/ab_p3.py, profiles/r5/ab_p3_tiles_and_small_launches.txt): the plane ring wins on every convolution-level launch of
+  // the bs 256 step down to the encoder's 4096-unit ones (x1.2-1.5; the one-group k4 s1 p0 input gradient x2.8 against the
+  // register-staged quad walk) -- stream-K cuts even a 100-tile launch into equal ranges for all CUs.  Below ~8 K-steps per CU a
+  // launch is all prologue; those keep the fp32-operand kernels.
+  long units, min_units = 8L * cus;
+  if (const char* e = lab_env("MMDYN_P3_MIN_UNITS")) min_units = atol(e);
+  if (mode == MMDYN_TCONV_S1P0) {
+    if (N != 128 || Hi != 5 || Wi != 5 || Hr != 8 || Wr != 8) return c;
+    units = (long)G * ((Bg + 127) / 128) * 400 * cin_steps;
+    if (units < min_units || units >= (1L << 30)) return c;
+    return Wsp3Cfg{128, 128, 3, 1};
+  }
+  const long rows_g = (long)Bg * Hr * Wr;
+  if (rows_g >= (1L << 23)) return c;                    // float-reciprocal row decode
+  const int ksteps = (mode == MMDYN_CONV ? 16 : 4) * cin_steps;
+  if (N % 128 == 0) {
+    c = Wsp3Cfg{128, 128, 3, 1};
+  } else {
+    // N % 128 == 64: 128x64 tiles, three slots (36 KB per K-step).  Against the register-staged split kernels x1.25-1.5 on the
+    // step's four N = 64 launches; two slots at two blocks per CU and 256x64 tiles at two slots measured slower on most of them.
+    c = Wsp3Cfg{128, 64, 3, 1};
+  }
+  if (const char* e = lab_env("MMDYN_P3_TILE")) {        // LAB build: force one configuration "BM,BN,S"
+    int a = 0, b = 0, sl = 0;
+    if (sscanf(e, "%d,%d,%d", &a, &b, &sl) == 3 && N % b == 0) {
+      if (a == 128 && b == 128 && sl == 3) c = Wsp3Cfg{128, 128, 3, 1};
+      else if (a == 128 && b == 64 && sl == 3) c = Wsp3Cfg{128, 64, 3, 1};
+      else if (a == 128 && b == 64 && sl == 2) c = Wsp3Cfg{128, 64, 2, 2};
+      else if (a == 256 && b == 64 && sl == 2) c = Wsp3Cfg{256, 64, 2, 1};
+    }
+  }
+  const long tiles = (long)G * ((rows_g + c.bm - 1) / c.bm) * (N / c.bn) * ncls;
+  if (tiles * ksteps >= (1L << 30) || tiles * ksteps * (c.bn == 64 ? 1 : 2) < min_units * 2) return Wsp3Cfg{0, 0, 0, 0};
+  return c;
+}
+
+static WspSched make_sched3(const IgemmGeom& g, const Wsp3Cfg& c) {
+  WspPick p{c.bm, c.bn, c.bpc};
+  return make_sched(g, p, false);
 }
 
 // geometry of a launch as the queries below know it (shape only)
@@ -1122,31 +1179,54 @@ int mmdyn_igemm_wsp_try(const float* A, const float* Bp, const float* bias, floa
   return wsp_dispatch<0>(A, Bp, bias, C, C_act, stats, slabs, g, p, sc, st);
 }
 
-// The launch with both operands ARRIVING as three-plane bf16 rows (igemm_wsp3_kernel).  Served: what the fp32 persistent kernel
-// serves on 128x128 tiles (same wsp_pick, so partial-sum tile counts and slab sizes are the fp32 launch's), convolution modes only.
-// Returns 1 when the shape is not served.
+// The launch with both operands ARRIVING as three-plane bf16 rows (igemm_wsp3_kernel).  Returns 1 when the shape is not served.
 bool mmdyn_igemm_wsp3_serves(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
-  if (mode != MMDYN_CONV && mode != MMDYN_TCONV_S2P1 && mode != MMDYN_TCONV_S1P0) return false;
   const IgemmGeom g = query_geom(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
-  const WspPick p = wsp_pick(mode, G, Bg, Hi, Wi, g.Hr, g.Wr, Cin, N, g.nclasses, 1, false, 0);
-  if (p.bm != 128 || p.bn != 128) return false;
-  return (int64_t)G * Bg * Hi * Wi * Cin * 6 < MAX_BUFFER_BYTES && (int64_t)16 * N * Cin * 6 < MAX_BUFFER_BYTES;
+  return wsp3_pick(mode, G, Bg, Hi, Wi, g.Hr, g.Wr, Cin, N, g.nclasses, 1, 0).bm != 0;
+}
+// BatchNorm partial-sum tiles per group of a plane launch (0: not served): one per M-tile, parity class and wave row
+int mmdyn_igemm_wsp3_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+  const IgemmGeom g = query_geom(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  const Wsp3Cfg c = wsp3_pick(mode, G, Bg, Hi, Wi, g.Hr, g.Wr, Cin, N, g.nclasses, 1, 0);
+  if (!c.bm) return 0;
+  if (mode == MMDYN_TCONV_S1P0) return 64 * ceil_div(Bg, c.bm) * 2;
+  return g.nclasses * ceil_div(Bg * g.Hr * g.Wr, c.bm) * 2;
+}
+int64_t mmdyn_igemm_wsp3_slab_bytes(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+  const IgemmGeom g = query_geom(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+  const Wsp3Cfg c = wsp3_pick(mode, G, Bg, Hi, Wi, g.Hr, g.Wr, Cin, N, g.nclasses, 1, 0);
+  if (!c.bm) return 0;
+  const WspSched sc = make_sched3(g, c);
+  if (!has_split_tiles(g, sc)) return 0;
+  const long nblk = (sc.units + sc.per - 1) / sc.per;
+  return (int64_t)nblk * 2 * c.bm * c.bn * 4;
 }
 
 int mmdyn_igemm_wsp3_try(const void* A, const void* Bp, const float* bias, float* C, float* C_act, float* stats, float* slabs,
                          const IgemmGeom& g_in, hipStream_t st) {
   IgemmGeom g = g_in;
-  if (g.splitk > 1 || g.b_group_stride || !mmdyn_igemm_wsp3_serves(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Cin, g.Ho, g.Wo, g.N)) return 1;
+  const Wsp3Cfg c = wsp3_pick(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Hr, g.Wr, g.Cin, g.N, g.nclasses, g.splitk, g.b_group_stride);
+  if (!c.bm) return 1;
   g.tap_order = g.mode == MMDYN_CONV && g.rs == 2;
-  const WspPick p = wsp_pick(g.mode, g.G, g.Bg, g.Hi, g.Wi, g.Hr, g.Wr, g.Cin, g.N, g.nclasses, g.splitk, false, 0);
-  const WspSched sc = make_sched(g, p, false);
+  const WspSched sc = make_sched3(g, c);
   const unsigned a_bytes = (unsigned)((int64_t)g.G * g.Bg * g.Hi * g.Wi * g.Cin * 6);
   const unsigned b_bytes = (unsigned)((int64_t)16 * g.N * g.Cin * 6);
   const bf16_t* Ap = reinterpret_cast<const bf16_t*>(A);
   const bf16_t* Bq = reinterpret_cast<const bf16_t*>(Bp);
-  if (g.mode == MMDYN_CONV) return wsp3_launch<MMDYN_CONV>(Ap, Bq, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
-  if (g.mode == MMDYN_TCONV_S1P0) return wsp3_launch<MMDYN_TCONV_S1P0>(Ap, Bq, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
-  return wsp3_launch<MMDYN_TCONV_S2P1>(Ap, Bq, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st);
+#define P3_GO(MODE_, BM_, BN_, WM_, WN_, S_) \
+  return wsp3_launch<MODE_, BM_, BN_, WM_, WN_, S_>(Ap, Bq, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st)
+  if (g.mode == MMDYN_TCONV_S1P0) P3_GO(MMDYN_TCONV_S1P0, 128, 128, 64, 32, 3);
+  if (g.mode == MMDYN_CONV) {
+    if (c.bn == 128) P3_GO(MMDYN_CONV, 128, 128, 64, 32, 3);
+    if (c.bm == 256) P3_GO(MMDYN_CONV, 256, 64, 128, 16, 2);
+    if (c.s == 2) P3_GO(MMDYN_CONV, 128, 64, 64, 16, 2);
+    P3_GO(MMDYN_CONV, 128, 64, 64, 16, 3);
+  }
+  if (c.bn == 128) P3_GO(MMDYN_TCONV_S2P1, 128, 128, 64, 32, 3);
+  if (c.bm == 256) P3_GO(MMDYN_TCONV_S2P1, 256, 64, 128, 16, 2);
+  if (c.s == 2) P3_GO(MMDYN_TCONV_S2P1, 128, 64, 64, 16, 2);
+  P3_GO(MMDYN_TCONV_S2P1, 128, 64, 64, 16, 3);
+#undef P3_GO
 }
 
 #ifdef MMDYN_LAB

@@ -17,6 +17,7 @@ struct WgradGeom {
   // [slab][group][Cd][Cg], so that ONE mmdyn_wgrad_reduce over Cd' = groups*Cd sums them all.  0 / 1 = a plain launch.
   int groups;
   int x3;      // fp32 launch on the bf16 matrix cores through the exact three-term operand split (wgrad_tn_kernel X3)
+  int pre;     // x3: bit 0 = D, bit 1 = Gt arrives already split (rows of [plane][C] bf16) -- wgrad_tn_kernel / wgrad_tn4_kernel PRE
 };
 
 // wgrad_ws.hip (LAB build only: measured no faster than wgrad_tn.hip, see wgrad_entry): fp32 weight-gradient GEMM with loader

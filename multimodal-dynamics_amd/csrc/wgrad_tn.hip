@@ -55,11 +55,16 @@ __device__ __forceinline__ s16x4 pack4_bf16(float a, float b, float c, float d) 
 // is done once per element as the tile is written to LDS (three bf16 planes per operand); the k-strided fragments (the reduction
 // index is the tile ROW) come from the transposing read ds_read_b64_tr_b16, as in wgrad_b16_kernel below.
 template <int BX> struct x3_ld { static constexpr int v = (BX == 32) ? 32 : BX + 32; };   // plane row stride in elements
-template <int MODE, int BD, int BG, int WD, int WG, int WK, bool BF16, int ST, bool X3 = false>
+// PRE (X3 only; bit 0: D, bit 1: Gt): that operand ARRIVES split -- rows of [plane][C] bf16 written by its producer (the exact
+// three-term split, mmdyn_split_planes) -- and goes from HBM to the LDS planes as it is: three 8-byte loads per four channels, no
+// VALU work ("split once, not once per tile that reads the operand").
+template <int MODE, int BD, int BG, int WD, int WG, int WK, bool BF16, int ST, bool X3 = false, int PRE = 0>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__ D,
                                                        const float* __restrict__ Gt,
                                                        float* __restrict__ partial, const WgradGeom g) {
   static_assert(!X3 || (!BF16 && ST == 0 && WK == 1 && MODE != MMDYN_IM2COL3), "the three-term split is a variant of the fp32 kernel");
+  static_assert(PRE == 0 || X3, "operands that arrive split belong to the three-term split arithmetic");
+  constexpr bool PD = (PRE & 1) != 0, PG = (PRE & 2) != 0;
   constexpr int DT = WD / 32, GT = WG / 32;
   constexpr int WAVES_G = BG / WG;
   constexpr int WAVES_DG = (BD / WD) * WAVES_G;
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
     if (r >= d) { q += 1; r -= d; }
   };
   f32x4 rd[D_LOADS], rg[G_LOADS];
+  uint2 pd[PD ? D_LOADS : 1][3], pg[PG ? G_LOADS : 1][3];      // PRE: the three plane granules of a load slot
   unsigned okd = 0, okg = 0;   // okg: 4 bits per load (per-element validity in the im2col mode)
   auto gload = [&](int r0) {
 #pragma unroll
@@ -112,6 +118,11 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
       const int r = idx / DV, v = idx - r * DV;
       const int row = r0 + r;
       const bool ok = row < row_end;
+      if constexpr (PD) {
+        const bf16_t* b = reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * 3 * g.Cd + cd0 + v * 4;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pd[i][p] = *reinterpret_cast<const uint2*>(b + p * g.Cd);
+      } else
       if constexpr (BF16 && (ST == 1 || ST == 2))
         rd[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       else if constexpr (BF16 && (ST == 5 || ST == 6))
@@ -155,6 +166,11 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
         ok = ok & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
         pix = (bb * g.Hi + y) * g.Wi + x;
       }
+      if constexpr (PG) {
+        const bf16_t* b = reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * 3 * g.Cg + cg0 + v * 4;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pg[i][p] = *reinterpret_cast<const uint2*>(b + p * g.Cg);
+      } else
       if constexpr (BF16 && (ST == 1 || ST == 3))
         rg[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       else if constexpr (BF16 && (ST == 5 || ST == 7))
@@ -167,15 +183,23 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
   auto lds_store = [&]() {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     if constexpr (X3) {
+      const uint2 z2 = {0u, 0u};
 #pragma unroll
       for (int i = 0; i < D_LOADS; ++i) {
         const int idx = tid + 256 * i;
         const int r = idx / DV, v = idx - r * DV;
-        const f32x4 x = ((okd >> i) & 1u) ? rd[i] : zero;
-        uint2 hh, mm, ll;
-        split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
-        split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
         const int o = r * LDD + v * 4;
+        const bool ok = (okd >> i) & 1u;
+        uint2 hh, mm, ll;
+        if constexpr (PD) {
+          hh = ok ? pd[i][0] : z2;
+          mm = ok ? pd[i][1] : z2;
+          ll = ok ? pd[i][2] : z2;
+        } else {
+          const f32x4 x = ok ? rd[i] : zero;
+          split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
+          split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
+        }
         *reinterpret_cast<uint2*>(&Ds16[o]) = hh;
         *reinterpret_cast<uint2*>(&Ds16[RK * LDD + o]) = mm;
         *reinterpret_cast<uint2*>(&Ds16[2 * RK * LDD + o]) = ll;
@@ -184,11 +208,18 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
       for (int i = 0; i < G_LOADS; ++i) {
         const int idx = tid + 256 * i;
         const int r = idx / GV, v = idx - r * GV;
-        const f32x4 x = ((okg >> (4 * i)) & 1u) ? rg[i] : zero;        // (all four mask bits are equal outside IM2COL3)
-        uint2 hh, mm, ll;
-        split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
-        split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
         const int o = r * LDG + v * 4;
+        const bool ok = (okg >> (4 * i)) & 1u;        // (all four mask bits are equal outside IM2COL3)
+        uint2 hh, mm, ll;
+        if constexpr (PG) {
+          hh = ok ? pg[i][0] : z2;
+          mm = ok ? pg[i][1] : z2;
+          ll = ok ? pg[i][2] : z2;
+        } else {
+          const f32x4 x = ok ? rg[i] : zero;
+          split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
+          split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
+        }
         *reinterpret_cast<uint2*>(&Gs16[o]) = hh;
         *reinterpret_cast<uint2*>(&Gs16[RK * LDG + o]) = mm;
         *reinterpret_cast<uint2*>(&Gs16[2 * RK * LDG + o]) = ll;
@@ -656,10 +687,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 // reduction (WK = 1: a quarter / half of the partial slabs).  grid.y = kh.
 // X3: the three-term split of the fp32 operands on the bf16 matrix cores, as in wgrad_tn_kernel (three bf16 planes per tile in
 // LDS, transposing fragment reads, six products).
-template <int BD, int BG, bool BF16, int ST, bool X3 = false>
+// PRE: as in wgrad_tn_kernel (bit 0: D arrives split, bit 1: Gt).
+template <int BD, int BG, bool BF16, int ST, bool X3 = false, int PRE = 0>
 __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict__ D, const float* __restrict__ Gt,
                                                         float* __restrict__ partial, const WgradGeom g) {
   static_assert(!X3 || (!BF16 && ST == 0), "the three-term split is a variant of the fp32 kernel");
+  static_assert(PRE == 0 || X3, "operands that arrive split belong to the three-term split arithmetic");
+  constexpr bool PD = (PRE & 1) != 0, PG = (PRE & 2) != 0;
   constexpr int DT = BD / 32, GT = BG / 32;
   constexpr int DV = BD / 4, GV = BG / 4;
   constexpr int D_LOADS = (RK * DV + 255) / 256;          // float4 per thread for the shared D tile
@@ -694,6 +728,7 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
   bf16_t* Gw16 = Ds16 + 3 * RK * LDD + wave * 3 * RK * LDG;
 
   f32x4 rd[D_LOADS], rg[G_LOADS];
+  uint2 pd[PD ? D_LOADS : 1][3], pg[PG ? G_LOADS : 1][3];
   unsigned okd = 0, okg = 0;
   auto gload = [&](int r0) {
 #pragma unroll
@@ -702,6 +737,11 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       const int r = idx / DV, v = idx - r * DV;
       const int row = r0 + r;
       const bool ok = (D_ALL || idx < RK * DV) & (row < row_end);
+      if constexpr (PD) {
+        const bf16_t* b = reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * 3 * g.Cd + cd0 + v * 4;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pd[i][p] = *reinterpret_cast<const uint2*>(b + p * g.Cd);
+      } else
       if constexpr (BF16 && (ST == 1 || ST == 2))
         rd[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       else if constexpr (BF16 && (ST == 5 || ST == 6))
@@ -721,6 +761,11 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       const int y = rr * g.rs + g.ro + kh, x = cc * g.rs + g.ro + kw;
       const bool ok = (row < row_end) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
       const int pix = (bb * g.Hi + y) * g.Wi + x;
+      if constexpr (PG) {
+        const bf16_t* b = reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * 3 * g.Cg + cg0 + v * 4;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pg[i][p] = *reinterpret_cast<const uint2*>(b + p * g.Cg);
+      } else
       if constexpr (BF16 && (ST == 1 || ST == 3))
         rg[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       else if constexpr (BF16 && (ST == 5 || ST == 7))
@@ -733,15 +778,23 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
   auto lds_store = [&]() {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     if constexpr (X3) {
+      const uint2 z2 = {0u, 0u};
 #pragma unroll
       for (int i = 0; i < D_LOADS; ++i) {
         const int idx = tid + 256 * i;
         if (D_ALL || idx < RK * DV) {
           const int r = idx / DV, v = idx - r * DV;
-          const f32x4 x = ((okd >> i) & 1u) ? rd[i] : zero;
+          const bool ok = (okd >> i) & 1u;
           uint2 hh, mm, ll;
-          split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
-          split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
+          if constexpr (PD) {
+            hh = ok ? pd[i][0] : z2;
+            mm = ok ? pd[i][1] : z2;
+            ll = ok ? pd[i][2] : z2;
+          } else {
+            const f32x4 x = ok ? rd[i] : zero;
+            split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
+            split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
+          }
           const int o = r * LDD + v * 4;
           *reinterpret_cast<uint2*>(&Ds16[o]) = hh;
           *reinterpret_cast<uint2*>(&Ds16[RK * LDD + o]) = mm;
@@ -752,10 +805,17 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       for (int i = 0; i < G_LOADS; ++i) {
         const int idx = lane + 64 * i;
         const int r = idx / GV, v = idx - r * GV;
-        const f32x4 x = ((okg >> i) & 1u) ? rg[i] : zero;
+        const bool ok = (okg >> i) & 1u;
         uint2 hh, mm, ll;
-        split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
-        split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
+        if constexpr (PG) {
+          hh = ok ? pg[i][0] : z2;
+          mm = ok ? pg[i][1] : z2;
+          ll = ok ? pg[i][2] : z2;
+        } else {
+          const f32x4 x = ok ? rg[i] : zero;
+          split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
+          split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
+        }
         const int o = r * LDG + v * 4;
         *reinterpret_cast<uint2*>(&Gw16[o]) = hh;
         *reinterpret_cast<uint2*>(&Gw16[RK * LDG + o]) = mm;
@@ -897,10 +957,18 @@ static int launch4(const float* D, const float* Gt, float* partial, WgradGeom g,
   if (g.x3 && !bf16) {       // fp32 through the bf16 matrix cores (three-term split)
     smem = (size_t)3 * RK * (x3_ld<BD>::v + 4 * x3_ld<BG>::v) * 2;
     // three planes of four tap tiles: the <32,64> instance needs 78 KB: opt in like every other > 64 KB kernel
-    static LdsOptIn x3_opt_in;
-    if (smem > 65536)
-      if (int e = x3_opt_in.ensure((const void*)wgrad_tn4_kernel<BD, BG, false, 0, true>, (int)smem)) return e;
-    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, false, 0, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
+#define WGRAD4_X3(PRE_)                                                                                               \
+  do {                                                                                                                \
+    static LdsOptIn opt_in_;                                                                                          \
+    if (smem > 65536)                                                                                                 \
+      if (int e = opt_in_.ensure((const void*)wgrad_tn4_kernel<BD, BG, false, 0, true, PRE_>, (int)smem)) return e;   \
+    hipLaunchKernelGGL((wgrad_tn4_kernel<BD, BG, false, 0, true, PRE_>), grid, dim3(256), smem, st, D, Gt, partial, g); \
+  } while (0)
+    if (g.pre == 3) WGRAD4_X3(3);
+    else if (g.pre == 2) WGRAD4_X3(2);
+    else if (g.pre == 1) WGRAD4_X3(1);
+    else WGRAD4_X3(0);
+#undef WGRAD4_X3
     MMDYN_LAUNCH_CHECK();
   }
   if (bf16 && g.d_b16 && g.g_b16 && g.f16)      // both operands IEEE half
@@ -1041,12 +1109,22 @@ static int launch(const float* D, const float* Gt, float* partial, WgradGeom g, 
   if constexpr (WK == 1) {
     if (g.x3 && !bf16 && g.mode != MMDYN_IM2COL3) {       // fp32 through the bf16 matrix cores (three-term split)
       smem = (size_t)3 * RK * (x3_ld<BD>::v + x3_ld<BG>::v) * 2;
-      static LdsOptIn x3_conv_opt_in, x3_dense_opt_in;
+      static LdsOptIn x3_dense_opt_in;
       if (g.mode == MMDYN_CONV) {
-        if (smem > 65536)
-          if (int e = x3_conv_opt_in.ensure((const void*)wgrad_tn_kernel<MMDYN_CONV, BD, BG, WD, WG, WK, false, 0, true>, (int)smem)) return e;
-        hipLaunchKernelGGL((wgrad_tn_kernel<MMDYN_CONV, BD, BG, WD, WG, WK, false, 0, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
+#define WGRAD_X3(PRE_)                                                                                                          \
+  do {                                                                                                                          \
+    static LdsOptIn opt_in_;                                                                                                    \
+    if (smem > 65536)                                                                                                           \
+      if (int e = opt_in_.ensure((const void*)wgrad_tn_kernel<MMDYN_CONV, BD, BG, WD, WG, WK, false, 0, true, PRE_>, (int)smem)) return e; \
+    hipLaunchKernelGGL((wgrad_tn_kernel<MMDYN_CONV, BD, BG, WD, WG, WK, false, 0, true, PRE_>), grid, dim3(256), smem, st, D, Gt, partial, g); \
+  } while (0)
+        if (g.pre == 3) WGRAD_X3(3);
+        else if (g.pre == 2) WGRAD_X3(2);
+        else if (g.pre == 1) WGRAD_X3(1);
+        else WGRAD_X3(0);
+#undef WGRAD_X3
       } else {
+        if (g.pre) return MMDYN_ERR_SHAPE;      // (operands that arrive split: convolution-level weight gradients only)
         if (smem > 65536)
           if (int e = x3_dense_opt_in.ensure((const void*)wgrad_tn_kernel<MMDYN_DENSE, BD, BG, WD, WG, WK, false, 0, true>, (int)smem)) return e;
         hipLaunchKernelGGL((wgrad_tn_kernel<MMDYN_DENSE, BD, BG, WD, WG, WK, false, 0, true>), grid, dim3(256), smem, st, D, Gt, partial, g);
@@ -1095,10 +1173,14 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
   if (mode == MMDYN_IM2COL3 && (Cg != 64 || Hi != 2 * Hr || Wi != 2 * Wr)) return MMDYN_ERR_SHAPE;
   WgradGeom g{};
   bool x3 = (storage_flags & 128) != 0;        // fp32 launch that may take the three-term split ("fp32x3" on the host side)
-  storage_flags &= ~128;
+  const int pre = (storage_flags >> 8) & 3;    // bits 8 / 9 (with bit 7): D / Gt ARRIVE split (rows of [plane][C] bf16)
+  storage_flags &= ~(128 | 256 | 512);
   if (x3 && (bf16 || storage_flags)) return MMDYN_ERR_SHAPE;
+  if (pre && (!x3 || mode != MMDYN_CONV || groups > 1)) return MMDYN_ERR_SHAPE;
   if (const char* e = lab_env("MMDYN_X3_WGRAD")) x3 = e[0] == '1';      // (LAB: override)
   g.x3 = x3 && !bf16;
+  g.pre = pre;
+  if (pre && !g.x3) return MMDYN_ERR_SHAPE;   // (a LAB override switched the split off: plane operands cannot be served)
   g.d_b16 = (storage_flags & 2) != 0;
   g.g_b16 = (storage_flags & 4) != 0;
   g.f16 = (storage_flags & 32) != 0;

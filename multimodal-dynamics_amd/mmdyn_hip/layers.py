@@ -127,6 +127,14 @@ def split_operands(x, Wp, mode, G, Bg, Hi, Cin, Ho, N):
     return x, wp
 
 
+def as_planes(x, C):
+    """The fp32 activation x ([rows][C], or any contiguous tensor whose rows are C channels) as an ops.Planes: one mmdyn_split_planes
+    launch (for tensors whose producer cannot write planes itself)."""
+    xp = ops.Planes(x.numel() // C, C, x.device)
+    ops.B.split_planes(x, xp)
+    return xp
+
+
 def conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride=1, offset=0, stats=False, out_dtype=None):
     """Implicit-GEMM conv / transposed conv on NHWC rows; optional per-tile BatchNorm partial sums."""
     Bt = G * Bg
@@ -135,8 +143,10 @@ def conv_like(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride=1, offset=0, stats=Fals
     y = _new(x, Bt * Ho * Ho, N, dtype=ACT_DTYPE if out_dtype is None else out_dtype)
     st, T = None, 0
     if stats:
-        planes = isinstance(x, ops.Planes)          # (operands that arrive split: the fp32x3 launch's tile count)
-        T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, all16=not planes and ops._is16(x) and ops._is16(Wp))
+        if isinstance(x, ops.Planes):                # (operands that arrive split: the plane launch's tile count)
+            T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, planes=True)
+        else:
+            T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, all16=ops._is16(x) and ops._is16(Wp))
         st = _new(x, G, T, 2, N)
     ops.B.igemm_nt(x, Wp, None, y, None, st, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset,
                    ACT_NONE, 1)
@@ -160,7 +170,10 @@ def tconv_s1p0(x, Wsp, G, Bg, Cin, N, stats=False):
     Bt = G * Bg
     # (from 256 blocks on: the per-GPU share of a 4-group decoder at bs 128 -- the column-matrix route costs 2.5x the
     # FLOPs plus a col2im pass: 0.55 vs ~0.15 ms there)
-    if G * 16 * _cdiv(Bg, 64) * (N // 64) >= 256 or ACT_DTYPE != torch.float32:      # (bf16 storage: no column matrix)
+    if (G * 16 * _cdiv(Bg, 64) * (N // 64) >= 256 or ACT_DTYPE != torch.float32      # (bf16 storage: no column matrix)
+            or isinstance(x, ops.Planes) or planes_served(TCONV_S1P0, G, Bg, 5, Cin, 8, N)):
+        # (fp32x3: the plane-ring kernel's stream-K schedule serves one-group launches too -- 51 us against 141 for the
+        #  register-staged quad walk and ~100 for the column-matrix route on the encoder's input gradient at bs 256)
         return conv_like(x, Wsp, TCONV_S1P0, G, Bg, 5, Cin, 8, N, stats=stats)
     col, _ = dense(x, Wsp, None, Bt * 25, Cin, 16 * N)
     y = _new(x, Bt * 64, N)
@@ -243,50 +256,67 @@ def _bn_backward_sums(y, partial, T, dgamma, dbeta, G, C):
     return sums
 
 
-def bn_swish_from_partials(y, partial, T, bn, G, rows_per_group, C, repeat=1):
+def bn_swish_from_partials(y, partial, T, bn, G, rows_per_group, C, repeat=1, planes=False):
+    """Returns (a, mean, rstd).  ``planes`` (fp32x3: the consumer GEMMs take their operand already split): the activated tensor is
+    written ONLY as an ops.Planes -- the split rides on this pass, no fp32 copy exists -- and returned in place of ``a``."""
     if partial is None:             # eval mode: running estimates, no update (nn.BatchNorm2d, training=False)
         mean, rstd = _new(y, G, C), _new(y, G, C)
         ops.B.bn_eval_stats(bn.rm, bn.rv, mean, rstd, G, C, BN_EPS)
     else:
         mean, rstd = _bn_forward_stats(y, partial, T, bn, G, rows_per_group, C, repeat)
+    if planes and y.dtype == torch.float32:
+        ap = ops.Planes(y.shape[0], C, y.device)
+        ops.B.bn_swish_fwd(y, mean, rstd, bn.gamma, bn.beta, None, G, rows_per_group, C, planes=ap)
+        return ap, mean, rstd
     a = torch.empty_like(y)
     ops.B.bn_swish_fwd(y, mean, rstd, bn.gamma, bn.beta, a, G, rows_per_group, C)
     return a, mean, rstd
 
 
-def bn_swish_backward(da, y, mean, rstd, bn, dgamma, dbeta, G, rows_per_group, C):
+def _apply_out(y, planes_out):
+    """Destination of a BatchNorm backward apply pass: (dy fp32 or None, dy as Planes or None) -- exactly one of the two."""
+    if planes_out and y.dtype == torch.float32:
+        return None, ops.Planes(y.shape[0], y.shape[1], y.device)
+    return torch.empty_like(y), None
+
+
+def bn_swish_backward(da, y, mean, rstd, bn, dgamma, dbeta, G, rows_per_group, C, planes_out=False):
+    """Returns dL/dy -- as an ops.Planes (and only so) with ``planes_out``: the GEMMs that consume it take plane operands."""
     T = ops.B.colstats_tiles(rows_per_group)
     partial = _new(y, G, T, 2, C)
     ops.B.bn_swish_bwd_reduce(da, y, mean, rstd, bn.gamma, bn.beta, partial, G, rows_per_group, C)
     sums = _bn_backward_sums(y, partial, T, dgamma, dbeta, G, C)
-    dy = torch.empty_like(y)
+    dy, dyp = _apply_out(y, planes_out)
+    if dyp is not None:
+        ops.B.bn_swish_bwd_apply(da, y, mean, rstd, bn.gamma, bn.beta, sums, None, G, rows_per_group, C, planes=dyp)
+        return dyp
     ops.B.bn_swish_bwd_apply(da, y, mean, rstd, bn.gamma, bn.beta, sums, dy, G, rows_per_group, C)
     return dy
 
 
-def dgrad_bn_swish_backward(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride, offset, y, mean, rstd, bn, dgamma, dbeta, planes_out=None):
+def dgrad_bn_swish_backward(x, Wp, mode, G, Bg, Hi, Cin, Ho, N, stride, offset, y, mean, rstd, bn, dgamma, dbeta, planes_out=False):
     """Input-gradient GEMM of the layer ABOVE fused with this layer's BatchNorm+Swish backward: the GEMM epilogue
     turns dL/da into du = dL/da * swish'(.) and emits the per-tile sums, so only finalize + apply remain.
-    Returns dL/dy (gradient w.r.t. this layer's conv output).  ``planes_out`` (True / False instead of None): returns the pair
-    (dL/dy, the same tensor as Planes or None) -- with True the apply pass writes the operand of the next plane launch already
-    split."""
+    Returns dL/dy (gradient w.r.t. this layer's conv output) -- as an ops.Planes (and only so) with ``planes_out``: the apply pass
+    writes the operand of the plane launches that consume it already split."""
     rows_per_group = Bg * Ho * Ho
     if y.dtype == torch.float32 and mode != IM2COL3:
         x, Wp = split_operands(x, Wp, mode, G, Bg, Hi, Cin, Ho, N)
-    T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N,
-                               all16=not isinstance(x, ops.Planes) and ops._is16(x) and ops._is16(Wp))
+    if isinstance(x, ops.Planes):
+        T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, planes=True)
+    else:
+        T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, all16=ops._is16(x) and ops._is16(Wp))
     du = torch.empty_like(y)
     partial = _new(y, G, T, 2, N)
     ops.B.igemm_nt_dgrad_bn(x, Wp, du, partial, y, mean, rstd, bn.gamma, bn.beta, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N,
                             stride, offset)
     sums = _bn_backward_sums(y, partial, T, dgamma, dbeta, G, N)
-    dy = torch.empty_like(y)
-    if planes_out and y.dtype == torch.float32:
-        dyp = ops.Planes(y.shape[0], N, y.device)
-        ops.B.bn_swish_bwd_apply(du, y, mean, rstd, bn.gamma, bn.beta, sums, dy, G, rows_per_group, N, True, planes=dyp)
-        return dy, dyp
+    dy, dyp = _apply_out(y, planes_out)
+    if dyp is not None:
+        ops.B.bn_swish_bwd_apply(du, y, mean, rstd, bn.gamma, bn.beta, sums, None, G, rows_per_group, N, True, planes=dyp)
+        return dyp
     ops.B.bn_swish_bwd_apply(du, y, mean, rstd, bn.gamma, bn.beta, sums, dy, G, rows_per_group, N, True)
-    return dy if planes_out is None else (dy, None)
+    return dy
 
 
 def wgrad(D, Gt, canon, mode, Bt, Hr, Cd, Hi, Cg, stride=1, offset=0, cg_canon=None, perm=0, defer=None):
@@ -474,9 +504,9 @@ def _alloc_packed(specs, like, w_dtype=None, pre=None):
 
 
 def wants_plane_twin(s):
-    """Conv-weight packs [16][N][Cin] whose launches the plane-ring kernel can serve (N % 128 == 0, Cin % 32 == 0) also get a
+    """Conv-weight packs [16][N][Cin] whose launches the plane-ring kernel can serve (N % 64 == 0, Cin % 32 == 0) also get a
     Planes twin from the plan in the fp32x3 arithmetic (whether a given batch's launch takes it: planes_served)."""
-    return s["kind"] >= K_KEEP and len(s["shape"]) == 3 and s["shape"][1] % 128 == 0 and s["shape"][2] % 32 == 0
+    return s["kind"] >= K_KEEP and len(s["shape"]) == 3 and s["shape"][1] % 64 == 0 and s["shape"][2] % 32 == 0
 
 
 def pack_now(specs, pre=None):
@@ -668,13 +698,22 @@ def encoder_trunk_forward_steps(P, buf, x, G=1, repeat=1, packed=None, training=
                    ACT_SWISH, 1)
     yield
     stages, a, cin = [], a1, 32
+    # fp32x3: an activation whose consumer GEMM takes plane operands exists ONLY as ops.Planes from here on (the convolution
+    # that reads it and the weight gradient that reads it as `a_in` both take it so); conv_net.0's output comes out of its kernel
+    # as fp32 and is split by its own launch
+    if training and len(convs) and planes_served(CONV, G, Bg, H, 32, H // 2, P[f"conv_net.{convs[0]}.weight"].shape[0]):
+        a = as_planes(a1, 32)
     for j, i in enumerate(convs):
         cout = P[f"conv_net.{i}.weight"].shape[0]
         last = j == len(convs) - 1                                           # Conv2d(128,256,4,1,0): 8 -> 5
         Ho, stride, offset = (H - 3, 1, 0) if last else (H // 2, 2, -1)
         bn = _bn_of(P, buf, f"conv_net.{i + 1}")
         y, st, T = conv_like(a, pk[f"W{j + 2}k"], CONV, G, Bg, H, cin, Ho, cout, stride, offset, training)
-        an, m, r = bn_swish_from_partials(y, st, T, bn, G, Bg * Ho * Ho, cout, repeat)
+        want = False           # does the NEXT convolution take its operand already split?  Then BatchNorm + Swish writes it so.
+        if not last and training:
+            nlast = j + 1 == len(convs) - 1
+            want = planes_served(CONV, G, Bg, Ho, cout, Ho - 3 if nlast else Ho // 2, P[f"conv_net.{convs[j + 1]}.weight"].shape[0])
+        an, m, r = bn_swish_from_partials(y, st, T, bn, G, Bg * Ho * Ho, cout, repeat, planes=want)
         stages.append(dict(i=i, Hi=H, Ho=Ho, cin=cin, cout=cout, stride=stride, offset=offset, a_in=a, y=y, a=an, m=m, r=r,
                            bn=bn))
         a, cin, H = an, cout, Ho
@@ -703,20 +742,25 @@ def encoder_trunk_backward_steps(P, c, dh, grads, dh_is_du=False):
         return grads[f"conv_net.{t['i'] + 1}.weight"], grads[f"conv_net.{t['i'] + 1}.bias"]
 
     # the k4 s1 p0 stage (8 -> 5): its input gradient is the tap-skipping transposed convolution
+    # (fp32x3: a dL/dy whose input-gradient launch takes plane operands is written by its apply pass ONLY as ops.Planes; the weight
+    #  gradient takes it so as well)
     t = st[n - 1]
-    dy = bn_swish_backward(da, t["y"], t["m"], t["r"], t["bn"], *bn_keys(t), G, Bg * t["Ho"] ** 2, t["cout"])
+    dy = bn_swish_backward(da, t["y"], t["m"], t["r"], t["bn"], *bn_keys(t), G, Bg * t["Ho"] ** 2, t["cout"],
+                           planes_out=planes_served(TCONV_S1P0, 1, Bt, 5, t["cout"], 8, t["cin"]))
     wgrad(dy, t["a_in"], grads[f"conv_net.{t['i']}.weight"], CONV, Bt, t["Ho"], t["cout"], t["Hi"], t["cin"], 1, 0)
     da = tconv_s1p0(dy, pk[f"W{n + 1}s"], 1, Bt, t["cout"], t["cin"])[0]     # W{n+1}s: [16][Cin][Cout]
     yield
     t = st[n - 2]
-    dy = bn_swish_backward(da, t["y"], t["m"], t["r"], t["bn"], *bn_keys(t), G, Bg * t["Ho"] ** 2, t["cout"])
+    dy = bn_swish_backward(da, t["y"], t["m"], t["r"], t["bn"], *bn_keys(t), G, Bg * t["Ho"] ** 2, t["cout"],
+                           planes_out=n >= 3 and planes_served(TCONV_S2P1, G, Bg, t["Ho"], t["cout"], t["Hi"], t["cin"]))
     wgrad(dy, t["a_in"], grads[f"conv_net.{t['i']}.weight"], CONV, Bt, t["Ho"], t["cout"], t["Hi"], t["cin"], 2, -1)
     yield
     for k in range(n - 3, -1, -1):
         # input gradient of stage k+1 with stage k's BatchNorm+Swish backward in its epilogue
         up, t = st[k + 1], st[k]
         dy = dgrad_bn_swish_backward(dy, pk[f"W{k + 3}s"], TCONV_S2P1, G, Bg, up["Ho"], up["cout"], up["Hi"], up["cin"], 1, 0,
-                                     t["y"], t["m"], t["r"], t["bn"], *bn_keys(t))
+                                     t["y"], t["m"], t["r"], t["bn"], *bn_keys(t),
+                                     planes_out=k > 0 and planes_served(TCONV_S2P1, G, Bg, t["Ho"], t["cout"], t["Hi"], t["cin"]))
         wgrad(dy, t["a_in"], grads[f"conv_net.{t['i']}.weight"], CONV, Bt, t["Ho"], t["cout"], t["Hi"], t["cin"], 2, -1)
         if k > 0:
             yield
@@ -754,6 +798,9 @@ def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, co
                    act_dtype=ACT_DTYPE if ACT_DTYPE != torch.float32 else None)
     yield
     stages, a, H = [], h0, 5
+    if training and planes_served(TCONV_S1P0, G, Bg, 5, P[f"hallucinate.{convs[0]}.weight"].shape[0], 8,
+                                  P[f"hallucinate.{convs[0]}.weight"].shape[1]):
+        a = as_planes(h0, P[f"hallucinate.{convs[0]}.weight"].shape[0])       # (the FC kernel's fp32 output, split by its own launch)
     for j, i in enumerate(convs):
         cin, cout = P[f"hallucinate.{i}.weight"].shape[0], P[f"hallucinate.{i}.weight"].shape[1]
         bn = _bn_of(P, buf, f"hallucinate.{i + 1}")
@@ -769,7 +816,10 @@ def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, co
             m, r = bn_stats_only(y, st, T, bn, G, Bg * Ho * Ho, cout, repeat)
             an = None
         else:
-            an, m, r = bn_swish_from_partials(y, st, T, bn, G, Bg * Ho * Ho, cout, repeat)
+            # (fp32x3: written ONLY as ops.Planes when the next transposed convolution takes plane operands)
+            want = training and j + 1 < len(convs) and planes_served(TCONV_S2P1, G, Bg, Ho, cout, 2 * Ho,
+                                                                     P[f"hallucinate.{convs[j + 1]}.weight"].shape[1])
+            an, m, r = bn_swish_from_partials(y, st, T, bn, G, Bg * Ho * Ho, cout, repeat, planes=want)
         stages.append(dict(i=i, Hi=H, Ho=Ho, cin=cin, cout=cout, a_in=a, y=y, a=an, m=m, r=r, bn=bn))
         a, H = an, Ho
         yield
@@ -812,21 +862,20 @@ def decoder_backward_steps(P, c, dlogits, grads, need_dz=True, defer=None):
             return planes_served(CONV, G, Bg, u["Ho"], u["cout"], u["Hi"], u["cin"])
         return planes_served(CONV, 1, Bt, 8, st[0]["cout"], 5, st[0]["cin"])
 
-    dy, dyp = dgrad_bn_swish_backward(dlogits, pk[f"W{n + 1}p"], IM2COL3, G, Bg, S, 64, S // 2, 32, 1, 0, t["y"], t["m"], t["r"],
-                                      t["bn"], *bn_keys(t), planes_out=next_takes_planes(n - 1))
+    dy = dgrad_bn_swish_backward(dlogits, pk[f"W{n + 1}p"], IM2COL3, G, Bg, S, 64, S // 2, 32, 1, 0, t["y"], t["m"], t["r"],
+                                 t["bn"], *bn_keys(t), planes_out=next_takes_planes(n - 1))
     yield
     for k in range(n - 1, 0, -1):
         up, t = st[k], st[k - 1]
         wgrad(up["a_in"], dy, grads[f"hallucinate.{up['i']}.weight"], CONV, Bt, up["Hi"], up["cin"], up["Ho"], up["cout"], 2, -1,
               defer=defer)
-        dy, dyp = dgrad_bn_swish_backward(dy if dyp is None else dyp, pk[f"W{k + 1}k"], CONV, G, Bg, up["Ho"], up["cout"], up["Hi"],
-                                          up["cin"], 2, -1, t["y"], t["m"], t["r"], t["bn"], *bn_keys(t),
-                                          planes_out=next_takes_planes(k - 1))
+        dy = dgrad_bn_swish_backward(dy, pk[f"W{k + 1}k"], CONV, G, Bg, up["Ho"], up["cout"], up["Hi"], up["cin"], 2, -1,
+                                     t["y"], t["m"], t["r"], t["bn"], *bn_keys(t), planes_out=next_takes_planes(k - 1))
         yield
     t = st[0]
-    wgrad(c["h0"], dy, grads[f"hallucinate.{t['i']}.weight"], CONV, Bt, 5, t["cin"], 8, t["cout"], 1, 0, defer=defer)
+    wgrad(t["a_in"], dy, grads[f"hallucinate.{t['i']}.weight"], CONV, Bt, 5, t["cin"], 8, t["cout"], 1, 0, defer=defer)
     # input gradient of the k4 s1 p0 layer with the FC layer's Swish backward in its epilogue (FC level: fp32)
-    du0 = dgrad_act(dy if dyp is None else dyp, pk["W1k"], CONV, 1, Bt, 8, t["cout"], 5, t["cin"], c["u0"], ACT_SWISH, 1, 0)
+    du0 = dgrad_act(dy, pk["W1k"], CONV, 1, Bt, 8, t["cout"], 5, t["cin"], c["u0"], ACT_SWISH, 1, 0)
     yield
     wgrad(du0, c["z"], grads["upsample.0.weight"], DENSE, Bt, 1, FEAT, 1, L, cg_canon=c["Lc"], perm=2, defer=defer)
     ops.B.colsum(du0, grads["upsample.0.bias"], Bt, FEAT, 2, 0.0)

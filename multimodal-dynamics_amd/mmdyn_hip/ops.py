@@ -178,9 +178,12 @@ class HipBackend:
         """Flags of a launch whose two operands are both 16-bit in HBM, in the current storage mode."""
         return 1 | 2 | 16 | (32 if self.precision == "fp16s" else 0)
 
-    def igemm_stat_tiles(self, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=False):
+    def igemm_stat_tiles(self, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=False, planes=False):
         """T of the per-tile BatchNorm partial sums the implicit GEMM of the current precision mode writes.  ``all16``: both
-        operands of the launch are 16-bit in HBM (the convolution-level launches of the "bf16s" / "fp16s" modes)."""
+        operands of the launch are 16-bit in HBM (the convolution-level launches of the "bf16s" / "fp16s" modes); ``planes``: the
+        fp32x3 launch takes its operands already split (ops.Planes)."""
+        if planes:
+            return self.lib.mmdyn_igemm_stat_tiles_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, 384)
         if self.precision == "fp32":
             if self._x3():
                 return self.lib.mmdyn_igemm_stat_tiles_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, 128)
@@ -200,9 +203,11 @@ class HipBackend:
         return r
 
     # ---- GEMMs ----
-    def _slabs(self, like, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=False):
+    def _slabs(self, like, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=False, planes=False):
         """Workspace for the pieces of the persistent ring kernel's split tiles (fp32 launches not split over K), or None."""
-        if self.precision == "fp32" and self._x3():
+        if planes:
+            n = self.lib.mmdyn_igemm_slab_floats_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, 384)
+        elif self.precision == "fp32" and self._x3():
             n = self.lib.mmdyn_igemm_slab_floats_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, 128)
         elif self.precision == "fp32":
             n = self.lib.mmdyn_igemm_slab_floats(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
@@ -223,12 +228,12 @@ class HipBackend:
                              f"(current: {self.precision})")
         return 1 | (32 if half else 0)
 
-    def _check_stat_tiles(self, stats, all16, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N):
+    def _check_stat_tiles(self, stats, all16, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, planes=False):
         """The partial-sum buffer must have the tile count the kernel that serves THIS launch writes (it depends on the
         storage types of the operands: igemm_stat_tiles(..., all16)) -- a mismatch would be an out-of-bounds write."""
         if stats is None:
             return
-        T = self.igemm_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=all16)
+        T = self.igemm_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=all16, planes=planes)
         if stats.dim() != 4 or tuple(stats.shape) != (G, T, 2, N):
             raise ValueError(f"mmdyn_hip: stats must be [G={G}][T={T}][2][N={N}] for this launch (igemm_stat_tiles with "
                              f"all16={all16}), got {tuple(stats.shape)}")
@@ -260,9 +265,9 @@ class HipBackend:
                  offset, act, splitk):
         if isinstance(A, Planes) or isinstance(Bp, Planes):
             pa, pb = self._planes_pair(A, Bp, Cin)
-            self._check_stat_tiles(stats, False, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+            self._check_stat_tiles(stats, False, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, planes=True)
             if ws is None and splitk == 1:
-                ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+                ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, planes=True)
             check(self.lib.mmdyn_igemm_nt_mx(pa, pb, _ptr(bias), _ptr(C), _ptr(C_act), _ptr(stats), _ptr(ws), None, None, None, None,
                                              None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, 384,
                                              _stream()), "mmdyn_igemm_nt_mx")
@@ -296,8 +301,8 @@ class HipBackend:
                           stride, offset):
         if isinstance(A, Planes) or isinstance(Bp, Planes):
             pa, pb = self._planes_pair(A, Bp, Cin)
-            self._check_stat_tiles(stats, False, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
-            ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+            self._check_stat_tiles(stats, False, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, planes=True)
+            ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, planes=True)
             check(self.lib.mmdyn_igemm_nt_dgrad_bn(pa, pb, _ptr(C), _ptr(stats), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma),
                                                    _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset, 4, _ptr(ws),
                                                    _stream()), "mmdyn_igemm_nt_dgrad_bn")
@@ -322,7 +327,7 @@ class HipBackend:
         """C = (A x Bp) * act'(u): input-gradient GEMM with the activation backward in its epilogue."""
         if isinstance(A, Planes) or isinstance(Bp, Planes):
             pa, pb = self._planes_pair(A, Bp, Cin)
-            ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
+            ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, planes=True)
             check(self.lib.mmdyn_igemm_nt_dgrad_act(pa, pb, _ptr(C), _ptr(u), int(act), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride,
                                                     offset, 384, _ptr(ws), _stream()), "mmdyn_igemm_nt_dgrad_act")
             return
@@ -361,6 +366,22 @@ class HipBackend:
                                            _stream()), "mmdyn_splitk_reduce")
 
     def wgrad_tn(self, D, Gt, partial, mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks):
+        if isinstance(D, Planes) or isinstance(Gt, Planes):
+            # fp32x3 with one or both operands arriving split (flag bits 8 / 9): that operand goes to the LDS planes as it is
+            if not self._x3() or mode != CONV:
+                raise ValueError("mmdyn_hip: plane operands belong to the convolution-level weight gradients of the fp32x3 arithmetic")
+            flags, ptrs = 128, []
+            for k, (t, C) in enumerate(((D, Cd), (Gt, Cg))):
+                if isinstance(t, Planes):
+                    if t.C != C or not t.t.is_cuda or not t.t.is_contiguous():
+                        raise ValueError("mmdyn_hip: wgrad_tn: plane operand of the wrong shape")
+                    flags |= 256 << k
+                    ptrs.append(t.t.data_ptr())
+                else:
+                    ptrs.append(_ptr(t))
+            check(self.lib.mmdyn_wgrad_tn_mx(ptrs[0], ptrs[1], _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks,
+                                             flags, _stream()), "mmdyn_wgrad_tn_mx")
+            return
         (pd, d16), (pg, g16) = _aptr(D), _aptr(Gt)
         if d16 or g16:
             check(self.lib.mmdyn_wgrad_tn_mx(pd, pg, _ptr(partial), mode, Bt, Hr, Wr, Cd, Hi, Wi, Cg, stride, offset, chunks,

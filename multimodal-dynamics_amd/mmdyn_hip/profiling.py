@@ -69,6 +69,8 @@ def _flops(name, a):
 def _bytes(a):
     n = 0
     for t in a:
+        if isinstance(t, ops.Planes):
+            t = t.t
         if torch.is_tensor(t):
             n += t.numel() * t.element_size()
     return n

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic: the N % 128 == 0 implicit-GEMM launches of one bs=256 train step in the fp32x3 arithmetic, each alone on the chip:
-(x3) the persistent kernel that splits its fp32 fragments in the MFMA waves' registers (igemm_wsp_kernel<X3>) against (p3) the
-plane-ring kernel on operands that ARRIVE split (igemm_wsp3_kernel); the split launch itself (mmdyn_split_planes: 10 bytes per
-element) is timed beside them.  Interleaved rounds in one process, product library."""
+"""Diagnostic: implicit-GEMM launches of one bs=256 train step in the fp32x3 arithmetic, each alone on the chip:
+(x3) what the product dispatch runs when the operands are fp32 -- the persistent kernel that splits its fragments in the MFMA
+waves' registers, or the register-staged split kernel -- against (p3) the plane-ring kernel on operands that ARRIVE split
+(igemm_wsp3_kernel), in the configurations named on the command line.  LAB build of the library (forces tiles / thresholds).
+usage: ab_p3.py [cfg ...]     cfg = "BM,BN,S" (forced through MMDYN_P3_TILE) or "rule" (the library's own pick; default)"""
 import os
 import statistics
 import sys
@@ -10,19 +11,22 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "multimodal-dynamics_amd"))
-from mmdyn_hip import ops  # noqa: E402
+from mmdyn_hip import ops, _lib  # noqa: E402
 
-HIP = ops.HipBackend()
+HIP = ops.HipBackend(lib_path=_lib.LAB_LIB_PATH)
 HIP.fp32_split = True
 # mode,G,Bg,Hi,Cin,Ho,N,stride,offset, kind
 SHAPES = [
     (4, 4, 256, 5, 256, 8, 128, 1, 0, "stats"),         # decoder layer 1: the k4 s1 p0 transposed convolution
     (1, 1, 1024, 8, 128, 5, 256, 1, 0, "actbwd"),       # decoder layer-1 input gradient
     (1, 4, 256, 16, 64, 8, 128, 2, -1, "bnbwd"),        # decoder layer-2 input gradient
-    (1, 4, 256, 16, 64, 8, 128, 2, -1, "plain"),
-    (4, 4, 128, 5, 256, 8, 128, 1, 0, "stats"),         # the same at the bs 128 share
-    (1, 1, 512, 8, 128, 5, 256, 1, 0, "actbwd"),
-    (1, 4, 128, 16, 64, 8, 128, 2, -1, "bnbwd"),
+    (1, 4, 256, 32, 32, 16, 64, 2, -1, "bnbwd"),        # decoder layer-3 input gradient (N = 64)
+    (2, 4, 256, 8, 128, 16, 64, 1, 0, "stats"),         # decoder layer 2 forward (N = 64)
+    (1, 1, 256, 8, 128, 5, 256, 1, 0, "stats"),         # encoder conv4
+    (1, 1, 256, 16, 64, 8, 128, 2, -1, "stats"),        # encoder conv3
+    (1, 1, 256, 32, 32, 16, 64, 2, -1, "stats"),        # encoder conv2 (N = 64)
+    (2, 1, 256, 8, 128, 16, 64, 1, 0, "bnbwd"),         # encoder conv3 input gradient (N = 64)
+    (4, 1, 256, 5, 256, 8, 128, 1, 0, "plain"),         # encoder conv4 input gradient (k4 s1 p0, one group)
 ]
 
 
@@ -38,12 +42,12 @@ def event_ms(fn, reps):
 
 def main():
     dev = "cuda"
-    tot = {"x3": 0.0, "p3": 0.0}
+    cfgs = [a for a in sys.argv[1:]] or ["rule"]
+    os.environ["MMDYN_P3_MIN_UNITS"] = "1"
+    os.environ["MMDYN_P3_N64"] = "1"
+    tot = {}
     for sh in SHAPES:
         mode, G, Bg, Hi, Cin, Ho, N, stride, offset, kind = sh
-        if not HIP.igemm_planes_served(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N):
-            print(sh, "not served")
-            continue
         Bt = G * Bg
         A = torch.randn(Bt * Hi * Hi, Cin, device=dev)
         Bp = torch.randn(16, N, Cin, device=dev) * 0.1
@@ -55,35 +59,46 @@ def main():
         y = torch.randn(rows, N, device=dev)
         mean, rstd = torch.randn(G, N, device=dev), torch.rand(G, N, device=dev) + 0.5
         gamma, beta = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
-        T = HIP.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N) if kind in ("stats", "bnbwd") else 0
-        st = torch.empty(G, T, 2, N, device=dev) if T else None
-        ws = HIP._slabs(C, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
 
-        def launch(a, b):
+        def launch(a, b, planes):
+            T = HIP.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, planes=planes) if kind in ("stats", "bnbwd") else 0
+            st = torch.empty(G, T, 2, N, device=dev) if T else None
+            ws = HIP._slabs(C, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, planes=planes)
             if kind == "bnbwd":
                 return lambda: HIP.igemm_nt_dgrad_bn(a, b, C, st, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride, offset)
             if kind == "actbwd":
                 return lambda: HIP.igemm_nt_dgrad_act(a, b, C, y, 1, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride, offset)
             return lambda: HIP.igemm_nt(a, b, None, C, None, st, ws, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1)
-        fns = {"x3": launch(A, Bp), "p3": launch(Ap, Bq)}
-        res, times = {}, {"x3": [], "p3": []}
-        for rnd in range(5):
-            for k in ("x3", "p3"):
+        variants = ["x3"] + cfgs
+        res, times = {}, {v: [] for v in variants}
+        for rnd in range(4):
+            for v in variants:
+                if v == "x3":
+                    fn = launch(A, Bp, False)
+                else:
+                    if v == "rule":
+                        os.environ.pop("MMDYN_P3_TILE", None)
+                    else:
+                        os.environ["MMDYN_P3_TILE"] = v
+                    if not HIP.igemm_planes_served(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N) or (v != "rule" and N % int(v.split(",")[1])):
+                        times[v].append(float("nan"))
+                        continue
+                    fn = launch(Ap, Bq, True)
                 if rnd == 0:
                     for _ in range(3):
-                        fns[k]()
+                        fn()
                     torch.cuda.synchronize()
-                    res[k] = C.clone()
-                times[k].append(event_ms(fns[k], 10))
-        t_split = event_ms(lambda: HIP.split_planes(A, Ap), 10)
+                    res[v] = C.clone()
+                times[v].append(event_ms(fn, 10))
         fl = 2.0 * rows * N * Cin * ({0: 1, 1: 16, 2: 4}[mode]) if mode != 4 else 2.0 * Bt * Hi * Hi * N * 16 * Cin
-        m0, m1 = statistics.median(times["x3"]), statistics.median(times["p3"])
-        tot["x3"] += m0
-        tot["p3"] += m1
-        same = torch.equal(res["x3"], res["p3"])
-        print(f"{str(sh):52s} x3 {m0 * 1e3:7.1f} us {fl / m0 / 1e9:6.1f} TF/s | p3 {m1 * 1e3:7.1f} us {fl / m1 / 1e9:6.1f} TF/s "
-              f"| x{m0 / m1:5.2f}  bit-identical {same} | split of A {t_split * 1e3:6.1f} us ({A.numel() * 10 / t_split / 1e9:5.2f} TB/s)", flush=True)
-    print(f"sum x3 {tot['x3']:.3f} ms, p3 {tot['p3']:.3f} ms")
+        line = f"{str(sh):50s}"
+        for v in variants:
+            m = statistics.median(times[v])
+            tot[v] = tot.get(v, 0.0) + (m if m == m else statistics.median(times["x3"]))
+            err = float((res[v] - res["x3"]).norm() / (res["x3"].norm() + 1e-30)) if v in res else float("nan")
+            line += f" | {v:9s} {m * 1e3:7.1f} us {fl / m / 1e9:6.1f} TF/s" + (f" d{err:.0e}" if v != "x3" else "")
+        print(line, flush=True)
+    print("sums (ms; a configuration that does not serve a shape is booked at the x3 time):", {k: round(v, 3) for k, v in tot.items()})
 
 
 if __name__ == "__main__":

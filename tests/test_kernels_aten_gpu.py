@@ -588,3 +588,27 @@ def test_pack_plan_writes_plane_twins(x3):
     assert layers._plane_twin(pk["W9k"]) is None
     ref = layers.pack_conv(W["hallucinate.0.weight"], swap=True)
     assert torch.equal(ref, pk["W1s"])
+
+
+@pytest.mark.parametrize("Cd,Cg,Hr,Hi,stride,off", [(256, 128, 5, 8, 1, 0), (128, 64, 8, 16, 2, -1), (64, 64, 8, 16, 2, -1),
+                                                    (64, 32, 16, 32, 2, -1), (32, 64, 16, 32, 2, -1)])
+def test_weight_gradient_on_operands_that_arrive_split(x3, Cd, Cg, Hr, Hi, stride, off):
+    """mmdyn_wgrad_tn_mx flag bits 8 / 9: either operand (or both) as ops.Planes -- bit for bit the launch that splits the same fp32
+    tensors inside the kernel (same terms, same tiles, same order), on every tile the convolution-level weight gradients use
+    (128x128, 128x64, 64x64 one-tap; 64x32 / 32x64 four-tap); and against fp64 autograd through F.conv2d."""
+    Bt = 64
+    D, Gt = rnd(Bt * Hr * Hr, Cd, seed=70).to(DEV), rnd(Bt * Hi * Hi, Cg, seed=71).to(DEV)
+    Dp, Gp = _planes(D), _planes(Gt)
+    outs = []
+    for d, g in ((D, Gt), (Dp, Gt), (D, Gp), (Dp, Gp)):
+        canon = torch.zeros(Cd, Cg, 4, 4, device=DEV)
+        layers.wgrad(d, g, canon, CONV, Bt, Hr, Cd, Hi, Cg, stride, off)
+        outs.append(canon)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    # D = dY of a Conv2d(Cg -> Cd, k4, stride, pad = -off), Gt = its input: canon = dL/dW [Cd][Cg][4][4]
+    x = Gt.view(Bt, Hi, Hi, Cg).permute(0, 3, 1, 2).double().requires_grad_(False)
+    W = torch.zeros(Cd, Cg, 4, 4, device=DEV, dtype=torch.float64, requires_grad=True)
+    yref = F.conv2d(x, W, stride=stride, padding=-off)
+    (gW,) = torch.autograd.grad(yref, W, D.view(Bt, Hr, Hr, Cd).permute(0, 3, 1, 2).double())
+    assert relg(outs[3], gW) < 5e-6
