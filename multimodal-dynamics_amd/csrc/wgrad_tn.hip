@@ -109,20 +109,32 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
     if (r >= d) { q += 1; r -= d; }
   };
   f32x4 rd[D_LOADS], rg[G_LOADS];
-  uint2 pd[PD ? D_LOADS : 1][3], pg[PG ? G_LOADS : 1][3];      // PRE: the three plane granules of a load slot
+  // PRE: a thread moves 8 channels of a row per slot -- one 16-byte granule of each of the three planes
+  constexpr int DV8 = BD / 8, GV8 = BG / 8;
+  constexpr int D_LOADS8 = (RK * DV8) / 256, G_LOADS8 = (RK * GV8) / 256;
+  static_assert(PRE == 0 || (D_LOADS8 >= 1 && G_LOADS8 >= 1), "plane granules: tile too small for 256 threads");
+  u32x4 pd[PD ? D_LOADS8 : 1][3], pg[PG ? G_LOADS8 : 1][3];      // (ext_vector_type: HIP uint4 structs selected as a whole go to scratch)
   unsigned okd = 0, okg = 0;   // okg: 4 bits per load (per-element validity in the im2col mode)
   auto gload = [&](int r0) {
+    if constexpr (PD) {
+#pragma unroll
+      for (int i = 0; i < D_LOADS8; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx / DV8, v = idx - r * DV8;
+        const int row = r0 + r;
+        const bool ok = row < row_end;
+        const bf16_t* b = reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * 3 * g.Cd + cd0 + v * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pd[i][p] = *reinterpret_cast<const u32x4*>(b + p * g.Cd);
+        okd = ok ? (okd | (1u << i)) : (okd & ~(1u << i));
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < D_LOADS; ++i) {
       const int idx = tid + 256 * i;
       const int r = idx / DV, v = idx - r * DV;
       const int row = r0 + r;
       const bool ok = row < row_end;
-      if constexpr (PD) {
-        const bf16_t* b = reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * 3 * g.Cd + cd0 + v * 4;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) pd[i][p] = *reinterpret_cast<const uint2*>(b + p * g.Cd);
-      } else
       if constexpr (BF16 && (ST == 1 || ST == 2))
         rd[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       else if constexpr (BF16 && (ST == 5 || ST == 6))
@@ -131,6 +143,28 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
         rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       okd = ok ? (okd | (1u << i)) : (okd & ~(1u << i));
     }
+    if constexpr (PG) {
+#pragma unroll
+      for (int i = 0; i < G_LOADS8; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx / GV8, v = idx - r * GV8;
+        const int row = r0 + r;
+        bool ok = row < row_end;
+        int pix = row;
+        if constexpr (MODE == MMDYN_CONV) {
+          int bb, p, rr, cc;
+          fdiv(row, HWr, inv_hw, bb, p);
+          fdiv(p, g.Wr, inv_w, rr, cc);
+          const int y = rr * g.rs + g.ro + dh, x = cc * g.rs + g.ro + dw;
+          ok = ok & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
+          pix = (bb * g.Hi + y) * g.Wi + x;
+        }
+        const bf16_t* b = reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * 3 * g.Cg + cg0 + v * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pg[i][p] = *reinterpret_cast<const u32x4*>(b + p * g.Cg);
+        okg = ok ? (okg | (0xFu << (4 * i))) : (okg & ~(0xFu << (4 * i)));
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < G_LOADS; ++i) {
       const int idx = tid + 256 * i;
@@ -166,11 +200,6 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
         ok = ok & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
         pix = (bb * g.Hi + y) * g.Wi + x;
       }
-      if constexpr (PG) {
-        const bf16_t* b = reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * 3 * g.Cg + cg0 + v * 4;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) pg[i][p] = *reinterpret_cast<const uint2*>(b + p * g.Cg);
-      } else
       if constexpr (BF16 && (ST == 1 || ST == 3))
         rg[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       else if constexpr (BF16 && (ST == 5 || ST == 7))
@@ -183,46 +212,56 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const float* __restrict__
   auto lds_store = [&]() {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     if constexpr (X3) {
-      const uint2 z2 = {0u, 0u};
+      const u32x4 z4 = {0u, 0u, 0u, 0u};
+      if constexpr (PD) {
 #pragma unroll
-      for (int i = 0; i < D_LOADS; ++i) {
-        const int idx = tid + 256 * i;
-        const int r = idx / DV, v = idx - r * DV;
-        const int o = r * LDD + v * 4;
-        const bool ok = (okd >> i) & 1u;
-        uint2 hh, mm, ll;
-        if constexpr (PD) {
-          hh = ok ? pd[i][0] : z2;
-          mm = ok ? pd[i][1] : z2;
-          ll = ok ? pd[i][2] : z2;
-        } else {
-          const f32x4 x = ok ? rd[i] : zero;
+        for (int i = 0; i < D_LOADS8; ++i) {
+          const int idx = tid + 256 * i;
+          const int r = idx / DV8, v = idx - r * DV8;
+          const int o = r * LDD + v * 8;
+          const bool ok = (okd >> i) & 1u;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&Ds16[p * RK * LDD + o]) = ok ? pd[i][p] : z4;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < D_LOADS; ++i) {
+          const int idx = tid + 256 * i;
+          const int r = idx / DV, v = idx - r * DV;
+          const int o = r * LDD + v * 4;
+          const f32x4 x = ((okd >> i) & 1u) ? rd[i] : zero;
+          uint2 hh, mm, ll;
           split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
           split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
+          *reinterpret_cast<uint2*>(&Ds16[o]) = hh;
+          *reinterpret_cast<uint2*>(&Ds16[RK * LDD + o]) = mm;
+          *reinterpret_cast<uint2*>(&Ds16[2 * RK * LDD + o]) = ll;
         }
-        *reinterpret_cast<uint2*>(&Ds16[o]) = hh;
-        *reinterpret_cast<uint2*>(&Ds16[RK * LDD + o]) = mm;
-        *reinterpret_cast<uint2*>(&Ds16[2 * RK * LDD + o]) = ll;
       }
+      if constexpr (PG) {
 #pragma unroll
-      for (int i = 0; i < G_LOADS; ++i) {
-        const int idx = tid + 256 * i;
-        const int r = idx / GV, v = idx - r * GV;
-        const int o = r * LDG + v * 4;
-        const bool ok = (okg >> (4 * i)) & 1u;        // (all four mask bits are equal outside IM2COL3)
-        uint2 hh, mm, ll;
-        if constexpr (PG) {
-          hh = ok ? pg[i][0] : z2;
-          mm = ok ? pg[i][1] : z2;
-          ll = ok ? pg[i][2] : z2;
-        } else {
-          const f32x4 x = ok ? rg[i] : zero;
+        for (int i = 0; i < G_LOADS8; ++i) {
+          const int idx = tid + 256 * i;
+          const int r = idx / GV8, v = idx - r * GV8;
+          const int o = r * LDG + v * 8;
+          const bool ok = (okg >> (4 * i)) & 1u;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&Gs16[p * RK * LDG + o]) = ok ? pg[i][p] : z4;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < G_LOADS; ++i) {
+          const int idx = tid + 256 * i;
+          const int r = idx / GV, v = idx - r * GV;
+          const int o = r * LDG + v * 4;
+          const f32x4 x = ((okg >> (4 * i)) & 1u) ? rg[i] : zero;        // (all four mask bits are equal outside IM2COL3)
+          uint2 hh, mm, ll;
           split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
           split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
+          *reinterpret_cast<uint2*>(&Gs16[o]) = hh;
+          *reinterpret_cast<uint2*>(&Gs16[RK * LDG + o]) = mm;
+          *reinterpret_cast<uint2*>(&Gs16[2 * RK * LDG + o]) = ll;
         }
-        *reinterpret_cast<uint2*>(&Gs16[o]) = hh;
-        *reinterpret_cast<uint2*>(&Gs16[RK * LDG + o]) = mm;
-        *reinterpret_cast<uint2*>(&Gs16[2 * RK * LDG + o]) = ll;
       }
       return;
     }
@@ -728,20 +767,28 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
   bf16_t* Gw16 = Ds16 + 3 * RK * LDD + wave * 3 * RK * LDG;
 
   f32x4 rd[D_LOADS], rg[G_LOADS];
-  uint2 pd[PD ? D_LOADS : 1][3], pg[PG ? G_LOADS : 1][3];
+  // PRE: 16-byte plane granules (8 channels of a row): the shared D tile by all 256 threads, each wave's tap tile by its 64 lanes
+  constexpr int DV8 = BD / 8, GV8 = BG / 8;
+  constexpr bool D_ALL8 = (RK * DV8) % 256 == 0;          // (BD = 32: the first 128 threads load)
+  constexpr int G_LOADS8 = (RK * GV8) / 64;
+  u32x4 pd8[3], pg[PG ? G_LOADS8 : 1][3];
   unsigned okd = 0, okg = 0;
   auto gload = [&](int r0) {
+    if constexpr (PD) {
+      const int r = tid / DV8, v = tid - r * DV8;
+      const int row = r0 + r;
+      const bool ok = (D_ALL8 || tid < RK * DV8) & (row < row_end);
+      const bf16_t* b = reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * 3 * g.Cd + cd0 + (D_ALL8 || tid < RK * DV8 ? v : 0) * 8;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) pd8[p] = *reinterpret_cast<const u32x4*>(b + p * g.Cd);
+      okd = ok ? 1u : 0u;
+    } else
 #pragma unroll
     for (int i = 0; i < D_LOADS; ++i) {
       const int idx = tid + 256 * i;
       const int r = idx / DV, v = idx - r * DV;
       const int row = r0 + r;
       const bool ok = (D_ALL || idx < RK * DV) & (row < row_end);
-      if constexpr (PD) {
-        const bf16_t* b = reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * 3 * g.Cd + cd0 + v * 4;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) pd[i][p] = *reinterpret_cast<const uint2*>(b + p * g.Cd);
-      } else
       if constexpr (BF16 && (ST == 1 || ST == 2))
         rd[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(D) + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       else if constexpr (BF16 && (ST == 5 || ST == 6))
@@ -750,6 +797,24 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
         rd[i] = *reinterpret_cast<const f32x4*>(D + (size_t)(ok ? row : 0) * g.Cd + cd0 + v * 4);
       okd = ok ? (okd | (1u << i)) : (okd & ~(1u << i));
     }
+    if constexpr (PG) {
+#pragma unroll
+      for (int i = 0; i < G_LOADS8; ++i) {
+        const int idx = lane + 64 * i;
+        const int r = idx / GV8, v = idx - r * GV8;
+        const int row = r0 + r;
+        int bb, p, rr, cc;
+        fdiv(row, HWr, inv_hw, bb, p);
+        fdiv(p, g.Wr, inv_w, rr, cc);
+        const int y = rr * g.rs + g.ro + kh, x = cc * g.rs + g.ro + kw;
+        const bool ok = (row < row_end) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
+        const int pix = (bb * g.Hi + y) * g.Wi + x;
+        const bf16_t* b = reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * 3 * g.Cg + cg0 + v * 8;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pg[i][q] = *reinterpret_cast<const u32x4*>(b + q * g.Cg);
+        okg = ok ? (okg | (1u << i)) : (okg & ~(1u << i));
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < G_LOADS; ++i) {
       const int idx = lane + 64 * i;
@@ -761,11 +826,6 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
       const int y = rr * g.rs + g.ro + kh, x = cc * g.rs + g.ro + kw;
       const bool ok = (row < row_end) & ((unsigned)y < (unsigned)g.Hi) & ((unsigned)x < (unsigned)g.Wi);
       const int pix = (bb * g.Hi + y) * g.Wi + x;
-      if constexpr (PG) {
-        const bf16_t* b = reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * 3 * g.Cg + cg0 + v * 4;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) pg[i][p] = *reinterpret_cast<const uint2*>(b + p * g.Cg);
-      } else
       if constexpr (BF16 && (ST == 1 || ST == 3))
         rg[i] = ld4<bf16_t>(reinterpret_cast<const bf16_t*>(Gt) + (size_t)(ok ? pix : 0) * g.Cg + cg0 + v * 4);
       else if constexpr (BF16 && (ST == 5 || ST == 7))
@@ -778,48 +838,55 @@ __global__ __launch_bounds__(256) void wgrad_tn4_kernel(const float* __restrict_
   auto lds_store = [&]() {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     if constexpr (X3) {
-      const uint2 z2 = {0u, 0u};
+      const u32x4 z4 = {0u, 0u, 0u, 0u};
+      if constexpr (PD) {
+        if (D_ALL8 || tid < RK * DV8) {
+          const int r = tid / DV8, v = tid - r * DV8;
+          const int o = r * LDD + v * 8;
 #pragma unroll
-      for (int i = 0; i < D_LOADS; ++i) {
-        const int idx = tid + 256 * i;
-        if (D_ALL || idx < RK * DV) {
-          const int r = idx / DV, v = idx - r * DV;
-          const bool ok = (okd >> i) & 1u;
-          uint2 hh, mm, ll;
-          if constexpr (PD) {
-            hh = ok ? pd[i][0] : z2;
-            mm = ok ? pd[i][1] : z2;
-            ll = ok ? pd[i][2] : z2;
-          } else {
-            const f32x4 x = ok ? rd[i] : zero;
+          for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&Ds16[p * RK * LDD + o]) = okd ? pd8[p] : z4;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < D_LOADS; ++i) {
+          const int idx = tid + 256 * i;
+          if (D_ALL || idx < RK * DV) {
+            const int r = idx / DV, v = idx - r * DV;
+            const f32x4 x = ((okd >> i) & 1u) ? rd[i] : zero;
+            uint2 hh, mm, ll;
             split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
             split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
+            const int o = r * LDD + v * 4;
+            *reinterpret_cast<uint2*>(&Ds16[o]) = hh;
+            *reinterpret_cast<uint2*>(&Ds16[RK * LDD + o]) = mm;
+            *reinterpret_cast<uint2*>(&Ds16[2 * RK * LDD + o]) = ll;
           }
-          const int o = r * LDD + v * 4;
-          *reinterpret_cast<uint2*>(&Ds16[o]) = hh;
-          *reinterpret_cast<uint2*>(&Ds16[RK * LDD + o]) = mm;
-          *reinterpret_cast<uint2*>(&Ds16[2 * RK * LDD + o]) = ll;
         }
       }
+      if constexpr (PG) {
 #pragma unroll
-      for (int i = 0; i < G_LOADS; ++i) {
-        const int idx = lane + 64 * i;
-        const int r = idx / GV, v = idx - r * GV;
-        const bool ok = (okg >> i) & 1u;
-        uint2 hh, mm, ll;
-        if constexpr (PG) {
-          hh = ok ? pg[i][0] : z2;
-          mm = ok ? pg[i][1] : z2;
-          ll = ok ? pg[i][2] : z2;
-        } else {
-          const f32x4 x = ok ? rg[i] : zero;
+        for (int i = 0; i < G_LOADS8; ++i) {
+          const int idx = lane + 64 * i;
+          const int r = idx / GV8, v = idx - r * GV8;
+          const int o = r * LDG + v * 8;
+          const bool ok = (okg >> i) & 1u;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&Gw16[p * RK * LDG + o]) = ok ? pg[i][p] : z4;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < G_LOADS; ++i) {
+          const int idx = lane + 64 * i;
+          const int r = idx / GV, v = idx - r * GV;
+          const f32x4 x = ((okg >> i) & 1u) ? rg[i] : zero;
+          uint2 hh, mm, ll;
           split3_bf16(x[0], x[1], hh.x, mm.x, ll.x);
           split3_bf16(x[2], x[3], hh.y, mm.y, ll.y);
+          const int o = r * LDG + v * 4;
+          *reinterpret_cast<uint2*>(&Gw16[o]) = hh;
+          *reinterpret_cast<uint2*>(&Gw16[RK * LDG + o]) = mm;
+          *reinterpret_cast<uint2*>(&Gw16[2 * RK * LDG + o]) = ll;
         }
-        const int o = r * LDG + v * 4;
-        *reinterpret_cast<uint2*>(&Gw16[o]) = hh;
-        *reinterpret_cast<uint2*>(&Gw16[RK * LDG + o]) = mm;
-        *reinterpret_cast<uint2*>(&Gw16[2 * RK * LDG + o]) = ll;
       }
       return;
     }

@@ -923,6 +923,9 @@ class MVAEStep:
                            ("main", lambda: (self._ph_heads_wgrad(), self._ph_pose_enc_bwd()))] + wq)
             stages.append([("l0", lambda: tail("v")), ("l1", lambda: tail("t"))])
         if getattr(self, "_wstreams", None) is None:
+            # (two streams; ONE stream for both decoders' queues measured the same step: 5.28-5.30 against 5.25-5.29 ms -- the
+            #  stage is bound by the chip's throughput, not by how its five streams are packed; GPU_MAX_HW_QUEUES=8 instead of the
+            #  default 4 measured 6.3-6.4 ms: profiles/r5/stage_timeline_and_streams.txt)
             self._wstreams = [torch.cuda.Stream(), torch.cuda.Stream()]
         cap_stream = {"main": torch.cuda.Stream(), "l0": LN.side[0], "l1": LN.side[1], "w0": self._wstreams[0], "w1": self._wstreams[1]}
         pools = {k: torch.cuda.graph_pool_handle() for k in cap_stream}

@@ -27,39 +27,45 @@ def main():
     E = lambda: torch.cuda.Event(enable_timing=True)
 
     def replay(captured):
+        """engine.MVAEStep._replay (one rank) with an event pair around every graph launch"""
         LN = step.lanes
         main = torch.cuda.current_stream()
         side = {"l0": LN.side[0], "l1": LN.side[1]}
-        handles = []
+        if step.defer_wgrad:
+            side.update({"w0": step._wstreams[0], "w1": step._wstreams[1]})
+        loose = []
+
+        def timed(ri, lane, g):
+            a, b = E(), E()
+            a.record()
+            g.replay()
+            b.record()
+            marks.append((ri, lane, a, b))
         for ri, row in enumerate(captured):
+            if ri == len(captured) - 1:
+                for lane in loose:
+                    main.wait_event(side[lane].record_event())
+                loose = []
             if len(row) == 1:
-                a, b = E(), E()
-                a.record()
-                row[0][1].replay()
-                b.record()
-                marks.append((ri, "main", a, b))
+                timed(ri, "main", row[0][1])
                 continue
             ev = main.record_event()
             for lane, g in row:
                 if lane != "main":
                     side[lane].wait_event(ev)
                     with torch.cuda.stream(side[lane]):
-                        a, b = E(), E()
-                        a.record()
-                        g.replay()
-                        b.record()
-                        marks.append((ri, lane, a, b))
+                        timed(ri, lane, g)
             for lane, g in row:
                 if lane == "main":
-                    a, b = E(), E()
-                    a.record()
-                    g.replay()
-                    b.record()
-                    marks.append((ri, "main", a, b))
+                    timed(ri, "main", g)
             for lane, g in row:
-                if lane != "main":
+                if lane.startswith("w"):
+                    loose.append(lane)
+                elif lane != "main":
                     main.wait_event(side[lane].record_event())
-        return handles
+        for lane in loose:
+            main.wait_event(side[lane].record_event())
+        return []
 
     step._replay = replay
     for _ in range(3):
