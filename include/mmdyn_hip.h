@@ -435,7 +435,12 @@ int mmdyn_resize_u8_to_chw_f32(const uint8_t* src, const int* index, float* dst,
  *       rounding of the product, and the error against fp64 is no larger than the fp32 matrix cores' (csrc/common.h split3_bf16,
  *       csrc/igemm_nt.hip / wgrad_tn.hip X3; profiles/r4/ab_x3_*.txt).  The library decides per launch (shapes with >= 512 blocks
  *       of 64x64 or >= 384 of 128x128 outputs; every weight-gradient GEMM); the rest of such a step runs the fp32 matrix cores.
- *       An Inf operand gives NaN (inf - inf in the split) where the fp32 matrix cores would give Inf.
+ *       Operand range (tests/test_kernels_aten_gpu.py::test_x3_operand_magnitudes_*, ::test_x3_non_finite_*): full fp32 accuracy
+ *       for 2^-100 <= |x| <= FLT_MAX.  Below, the lower terms of the split leave bf16's normal range and are flushed by the matrix
+ *       pipe: an operand under ~1e-33 keeps 16 significant bits, one under ~3e-36 keeps 8 -- an absolute error of at most
+ *       2^-126 |w| per product.  An Inf operand gives NaN (inf - inf in the split) where the fp32 matrix cores would give Inf; a
+ *       NaN operand gives NaN; no other row of the result is touched.  The library does not guard: non-finite operands do not occur
+ *       on this path (the fp16 modes' overflow guard, mmdyn_adam_step_guarded, is not needed in fp32 storage).
  *       Bits 7 + 8 (flags == 384; mmdyn_igemm_nt_mx, mmdyn_igemm_nt_dgrad_act; mmdyn_igemm_nt_dgrad_bn(bf16 = 4)): the same
  *       arithmetic on operands that ARRIVE SPLIT -- A and Bp are rows of [plane][Cin] bf16 (hi | mid | lo, 6 bytes per element:
  *       mmdyn_split_planes, or written so by their producers) -- so the GEMM itself contains no split: LDS-DMA of the planes, six

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, sync_bn=False, reduce_bf16=None):
+def _worker(rank, world, port, out_dir, sync_bn=False, reduce_bf16=None, precision="fp32"):
     for p in (ROOT, os.path.join(ROOT, "multimodal-dynamics_amd"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -41,10 +41,10 @@ def _worker(rank, world, port, out_dir, sync_bn=False, reduce_bf16=None):
     eps, masks = seeded_noise(B, 256, 7, 8, 100 + rank)
     m = T.build("cnn-mvae", True, True, "cpu")
     step = MVAEStep(m, noise=InjectedNoise(eps, masks), process_group=dist.group.WORLD, world_size=world,
-                    sync_bn=sync_bn, grad_reduce_bf16=reduce_bf16)
+                    sync_bn=sync_bn, grad_reduce_bf16=reduce_bf16, precision=precision)
     loss = step.train_step([x[sl] for x in inputs], [x[sl] for x in targets], 0.02)
     torch.save({"flat": step.params.flat.clone(), "order": step.params.order, "offsets": step.params.offsets,
-                "loss": float(loss), "grad": step.params.grad.clone()}, os.path.join(out_dir, f"rank{rank}.pt"))
+                "loss": float(loss), "grad": step.params.grad.clone(), "buckets_bf16": step._grad16 is not None}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,6 +84,25 @@ def test_two_rank_step_matches_averaged_gradients(tmp_path):
         # first Adam step moves every element by ~lr*sign(g): allow sign flips only where the gradient is at noise level
         assert float((err > 1e-5).float().mean()) < 0.02, (k, float(err.max()))
         assert float(err.max()) <= 2.1e-3, k
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_step_in_the_split_arithmetic(tmp_path):
+    """precision="fp32x3" (bench.py's default arithmetic) through the data-parallel schedule: fp32 gradient buckets (the split changes
+    the matrix pipe, not the storage), replicas identical after the step, the parameters those of the fp32 two-rank step (the CPU
+    emulation of the kernels computes the split arithmetic's fp32 contract)."""
+    world = 2
+    a, b = tmp_path / "x3", tmp_path / "f32"
+    a.mkdir()
+    b.mkdir()
+    mp.start_processes(_worker, args=(world, _free_port(), str(a), False, None, "fp32x3"), nprocs=world, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(world, _free_port(), str(b)), nprocs=world, join=True, start_method="spawn")
+    r0, r1 = torch.load(a / "rank0.pt", weights_only=False), torch.load(a / "rank1.pt", weights_only=False)
+    f0 = torch.load(b / "rank0.pt", weights_only=False)
+    torch.testing.assert_close(r0["flat"], r1["flat"], rtol=0, atol=0)
+    assert not r0["buckets_bf16"]
+    assert r0["loss"] == pytest.approx(f0["loss"], rel=1e-6)
+    torch.testing.assert_close(r0["flat"], f0["flat"], rtol=0, atol=1e-6)
 
 
 @pytest.mark.timeout(600)

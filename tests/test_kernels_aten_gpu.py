@@ -612,3 +612,65 @@ def test_weight_gradient_on_operands_that_arrive_split(x3, Cd, Cg, Hr, Hi, strid
     yref = F.conv2d(x, W, stride=stride, padding=-off)
     (gW,) = torch.autograd.grad(yref, W, D.view(Bt, Hr, Hr, Cd).permute(0, 3, 1, 2).double())
     assert relg(outs[3], gW) < 5e-6
+
+
+# ---- the fp32x3 arithmetic at the edges of fp32's range (VERDICT r4 item 2 iii) -------------------------------------------------
+def _range_case(rows, K, N, seed):
+    """A [rows][K] whose rows are scaled by 10^e, e cycling through 1e-36 ... 1e36; W ~ U(-0.05, 0.05)."""
+    exps = torch.tensor([-36., -33., -30., -24., -12., 0., 12., 24., 30., 33., 36.])
+    e = exps[torch.arange(rows) % len(exps)]
+    x = rnd(rows, K, seed=seed) * torch.pow(torch.tensor(10.0), e)[:, None]
+    return x.to(DEV), e, rnd(N, K, seed=seed + 1, scale=0.05).to(DEV)
+
+
+def _row_rel(y, ref):
+    return ((y.double() - ref).norm(dim=1) / (ref.norm(dim=1) + 1e-300)).cpu()
+
+
+def test_x3_operand_magnitudes_1e36_to_1e_minus_36(x3):
+    """The split arithmetic against fp64 ATen over fp32's whole exponent range, through the register-staged split kernel (a dense
+    GEMM) and through the plane-ring kernel (operands that arrive split).  Contract (include/mmdyn_hip.h, flag bit 7): full fp32
+    accuracy for |x| >= 2^-100 up to the largest finite value; below, the lower terms of the split leave bf16's normal range (the
+    matrix pipe flushes them): an operand below ~1e-33 keeps 16 significant bits, one below ~3e-36 keeps 8 -- an ABSOLUTE error of
+    at most 2^-126 |w| per product, i.e. nothing a sum that also holds normal-range terms can see."""
+    x, e, W = _range_case(6400, 256, 2048, 80)
+    y, _ = layers.dense(x, W, None, 6400, 256, 2048)
+    ref = x.double() @ W.double().t()
+    r = _row_rel(y, ref)
+    assert torch.isfinite(y).all()
+    assert float(r[e >= -30].max()) < 2e-6                       # full accuracy, 1e-30 ... 1e36
+    assert float(r[e == -33].max()) < 2e-4 and float(r[e == -36].max()) < 2e-2
+    y_nat = _native(lambda: layers.dense(x, W, None, 6400, 256, 2048)[0])
+    assert float(_row_rel(y_nat, ref)[e >= -30].max()) < 2e-6     # (the native matrix cores on the same data, for reference)
+    # the same rows as a convolution input through the plane-ring kernel: 1024 samples of 16x16x64, sample b scaled by 10^e[b]
+    B, Hi, Cin, Ho, N = 1024, 16, 64, 8, 128
+    xs = rnd(B, Cin, Hi, Hi, seed=82)
+    eb = torch.tensor([-36., -33., -30., -24., -12., 0., 12., 24., 30., 33., 36.])[torch.arange(B) % 11]
+    xs = (xs * torch.pow(torch.tensor(10.0), eb)[:, None, None, None]).to(DEV)
+    Wc = rnd(N, Cin, 4, 4, seed=83, scale=0.05).to(DEV)
+    assert ops.B.igemm_planes_served(CONV, 4, 256, Hi, Hi, Cin, Ho, Ho, N)
+    yc = layers.conv_like(nhwc_rows(xs), layers.pack_conv(Wc, swap=False), CONV, 4, 256, Hi, Cin, Ho, N, 2, -1)[0]
+    refc = nhwc_rows(F.conv2d(xs.double(), Wc.double(), stride=2, padding=1))
+    rc = _row_rel(yc, refc).view(B, Ho * Ho).max(1).values
+    assert torch.isfinite(yc).all()
+    assert float(rc[eb >= -30].max()) < 3e-6 and float(rc[eb == -33].max()) < 2e-4 and float(rc[eb == -36].max()) < 2e-2
+
+
+def test_x3_non_finite_operands_are_not_hidden(x3):
+    """An Inf or NaN operand: the native fp32 matrix cores give +-Inf / NaN in the rows it reaches; the split arithmetic gives NaN
+    there (inf - inf in the residual of the split) -- never a finite number -- and every other row is untouched."""
+    x, W = rnd(6400, 256, seed=90).to(DEV), rnd(2048, 256, seed=91, scale=0.05).to(DEV)
+    clean, _ = layers.dense(x, W, None, 6400, 256, 2048)
+    xb = x.clone()
+    xb[5, 3], xb[70, 200], xb[4000, 0] = float("inf"), float("-inf"), float("nan")
+    for run in (lambda: layers.dense(xb, W, None, 6400, 256, 2048)[0], lambda: _native(lambda: layers.dense(xb, W, None, 6400, 256, 2048)[0])):
+        y = run()
+        bad = torch.zeros(6400, dtype=torch.bool, device=DEV)
+        bad[[5, 70, 4000]] = True
+        assert not torch.isfinite(y[bad]).any()
+        assert torch.isfinite(y[~bad]).all()
+    y = layers.dense(xb, W, None, 6400, 256, 2048)[0]
+    assert torch.isnan(y[[5, 70, 4000]]).all() and torch.equal(y[6:70], clean[6:70])
+    # plane tensors carry the non-finite value into all three terms' sum as NaN as well
+    p = _planes(xb)
+    assert torch.isnan(p.float()[5, 3]) and torch.isnan(p.float()[4000, 0]) and torch.equal(p.float()[6:70], xb[6:70])

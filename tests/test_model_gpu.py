@@ -130,15 +130,55 @@ def test_conditional_training_loops(tmp_path):
     T.check_conditional_loops(tmp_path, no_cuda=False)
 
 
+class _ReluKnifeEdges:
+    """A ReLU input within fp32 rounding of zero has no defined gradient mask: the native and the split arithmetic (and the
+    oracle) may land on either side, and ONE flipped unit of the pose decoder moves the upstream gradients by 2e-3 (the pose term
+    is weighted 1000x; profiles/r4/x3_relu_knife_edge_b130.txt: B = 130, {tactile, pose} subset, sample 37, unit 507 of
+    deconv_net.2: +3.5e-7 natively, <= 0 in the split).  Either subgradient is right.  While active, the oracle's pose decoder takes
+    the ENGINE's mask for the units -- and only those -- whose oracle pre-activation is below 1e-5 of the layer's rms, and counts how
+    many it had to flip (`flips`), which the test bounds: a real error in the pose decoder flips thousands, a knife edge one or two."""
+    THR = 1e-5
+
+    def __init__(self, step, B):
+        self.step, self.B, self.flips, self.calls = step, B, 0, 0
+
+    def __enter__(self):
+        self._orig = O.pose_decoder
+        O.pose_decoder = self._pose_decoder
+        return self
+
+    def __exit__(self, *exc):
+        O.pose_decoder = self._orig
+
+    def _relu(self, u, eng_h):
+        mask = u > 0
+        if eng_h is not None:
+            knife = u.detach().abs() < self.THR * float(u.detach().pow(2).mean().sqrt())
+            eng = eng_h.detach().cpu() > 0
+            self.flips += int((knife & (eng != mask)).sum())
+            mask = torch.where(knife, eng, mask)
+        return u * mask
+
+    def _pose_decoder(self, z, prm, pre="pose_decoder"):
+        k = self.calls % 7                      # _evaluate_mvae's pass index (problems.py:473-546: one pose decoding per pass)
+        self.calls += 1
+        dp, live = self.step.ctx.get("dp"), list(self.step.pass_p)
+        h1 = h2 = None
+        if dp is not None and k in live:
+            g = live.index(k)
+            h1, h2 = dp["h1"][g * self.B:(g + 1) * self.B], dp["h2"][g * self.B:(g + 1) * self.B]
+        h = self._relu(torch.nn.functional.linear(z, prm[pre + ".deconv_net.0.weight"], prm[pre + ".deconv_net.0.bias"]), h1)
+        h = self._relu(torch.nn.functional.linear(h, prm[pre + ".deconv_net.2.weight"], prm[pre + ".deconv_net.2.bias"]), h2)
+        return torch.nn.functional.linear(h, prm[pre + ".deconv_net.4.weight"], prm[pre + ".deconv_net.4.bias"])
+
+
 @pytest.mark.parametrize("B,n_steps,precision", [(32, 3, "fp32"), (256, 1, "fp32"), (1, 1, "fp32"), (5, 2, "fp32"), (37, 1, "fp32"),
-                                                 (130, 1, "fp32"), (32, 3, "fp32x3"), (256, 1, "fp32x3"), (131, 1, "fp32x3"), (200, 1, "fp32x3")])
+                                                 (130, 1, "fp32"), (32, 3, "fp32x3"), (256, 1, "fp32x3"), (130, 1, "fp32x3"),
+                                                 (131, 1, "fp32x3"), (200, 1, "fp32x3")])
 def test_fused_engine_vs_oracle(B, n_steps, precision):
-    """(precision "fp32x3": the GEMMs that gain from it run on the bf16 matrix cores through the exact three-term split of their
-    fp32 operands -- held to the SAME tolerances as the native fp32 arithmetic.  Its ragged case is B = 131, not 130: at B = 130 with
-    this seed ONE ReLU input of the pose decoder (sample 37 of the {tactile, pose} subset, unit 507 of deconv_net.2) is 3.5e-7 in the
-    native arithmetic and the oracle and <= 0 in the split -- a rounding-level difference in the forward pass that flips the unit's
-    gradient mask and moves the tactile / pose encoder gradients by 2e-3 (profiles/r4/x3_relu_knife_edge_b130.txt,
-    tests/microbench/x3_state_diff.py); either subgradient is right, neither arithmetic is closer to the exact one.)
+    """(precision "fp32x3": the convolution-level GEMMs run on the bf16 matrix cores through the exact three-term split of their
+    fp32 operands -- held to the SAME tolerances as the native fp32 arithmetic, at the same batch sizes incl. the ragged B = 130,
+    whose one ReLU knife-edge unit is handled by construction: _ReluKnifeEdges.)
     ELBO (total and each of the 7 partials) within 1e-4 relative of the CPU oracle, gradients within 1e-3
     relative L2 per tensor, loss still within 1e-4 after 3 Adam steps; B=256 is the
     BASELINE batch (one oracle step takes a few seconds on the host cores); 1, 5, 37 and 130 are ragged sizes: no
@@ -155,10 +195,12 @@ def test_fused_engine_vs_oracle(B, n_steps, precision):
     gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
     for s in range(n_steps):
         opt.zero_grad()
-        _, loss_o, partials_o = O.evaluate_mvae(prm, inputs, targets, eps[7 * s:7 * s + 7], masks[8 * s:8 * s + 8], klw,
-                                                1000.0, True, buf)
-        loss_o.backward()
         loss = step.forward(gi, gt, klw)
+        with _ReluKnifeEdges(step, B) as knife:
+            _, loss_o, partials_o = O.evaluate_mvae(prm, inputs, targets, eps[7 * s:7 * s + 7], masks[8 * s:8 * s + 8], klw,
+                                                    1000.0, True, buf)
+        assert knife.flips <= 3, knife.flips          # (B = 130, fp32x3, r4 kernels: 1)
+        loss_o.backward()
         assert float(loss) == pytest.approx(float(loss_o.detach()), rel=1e-4), s
         # every partial within 1e-4 on identical weights (step 0).  After Adam steps the weights themselves differ by
         # rounding-level gradient differences that Adam amplifies where |g| ~ 0 (update = lr * g / (|g| + eps)), so the
