@@ -107,9 +107,11 @@ static inline int bn_splits(int T) {
   int s = T / 128;
   return s < 1 ? 1 : (s > BN_MAX_SPLITS ? BN_MAX_SPLITS : s);
 }
+// (2 KB of LDS, not 4: the persistent plane-ring GEMM of the OTHER lane holds 156 of a CU's 160 KB, and a finalize launch that
+//  does not fit beside it waits for that whole GEMM -- the two half-waves of a wave are combined by a shuffle first)
 __global__ __launch_bounds__(256) void tile_sum_kernel(const float* __restrict__ partial,
                                                        double* __restrict__ out, int T, int C) {
-  __shared__ double red[2][8][32];
+  __shared__ double red[2][4][32];
   const int g = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31), tl = threadIdx.x >> 5;
   const int per = (T + gridDim.z - 1) / gridDim.z;
   const int t_lo = blockIdx.z * per, t_hi = min(T, t_lo + per);
@@ -120,14 +122,18 @@ __global__ __launch_bounds__(256) void tile_sum_kernel(const float* __restrict__
     a += (double)partial[o];
     b += (double)partial[o + C];
   }
-  red[0][tl][threadIdx.x & 31] = a;
-  red[1][tl][threadIdx.x & 31] = b;
+  a += __shfl_xor(a, 32, 64);
+  b += __shfl_xor(b, 32, 64);
+  if ((threadIdx.x & 32) == 0) {
+    red[0][threadIdx.x >> 6][threadIdx.x & 31] = a;
+    red[1][threadIdx.x >> 6][threadIdx.x & 31] = b;
+  }
   __syncthreads();
   if (threadIdx.x < 64) {
     const int which = threadIdx.x >> 5, cc = threadIdx.x & 31;
     double s = 0.0;
 #pragma unroll
-    for (int l = 0; l < 8; ++l) s += red[which][l][cc];
+    for (int l = 0; l < 4; ++l) s += red[which][l][cc];
     out[((size_t)g * 2 + which) * C + blockIdx.x * 32 + cc] = s;
   }
 }
@@ -263,7 +269,7 @@ __global__ void bn_bwd_param_kernel(const double* __restrict__ sums, float* __re
 // BatchNorm layer and direction (24 per train step of the cnn-mvae).
 __global__ __launch_bounds__(256) void tile_sum_finish_kernel(const float* __restrict__ partial, double* out, int T, int C,
                                                               unsigned* ticket, BnFinish f) {
-  __shared__ double red[2][8][32];
+  __shared__ double red[2][4][32];
   __shared__ int last_flag;
   const int g = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31), tl = threadIdx.x >> 5;
   const int per = (T + gridDim.z - 1) / gridDim.z;
@@ -275,14 +281,18 @@ __global__ __launch_bounds__(256) void tile_sum_finish_kernel(const float* __res
     a += (double)partial[o];
     b += (double)partial[o + C];
   }
-  red[0][tl][threadIdx.x & 31] = a;
-  red[1][tl][threadIdx.x & 31] = b;
+  a += __shfl_xor(a, 32, 64);
+  b += __shfl_xor(b, 32, 64);
+  if ((threadIdx.x & 32) == 0) {
+    red[0][threadIdx.x >> 6][threadIdx.x & 31] = a;
+    red[1][threadIdx.x >> 6][threadIdx.x & 31] = b;
+  }
   __syncthreads();
   if (threadIdx.x < 64) {
     const int which = threadIdx.x >> 5, cc = threadIdx.x & 31;
     double s = 0.0;
 #pragma unroll
-    for (int l = 0; l < 8; ++l) s += red[which][l][cc];
+    for (int l = 0; l < 4; ++l) s += red[which][l][cc];
     st_wt(&myout[((size_t)g * 2 + which) * C + blockIdx.x * 32 + cc], s);
   }
   const unsigned nblocks = gridDim.x * gridDim.y * gridDim.z;

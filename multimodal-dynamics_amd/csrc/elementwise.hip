@@ -150,7 +150,7 @@ __device__ __forceinline__ void colsum_final_channel(const float* partial, float
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* partial,
                                                              int rows, int C, int rows_per_chunk, unsigned* ticket,
                                                              float* out, int perm, float beta) {
-  __shared__ f32x4 red[8][32];
+  __shared__ f32x4 red[4][32];          // (2 KB: fits beside a persistent GEMM block of the other lane, see tile_sum_kernel)
   __shared__ int last_flag;
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c4 = blockIdx.x * 32 + cl;                     // float4 column
@@ -170,12 +170,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         if (r + 8 * u < r1) s += v[u];
     }
   }
-  red[rl][cl] = s;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s[k] += __shfl_xor(s[k], 32, 64);          // the two half-waves of a wave
+  if ((rl & 1) == 0) red[rl >> 1][cl] = s;
   __syncthreads();
   if (rl == 0 && c4 < CV) {
     f32x4 t = red[0][cl];
 #pragma unroll
-    for (int l = 1; l < 8; ++l) t += red[l][cl];
+    for (int l = 1; l < 4; ++l) t += red[l][cl];
     float* dst = partial + (size_t)blockIdx.y * C + c4 * 4;
     if (ticket) {
 #pragma unroll

@@ -27,3 +27,9 @@ int mmdyn_wgrad_ws_try(const float* D, const float* Gt, float* partial, const Wg
 #else
 static inline int mmdyn_wgrad_ws_try(const float*, const float*, float*, const WgradGeom&, hipStream_t) { return 1; }
 #endif
+
+// wgrad_p3.hip: the plane-ring form for convolution-level weight gradients whose two operands arrive split (LDS-DMA ring + MFMA
+// waves, no register staging).  try: MMDYN_OK / an error code, or 1 when the shape is not served; chunks: its slab count (0: not
+// served).
+int mmdyn_wgrad_p3_try(const void* D, const void* Gt, float* partial, const WgradGeom& g, int Bt, hipStream_t st);
+int mmdyn_wgrad_p3_chunks(int rows, int Cd, int Cg);

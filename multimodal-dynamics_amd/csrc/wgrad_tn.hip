@@ -1230,6 +1230,12 @@ static bool tile_128x64() {
   return !(e && e[0] == '0');
 }
 
+// (LAB build: MMDYN_WGRAD_P3=0 keeps the register-staged kernels on plane operands -- per-shape A/B)
+static bool p3_enabled() {
+  const char* e = lab_env("MMDYN_WGRAD_P3");
+  return !(e && e[0] == '0');
+}
+
 static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode, int Bt, int Hr,
                        int Wr, int Cd, int Hi, int Wi, int Cg, int stride, int offset, int chunks,
                        void* stream, bool bf16, int storage_flags = 0, int groups = 1) {
@@ -1274,6 +1280,10 @@ static int wgrad_entry(const float* D, const float* Gt, float* partial, int mode
     if (rc != 1) return rc;
   }
   const bool d64 = (Cd % 64 == 0), g64 = (Cg % 64 == 0);
+  if (g.x3 && g.pre == 3 && mode == MMDYN_CONV && p3_enabled()) {      // both operands arrive split: the plane-ring kernel (wgrad_p3.hip)
+    const int rc = mmdyn_wgrad_p3_try(D, Gt, partial, g, Bt, st);
+    if (rc != 1) return rc;
+  }
   if (!bf16 && mode != MMDYN_IM2COL3) {
     // LAB build, MMDYN_WGRAD_WS=1: the wave-specialised LDS-DMA ring form of this GEMM (wgrad_ws.hip).  Measured per shape
     // against the kernels below (profiles/r3/ab_ws_wgrad.txt): x0.97-1.10, one launch x0.69, sum +3 % -- unlike the implicit
@@ -1404,6 +1414,10 @@ static int wgrad_chunks_impl(int mode, int rows, int Cd, int Cg, bool b16_storag
 extern "C" int mmdyn_wgrad_chunks(int mode, int rows, int Cd, int Cg) { return wgrad_chunks_impl(mode, rows, Cd, Cg, false); }
 /* flags as mmdyn_wgrad_tn_mx: the count for the kernel those storage flags select */
 extern "C" int mmdyn_wgrad_chunks_mx(int mode, int rows, int Cd, int Cg, int flags) {
+  if ((flags & 896) == 896 && !(flags & 1) && mode == MMDYN_CONV && p3_enabled()) {     // both operands arrive split: the plane-ring kernel's cut
+    const int c = mmdyn_wgrad_p3_chunks(rows, Cd, Cg);
+    if (c > 0) return c;
+  }
   return wgrad_chunks_impl(mode, rows, Cd, Cg, (flags & 6) == 6, (flags & 128) != 0 && !(flags & 1));
 }
 

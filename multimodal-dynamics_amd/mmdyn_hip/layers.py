@@ -328,7 +328,10 @@ def wgrad(D, Gt, canon, mode, Bt, Hr, Cd, Hi, Cg, stride=1, offset=0, cg_canon=N
         return
     rows = Bt * Hr * Hr
     taps = 16 if mode == CONV else 1
-    chunks = ops.B.wgrad_chunks(mode, rows, Cd, Cg)
+    if isinstance(D, ops.Planes) or isinstance(Gt, ops.Planes):
+        chunks = ops.B.wgrad_chunks(mode, rows, Cd, Cg, planes=(isinstance(D, ops.Planes), isinstance(Gt, ops.Planes)))
+    else:
+        chunks = ops.B.wgrad_chunks(mode, rows, Cd, Cg)
     partial = _new(D, chunks, taps, Cd, Cg)
     ops.B.wgrad_tn(D, Gt, partial, mode, Bt, Hr, Hr, Cd, Hi, Hi, Cg, stride, offset, chunks)
     ops.B.wgrad_reduce(partial, canon, chunks, taps, Cd, Cg, Cg if cg_canon is None else cg_canon, perm, 0.0)

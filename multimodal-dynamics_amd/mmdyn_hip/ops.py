@@ -195,9 +195,11 @@ class HipBackend:
     def colstats_tiles(self, rows_per_group):
         return self.lib.mmdyn_colstats_tiles(rows_per_group)
 
-    def wgrad_chunks(self, mode, rows, Cd, Cg):
+    def wgrad_chunks(self, mode, rows, Cd, Cg, planes=(False, False)):
+        """``planes``: which of (D, Gt) arrive split (ops.Planes): the cut follows the kernel that serves the launch."""
         # (16-bit storage modes: the all-16-bit weight-gradient kernels keep their own tile rule)
-        r = self.lib.mmdyn_wgrad_chunks_mx(mode, rows, Cd, Cg, 7 if self.precision in ("bf16s", "fp16s") else self._x3())
+        pre = (256 if planes[0] else 0) | (512 if planes[1] else 0)
+        r = self.lib.mmdyn_wgrad_chunks_mx(mode, rows, Cd, Cg, 7 if self.precision in ("bf16s", "fp16s") else (self._x3() | (pre if self._x3() else 0)))
         if r < 0:
             check(r, "mmdyn_wgrad_chunks_mx")
         return r

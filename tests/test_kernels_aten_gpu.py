@@ -593,9 +593,9 @@ def test_pack_plan_writes_plane_twins(x3):
 @pytest.mark.parametrize("Cd,Cg,Hr,Hi,stride,off", [(256, 128, 5, 8, 1, 0), (128, 64, 8, 16, 2, -1), (64, 64, 8, 16, 2, -1),
                                                     (64, 32, 16, 32, 2, -1), (32, 64, 16, 32, 2, -1)])
 def test_weight_gradient_on_operands_that_arrive_split(x3, Cd, Cg, Hr, Hi, stride, off):
-    """mmdyn_wgrad_tn_mx flag bits 8 / 9: either operand (or both) as ops.Planes -- bit for bit the launch that splits the same fp32
-    tensors inside the kernel (same terms, same tiles, same order), on every tile the convolution-level weight gradients use
-    (128x128, 128x64, 64x64 one-tap; 64x32 / 32x64 four-tap); and against fp64 autograd through F.conv2d."""
+    """mmdyn_wgrad_tn_mx flag bits 8 / 9: either operand (or both) as ops.Planes against the launch that splits the same fp32
+    tensors inside the kernel, on every tile the convolution-level weight gradients use (128x128, 128x64, 64x64 one-tap; 64x32 /
+    32x64 four-tap; the plane-ring kernel's 128 x (1 x 128 | 2 x 64) and 64 x (4 x 32)); and against fp64 autograd through F.conv2d."""
     Bt = 64
     D, Gt = rnd(Bt * Hr * Hr, Cd, seed=70).to(DEV), rnd(Bt * Hi * Hi, Cg, seed=71).to(DEV)
     Dp, Gp = _planes(D), _planes(Gt)
@@ -604,8 +604,10 @@ def test_weight_gradient_on_operands_that_arrive_split(x3, Cd, Cg, Hr, Hi, strid
         canon = torch.zeros(Cd, Cg, 4, 4, device=DEV)
         layers.wgrad(d, g, canon, CONV, Bt, Hr, Cd, Hi, Cg, stride, off)
         outs.append(canon)
-    for o in outs[1:]:
-        assert torch.equal(o, outs[0])
+    # one operand split: the register-staged kernel with the same tiles and the same cut -- bit for bit.  Both split: the plane-ring
+    # kernel (csrc/wgrad_p3.hip) where it serves the shape, with its own cut of the rows: same terms, another summation order
+    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+    assert relg(outs[3], outs[0]) < 1e-6
     # D = dY of a Conv2d(Cg -> Cd, k4, stride, pad = -off), Gt = its input: canon = dL/dW [Cd][Cg][4][4]
     x = Gt.view(Bt, Hi, Hi, Cg).permute(0, 3, 1, 2).double().requires_grad_(False)
     W = torch.zeros(Cd, Cg, 4, 4, device=DEV, dtype=torch.float64, requires_grad=True)
