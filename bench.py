@@ -92,13 +92,13 @@ def sources_sha256():
 
 
 def pmc_traffic(workload_key):
-    """HBM-side bytes of one step of this workload from the committed rocprofv3 PMC passes (profiles/r4/traffic_<key>.json, else r3's:
-    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; profiles/collect_r4.sh traffic).  PMC counters cannot be
+    """HBM-side bytes of one step of this workload from the committed rocprofv3 PMC passes (profiles/r5/traffic_<key>.json, else r4's / r3's:
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; profiles/collect_r5.sh traffic).  PMC counters cannot be
     read from inside this process, so the values are the last profiled ones -- WITH their provenance: the profile records
     the sha-256 of the kernel sources it was taken on, and the values are reported as None (plus the reason) when the
     sources have changed since.  Returns (dict | None, note)."""
     d = None
-    for rnd in ("r4", "r3"):                      # the latest round's collection first
+    for rnd in ("r5", "r4", "r3"):                # the latest round's collection first
         rel = ("profiles", rnd, f"traffic_{workload_key}.json")
         try:
             d = json.load(open(os.path.join(ROOT, *rel)))
@@ -106,7 +106,7 @@ def pmc_traffic(workload_key):
         except (OSError, ValueError):
             continue
     if d is None:
-        return None, {"stale": f"no PMC profile committed for this workload (profiles/r4|r3/traffic_{workload_key}.json)"}
+        return None, {"stale": f"no PMC profile committed for this workload (profiles/r5|r4|r3/traffic_{workload_key}.json)"}
     note = {"profile": "/".join(rel), "collected": d.get("collected"), "sources_sha256": d.get("sources_sha256")}
     if d.get("sources_sha256") and d["sources_sha256"] == sources_sha256():
         return d, note

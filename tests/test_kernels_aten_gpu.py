@@ -577,7 +577,7 @@ def test_pack_plan_writes_plane_twins(x3):
     W = {"hallucinate.0.weight": rnd(256, 128, 4, 4, seed=60, scale=0.1).to(DEV), "conv": rnd(128, 64, 4, 4, seed=61, scale=0.1).to(DEV)}
     specs = [layers._spec("W1s", W["hallucinate.0.weight"], layers.K_SWAP, 256, 128, 0, 0, (16, 128, 256)),
              layers._spec("W3k", W["conv"], layers.K_KEEP, 128, 64, 0, 0, (16, 128, 64)),
-             layers._spec("W9k", W["conv"][:64].contiguous(), layers.K_KEEP, 64, 64, 0, 0, (16, 64, 64))]
+             layers._spec("W9k", W["conv"][:32].contiguous(), layers.K_KEEP, 32, 64, 0, 0, (16, 32, 64))]      # (N = 32: no plane launch)
     plan = layers.PackPlan({"d": specs}, early=("W3k",), plane_twins=True)
     plan.run()
     pk = plan.packed["d"]
