@@ -503,26 +503,37 @@ def main():
         return rl, total_ms
 
     def kernel_mix(by_shape, dtype):
-        """Which kernels served the implicit-GEMM entry-point calls, asked of the library's own launch rule (host-side shape
-        queries: a launch with stream-K slabs runs the persistent kernel)."""
+        """Which kernels served the implicit-GEMM entry-point calls, asked of the library's own launch rules (host-side shape
+        queries): a launch the plane-ring kernel serves takes its operands already split (igemm_wsp3_kernel); one with stream-K
+        slabs runs the persistent fp32-operand kernel (igemm_wsp_kernel)."""
         from mmdyn_hip import ops as _ops
         lib = getattr(_ops.B, "lib", None)
-        n_all = n_wsp = 0
+        n_all = n_p3 = n_wsp = 0
+        fl_all = fl_p3 = 0.0
         for k, d in by_shape.items():
             if k[0] != "igemm_nt":
                 continue
             n_all += d["calls"]
+            fl_all += d["flops"]
             ints = [x for x in k[1:] if isinstance(x, int)]
             try:
                 mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N = ints[:9]
-                flags = 128 if dtype == "f32x3" else 0
-                if lib is not None and ints[13] == 1 and lib.mmdyn_igemm_slab_floats_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, flags) > 0:
+                if lib is None or ints[13] != 1:
+                    continue
+                if dtype == "f32x3" and not args.no_planes and lib.mmdyn_igemm_planes_served(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) == 1:
+                    n_p3 += d["calls"]
+                    fl_p3 += d["flops"]
+                elif lib.mmdyn_igemm_slab_floats_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, 128 if dtype == "f32x3" else 0) > 0:
                     n_wsp += d["calls"]
             except Exception:
                 pass
-        arith = " in the three-term split arithmetic where the launch rule selects it" if dtype == "f32x3" else ""
+        if dtype == "f32x3":
+            return (f"{n_all} calls: {n_p3} convolution-level launches ({100.0 * fl_p3 / max(fl_all, 1.0):.0f} % of the family's flops) on the "
+                    f"persistent plane-ring kernel igemm_wsp3_kernel + its stream-K fix-up launch, operands arriving split; {n_wsp} on the "
+                    f"persistent fp32-operand kernel igemm_wsp_kernel (split in the MFMA waves); the rest -- the 32-channel layer, FC-level "
+                    f"GEMMs -- on igemm_ws_kernel / igemm_nt_kernel / tconv_patch_kernel")
         return (f"{n_all} calls: {n_wsp} on the persistent stream-K ring kernel igemm_wsp_kernel + its fix-up launch, the rest on "
-                f"the one-tile ring kernel igemm_ws_kernel / the register-staged igemm_nt_kernel{arith}")
+                f"the one-tile ring kernel igemm_ws_kernel / the register-staged igemm_nt_kernel")
 
     if pg is not None:
         import torch.distributed as dist

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: shader clock and package power (rocm-smi) while ONE implicit-GEMM launch shape runs back to back, native fp32
-arithmetic and the three-term split (LAB library).  usage: clock_under_load.py"""
+arithmetic, the three-term split done in the MFMA waves, and the plane-ring kernel on operands split beforehand (LAB library).
+usage: clock_under_load.py"""
 import os
 import subprocess
 import sys
@@ -34,9 +35,14 @@ def main():
     C = torch.empty(rows, N, device=dev)
     fl = 2.0 * rows * N * Cin * 16
     print("idle:", smi())
-    for flag in ("0", "1"):
-        os.environ["MMDYN_X3"] = flag
-        fn = lambda: HIP.igemm_nt(A, Bp, None, C, None, None, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1)
+    Ap, Bpp = ops.Planes(A.shape[0], Cin, dev), ops.Planes(16 * N, Cin, dev)
+    HIP.split_planes(A, Ap)
+    HIP.split_planes(Bp, Bpp)
+    for flag in ("0", "1", "planes"):
+        os.environ["MMDYN_X3"] = "0" if flag == "0" else "1"
+        HIP.fp32_split = flag != "0"
+        a, b = (Ap, Bpp) if flag == "planes" else (A, Bp)
+        fn = lambda: HIP.igemm_nt(a, b, None, C, None, None, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1)
         for _ in range(20):
             fn()
         torch.cuda.synchronize()
@@ -64,7 +70,7 @@ def main():
         stop[0] = True
         th.join()
         ms = s.elapsed_time(e) / n
-        print(f"MMDYN_X3={flag}: {ms * 1e3:.1f} us per launch, {fl / ms / 1e9:.1f} TFLOP/s (fp32-equivalent)")
+        print(f"{ {'0': 'native fp32', '1': 'split in the MFMA waves', 'planes': 'plane-ring kernel'}[flag] }: {ms * 1e3:.1f} us per launch, {fl / ms / 1e9:.1f} TFLOP/s (fp32-equivalent)")
         for x in samples[:4]:
             print("    ", x)
 

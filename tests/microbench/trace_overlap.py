@@ -24,8 +24,8 @@ def main():
     t0, t1 = adam_ends[skip], adam_ends[-2]          # (the last step of bench.py is its eager single-lane profiling step)
     nsteps = len(adam_ends) - 2 - skip
     win = [(max(s, t0), min(e, t1), n) for s, e, n in ev if e > t0 and s < t1]
-    is_mfma = lambda n: (("igemm_" in n and "fixup" not in n) or "wgrad_tn" in n or "wgrad_b16" in n or "conv3_" in n
-                         or "tconv_patch" in n)
+    is_mfma = lambda n: (("igemm_" in n and "fixup" not in n) or "wgrad_tn" in n or "wgrad_b16" in n or "wgrad_p3" in n
+                         or "conv3_" in n or "tconv_patch" in n)
     pts = []
     for s, e, n in win:
         pts.append((s, 1, n))
