@@ -18,6 +18,7 @@ summation order (tests/test_engine_*.py).  BatchNorm running statistics: encoder
 4 EMA updates as in the reference; decoder buffers receive the live passes' updates only (the
 reference also folds in the discarded passes) unless ``exact_running_stats=True``.
 """
+import os
 import torch
 
 from . import layers, ops
@@ -962,6 +963,11 @@ class MVAEStep:
         if self.defer_wgrad:
             side.update({"w0": self._wstreams[0], "w1": self._wstreams[1]})
         handles, loose = [], []
+        # (LAB, MMDYN_WGRAD_FORK=dec: each decoder's deferred weight gradients forked behind ITS OWN backward instead of next to
+        #  the encoder backward -- measured WORSE, same box, alternating: 5.33 / 5.25 / 5.28 ms against 5.14 / 5.12 / 5.10 ms
+        #  (tests/microbench/run_ab_wgrad_fork.sh): the full-chip weight-gradient kernels slow the other decoder's dependent chain by
+        #  more than they fill of its gaps)
+        early = self.defer_wgrad and os.environ.get("MMDYN_WGRAD_FORK", "enc") == "dec"
         for ri, row in enumerate(captured):
             if ri == self.DEC_STAGE + 1 and not self.defer_wgrad:
                 handles += self._reduce_bucket(0)          # decoders done: reduce them under the encoder backward
@@ -982,10 +988,20 @@ class MVAEStep:
                 continue
             ev = main.record_event()
             for lane, g in row:
+                if lane.startswith("w") and early:
+                    continue                               # launched behind its decoder lane, two rows up
                 if lane != "main":
                     side[lane].wait_event(ev)
                     with torch.cuda.stream(side[lane]):
                         g.replay()
+                if ri == self.DEC_STAGE and early and lane in ("l0", "l1"):
+                    # (LAB: this decoder's deferred weight gradients start as soon as ITS backward is done)
+                    wl = "w" + lane[1]
+                    wg = dict(captured[self.DEC_STAGE + 2]).get(wl)
+                    if wg is not None:
+                        side[wl].wait_event(side[lane].record_event())
+                        with torch.cuda.stream(side[wl]):
+                            wg.replay()
             for lane, g in row:
                 if lane == "main":
                     g.replay()
