@@ -278,6 +278,8 @@ def main():
     ap.add_argument("--no-planes", action="store_true",
                     help="A/B switch (f32x3): every GEMM splits its fp32 operands inside the kernel (the round-4 structure) instead of "
                          "taking them already split where the plane-ring kernel serves the launch")
+    ap.add_argument("--no-patch-planes", action="store_true",
+                    help="A/B switch (f32x3): the 32-channel up-sampling layers (tconv_patch_kernel) keep fp32 operands")
     ap.add_argument("--single-lane", action="store_true",
                     help="no visual/tactile stream overlap: per-kernel durations in a rocprofv3 trace then match "
                          "the roofline object's live HIP-event measurement")
@@ -333,6 +335,9 @@ def main():
     if args.no_planes:
         from mmdyn_hip import layers as _layers
         _layers.PLANES = False
+    if args.no_patch_planes:
+        from mmdyn_hip import layers as _layers
+        _layers.PATCH_PLANES = False
     from mmdyn_hip.utils.seeded_init import seeded_batch
 
     S = args.image_size

@@ -61,6 +61,10 @@ static inline int mmdyn_igemm_d16_stat_tiles(int, int, int, int, int, int, int, 
 int mmdyn_tconv_patch_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
                           const IgemmGeom& g, hipStream_t st);
 int mmdyn_tconv_patch_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
+// ... on operands that arrive split (fp32x3 plane rows): the shapes served, and the launch (1: not served)
+bool mmdyn_tconv_patch_p3_serves(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N);
+int mmdyn_tconv_patch_p3_try(const void* A, const void* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
+                             const IgemmGeom& g, hipStream_t st);
 
 // igemm_ws.hip: wave-specialised fp32 implicit GEMM (loader waves + LDS-DMA ring).  Same protocol as the hooks above.
 int mmdyn_igemm_ws_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,

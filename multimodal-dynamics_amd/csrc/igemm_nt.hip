@@ -946,6 +946,7 @@ extern "C" int mmdyn_igemm_slab_floats(int mode, int G, int Bg, int Hi, int Wi, 
  * partial-sum tile count and slab workspace are those of the flags == 128 queries.  0: keep fp32 operands. */
 extern "C" int mmdyn_igemm_planes_served(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   if (G <= 0 || Bg <= 0 || Cin <= 0 || N <= 0 || Cin % BK || N % 32) return 0;
+  if (mmdyn_tconv_patch_p3_serves(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)) return 1;      // the patch-resident 32-channel up-sampling layers
   if (!ws_enabled()) return 0;
   return mmdyn_igemm_wsp3_serves(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) ? 1 : 0;
 }
@@ -955,7 +956,10 @@ extern "C" int mmdyn_igemm_stat_tiles_bf16(int mode, int G, int Bg, int Hi, int 
 /* ... of the mixed-storage entry points, flags as mmdyn_igemm_nt_mx: launches whose operands are BOTH 16-bit in HBM (bits 1 and
  * 4) may run the persistent ring kernel (igemm_wsp.hip), which writes one partial tile per wave row */
 extern "C" int mmdyn_igemm_stat_tiles_mx(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int flags) {
-  if ((flags & 384) == 384) return ws_enabled() ? mmdyn_igemm_wsp3_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) : 0;     // plane launch
+  if ((flags & 384) == 384) {     // plane launch
+    if (mmdyn_tconv_patch_p3_serves(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)) return mmdyn_tconv_patch_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
+    return ws_enabled() ? mmdyn_igemm_wsp3_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) : 0;
+  }
   if (!(flags & 1) && !(flags & 32)) return f32_stat_tiles((flags & 128) != 0, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   if ((flags & 2) && (flags & 16) && ws_enabled()) {
     const int t = mmdyn_igemm_wsp_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, true);
@@ -964,7 +968,10 @@ extern "C" int mmdyn_igemm_stat_tiles_mx(int mode, int G, int Bg, int Hi, int Wi
   return lds_stat_tiles(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
 }
 extern "C" int mmdyn_igemm_slab_floats_mx(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int flags) {
-  if ((flags & 384) == 384) return ws_enabled() ? (int)(mmdyn_igemm_wsp3_slab_bytes(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) / 4) : 0;
+  if ((flags & 384) == 384) {
+    if (mmdyn_tconv_patch_p3_serves(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)) return 0;
+    return ws_enabled() ? (int)(mmdyn_igemm_wsp3_slab_bytes(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) / 4) : 0;
+  }
   if (!(flags & 1) && !(flags & 32)) return f32_slab_floats((flags & 128) != 0, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N);
   if (!((flags & 2) && (flags & 16)) || !ws_enabled()) return 0;
   return (int)(mmdyn_igemm_wsp_slab_bytes(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, true) / 4);
@@ -1078,7 +1085,11 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
                                       st);
     if (rc != 1) return rc;
   }
-  if (planes) {       // operands already split: served by the persistent plane-ring kernel or not at all (mmdyn_igemm_planes_served)
+  if (planes) {       // operands already split: served by a plane kernel or not at all (mmdyn_igemm_planes_served)
+    if (mode == MMDYN_TCONV_S2P1 && !b_group_stride) {
+      const int rp = mmdyn_tconv_patch_p3_try(A, Bp, bias, C, C_act, stats, ws, g, st);
+      if (rp != 1) return rp;
+    }
     const int rc = ws_enabled() ? mmdyn_igemm_wsp3_try(A, Bp, bias, C, C_act, stats, ws, g, st) : 1;
     return rc == 1 ? MMDYN_ERR_SHAPE : rc;
   }

@@ -10,6 +10,11 @@
 // operands, as in igemm_d16.hip).  The K loop has no gather arithmetic and no global operand load.  64 -> 32 channels on
 // 4 x 256 samples: 169 us against 208 us (tests/microbench/patch_tconv.hip is the prototype), and the gain survives next to
 // the other lane's kernels (step 6.93 -> 6.86 ms).  BatchNorm partial sums are written per tile (T = Bg * H / TH per group).
+//
+// P3 = the same kernel in the fp32x3 arithmetic on operands that ARRIVE SPLIT (rows of [plane][CIN] bf16, include/mmdyn_hip.h flag
+// bits 7 + 8): the patch and the weight ring hold plane rows (6 * CIN bytes + 32 of padding: a row stride of 32 * odd bytes makes
+// the 16-byte fragment reads of 16 consecutive pixels conflict-free in ds_read_b128's lane groups), the K loop is ds_read_b128 +
+// v_mfma_f32_16x16x32_bf16 only -- six of the nine plane products per 32 channels, smallest first, as in igemm_wsp3_kernel.
 #include "igemm_geom.h"
 
 namespace {
@@ -26,40 +31,55 @@ struct PatchEpi {            // the epilogue set of igemm_nt_kernel (all optiona
   int bwd_act;               // bn_mean == nullptr: activation-only backward, C = acc * act'(bn_y)
 };
 
-template <int H, int W, int CIN, int N, int TH>
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+
+template <int H, int W, int CIN, int N, int TH, bool P3>
 struct PatchCfg {
-  static constexpr int CP = CIN + 4, PW2 = W + 2, PH2 = TH + 2;       // padded channel stride: conflict-free 16-byte LDS reads
+  static constexpr int CP = CIN + 4, PW2 = W + 2, PH2 = TH + 2;       // fp32: padded channel stride, conflict-free 16-byte LDS reads
+  static constexpr int ROWB = P3 ? 6 * CIN : 4 * CIN;                  // bytes of one pixel / one weight row in HBM
+  static constexpr int PSB = P3 ? 6 * CIN + 32 : 4 * CP;               // ... and in LDS
+  static constexpr int PPP = ROWB / 16;                                 // 16-byte pieces of a row
   static constexpr int NT = N / 16, MT = TH * W / 16 / 8;              // n-tiles; m-tiles (16 pixels) per wave, 8 waves
   static constexpr int TILES = H / TH;                                  // row tiles per image
-  static constexpr int SLICE_V = N * CIN / 4;                           // 16-byte pieces of one weight slice
-  static constexpr size_t SMEM = ((size_t)PH2 * PW2 * CP + 2 * N * CP) * sizeof(float);
-  static_assert(H % TH == 0 && (TH * W) % 128 == 0 && (W & (W - 1)) == 0 && CIN % 16 == 0 && N % 16 == 0, "tile geometry");
-  static_assert(SLICE_V <= 512, "one 16-byte piece of a weight slice per thread");
+  static constexpr int SLICE_V = N * PPP;                               // 16-byte pieces of one weight slice
+  static constexpr int NWL = (SLICE_V + 511) / 512;                     // ... per thread
+  static constexpr size_t SMEM = (size_t)(PH2 * PW2 + 2 * N) * PSB;
+  static_assert(H % TH == 0 && (TH * W) % 128 == 0 && (W & (W - 1)) == 0 && W >= 16 && CIN % 32 == 0 && N % 16 == 0, "tile geometry");
+  static_assert(!P3 || (PSB / 32) % 2 == 1, "plane rows: a stride of 32 * odd bytes");
   static_assert(SMEM <= 160 * 1024, "LDS of one CU");
 };
 
-template <int H, int W, int CIN, int N, int TH>
-__global__ __launch_bounds__(512) void tconv_patch_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
+template <int H, int W, int CIN, int N, int TH, bool P3, bool BWD>
+__global__ __launch_bounds__(512) void tconv_patch_kernel(const void* __restrict__ X, const void* __restrict__ Wp,
                                                           float* __restrict__ Y, float* __restrict__ stats, int Bt, int Bg,
                                                           int ldc, const PatchEpi ep) {
-  using K = PatchCfg<H, W, CIN, N, TH>;
-  constexpr int CP = K::CP, PW2 = K::PW2, PH2 = K::PH2, NT = K::NT, MT = K::MT;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* patch = smem;                         // [TH+2][W+2][CIN+4]
-  float* Bs = smem + PH2 * PW2 * CP;           // [2][N][CIN+4]; reused as the statistics scratch at the end of a tile
+  using K = PatchCfg<H, W, CIN, N, TH, P3>;
+  constexpr int PW2 = K::PW2, PH2 = K::PH2, NT = K::NT, MT = K::MT, PSB = K::PSB, PPP = K::PPP, ROWB = K::ROWB, NWL = K::NWL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;                          // [TH+2][W+2] pixel rows of PSB bytes
+  char* Bs = smem + PH2 * PW2 * PSB;           // [2][N] weight rows of PSB bytes; reused as the statistics scratch at the end of a tile
+  const char* Xb = static_cast<const char*>(X);
+  const char* Wb = static_cast<const char*>(Wp);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   auto widx = [](int s) {                      // slice s = class*4 + tap -> kernel tap kh*4 + kw (igemm_nt.hip, TCONV_S2P1)
     const int ph = s >> 3, pw = (s >> 2) & 1, th = (s >> 1) & 1, tw = s & 1;
     return (1 - ph + 2 * th) * 4 + (1 - pw + 2 * tw);
   };
-  f32x4 rb[2];                                 // one 16-byte piece of a weight slice per thread, two slices in flight
-  auto bload = [&](int s, f32x4& dst) {
-    if (tid < K::SLICE_V) dst = *reinterpret_cast<const f32x4*>(Wp + (size_t)widx(s) * N * CIN + (size_t)tid * 4);
+  u32x4_t rb[4][NWL];                          // the 16-byte pieces of a weight slice this thread moves, four slices in flight
+  auto bload = [&](int s, u32x4_t (&dst)[NWL]) {
+#pragma unroll
+    for (int k = 0; k < NWL; ++k) {
+      const int i = tid + 512 * k;
+      if (i < K::SLICE_V) dst[k] = *reinterpret_cast<const u32x4_t*>(Wb + (size_t)widx(s) * N * ROWB + (size_t)i * 16);
+    }
   };
-  auto bstore = [&](int slot, const f32x4& src) {
-    const int e = tid * 4, n = e / CIN, c = e - n * CIN;
-    if (tid < K::SLICE_V) *reinterpret_cast<f32x4*>(Bs + ((size_t)slot * N + n) * CP + c) = src;
+  auto bstore = [&](int slot, const u32x4_t (&src)[NWL]) {
+#pragma unroll
+    for (int k = 0; k < NWL; ++k) {
+      const int i = tid + 512 * k, n = i / PPP, c = i - n * PPP;
+      if (i < K::SLICE_V) *reinterpret_cast<u32x4_t*>(Bs + ((size_t)slot * N + n) * PSB + c * 16) = src[k];
+    }
   };
   // pixel of (m-tile m of this wave, lane r) inside the tile
   int py_[MT], px_[MT];
@@ -69,40 +89,59 @@ __global__ __launch_bounds__(512) void tconv_patch_kernel(const float* __restric
     py_[m] = p / W;
     px_[m] = p % W;
   }
-  for (int u = blockIdx.x; u < Bt * K::TILES; u += gridDim.x) {
-    const int b = u / K::TILES, y0 = (u - b * K::TILES) * TH;          // image, first input row of the tile
-    __syncthreads();                           // the previous tile's LDS reads are done
-    // (all of a thread's patch loads are issued before its first LDS store: as a load -> store loop the ten round trips
-    //  were serial -- ~10 us of a block's ~70 at one block per CU)
-    constexpr int NPIECE = PH2 * PW2 * (CIN / 4), NLD = (NPIECE + 511) / 512;
-    f32x4 pv[NLD];
+  // The block is persistent: the patch of its NEXT tile is requested while the current one is multiplied (16-byte pieces parked in
+  // registers, zero-filled and stored into LDS once the current tile's last fragment read is behind a barrier), and the weight
+  // slices -- the same sixteen for every tile -- run four ahead of their use through a register ring, across tile boundaries.
+  constexpr int NPIECE = PH2 * PW2 * PPP, NLD = (NPIECE + 511) / 512;
+  const int total = Bt * K::TILES;
+  u32x4_t pv[NLD];
+  unsigned pok = 0;                            // bit k: piece k of this thread lies inside the image
+  auto pload = [&](int u) {
+    const int b = u / K::TILES, y0 = (u - b * K::TILES) * TH;
+    pok = 0;
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int i = tid + 512 * k;
-      const int c4 = i % (CIN / 4), p = i / (CIN / 4);
+      const int c = i % PPP, p = i / PPP;
       const int py = p / PW2, px = p - py * PW2;
       const int iy = y0 + py - 1, ix = px - 1;
       const bool ok = i < NPIECE && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      pok |= ok ? 1u << k : 0u;
       // (masked lanes read a valid dummy address: a predicated load would be sunk into its own branch)
-      const f32x4 r = __builtin_nontemporal_load(
-          reinterpret_cast<const f32x4*>(X + (ok ? (((size_t)b * H + iy) * W + ix) * CIN + c4 * 4 : (size_t)0)));
-      pv[k] = ok ? r : z;
+      pv[k] = __builtin_nontemporal_load(
+          reinterpret_cast<const u32x4_t*>(Xb + (ok ? (((size_t)b * H + iy) * W + ix) * ROWB + c * 16 : (size_t)0)));
     }
+  };
+  auto pstore = [&]() {
+    const u32x4_t z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int i = tid + 512 * k;
-      if (i < NPIECE) *reinterpret_cast<f32x4*>(patch + (size_t)(i / (CIN / 4)) * CP + (i % (CIN / 4)) * 4) = pv[k];
+      if (i < NPIECE) *reinterpret_cast<u32x4_t*>(patch + (size_t)(i / PPP) * PSB + (i % PPP) * 16) = ((pok >> k) & 1u) ? pv[k] : z;
     }
-    bload(0, rb[0]);
-    bload(1, rb[1]);
+  };
+  // (the backward-epilogue instances hold the saved pre-activations of a class in registers as well: they request their patch at
+  //  the tile's start instead -- with both parked the allocator spills ~100 registers)
+  constexpr bool PREF = !BWD;
+  if ((int)blockIdx.x < total) {
+    if constexpr (PREF) pload(blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bload(k, rb[k]);
+  }
+  for (int u = blockIdx.x; u < total; u += gridDim.x) {
+    const int b = u / K::TILES, y0 = (u - b * K::TILES) * TH;          // image, first input row of the tile
+    if constexpr (!PREF) pload(u);
+    __syncthreads();                           // the previous tile's LDS reads are done
+    pstore();
     bstore(0, rb[0]);
     __syncthreads();
+    if constexpr (PREF)
+      if (u + (int)gridDim.x < total) pload(u + gridDim.x);
     float colsum[NT], colsq[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) colsum[n] = colsq[n] = 0.f;
     const int grp_b = b / Bg;
-    const bool bnbwd = ep.bn_y != nullptr;
+    constexpr bool bnbwd = BWD;                // (the launch picks the instance: ep.bn_y != nullptr)
     float bn_m[NT], bn_r[NT], bn_g[NT], bn_b[NT], bias_v[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -123,8 +162,8 @@ __global__ __launch_bounds__(512) void tconv_patch_kernel(const float* __restric
         for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
       // backward epilogues: the saved pre-activation values of this class's outputs are requested NOW and land under the
       // MFMAs of the four taps (issued inside the epilogue they were 16 dependent round trips: 77 vs 50 us on 256 samples)
-      float yv[MT][4][NT];
-      if (bnbwd) {
+      float yv[BWD ? MT : 1][4][NT];
+      if constexpr (bnbwd) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -138,30 +177,59 @@ __global__ __launch_bounds__(512) void tconv_patch_kernel(const float* __restric
       }
 #pragma unroll
       for (int tap = 0; tap < 4; ++tap) {
-        const int s = cls * 4 + tap, slot = tap & 1;          // (s & 1 == tap & 1: register set and slot are compile-time)
-        if (s + 2 < 16) bload(s + 2, rb[tap & 1]);            // rb[tap & 1] held slice s, which is in LDS already
+        const int s = cls * 4 + tap, slot = tap & 1;          // (s & 3 == tap: register set and slot are compile-time)
+        bload((s + 4) & 15, rb[tap]);          // slice s is in LDS: its register set takes slice s + 4 (of the next tile past the 16th)
+        // slice s+1 (loaded three taps ago) goes into the other slot now -- last read in tap s-1, behind that tap's barrier -- so
+        // that its stores run under this tap's MFMAs; the barrier at the end of the tap publishes it
+        if (s + 1 < 16) bstore(slot ^ 1, rb[(tap + 1) & 3]);
         const int dh = ph - (tap >> 1), dw = pw - (tap & 1);
-        const float* bbase = Bs + (size_t)slot * N * CP + r * CP + q * 4;
+        if constexpr (P3) {
+          const char* bbase = Bs + ((size_t)slot * N + r) * PSB + q * 16;
+          const char* abase[MT];
 #pragma unroll
-        for (int c0 = 0; c0 < CIN; c0 += 16) {
-          f32x4 af[MT], bf[NT];
+          for (int m = 0; m < MT; ++m) abase[m] = patch + ((size_t)(py_[m] + dh + 1) * PW2 + (px_[m] + dw + 1)) * PSB + q * 16;
+          constexpr int order[6][2] = {{0, 2}, {2, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 0}};      // (plane of A, plane of B), smallest first
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            af[m] = *reinterpret_cast<const f32x4*>(patch + ((size_t)(py_[m] + dh + 1) * PW2 + (px_[m] + dw + 1)) * CP + c0 + q * 4);
+          for (int kk = 0; kk < CIN / 32; ++kk) {
+            // (one m-tile's fragments at a time: 9 fragments live instead of 18; every accumulator still takes its six products
+            //  in the same order)
+            bf16x8v bf[NT][3];
 #pragma unroll
-          for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const f32x4*>(bbase + (size_t)n * 16 * CP + c0);
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+              for (int p = 0; p < 3; ++p) bf[n][p] = *reinterpret_cast<const bf16x8v*>(bbase + (size_t)n * 16 * PSB + p * CIN * 2 + kk * 64);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              bf16x8v af[3];
+#pragma unroll
+              for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8v*>(abase[m] + p * CIN * 2 + kk * 64);
+#pragma unroll
+              for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[order[t][0]], bf[n][order[t][1]], acc[m][n], 0, 0, 0);
+            }
+          }
+        } else {
+          const float* bbase = reinterpret_cast<const float*>(Bs + ((size_t)slot * N + r) * PSB) + q * 4;
+#pragma unroll
+          for (int c0 = 0; c0 < CIN; c0 += 16) {
+            f32x4 af[MT], bf[NT];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
+              af[m] = *reinterpret_cast<const f32x4*>(patch + ((size_t)(py_[m] + dh + 1) * PW2 + (px_[m] + dw + 1)) * PSB + (c0 + q * 4) * 4);
 #pragma unroll
-              for (int n = 0; n < NT; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const f32x4*>(bbase + (size_t)n * 16 * (PSB / 4) + c0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
+          }
         }
-        if (s + 1 < 16) {
-          bstore(slot ^ 1, rb[(tap + 1) & 1]);                 // slice s+1, loaded during tap s-1; slot^1 was last read then
-          __syncthreads();
-        }
+        if (s + 1 < 16) __syncthreads();
       }
       // accumulator element e of tile (m, n): pixel 4q + e of the m-tile, channel n*16 + r
 #pragma unroll
@@ -174,7 +242,7 @@ __global__ __launch_bounds__(512) void tconv_patch_kernel(const float* __restric
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
             float v = acc[m][n][e];
-            if (bnbwd) {               // du = da * swish'(gamma * xhat + beta); the sums are those of the BatchNorm backward
+            if constexpr (bnbwd) {     // du = da * swish'(gamma * xhat + beta); the sums are those of the BatchNorm backward
               const float xh = (yv[m][e][n] - bn_m[n]) * bn_r[n];
               v *= act_grad(bn_g[n] * xh + bn_b[n], ep.bwd_act);
               colsum[n] += v;
@@ -193,7 +261,7 @@ __global__ __launch_bounds__(512) void tconv_patch_kernel(const float* __restric
     if (stats) {
       // per-tile column sums: over the four lane groups q (shuffles), then over the eight waves (LDS)
       __syncthreads();                         // every wave is past its last read of the weight ring
-      float* red = Bs;                         // [8][2][N]
+      float* red = reinterpret_cast<float*>(Bs);     // [8][2][N]
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         float s0 = colsum[n], s1 = colsq[n];
@@ -236,15 +304,54 @@ int patch_tiles(int mode, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
   return 0;
 }
 
-template <int H, int W, int CIN, int N, int TH>
-int patch_launch(const float* A, const float* Bp, float* C, float* stats, const IgemmGeom& g, const PatchEpi& ep, hipStream_t st) {
-  using K = PatchCfg<H, W, CIN, N, TH>;
-  static LdsOptIn lds_opt_in;                               // (~105 KB of the CU's 160 KB)
-  if (int e = lds_opt_in.ensure((const void*)tconv_patch_kernel<H, W, CIN, N, TH>, (int)K::SMEM)) return e;
+int patch_cus() {
+  static int cus[LdsOptIn::MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LdsOptIn::MAX_DEVICES) return 256;
+  if (!cus[dev]) {
+    hipDeviceProp_t p;
+    cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
+template <int H, int W, int CIN, int N, int TH, bool P3>
+int patch_launch(const void* A, const void* Bp, float* C, float* stats, const IgemmGeom& g, const PatchEpi& ep, hipStream_t st) {
+  using K = PatchCfg<H, W, CIN, N, TH, P3>;
+  static LdsOptIn lds_opt_in;                               // (~105 KB of the CU's 160 KB; plane rows: 148-158 KB)
+  static LdsOptIn lds_opt_in_bwd;
   const int Bt = g.G * g.Bg;
-  hipLaunchKernelGGL((tconv_patch_kernel<H, W, CIN, N, TH>), dim3(Bt * K::TILES), dim3(512), K::SMEM, st, A, Bp, C, stats, Bt, g.Bg,
-                     g.ldc, ep);
+  const int grid = Bt * K::TILES < patch_cus() ? Bt * K::TILES : patch_cus();      // one resident block per CU, persistent
+  if (ep.bn_y) {
+    if (int e = lds_opt_in_bwd.ensure((const void*)tconv_patch_kernel<H, W, CIN, N, TH, P3, true>, (int)K::SMEM)) return e;
+    hipLaunchKernelGGL((tconv_patch_kernel<H, W, CIN, N, TH, P3, true>), dim3(grid), dim3(512), K::SMEM, st, A, Bp, C, stats, Bt, g.Bg,
+                       g.ldc, ep);
+  } else {
+    if (int e = lds_opt_in.ensure((const void*)tconv_patch_kernel<H, W, CIN, N, TH, P3, false>, (int)K::SMEM)) return e;
+    hipLaunchKernelGGL((tconv_patch_kernel<H, W, CIN, N, TH, P3, false>), dim3(grid), dim3(512), K::SMEM, st, A, Bp, C, stats, Bt, g.Bg,
+                       g.ldc, ep);
+  }
   MMDYN_LAUNCH_CHECK();
+}
+
+template <bool P3>
+int patch_try(const void* A, const void* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws, const IgemmGeom& g,
+              hipStream_t st) {
+  if (!patch_tiles(g.mode, g.Hi, g.Wi, g.Cin, g.Ho, g.Wo, g.N)) return 1;
+  if (ws || g.splitk != 1) return MMDYN_ERR_SHAPE;          // (split-K is a DENSE-mode feature: the entry point has refused it)
+  if (g.bn_y && g.ldc != g.N) return MMDYN_ERR_SHAPE;
+  const PatchEpi ep{bias, C_act, g.act, g.bn_y, g.bn_mean, g.bn_rstd, g.bn_gamma, g.bn_beta, g.bwd_act};
+  if (g.Hi == 16) return patch_launch<16, 16, 64, 32, 16, P3>(A, Bp, C, stats, g, ep, st);
+  if (g.Hi == 32) return patch_launch<32, 32, 32, 32, 16, P3>(A, Bp, C, stats, g, ep, st);
+  return patch_launch<64, 64, 32, 32, 8, P3>(A, Bp, C, stats, g, ep, st);
+}
+
+bool patch_p3_enabled() {      // (LAB, MMDYN_TCONV_PATCH_P3=0: the 32-channel up-sampling layers keep fp32 operands in the fp32x3 mode)
+  static const bool off = [] {
+    const char* e = lab_env("MMDYN_TCONV_PATCH_P3");
+    return e && atoi(e) == 0;
+  }();
+  return !off;
 }
 
 }  // namespace
@@ -258,11 +365,15 @@ int mmdyn_tconv_patch_stat_tiles(int mode, int G, int Bg, int Hi, int Wi, int Ci
 // Returns MMDYN_OK / an error code, or 1 when the launch is not served (fp32 only: the caller has checked that).
 int mmdyn_tconv_patch_try(const float* A, const float* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
                           const IgemmGeom& g, hipStream_t st) {
-  if (!patch_tiles(g.mode, g.Hi, g.Wi, g.Cin, g.Ho, g.Wo, g.N)) return 1;
-  if (ws || g.splitk != 1) return MMDYN_ERR_SHAPE;          // (split-K is a DENSE-mode feature: the entry point has refused it)
-  if (g.bn_y && g.ldc != g.N) return MMDYN_ERR_SHAPE;
-  const PatchEpi ep{bias, C_act, g.act, g.bn_y, g.bn_mean, g.bn_rstd, g.bn_gamma, g.bn_beta, g.bwd_act};
-  if (g.Hi == 16) return patch_launch<16, 16, 64, 32, 16>(A, Bp, C, stats, g, ep, st);
-  if (g.Hi == 32) return patch_launch<32, 32, 32, 32, 16>(A, Bp, C, stats, g, ep, st);
-  return patch_launch<64, 64, 32, 32, 8>(A, Bp, C, stats, g, ep, st);
+  return patch_try<false>(A, Bp, bias, C, C_act, stats, ws, g, st);
+}
+
+// The same shapes on operands that arrive split (fp32x3, rows of [plane][Cin] bf16): same tile count, no workspace.
+bool mmdyn_tconv_patch_p3_serves(int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N) {
+  return patch_p3_enabled() && G > 0 && Bg > 0 && patch_tiles(mode, Hi, Wi, Cin, Ho, Wo, N) > 0;
+}
+int mmdyn_tconv_patch_p3_try(const void* A, const void* Bp, const float* bias, float* C, float* C_act, float* stats, float* ws,
+                             const IgemmGeom& g, hipStream_t st) {
+  if (!patch_p3_enabled()) return 1;
+  return patch_try<true>(A, Bp, bias, C, C_act, stats, ws, g, st);
 }

@@ -98,9 +98,15 @@ def _plane_twin(Wp):
     return ent[1]
 
 
+PATCH_PLANES = True      # (False: the 32-channel up-sampling layers keep fp32 operands -- A/B measurements only)
+
+
 def planes_served(mode, G, Bg, Hi, Cin, Ho, N):
-    """True when the fp32x3 launch of this shape takes its operands already split (plane-ring kernel, host-side query)."""
+    """True when the fp32x3 launch of this shape takes its operands already split (plane-ring kernel / the patch-resident kernel of
+    the 32-channel up-sampling layers, host-side query)."""
     served = getattr(ops.B, "igemm_planes_served", None) if PLANES else None
+    if N == 32 and not PATCH_PLANES:
+        return False
     return bool(served is not None and ACT_DTYPE == torch.float32 and served(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N))
 
 
@@ -507,9 +513,11 @@ def _alloc_packed(specs, like, w_dtype=None, pre=None):
 
 
 def wants_plane_twin(s):
-    """Conv-weight packs [16][N][Cin] whose launches the plane-ring kernel can serve (N % 64 == 0, Cin % 32 == 0) also get a
-    Planes twin from the plan in the fp32x3 arithmetic (whether a given batch's launch takes it: planes_served)."""
-    return s["kind"] >= K_KEEP and len(s["shape"]) == 3 and s["shape"][1] % 64 == 0 and s["shape"][2] % 32 == 0
+    """Conv-weight packs [16][N][Cin] whose launches a plane kernel can serve (N % 64 == 0: the plane-ring kernel; N == 32: the
+    patch-resident up-sampling kernel; Cin % 32 == 0) also get a Planes twin from the plan in the fp32x3 arithmetic (whether a
+    given batch's launch takes it: planes_served)."""
+    return (s["kind"] >= K_KEEP and len(s["shape"]) == 3 and (s["shape"][1] % 64 == 0 or s["shape"][1] == 32)
+            and s["shape"][2] % 32 == 0)
 
 
 def pack_now(specs, pre=None):
@@ -755,7 +763,8 @@ def encoder_trunk_backward_steps(P, c, dh, grads, dh_is_du=False):
     yield
     t = st[n - 2]
     dy = bn_swish_backward(da, t["y"], t["m"], t["r"], t["bn"], *bn_keys(t), G, Bg * t["Ho"] ** 2, t["cout"],
-                           planes_out=n >= 3 and planes_served(TCONV_S2P1, G, Bg, t["Ho"], t["cout"], t["Hi"], t["cin"]))
+                           planes_out=planes_served(TCONV_S2P1, G if n >= 3 else 1, Bg if n >= 3 else Bt, t["Ho"], t["cout"], t["Hi"],
+                                                    t["cin"]))
     wgrad(dy, t["a_in"], grads[f"conv_net.{t['i']}.weight"], CONV, Bt, t["Ho"], t["cout"], t["Hi"], t["cin"], 2, -1)
     yield
     for k in range(n - 3, -1, -1):
@@ -763,7 +772,8 @@ def encoder_trunk_backward_steps(P, c, dh, grads, dh_is_du=False):
         up, t = st[k + 1], st[k]
         dy = dgrad_bn_swish_backward(dy, pk[f"W{k + 3}s"], TCONV_S2P1, G, Bg, up["Ho"], up["cout"], up["Hi"], up["cin"], 1, 0,
                                      t["y"], t["m"], t["r"], t["bn"], *bn_keys(t),
-                                     planes_out=k > 0 and planes_served(TCONV_S2P1, G, Bg, t["Ho"], t["cout"], t["Hi"], t["cin"]))
+                                     planes_out=planes_served(TCONV_S2P1, G if k > 0 else 1, Bg if k > 0 else Bt, t["Ho"], t["cout"],
+                                                              t["Hi"], t["cin"]))
         wgrad(dy, t["a_in"], grads[f"conv_net.{t['i']}.weight"], CONV, Bt, t["Ho"], t["cout"], t["Hi"], t["cin"], 2, -1)
         if k > 0:
             yield

@@ -3,7 +3,8 @@
 (x3) what the product dispatch runs when the operands are fp32 -- the persistent kernel that splits its fragments in the MFMA
 waves' registers, or the register-staged split kernel -- against (p3) the plane-ring kernel on operands that ARRIVE split
 (igemm_wsp3_kernel), in the configurations named on the command line.  LAB build of the library (forces tiles / thresholds).
-usage: ab_p3.py [cfg ...]     cfg = "BM,BN,S" (forced through MMDYN_P3_TILE) or "rule" (the library's own pick; default)"""
+usage: ab_p3.py [patch] [cfg ...]     cfg = "BM,BN,S" (forced through MMDYN_P3_TILE) or "rule" (the library's own pick; default);
+"patch": the 32-channel up-sampling launches instead (tconv_patch_kernel on fp32 operands against its plane form)"""
 import os
 import statistics
 import sys
@@ -30,6 +31,15 @@ SHAPES = [
 ]
 
 
+PATCH_SHAPES = [
+    (2, 4, 256, 16, 64, 32, 32, 1, 0, "stats"),         # decoder layer 3 forward (64 -> 32 channels)
+    (2, 1, 256, 16, 64, 32, 32, 1, 0, "actbwd"),        # encoder conv2 input gradient
+    (2, 3, 128, 32, 32, 64, 32, 1, 0, "stats"),         # 128-pixel stacks: 32 -> 32 channels on 32x32 inputs
+    (2, 3, 128, 32, 32, 64, 32, 1, 0, "bnbwd"),
+    (2, 1, 64, 64, 32, 128, 32, 1, 0, "stats"),         # 256-pixel stacks: 32 -> 32 channels on 64x64 inputs
+]
+
+
 def event_ms(fn, reps):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -42,11 +52,15 @@ def event_ms(fn, reps):
 
 def main():
     dev = "cuda"
-    cfgs = [a for a in sys.argv[1:]] or ["rule"]
+    args = list(sys.argv[1:])
+    shapes = SHAPES
+    if args and args[0] == "patch":
+        shapes, args = PATCH_SHAPES, args[1:]
+    cfgs = args or ["rule"]
     os.environ["MMDYN_P3_MIN_UNITS"] = "1"
     os.environ["MMDYN_P3_N64"] = "1"
     tot = {}
-    for sh in SHAPES:
+    for sh in shapes:
         mode, G, Bg, Hi, Cin, Ho, N, stride, offset, kind = sh
         Bt = G * Bg
         A = torch.randn(Bt * Hi * Hi, Cin, device=dev)

@@ -539,6 +539,43 @@ def test_planes_input_gradient_with_the_epilogues(x3):
     assert relg(d1, d2) < 1.5e-6
 
 
+@pytest.mark.parametrize("G,Bg,Hi,Cin", [(4, 6, 16, 64), (2, 3, 32, 32), (1, 3, 64, 32)])
+def test_planes_patch_resident_up_sampling_layers(x3, G, Bg, Hi, Cin):
+    """ConvTranspose2d(Cin, 32, 4, 2, 1) on split operands (csrc/tconv_patch.hip, P3): the plain launch with its BatchNorm partial sums
+    against fp64 ATen and against the fp32-operand launch of the same kernel; the BatchNorm + Swish backward epilogue with its sums
+    and the activation-backward epilogue against the fp32-operand launches."""
+    N, B, Ho = 32, G * Bg, 2 * Hi
+    x, W = rnd(B, Cin, Hi, Hi, seed=50).to(DEV), rnd(Cin, N, 4, 4, seed=51, scale=0.1).to(DEV)
+    Ws, xr = layers.pack_conv(W, swap=True), nhwc_rows(x)
+    assert ops.B.igemm_planes_served(TCONV_S2P1, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
+    xp, wp = _planes(xr), _planes(Ws.view(-1, Cin))
+    y, st, T = layers.conv_like(xp, wp, TCONV_S2P1, G, Bg, Hi, Cin, Ho, N, stats=True)
+    ref = F.conv_transpose2d(x.double(), W.double(), stride=2, padding=1)
+    assert relg(from_rows(y, B, Ho, N), ref) < 2e-6
+    y2, st2, T2 = layers.conv_like(xr, Ws, TCONV_S2P1, G, Bg, Hi, Cin, Ho, N, stats=True)
+    assert T == T2 and relg(y, y2) < 1.5e-6
+    rr = ref.reshape(G, Bg, N, Ho * Ho).permute(0, 1, 3, 2).reshape(G, Bg * Ho * Ho, N)
+    sums = st.double().sum(1)
+    assert float((sums[:, 0] - rr.sum(1)).norm() / rr.abs().sum(1).norm()) < 1e-6 and relg(sums[:, 1], (rr * rr).sum(1)) < 1e-5
+    # the two backward epilogues (this launch as an input-gradient GEMM of a k4 s2 p1 convolution)
+    rows = B * Ho * Ho
+    u = rnd(rows, N, seed=52).to(DEV)
+    mean, rstd = rnd(G, N, seed=53).to(DEV), (rnd(G, N, seed=54).abs() + 0.5).to(DEV)
+    gamma, beta = (rnd(N, seed=55).abs() + 0.5).to(DEV), rnd(N, seed=56).to(DEV)
+
+    def run(a, b):
+        C, s = torch.empty(rows, N, device=DEV), torch.empty(G, T, 2, N, device=DEV)
+        ops.B.igemm_nt_dgrad_bn(a, b, C, s, u, mean, rstd, gamma, beta, TCONV_S2P1, G, Bg, Hi, Hi, Cin, Ho, Ho, N, 1, 0)
+        return C, s
+    (C, s), (C2, s2) = run(xp, wp), run(xr, Ws)
+    assert relg(C, C2) < 1.5e-6 and relg(s.double().sum(1), s2.double().sum(1)) < 1e-5
+    d1 = layers.dgrad_act(xp, wp, TCONV_S2P1, G, Bg, Hi, Cin, Ho, N, u, ops.ACT_SWISH)
+    d2 = layers.dgrad_act(xr, Ws, TCONV_S2P1, G, Bg, Hi, Cin, Ho, N, u, ops.ACT_SWISH)
+    assert relg(d1, d2) < 1.5e-6
+    sw = torch.sigmoid(u.double())
+    assert relg(d1, nhwc_rows(ref) * (sw * (1 + u.double() * (1 - sw)))) < 2e-6
+
+
 def test_planes_launch_is_refused_where_it_is_not_served(x3):
     A, Bp = rnd(4 * 64, 64, seed=40).to(DEV), rnd(16, 64, 64, seed=41).to(DEV)
     assert not ops.B.igemm_planes_served(CONV, 1, 4, 8, 8, 64, 4, 4, 64)
@@ -577,7 +614,7 @@ def test_pack_plan_writes_plane_twins(x3):
     W = {"hallucinate.0.weight": rnd(256, 128, 4, 4, seed=60, scale=0.1).to(DEV), "conv": rnd(128, 64, 4, 4, seed=61, scale=0.1).to(DEV)}
     specs = [layers._spec("W1s", W["hallucinate.0.weight"], layers.K_SWAP, 256, 128, 0, 0, (16, 128, 256)),
              layers._spec("W3k", W["conv"], layers.K_KEEP, 128, 64, 0, 0, (16, 128, 64)),
-             layers._spec("W9k", W["conv"][:32].contiguous(), layers.K_KEEP, 32, 64, 0, 0, (16, 32, 64))]      # (N = 32: no plane launch)
+             layers._spec("W9k", W["conv"][:16].contiguous(), layers.K_KEEP, 16, 64, 0, 0, (16, 16, 64))]      # (N = 16: no plane launch)
     plan = layers.PackPlan({"d": specs}, early=("W3k",), plane_twins=True)
     plan.run()
     pk = plan.packed["d"]
