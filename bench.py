@@ -513,7 +513,7 @@ def main():
         slabs runs the persistent fp32-operand kernel (igemm_wsp_kernel)."""
         from mmdyn_hip import ops as _ops
         lib = getattr(_ops.B, "lib", None)
-        n_all = n_p3 = n_wsp = 0
+        n_all = n_p3 = n_wsp = n_patch = 0
         fl_all = fl_p3 = 0.0
         for k, d in by_shape.items():
             if k[0] != "igemm_nt":
@@ -525,18 +525,23 @@ def main():
                 mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N = ints[:9]
                 if lib is None or ints[13] != 1:
                     continue
-                if dtype == "f32x3" and not args.no_planes and lib.mmdyn_igemm_planes_served(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) == 1:
-                    n_p3 += d["calls"]
+                planes_on = dtype == "f32x3" and not args.no_planes and not (N == 32 and args.no_patch_planes)
+                if planes_on and lib.mmdyn_igemm_planes_served(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N) == 1:
+                    if N == 32:          # the patch-resident kernel of the 32-channel up-sampling layers, plane form
+                        n_patch += d["calls"]
+                    else:
+                        n_p3 += d["calls"]
                     fl_p3 += d["flops"]
                 elif lib.mmdyn_igemm_slab_floats_mx(mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, 128 if dtype == "f32x3" else 0) > 0:
                     n_wsp += d["calls"]
             except Exception:
                 pass
         if dtype == "f32x3":
-            return (f"{n_all} calls: {n_p3} convolution-level launches ({100.0 * fl_p3 / max(fl_all, 1.0):.0f} % of the family's flops) on the "
-                    f"persistent plane-ring kernel igemm_wsp3_kernel + its stream-K fix-up launch, operands arriving split; {n_wsp} on the "
-                    f"persistent fp32-operand kernel igemm_wsp_kernel (split in the MFMA waves); the rest -- the 32-channel layer, FC-level "
-                    f"GEMMs -- on igemm_ws_kernel / igemm_nt_kernel / tconv_patch_kernel")
+            return (f"{n_all} calls, {n_p3 + n_patch} of them ({100.0 * fl_p3 / max(fl_all, 1.0):.0f} % of the family's flops) on operands that "
+                    f"arrive split: {n_p3} convolution-level launches on the persistent plane-ring kernel igemm_wsp3_kernel + its stream-K "
+                    f"fix-up launch, {n_patch} on the plane form of the patch-resident tconv_patch_kernel (32-channel up-sampling layers); "
+                    f"{n_wsp} on the persistent fp32-operand kernel igemm_wsp_kernel (split in the MFMA waves); the rest -- FC-level GEMMs "
+                    f"-- on igemm_ws_kernel / igemm_nt_kernel")
         return (f"{n_all} calls: {n_wsp} on the persistent stream-K ring kernel igemm_wsp_kernel + its fix-up launch, the rest on "
                 f"the one-tile ring kernel igemm_ws_kernel / the register-staged igemm_nt_kernel")
 
