@@ -62,10 +62,19 @@ __global__ __launch_bounds__(64 * (NLD + NMW)) void wgrad_p3_kernel(const bf16_t
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware block order (speed only, as wgrad_tn_kernel): workgroups are dealt round-robin over the 8 XCDs, each with its own L2.
+  // All blocks of one row chunk -- its channel tiles x tap groups, which re-read the same rows of D and Gt -- get linear ids that
+  // are equal modulo 8, so a chunk's rows pass through ONE L2 instead of up to eight.
   const int tiles_g = TAPS == 1 ? g.Cg / 128 : 1;
-  const int td = blockIdx.x / tiles_g, tg = blockIdx.x - td * tiles_g;
+  constexpr int NTG = 16 / TAPS;
+  const int per_chunk = (g.Cd / BD) * tiles_g * NTG;
+  // (chunk counts that are no multiple of 8 -- small launches -- keep the plain order: the fold would leave XCDs idle)
+  const int L = blockIdx.x, xcd = L & 7, jj = L >> 3;
+  const bool fold = (g.chunks & 7) == 0;
+  const int chunk = fold ? xcd + 8 * (jj / per_chunk) : L / per_chunk, inner = fold ? jj % per_chunk : L % per_chunk;
+  const int tgrp = inner % NTG, tile = inner / NTG;
+  const int td = tile / tiles_g, tg = tile - td * tiles_g;
   const int cd0 = td * BD, cg0 = TAPS == 1 ? tg * 128 : 0;
-  const int tgrp = blockIdx.y, chunk = blockIdx.z;
   const int kh = TAPS == 1 ? (tgrp >> 2) : (TAPS == 2 ? (tgrp >> 1) : tgrp);
   const int kw0 = TAPS == 1 ? (tgrp & 3) : (TAPS == 2 ? 2 * (tgrp & 1) : 0);
   const int row_begin = chunk * g.rows_per_chunk;
@@ -208,7 +217,7 @@ template <int BD, int TAPS, int CGB>
 static int p3_launch(const bf16_t* D, const bf16_t* Gt, float* partial, WgradGeom g, unsigned g_bytes, hipStream_t st) {
   g.rows_per_chunk = ceil_div(ceil_div(g.rows, g.chunks), RK) * RK;
   const int tiles = (g.Cd / BD) * (TAPS == 1 ? g.Cg / 128 : 1);
-  dim3 grid(tiles, 16 / TAPS, g.chunks);
+  dim3 grid(g.chunks * tiles * (16 / TAPS));             // (chunk, tile, tap group) folded XCD-aware: see the kernel
   const size_t smem = (size_t)S * 3 * (RK * BD * 2 + RK * 256);
   static LdsOptIn opt_in;
   if (int e = opt_in.ensure((const void*)wgrad_p3_kernel<BD, TAPS, CGB>, (int)smem)) return e;

@@ -48,7 +48,7 @@ elif [ "$part" = traffic ]; then
   key=$2; shift 2
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$key -- python3 $R/bench.py --no-alt --steps 2 --warmup 1 --no-graph --no-cpu-baseline "$@" > /dev/null 2> $O/pmc_fetch_$key.err
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$key -- python3 $R/bench.py --no-alt --steps 2 --warmup 1 --no-graph --no-cpu-baseline "$@" > /dev/null 2> $O/pmc_write_$key.err
-  python3 $R/tests/microbench/pmc_by_kernel.py $O/pmc_fetch_$key $O/pmc_write_$key 4 $O/hbm_traffic_by_kernel_$key.json > $O/hbm_traffic_by_kernel_$key.txt
+  python3 $R/tests/microbench/pmc_by_kernel.py $O/pmc_fetch_$key $O/pmc_write_$key 0 $O/hbm_traffic_by_kernel_$key.json > $O/hbm_traffic_by_kernel_$key.txt
   python3 $R/profiles/make_traffic_json.py $O/hbm_traffic_by_kernel_$key.json $O/traffic_$key.json $key "$@" > /dev/null
   rm -rf $O/pmc_fetch_$key $O/pmc_write_$key
   tail -1 $O/hbm_traffic_by_kernel_$key.txt

@@ -26,20 +26,21 @@ def sources_sha256():
 if __name__ == "__main__":
     d = json.load(open(sys.argv[1]))
     # (igemm_wsp_fixup_kernel is the second half of a persistent launch with split tiles: its bytes count, its launches do not)
-    fam = ("igemm_nt_kernel", "igemm_ws_kernel", "igemm_wsp_kernel", "igemm_wsp3_kernel", "igemm_wsp_fixup_kernel")
+    fam = ("igemm_nt_kernel", "igemm_ws_kernel", "igemm_wsp_kernel", "igemm_wsp3_kernel", "igemm_wsp_fixup_kernel", "tconv_patch_kernel")
     rows = [r for r in d["kernels"] if r["kernel"].startswith(fam)]
     launches = sum(r["launches_per_step"] for r in rows if not r["kernel"].startswith("igemm_wsp_fixup_kernel"))
     fetch = sum(r["fetch_MB_per_step"] for r in rows) * 1e6
     write = sum(r["write_MB_per_step"] for r in rows) * 1e6
     out = {
-        "source_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 "
-                       "--warmup 1 --no-graph --no-cpu-baseline <args>; FETCH_SIZE doubled (gfx950 correction, "
+        "source_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --no-alt --steps 2 "
+                       "--warmup 1 --no-graph --no-cpu-baseline <args> (five steps in the trace: the warm-up, the two timed ones, the two "
+                       "profiled passes; per-step figures = totals / the number of adam_kernel launches); FETCH_SIZE doubled (gfx950 correction, "
                        "MI355X_MICROARCH.md HBM section); KiB units; aggregated by tests/microbench/pmc_by_kernel.py "
                        "(profiles/collect_r5.sh traffic)",
         "workload": sys.argv[3],
         "bench_args": sys.argv[4:],
-        "kernel": "igemm_wsp3_kernel / igemm_wsp_kernel (+ their fix-up launch) + igemm_ws_kernel + igemm_nt_kernel (every implicit-GEMM launch of the step; the 3-channel layers run "
-                  "conv3_nt_kernel, the 64 -> 32 channel transposed convolution tconv_patch_kernel: not counted)",
+        "kernel": "igemm_wsp3_kernel / igemm_wsp_kernel (+ their fix-up launch) + tconv_patch_kernel + igemm_ws_kernel + igemm_nt_kernel (every "
+                  "launch behind the mmdyn_igemm_nt* entry points but the 3-channel layers, which run conv3_nt_kernel: not counted)",
         "sources_sha256": sources_sha256(),
         "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
         "launches_per_step": launches,

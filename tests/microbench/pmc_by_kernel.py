@@ -2,7 +2,7 @@
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, --kernel-trace only) per kernel:
 HBM-side megabytes per step next to the time each kernel took in the same runs.  FETCH_SIZE is doubled (gfx950
 reports half the bytes of wide streaming reads, MI355X_MICROARCH.md); both counters are in KiB.
-usage: pmc_by_kernel.py <fetch_dir> <write_dir> <steps_in_trace> [out.json]"""
+usage: pmc_by_kernel.py <fetch_dir> <write_dir> <steps_in_trace | 0 = the number of adam_kernel launches in the trace> [out.json]"""
 import collections
 import csv
 import glob
@@ -29,6 +29,8 @@ def load(d, counter):
 def main():
     fd, wd, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
     fe, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
+    if steps <= 0:          # one optimiser launch per step: warm-up, timed and profiled passes alike
+        steps = max(1, fe.get("adam_kernel", [0, 0, 0])[1])
     rows = []
     for k in sorted(set(fe) | set(wr)):
         f = fe.get(k, [0, 0, 0])
