@@ -66,7 +66,8 @@ __global__ __launch_bounds__(512) void tconv_patch_kernel(const void* __restrict
     const int ph = s >> 3, pw = (s >> 2) & 1, th = (s >> 1) & 1, tw = s & 1;
     return (1 - ph + 2 * th) * 4 + (1 - pw + 2 * tw);
   };
-  u32x4_t rb[4][NWL];                          // the 16-byte pieces of a weight slice this thread moves, four slices in flight
+  constexpr int RD = 4;                        // weight slices in flight
+  u32x4_t rb[RD][NWL];                         // the 16-byte pieces of a weight slice this thread moves
   auto bload = [&](int s, u32x4_t (&dst)[NWL]) {
 #pragma unroll
     for (int k = 0; k < NWL; ++k) {
@@ -96,47 +97,51 @@ __global__ __launch_bounds__(512) void tconv_patch_kernel(const void* __restrict
   const int total = Bt * K::TILES;
   u32x4_t pv[NLD];
   unsigned pok = 0;                            // bit k: piece k of this thread lies inside the image
-  auto pload = [&](int u) {
+  auto pload = [&](int u, int k0, int k1) {    // pieces k0 .. k1-1 of this thread (compile-time bounds at every call)
     const int b = u / K::TILES, y0 = (u - b * K::TILES) * TH;
-    pok = 0;
+    int t = tid;                               // (laundered: the per-piece index arithmetic is redone for every tile instead of being
+    asm volatile("" : "+v"(t));                //  hoisted out of the tile loop, where ~60 loop-invariant registers made the allocator spill)
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-      const int i = tid + 512 * k;
+      if (k < k0 || k >= k1) continue;
+      const int i = t + 512 * k;
       const int c = i % PPP, p = i / PPP;
       const int py = p / PW2, px = p - py * PW2;
       const int iy = y0 + py - 1, ix = px - 1;
       const bool ok = i < NPIECE && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      pok |= ok ? 1u << k : 0u;
+      pok = (pok & ~(1u << k)) | (ok ? 1u << k : 0u);
       // (masked lanes read a valid dummy address: a predicated load would be sunk into its own branch)
       pv[k] = __builtin_nontemporal_load(
           reinterpret_cast<const u32x4_t*>(Xb + (ok ? (((size_t)b * H + iy) * W + ix) * ROWB + c * 16 : (size_t)0)));
     }
   };
-  auto pstore = [&]() {
+  auto pstore = [&](int k0, int k1) {
     const u32x4_t z = {0u, 0u, 0u, 0u};
+    int t = tid;
+    asm volatile("" : "+v"(t));
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-      const int i = tid + 512 * k;
+      if (k < k0 || k >= k1) continue;
+      const int i = t + 512 * k;
       if (i < NPIECE) *reinterpret_cast<u32x4_t*>(patch + (size_t)(i / PPP) * PSB + (i % PPP) * 16) = ((pok >> k) & 1u) ? pv[k] : z;
     }
   };
-  // (the backward-epilogue instances hold the saved pre-activations of a class in registers as well: they request their patch at
-  //  the tile's start instead -- with both parked the allocator spills ~100 registers)
-  constexpr bool PREF = !BWD;
+  // (the backward-epilogue instances hold the saved pre-activations of a class in registers as well: they park half of a
+  //  thread's pieces and request the rest at the tile's start; no instance of this kernel uses scratch memory)
+  constexpr int NPRE = BWD ? NLD / 2 : NLD, NH = NLD;
   if ((int)blockIdx.x < total) {
-    if constexpr (PREF) pload(blockIdx.x);
+    pload(blockIdx.x, 0, NPRE);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bload(k, rb[k]);
+    for (int k = 0; k < RD; ++k) bload(k, rb[k]);
   }
   for (int u = blockIdx.x; u < total; u += gridDim.x) {
     const int b = u / K::TILES, y0 = (u - b * K::TILES) * TH;          // image, first input row of the tile
-    if constexpr (!PREF) pload(u);
+    pload(u, NPRE, NH);
     __syncthreads();                           // the previous tile's LDS reads are done
-    pstore();
+    pstore(0, NH);
     bstore(0, rb[0]);
     __syncthreads();
-    if constexpr (PREF)
-      if (u + (int)gridDim.x < total) pload(u + gridDim.x);
+    if (u + (int)gridDim.x < total) pload(u + gridDim.x, 0, NPRE);
     float colsum[NT], colsq[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) colsum[n] = colsq[n] = 0.f;
@@ -178,10 +183,11 @@ __global__ __launch_bounds__(512) void tconv_patch_kernel(const void* __restrict
 #pragma unroll
       for (int tap = 0; tap < 4; ++tap) {
         const int s = cls * 4 + tap, slot = tap & 1;          // (s & 3 == tap: register set and slot are compile-time)
-        bload((s + 4) & 15, rb[tap]);          // slice s is in LDS: its register set takes slice s + 4 (of the next tile past the 16th)
-        // slice s+1 (loaded three taps ago) goes into the other slot now -- last read in tap s-1, behind that tap's barrier -- so
-        // that its stores run under this tap's MFMAs; the barrier at the end of the tap publishes it
-        if (s + 1 < 16) bstore(slot ^ 1, rb[(tap + 1) & 3]);
+        // slice s+1 (loaded RD-1 taps ago) goes into the other slot now -- last read in tap s-1, behind that tap's barrier -- so
+        // that its stores run under this tap's MFMAs; the barrier at the end of the tap publishes it.  Slice s is in LDS: its
+        // register set takes slice s + RD (of the next tile past the sixteenth)
+        if (s + 1 < 16) bstore(slot ^ 1, rb[(tap + 1) % RD]);
+        bload((s + RD) & 15, rb[tap % RD]);
         const int dh = ph - (tap >> 1), dw = pw - (tap & 1);
         if constexpr (P3) {
           const char* bbase = Bs + ((size_t)slot * N + r) * PSB + q * 16;
