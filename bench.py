@@ -537,11 +537,11 @@ def main():
             except Exception:
                 pass
         if dtype == "f32x3":
-            return (f"{n_all} calls, {n_p3 + n_patch} of them ({100.0 * fl_p3 / max(fl_all, 1.0):.0f} % of the family's flops) on operands that "
-                    f"arrive split: {n_p3} convolution-level launches on the persistent plane-ring kernel igemm_wsp3_kernel + its stream-K "
-                    f"fix-up launch, {n_patch} on the plane form of the patch-resident tconv_patch_kernel (32-channel up-sampling layers); "
-                    f"{n_wsp} on the persistent fp32-operand kernel igemm_wsp_kernel (split in the MFMA waves); the rest -- FC-level GEMMs "
-                    f"-- on igemm_ws_kernel / igemm_nt_kernel")
+            return (f"{n_all} calls, {n_p3 + n_patch} of them ({100.0 * fl_p3 / max(fl_all, 1.0):.0f} % of the family's flops) convolution-level "
+                    f"launches on operands that arrive split, on the persistent plane-ring kernel igemm_wsp3_kernel + its stream-K fix-up "
+                    f"launch; {n_wsp} on the persistent fp32-operand kernel igemm_wsp_kernel (split in the MFMA waves); the rest -- FC-level "
+                    f"GEMMs -- on igemm_ws_kernel / igemm_nt_kernel.  Booked apart, as in rounds 3-4: the 3-channel layers (conv3.hip) and "
+                    f"the 32-channel up-sampling layers (tconv_patch_kernel, in its plane form)")
         return (f"{n_all} calls: {n_wsp} on the persistent stream-K ring kernel igemm_wsp_kernel + its fix-up launch, the rest on "
                 f"the one-tile ring kernel igemm_ws_kernel / the register-staged igemm_nt_kernel")
 

@@ -26,7 +26,7 @@ def sources_sha256():
 if __name__ == "__main__":
     d = json.load(open(sys.argv[1]))
     # (igemm_wsp_fixup_kernel is the second half of a persistent launch with split tiles: its bytes count, its launches do not)
-    fam = ("igemm_nt_kernel", "igemm_ws_kernel", "igemm_wsp_kernel", "igemm_wsp3_kernel", "igemm_wsp_fixup_kernel", "tconv_patch_kernel")
+    fam = ("igemm_nt_kernel", "igemm_ws_kernel", "igemm_wsp_kernel", "igemm_wsp3_kernel", "igemm_wsp_fixup_kernel")
     rows = [r for r in d["kernels"] if r["kernel"].startswith(fam)]
     launches = sum(r["launches_per_step"] for r in rows if not r["kernel"].startswith("igemm_wsp_fixup_kernel"))
     fetch = sum(r["fetch_MB_per_step"] for r in rows) * 1e6
@@ -39,8 +39,8 @@ if __name__ == "__main__":
                        "(profiles/collect_r5.sh traffic)",
         "workload": sys.argv[3],
         "bench_args": sys.argv[4:],
-        "kernel": "igemm_wsp3_kernel / igemm_wsp_kernel (+ their fix-up launch) + tconv_patch_kernel + igemm_ws_kernel + igemm_nt_kernel (every "
-                  "launch behind the mmdyn_igemm_nt* entry points but the 3-channel layers, which run conv3_nt_kernel: not counted)",
+        "kernel": "igemm_wsp3_kernel / igemm_wsp_kernel (+ their fix-up launch) + igemm_ws_kernel + igemm_nt_kernel (every implicit-GEMM launch of the step; the 3-channel layers run "
+                  "conv3_nt_kernel, the 32-channel up-sampling layers tconv_patch_kernel: booked apart, as in bench.py's launch count)",
         "sources_sha256": sources_sha256(),
         "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
         "launches_per_step": launches,
