@@ -79,3 +79,34 @@ def test_split_arithmetic_host_queries_without_a_gpu():
     assert lib.mmdyn_igemm_slab_floats_mx(TCONV_S2P1, 4, 256, 8, 8, 128, 16, 16, 64, 128) == 0
     # too small for the split's launch rule: the plain answer
     assert lib.mmdyn_igemm_stat_tiles_mx(DENSE, 1, 256, 1, 1, 512, 1, 1, 512, 128) == lib.mmdyn_igemm_stat_tiles(DENSE, 1, 256, 1, 1, 512, 1, 1, 512)
+
+
+def test_plane_operand_host_queries_without_a_gpu():
+    """Round 5: operands that arrive split (flag bits 7 + 8 / 9).  Host arithmetic only: which launches a plane kernel serves, the
+    partial-sum tile count and slab workspace of such a launch, the cut of the plane weight gradient, the ABI version."""
+    lib = _lib.load()
+    CONV, TCONV_S2P1, TCONV_S1P0, DENSE = 1, 2, 4, 0
+    assert lib.mmdyn_abi_version() == _lib.ABI_VERSION == 5
+    # convolution-level launches of the bs-256 step: N % 128 == 0 and N == 64 on the plane-ring kernel, the one-group k4 s1 p0 launch too
+    assert lib.mmdyn_igemm_planes_served(CONV, 4, 256, 16, 16, 64, 8, 8, 128) == 1
+    assert lib.mmdyn_igemm_planes_served(CONV, 4, 256, 32, 32, 32, 16, 16, 64) == 1
+    assert lib.mmdyn_igemm_planes_served(TCONV_S1P0, 1, 256, 5, 5, 256, 8, 8, 128) == 1
+    # the 32-channel up-sampling layers: the patch-resident kernel's plane form, at any batch size; one partial-sum tile per image
+    assert lib.mmdyn_igemm_planes_served(TCONV_S2P1, 4, 2, 16, 16, 64, 32, 32, 32) == 1
+    assert lib.mmdyn_igemm_stat_tiles_mx(TCONV_S2P1, 4, 256, 16, 16, 64, 32, 32, 32, 384) == 256
+    assert lib.mmdyn_igemm_slab_floats_mx(TCONV_S2P1, 4, 256, 16, 16, 64, 32, 32, 32, 384) == 0
+    # not served: FC-level GEMMs, too little work, channel counts the ring's 32-channel K-step does not divide
+    assert lib.mmdyn_igemm_planes_served(DENSE, 1, 1024, 1, 1, 512, 1, 1, 512) == 0
+    assert lib.mmdyn_igemm_planes_served(CONV, 1, 4, 8, 8, 64, 4, 4, 64) == 0
+    assert lib.mmdyn_igemm_planes_served(CONV, 4, 256, 16, 16, 48, 8, 8, 128) == 0
+    # a served plane launch writes one partial-sum tile per wave row of its 128-row tiles; the k4 s1 p0 layer's stream-K cut always
+    # splits tiles and so wants slabs
+    T = lib.mmdyn_igemm_stat_tiles_mx(CONV, 4, 256, 16, 16, 64, 8, 8, 128, 384)
+    assert T == 2 * (256 * 64 // 128)
+    assert lib.mmdyn_igemm_slab_floats_mx(TCONV_S1P0, 4, 256, 5, 5, 256, 8, 8, 128, 384) > 0
+    # weight gradient with both operands split: ~256 blocks (one per CU), a multiple of four slabs; one operand split keeps the
+    # register-staged kernels' cut
+    assert lib.mmdyn_wgrad_chunks_mx(CONV, 1024 * 25, 256, 128, 128 | 256 | 512) == 8
+    assert lib.mmdyn_wgrad_chunks_mx(CONV, 1024 * 64, 128, 64, 128 | 256 | 512) == 32
+    assert lib.mmdyn_wgrad_chunks_mx(CONV, 1024 * 256, 64, 32, 128 | 256 | 512) == 64
+    assert lib.mmdyn_wgrad_chunks_mx(CONV, 1024 * 25, 256, 128, 128 | 256) == lib.mmdyn_wgrad_chunks_mx(CONV, 1024 * 25, 256, 128, 128)
