@@ -174,7 +174,9 @@ class _Lanes:
     def __init__(self, device, enabled=True):
         self.on = enabled and device.type == "cuda"
         if device.type == "cuda":        # (the graph path replays its lane graphs on these even when eager launches stay on one stream)
-            self.side = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+            # (LAB, MMDYN_LANE_PRIO=<p>: the two lanes as priority-p streams -- -1 = high -- next to default-priority weight-gradient streams)
+            prio = int(os.environ.get("MMDYN_LANE_PRIO", "0"))
+            self.side = [torch.cuda.Stream(device=device, priority=prio), torch.cuda.Stream(device=device, priority=prio)]
 
     def fork(self):
         if self.on:
@@ -927,7 +929,8 @@ class MVAEStep:
             # (two streams; ONE stream for both decoders' queues measured the same step: 5.28-5.30 against 5.25-5.29 ms -- the
             #  stage is bound by the chip's throughput, not by how its five streams are packed; GPU_MAX_HW_QUEUES=8 instead of the
             #  default 4 measured 6.3-6.4 ms: profiles/r5/stage_timeline_and_streams.txt)
-            self._wstreams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            wprio = int(os.environ.get("MMDYN_WGRAD_PRIO", "0"))
+            self._wstreams = [torch.cuda.Stream(priority=wprio), torch.cuda.Stream(priority=wprio)]
         cap_stream = {"main": torch.cuda.Stream(), "l0": LN.side[0], "l1": LN.side[1], "w0": self._wstreams[0], "w1": self._wstreams[1]}
         pools = {k: torch.cuda.graph_pool_handle() for k in cap_stream}
         self._capturing = True
@@ -967,7 +970,13 @@ class MVAEStep:
         #  the encoder backward -- measured WORSE, same box, alternating: 5.33 / 5.25 / 5.28 ms against 5.14 / 5.12 / 5.10 ms
         #  (tests/microbench/run_ab_wgrad_fork.sh): the full-chip weight-gradient kernels slow the other decoder's dependent chain by
         #  more than they fill of its gaps)
-        early = self.defer_wgrad and os.environ.get("MMDYN_WGRAD_FORK", "enc") == "dec"
+        fork = os.environ.get("MMDYN_WGRAD_FORK", "main")
+        early = self.defer_wgrad and fork == "dec"
+        # Default ("main"): the two deferred queues are replayed on the MAIN stream behind its own (short) work of the encoder-backward
+        # row -- three streams in all.  Two more streams for them ("enc", rounds 3-4) measured 1.3 % slower on the same box, alternating:
+        # 4.98 / 5.03 / 5.00 ms against 4.95 / 4.92 / 4.94 (profiles/r5/step_ab_wgrad_fork.txt); the step's five streams then shared four
+        # hardware queues, and every other queue count or stream priority measured 4-40 % worse (stage_timeline_and_streams.txt).
+        on_main = self.defer_wgrad and fork == "main"
         for ri, row in enumerate(captured):
             if ri == self.DEC_STAGE + 1 and not self.defer_wgrad:
                 handles += self._reduce_bucket(0)          # decoders done: reduce them under the encoder backward
@@ -988,8 +997,8 @@ class MVAEStep:
                 continue
             ev = main.record_event()
             for lane, g in row:
-                if lane.startswith("w") and early:
-                    continue                               # launched behind its decoder lane, two rows up
+                if lane.startswith("w") and (early or on_main):
+                    continue                               # launched behind its decoder lane, two rows up / on the main stream below
                 if lane != "main":
                     side[lane].wait_event(ev)
                     with torch.cuda.stream(side[lane]):
@@ -1005,8 +1014,12 @@ class MVAEStep:
             for lane, g in row:
                 if lane == "main":
                     g.replay()
+            if on_main:
+                for lane, g in row:
+                    if lane.startswith("w"):
+                        g.replay()
             for lane, g in row:
-                if lane.startswith("w"):
+                if lane.startswith("w") and not on_main:
                     loose.append(lane)                     # joined in front of the optimiser, not at the end of this row
                 elif lane != "main":
                     main.wait_event(side[lane].record_event())

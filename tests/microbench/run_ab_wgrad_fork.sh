@@ -4,7 +4,7 @@
 out=${1:-gpurun_out/ab_fork}
 mkdir -p $out
 for r in 1 2 3; do
-  for v in dec enc; do
+  for v in ${FORKS:-dec enc}; do
     MMDYN_WGRAD_FORK=$v python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-alt 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],3), 'ms', round(d['value']), 'samples/s')"
   done
 done | tee $out/step_ab.txt
