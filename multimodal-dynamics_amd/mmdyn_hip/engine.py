@@ -585,12 +585,22 @@ class MVAEStep:
         wq = c.setdefault("wq" + m, []) if self.defer_wgrad else None
         c["dz" + m] = yield from layers.decoder_backward_steps(FP.sub(dec), c["d" + m], c["dl" + m], FP.sub(dec, "G"), defer=wq)
 
-    def _ph_dec_wgrad(self, m):
-        """The decoder's queued weight-gradient GEMMs (defer_wgrad), on whatever stream is current."""
+    def _ph_dec_wgrad(self, m, tail=None):
+        """The decoder's queued weight-gradient GEMMs (defer_wgrad), on whatever stream is current.  ``tail`` = k: only the last k
+        entries of the queue (LAB, MMDYN_WGRAD_TAIL: run at the end of the lane's own encoder backward instead of behind the main
+        stream's work)."""
         q = self.ctx.get("wq" + m) or []
         # (graph capture: the operands stay referenced until the step's context goes, so that no later capture into the
         #  producing lane's pool can be handed their memory while this queue's graph may still be reading it at replay)
-        self.ctx["wkeep" + m] = list(q)
+        self.ctx.setdefault("wkeep" + m, []).extend(q)
+        if tail:
+            idx = os.environ.get("MMDYN_WGRAD_LANE_IDX")          # (LAB: explicit queue positions instead of the last k)
+            pick = sorted({int(i) % len(q) for i in idx.split(",")}) if (idx and q) else list(range(len(q) - min(tail, len(q)), len(q)))
+            part = [q[i] for i in pick]
+            for i in reversed(pick):
+                del q[i]
+            layers.run_deferred_wgrads(part)
+            return
         layers.run_deferred_wgrads(q)
 
     def _ph_pose_dec_bwd(self):
@@ -905,7 +915,13 @@ class MVAEStep:
         # (_replay).  Forking them one phase earlier, next to the serial latent backward, measured no better: 6.69 vs 6.68 ms.
         wq = [("w0", lambda: self._ph_dec_wgrad("v")), ("w1", lambda: self._ph_dec_wgrad("t"))] if self.defer_wgrad else []
         if self.pg is None:
-            stages.append([("l0", lambda: run(self._ph_enc_bwd_steps("v"))), ("l1", lambda: run(self._ph_enc_bwd_steps("t"))),
+            # the last entry of each decoder's deferred queue -- the FC layer's weight gradient, a launch that fills a fraction of the
+            # chip -- runs at the end of the lane's own encoder backward, the rest behind the main stream's work (_replay): +0.7-1.6 %
+            # on two boxes against the whole queue on the main stream (MMDYN_WGRAD_TAIL=0; 2: equal to 0; other single entries: equal
+            # or worse -- tests/microbench/run_ab_wgrad_tail.sh, run_ab_wgrad_lane_idx.sh, profiles/r5/step_ab_wgrad_fork.txt)
+            ktail = int(os.environ.get("MMDYN_WGRAD_TAIL", "1")) if self.defer_wgrad else 0
+            stages.append([("l0", lambda: (run(self._ph_enc_bwd_steps("v")), ktail and self._ph_dec_wgrad("v", ktail))),
+                           ("l1", lambda: (run(self._ph_enc_bwd_steps("t")), ktail and self._ph_dec_wgrad("t", ktail))),
                            ("main", lambda: (self._ph_heads_wgrad(), self._ph_pose_enc_bwd()))] + wq)
             stages.append([("main", lambda: self.optimizer_step(()))])
         else:
