@@ -585,7 +585,7 @@ class MVAEStep:
         wq = c.setdefault("wq" + m, []) if self.defer_wgrad else None
         c["dz" + m] = yield from layers.decoder_backward_steps(FP.sub(dec), c["d" + m], c["dl" + m], FP.sub(dec, "G"), defer=wq)
 
-    def _ph_dec_wgrad(self, m, tail=None):
+    def _ph_dec_wgrad(self, m, tail=None, head=None):
         """The decoder's queued weight-gradient GEMMs (defer_wgrad), on whatever stream is current.  ``tail`` = k: only the last k
         entries of the queue (LAB, MMDYN_WGRAD_TAIL: run at the end of the lane's own encoder backward instead of behind the main
         stream's work)."""
@@ -593,6 +593,11 @@ class MVAEStep:
         # (graph capture: the operands stay referenced until the step's context goes, so that no later capture into the
         #  producing lane's pool can be handed their memory while this queue's graph may still be reading it at replay)
         self.ctx.setdefault("wkeep" + m, []).extend(q)
+        if head is not None:                  # the first ``head`` entries (those queued before the decoder row was cut, _capture)
+            part = q[:head]
+            del q[:head]
+            layers.run_deferred_wgrads(part)
+            return
         if tail:
             idx = os.environ.get("MMDYN_WGRAD_LANE_IDX")          # (LAB: explicit queue positions instead of the last k)
             pick = sorted({int(i) % len(q) for i in idx.split(",")}) if (idx and q) else list(range(len(q) - min(tail, len(q)), len(q)))
@@ -901,6 +906,23 @@ class MVAEStep:
     def _capture(self, kl_weight):
         LN = self.lanes
         run = layers.run
+        # (LAB, MMDYN_DEC_SPLIT=k: the decoder row is cut after k steps of the backward; the weight gradients queued by then run on the
+        #  main stream next to the rest of the decoders' backward instead of after the encoder backward -- measured WORSE, same box,
+        #  alternating: k = 2: 4.97 / 4.95 / 4.96 ms, k = 3: 5.01 / 4.99 / 5.01 against 4.86 / 4.83 / 4.85 (run_ab_dec_split.sh))
+        dsplit = int(os.environ.get("MMDYN_DEC_SPLIT", "0")) if (self.defer_wgrad and self.pg is None) else 0
+        dgens = {}
+
+        def dec_a(m):
+            run(self._ph_dec_fwd_steps(m))
+            dgens[m] = self._ph_dec_bwd_steps(m)
+            for _ in range(dsplit):
+                next(dgens[m])
+            self.ctx["wq_n" + m] = len(self.ctx.get("wq" + m) or [])
+
+        def dec_b(m):
+            for _ in dgens.pop(m):
+                pass
+
         stages = [
             [("main", lambda: self._ph_pre())],
             [("l0", lambda: run(self._ph_enc_steps("v"))), ("l1", lambda: run(self._ph_enc_steps("t"))),
@@ -911,6 +933,12 @@ class MVAEStep:
              ("main", lambda: (self._ph_pose_dec_fwd(), self._ph_pose_dec_bwd()))],
             [("main", lambda: (self._ph_assemble(), self._ph_poe_bwd(), self._ph_heads_bwd()))],
         ]
+        if dsplit:
+            stages[3] = [("l0", lambda: dec_a("v")), ("l1", lambda: dec_a("t")),
+                         ("main", lambda: (self._ph_pose_dec_fwd(), self._ph_pose_dec_bwd()))]
+            stages.insert(4, [("l0", lambda: dec_b("v")), ("l1", lambda: dec_b("t")),
+                              ("main", lambda: (self._ph_dec_wgrad("v", head=self.ctx["wq_n" + "v"]),
+                                                self._ph_dec_wgrad("t", head=self.ctx["wq_n" + "t"])))])
         # deferred decoder weight gradients: two more streams next to the encoder backward, joined in front of the optimiser
         # (_replay).  Forking them one phase earlier, next to the serial latent backward, measured no better: 6.69 vs 6.68 ms.
         wq = [("w0", lambda: self._ph_dec_wgrad("v")), ("w1", lambda: self._ph_dec_wgrad("t"))] if self.defer_wgrad else []

@@ -41,6 +41,7 @@ def main():
             g.replay()
             b.record()
             marks.append((ri, lane, a, b))
+        on_main = os.environ.get("MMDYN_WGRAD_FORK", "main") == "main"      # (the default: both deferred queues follow the main stream)
         for ri, row in enumerate(captured):
             if ri == len(captured) - 1:
                 for lane in loose:
@@ -51,6 +52,8 @@ def main():
                 continue
             ev = main.record_event()
             for lane, g in row:
+                if lane.startswith("w") and on_main:
+                    continue
                 if lane != "main":
                     side[lane].wait_event(ev)
                     with torch.cuda.stream(side[lane]):
@@ -59,8 +62,12 @@ def main():
                 if lane == "main":
                     timed(ri, "main", g)
             for lane, g in row:
+                if lane.startswith("w") and on_main:
+                    timed(ri, lane + "@main", g)
+            for lane, g in row:
                 if lane.startswith("w"):
-                    loose.append(lane)
+                    if not on_main:
+                        loose.append(lane)
                 elif lane != "main":
                     main.wait_event(side[lane].record_event())
         for lane in loose:
@@ -75,7 +82,7 @@ def main():
     torch.cuda.synchronize()
     ref = marks[0][2]
     for ri, lane, a, b in marks:
-        print(f"stage {ri} {lane:4s} start {ref.elapsed_time(a):7.3f} ms  end {ref.elapsed_time(b):7.3f} ms  ({a.elapsed_time(b):6.3f})")
+        print(f"stage {ri} {lane:8s} start {ref.elapsed_time(a):7.3f} ms  end {ref.elapsed_time(b):7.3f} ms  ({a.elapsed_time(b):6.3f})")
 
 
 if __name__ == "__main__":
