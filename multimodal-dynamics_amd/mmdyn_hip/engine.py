@@ -1055,10 +1055,15 @@ class MVAEStep:
                         side[wl].wait_event(side[lane].record_event())
                         with torch.cuda.stream(side[wl]):
                             wg.replay()
+            wfirst = on_main and os.environ.get("MMDYN_WGRAD_FIRST") == "1"     # (LAB: the deferred queues in FRONT of the main stream's own work)
+            if wfirst:
+                for lane, g in row:
+                    if lane.startswith("w"):
+                        g.replay()
             for lane, g in row:
                 if lane == "main":
                     g.replay()
-            if on_main:
+            if on_main and not wfirst:
                 for lane, g in row:
                     if lane.startswith("w"):
                         g.replay()
