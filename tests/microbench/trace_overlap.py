@@ -21,8 +21,20 @@ def main():
     if len(adam_ends) < skip + 3:
         print("not enough steps in trace", len(adam_ends))
         return
-    t0, t1 = adam_ends[skip], adam_ends[-2]          # (the last step of bench.py is its eager single-lane profiling step)
-    nsteps = len(adam_ends) - 2 - skip
+    # the window: the longest run of consecutive steps whose length is within 1.25x of the median step (bench.py's timed graph
+    # replays; the eager profiling passes at the end of the run and the steps around a synchronisation fall outside)
+    gaps = [adam_ends[i + 1] - adam_ends[i] for i in range(skip, len(adam_ends) - 1)]
+    med = sorted(gaps)[len(gaps) // 2]
+    best, cur = (0, 0), None
+    for i, gp in enumerate(gaps + [10 ** 18]):
+        if gp <= 1.25 * med:
+            cur = i if cur is None else cur
+        else:
+            if cur is not None and i - cur > best[1] - best[0]:
+                best = (cur, i)
+            cur = None
+    t0, t1 = adam_ends[skip + best[0]], adam_ends[skip + best[1]]
+    nsteps = best[1] - best[0]
     win = [(max(s, t0), min(e, t1), n) for s, e, n in ev if e > t0 and s < t1]
     is_mfma = lambda n: (("igemm_" in n and "fixup" not in n) or "wgrad_tn" in n or "wgrad_b16" in n or "wgrad_p3" in n
                          or "conv3_" in n or "tconv_patch" in n)
