@@ -948,9 +948,14 @@ class MVAEStep:
             # on two boxes against the whole queue on the main stream (MMDYN_WGRAD_TAIL=0; 2: equal to 0; other single entries: equal
             # or worse -- tests/microbench/run_ab_wgrad_tail.sh, run_ab_wgrad_lane_idx.sh, profiles/r5/step_ab_wgrad_fork.txt)
             ktail = int(os.environ.get("MMDYN_WGRAD_TAIL", "1")) if self.defer_wgrad else 0
-            stages.append([("l0", lambda: (run(self._ph_enc_bwd_steps("v")), ktail and self._ph_dec_wgrad("v", ktail))),
-                           ("l1", lambda: (run(self._ph_enc_bwd_steps("t")), ktail and self._ph_dec_wgrad("t", ktail))),
-                           ("main", lambda: (self._ph_heads_wgrad(), self._ph_pose_enc_bwd()))] + wq)
+            # (LAB, MMDYN_POSE_BWD_LANE=0|1: the pose encoder's backward at the end of that lane's graph instead of on the main stream --
+            #  measured worse, same box, alternating: 4.69 / 4.68 / 4.70 ms against 4.64 / 4.65 / 4.65: run_ab_pose_bwd_lane.sh)
+            pl = os.environ.get("MMDYN_POSE_BWD_LANE", "") if self.defer_wgrad else ""
+            stages.append([("l0", lambda: (run(self._ph_enc_bwd_steps("v")), ktail and self._ph_dec_wgrad("v", ktail),
+                                           pl == "0" and self._ph_pose_enc_bwd())),
+                           ("l1", lambda: (run(self._ph_enc_bwd_steps("t")), ktail and self._ph_dec_wgrad("t", ktail),
+                                           pl == "1" and self._ph_pose_enc_bwd())),
+                           ("main", lambda: (self._ph_heads_wgrad(), pl not in ("0", "1") and self._ph_pose_enc_bwd()))] + wq)
             stages.append([("main", lambda: self.optimizer_step(()))])
         else:
             # data parallel: the encoder backward is cut after the heads + FC layer (gradient bucket 1: 31 MB of the 37 MB
