@@ -256,8 +256,8 @@ class MVAEStep:
         # skipped, counted in ``skipped_steps``, and leaves parameters and moments as they were.
         self._scale_per_sample = 4.0 if precision in ("fp16", "fp16s") else 0.0
         # The decoders' weight-gradient GEMMs (nothing on the backward chain reads them) are queued during the decoder
-        # backward and run on two more streams next to the encoder backward: the replayed step then has four chains in
-        # flight instead of two.  None: the measured rule (tests/microbench/run_ab_defer_wgrad.sh, same box, alternating runs:
+        # backward and replayed as two more graphs during the encoder backward -- on the main stream since round 5 (_replay; rounds
+        # 3-4: on two more streams).  None: the measured rule (tests/microbench/run_ab_defer_wgrad.sh, same box, alternating runs:
         # fp32 bs 256 +0.3 .. 0.9 % over three boxes, 128x128 fp32 7.0 -> 6.85 ms (+2 %), 256x256 fp32 +0.5 .. 5 %; the 16-bit
         # storage modes 0 .. -2 %) -- on in fp32 on one GPU.
         # Data parallel: off, the decoders' gradient bucket would start its all-reduce a phase later.
@@ -939,8 +939,8 @@ class MVAEStep:
             stages.insert(4, [("l0", lambda: dec_b("v")), ("l1", lambda: dec_b("t")),
                               ("main", lambda: (self._ph_dec_wgrad("v", head=self.ctx["wq_n" + "v"]),
                                                 self._ph_dec_wgrad("t", head=self.ctx["wq_n" + "t"])))])
-        # deferred decoder weight gradients: two more streams next to the encoder backward, joined in front of the optimiser
-        # (_replay).  Forking them one phase earlier, next to the serial latent backward, measured no better: 6.69 vs 6.68 ms.
+        # deferred decoder weight gradients: two more graphs of the encoder-backward row, captured on streams of their own and replayed
+        # where _replay puts them.  Forking them one phase earlier, next to the serial latent backward, measured no better: 6.69 vs 6.68 ms.
         wq = [("w0", lambda: self._ph_dec_wgrad("v")), ("w1", lambda: self._ph_dec_wgrad("t"))] if self.defer_wgrad else []
         if self.pg is None:
             # the last entry of each decoder's deferred queue -- the FC layer's weight gradient, a launch that fills a fraction of the
@@ -975,9 +975,9 @@ class MVAEStep:
                            ("main", lambda: (self._ph_heads_wgrad(), self._ph_pose_enc_bwd()))] + wq)
             stages.append([("l0", lambda: tail("v")), ("l1", lambda: tail("t"))])
         if getattr(self, "_wstreams", None) is None:
-            # (two streams; ONE stream for both decoders' queues measured the same step: 5.28-5.30 against 5.25-5.29 ms -- the
-            #  stage is bound by the chip's throughput, not by how its five streams are packed; GPU_MAX_HW_QUEUES=8 instead of the
-            #  default 4 measured 6.3-6.4 ms: profiles/r5/stage_timeline_and_streams.txt)
+            # (the capture streams of the two queues, and their replay streams with MMDYN_WGRAD_FORK=enc|dec; ONE stream for both
+            #  queues measured the same step as two, 5.28-5.30 against 5.25-5.29 ms; GPU_MAX_HW_QUEUES other than the default 4 cost
+            #  4-25 %: profiles/r5/stage_timeline_and_streams.txt)
             wprio = int(os.environ.get("MMDYN_WGRAD_PRIO", "0"))
             self._wstreams = [torch.cuda.Stream(priority=wprio), torch.cuda.Stream(priority=wprio)]
         cap_stream = {"main": torch.cuda.Stream(), "l0": LN.side[0], "l1": LN.side[1], "w0": self._wstreams[0], "w1": self._wstreams[1]}
