@@ -444,13 +444,16 @@ int mmdyn_resize_u8_to_chw_f32(const uint8_t* src, const int* index, float* dst,
  *       Bits 7 + 8 (flags == 384; mmdyn_igemm_nt_mx, mmdyn_igemm_nt_dgrad_act; mmdyn_igemm_nt_dgrad_bn(bf16 = 4)): the same
  *       arithmetic on operands that ARRIVE SPLIT -- A and Bp are rows of [plane][Cin] bf16 (hi | mid | lo, 6 bytes per element:
  *       mmdyn_split_planes, or written so by their producers) -- so the GEMM itself contains no split: LDS-DMA of the planes, six
- *       v_mfma_f32_16x16x32_bf16 per fragment pair (csrc/igemm_wsp.hip, igemm_wsp3_kernel).  Same terms, same product order per
+ *       v_mfma_f32_16x16x32_bf16 per fragment pair (csrc/igemm_wsp.hip, igemm_wsp3_kernel; the 32-channel up-sampling layers:
+ *       csrc/tconv_patch.hip, tconv_patch_kernel<..., P3>).  Same terms, same product order per
  *       K-step as the flags == 128 launch of the shape (results agree to the last bits; the channel -> k-lane map inside the 32-deep
  *       MFMA differs, so not bit for bit).  Only for shapes mmdyn_igemm_planes_served answers 1 for
  *       (MMDYN_ERR_SHAPE otherwise); partial-sum tile count and workspace: the *_stat_tiles_mx / *_slab_floats_mx queries with flags == 384.
  *   mmdyn_wgrad_tn_mx : bit 0 as above, bit 1 D is 16-bit, bit 2 Gt is 16-bit (not IM2COL3), bit 5 as above, bit 7 alone as above;
  *       with bit 7, bit 8: D arrives split, bit 9: Gt arrives split (plane tensors, rows of [plane][C] bf16; MMDYN_CONV only) -- that
- *       operand goes from HBM to the LDS planes as it is, the other is split in the kernel as with bit 7 alone.
+ *       operand goes from HBM to the LDS planes as it is, the other is split in the kernel as with bit 7 alone; both bits: the
+ *       plane-ring weight-gradient kernel where it serves the channel counts (csrc/wgrad_p3.hip; chunks from mmdyn_wgrad_chunks_mx
+ *       with the same flags).
  *   *_b16             : the element-wise kernels on 16-bit activation tensors (half = 0: bf16, half = 1: IEEE half). */
 int mmdyn_igemm_nt_mx(const void* A, const void* Bp, const float* bias, void* C, void* C_act, float* stats,
                       float* ws, const void* y, const float* mean, const float* rstd, const float* gamma,
