@@ -576,6 +576,28 @@ def test_planes_patch_resident_up_sampling_layers(x3, G, Bg, Hi, Cin):
     assert relg(d1, nhwc_rows(ref) * (sw * (1 + u.double() * (1 - sw)))) < 2e-6
 
 
+@pytest.mark.parametrize("mode,G,Bg,Hi,Cin,Ho,N", [(CONV, 4, 75, 16, 64, 8, 128), (CONV, 1, 301, 16, 64, 8, 128), (TCONV_S2P1, 2, 77, 8, 128, 16, 64),
+                                                   (TCONV_S2P1, 1, 301, 8, 128, 16, 64)])
+def test_planes_ragged_row_counts(x3, mode, G, Bg, Hi, Cin, Ho, N):
+    """Plane launches whose rows per group are no multiple of the 128-row tile (the last tile of every group is part empty, the
+    stream-K cut falls inside tiles): result and BatchNorm partial sums against fp64 ATen, group by group."""
+    B = G * Bg
+    assert (Bg * (Ho if mode == CONV else Hi) ** 2) % 128 != 0 and ops.B.igemm_planes_served(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
+    x = rnd(B, Cin, Hi, Hi, seed=80).to(DEV)
+    if mode == CONV:
+        W = rnd(N, Cin, 4, 4, seed=81, scale=0.1).to(DEV)
+        Wp, ref = layers.pack_conv(W, swap=False), F.conv2d(x.double(), W.double(), stride=2, padding=1)
+        y, st, T = layers.conv_like(_planes(nhwc_rows(x)), _planes(Wp.view(-1, Cin)), CONV, G, Bg, Hi, Cin, Ho, N, 2, -1, stats=True)
+    else:
+        W = rnd(Cin, N, 4, 4, seed=81, scale=0.1).to(DEV)
+        Wp, ref = layers.pack_conv(W, swap=True), F.conv_transpose2d(x.double(), W.double(), stride=2, padding=1)
+        y, st, T = layers.conv_like(_planes(nhwc_rows(x)), _planes(Wp.view(-1, Cin)), TCONV_S2P1, G, Bg, Hi, Cin, Ho, N, stats=True)
+    assert relg(from_rows(y, B, Ho, N), ref) < 2e-6
+    rr = ref.reshape(G, Bg, N, Ho * Ho).permute(0, 1, 3, 2).reshape(G, Bg * Ho * Ho, N)
+    sums = st.double().sum(1)
+    assert float((sums[:, 0] - rr.sum(1)).norm() / rr.abs().sum(1).norm()) < 1e-6 and relg(sums[:, 1], (rr * rr).sum(1)) < 1e-5
+
+
 def test_planes_launch_is_refused_where_it_is_not_served(x3):
     A, Bp = rnd(4 * 64, 64, seed=40).to(DEV), rnd(16, 64, 64, seed=41).to(DEV)
     assert not ops.B.igemm_planes_served(CONV, 1, 4, 8, 8, 64, 4, 4, 64)
