@@ -539,11 +539,13 @@ def test_planes_input_gradient_with_the_epilogues(x3):
     assert relg(d1, d2) < 1.5e-6
 
 
-@pytest.mark.parametrize("G,Bg,Hi,Cin", [(4, 6, 16, 64), (2, 3, 32, 32), (1, 3, 64, 32)])
+@pytest.mark.parametrize("G,Bg,Hi,Cin", [(4, 6, 16, 64), (2, 3, 32, 32), (1, 3, 64, 32), (2, 301, 16, 64), (1, 150, 32, 32)])
 def test_planes_patch_resident_up_sampling_layers(x3, G, Bg, Hi, Cin):
     """ConvTranspose2d(Cin, 32, 4, 2, 1) on split operands (csrc/tconv_patch.hip, P3): the plain launch with its BatchNorm partial sums
     against fp64 ATen and against the fp32-operand launch of the same kernel; the BatchNorm + Swish backward epilogue with its sums
-    and the activation-backward epilogue against the fp32-operand launches."""
+    and the activation-backward epilogue against the fp32-operand launches.  (The last two cases have more tiles than the chip has
+    CUs: every persistent block walks several tiles -- the next tile's patch parked in registers, the weight ring across the
+    tile boundary -- and the last round of blocks is ragged.)"""
     N, B, Ho = 32, G * Bg, 2 * Hi
     x, W = rnd(B, Cin, Hi, Hi, seed=50).to(DEV), rnd(Cin, N, 4, 4, seed=51, scale=0.1).to(DEV)
     Ws, xr = layers.pack_conv(W, swap=True), nhwc_rows(x)
