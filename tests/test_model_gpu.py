@@ -218,6 +218,43 @@ def test_fused_engine_vs_oracle(B, n_steps, precision):
         opt.step()
 
 
+@pytest.mark.parametrize("variant", ["no_pose", "conditional", "mask_loss"])
+def test_fp32x3_plane_operands_in_the_engine_variants(variant):
+    """The engine variants the oracle test above does not build -- no pose term, --conditional, --mask-loss -- at a batch where the
+    plane kernels serve the convolution-level launches (B = 96): the fp32x3 step against the native fp32 step on the same weights,
+    inputs and injected noise.  Both are fp32-grade arithmetics of the same computation: loss within 2e-6 relative, every gradient
+    within 2e-4 relative L2 (rounding-level differences through BatchNorm's 1/sigma and the knife edges of ReLU / dropout masks)."""
+    B, klw = 96, 0.05
+    use_pose = variant == "conditional"            # (--mask-loss is defined for models without the pose term: problems.py:445-447)
+    results = []
+    for precision in ("fp32", "fp32x3"):
+        kw = dict(T.MODEL_KW, use_pose=use_pose)
+        if variant == "conditional":
+            kw.update(conditional=True, condition_dim=3)
+        m = T.setup_model("cnn-mvae", cross_modal=True, **kw)
+        m.load_state_dict(seeded_state_dict(m.state_dict(), 0))
+        m.to(DEV).train()
+        eps, masks = seeded_noise(B, 256, 7, 8, 4321)
+        step = MVAEStep(m, noise=InjectedNoise(eps, masks), precision=precision)
+        inputs, targets = seeded_batch(B, 99, with_pose=use_pose)
+        gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+        extra = {}
+        if variant == "conditional":
+            extra["condition"] = torch.linspace(-1, 1, B * 3).view(B, 3).to(DEV)
+        if variant == "mask_loss":
+            g = torch.Generator().manual_seed(5)
+            extra["loss_mask"] = (torch.rand(B, 1, 64, 64, generator=g) > 0.3).float().to(DEV)
+        loss = float(step.forward(gi, gt, klw, **extra))
+        step.backward()
+        results.append((loss, {k: v.grad.double().cpu().clone() for k, v in m.named_parameters()}))
+    (l0, g0), (l1, g1) = results
+    assert l1 == pytest.approx(l0, rel=2e-6)
+    for k in g0:
+        assert float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-30)) < 2e-4, k
+    from mmdyn_hip import ops
+    assert ops.B.lib.mmdyn_igemm_planes_served(ops.CONV, 2, B, 16, 16, 64, 8, 8, 128) == 1     # (the decoders' launches took plane operands)
+
+
 def test_bf16_engine_vs_oracle():
     """BASELINE configs[2] arithmetic (bf16 matrix-core operands, fp32 accumulate / storage / master weights) against
     the fp32 CPU oracle, B=32, injected noise.  Stated tolerance for this mode: ELBO and each partial within 5e-3
