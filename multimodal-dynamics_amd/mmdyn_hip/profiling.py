@@ -9,6 +9,7 @@ import torch
 
 from . import ops
 
+PAD_CYCLES = 100000       # torch.cuda._sleep argument: ~43 us on an MI355X
 HOST_ONLY = {"igemm_stat_tiles", "colstats_tiles", "wgrad_chunks", "igemm_planes_served"}
 
 
@@ -106,6 +107,11 @@ class TimedBackend:
 
         def wrapped(*a, **k):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # A ~40 us spin kernel (one wave, no memory traffic) in front of the start event: the GPU reaches the event only after the
+            # host has queued the launch and the end event behind it, so the bracket holds the kernel(s) of the call and not the host's
+            # launch latency -- which an eager pass otherwise books on every kernel shorter than it (the FC-level GEMMs read 33-36 us by
+            # events against 13-22 us in the rocprofv3 trace of the same run).
+            torch.cuda._sleep(PAD_CYCLES)
             s.record()
             r = fn(*a, **k)
             e.record()
