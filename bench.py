@@ -98,7 +98,7 @@ def pmc_traffic(workload_key):
     the sha-256 of the kernel sources it was taken on, and the values are reported as None (plus the reason) when the
     sources have changed since.  Returns (dict | None, note)."""
     d = None
-    for rnd in ("r5", "r4", "r3"):                # the latest round's collection first
+    for rnd in ("r6", "r5", "r4", "r3"):          # the latest round's collection first
         rel = ("profiles", rnd, f"traffic_{workload_key}.json")
         try:
             d = json.load(open(os.path.join(ROOT, *rel)))
@@ -106,7 +106,7 @@ def pmc_traffic(workload_key):
         except (OSError, ValueError):
             continue
     if d is None:
-        return None, {"stale": f"no PMC profile committed for this workload (profiles/r5|r4|r3/traffic_{workload_key}.json)"}
+        return None, {"stale": f"no PMC profile committed for this workload (profiles/r6|r5|r4|r3/traffic_{workload_key}.json)"}
     note = {"profile": "/".join(rel), "collected": d.get("collected"), "sources_sha256": d.get("sources_sha256")}
     if d.get("sources_sha256") and d["sources_sha256"] == sources_sha256():
         return d, note
@@ -498,6 +498,10 @@ def main():
               "step_hbm_bytes": step_bytes, "step_hbm_frac_of_8TBps": step_hbm_frac,
               "step_launches": prof["whole_step"]["launches"] if prof else None,
               "step_bound": bound_of(step_mfma_frac, step_hbm_frac)}
+        # what the measured arithmetic adds around the family and is booked under its own name: stand-alone operand splits
+        rl["split_planes_ms_per_step"] = kern.get("split_planes", {"ms": 0.0})["ms"]
+        rl["bound_note"] = ("label only: `traffic` / `step_hbm_bytes` are the COMMITTED rocprofv3 PMC profile of these kernel sources "
+                            "(traffic_provenance; possibly another box), divided by THIS run's event times -- boxes differ by up to 6 %")
         if dtype == "f32x3":
             rl["peak_note"] = ("dense bf16 MFMA peak / 6: every fp32 product is six bf16 products of the exact three-term split "
                                "(MI355X_MICROARCH.md: ~2.5 PF dense at the 2.4 GHz the chip does not hold on random data -- bf16 loops "
@@ -579,6 +583,10 @@ def main():
         "value": sps, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        # the arithmetic `value` was measured in, at the top level: BENCH_r01..r04 are native-fp32 lines and compare
+        # with `native_fp32.value` of this line, BENCH_r05 onwards (f32x3) with `value`
+        "arithmetic": arith,
+        "compare_with": {"BENCH_r01..r04 (dtype f32)": "native_fp32.value", "BENCH_r05.. (dtype f32x3)": "value"},
         "config": {"workload": workload,
                    "global_batch": global_batch, "parallelism": f"dp{world}", "bn": "sync" if (args.sync_bn and pg is not None) else "local",
                    "launch": "eager" if (args.no_graph or (args.sync_bn and pg is not None and dry)) else "hip_graph",

@@ -51,10 +51,11 @@ extern "C" {
 const char* mmdyn_version(void);
 /* ABI revision of this header.  It changes whenever an exported signature or a workspace requirement changes (round 4 added
  * the `ws` argument of mmdyn_igemm_nt_dgrad_act / _dgrad_bn and the slab workspace of large launches: revision 4; round 5 the
- * plane-packed weight kinds of the pack plan: revision 5).  A binding checks mmdyn_abi_version() == MMDYN_ABI_VERSION right after
+ * plane-packed weight kinds of the pack plan: revision 5; round 6 the `zdst` field of mmdyn_pass_experts, the arrival-flag words in
+ * front of the slab workspace (mmdyn_igemm_slab_floats*) and new entry points: revision 6).  A binding checks mmdyn_abi_version() == MMDYN_ABI_VERSION right after
  * loading the library (mmdyn_hip/_lib.py does) so that a caller built against an older header fails at load time instead of
  * passing its stream handle where the library now expects a workspace pointer. */
-#define MMDYN_ABI_VERSION 5
+#define MMDYN_ABI_VERSION 6
 int mmdyn_abi_version(void);
 
 /* ---- MFMA implicit GEMM, "NT" form ---------------------------------------------------------
@@ -235,6 +236,18 @@ int mmdyn_tconv_out3_fwd(const float* a, const float* w, float* out, int Bt, int
  * the input tile is staged, the activated tensor never exists in HBM. */
 int mmdyn_tconv_out3_bn_fwd(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                             const float* w, float* out, int G, int Bg, int Hi, int Wi, int b16, void* stream);
+/* ... and with the reconstruction term of the ELBO in its epilogue (round 6): F.binary_cross_entropy_with_logits(recon, target,
+ * reduction='sum') of problems.py:433-437 (with `mask`, [Bg][mask_channels][2Hi][2Wi], mask_channels 1 or 3: torch.mul of logits and
+ * target with the loss mask first, problems.py:445-447; `unmasked_slots`, may be null, then also gets the plain sums) for the G
+ * groups of the batch against ONE target [Bg][3][2Hi][2Wi]: loss_slots[slot_of_group[g]] += sum over group g (slot < 0: a discarded
+ * pass -- zero gradient, no loss); dlogit [G*Bg][3][2Hi][2Wi] (null in evaluation) = (sigmoid(logit) - target) * grad_scale, the
+ * gradient the backward of the layer consumes.  The logits themselves are written only for group `logits_group` (`logits`
+ * [Bg][3][2Hi][2Wi]; -1: for all groups, [G*Bg]...; `logits` null: for none) -- the reconstruction the caller publishes
+ * (problems.py:537-545).  Element arithmetic identical to mmdyn_bce_logits_groups. */
+int mmdyn_tconv_out3_bn_bce(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            const float* w, float* logits, int logits_group, const float* target, const float* mask,
+                            int mask_channels, float* dlogit, double* loss_slots, double* unmasked_slots,
+                            const int* slot_of_group, float grad_scale, int G, int Bg, int Hi, int Wi, int b16, void* stream);
 
 /* ---- train-mode BatchNorm2d + Swish, channels-last, per group (vae.py:201-208, 269-276) ----- */
 /* column sums of y and y*y over row chunks -> partial[G][T][2][C], T = mmdyn_colstats_tiles(rows_per_group) */
@@ -314,6 +327,11 @@ int mmdyn_scale_dev(const float* x, const float* s, float* out, int64_t n, void*
  * widen it back behind it.  src / dst 16-byte (fp32 side) and 8-byte (bf16 side) aligned. */
 int mmdyn_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mmdyn_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* n <= MMDYN_COPY_MANY_MAX device-to-device copies (src[i] -> dst[i], bytes[i] bytes; host arrays of device pointers) as ONE
+ * launch: a batch (inputs + targets of problems.py:148-156) moved into the static buffers of a captured step.  Segments must not
+ * overlap.  (The reference hands its batch to the model by reference; there is no counterpart call.) */
+#define MMDYN_COPY_MANY_MAX 8
+int mmdyn_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int n, void* stream);
 /* sum of P row blocks: out[b][:] = sum_p x[p][b][:] */
 int mmdyn_sum_blocks(const float* x, float* out, int P, int64_t n, void* stream);
 /* tiny Linear layers of the 7-DoF pose MLP (K or N == 7; vae.py:117-123): y = x W^T + b */
@@ -333,6 +351,10 @@ typedef struct {
   int ld[MMDYN_MAX_EXPERTS];            /* row stride of the expert tensors (heads are stored fused: [rows][2L]) */
   const float* dz[3];                   /* backward only: up to three [B][L] latent gradients of this pass (one per
                                            decoder that consumed z), summed by the kernel; null = none */
+  float* zdst[3];                       /* forward only (revision 6): up to three further [B][L] destinations of this pass's z --
+                                           its row block in the stacked input of each decoder that consumes it (the
+                                           torch.cat of the subset passes, problems.py:478-529, without a copy launch);
+                                           null = none */
 } mmdyn_pass_experts;
 /* P passes of [B][L].  with_prior=1 adds the universal N(0,1) expert first (vae.py:139, 321-328).
  * Outputs mu/logvar [P][B][L]; optional z = eps*exp(logvar/2)+mu; optional kl_sum[p] (double)
@@ -374,6 +396,10 @@ int mmdyn_bce_logits_groups_masked(const float* logits, const float* target, con
 /* sum (r-t)^2 added to *loss_sum; dr = 2 (r-t) grad_scale */
 int mmdyn_mse(const float* r, const float* t, float* dr, double* loss_sum, int64_t n, float grad_scale,
               void* stream);
+/* The same for G passes against ONE target (F.mse_loss of the pose term, problems.py:439-443, for every pose-bearing subset of
+ * the multi-subset ELBO): r / dr [G][n], t [n], loss_slots[slot_of_group[g]] += the sum of pass g.  One launch. */
+int mmdyn_mse_groups(const float* r, const float* t, float* dr, double* loss_slots, const int* slot_of_group, int G, int64_t n,
+                     float grad_scale, void* stream);
 /* loss[0] = (sum_p bce[p] + pose_multiplier * mse[p] + kl_weight * kl[p]) / B; partial[p] likewise.
  * kl_weight_dev (here and in mmdyn_poe_bwd; may be null): one float in device memory that multiplies kl_weight /
  * kl_scale -- the annealed KL weight of problems.py:212-216 kept on the device, so that a captured launch serves every
@@ -436,7 +462,8 @@ int mmdyn_resize_u8_to_chw_f32(const uint8_t* src, const int* index, float* dst,
  *       csrc/igemm_nt.hip / wgrad_tn.hip X3; profiles/r4/ab_x3_*.txt).  The library decides per launch (shapes with >= 512 blocks
  *       of 64x64 or >= 384 of 128x128 outputs; every weight-gradient GEMM); the rest of such a step runs the fp32 matrix cores.
  *       Operand range (tests/test_kernels_aten_gpu.py::test_x3_operand_magnitudes_*, ::test_x3_non_finite_*): full fp32 accuracy
- *       for 2^-100 <= |x| <= FLT_MAX.  Below, the lower terms of the split leave bf16's normal range and are flushed by the matrix
+ *       for 2^-100 <= |x| < 0x1.ffp+127 (bit pattern 0x7F7F8000, ~3.39e38: from there to FLT_MAX bf16's round-to-nearest takes the
+ *       high term to Inf and the split gives NaN, like an Inf operand).  Below 2^-100 the lower terms of the split leave bf16's normal range and are flushed by the matrix
  *       pipe: an operand under ~1e-33 keeps 16 significant bits, one under ~3e-36 keeps 8 -- an absolute error of at most
  *       2^-126 |w| per product.  An Inf operand gives NaN (inf - inf in the split) where the fp32 matrix cores would give Inf; a
  *       NaN operand gives NaN; no other row of the result is touched.  The library does not guard: non-finite operands do not occur

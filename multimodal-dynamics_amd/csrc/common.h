@@ -295,6 +295,20 @@ __device__ __forceinline__ float act_grad(float x, int act) {
   return 1.f;
 }
 
+// One element of BCE-with-logits (torch.nn.functional.binary_cross_entropy_with_logits, problems.py:421-428) and its
+// derivative from ONE exponential: e = exp(-|x|) in (0, 1]; loss = max(x, 0) - x t + log(1 + e); sigmoid(x) = 1 / (1 + e) for
+// x >= 0 and e / (1 + e) below.  Hardware exp / log / reciprocal (v_exp_f32, v_log_f32, v_rcp_f32: ~1 ulp on these ranges; log
+// of 1 + e loses at most 6e-8 absolute, against terms of 0.3-0.7): the library log1pf + two expf + a division made this
+// 113 MB pass VALU-bound at 2.1 TB/s.
+__device__ __forceinline__ void bce_elem(float x, float t, float& loss, float& sig) {
+  const float e = __expf(-fabsf(x));
+  const float inv = __frcp_rn(__fadd_rn(1.f, e));
+  // (explicitly rounded products and sums: every kernel that inlines this evaluates the same expression tree, whatever
+  //  contraction the compiler would pick around it)
+  loss = __fadd_rn(__fsub_rn(fmaxf(x, 0.f), __fmul_rn(x, t)), __logf(__fadd_rn(1.f, e)));
+  sig = x >= 0.f ? inv : __fmul_rn(e, inv);
+}
+
 // conv3.hip: direct kernels for the 3-channel k4 s2 p1 layers (MMDYN_IM2COL3 geometry).  Return MMDYN_OK / an error
 // code, or 1 when the shape is not theirs (the caller then takes the generic tiled kernel).
 int mmdyn_conv3_nt_try(const float* A, const float* Bp, const float* bias, void* C, void* C_act, float* stats, int G,

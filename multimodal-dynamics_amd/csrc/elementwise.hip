@@ -198,6 +198,76 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
   colsum_final_channel(partial, out, chunks, C, perm, beta, c);
 }
 
+// Single-launch form for the row counts of the FC level (rows <= COLSUM_DIRECT_ROWS: bias gradients of the Linear layers,
+// vae.py:211-222, 264-265): a block owns 32 channels and ALL rows -- 32 row lanes x 8 float4 columns, 4 rows in flight per thread,
+// shuffle + 512 bytes of LDS -- so there is no partial table and no second launch (round 6: 20 -> 10 launches per step).
+constexpr int COLSUM_DIRECT_ROWS = 4096;
+__global__ __launch_bounds__(256) void colsum_direct_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int C,
+                                                            int perm, float beta) {
+  __shared__ f32x4 red[4][8];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c4 = blockIdx.x * 8 + cl;                      // float4 column
+  const int CV = C >> 2;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < CV) {
+    for (int r = rl; r < rows; r += 128) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + 32 * u;
+        v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(rr < rows ? rr : r) * C + c4 * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + 32 * u < rows) s += v[u];
+    }
+  }
+#pragma unroll
+  for (int m = 8; m < 64; m <<= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] += __shfl_xor(s[k], m, 64);         // the 8 row lanes of a wave
+  if ((threadIdx.x & 63) < 8) red[threadIdx.x >> 6][cl] = s;
+  __syncthreads();
+  if (threadIdx.x < 8 && c4 < CV) {
+    f32x4 t = red[0][cl];
+#pragma unroll
+    for (int l = 1; l < 4; ++l) t += red[l][cl];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c4 * 4 + k;
+      int o = c;
+      if (perm == 2) {
+        const int hw = c / 256, ch = c - hw * 256;
+        o = ch * 25 + hw;
+      }
+      out[o] = (beta != 0.f ? beta * out[o] : 0.f) + t[k];
+    }
+  }
+}
+
+// Up to MMDYN_COPY_MANY_MAX device-to-device copies as ONE launch: the batch of a replayed step (visual / tactile / pose inputs and
+// their targets, problems.py:148-156) moves into the captured step's static buffers with one kernel instead of one runtime copy
+// per tensor.  blockIdx.y = segment; 16-byte lanes where both ends are 16-byte aligned, bytes otherwise.
+struct CopyMany {
+  const char* src[MMDYN_COPY_MANY_MAX];
+  char* dst[MMDYN_COPY_MANY_MAX];
+  int64_t bytes[MMDYN_COPY_MANY_MAX];
+};
+__global__ __launch_bounds__(256) void copy_many_kernel(const CopyMany cm) {
+  const int sgm = blockIdx.y;
+  const char* __restrict__ src = cm.src[sgm];
+  char* __restrict__ dst = cm.dst[sgm];
+  const int64_t n = cm.bytes[sgm];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const int64_t n16 = n >> 4;
+    for (int64_t i = i0; i < n16; i += stride) reinterpret_cast<u32x4_t*>(dst)[i] = reinterpret_cast<const u32x4_t*>(src)[i];
+    for (int64_t i = (n16 << 4) + i0; i < n; i += stride) dst[i] = src[i];
+  } else {
+    for (int64_t i = i0; i < n; i += stride) dst[i] = src[i];
+  }
+}
+
 __global__ void sum_blocks_kernel(const float* __restrict__ x, float* __restrict__ out, int P, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -473,6 +543,10 @@ extern "C" int mmdyn_colsum(const float* x, float* out, float* scratch, int rows
                             uint32_t* ticket, void* stream) {
   if (!x || !out || !scratch) return MMDYN_ERR_NULL;
   if ((perm == 2 && C != 6400) || C % 4 || rows <= 0) return MMDYN_ERR_SHAPE;
+  if (rows <= COLSUM_DIRECT_ROWS && !ticket) {
+    hipLaunchKernelGGL(colsum_direct_kernel, dim3(ceil_div(C / 4, 8)), dim3(256), 0, ST, x, out, rows, C, perm, beta);
+    MMDYN_LAUNCH_CHECK();
+  }
   const int chunks = mmdyn_colsum_chunks(rows);
   const int rpc = ceil_div(rows, chunks);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C / 4, 32), chunks), dim3(256), 0, ST, x, scratch, rows, C,
@@ -480,6 +554,25 @@ extern "C" int mmdyn_colsum(const float* x, float* out, float* scratch, int rows
   if (ticket) MMDYN_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, ST, scratch, out, chunks, C, perm,
                      beta);
+  MMDYN_LAUNCH_CHECK();
+}
+extern "C" int mmdyn_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int n, void* stream) {
+  if (!src || !dst || !bytes) return MMDYN_ERR_NULL;
+  if (n < 0 || n > MMDYN_COPY_MANY_MAX) return MMDYN_ERR_SHAPE;
+  if (n == 0) return MMDYN_OK;
+  CopyMany cm{};
+  int64_t longest = 0;
+  for (int i = 0; i < n; ++i) {
+    if (bytes[i] < 0) return MMDYN_ERR_SHAPE;
+    if (bytes[i] > 0 && (!src[i] || !dst[i])) return MMDYN_ERR_NULL;
+    cm.src[i] = (const char*)src[i];
+    cm.dst[i] = (char*)dst[i];
+    cm.bytes[i] = bytes[i];
+    longest = bytes[i] > longest ? bytes[i] : longest;
+  }
+  int g = ew_grid((longest + 15) / 16);
+  if (g > 512) g = 512;
+  hipLaunchKernelGGL(copy_many_kernel, dim3(g, n), dim3(256), 0, ST, cm);
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_sum_blocks(const float* x, float* out, int P, int64_t n, void* stream) {

@@ -1079,6 +1079,7 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
     return MMDYN_ERR_RANGE;
   g.rows_total = (int)rows;
   hipStream_t st = (hipStream_t)stream;
+  if (planes && mode == MMDYN_IM2COL3) return MMDYN_ERR_SHAPE;   // (the 3-channel layers read the NCHW image: no plane form)
   if (mode == MMDYN_IM2COL3) {     // the 3-channel layers have their own direct kernel (conv3.hip)
     const int rc = mmdyn_conv3_nt_try(A, Bp, bias, C, C_act, stats, G, Bg, Hi, Wi, Ho, Wo, N, ldc, act, splitk, bn_y,
                                       bn_mean, bn_rstd, bn_gamma, bn_beta, g.c_b16 << g.f16, g.bny_b16 << g.f16, g.b_b16 << g.f16,

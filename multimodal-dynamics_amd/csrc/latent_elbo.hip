@@ -45,7 +45,13 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(PoeArgs args, const float*
     const size_t o = (size_t)p * n + i;
     mu_out[o] = pd_mu;
     lv_out[o] = pd_lv;
-    if (z_out) z_out[o] = eps_noise[o] * expf(0.5f * pd_lv) + pd_mu;
+    if (z_out) {
+      const float zv = eps_noise[o] * expf(0.5f * pd_lv) + pd_mu;
+      z_out[o] = zv;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (e.zdst[k]) e.zdst[k][i] = zv;
+    }
     kl += (double)(1.f + pd_lv - pd_mu * pd_mu - expf(pd_lv));
   }
   if (kl_sum) {
@@ -171,19 +177,7 @@ __device__ __forceinline__ void block_atomic_add(double v, double* dst) {
   if (threadIdx.x == 0) atomicAdd(dst, red[0] + red[1] + red[2] + red[3]);
 }
 
-// One element of BCE-with-logits (torch.nn.functional.binary_cross_entropy_with_logits, problems.py:421-428) and its
-// derivative from ONE exponential: e = exp(-|x|) in (0, 1]; loss = max(x, 0) - x t + log(1 + e); sigmoid(x) = 1 / (1 + e) for
-// x >= 0 and e / (1 + e) below.  Hardware exp / log / reciprocal (v_exp_f32, v_log_f32, v_rcp_f32: ~1 ulp on these ranges; log
-// of 1 + e loses at most 6e-8 absolute, against terms of 0.3-0.7): the library log1pf + two expf + a division made this
-// 113 MB pass VALU-bound at 2.1 TB/s.
-__device__ __forceinline__ void bce_elem(float x, float t, float& loss, float& sig) {
-  const float e = __expf(-fabsf(x));
-  const float inv = __frcp_rn(__fadd_rn(1.f, e));
-  // (explicitly rounded products and sums: every kernel that inlines this evaluates the same expression tree, whatever
-  //  contraction the compiler would pick around it)
-  loss = __fadd_rn(__fsub_rn(fmaxf(x, 0.f), __fmul_rn(x, t)), __logf(__fadd_rn(1.f, e)));
-  sig = x >= 0.f ? inv : __fmul_rn(e, inv);
-}
+// (bce_elem: common.h -- shared with the last decoder layer's fused loss epilogue, tconv_out3.hip)
 
 // The same reconstruction term for several decoder passes that share ONE target (the live passes of a modality in the
 // multi-subset ELBO): logits [G][n], target [n], one loss slot per pass; blockIdx.y = pass.  A pass whose slot is negative
@@ -264,6 +258,23 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ r, c
     if (dr) dr[i] = 2.f * d * grad_scale;
   }
   block_atomic_add(acc, loss);
+}
+
+// the pose term of several passes against ONE target (the pose-bearing subsets of the multi-subset ELBO): r / dr [G][n], t [n],
+// one loss slot per pass; blockIdx.y = pass.  Same arithmetic per pass as mse_kernel.
+__global__ __launch_bounds__(256) void mse_groups_kernel(const float* __restrict__ r, const float* __restrict__ t,
+                                                         float* __restrict__ dr, double* __restrict__ loss, const BceGroups gs,
+                                                         int64_t n, float grad_scale) {
+  const int grp = blockIdx.y;
+  r += (size_t)grp * n;
+  if (dr) dr += (size_t)grp * n;
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = r[i] - t[i];
+    acc += (double)(d * d);
+    if (dr) dr[i] = 2.f * d * grad_scale;
+  }
+  block_atomic_add(acc, loss + gs.slot[grp]);
 }
 
 __global__ void elbo_assemble_kernel(const double* __restrict__ bce, const double* __restrict__ mse,
@@ -404,6 +415,21 @@ extern "C" int mmdyn_mse(const float* r, const float* t, float* dr, double* loss
   int g = ew_grid(n);
   if (g > 256) g = 256;
   hipLaunchKernelGGL(mse_kernel, dim3(g), dim3(256), 0, ST, r, t, dr, loss_sum, n, grad_scale);
+  MMDYN_LAUNCH_CHECK();
+}
+
+extern "C" int mmdyn_mse_groups(const float* r, const float* t, float* dr, double* loss_slots, const int* slot_of_group, int G,
+                                int64_t n, float grad_scale, void* stream) {
+  if (!r || !t || !loss_slots || !slot_of_group) return MMDYN_ERR_NULL;
+  if (G <= 0 || G > MMDYN_BCE_GROUPS_MAX || n <= 0) return MMDYN_ERR_SHAPE;
+  BceGroups gs{};
+  for (int i = 0; i < G; ++i) {
+    if (slot_of_group[i] < 0) return MMDYN_ERR_SHAPE;
+    gs.slot[i] = slot_of_group[i];
+  }
+  int g = ew_grid(n);
+  if (g > 64) g = 64;
+  hipLaunchKernelGGL(mse_groups_kernel, dim3(g, G), dim3(256), 0, ST, r, t, dr, loss_slots, gs, n, grad_scale);
   MMDYN_LAUNCH_CHECK();
 }
 

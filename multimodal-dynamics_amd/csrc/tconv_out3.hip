@@ -34,11 +34,28 @@ struct Out3Bn {
   const float* beta;      // [32]
   int Bg;                 // samples per BatchNorm group
 };
-template <typename TA, bool FUSED = false>
+// Round 6: LOSS = the reconstruction term rides in the epilogue.  The logits of a pixel pair are in
+// registers when the layer is done; binary_cross_entropy_with_logits against the pass's target (problems.py:433-437, 445-447 with
+// a loss mask), its sum into the pass's loss slot and dlogit = (sigmoid(l) - t) * grad_scale are computed there, so the logits
+// of the passes nobody reads are never written and read back (bce_logits_groups_kernel: 8 bytes read per logit) -- they are
+// materialised only for the group the caller publishes (`logit_group`; -1: all).  Same element expression as the stand-alone
+// loss kernel (bce_elem, common.h); per-thread fp32 sums of 12 elements, fp64 from there on.
+struct Out3Loss {
+  const float* target;    // [Bg][3][2Hi][2Wi]: every group is scored against the same target
+  const float* mask;      // [Bg][mask_c][2Hi][2Wi] or null (--mask-loss)
+  float* dlogit;          // [G*Bg][3][2Hi][2Wi] or null (evaluation)
+  double* loss;           // loss[slot[g]] += sum over group g
+  double* unmasked;       // with a mask: the plain sums as well (or null)
+  int slot[MMDYN_BCE_GROUPS_MAX];      // < 0: a discarded pass (zero gradient, no loss)
+  int mask_c;
+  int logit_group;        // group whose logits go to `out` ([Bg][3][2Hi][2Wi]); -1: all groups ([G*Bg]...)
+  float grad_scale;
+};
+template <typename TA, bool FUSED = false, bool LOSS = false>
 __global__ __launch_bounds__(256) void tconv_out3_kernel(const TA* __restrict__ a,         // [Bt][Hi][Wi][32]
                                                          const float* __restrict__ w,      // [32][3][4][4]
                                                          float* __restrict__ out,          // [Bt][3][2Hi][2Wi]
-                                                         int Hi, int Wi, const Out3Bn bn) {
+                                                         int Hi, int Wi, const Out3Bn bn, const Out3Loss ls) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tile = reinterpret_cast<float*>(smem);           // [32][TH][PX_LD]
   const int tid = threadIdx.x;
@@ -130,11 +147,65 @@ __global__ __launch_bounds__(256) void tconv_out3_kernel(const TA* __restrict__ 
 
   const int Ho = 2 * Hi, Wo = 2 * Wi;
   const int oy = 2 * (ty * TI + li), ox = 2 * (tx * TI + lj);
+  if constexpr (!LOSS) {
 #pragma unroll
-  for (int co = 0; co < 3; ++co)
+    for (int co = 0; co < 3; ++co)
 #pragma unroll
-    for (int ph = 0; ph < 2; ++ph)
-      *reinterpret_cast<f32x2*>(out + (((size_t)b * 3 + co) * Ho + oy + ph) * Wo + ox) = acc[ph][co];
+      for (int ph = 0; ph < 2; ++ph)
+        *reinterpret_cast<f32x2*>(out + (((size_t)b * 3 + co) * Ho + oy + ph) * Wo + ox) = acc[ph][co];
+  } else {
+    const int grp = b / bn.Bg, smp = b - grp * bn.Bg, slot = ls.slot[grp];
+    const bool keep = out != nullptr && (ls.logit_group < 0 || ls.logit_group == grp);
+    const int ob = ls.logit_group < 0 ? b : smp;
+    float part = 0.f, part_u = 0.f;
+#pragma unroll
+    for (int co = 0; co < 3; ++co)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        const size_t row = (size_t)(oy + ph) * Wo + ox;
+        const f32x2 x = acc[ph][co];
+        if (keep) *reinterpret_cast<f32x2*>(out + ((size_t)ob * 3 + co) * Ho * Wo + row) = x;
+        f32x2 d = {0.f, 0.f};
+        if (slot >= 0) {
+          const f32x2 t = *reinterpret_cast<const f32x2*>(ls.target + ((size_t)smp * 3 + co) * Ho * Wo + row);
+          if (ls.mask) {
+            const f32x2 mk = *reinterpret_cast<const f32x2*>(ls.mask + ((size_t)smp * ls.mask_c + (ls.mask_c == 1 ? 0 : co)) * Ho * Wo + row);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const float xm = x[k] * mk[k], tm = t[k] * mk[k];
+              float l, sg, lu, su;
+              bce_elem(xm, tm, l, sg);
+              bce_elem(x[k], t[k], lu, su);
+              part += l;
+              part_u += lu;
+              d[k] = mk[k] * (sg - tm) * ls.grad_scale;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              float l, sg;
+              bce_elem(x[k], t[k], l, sg);
+              part += l;
+              d[k] = (sg - t[k]) * ls.grad_scale;
+            }
+          }
+        }
+        if (ls.dlogit) *reinterpret_cast<f32x2*>(ls.dlogit + ((size_t)b * 3 + co) * Ho * Wo + row) = d;
+      }
+    if (slot >= 0) {          // (block-uniform)
+      __shared__ double red[2][4];
+      const double s = wave_sum_d((double)part), su = wave_sum_d((double)part_u);
+      if ((tid & 63) == 0) {
+        red[0][tid >> 6] = s;
+        red[1][tid >> 6] = su;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        atomicAdd(ls.loss + slot, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        if (ls.mask && ls.unmasked) atomicAdd(ls.unmasked + slot, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -146,7 +217,7 @@ extern "C" int mmdyn_tconv_out3_fwd(const float* a, const float* w, float* out, 
   if ((int64_t)Bt * Hi * Wi * 32 >= (1LL << 31)) return MMDYN_ERR_RANGE;
   dim3 grid((Hi / TI) * (Wi / TI), Bt);
   size_t smem = (size_t)32 * CH_LD * sizeof(float);
-  hipLaunchKernelGGL(tconv_out3_kernel<float>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi, Out3Bn{});
+  hipLaunchKernelGGL(tconv_out3_kernel<float>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi, Out3Bn{}, Out3Loss{});
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -162,11 +233,45 @@ extern "C" int mmdyn_tconv_out3_bn_fwd(const void* y, const float* mean, const f
   size_t smem = (size_t)32 * CH_LD * sizeof(float);
   const Out3Bn bn{mean, rstd, gamma, beta, Bg};
   if (b16 == 2)
-    hipLaunchKernelGGL((tconv_out3_kernel<half_t, true>), grid, dim3(256), smem, (hipStream_t)stream, (const half_t*)y, w, out, Hi, Wi, bn);
+    hipLaunchKernelGGL((tconv_out3_kernel<half_t, true>), grid, dim3(256), smem, (hipStream_t)stream, (const half_t*)y, w, out, Hi, Wi, bn, Out3Loss{});
   else if (b16 == 1)
-    hipLaunchKernelGGL((tconv_out3_kernel<bf16_t, true>), grid, dim3(256), smem, (hipStream_t)stream, (const bf16_t*)y, w, out, Hi, Wi, bn);
+    hipLaunchKernelGGL((tconv_out3_kernel<bf16_t, true>), grid, dim3(256), smem, (hipStream_t)stream, (const bf16_t*)y, w, out, Hi, Wi, bn, Out3Loss{});
   else
-    hipLaunchKernelGGL((tconv_out3_kernel<float, true>), grid, dim3(256), smem, (hipStream_t)stream, (const float*)y, w, out, Hi, Wi, bn);
+    hipLaunchKernelGGL((tconv_out3_kernel<float, true>), grid, dim3(256), smem, (hipStream_t)stream, (const float*)y, w, out, Hi, Wi, bn, Out3Loss{});
+  MMDYN_LAUNCH_CHECK();
+}
+
+/* mmdyn_tconv_out3_bn_fwd with the reconstruction term in its epilogue (problems.py:433-437, 445-447): the logits never leave the
+ * kernel except for group `logits_group` (-1: all; `logits` may be null: none).  See the header. */
+extern "C" int mmdyn_tconv_out3_bn_bce(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                       const float* w, float* logits, int logits_group, const float* target, const float* mask,
+                                       int mask_channels, float* dlogit, double* loss_slots, double* unmasked_slots,
+                                       const int* slot_of_group, float grad_scale, int G, int Bg, int Hi, int Wi, int b16,
+                                       void* stream) {
+  if (!y || !mean || !rstd || !gamma || !beta || !w || !target || !loss_slots || !slot_of_group) return MMDYN_ERR_NULL;
+  const int64_t Bt = (int64_t)G * Bg;
+  if (G <= 0 || G > MMDYN_BCE_GROUPS_MAX || Bg <= 0 || Hi % TI || Wi % TI || Bt > 65535 || b16 < 0 || b16 > 2) return MMDYN_ERR_SHAPE;
+  if (logits_group < -1 || logits_group >= G || (mask && mask_channels != 1 && mask_channels != 3)) return MMDYN_ERR_SHAPE;
+  if (Bt * Hi * Wi * 32 >= (1LL << 31)) return MMDYN_ERR_RANGE;
+  dim3 grid((Hi / TI) * (Wi / TI), (unsigned)Bt);
+  size_t smem = (size_t)32 * CH_LD * sizeof(float);
+  const Out3Bn bn{mean, rstd, gamma, beta, Bg};
+  Out3Loss ls{};
+  ls.target = target;
+  ls.mask = mask;
+  ls.dlogit = dlogit;
+  ls.loss = loss_slots;
+  ls.unmasked = unmasked_slots;
+  for (int i = 0; i < G; ++i) ls.slot[i] = slot_of_group[i];
+  ls.mask_c = mask ? mask_channels : 1;
+  ls.logit_group = logits_group;
+  ls.grad_scale = grad_scale;
+  if (b16 == 2)
+    hipLaunchKernelGGL((tconv_out3_kernel<half_t, true, true>), grid, dim3(256), smem, (hipStream_t)stream, (const half_t*)y, w, logits, Hi, Wi, bn, ls);
+  else if (b16 == 1)
+    hipLaunchKernelGGL((tconv_out3_kernel<bf16_t, true, true>), grid, dim3(256), smem, (hipStream_t)stream, (const bf16_t*)y, w, logits, Hi, Wi, bn, ls);
+  else
+    hipLaunchKernelGGL((tconv_out3_kernel<float, true, true>), grid, dim3(256), smem, (hipStream_t)stream, (const float*)y, w, logits, Hi, Wi, bn, ls);
   MMDYN_LAUNCH_CHECK();
 }
 
@@ -179,8 +284,8 @@ extern "C" int mmdyn_tconv_out3_fwd_b16(const uint16_t* a, const float* w, float
   dim3 grid((Hi / TI) * (Wi / TI), Bt);
   size_t smem = (size_t)32 * CH_LD * sizeof(float);
   if (half)
-    hipLaunchKernelGGL(tconv_out3_kernel<half_t>, grid, dim3(256), smem, (hipStream_t)stream, (const half_t*)a, w, out, Hi, Wi, Out3Bn{});
+    hipLaunchKernelGGL(tconv_out3_kernel<half_t>, grid, dim3(256), smem, (hipStream_t)stream, (const half_t*)a, w, out, Hi, Wi, Out3Bn{}, Out3Loss{});
   else
-    hipLaunchKernelGGL(tconv_out3_kernel<bf16_t>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi, Out3Bn{});
+    hipLaunchKernelGGL(tconv_out3_kernel<bf16_t>, grid, dim3(256), smem, (hipStream_t)stream, a, w, out, Hi, Wi, Out3Bn{}, Out3Loss{});
   MMDYN_LAUNCH_CHECK();
 }

@@ -14,7 +14,8 @@ _P, _I, _L, _F, _Q = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_flo
 
 class PassExperts(ctypes.Structure):
     """mmdyn_pass_experts (include/mmdyn_hip.h)."""
-    _fields_ = [("mu", _P * 4), ("lv", _P * 4), ("dmu", _P * 4), ("dlv", _P * 4), ("ld", _I * 4), ("dz", _P * 3)]
+    _fields_ = [("mu", _P * 4), ("lv", _P * 4), ("dmu", _P * 4), ("dlv", _P * 4), ("ld", _I * 4), ("dz", _P * 3),
+                ("zdst", _P * 3)]
 
 
 class PackEntry(ctypes.Structure):
@@ -25,7 +26,7 @@ class PackEntry(ctypes.Structure):
 
 MAX_PASSES = 8
 MAX_EXPERTS = 4
-ABI_VERSION = 5          # MMDYN_ABI_VERSION of the include/mmdyn_hip.h this table was written against
+ABI_VERSION = 6          # MMDYN_ABI_VERSION of the include/mmdyn_hip.h this table was written against
 
 # name -> argument type codes, in header order: p pointer, i int, l int64, f float, Q uint64
 _SIGNATURES = {
@@ -59,6 +60,7 @@ _SIGNATURES = {
     "mmdyn_col2im_k4": "pp" + "iiiiiiiiii" + "p",
     "mmdyn_tconv_out3_fwd": "ppp" + "iii" + "p",
     "mmdyn_tconv_out3_bn_fwd": "ppppppp" + "iiiii" + "p",
+    "mmdyn_tconv_out3_bn_bce": "ppppppp" + "i" + "pp" + "i" + "pppp" + "f" + "iiiii" + "p",
     "mmdyn_wgrad_out3_bn": "ppppppp" + "iiiii" + "p",
     "mmdyn_colstats": "pp" + "iii" + "p",
     "mmdyn_colstats_tiles": "i",
@@ -82,6 +84,7 @@ _SIGNATURES = {
     "mmdyn_colsum_chunks": "i",
     "mmdyn_scale_dev": "ppp" + "l" + "p",
     "mmdyn_sum_blocks": "pp" + "i" + "l" + "p",
+    "mmdyn_copy_many": "ppp" + "i" + "p",
     "mmdyn_cast_f32_to_bf16": "pp" + "l" + "p",
     "mmdyn_cast_bf16_to_f32": "pp" + "l" + "p",
     "mmdyn_linear_small_fwd": "pppp" + "iiii" + "p",
@@ -94,6 +97,7 @@ _SIGNATURES = {
     "mmdyn_bce_logits_groups": "ppppp" + "i" + "l" + "f" + "p",
     "mmdyn_bce_logits_groups_masked": "ppppppp" + "i" + "l" + "iii" + "f" + "p",
     "mmdyn_mse": "pppp" + "l" + "f" + "p",
+    "mmdyn_mse_groups": "ppppp" + "i" + "l" + "f" + "p",
     "mmdyn_elbo_assemble": "ppppp" + "ii" + "ff" + "pp",
     "mmdyn_adam_step": "ppppp" + "l" + "fffff" + "p",
     "mmdyn_adam_step_guarded": "ppppp" + "l" + "fffff" + "p",

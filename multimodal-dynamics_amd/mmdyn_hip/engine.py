@@ -232,13 +232,18 @@ class MVAEStep:
     """Fused train / eval step for an :class:`mmdyn_hip.models.MVAE` on one GPU (one rank)."""
 
     def __init__(self, model, lr=1e-3, pose_multiplier=1000.0, betas=(0.9, 0.999), eps=1e-8, noise=None,
-                 process_group=None, world_size=1, two_lanes=True, precision="fp32", exact_running_stats=False, sync_bn=False,
-                 defer_wgrad=None, grad_reduce_bf16=None, group_heads=True):
+                 process_group=None, world_size=1, two_lanes=True, precision="fp32x3", exact_running_stats=False, sync_bn=False,
+                 defer_wgrad=None, grad_reduce_bf16=None, group_heads=True, keep_logits=False):
         # --conditional (vae.py:231-237, 286-291): the condition joins the 512 features in front of the image encoders' heads
         # and the latent in front of the image decoders' first layer; the pose MLPs are built unconditional (vae.py:117-123)
         self.conditional = bool(getattr(model, "conditional", False))
+        # False (default): the image decoders' logits are materialised only for the pass whose reconstruction the caller receives
+        # (outputs['recon_x'] = the joint pass: problems.py:537-545) -- the BCE term and dlogits come out of the last layer's
+        # epilogue.  True: the logits of every live pass are written as well (self.last["logits_v" / "logits_t"])
+        self.keep_logits = bool(keep_logits)
         if precision not in PRECISIONS:
-            raise ValueError("precision must be 'fp32' (the reference's arithmetic), 'bf16s' (bf16 activation storage + "
+            raise ValueError("precision must be 'fp32x3' (default: fp32 storage and results, the GEMMs on the bf16 matrix cores "
+                             "through the exact three-term operand split), 'fp32' (the native fp32 matrix cores), 'bf16s' (bf16 activation storage + "
                              "bf16 matrix cores, fp32 accumulate / master weights: BASELINE configs[2]), 'bf16' (bf16 matrix-core "
                              "operands only, fp32 storage), 'fp16' (fp16 matrix-core operands, fp32 accumulate / storage: "
                              "BASELINE configs[4]) or 'fp16s' (fp16 + fp16 activation storage)")
@@ -344,6 +349,9 @@ class MVAEStep:
                      "dt": layers.decoder_pack_specs(FP.sub("tactile_decoder"))}
             if self.use_pose:
                 specs["hp"] = layers.heads_pack_specs(FP.sub("pose_encoder"))
+                # W^T of the pose MLPs' 512-wide layers (their input-gradient GEMMs' operand) ride on the late half of the plan
+                specs["pe"] = layers.pose_mlp_pack_specs(FP.sub("pose_encoder"), ["fc_net.2.weight"])
+                specs["pd"] = layers.pose_mlp_pack_specs(FP.sub("pose_decoder"), ["deconv_net.0.weight", "deconv_net.2.weight"])
             # what the encoder forward reads goes first (critical path); the transposed / decoder packs are launched
             # next to the encoder phase (run_late) and are ready long before the decoders start
             pre = None
@@ -369,6 +377,12 @@ class MVAEStep:
         self.ctx = None
         if self.lanes.on:
             torch.cuda.synchronize()
+        # the pack plan's plane twins (6 bytes per convolution weight) are registered in layers.PLANE_TWIN by strong reference:
+        # a closed engine gives them back
+        for ptr, pl in getattr(self.plan, "twins", None) or ():
+            ent = layers.PLANE_TWIN.get(ptr)
+            if ent is not None and ent[1] is pl:
+                del layers.PLANE_TWIN[ptr]
 
     # ------------------------------------------------------------------------------------------
     def _noise(self):
@@ -540,24 +554,44 @@ class MVAEStep:
         """Product of experts + reparametrisation + KL for every pass, one launch."""
         c, B, L, P, dev = self.ctx, self.ctx["B"], self.L, self.P, self.ctx["dev"]
         c["mu"], c["lv"], c["z"] = (torch.empty(P, B, L, device=dev) for _ in range(3))
-        ops.B.poe_fwd(self._passes(c, B, None), c["eps"], c["mu"], c["lv"], c["z"], self.acc[2], True, P, B, L)
+        # the decoders' stacked inputs (torch.cat of the passes each decoder runs on: vae.py:157-163 per pass) are written by the
+        # same launch: every pass's z goes to its row block of each decoder that consumes it
+        lists = {"v": self._dec_passes("v"), "t": self._dec_passes("t"), "p": self.pass_p if self.use_pose else []}
+        for m, pl in lists.items():
+            c["zz" + m] = torch.empty(len(pl) * B, L, device=dev) if pl else None
+        passes = self._passes(c, B, None)
+        for p, d in enumerate(passes):
+            d["zdst"] = [c["zz" + m][pl.index(p) * B:(pl.index(p) + 1) * B] if p in pl else None for m, pl in lists.items()]
+        ops.B.poe_fwd(passes, c["eps"], c["mu"], c["lv"], c["z"], self.acc[2], True, P, B, L)
 
     def _ph_dec_fwd_steps(self, m):
         """Image decoder on its live passes (groups) followed by the BCE sums (+ logit gradients when training)."""
         c, FP, B = self.ctx, self.params, self.ctx["B"]
         dec, plist, live = self._MOD[m][1], self._dec_passes(m), self._passes_of(m)
-        zz = torch.cat([c["z"][p] for p in plist])
+        zz = c["zz" + m]
         cond = None if c["cond"] is None else c["cond"].repeat(len(plist), 1)
-        lg, c["d" + m] = yield from layers.decoder_forward_steps(FP.sub(dec), self._buffers(dec), zz, len(plist),
-                                                                 packed=c["pk"].get("d" + m), cond=cond)
-        dl = torch.empty_like(lg) if c["train"] else None
-        # every live pass of the modality against the same target: one launch, one loss slot per pass
+        # every live pass of the modality against the same target: one loss slot per pass
         # (slot -1: exact_running_stats ran a pass whose reconstruction is discarded -- zero gradient, no loss)
         tg, mk = c["tg"][m], c["lmask"]
+        slots = [p if p in live else -1 for p in plist]
+        joint = self.subsets.index((1, 1, 1)) if self.use_pose else 0
+        # the BCE term rides in the last decoder layer's epilogue (layers.decoder_forward_steps(loss=...)): the logits of the
+        # passes nobody reads are never written; ``keep_logits`` materialises all of them (self.last["logits_*"])
+        spec = dict(target=tg, slots=slots, acc=self.acc[0], grad_scale=self.loss_scale / B, want_grad=c["train"],
+                    keep=None if self.keep_logits else plist.index(joint), mask=mk,
+                    mask_channels=1 if mk is None else mk.shape[1], acc_u=None if mk is None else self.acc[3])
+        lg, c["d" + m] = yield from layers.decoder_forward_steps(FP.sub(dec), self._buffers(dec), zz, len(plist),
+                                                                 packed=c["pk"].get("d" + m), cond=cond, loss=spec)
+        if c["d" + m]["loss_fused"]:
+            c["lg" + m], c["dl" + m] = lg, c["d" + m]["dl"]
+            c["lg_joint_only" + m] = not self.keep_logits
+            return
+        c["lg_joint_only" + m] = False
+        dl = torch.empty_like(lg) if c["train"] else None
         if mk is None:
-            ops.B.bce_logits_groups(lg, tg, dl, self.acc[0], [p if p in live else -1 for p in plist], tg.numel(), self.loss_scale / B)
+            ops.B.bce_logits_groups(lg, tg, dl, self.acc[0], slots, tg.numel(), self.loss_scale / B)
         else:
-            ops.B.bce_logits_groups(lg, tg, dl, self.acc[0], [p if p in live else -1 for p in plist], tg.numel(),
+            ops.B.bce_logits_groups(lg, tg, dl, self.acc[0], slots, tg.numel(),
                                     self.loss_scale / B, mask=mk, chw=tg[0].numel(), hw=tg[0, 0].numel(), mask_channels=mk.shape[1],
                                     unmasked_slots=self.acc[3])
         c["lg" + m], c["dl" + m] = lg, dl
@@ -566,12 +600,11 @@ class MVAEStep:
         c, FP, B = self.ctx, self.params, self.ctx["B"]
         c["pr"], c["dpr"] = None, None
         if self.use_pose:
-            zp = torch.cat([c["z"][p] for p in self.pass_p])
+            zp = c["zzp"]
             pr, c["dp"] = layers.pose_decoder_forward(FP.sub("pose_decoder"), zp)
             dpr = torch.empty_like(pr) if c["train"] else None
-            for g, p in enumerate(self.pass_p):
-                ops.B.mse(pr[g * B:(g + 1) * B], c["pose_tg"], None if dpr is None else dpr[g * B:(g + 1) * B],
-                          self.acc[1, p:p + 1], B * 7, self.loss_scale * self.pose_multiplier / B)
+            # every pose-bearing pass against the same target: one launch, one loss slot per pass
+            ops.B.mse_groups(pr, c["pose_tg"], dpr, self.acc[1], list(self.pass_p), B * 7, self.loss_scale * self.pose_multiplier / B)
             c["pr"], c["dpr"] = pr, dpr
 
     def _ph_assemble(self):
@@ -612,7 +645,8 @@ class MVAEStep:
         c, FP = self.ctx, self.params
         c["dzp"] = None
         if self.use_pose:
-            c["dzp"] = layers.pose_decoder_backward(FP.sub("pose_decoder"), c["dp"], c["dpr"], FP.sub("pose_decoder", "G"))
+            c["dzp"] = layers.pose_decoder_backward(FP.sub("pose_decoder"), c["dp"], c["dpr"], FP.sub("pose_decoder", "G"),
+                                                    packed=c["pk"].get("pd"))
 
     def _ph_poe_bwd(self):
         """Latent gradients of every pass (summed over the decoders that consumed z) through PoE / KL."""
@@ -659,18 +693,22 @@ class MVAEStep:
             else:
                 dhp = layers.heads_backward(c["hp"], c["dop"], FP.sub("pose_encoder", "G"),
                                             fused=FP.fused_heads_grad("pose_encoder"))
-            layers.pose_encoder_trunk_backward(FP.sub("pose_encoder"), c["ep"], dhp, FP.sub("pose_encoder", "G"))
+            layers.pose_encoder_trunk_backward(FP.sub("pose_encoder"), c["ep"], dhp, FP.sub("pose_encoder", "G"),
+                                               packed=c["pk"].get("pe"))
 
     def _publish(self):
         c, B, P = self.ctx, self.ctx["B"], self.P
         joint = self.subsets.index((1, 1, 1)) if self.use_pose else 0
         gv, gt = self._dec_passes("v").index(joint), self._dec_passes("t").index(joint)
-        recon = [c["lgv"][gv * B:(gv + 1) * B], c["lgt"][gt * B:(gt + 1) * B]]
+        # (fused loss epilogue without keep_logits: the logits buffer holds the joint pass only)
+        recon = [c["lgv"] if c["lg_joint_onlyv"] else c["lgv"][gv * B:(gv + 1) * B],
+                 c["lgt"] if c["lg_joint_onlyt"] else c["lgt"][gt * B:(gt + 1) * B]]
         if self.use_pose:
             gp = self.pass_p.index(joint)
             recon.append(c["pr"][gp * B:(gp + 1) * B])
         self.last = {"recon_x": recon, "means": c["mu"][P - 1], "log_var": c["lv"][P - 1],
-                     "logits_v": c["lgv"], "logits_t": c["lgt"], "pose_recon": c["pr"], "masked": c["lmask"] is not None}
+                     "logits_v": None if c["lg_joint_onlyv"] else c["lgv"], "logits_t": None if c["lg_joint_onlyt"] else c["lgt"],
+                     "pose_recon": c["pr"], "masked": c["lmask"] is not None}
 
     def _two(self, phase):
         """Run a per-modality steps-phase for both modalities, lane 0 / lane 1, enqueued in alternation."""
@@ -836,20 +874,31 @@ class MVAEStep:
                 mark()
             try:
                 captured = self._capture(kl_weight)
-            finally:
-                slots = ops.B.ticket_take() if mark is not None else []
+            except BaseException:
+                # a failed capture never becomes self._graph: the arrival-counter slots its launches drew go back now
+                # (nothing of the partial capture can be replayed; the sync covers the warm-up step that used other slots)
+                if mark is not None:
+                    torch.cuda.synchronize()
+                    ops.B.ticket_release(ops.B.ticket_take())
+                raise
+            slots = ops.B.ticket_take() if mark is not None else []
             # the loss scale baked into the captured backward: an eval_step or an eager step on another batch size in
             # between rewrites self.loss_scale, the replayed gradients keep this one (the eager Adam of the data-parallel
             # replay divides by it)
             self._graph = (key, captured, self.loss_scale, slots)
             return self.loss             # the warm-up above WAS this call's optimiser step
-        for dst, src in zip(self._static_in + self._static_tg, list(inputs) + list(targets)):
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src)
+        # the batch moves into the captured step's static buffers with ONE launch (six runtime copies before round 6)
+        moves = list(zip(self._static_in + self._static_tg, list(inputs) + list(targets)))
         if loss_mask is not None:
-            self._static_mask.copy_(loss_mask.reshape(self._static_mask.shape))
+            moves.append((self._static_mask, loss_mask.reshape(self._static_mask.shape)))
         if condition is not None:
-            self._static_cond.copy_(condition)
+            moves.append((self._static_cond, condition))
+        if all(d.dtype == s_.dtype and s_.is_cuda and s_.is_contiguous() for d, s_ in moves):
+            ops.B.copy_many(moves)
+        else:                        # (a batch that arrives in another type / layout / on the host: the runtime's converting copy)
+            for d, s_ in moves:
+                if d.data_ptr() != s_.data_ptr():
+                    d.copy_(s_)
         handles = self._replay(self._graph[1])
         if self.pg is not None:
             # buckets 0 and 1 were reduced under the encoder backward graphs; the conv stacks' gradients go now
@@ -1100,12 +1149,12 @@ class MVAEInference:
     use and replayed afterwards, so a request costs one graph launch.  Latent draws come from the device-side Philox
     stream, so replays draw fresh noise."""
 
-    def __init__(self, model, precision="fp32", use_graph=True, seed=0):
+    def __init__(self, model, precision="fp32x3", use_graph=True, seed=0):
         from .models.vae import NoiseSource
         if getattr(model, "conditional", False):
             raise NotImplementedError("mmdyn_hip: MVAEInference is built for the unconditional cnn-mvae")
         if precision not in PRECISIONS:
-            raise ValueError("precision must be 'fp32', 'bf16' / 'fp16' (matrix-core operands) or 'bf16s' / 'fp16s' (+ 16-bit "
+            raise ValueError("precision must be 'fp32x3' (default), 'fp32', 'bf16' / 'fp16' (matrix-core operands) or 'bf16s' / 'fp16s' (+ 16-bit "
                              "activation storage)")
         self.model, self.precision, self.use_graph = model, precision, use_graph
         self.use_pose = bool(model._use_pose)

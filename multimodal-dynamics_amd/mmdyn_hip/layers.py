@@ -618,9 +618,10 @@ def linear_forward(x, W, b, act=ACT_NONE, out=None):
     return None, y
 
 
-def linear_backward(dy, x, W, gW, gb, need_dx=True, x_act=ACT_NONE):
+def linear_backward(dy, x, W, gW, gb, need_dx=True, x_act=ACT_NONE, Wt=None):
     """Gradients of y = x W^T + b given dy (already through the activation).  Returns dx or None.
-    ``x_act``: x is the OUTPUT of that activation (ReLU: act'(u) = [x > 0]) and dx is returned through it: dL/du."""
+    ``x_act``: x is the OUTPUT of that activation (ReLU: act'(u) = [x > 0]) and dx is returned through it: dL/du.
+    ``Wt``: W^T [K][N] where the caller's pack plan has written it (else transposed here, one launch)."""
     rows, K = x.shape
     N = W.shape[0]
     if K % 32 == 0 and N % 32 == 0:
@@ -629,7 +630,8 @@ def linear_backward(dy, x, W, gW, gb, need_dx=True, x_act=ACT_NONE):
             ops.B.colsum(dy, gb, rows, N, 0, 0.0)
         if not need_dx:
             return None
-        Wt = repack(W, N, K, K, N, 1)
+        if Wt is None:
+            Wt = repack(W, N, K, K, N, 1)
         if x_act != ACT_NONE:
             return dgrad_act(dy, Wt, DENSE, 1, rows, 1, N, 1, K, x, x_act)
         dx, _ = dense(dy, Wt, None, rows, N, K)
@@ -793,9 +795,13 @@ def decoder_forward(*a, **k):
     return run(decoder_forward_steps(*a, **k))
 
 
-def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, cond=None, training=True):
+def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, cond=None, training=True, loss=None):
     """z: [Bt, L] -> logits NCHW [Bt,3,S,S]; returns (logits, ctx).  ``logits=False`` stops after the last
-    BatchNorm (used only to reproduce the running statistics of the reference's unused decoder passes)."""
+    BatchNorm (used only to reproduce the running statistics of the reference's unused decoder passes).
+    ``loss`` (fused engine): dict(target [Bg,3,S,S], slots [G], acc (fp64 loss slots), grad_scale, want_grad, keep (group whose logits
+    are published, or None: all), mask, mask_channels, acc_u) -- where the last layer is the direct fused kernel, the BCE term of
+    problems.py:433-437 rides in its epilogue: ctx["dl"] = dlogits (or None), ctx["loss_fused"] = True, and the returned logits hold
+    group ``keep`` only ([Bg,3,S,S]).  Otherwise ctx["loss_fused"] is False and the caller runs the loss kernel."""
     Bt, L0 = z.shape
     Bg = Bt // G
     convs, last, S = dec_layout(P)
@@ -837,9 +843,21 @@ def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, co
         a, H = an, Ho
         yield
     out = None
+    c["loss_fused"] = False
     if logits:
-        out = _new(z, Bt, 3, S, S)
         t = stages[-1]
+        if t["a"] is None and loss is not None:
+            keep = loss.get("keep")
+            out = _new(z, Bt if keep is None else Bg, 3, S, S)
+            c["dl"] = _new(z, Bt, 3, S, S) if loss["want_grad"] else None
+            ops.B.tconv_out3_bn_bce(t["y"], t["m"], t["r"], t["bn"].gamma, t["bn"].beta, P[f"hallucinate.{last}.weight"], out,
+                                    -1 if keep is None else keep, loss["target"], c["dl"], loss["acc"], loss["slots"],
+                                    loss["grad_scale"], G, Bg, H, H, mask=loss.get("mask"),
+                                    mask_channels=loss.get("mask_channels", 1), unmasked_slots=loss.get("acc_u"))
+            c["loss_fused"] = True
+            c.update(u0=u0, h0=h0, stages=stages)
+            return out, c
+        out = _new(z, Bt, 3, S, S)
         if t["a"] is None:
             ops.B.tconv_out3_bn_fwd(t["y"], t["m"], t["r"], t["bn"].gamma, t["bn"].beta, P[f"hallucinate.{last}.weight"], out, G, Bg,
                                     H, H)
@@ -991,10 +1009,22 @@ def pose_encoder_trunk_forward(P, pose, out=None):
     return h2, {"x": pose, "h1": h1}
 
 
-def pose_encoder_trunk_backward(P, c, dh2, grads):
+def pose_mlp_pack_specs(P, keys):
+    """W^T of the pose MLPs' MFMA-sized Linear layers (the input-gradient GEMMs' operand), written by the step's pack plan:
+    one entry "<key>T" per weight [N][K] -> [K][N]."""
+    out = []
+    for k in keys:
+        N, K = P[k].shape
+        if K % 32 == 0 and N % 32 == 0:
+            out.append(_spec(k + "T", P[k], 1, N, K, K, N, (K, N)))
+    return out
+
+
+def pose_encoder_trunk_backward(P, c, dh2, grads, packed=None):
     # (ReLU: the sign of the output equals the sign of the input, so h1 stands in for the pre-activation)
+    pk = packed or {}
     du1 = linear_backward(dh2, c["h1"], P["fc_net.2.weight"], grads["fc_net.2.weight"], grads["fc_net.2.bias"],
-                          x_act=ACT_RELU)
+                          x_act=ACT_RELU, Wt=pk.get("fc_net.2.weightT"))
     linear_backward(du1, c["x"], P["fc_net.0.weight"], grads["fc_net.0.weight"], grads["fc_net.0.bias"],
                     need_dx=False)
 
@@ -1007,10 +1037,11 @@ def pose_decoder_forward(P, z):
     return out, {"z": z, "h1": h1, "h2": h2}
 
 
-def pose_decoder_backward(P, c, dout, grads, need_dz=True):
+def pose_decoder_backward(P, c, dout, grads, need_dz=True, packed=None):
+    pk = packed or {}
     du2 = linear_backward(dout, c["h2"], P["deconv_net.4.weight"], grads["deconv_net.4.weight"],
                           grads["deconv_net.4.bias"], x_act=ACT_RELU)
     du1 = linear_backward(du2, c["h1"], P["deconv_net.2.weight"], grads["deconv_net.2.weight"],
-                          grads["deconv_net.2.bias"], x_act=ACT_RELU)
+                          grads["deconv_net.2.bias"], x_act=ACT_RELU, Wt=pk.get("deconv_net.2.weightT"))
     return linear_backward(du1, c["z"], P["deconv_net.0.weight"], grads["deconv_net.0.weight"],
-                           grads["deconv_net.0.bias"], need_dx=need_dz)
+                           grads["deconv_net.0.bias"], need_dx=need_dz, Wt=pk.get("deconv_net.0.weightT"))

@@ -45,7 +45,7 @@ _BUILD_FLAGS = (
     ("reference-schedule", False, None, "run the reference's 7-forward autograd schedule instead of the fused step"),
     ("image-size", 64, int, "side of the input images: 64 (the reference's only size) or the 128 / 256 pixel extended stacks "
                             "(models/shapes.py; BASELINE configs[3] / configs[4], no reference architecture)"),
-    ("precision", "fp32", str, "matrix-core arithmetic of the fused step: fp32 | fp32x3 (fp32 results, exact three-term split on the bf16 matrix cores) | bf16 | bf16s | fp16 | fp16s"),
+    ("precision", "fp32x3", str, "matrix-core arithmetic of the fused step: fp32x3 (default: fp32 storage and results, exact three-term operand split on the bf16 matrix cores) | fp32 (the native fp32 matrix cores) | bf16 | bf16s | fp16 | fp16s"),
     ("exact-running-stats", False, None, "fused step: also run the image decoders on the subset passes whose reconstruction the "
                                          "reference computes and discards, so that the decoders' BatchNorm running statistics "
                                          "get the reference's 7 (3) updates per step instead of 4 (2); ~1.4x the step time"),

@@ -101,6 +101,7 @@ class HipBackend:
         self._l, self._lib_path = None, lib_path       # lib_path: the LAB build (tests / microbenchmarks only)
         self._tickets = {}                             # device -> [zeroed int32 pool, next eager slot, next graph slot, free graph slots]
         self._drawn = None                             # (device, slot) pairs drawn by captured launches since ticket_mark()
+        self._flagpool = {}                            # device -> [zeroed int32 pool, next eager block, next graph block, free graph blocks]
         self.force_ticket = False
         # "fp32": v_mfma_f32_32x32x2_f32 (the reference's arithmetic, the default and the BASELINE configs[1] path);
         # "bf16": operands rounded to bf16 on their way into the matrix cores, fp32 accumulate (configs[2]);
@@ -148,6 +149,37 @@ class HipBackend:
             slot = half + nxt_eager
         return pool.data_ptr() + 4 * self.TICKET_STRIDE * slot
 
+    # arrival flags of the persistent stream-K GEMMs (igemm_wsp.hip, round 6): one block of FLAG_WORDS zeroed words per launch, the
+    # same ownership rules as the tickets (captured launches own theirs until ticket_release, eager launches cycle through the upper
+    # half); the kernel leaves every flag it set back at zero.  Exhausted (hundreds of live captures): None -- the launch then takes
+    # the two-launch form (slabs + fix-up kernel).
+    FLAG_BLOCKS, FLAG_WORDS = 1024, 8192
+
+    def _flags(self, like):
+        if os.environ.get("MMDYN_NO_FLAGS"):
+            return None
+        dev = like.device
+        ent = self._flagpool.get(dev)
+        if ent is None:
+            ent = [torch.zeros(self.FLAG_BLOCKS * self.FLAG_WORDS, dtype=torch.int32, device=dev), 0, 0, []]
+            self._flagpool[dev] = ent
+        pool, nxt_eager, nxt_graph, free = ent
+        half = self.FLAG_BLOCKS // 2
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            if free:
+                blk = free.pop()
+            elif nxt_graph >= half:
+                return None
+            else:
+                ent[2] = nxt_graph + 1
+                blk = nxt_graph
+            if self._drawn is not None:
+                self._drawn.append((dev, -1 - blk))            # (negative: a flag block, not a ticket slot)
+        else:
+            ent[1] = (nxt_eager + 1) % half
+            blk = half + nxt_eager
+        return pool.data_ptr() + 4 * self.FLAG_WORDS * blk
+
     def ticket_mark(self):
         """Start recording the slots that captured launches draw (one capture at a time)."""
         self._drawn = []
@@ -161,7 +193,10 @@ class HipBackend:
         """Give back the slots of graphs that will never be replayed again.  The caller has synchronised the device (a replay
         still in flight would otherwise share its counter with the next capture's launch)."""
         for dev, slot in slots or ():
-            self._tickets[dev][3].append(slot)
+            if slot < 0:
+                self._flagpool[dev][3].append(-1 - slot)
+            else:
+                self._tickets[dev][3].append(slot)
 
     @property
     def lib(self):
@@ -453,6 +488,26 @@ class HipBackend:
         check(self.lib.mmdyn_tconv_out3_bn_fwd(py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(w), _ptr(out), G, Bg, Hi, Wi,
                                                y16, _stream()), "mmdyn_tconv_out3_bn_fwd")
 
+    def tconv_out3_bn_bce(self, y, mean, rstd, gamma, beta, w, logits, logits_group, target, dlogit, loss_slots, slot_of_group,
+                          grad_scale, G, Bg, Hi, Wi, mask=None, mask_channels=1, unmasked_slots=None):
+        """tconv_out3_bn_fwd with the BCE-with-logits term (sums into loss_slots[slot_of_group[g]], dlogit) in its epilogue; the
+        logits are written for group ``logits_group`` only (-1: all groups; ``logits`` None: none)."""
+        py, y16 = _aptr(y)
+        if len(slot_of_group) != G or tuple(target.shape) != (Bg, 3, 2 * Hi, 2 * Wi):
+            raise ValueError("mmdyn_hip: tconv_out3_bn_bce: one slot per group and a [Bg][3][2Hi][2Wi] target")
+        if logits is not None and logits.numel() != (G if logits_group < 0 else 1) * Bg * 3 * 4 * Hi * Wi:
+            raise ValueError("mmdyn_hip: tconv_out3_bn_bce: logits buffer of the wrong size")
+        if dlogit is not None and dlogit.numel() != G * Bg * 3 * 4 * Hi * Wi:
+            raise ValueError("mmdyn_hip: tconv_out3_bn_bce: dlogit buffer of the wrong size")
+        if mask is not None and tuple(mask.shape) != (Bg, mask_channels, 2 * Hi, 2 * Wi):
+            raise ValueError(f"mmdyn_hip: tconv_out3_bn_bce: mask {tuple(mask.shape)} is not [Bg][{mask_channels}][2Hi][2Wi]")
+        slots = (ctypes.c_int * G)(*[int(s) for s in slot_of_group])
+        check(self.lib.mmdyn_tconv_out3_bn_bce(py, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(w), _ptr(logits),
+                                               int(logits_group), _ptr(target), _ptr(mask), int(mask_channels), _ptr(dlogit),
+                                               loss_slots.data_ptr(), None if unmasked_slots is None else unmasked_slots.data_ptr(),
+                                               ctypes.addressof(slots), float(grad_scale), G, Bg, Hi, Wi, y16, _stream()),
+              "mmdyn_tconv_out3_bn_bce")
+
     def wgrad_out3_bn(self, y, mean, rstd, gamma, beta, Gt, partial, G, Bg, Hr, chunks):
         """Weight gradient of the last decoder layer with swish(BatchNorm(y)) recomputed on the operand fetch."""
         py, y16 = _aptr(y)
@@ -599,6 +654,22 @@ class HipBackend:
         check(self.lib.mmdyn_cast_f32_to_bf16(_ptr(src), _ptr(dst, torch.bfloat16), src.numel(), _stream()),
               "mmdyn_cast_f32_to_bf16")
 
+    def copy_many(self, pairs):
+        """[(dst, src)]: contiguous GPU tensors of equal byte size, copied by ONE launch per 8 pairs."""
+        pairs = [(d, s_) for d, s_ in pairs if d.data_ptr() != s_.data_ptr()]
+        for d, s_ in pairs:
+            if not (d.is_cuda and s_.is_cuda and d.is_contiguous() and s_.is_contiguous()) or \
+                    d.numel() * d.element_size() != s_.numel() * s_.element_size() or d.dtype != s_.dtype:
+                raise ValueError("mmdyn_hip: copy_many takes contiguous GPU tensors of equal type and size")
+        for i in range(0, len(pairs), 8):
+            part = pairs[i:i + 8]
+            n = len(part)
+            src = (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in part])
+            dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in part])
+            nb = (ctypes.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in part])
+            check(self.lib.mmdyn_copy_many(ctypes.addressof(src), ctypes.addressof(dst), ctypes.addressof(nb), n, _stream()),
+                  "mmdyn_copy_many")
+
     def cast_bf16_to_f32(self, src, dst):
         check(self.lib.mmdyn_cast_bf16_to_f32(_ptr(src, torch.bfloat16), _ptr(dst), src.numel(), _stream()),
               "mmdyn_cast_bf16_to_f32")
@@ -629,6 +700,9 @@ class HipBackend:
             for k, t in enumerate(p.get("dz", [])):
                 if t is not None:
                     arr[i].dz[k] = _ptr(t)
+            for k, t in enumerate(p.get("zdst", [])):      # forward: further [B][L] destinations of the pass's z
+                if t is not None:
+                    arr[i].zdst[k] = _ptr(t)
         return arr
 
     def poe_fwd(self, passes, eps_noise, mu, logvar, z, kl_sum, with_prior, P, B, L):
@@ -685,6 +759,13 @@ class HipBackend:
     def mse(self, r, t, dr, loss_sum, n, grad_scale):
         check(self.lib.mmdyn_mse(_ptr(r), _ptr(t), _ptr(dr), loss_sum.data_ptr(), n, float(grad_scale), _stream()),
               "mmdyn_mse")
+
+    def mse_groups(self, r, t, dr, loss_slots, slot_of_group, n, grad_scale):
+        """r / dr: [G*n]; t: [n]; loss_slots: fp64 vector, pass g adds its sum to loss_slots[slot_of_group[g]].  One launch."""
+        G = len(slot_of_group)
+        slots = (ctypes.c_int * G)(*[int(s) for s in slot_of_group])
+        check(self.lib.mmdyn_mse_groups(_ptr(r), _ptr(t), _ptr(dr), loss_slots.data_ptr(), ctypes.addressof(slots), G, n,
+                                        float(grad_scale), _stream()), "mmdyn_mse_groups")
 
     def elbo_assemble(self, bce, mse, kl, loss, partials, P, B, kl_weight, pose_multiplier, kl_weight_dev=None):
         check(self.lib.mmdyn_elbo_assemble(_ptr(bce, torch.float64), _ptr(mse, torch.float64),

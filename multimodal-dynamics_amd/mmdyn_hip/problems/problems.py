@@ -183,11 +183,13 @@ class Problem:
         use_engine = (self._fused and isinstance(self._model, MVAE) and self._cross_modal
                       and isinstance(self, SeqModeling)
                       and not (self.parameters.get('mask_loss') and self.parameters.get('use_pose')))
-        precision = self.parameters.get('precision', 'fp32')
+        # fp32x3 (fp32 storage and results, the GEMMs on the bf16 matrix cores through the exact three-term operand split) is the
+        # fused step's default arithmetic; the module path below always computes on the native fp32 matrix cores
+        precision = self.parameters.get('precision', 'fp32x3')
         if use_engine:
             self._step = MVAEStep(self._model, lr=self.parameters['lr'], pose_multiplier=self._pose_multiplier,
                                   precision=precision, exact_running_stats=bool(self.parameters.get('exact_running_stats')))
-        elif precision != 'fp32':
+        elif precision not in ('fp32', 'fp32x3'):
             raise ValueError("--precision %s is a mode of the fused cnn-mvae step; this configuration runs the module "
                              "path, which computes in fp32" % precision)
         # the module path's optimiser: also what a batch the fused step does not take falls back to

@@ -285,6 +285,18 @@ class EmuBackend:
         EmuBackend.bn_swish_fwd(self, y.float(), mean, rstd, gamma, beta, a, G, Bg * Hi * Wi, 32)
         EmuBackend.tconv_out3_fwd(self, a, w, out, G * Bg, Hi, Wi)
 
+    def tconv_out3_bn_bce(self, y, mean, rstd, gamma, beta, w, logits, logits_group, target, dlogit, loss_slots, slot_of_group,
+                          grad_scale, G, Bg, Hi, Wi, mask=None, mask_channels=1, unmasked_slots=None):
+        full = torch.empty(G * Bg, 3, 2 * Hi, 2 * Wi)
+        EmuBackend.tconv_out3_bn_fwd(self, y, mean, rstd, gamma, beta, w, full, G, Bg, Hi, Wi)
+        n = target.numel()
+        EmuBackend.bce_logits_groups(self, full, target, dlogit, loss_slots, slot_of_group, n, grad_scale, mask=mask,
+                                     chw=target[0].numel(), hw=target[0, 0].numel(), mask_channels=mask_channels,
+                                     unmasked_slots=unmasked_slots)
+        if logits is not None:
+            src = full if logits_group < 0 else full[logits_group * Bg:(logits_group + 1) * Bg]
+            logits.reshape(-1).copy_(src.reshape(-1))
+
     def wgrad_out3_bn(self, y, mean, rstd, gamma, beta, Gt, partial, G, Bg, Hr, chunks):
         a = torch.empty(y.shape, dtype=torch.float32)
         EmuBackend.bn_swish_fwd(self, y.float(), mean, rstd, gamma, beta, a, G, Bg * Hr * Hr, 32)
@@ -426,6 +438,11 @@ class EmuBackend:
     def sum_blocks(self, x, out, P, n):
         out.reshape(-1).copy_(x.reshape(P, n).sum(0))
 
+    def copy_many(self, pairs):
+        for d, s_ in pairs:
+            if d.data_ptr() != s_.data_ptr():
+                d.copy_(s_)
+
     def cast_f32_to_bf16(self, src, dst):
         dst.copy_(src.to(torch.bfloat16))
 
@@ -479,6 +496,9 @@ class EmuBackend:
             logvar.reshape(P, B, L)[i] = plv
             if z is not None:
                 z.reshape(P, B, L)[i] = eps_noise.reshape(P, B, L)[i] * torch.exp(0.5 * plv) + pm
+                for t in p.get("zdst", []):
+                    if t is not None:
+                        t.reshape(B, L).copy_(z.reshape(P, B, L)[i])
             if kl_sum is not None:
                 kl_sum[i] += (-0.5 * (1 + plv - pm * pm - plv.exp()).double().sum())
 
@@ -563,6 +583,11 @@ class EmuBackend:
         loss_sum += (d * d).double().sum()
         if dr is not None:
             dr.reshape(-1)[:n] = 2 * d * grad_scale
+
+    def mse_groups(self, r, t, dr, loss_slots, slot_of_group, n, grad_scale):
+        for g, slot in enumerate(slot_of_group):
+            self.mse(r.reshape(-1)[g * n:(g + 1) * n], t, None if dr is None else dr.reshape(-1)[g * n:(g + 1) * n],
+                     loss_slots[slot:slot + 1], n, grad_scale)
 
     def elbo_assemble(self, bce, mse, kl, loss, partials, P, B, kl_weight, pose_multiplier, kl_weight_dev=None):
         if kl_weight_dev is not None:

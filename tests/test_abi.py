@@ -86,7 +86,7 @@ def test_plane_operand_host_queries_without_a_gpu():
     partial-sum tile count and slab workspace of such a launch, the cut of the plane weight gradient, the ABI version."""
     lib = _lib.load()
     CONV, TCONV_S2P1, TCONV_S1P0, DENSE = 1, 2, 4, 0
-    assert lib.mmdyn_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.mmdyn_abi_version() == _lib.ABI_VERSION == 6
     # convolution-level launches of the bs-256 step: N % 128 == 0 and N == 64 on the plane-ring kernel, the one-group k4 s1 p0 launch too
     assert lib.mmdyn_igemm_planes_served(CONV, 4, 256, 16, 16, 64, 8, 8, 128) == 1
     assert lib.mmdyn_igemm_planes_served(CONV, 4, 256, 32, 32, 32, 16, 16, 64) == 1

@@ -155,7 +155,12 @@ def test_single_launch_finalize_equals_two_launches():
             outs.append([t.clone() for t in (mean, rstd, rm, rv, nbt, sums, dg, db, cs)])
         finally:
             HIP.force_ticket = False
-    for a, b, c in zip(*outs):
+    for i, (a, b, c) in enumerate(zip(*outs)):
+        if i == len(outs[0]) - 1:
+            # column sums: without a ticket the FC-level row counts take the single-launch kernel (one block per 32 channels over all
+            # rows, round 6) -- another summation order than the chunked last-block-finishes form
+            assert torch.equal(b, c) and torch.allclose(a, b, rtol=1e-5, atol=1e-4)
+            continue
         assert torch.equal(a, b) and torch.equal(a, c)
 
 

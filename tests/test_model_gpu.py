@@ -45,7 +45,7 @@ def test_fused_engine_mask_loss_graph_replay():
     replay sees the mask of its call; masked / unmasked sums of the visual passes against torch on the step's own logits."""
     import torch.nn.functional as F
     B = 4
-    step = MVAEStep(T.build("cnn-mvae", True, False, DEV), noise=NoiseSource(3))
+    step = MVAEStep(T.build("cnn-mvae", True, False, DEV), noise=NoiseSource(3), keep_logits=True)   # (every pass's logits, not only the published pass's)
     inputs, targets = seeded_batch(B, 77, with_pose=False)
     inputs, targets = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
     gen = torch.Generator().manual_seed(9)
@@ -136,11 +136,13 @@ class _ReluKnifeEdges:
     is weighted 1000x; profiles/r4/x3_relu_knife_edge_b130.txt: B = 130, {tactile, pose} subset, sample 37, unit 507 of
     deconv_net.2: +3.5e-7 natively, <= 0 in the split).  Either subgradient is right.  While active, the oracle's pose decoder takes
     the ENGINE's mask for the units -- and only those -- whose oracle pre-activation is below 1e-5 of the layer's rms, and counts how
-    many it had to flip (`flips`), which the test bounds: a real error in the pose decoder flips thousands, a knife edge one or two."""
+    many it had to flip (`flips`), which the test bounds: a real error in the pose decoder flips thousands, a knife edge one or two.
+    Used ONLY as the second opinion of an fp32x3 case whose gradients upstream of the pose decoder's ReLUs missed the bound against
+    the untouched oracle (test_fused_engine_vs_oracle); the native fp32 cases never see it."""
     THR = 1e-5
 
-    def __init__(self, step, B):
-        self.step, self.B, self.flips, self.calls = step, B, 0, 0
+    def __init__(self, dp, live, B):
+        self.dp, self.live, self.B, self.flips, self.calls = dp, list(live), B, 0, 0
 
     def __enter__(self):
         self._orig = O.pose_decoder
@@ -154,7 +156,7 @@ class _ReluKnifeEdges:
         mask = u > 0
         if eng_h is not None:
             knife = u.detach().abs() < self.THR * float(u.detach().pow(2).mean().sqrt())
-            eng = eng_h.detach().cpu() > 0
+            eng = eng_h > 0
             self.flips += int((knife & (eng != mask)).sum())
             mask = torch.where(knife, eng, mask)
         return u * mask
@@ -162,27 +164,35 @@ class _ReluKnifeEdges:
     def _pose_decoder(self, z, prm, pre="pose_decoder"):
         k = self.calls % 7                      # _evaluate_mvae's pass index (problems.py:473-546: one pose decoding per pass)
         self.calls += 1
-        dp, live = self.step.ctx.get("dp"), list(self.step.pass_p)
         h1 = h2 = None
-        if dp is not None and k in live:
-            g = live.index(k)
-            h1, h2 = dp["h1"][g * self.B:(g + 1) * self.B], dp["h2"][g * self.B:(g + 1) * self.B]
+        if k in self.live:
+            g = self.live.index(k)
+            h1, h2 = self.dp["h1"][g * self.B:(g + 1) * self.B], self.dp["h2"][g * self.B:(g + 1) * self.B]
         h = self._relu(torch.nn.functional.linear(z, prm[pre + ".deconv_net.0.weight"], prm[pre + ".deconv_net.0.bias"]), h1)
         h = self._relu(torch.nn.functional.linear(h, prm[pre + ".deconv_net.2.weight"], prm[pre + ".deconv_net.2.bias"]), h2)
         return torch.nn.functional.linear(h, prm[pre + ".deconv_net.4.weight"], prm[pre + ".deconv_net.4.bias"])
+
+
+# parameters whose gradient does not pass through a ReLU of the pose decoder on its way back: the image decoders and the pose
+# decoder's output layer (its gradient needs the forward activations only)
+_NOT_BEHIND_POSE_RELU = ("visual_decoder.", "tactile_decoder.", "pose_decoder.deconv_net.4.")
 
 
 @pytest.mark.parametrize("B,n_steps,precision", [(32, 3, "fp32"), (256, 1, "fp32"), (1, 1, "fp32"), (5, 2, "fp32"), (37, 1, "fp32"),
                                                  (130, 1, "fp32"), (32, 3, "fp32x3"), (256, 1, "fp32x3"), (130, 1, "fp32x3"),
                                                  (131, 1, "fp32x3"), (200, 1, "fp32x3")])
 def test_fused_engine_vs_oracle(B, n_steps, precision):
-    """(precision "fp32x3": the convolution-level GEMMs run on the bf16 matrix cores through the exact three-term split of their
-    fp32 operands -- held to the SAME tolerances as the native fp32 arithmetic, at the same batch sizes incl. the ragged B = 130,
-    whose one ReLU knife-edge unit is handled by construction: _ReluKnifeEdges.)
+    """(precision "fp32x3", the product's default: the convolution-level GEMMs run on the bf16 matrix cores through the exact
+    three-term split of their fp32 operands -- held to the SAME tolerances as the native fp32 arithmetic, at the same batch sizes
+    incl. the ragged B = 130.)
     ELBO (total and each of the 7 partials) within 1e-4 relative of the CPU oracle, gradients within 1e-3
     relative L2 per tensor, loss still within 1e-4 after 3 Adam steps; B=256 is the
     BASELINE batch (one oracle step takes a few seconds on the host cores); 1, 5, 37 and 130 are ragged sizes: no
-    row count is a multiple of any tile, split-K / chunk / band sizes all hit their remainders."""
+    row count is a multiple of any tile, split-K / chunk / band sizes all hit their remainders.
+    The oracle runs UNTOUCHED and every case is compared with that run.  Only if an fp32x3 case then misses the gradient bound, and
+    only on tensors behind a ReLU of the pose decoder (every other tensor must have met it against the untouched oracle), the
+    oracle is run a second time with the engine's mask on that decoder's knife-edge units (_ReluKnifeEdges: between one and three
+    units below 1e-5 of the layer rms) and the bound must hold against that run."""
     klw = 1.0 / 50
     sd = seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True), 0)
     prm, buf = O.split_state(sd)
@@ -193,13 +203,18 @@ def test_fused_engine_vs_oracle(B, n_steps, precision):
     names = list(prm.keys())
     opt = O.Adam([prm[k] for k in names], lr=1e-3)
     gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+
+    def rel_errors():
+        named = dict(m.named_parameters())
+        return {k: float((named[k].grad.double().cpu() - prm[k].grad.double()).norm() / (prm[k].grad.double().norm() + 1e-30))
+                for k in names}
+
     for s in range(n_steps):
         opt.zero_grad()
         loss = step.forward(gi, gt, klw)
-        with _ReluKnifeEdges(step, B) as knife:
-            _, loss_o, partials_o = O.evaluate_mvae(prm, inputs, targets, eps[7 * s:7 * s + 7], masks[8 * s:8 * s + 8], klw,
-                                                    1000.0, True, buf)
-        assert knife.flips <= 3, knife.flips          # (B = 130, fp32x3, r4 kernels: 1)
+        buf0 = {k: v.clone() for k, v in buf.items()}
+        _, loss_o, partials_o = O.evaluate_mvae(prm, inputs, targets, eps[7 * s:7 * s + 7], masks[8 * s:8 * s + 8], klw,
+                                                1000.0, True, buf)
         loss_o.backward()
         assert float(loss) == pytest.approx(float(loss_o.detach()), rel=1e-4), s
         # every partial within 1e-4 on identical weights (step 0).  After Adam steps the weights themselves differ by
@@ -208,12 +223,24 @@ def test_fused_engine_vs_oracle(B, n_steps, precision):
         # (tests/microbench/drift_probe.py: 5e-5 .. 1.2e-4 at step 2); the total stays within 1e-4
         np.testing.assert_allclose(step.partials[:7].cpu().numpy(), [float(x.detach()) for x in partials_o],
                                    rtol=1e-4 if s == 0 else 5e-4)
+        dp = {k: step.ctx["dp"][k].detach().cpu().clone() for k in ("h1", "h2")}
         h = step.backward()
         if s == 0:
-            named = dict(m.named_parameters())
-            for k in names:
-                a, b = named[k].grad.double().cpu(), prm[k].grad.double()
-                assert float((a - b).norm() / (b.norm() + 1e-30)) < 1e-3, k
+            bad = {k: e for k, e in rel_errors().items() if not e < 1e-3}
+            if bad:
+                # the native arithmetic is held to the untouched oracle, full stop
+                assert precision == "fp32x3", bad
+                assert not any(k.startswith(_NOT_BEHIND_POSE_RELU) for k in bad), bad
+                opt.zero_grad()
+                buf.update(buf0)                   # (the second run starts from the same running statistics)
+                with _ReluKnifeEdges(dp, step.pass_p, B) as knife:
+                    _, loss_k, _ = O.evaluate_mvae(prm, inputs, targets, eps[7 * s:7 * s + 7], masks[8 * s:8 * s + 8], klw,
+                                                   1000.0, True, buf)
+                assert 1 <= knife.flips <= 3, knife.flips          # (B = 130, fp32x3, r4 kernels: 1)
+                loss_k.backward()
+                assert float(loss_k.detach()) == pytest.approx(float(loss_o.detach()), rel=1e-6)
+                for k, e in rel_errors().items():
+                    assert e < 1e-3, (k, e)
         step.optimizer_step(h)
         opt.step()
 
