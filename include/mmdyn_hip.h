@@ -73,7 +73,13 @@ int mmdyn_abi_version(void);
  *            that straddle two blocks there: ws must hold mmdyn_igemm_slab_floats(...) floats whenever that query answers
  *            > 0 (MMDYN_ERR_NULL otherwise); NULL is fine when it answers 0.  Same rule for mmdyn_igemm_nt_mx
  *            (mmdyn_igemm_slab_floats_mx).
+ *   arrival_flags (mmdyn_igemm_nt_mx, _dgrad_bn, _dgrad_act; revision 6): MMDYN_IGEMM_FLAG_WORDS uint32 words that are ZERO when the
+ *            launch starts and that the launch leaves zero, owned by this launch until it has completed (a launch captured
+ *            into a graph owns them for the graph's life).  With them the persistent kernel finishes a tile whose K range
+ *            straddles several blocks INSIDE the launch -- the piece that arrives last on the tile's word sums the pieces in K
+ *            order and runs the epilogue: same results bit for bit, no fix-up launch.  NULL: slabs + the fix-up launch.
  * Requirements: Cin % 32 == 0, N % 32 == 0.  v_mfma_f32_32x32x2_f32, fp32 in / fp32 accumulate. */
+#define MMDYN_IGEMM_FLAG_WORDS 8192
 int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
                    float* stats, float* ws, int mode, int G, int Bg, int Hi, int Wi, int Cin,
                    int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
@@ -86,7 +92,7 @@ int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C,
  * ws: workspace of mmdyn_igemm_slab_floats(...) floats (NULL when that is 0). */
 int mmdyn_igemm_nt_dgrad_act(const void* A, const void* Bp, void* C, const void* u, int act, int mode, int G, int Bg,
                              int Hi, int Wi, int Cin, int Ho, int Wo, int N, int stride, int offset, int flags,
-                             float* ws, void* stream);
+                             float* ws, uint32_t* arrival_flags, void* stream);
 /* Input-gradient GEMM with the BatchNorm+Swish backward of the PRECEDING layer fused into its epilogue.
  * The tile of dL/d(activation) never reaches HBM as such: with y the layer's saved pre-BatchNorm output (same
  * rows/columns as C) and xhat = (y - mean[g]) * rstd[g], the kernel writes
@@ -100,7 +106,7 @@ int mmdyn_igemm_nt_dgrad_act(const void* A, const void* Bp, void* C, const void*
 int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C, float* stats, const float* y,
                             const float* mean, const float* rstd, const float* gamma, const float* beta,
                             int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
-                            int stride, int offset, int bf16, float* ws, void* stream);
+                            int stride, int offset, int bf16, float* ws, uint32_t* arrival_flags, void* stream);
 /* Workspace (floats) the fp32 launch of a shape wants in its `ws` argument when it is not split over K: the persistent,
  * stream-K-scheduled ring kernel (csrc/igemm_wsp.hip) accumulates a tile whose K range straddles two blocks in pieces and
  * parks the pieces there for its fix-up launch.  0 = none (ws may be NULL). */
@@ -485,7 +491,7 @@ int mmdyn_resize_u8_to_chw_f32(const uint8_t* src, const int* index, float* dst,
 int mmdyn_igemm_nt_mx(const void* A, const void* Bp, const float* bias, void* C, void* C_act, float* stats,
                       float* ws, const void* y, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
-                      int ldc, int stride, int offset, int act, int splitk, int flags, void* stream);
+                      int ldc, int stride, int offset, int act, int splitk, int flags, uint32_t* arrival_flags, void* stream);
 int mmdyn_wgrad_tn_mx(const void* D, const void* Gt, float* partial, int mode, int Bt, int Hr, int Wr, int Cd, int Hi,
                       int Wi, int Cg, int stride, int offset, int chunks, int flags, void* stream);
 /* The exact three-term bf16 split of an fp32 matrix, stored for the plane launches above: x [rows][C] fp32 ->

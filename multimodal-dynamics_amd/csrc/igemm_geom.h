@@ -40,6 +40,9 @@ struct IgemmGeom {
   int b_group_stride, bias_group_stride;
   int x3;          // fp32 launch on the bf16 matrix cores through the exact three-term operand split (igemm_nt.hip, X3)
   int tap_order;   // ring kernels, stride-2 CONV: the four taps of one input-pixel class back to back (0 = raster order)
+  // persistent stream-K kernels (igemm_wsp.hip): arrival words of the split tiles, MMDYN_IGEMM_FLAG_WORDS zeroed uint32 the launch
+  // leaves zero -- the tiles are then finished inside the launch; nullptr: slabs + the fix-up launch
+  unsigned* flags;
 };
 
 // igemm_d16.hip: fp32 implicit GEMM on v_mfma_f32_16x16x4_f32 with operand fragments loaded straight from global

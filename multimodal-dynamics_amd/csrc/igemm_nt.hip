@@ -983,7 +983,7 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
                        void* stream, bool bf16, const float* bn_y = nullptr, const float* bn_mean = nullptr,
                        const float* bn_rstd = nullptr, const float* bn_gamma = nullptr,
                        const float* bn_beta = nullptr, int storage_flags = 0, int b_group_stride = 0,
-                       int bias_group_stride = 0) {
+                       int bias_group_stride = 0, uint32_t* arrival_flags = nullptr) {
   if (!A || !Bp || !C) return MMDYN_ERR_NULL;
   if (Cin <= 0 || N <= 0 || Cin % BK || N % 32 || G <= 0 || Bg <= 0 || ldc < N) return MMDYN_ERR_SHAPE;
   if (splitk < 1) splitk = 1;
@@ -1031,6 +1031,7 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   g.want_act_out = C_act != nullptr;
   g.b_group_stride = b_group_stride;
   g.bias_group_stride = bias_group_stride;
+  g.flags = arrival_flags;
   g.splitk = splitk;
   g.nclasses = 1;
   g.os = 1;
@@ -1159,24 +1160,24 @@ extern "C" int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias
 extern "C" int mmdyn_igemm_nt_dgrad_bn(const float* A, const float* Bp, float* C, float* stats, const float* y,
                                        const float* mean, const float* rstd, const float* gamma, const float* beta,
                                        int mode, int G, int Bg, int Hi, int Wi, int Cin, int Ho, int Wo, int N,
-                                       int stride, int offset, int bf16, float* ws, void* stream) {
+                                       int stride, int offset, int bf16, float* ws, uint32_t* flags, void* stream) {
   if (!stats || !y || !mean || !rstd || !gamma || !beta) return MMDYN_ERR_NULL;
   if (bf16 < 0 || bf16 > 4) return MMDYN_ERR_SHAPE;        // (3: fp32 arithmetic, the three-term split allowed; 4: A and Bp arrive split)
   return igemm_entry(A, Bp, nullptr, C, nullptr, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride, offset,
                      MMDYN_ACT_NONE, 1, stream, bf16 == 1 || bf16 == 2, y, mean, rstd, gamma, beta,
-                     bf16 == 2 ? 32 : bf16 == 3 ? 128 : bf16 == 4 ? 384 : 0);
+                     bf16 == 2 ? 32 : bf16 == 3 ? 128 : bf16 == 4 ? 384 : 0, 0, 0, flags);
 }
 
 /* Input-gradient GEMM with the backward of a plain ACTIVATION in its epilogue: C = (A x Bp) * act'(u), u the layer's saved
  * pre-activation, same rows / columns as C.  flags as mmdyn_igemm_nt_mx (bit 3: u is bf16); 0 = fp32 everywhere. */
 extern "C" int mmdyn_igemm_nt_dgrad_act(const void* A, const void* Bp, void* C, const void* u, int act, int mode, int G, int Bg,
                                         int Hi, int Wi, int Cin, int Ho, int Wo, int N, int stride, int offset, int flags,
-                                        float* ws, void* stream) {
+                                        float* ws, uint32_t* arrival_flags, void* stream) {
   if (!u) return MMDYN_ERR_NULL;
   if (act != MMDYN_ACT_SWISH && act != MMDYN_ACT_RELU) return MMDYN_ERR_SHAPE;
   return igemm_entry((const float*)A, (const float*)Bp, nullptr, (float*)C, nullptr, nullptr, ws, mode, G, Bg, Hi, Wi, Cin,
                      Ho, Wo, N, N, stride, offset, act, 1, stream, (flags & 1) != 0 || (flags & 32) != 0, (const float*)u, nullptr,
-                     nullptr, nullptr, nullptr, flags & ~1);
+                     nullptr, nullptr, nullptr, flags & ~1, 0, 0, arrival_flags);
 }
 
 /* fp16 matrix cores (v_mfma_f32_32x32x16_f16): operands rounded to IEEE half (RNE) on their way into the MFMA, fp32
@@ -1195,11 +1196,11 @@ extern "C" int mmdyn_igemm_nt_mx(const void* A, const void* Bp, const float* bia
                                  float* ws, const void* bn_y, const float* bn_mean, const float* bn_rstd,
                                  const float* bn_gamma, const float* bn_beta, int mode, int G, int Bg, int Hi, int Wi,
                                  int Cin, int Ho, int Wo, int N, int ldc, int stride, int offset, int act, int splitk,
-                                 int flags, void* stream) {
+                                 int flags, uint32_t* arrival_flags, void* stream) {
   if (bn_y && (!stats || !bn_mean || !bn_rstd || !bn_gamma || !bn_beta)) return MMDYN_ERR_NULL;
   return igemm_entry((const float*)A, (const float*)Bp, bias, (float*)C, (float*)C_act, stats, ws, mode, G, Bg, Hi, Wi, Cin, Ho,
                      Wo, N, ldc, stride, offset, act, splitk, stream, (flags & 1) != 0, (const float*)bn_y, bn_mean,
-                     bn_rstd, bn_gamma, bn_beta, flags & ~1);
+                     bn_rstd, bn_gamma, bn_beta, flags & ~1, 0, 0, arrival_flags);
 }
 
 /* Grouped dense GEMM: G independent problems of ONE shape in one launch -- C_g[rows][N] = A_g[rows][K] . Bp_g[N][K]^T (+ bias_g),

@@ -292,6 +292,69 @@ __device__ __forceinline__ void wsp_epilogue(f32x4v (&acc)[WM / 16][WN / 16], co
   }
 }
 
+// ---- split tiles finished INSIDE the launch (round 6) ----
+// A tile whose K range straddles the ranges of several blocks is finished by whichever of its pieces' owners ARRIVES LAST -- no
+// block ever waits for another one, so there is no progress assumption about dispatch order or co-residency (the lanes' persistent
+// kernels share the chip).  Per MFMA wave (the slab regions are per wave and the fragment layout is the same in every block, so
+// wave w only needs wave w of the other blocks: no block-level hand-off, the ring's barrier count is untouched): the piece is stored
+// WRITE-THROUGH (sc1 stores -- no release fence, which would write back the L2's dirty lines of whatever the other lane is
+// running), drained (s_waitcnt vmcnt(0)) and counted on the tile's arrival word (agent-scope fetch-add).  The wave that draws the
+// last ticket takes one agent-scope acquire, adds the pieces in piece (= K) order -- its own from registers, the others with
+// agent-scope loads: the additions of igemm_wsp_fixup_kernel, bit for bit, whoever arrives last --, puts the word back to zero
+// (a replay finds it zero) and runs the epilogue.  `flags`: one word per (block range, MFMA wave), indexed by the range that owns
+// the tile's FIRST piece; zero at launch (mmdyn_hip/ops.py hands out a zeroed block per launch site).
+// Returns true when this wave finished the tile (`acc` then holds the whole tile and the caller runs the epilogue).
+template <int MT, int NT, int NM>
+__device__ __forceinline__ bool wsp_arrive_and_sum(f32x4v (&acc)[MT][NT], float* slabs, unsigned* flags, const int ub, const int ue,
+                                                   const int per, const int rb, const bool first_seg, const int mw, const int lane) {
+  constexpr int SLAB = MT * NT * 256;
+  float* mine = slabs + ((size_t)(rb * 2 + (first_seg ? 0 : 1)) * NM + mw) * SLAB;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st_wt(mine + ((mt * NT + nt) * 64 + lane) * 4 + e, acc[mt][nt][e]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the piece has left the core before it is counted
+  const int b0 = ub / per, npieces = (ue - 1) / per - b0 + 1;
+  unsigned* word = flags + b0 * NM + mw;
+  unsigned t = 0;
+  if (lane == 0) t = __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = __shfl(t, 0, 64);
+  if (t != (unsigned)(npieces - 1)) return false;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  f32x4v sum[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) sum[mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  for (int u = ub; u < ue;) {
+    const int b = u / per;
+    if (b == rb) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) sum[mt][nt] += acc[mt][nt];
+    } else {
+      const float* sb = slabs + ((size_t)(b * 2 + (u == b * per ? 0 : 1)) * NM + mw) * SLAB;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            sum[mt][nt][e] += __hip_atomic_load(sb + ((mt * NT + nt) * 64 + lane) * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    u = min(ue, (b + 1) * per);
+  }
+  if (lane == 0) __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = sum[mt][nt];
+  return true;
+}
+
 // X3 (B16 = 0: fp32 operands in HBM and in the ring): the MFMA waves split their fp32 fragments in registers into three bf16
 // terms (split3_bf16, common.h) and multiply six of the nine plane pairs on v_mfma_f32_16x16x32_bf16 -- the fp32 product at 6/16 of
 // the fp32 matrix time (see X3 at igemm_nt_kernel).  The fragment reads are the fp32 kernel's own: lane (row l&15, quarter h)
@@ -550,6 +613,12 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
     if (DIAG) { const long long c = WSP_STAMP(); d_loop += c; d_epi -= c; }
     if (full) {
       wsp_epilogue<BM, BN, WM, WN, B16>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
+    } else if (g.flags != nullptr) {
+      // a piece of a split tile, finished inside the launch by the piece that arrives last (wsp_arrive_and_sum)
+      if (wsp_arrive_and_sum<MT, NT, NM>(acc, slabs, g.flags, sg.ub, sg.ub + sg.kt, sc.per, rb, cu == u0, mw, lane)) {
+        if (bnbwd) wsp_fetch_y<MT, NT, B16>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
+        wsp_epilogue<BM, BN, WM, WN, B16>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
+      }
     } else {
       // a piece of a split tile: the accumulator fragments as they are, 16 bytes per lane (slot 0: the piece is this block's
       // first segment, slot 1: its last); igemm_wsp_fixup_kernel sums the pieces and runs the epilogue
@@ -768,6 +837,12 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NLD)) void igemm_wsp3
     }
     if (full) {
       wsp_epilogue<BM, BN, WM, WN, 0>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
+    } else if (g.flags != nullptr) {
+      // a piece of a split tile, finished inside the launch by the piece that arrives last (wsp_arrive_and_sum)
+      if (wsp_arrive_and_sum<MT, NT, NM>(acc, slabs, g.flags, sg.ub, sg.ub + sg.kt, sc.per, rb, cu == u0, mw, lane)) {
+        if (bnbwd) wsp_fetch_y<MT, NT, 0>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
+        wsp_epilogue<BM, BN, WM, WN, 0>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
+      }
     } else {
       float* sb = slabs + ((size_t)(rb * 2 + (cu == u0 ? 0 : 1)) * NM + mw) * (MT * NT * 256);
 #pragma unroll
@@ -960,9 +1035,10 @@ static int wsp_launch(const float* A, const float* Bp, const float* bias, float*
       if (int e = x3_opt_in.ensure((const void*)igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, 0, false, true>, (int)smemx)) return e;
       const bool splitx = has_split_tiles(g, sc);
       if (splitx && !slabs) return MMDYN_ERR_NULL;
+      if (!splitx || nblkx * NMx > MMDYN_IGEMM_FLAG_WORDS) g.flags = nullptr;     // (flags: split tiles are finished inside the launch)
       hipLaunchKernelGGL((igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, 0, false, true>), dim3(nblkx), dim3(64 * (NMx + NL)), smemx, st, A,
                          Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes);
-      if (splitx)
+      if (splitx && !g.flags)
         hipLaunchKernelGGL((igemm_wsp_fixup_kernel<MODE, BM, BN, WM, WN, 0>), dim3(sc.tiles), dim3(64 * NMx), 0, st, bias, C, C_act,
                            stats, slabs, g, sc);
       MMDYN_LAUNCH_CHECK();
@@ -977,6 +1053,7 @@ static int wsp_launch(const float* A, const float* Bp, const float* bias, float*
   if (int e = lds_opt_in.ensure((const void*)igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16>, (int)smem)) return e;
   const bool split = has_split_tiles(g, sc);
   if (split && !slabs) return MMDYN_ERR_NULL;
+  if (!split || nblk * NM > MMDYN_IGEMM_FLAG_WORDS) g.flags = nullptr;
 #ifdef MMDYN_LAB
   if constexpr (B16 == 0 && MODE != MMDYN_DENSE) {
     const char* e = lab_env("MMDYN_WSP_DIAG");
@@ -985,7 +1062,7 @@ static int wsp_launch(const float* A, const float* Bp, const float* bias, float*
       if (int er = diag_opt_in.ensure((const void*)igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16, true>, (int)smem)) return er;
       hipLaunchKernelGGL((igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16, true>), dim3(nblk), dim3(64 * (NM + NL)), smem, st, A, Bp,
                          bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes);
-      if (split)
+      if (split && !g.flags)
         hipLaunchKernelGGL((igemm_wsp_fixup_kernel<MODE, BM, BN, WM, WN, B16>), dim3(sc.tiles), dim3(64 * NM), 0, st, bias, C, C_act,
                            stats, slabs, g, sc);
       MMDYN_LAUNCH_CHECK();
@@ -994,7 +1071,7 @@ static int wsp_launch(const float* A, const float* Bp, const float* bias, float*
 #endif
   hipLaunchKernelGGL((igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16>), dim3(nblk), dim3(64 * (NM + NL)), smem, st, A, Bp, bias, C,
                      C_act, stats, slabs, g, sc, a_bytes, b_bytes);
-  if (split)
+  if (split && !g.flags)
     hipLaunchKernelGGL((igemm_wsp_fixup_kernel<MODE, BM, BN, WM, WN, B16>), dim3(sc.tiles), dim3(64 * NM), 0, st, bias, C, C_act,
                        stats, slabs, g, sc);
   MMDYN_LAUNCH_CHECK();
@@ -1058,9 +1135,10 @@ static int wsp3_launch(const bf16_t* A, const bf16_t* Bp, const float* bias, flo
   if (int e = opt_in.ensure((const void*)igemm_wsp3_kernel<MODE, BM, BN, WM, WN, S, P3_NLD>, (int)smem)) return e;
   const bool split = has_split_tiles(g, sc);
   if (split && !slabs) return MMDYN_ERR_NULL;
+  if (!split || nblk * NM > MMDYN_IGEMM_FLAG_WORDS) g.flags = nullptr;      // (flags: split tiles are finished inside the launch)
   hipLaunchKernelGGL((igemm_wsp3_kernel<MODE, BM, BN, WM, WN, S, P3_NLD>), dim3(nblk), dim3(64 * (NM + P3_NLD)), smem, st, A, Bp,
                      bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes);
-  if (split)
+  if (split && !g.flags)
     hipLaunchKernelGGL((igemm_wsp_fixup_kernel<MODE, BM, BN, WM, WN, 0>), dim3(sc.tiles), dim3(64 * NM), 0, st, bias, C, C_act,
                        stats, slabs, g, sc);
   MMDYN_LAUNCH_CHECK();

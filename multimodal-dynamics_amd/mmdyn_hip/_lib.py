@@ -32,8 +32,8 @@ ABI_VERSION = 6          # MMDYN_ABI_VERSION of the include/mmdyn_hip.h this tab
 _SIGNATURES = {
     "mmdyn_abi_version": "",
     "mmdyn_igemm_nt": "ppppppp" + "iiiiiiiiiiiiii" + "p",
-    "mmdyn_igemm_nt_dgrad_bn": "ppppppppp" + "iiiiiiiiiiii" + "pp",
-    "mmdyn_igemm_nt_dgrad_act": "pppp" + "i" + "iiiiiiiiiii" + "i" + "pp",
+    "mmdyn_igemm_nt_dgrad_bn": "ppppppppp" + "iiiiiiiiiiii" + "ppp",
+    "mmdyn_igemm_nt_dgrad_act": "pppp" + "i" + "iiiiiiiiiii" + "i" + "ppp",
     "mmdyn_igemm_slab_floats": "iiiiiiiii",
     "mmdyn_igemm_nt_bf16": "ppppppp" + "iiiiiiiiiiiiii" + "p",
     "mmdyn_igemm_nt_f16": "ppppppp" + "iiiiiiiiiiiiii" + "p",
@@ -102,7 +102,7 @@ _SIGNATURES = {
     "mmdyn_adam_step": "ppppp" + "l" + "fffff" + "p",
     "mmdyn_adam_step_guarded": "ppppp" + "l" + "fffff" + "p",
     "mmdyn_sgd_step": "ppp" + "l" + "ffff" + "i" + "p",
-    "mmdyn_igemm_nt_mx": "pppppppppppp" + "iiiiiiiiiiiiii" + "i" + "p",
+    "mmdyn_igemm_nt_mx": "pppppppppppp" + "iiiiiiiiiiiiii" + "i" + "pp",
     "mmdyn_wgrad_tn_mx": "ppp" + "iiiiiiiiiii" + "i" + "p",
     "mmdyn_split_planes": "pp" + "l" + "i" + "p",
     "mmdyn_igemm_planes_served": "iiiiiiiii",

@@ -101,6 +101,7 @@ class HipBackend:
         self._l, self._lib_path = None, lib_path       # lib_path: the LAB build (tests / microbenchmarks only)
         self._tickets = {}                             # device -> [zeroed int32 pool, next eager slot, next graph slot, free graph slots]
         self._drawn = None                             # (device, slot) pairs drawn by captured launches since ticket_mark()
+        self.use_flags = True
         self._flagpool = {}                            # device -> [zeroed int32 pool, next eager block, next graph block, free graph blocks]
         self.force_ticket = False
         # "fp32": v_mfma_f32_32x32x2_f32 (the reference's arithmetic, the default and the BASELINE configs[1] path);
@@ -156,7 +157,7 @@ class HipBackend:
     FLAG_BLOCKS, FLAG_WORDS = 1024, 8192
 
     def _flags(self, like):
-        if os.environ.get("MMDYN_NO_FLAGS"):
+        if not self.use_flags:       # (A/B measurements and the bit-equality test against the two-launch form)
             return None
         dev = like.device
         ent = self._flagpool.get(dev)
@@ -307,7 +308,7 @@ class HipBackend:
                 ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, planes=True)
             check(self.lib.mmdyn_igemm_nt_mx(pa, pb, _ptr(bias), _ptr(C), _ptr(C_act), _ptr(stats), _ptr(ws), None, None, None, None,
                                              None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, 384,
-                                             _stream()), "mmdyn_igemm_nt_mx")
+                                             self._flags(C) if ws is not None and splitk == 1 else None, _stream()), "mmdyn_igemm_nt_mx")
             return
         (pa, a16), (pc, c16), (pca, ca16), (pb, b16) = _aptr(A), _aptr(C), _aptr(C_act), _aptr(Bp)
         self._check_stat_tiles(stats, bool(a16 and b16), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
@@ -320,7 +321,8 @@ class HipBackend:
             check(self.lib.mmdyn_igemm_nt_mx(pa, pb, _ptr(bias), pc, pca, _ptr(stats), _ptr(ws), None, None, None,
                                              None, None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act,
                                              splitk, self._mx(a16, c16, ca16, b16) | (2 if a16 else 0) | (4 if c16 else 0) |
-                                             (16 if b16 else 0) | (64 if mixed_out else 0), _stream()), "mmdyn_igemm_nt_mx")
+                                             (16 if b16 else 0) | (64 if mixed_out else 0),
+                                             self._flags(C) if ws is not None and splitk == 1 else None, _stream()), "mmdyn_igemm_nt_mx")
             return
         fn = {"fp32": self.lib.mmdyn_igemm_nt, "fp16": self.lib.mmdyn_igemm_nt_f16,
               "fp16s": self.lib.mmdyn_igemm_nt_f16}.get(self.precision, self.lib.mmdyn_igemm_nt_bf16)
@@ -329,7 +331,7 @@ class HipBackend:
         if self._x3():
             check(self.lib.mmdyn_igemm_nt_mx(pa, pb, _ptr(bias), pc, pca, _ptr(stats), _ptr(ws), None, None, None, None, None,
                                              mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, 128,
-                                             _stream()), "mmdyn_igemm_nt_mx")
+                                             self._flags(C) if ws is not None and splitk == 1 else None, _stream()), "mmdyn_igemm_nt_mx")
             return
         check(fn(pa, _ptr(Bp), _ptr(bias), pc, pca, _ptr(stats), _ptr(ws),
                  mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, _stream()), "mmdyn_igemm_nt")
@@ -342,7 +344,7 @@ class HipBackend:
             ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, planes=True)
             check(self.lib.mmdyn_igemm_nt_dgrad_bn(pa, pb, _ptr(C), _ptr(stats), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma),
                                                    _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset, 4, _ptr(ws),
-                                                   _stream()), "mmdyn_igemm_nt_dgrad_bn")
+                                                   self._flags(C) if ws is not None else None, _stream()), "mmdyn_igemm_nt_dgrad_bn")
             return
         (pa, a16), (pc, c16), (py, y16), (pb, b16) = _aptr(A), _aptr(C), _aptr(y), _aptr(Bp)
         self._check_stat_tiles(stats, bool(a16 and b16), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
@@ -351,13 +353,14 @@ class HipBackend:
             check(self.lib.mmdyn_igemm_nt_mx(pa, pb, None, pc, None, _ptr(stats), _ptr(ws), py, _ptr(mean), _ptr(rstd),
                                              _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, N, stride,
                                              offset, ACT_NONE, 1, self._mx(a16, c16, y16, b16) | (2 if a16 else 0) | (4 if c16 else 0) |
-                                             (8 if y16 else 0) | (16 if b16 else 0), _stream()), "mmdyn_igemm_nt_mx")
+                                             (8 if y16 else 0) | (16 if b16 else 0), self._flags(C) if ws is not None else None,
+                                             _stream()), "mmdyn_igemm_nt_mx")
             return
         ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N)
         check(self.lib.mmdyn_igemm_nt_dgrad_bn(pa, _ptr(Bp), pc, _ptr(stats), py, _ptr(mean), _ptr(rstd),
                                                _ptr(gamma), _ptr(beta), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride,
                                                offset, 3 if self._x3() else {"fp32": 0, "fp16": 2, "fp16s": 2}.get(self.precision, 1), _ptr(ws),
-                                               _stream()),
+                                               self._flags(C) if ws is not None else None, _stream()),
               "mmdyn_igemm_nt_dgrad_bn")
 
     def igemm_nt_dgrad_act(self, A, Bp, C, u, act, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset):
@@ -366,7 +369,8 @@ class HipBackend:
             pa, pb = self._planes_pair(A, Bp, Cin)
             ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, planes=True)
             check(self.lib.mmdyn_igemm_nt_dgrad_act(pa, pb, _ptr(C), _ptr(u), int(act), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride,
-                                                    offset, 384, _ptr(ws), _stream()), "mmdyn_igemm_nt_dgrad_act")
+                                                    offset, 384, _ptr(ws), self._flags(C) if ws is not None else None, _stream()),
+                  "mmdyn_igemm_nt_dgrad_act")
             return
         (pa, a16), (pc, c16), (pu, u16), (pb, b16) = _aptr(A), _aptr(C), _aptr(u), _aptr(Bp)
         flags = {"fp32": self._x3(), "fp16": 32, "fp16s": 32}.get(self.precision, 1)
@@ -375,7 +379,8 @@ class HipBackend:
         flags |= (2 if a16 else 0) | (4 if c16 else 0) | (8 if u16 else 0) | (16 if b16 else 0)
         ws = self._slabs(A, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, all16=bool(a16 and b16)) if (flags in (0, 128) or (a16 and b16)) else None
         check(self.lib.mmdyn_igemm_nt_dgrad_act(pa, pb, pc, pu, int(act), mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, stride, offset,
-                                                flags, _ptr(ws), _stream()), "mmdyn_igemm_nt_dgrad_act")
+                                                flags, _ptr(ws), self._flags(C) if ws is not None else None, _stream()),
+              "mmdyn_igemm_nt_dgrad_act")
 
     def igemm_nt_grouped(self, A, Bp, bias, C, C_act, u, G, rows, K, N, act):
         """G dense GEMMs of one shape in one launch: A [G*rows][K], Bp [G][N][K], bias [G][N] | None, C [G*rows][N];
