@@ -280,6 +280,9 @@ def main():
                          "taking them already split where the plane-ring kernel serves the launch")
     ap.add_argument("--no-patch-planes", action="store_true",
                     help="A/B switch (f32x3): the 32-channel up-sampling layers (tconv_patch_kernel) keep fp32 operands")
+    ap.add_argument("--fixup-launch", action="store_true",
+                    help="A/B switch: the persistent stream-K kernels park the pieces of split tiles and a fix-up launch sums them "
+                         "(rounds 4-5) instead of finishing those tiles inside the launch")
     ap.add_argument("--single-lane", action="store_true",
                     help="no visual/tactile stream overlap: per-kernel durations in a rocprofv3 trace then match "
                          "the roofline object's live HIP-event measurement")
@@ -332,6 +335,9 @@ def main():
     from mmdyn_hip.engine import MVAEStep
     from mmdyn_hip.models import setup_model, NoiseSource
     from mmdyn_hip.profiling import profile_step
+    if args.fixup_launch:
+        from mmdyn_hip import ops as _ops2
+        _ops2.B.use_flags = False
     if args.no_planes:
         from mmdyn_hip import layers as _layers
         _layers.PLANES = False

@@ -299,8 +299,8 @@ __device__ __forceinline__ void wsp_epilogue(f32x4v (&acc)[WM / 16][WN / 16], co
 // wave w only needs wave w of the other blocks: no block-level hand-off, the ring's barrier count is untouched): the piece is stored
 // WRITE-THROUGH (sc1 stores -- no release fence, which would write back the L2's dirty lines of whatever the other lane is
 // running), drained (s_waitcnt vmcnt(0)) and counted on the tile's arrival word (agent-scope fetch-add).  The wave that draws the
-// last ticket takes one agent-scope acquire, adds the pieces in piece (= K) order -- its own from registers, the others with
-// agent-scope loads: the additions of igemm_wsp_fixup_kernel, bit for bit, whoever arrives last --, puts the word back to zero
+// last ticket takes one agent-scope acquire, adds the pieces in piece (= K) order with agent-scope loads -- the additions of
+// igemm_wsp_fixup_kernel, bit for bit, whoever arrives last --, puts the word back to zero
 // (a replay finds it zero) and runs the epilogue.  `flags`: one word per (block range, MFMA wave), indexed by the range that owns
 // the tile's FIRST piece; zero at launch (mmdyn_hip/ops.py hands out a zeroed block per launch site).
 // Returns true when this wave finished the tile (`acc` then holds the whole tile and the caller runs the epilogue).
@@ -323,35 +323,25 @@ __device__ __forceinline__ bool wsp_arrive_and_sum(f32x4v (&acc)[MT][NT], float*
   t = __shfl(t, 0, 64);
   if (t != (unsigned)(npieces - 1)) return false;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  f32x4v sum[MT][NT];
+  // every piece comes back from its slab, this wave's own included (8 KB it has just written through): one accumulator set, the
+  // same code whoever arrives last, 0 + p0 + p1 + ... in piece order
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) sum[mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
   for (int u = ub; u < ue;) {
     const int b = u / per;
-    if (b == rb) {
+    const float* sb = slabs + ((size_t)(b * 2 + (u == b * per ? 0 : 1)) * NM + mw) * SLAB;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) sum[mt][nt] += acc[mt][nt];
-    } else {
-      const float* sb = slabs + ((size_t)(b * 2 + (u == b * per ? 0 : 1)) * NM + mw) * SLAB;
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            sum[mt][nt][e] += __hip_atomic_load(sb + ((mt * NT + nt) * 64 + lane) * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+        for (int e = 0; e < 4; ++e)
+          acc[mt][nt][e] += __hip_atomic_load(sb + ((mt * NT + nt) * 64 + lane) * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u = min(ue, (b + 1) * per);
   }
   if (lane == 0) __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = sum[mt][nt];
   return true;
 }
 
@@ -611,23 +601,24 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
       }
     }
     if (DIAG) { const long long c = WSP_STAMP(); d_loop += c; d_epi -= c; }
-    if (full) {
-      wsp_epilogue<BM, BN, WM, WN, B16>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
-    } else if (g.flags != nullptr) {
-      // a piece of a split tile, finished inside the launch by the piece that arrives last (wsp_arrive_and_sum)
-      if (wsp_arrive_and_sum<MT, NT, NM>(acc, slabs, g.flags, sg.ub, sg.ub + sg.kt, sc.per, rb, cu == u0, mw, lane)) {
-        if (bnbwd) wsp_fetch_y<MT, NT, B16>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
-        wsp_epilogue<BM, BN, WM, WN, B16>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
+    bool finish = full;
+    if (!full) {
+      if (g.flags != nullptr) {
+        // a piece of a split tile, finished inside the launch by the piece that arrives last (wsp_arrive_and_sum)
+        finish = wsp_arrive_and_sum<MT, NT, NM>(acc, slabs, g.flags, sg.ub, sg.ub + sg.kt, sc.per, rb, cu == u0, mw, lane);
+        if (finish && bnbwd) wsp_fetch_y<MT, NT, B16>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
+      } else {
+        // a piece of a split tile: the accumulator fragments as they are, 16 bytes per lane (slot 0: the piece is this block's
+        // first segment, slot 1: its last); igemm_wsp_fixup_kernel sums the pieces and runs the epilogue
+        float* sb = slabs + ((size_t)(rb * 2 + (cu == u0 ? 0 : 1)) * NM + mw) * (MT * NT * 256);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4v*>(sb + ((mt * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
       }
-    } else {
-      // a piece of a split tile: the accumulator fragments as they are, 16 bytes per lane (slot 0: the piece is this block's
-      // first segment, slot 1: its last); igemm_wsp_fixup_kernel sums the pieces and runs the epilogue
-      float* sb = slabs + ((size_t)(rb * 2 + (cu == u0 ? 0 : 1)) * NM + mw) * (MT * NT * 256);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4v*>(sb + ((mt * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
     }
+    if (finish)
+      wsp_epilogue<BM, BN, WM, WN, B16>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
     if (DIAG) d_epi += WSP_STAMP();
     cu += ke - kb;
   }
@@ -835,21 +826,21 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NLD)) void igemm_wsp3
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[order[t][0]], bp[order[t][1]][nt], acc[mt][nt], 0, 0, 0);
       }
     }
-    if (full) {
-      wsp_epilogue<BM, BN, WM, WN, 0>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
-    } else if (g.flags != nullptr) {
-      // a piece of a split tile, finished inside the launch by the piece that arrives last (wsp_arrive_and_sum)
-      if (wsp_arrive_and_sum<MT, NT, NM>(acc, slabs, g.flags, sg.ub, sg.ub + sg.kt, sc.per, rb, cu == u0, mw, lane)) {
-        if (bnbwd) wsp_fetch_y<MT, NT, 0>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
-        wsp_epilogue<BM, BN, WM, WN, 0>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
+    bool finish = full;
+    if (!full) {
+      if (g.flags != nullptr) {
+        // a piece of a split tile, finished inside the launch by the piece that arrives last (wsp_arrive_and_sum)
+        finish = wsp_arrive_and_sum<MT, NT, NM>(acc, slabs, g.flags, sg.ub, sg.ub + sg.kt, sc.per, rb, cu == u0, mw, lane);
+        if (finish && bnbwd) wsp_fetch_y<MT, NT, 0>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
+      } else {
+        float* sb = slabs + ((size_t)(rb * 2 + (cu == u0 ? 0 : 1)) * NM + mw) * (MT * NT * 256);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4v*>(sb + ((mt * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
       }
-    } else {
-      float* sb = slabs + ((size_t)(rb * 2 + (cu == u0 ? 0 : 1)) * NM + mw) * (MT * NT * 256);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4v*>(sb + ((mt * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
     }
+    if (finish) wsp_epilogue<BM, BN, WM, WN, 0>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
     cu += ke - kb;
   }
 }

@@ -548,7 +548,7 @@ def test_split_tiles_finished_inside_the_launch_equal_the_fixup_launch(x3, arith
     epilogue and on the activation-backward epilogue; launched three times in a row on the same words (they are left zero)."""
     from mmdyn_hip.ops import TCONV_S1P0
     cases = [("s1p0", TCONV_S1P0, 4, 256, 5, 256, 8, 128, 1, 0), ("s1p0", TCONV_S1P0, 1, 256, 5, 256, 8, 128, 1, 0),
-             ("bn", CONV, 4, 256, 16, 64, 8, 128, 2, -1), ("act", CONV, 1, 1024, 8, 128, 5, 256, 1, 0)]
+             ("bn", CONV, 3, 256, 16, 64, 8, 128, 2, -1), ("act", CONV, 1, 1024, 8, 128, 5, 256, 1, 0)]
     prev_split = ops.B.fp32_split
     ops.B.fp32_split = arith != "native"
     try:
