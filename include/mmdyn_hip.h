@@ -312,7 +312,8 @@ int mmdyn_dropout_expand(const float* h, const uint8_t* masks, float* out, int P
                          float p_drop, void* stream);
 int mmdyn_dropout_reduce(const float* dout, const uint8_t* masks, float* dh, int P, int B, int H,
                          float p_drop, const float* u /* nullable [B][H]: dh *= act'(u), the activation in front of the
-                         dropout (vae.py:213-216) */, int act, void* stream);
+                         dropout (vae.py:213-216) */, int act, void* dh_planes /* nullable (revision 6): dh also as a plane tensor,
+                         rows of [plane][H] bf16 -- the operand of a plane launch */, void* stream);
 /* keep-masks / N(0,1) draws from a counter-based Philox-4x32-10 stream (throughput runs; parity runs inject
  * tensors).  The stream position is offset + *offset_dev (offset_dev may be null): keeping the running position
  * in device memory and bumping it with mmdyn_counter_add makes a captured HIP graph draw fresh numbers on replay. */
@@ -361,6 +362,9 @@ typedef struct {
                                            its row block in the stacked input of each decoder that consumes it (the
                                            torch.cat of the subset passes, problems.py:478-529, without a copy launch);
                                            null = none */
+  void* zpl[3];                         /* forward only (revision 6): the same row blocks as PLANE tensors (rows of [plane][L] bf16,
+                                           the exact three-term split: mmdyn_split_planes) for a decoder whose first GEMM takes
+                                           its operand already split; null = none */
 } mmdyn_pass_experts;
 /* P passes of [B][L].  with_prior=1 adds the universal N(0,1) expert first (vae.py:139, 321-328).
  * Outputs mu/logvar [P][B][L]; optional z = eps*exp(logvar/2)+mu; optional kl_sum[p] (double)
@@ -474,6 +478,10 @@ int mmdyn_resize_u8_to_chw_f32(const uint8_t* src, const int* index, float* dst,
  *       2^-126 |w| per product.  An Inf operand gives NaN (inf - inf in the split) where the fp32 matrix cores would give Inf; a
  *       NaN operand gives NaN; no other row of the result is touched.  The library does not guard: non-finite operands do not occur
  *       on this path (the fp16 modes' overflow guard, mmdyn_adam_step_guarded, is not needed in fp32 storage).
+ *       Bit 10 (with bits 7 + 8, DENSE launches; round 6): C_act is written as a plane tensor -- the activated output of a Linear
+ *       layer handed to the next plane launch without a stand-alone split; C stays fp32, ldc == N.  Bits 16-27 = c / 8: the plane
+ *       rows hold c channels, c dividing N (an output row is N / c consecutive plane rows: the decoder's Linear output
+ *       [B][hw*256 + ch] read as [B*25][256] by the transposed convolution above it, vae.py:264-271); 0: rows of [plane][N].
  *       Bits 7 + 8 (flags == 384; mmdyn_igemm_nt_mx, mmdyn_igemm_nt_dgrad_act; mmdyn_igemm_nt_dgrad_bn(bf16 = 4)): the same
  *       arithmetic on operands that ARRIVE SPLIT -- A and Bp are rows of [plane][Cin] bf16 (hi | mid | lo, 6 bytes per element:
  *       mmdyn_split_planes, or written so by their producers) -- so the GEMM itself contains no split: LDS-DMA of the planes, six

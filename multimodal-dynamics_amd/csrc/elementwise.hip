@@ -48,14 +48,27 @@ __global__ void dropout_expand_kernel(const float* __restrict__ h, const uint8_t
 }
 
 // u != nullptr: the backward of the activation in front of the dropout rides along: dh = (sum ...) * act'(u)
+// dh_planes != nullptr (round 6): dh also as a PLANE tensor (rows of [plane][H] bf16, the exact three-term split) -- the operand of
+// the FC layer's input-gradient GEMM where that launch takes its operands already split
 __global__ void dropout_reduce_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ masks,
                                       float* __restrict__ dh, int P, int64_t bh, float scale,
-                                      const float* __restrict__ u, int act) {
+                                      const float* __restrict__ u, int act, bf16_t* __restrict__ dh_planes, int H) {
   for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < bh;
        j += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int p = 0; p < P; ++p) s += dout[(int64_t)p * bh + j] * ((float)masks[(int64_t)p * bh + j] * scale);
-    dh[j] = u ? s * act_grad(u[j], act) : s;
+    const float v = u ? s * act_grad(u[j], act) : s;
+    dh[j] = v;
+    if (dh_planes) {
+      const int64_t row = j / H;
+      const int col = (int)(j - row * H);
+      uint32_t h, m, lo;
+      split3_bf16(v, 0.f, h, m, lo);
+      bf16_t* pr = dh_planes + row * 3 * H + col;
+      pr[0] = (bf16_t)(h & 0xffffu);
+      pr[H] = (bf16_t)(m & 0xffffu);
+      pr[2 * H] = (bf16_t)(lo & 0xffffu);
+    }
   }
 }
 
@@ -508,12 +521,12 @@ extern "C" int mmdyn_dropout_expand(const float* h, const uint8_t* masks, float*
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_dropout_reduce(const float* dout, const uint8_t* masks, float* dh, int P, int B, int H,
-                                    float p_drop, const float* u, int act, void* stream) {
+                                    float p_drop, const float* u, int act, void* dh_planes, void* stream) {
   if (!dout || !masks || !dh) return MMDYN_ERR_NULL;
   if (p_drop < 0.f || p_drop >= 1.f) return MMDYN_ERR_SHAPE;
   int64_t bh = (int64_t)B * H;
   hipLaunchKernelGGL(dropout_reduce_kernel, dim3(ew_grid(bh)), dim3(256), 0, ST, dout, masks, dh, P, bh,
-                     1.0f / (1.0f - p_drop), u, act);
+                     1.0f / (1.0f - p_drop), u, act, reinterpret_cast<bf16_t*>(dh_planes), H);
   MMDYN_LAUNCH_CHECK();
 }
 extern "C" int mmdyn_random_masks(uint8_t* masks, int64_t n, float p_drop, uint64_t seed, uint64_t offset,

@@ -33,6 +33,8 @@ struct IgemmGeom {
   // bf16 activation storage (bf16 matrix-core variants only): which of the activation tensors are bf16 in HBM
   int a_b16, c_b16, bny_b16;
   int cact_b16;   // the second (activated) output is bf16 while C itself is fp32
+  int cact_planes;  // fp32x3 plane launches: the second (activated) output is a PLANE tensor, rows of [plane][cact_planes] bf16
+                    // (cact_planes divides N, ldc == N); 0: a plain tensor
   int f16;     // the 16-bit format is IEEE half instead of bf16 (v_mfma_*_f16): operands, and every tensor the *_b16 fields mark
   int b_b16;   // packed weights are bf16 (written so by the pack kernels in the bf16 modes: half the L2 -> LDS traffic)
   // Grouped launch (mmdyn_igemm_nt_grouped): every group multiplies its OWN weights -- group grp reads Bp + grp * b_group_stride

@@ -1016,7 +1016,14 @@ static int igemm_entry(const float* A, const float* Bp, const float* bias, float
   // bit 8 (with bit 7): A and Bp ARRIVE split -- rows of [plane][Cin] bf16, written by mmdyn_split_planes / the plane kinds of the
   // pack plan / a producing kernel -- and the launch runs igemm_wsp3_kernel: no split anywhere in the GEMM
   const bool planes = (storage_flags & 256) != 0;
-  storage_flags &= ~(128 | 256);
+  // bit 10 (with bits 7 + 8): C_act is written as a plane tensor (the operand of the next plane launch), C stays fp32
+  // (bits 16-27: the plane rows' channel count / 8 when it is not N -- it must divide N: an output row is then N / count plane rows)
+  const bool cact_planes = (storage_flags & 1024) != 0;
+  const int cact_c = ((storage_flags >> 16) & 0xfff) * 8;
+  if (cact_planes && (!planes || !C_act || ldc != N || splitk > 1 || mode != MMDYN_DENSE || (cact_c && (N % cact_c || cact_c % 8))))
+    return MMDYN_ERR_SHAPE;
+  g.cact_planes = cact_planes ? (cact_c ? cact_c : N) : 0;
+  storage_flags &= ~(128 | 256 | 1024 | (0xfff << 16));
   if (x3_allowed && (bf16 || storage_flags)) return MMDYN_ERR_SHAPE;
   if (planes && !x3_allowed) return MMDYN_ERR_SHAPE;
   g.a_b16 = (storage_flags & 2) != 0;

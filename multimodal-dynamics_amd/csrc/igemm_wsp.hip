@@ -259,7 +259,21 @@ __device__ __forceinline__ void wsp_epilogue(f32x4v (&acc)[WM / 16][WN / 16], co
           *reinterpret_cast<f32x4v*>(C + (size_t)oo + col) = v;
           if (g.want_act_out) {
             if (B16 && g.cact_b16) st4<st16_t>(reinterpret_cast<st16_t*>(C_act) + (size_t)oo + col, a);
-            else *reinterpret_cast<f32x4v*>(C_act + (size_t)oo + col) = a;
+            else if (!B16 && g.cact_planes) {
+              // the activated output as a PLANE tensor (rows of [plane][cact_planes] bf16, the exact three-term split; ldc == N): the GEMM that
+              // consumes it takes its operand already split and no stand-alone split launch is needed (round 6)
+              uint32_t h0, m0, l0, h1, m1, l1;
+              split3_bf16(a[0], a[1], h0, m0, l0);
+              split3_bf16(a[2], a[3], h1, m1, l1);
+              typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+              // (plane rows of cact_planes channels: an output row of N columns is N / cact_planes consecutive plane rows -- the
+              //  [B][hw*256 + c] output of the decoder's Linear layer read as [B*25 pixels][256 channels] by the layer above)
+              const int cp = g.cact_planes, cin = col % cp;
+              bf16_t* pr = reinterpret_cast<bf16_t*>(C_act) + (size_t)oo * 3 + (size_t)(col - cin) * 3 + cin;
+              *reinterpret_cast<u32x2v*>(pr) = u32x2v{h0, h1};
+              *reinterpret_cast<u32x2v*>(pr + cp) = u32x2v{m0, m1};
+              *reinterpret_cast<u32x2v*>(pr + 2 * cp) = u32x2v{l0, l1};
+            } else *reinterpret_cast<f32x4v*>(C_act + (size_t)oo + col) = a;
           }
         }
       }
@@ -308,37 +322,45 @@ template <int MT, int NT, int NM>
 __device__ __forceinline__ bool wsp_arrive_and_sum(f32x4v (&acc)[MT][NT], float* slabs, unsigned* flags, const int ub, const int ue,
                                                    const int per, const int rb, const bool first_seg, const int mw, const int lane) {
   constexpr int SLAB = MT * NT * 256;
-  float* mine = slabs + ((size_t)(rb * 2 + (first_seg ? 0 : 1)) * NM + mw) * SLAB;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) st_wt(mine + ((mt * NT + nt) * 64 + lane) * 4 + e, acc[mt][nt][e]);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the piece has left the core before it is counted
   const int b0 = ub / per, npieces = (ue - 1) / per - b0 + 1;
   unsigned* word = flags + b0 * NM + mw;
-  unsigned t = 0;
-  if (lane == 0) t = __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  t = __shfl(t, 0, 64);
-  if (t != (unsigned)(npieces - 1)) return false;
+  // The owner of the tile's FIRST piece reaches it at the END of its range, the others computed theirs first thing: when it finds
+  // every other piece counted already (the usual case) it is the last arriver without publishing anything -- its own piece stays
+  // in registers and the others are added to it in place, p0 + p1 + ...
+  bool head_last = false;
+  if (b0 == rb) head_last = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(npieces - 1);
+  if (!head_last) {
+    float* mine = slabs + ((size_t)(rb * 2 + (first_seg ? 0 : 1)) * NM + mw) * SLAB;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st_wt(mine + ((mt * NT + nt) * 64 + lane) * 4 + e, acc[mt][nt][e]);      // write-through (sc1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the piece has left the core before it is counted
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = __shfl(t, 0, 64);
+    if (t != (unsigned)(npieces - 1)) return false;
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  // every piece comes back from its slab, this wave's own included (8 KB it has just written through): one accumulator set, the
-  // same code whoever arrives last, 0 + p0 + p1 + ... in piece order
+  asm volatile("" ::: "memory");
+  // pieces in K order: 0 + p0 + p1 + ...; a piece of this very wave comes from its registers when it is the first one (head_last),
+  // from its slab otherwise (one accumulator set whoever finishes).  Plain 16-byte loads behind the acquire: eight in flight per piece.
+  if (!head_last) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  for (int u = ub; u < ue;) {
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int u = head_last ? min(ue, (b0 + 1) * per) : ub; u < ue;) {
     const int b = u / per;
     const float* sb = slabs + ((size_t)(b * 2 + (u == b * per ? 0 : 1)) * NM + mw) * SLAB;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc[mt][nt][e] += __hip_atomic_load(sb + ((mt * NT + nt) * 64 + lane) * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc[mt][nt] += __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(sb + ((mt * NT + nt) * 64 + lane) * 4));
     u = min(ue, (b + 1) * per);
   }
   if (lane == 0) __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1140,8 +1162,20 @@ static int wsp3_launch(const bf16_t* A, const bf16_t* Bp, const float* bias, flo
 static Wsp3Cfg wsp3_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr, int Cin, int N, int ncls, int splitk,
                          int b_group_stride) {
   Wsp3Cfg c{0, 0, 0, 0};
-  if (mode != MMDYN_CONV && mode != MMDYN_TCONV_S2P1 && mode != MMDYN_TCONV_S1P0) return c;
+  if (mode != MMDYN_CONV && mode != MMDYN_TCONV_S2P1 && mode != MMDYN_TCONV_S1P0 && mode != MMDYN_DENSE) return c;
   if (splitk > 1 || b_group_stride || Cin % BK || N % 64) return c;
+  if (mode == MMDYN_DENSE) {
+    // FC-level GEMMs (round 6): 128x128 tiles of the plane ring, stream-K over all CUs with the split tiles finished inside the
+    // launch.  Served where the tiles outnumber their K-steps' pieces: at least 4 K-steps of 128x128 work per CU and at most
+    // ~4 pieces per tile (K <= 1024 at one tile per CU) -- the deep-K / few-tile shapes (6400 -> 512 / 256) would hand one block
+    // the sum of 16-32 slabs and stay on split-K + reduce.
+    if (N % 128 || Hi != 1 || Wi != 1 || Hr != 1 || Wr != 1) return c;
+    const int cusd = device_cus();
+    const long tiles = (long)G * ((Bg + 127) / 128) * (N / 128), ks = Cin / BK;
+    if (tiles * ks < 4L * cusd || tiles * 4 < cusd || tiles * ks >= (1L << 30) || Bg >= (1 << 23)) return c;
+    if ((int64_t)G * Bg * Cin * 6 >= MAX_BUFFER_BYTES || (int64_t)N * Cin * 6 >= MAX_BUFFER_BYTES) return c;
+    return Wsp3Cfg{128, 128, 3, 1};
+  }
   if ((int64_t)G * Bg * Hi * Wi * Cin * 6 >= MAX_BUFFER_BYTES || (int64_t)16 * N * Cin * 6 >= MAX_BUFFER_BYTES) return c;
   const int cus = device_cus();
   const int cin_steps = Cin / BK;
@@ -1279,12 +1313,13 @@ int mmdyn_igemm_wsp3_try(const void* A, const void* Bp, const float* bias, float
   g.tap_order = g.mode == MMDYN_CONV && g.rs == 2;
   const WspSched sc = make_sched3(g, c);
   const unsigned a_bytes = (unsigned)((int64_t)g.G * g.Bg * g.Hi * g.Wi * g.Cin * 6);
-  const unsigned b_bytes = (unsigned)((int64_t)16 * g.N * g.Cin * 6);
+  const unsigned b_bytes = (unsigned)((int64_t)(g.mode == MMDYN_DENSE ? 1 : 16) * g.N * g.Cin * 6);
   const bf16_t* Ap = reinterpret_cast<const bf16_t*>(A);
   const bf16_t* Bq = reinterpret_cast<const bf16_t*>(Bp);
 #define P3_GO(MODE_, BM_, BN_, WM_, WN_, S_) \
   return wsp3_launch<MODE_, BM_, BN_, WM_, WN_, S_>(Ap, Bq, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st)
   if (g.mode == MMDYN_TCONV_S1P0) P3_GO(MMDYN_TCONV_S1P0, 128, 128, 64, 32, 3);
+  if (g.mode == MMDYN_DENSE) P3_GO(MMDYN_DENSE, 128, 128, 64, 32, 3);
   if (g.mode == MMDYN_CONV) {
     if (c.bn == 128) P3_GO(MMDYN_CONV, 128, 128, 64, 32, 3);
     if (c.bm == 256) P3_GO(MMDYN_CONV, 256, 64, 128, 16, 2);

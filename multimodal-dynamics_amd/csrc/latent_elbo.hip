@@ -49,8 +49,17 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(PoeArgs args, const float*
       const float zv = eps_noise[o] * expf(0.5f * pd_lv) + pd_mu;
       z_out[o] = zv;
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
+      for (int k = 0; k < 3; ++k) {
         if (e.zdst[k]) e.zdst[k][i] = zv;
+        if (e.zpl[k]) {                  // ... and as a plane row block: hi | mid | lo of the exact three-term split
+          uint32_t h, m, lo;
+          split3_bf16(zv, 0.f, h, m, lo);
+          bf16_t* pr = reinterpret_cast<bf16_t*>(e.zpl[k]) + (size_t)b * 3 * L + l;
+          pr[0] = (bf16_t)(h & 0xffffu);
+          pr[L] = (bf16_t)(m & 0xffffu);
+          pr[2 * L] = (bf16_t)(lo & 0xffffu);
+        }
+      }
     }
     kl += (double)(1.f + pd_lv - pd_mu * pd_mu - expf(pd_lv));
   }

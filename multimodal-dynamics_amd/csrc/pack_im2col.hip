@@ -92,6 +92,13 @@ __device__ __forceinline__ void st1_planes(bf16_t* row_y, int ny, float v) {
   row_y[ny] = (bf16_t)(m & 0xffffu);
   row_y[2 * ny] = (bf16_t)(l & 0xffffu);
 }
+// element (r, c) of a packed 2-D operand with leading dimension ld: a plain tensor, or (PL) a plane tensor -- rows of [plane][ld]
+// bf16, the exact three-term split (round 6: the FC-level weights whose launches take their operands already split)
+template <typename TO, bool PL>
+__device__ __forceinline__ void put_rc(TO* dst, int64_t r, int ld, int c, float v) {
+  if constexpr (PL) st1_planes(reinterpret_cast<bf16_t*>(dst) + r * 3 * ld + c, ld, v);
+  else st1<TO>(dst + r * ld + c, v);
+}
 template <typename TO, bool PLANES = false>
 __device__ __forceinline__ void pack_conv_tiled(const float* __restrict__ src, TO* __restrict__ dst, int d0, int d1, int swap,
                                                 float* lds) {
@@ -128,7 +135,7 @@ __device__ __forceinline__ void pack_conv_tiled(const float* __restrict__ src, T
 }
 
 // kind 2: out[r][hw*256+ch] = in[r][ch*25+hw] (a permutation inside every 6400-float row): one row per tile
-template <typename TO>
+template <typename TO, bool PL = false>
 __device__ __forceinline__ void pack_rowperm_tiled(const mmdyn_pack_entry& e, float* lds) {
   const float* __restrict__ src = e.src;
   TO* __restrict__ dst = reinterpret_cast<TO*>(e.dst);
@@ -142,7 +149,7 @@ __device__ __forceinline__ void pack_rowperm_tiled(const mmdyn_pack_entry& e, fl
     for (int c = threadIdx.x; c < e.cols_out; c += blockDim.x) {
       const int hw = c >> 8, ch = c & 255;
       const int ci = ch * 25 + hw;
-      st1<TO>(dst + (size_t)r * e.ld_out + c, ci < W ? lds[ci] : 0.f);
+      put_rc<TO, PL>(dst, r, e.ld_out, c, ci < W ? lds[ci] : 0.f);
     }
   }
 }
@@ -152,7 +159,7 @@ __device__ __forceinline__ void pack_rowperm_tiled(const mmdyn_pack_entry& e, fl
 //   kind 1: out[r][c] = in[c][r]
 //   kind 4: out[hw*256+ch][c] = in[c][ch*25+hw]        input rows c, input columns ch*25+hw
 //   kind 5: out[r][hw*256+ch] = in[ch*25+hw][r]        input rows ch*25+hw, input columns r
-template <typename TO>
+template <typename TO, bool PL = false>
 __device__ __forceinline__ void pack_transpose_tiled(const mmdyn_pack_entry& e, float* lds) {
   const float* __restrict__ src = e.src;
   TO* __restrict__ dst = reinterpret_cast<TO*>(e.dst);
@@ -208,38 +215,38 @@ __device__ __forceinline__ void pack_transpose_tiled(const mmdyn_pack_entry& e, 
         ro = ci;
         co = hw * 256 + ch;
       }
-      if (ro < e.rows_out && co < e.cols_out) st1<TO>(dst + (size_t)ro * e.ld_out + co, lds[ir * LDT + ic]);
+      if (ro < e.rows_out && co < e.cols_out) put_rc<TO, PL>(dst, ro, e.ld_out, co, lds[ir * LDT + ic]);
     }
   }
 }
 
-template <typename TO>
+template <typename TO, bool PL = false>
 __device__ __forceinline__ void pack_plan_entry(const mmdyn_pack_entry& e, float* lds) {
   const float* __restrict__ src = e.src;
   TO* __restrict__ dst = reinterpret_cast<TO*>(e.dst);
   if (e.kind >= 100) {                       // conv weight: Wc[d0][d1][16] -> P[tap][x][y]
-    pack_conv_tiled<TO>(src, dst, e.rows_in, e.cols_in, e.kind - 100, lds);
+    pack_conv_tiled<TO, PL>(src, dst, e.rows_in, e.cols_in, e.kind - 100, lds);
   } else if (e.kind == 2 && e.cols_in == 6400 && e.cols_out == 6400 && e.cols_in % 4 == 0) {
-    pack_rowperm_tiled<TO>(e, lds);
+    pack_rowperm_tiled<TO, PL>(e, lds);
   } else if (e.kind == 1 || ((e.kind == 4 || e.kind == 5) && (e.kind == 4 ? e.cols_in : e.rows_in) == 6400)) {
     // (zero padding beyond the transposed source is written by the element-wise pass: only when the shapes differ)
     const bool padded = e.kind == 1 ? (e.rows_out != e.cols_in || e.cols_out != e.rows_in)
                                     : (e.kind == 4 ? (e.rows_out != 6400 || e.cols_out != e.rows_in)
                                                    : (e.cols_out != 6400 || e.rows_out != e.cols_in));
     if (!padded) {
-      pack_transpose_tiled<TO>(e, lds);
+      pack_transpose_tiled<TO, PL>(e, lds);
       return;
     }
     const int64_t total = (int64_t)e.rows_out * e.cols_out;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
       int c = (int)(i % e.cols_out), r = (int)(i / e.cols_out);
-      st1<TO>(dst + (int64_t)r * e.ld_out + c, repack_fetch(src, e.rows_in, e.cols_in, r, c, e.kind));
+      put_rc<TO, PL>(dst, r, e.ld_out, c, repack_fetch(src, e.rows_in, e.cols_in, r, c, e.kind));
     }
   } else {                                   // 2-D repack with output leading dimension
     const int64_t total = (int64_t)e.rows_out * e.cols_out;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
       int c = (int)(i % e.cols_out), r = (int)(i / e.cols_out);
-      st1<TO>(dst + (int64_t)r * e.ld_out + c, repack_fetch(src, e.rows_in, e.cols_in, r, c, e.kind));
+      put_rc<TO, PL>(dst, r, e.ld_out, c, repack_fetch(src, e.rows_in, e.cols_in, r, c, e.kind));
     }
   }
 }
@@ -247,8 +254,8 @@ __device__ __forceinline__ void pack_plan_entry(const mmdyn_pack_entry& e, float
 __global__ __launch_bounds__(256) void pack_plan_kernel(const mmdyn_pack_entry* __restrict__ plan) {
   __shared__ __attribute__((aligned(16))) float lds[PACK_LDS_FLOATS];
   const mmdyn_pack_entry e = plan[blockIdx.y];
-  if (e.dst_bf16 == 3) {          // (3: plane tensor -- conv-weight kinds only, checked by mmdyn_pack_plan's caller side)
-    if (e.kind >= 100) pack_conv_tiled<bf16_t, true>(e.src, reinterpret_cast<bf16_t*>(e.dst), e.rows_in, e.cols_in, e.kind - 100, lds);
+  if (e.dst_bf16 == 3) {          // (3: plane tensor -- rows of [plane][ld_out] bf16; conv kinds: rows (tap, x) of [plane][y])
+    pack_plan_entry<bf16_t, true>(e, lds);
   } else if (e.dst_bf16 == 2)     // (2: IEEE half, the fp16-storage mode)
     pack_plan_entry<half_t>(e, lds);
   else if (e.dst_bf16)

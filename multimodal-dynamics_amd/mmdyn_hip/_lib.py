@@ -15,7 +15,7 @@ _P, _I, _L, _F, _Q = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_flo
 class PassExperts(ctypes.Structure):
     """mmdyn_pass_experts (include/mmdyn_hip.h)."""
     _fields_ = [("mu", _P * 4), ("lv", _P * 4), ("dmu", _P * 4), ("dlv", _P * 4), ("ld", _I * 4), ("dz", _P * 3),
-                ("zdst", _P * 3)]
+                ("zdst", _P * 3), ("zpl", _P * 3)]
 
 
 class PackEntry(ctypes.Structure):
@@ -76,7 +76,7 @@ _SIGNATURES = {
     "mmdyn_act_fwd": "pp" + "l" + "i" + "p",
     "mmdyn_act_bwd": "ppp" + "l" + "i" + "p",
     "mmdyn_dropout_expand": "ppp" + "iii" + "f" + "p",
-    "mmdyn_dropout_reduce": "ppp" + "iii" + "f" + "pi" + "p",
+    "mmdyn_dropout_reduce": "ppp" + "iii" + "f" + "pi" + "pp",
     "mmdyn_random_masks": "p" + "l" + "f" + "QQ" + "pp",
     "mmdyn_random_normal": "p" + "l" + "QQ" + "pp",
     "mmdyn_counter_add": "p" + "Q" + "p",

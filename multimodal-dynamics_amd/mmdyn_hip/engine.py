@@ -559,9 +559,19 @@ class MVAEStep:
         lists = {"v": self._dec_passes("v"), "t": self._dec_passes("t"), "p": self.pass_p if self.use_pose else []}
         for m, pl in lists.items():
             c["zz" + m] = torch.empty(len(pl) * B, L, device=dev) if pl else None
+        # fp32x3: an image decoder whose Linear layer the plane-ring kernel serves gets its stacked input already split as well
+        zpl = {}
+        for m in ("v", "t"):
+            pl = lists[m]
+            ok = (self.precision == "fp32x3" and not self.conditional and c["train"] and L % 32 == 0 and ops.B.name == "hip"
+                  and layers.dense_planes_served(len(pl) * B, L, layers.FEAT))
+            zpl[m] = ops.Planes(len(pl) * B, L, dev) if ok else None
+            c["zzpl" + m] = zpl[m]
         passes = self._passes(c, B, None)
         for p, d in enumerate(passes):
             d["zdst"] = [c["zz" + m][pl.index(p) * B:(pl.index(p) + 1) * B] if p in pl else None for m, pl in lists.items()]
+            d["zpl"] = [zpl[m].t.data_ptr() + lists[m].index(p) * B * 3 * L * 2 if (zpl.get(m) is not None and p in lists[m]) else None
+                        for m in ("v", "t")]
         ops.B.poe_fwd(passes, c["eps"], c["mu"], c["lv"], c["z"], self.acc[2], True, P, B, L)
 
     def _ph_dec_fwd_steps(self, m):
@@ -581,7 +591,8 @@ class MVAEStep:
                     keep=None if self.keep_logits else plist.index(joint), mask=mk,
                     mask_channels=1 if mk is None else mk.shape[1], acc_u=None if mk is None else self.acc[3])
         lg, c["d" + m] = yield from layers.decoder_forward_steps(FP.sub(dec), self._buffers(dec), zz, len(plist),
-                                                                 packed=c["pk"].get("d" + m), cond=cond, loss=spec)
+                                                                 packed=c["pk"].get("d" + m), cond=cond, loss=spec,
+                                                                 z_planes=c.get("zzpl" + m))
         if c["d" + m]["loss_fused"]:
             c["lg" + m], c["dl" + m] = lg, c["d" + m]["dl"]
             c["lg_joint_only" + m] = not self.keep_logits
@@ -679,11 +690,16 @@ class MVAEStep:
         else:
             dhd = layers.heads_backward(c["h" + m], c["do" + m], FP.sub(enc, "G"), fused=FP.fused_heads_grad(enc))
         dh = torch.empty(B, 512, device=c["dev"])
+        # fp32x3: where the plane-ring kernel serves the FC layer's input gradient, dh is written already split as well
+        dhp = None
+        if (self.precision == "fp32x3" and ops.B.name == "hip" and layers.ACT_DTYPE == torch.float32
+                and layers.dense_planes_served(B, 512, layers.FEAT)):
+            dhp = ops.Planes(B, 512, c["dev"])
         # (the FC layer's Swish backward rides along: dh is dL/du5)
         ops.B.dropout_reduce(dhd, c["mask"][m], dh, len(self._passes_of(m)), B, 512, DROPOUT_P, u=c["e" + m]["u5"],
-                             act=ops.ACT_SWISH)
+                             act=ops.ACT_SWISH, **({} if dhp is None else {"planes": dhp}))
         yield
-        yield from layers.encoder_trunk_backward_steps(FP.sub(enc), c["e" + m], dh, FP.sub(enc, "G"), dh_is_du=True)
+        yield from layers.encoder_trunk_backward_steps(FP.sub(enc), c["e" + m], dh, FP.sub(enc, "G"), dh_is_du=True, dh_planes=dhp)
 
     def _ph_pose_enc_bwd(self):
         c, FP = self.ctx, self.params

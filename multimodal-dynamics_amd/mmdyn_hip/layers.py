@@ -51,11 +51,32 @@ def _cdiv(a, b):
 # ------------------------------------------------------------------------------------------------
 # primitive helpers
 # ------------------------------------------------------------------------------------------------
-def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch.float32, act_dtype=None, out=None):
+def dense_planes_served(rows, K, N):
+    """fp32x3: does the plane-ring kernel take this Linear-level launch on operands that arrive split (host-side query)?"""
+    return planes_served(DENSE, 1, rows, 1, K, 1, N)
+
+
+def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch.float32, act_dtype=None, out=None,
+          A_planes=None, act_planes=0):
     """C = A[rows][K] . Bp[N][K]^T (+bias) on the MFMA GEMM; picks split-K for short, wide-K problems.
     Returns (pre_activation, activated or None).  ``act_dtype``: storage type of the activated output alone (bf16 when it
     feeds a convolution of the bf16-storage mode; only without split-K).  ``out``: write the pre-activation there (a
-    contiguous [rows][N] view, e.g. one group's rows of a grouped launch's operand) instead of a fresh tensor."""
+    contiguous [rows][N] view, e.g. one group's rows of a grouped launch's operand) instead of a fresh tensor.
+    ``A_planes`` (fp32x3, round 6): A as an ops.Planes written by its producer -- with the packed weight's plane twin the launch then
+    runs on the persistent plane-ring kernel (stream-K over all CUs, split tiles finished inside the launch) where that serves the
+    shape (dense_planes_served).  ``act_planes`` = c > 0: the activated output is returned as an ops.Planes of c-channel rows
+    ([rows * N / c][c]: the operand of the plane launch that consumes it) instead of a tensor."""
+    if A_planes is not None and out_dtype == torch.float32 and act_dtype is None and dense_planes_served(rows, K, N):
+        wp = _plane_twin(Bp)
+        if wp is not None and wp.C == K and wp.rows == N:
+            C = _new(Bp, rows, N) if out is None else out
+            Ca = None
+            if want_act:
+                Ca = ops.Planes(rows * N // act_planes, act_planes, Bp.device) if act_planes else _new(Bp, rows, N)
+            ops.B.igemm_nt(A_planes, wp, bias, C, Ca, None, None, DENSE, 1, rows, 1, 1, K, 1, 1, N, N, 1, 0, act, 1)
+            return C, Ca
+    if act_planes:
+        raise ValueError("mmdyn_hip: dense(act_planes=...) needs a launch the plane-ring kernel serves (ask dense_planes_served)")
     C = _new(A, rows, N, dtype=out_dtype) if out is None else out
     Ca = _new(A, rows, N, dtype=out_dtype if act_dtype is None else act_dtype) if want_act else None
     # split-K only when the 64x64 tiling leaves most of the 256 CUs idle AND K is long enough to amortise the
@@ -512,10 +533,18 @@ def _alloc_packed(specs, like, w_dtype=None, pre=None):
     return out
 
 
+PLANE_TWIN_2D = ("Wu", "WfT")
+
+
 def wants_plane_twin(s):
     """Conv-weight packs [16][N][Cin] whose launches a plane kernel can serve (N % 64 == 0: the plane-ring kernel; N == 32: the
     patch-resident up-sampling kernel; Cin % 32 == 0) also get a Planes twin from the plan in the fp32x3 arithmetic (whether a
     given batch's launch takes it: planes_served)."""
+    if s["kind"] < K_KEEP:
+        # FC-level operands whose Linear launch the plane-ring kernel can serve (round 6): the decoder's Wu [6400][L] and the
+        # encoder's WfT [6400][512] -- whole, unpadded 2-D packs with K % 32 == 0 and N % 128 == 0
+        return (s["name"] in PLANE_TWIN_2D and s["part"] is None and len(s["shape"]) == 2 and s["shape"][1] % 32 == 0
+                and s["shape"][0] % 128 == 0 and s["cout"] == s["shape"][1] and s["rout"] == s["shape"][0])
     return (s["kind"] >= K_KEEP and len(s["shape"]) == 3 and (s["shape"][1] % 64 == 0 or s["shape"][1] == 32)
             and s["shape"][2] % 32 == 0)
 
@@ -563,10 +592,13 @@ class PackPlan:
                 e.src = s["src"].data_ptr()
                 e.kind, e.rows_in, e.cols_in = s["kind"], s["rin"], s["cin"]
                 if twin:
-                    pl = ops.Planes(16 * s["shape"][1], s["shape"][2], dst.device)
+                    conv = s["kind"] >= K_KEEP
+                    pl = ops.Planes(16 * s["shape"][1] if conv else s["shape"][0], s["shape"][2] if conv else s["shape"][1], dst.device)
                     PLANE_TWIN[dst.data_ptr()] = (weakref.ref(dst), pl)
                     self.twins.append((dst.data_ptr(), pl))
                     e.dst, e.rows_out, e.cols_out, e.ld_out, e.dst_bf16 = pl.t.data_ptr(), 0, 0, 0, 3
+                    if not conv:           # (2-D kinds: the same permutation as the fp32 pack, rows of [plane][cols_out])
+                        e.rows_out, e.cols_out, e.ld_out = s["rout"], s["cout"], s["cout"]
                     if s["name"] in early:
                         self.n_early += 1
                     entries.append(e)
@@ -740,15 +772,18 @@ def encoder_trunk_backward(*a, **k):
     return run(encoder_trunk_backward_steps(*a, **k))
 
 
-def encoder_trunk_backward_steps(P, c, dh, grads, dh_is_du=False):
+def encoder_trunk_backward_steps(P, c, dh, grads, dh_is_du=False, dh_planes=None):
     """dh: [Bt,512]; writes every weight gradient of the trunk into ``grads[key]`` (canonical layout).
-    ``dh_is_du``: the caller has already taken dh through the FC layer's Swish (c["u5"]), e.g. in its dropout backward."""
+    ``dh_is_du``: the caller has already taken dh through the FC layer's Swish (c["u5"]), e.g. in its dropout backward.
+    ``dh_planes`` (with dh_is_du): the same tensor as an ops.Planes -- the FC layer's input gradient then runs on the plane-ring
+    kernel where it serves the launch."""
     Bt, G, Bg, pk, S, st = c["Bt"], c["G"], c["Bg"], c["pk"], c["S"], c["stages"]
     n = len(st)
     du5 = act_backward(dh, c["u5"], ACT_SWISH) if not dh_is_du else dh
     wgrad(du5, st[-1]["a"], grads["fc_net.0.weight"], DENSE, Bt, 1, 512, 1, FEAT, perm=1)
     ops.B.colsum(du5, grads["fc_net.0.bias"], Bt, 512, 0, 0.0)
-    da, _ = dense(du5, pk["WfT"], None, Bt, 512, FEAT, out_dtype=ACT_DTYPE)  # WfT: [hw*256+c][512]
+    da, _ = dense(du5, pk["WfT"], None, Bt, 512, FEAT, out_dtype=ACT_DTYPE,  # WfT: [hw*256+c][512]
+                  A_planes=dh_planes if dh_is_du else None)
     yield
 
     def bn_keys(t):
@@ -795,7 +830,7 @@ def decoder_forward(*a, **k):
     return run(decoder_forward_steps(*a, **k))
 
 
-def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, cond=None, training=True, loss=None):
+def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, cond=None, training=True, loss=None, z_planes=None):
     """z: [Bt, L] -> logits NCHW [Bt,3,S,S]; returns (logits, ctx).  ``logits=False`` stops after the last
     BatchNorm (used only to reproduce the running statistics of the reference's unused decoder passes).
     ``loss`` (fused engine): dict(target [Bg,3,S,S], slots [G], acc (fp64 loss slots), grad_scale, want_grad, keep (group whose logits
@@ -813,13 +848,22 @@ def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, co
     c = {"Bt": Bt, "G": G, "Bg": Bg, "L": L, "L0": L0, "Lc": Lc, "z": z, "pk": pk, "S": S, "last": last}
     # rows -> hw*256+c.  bf16 storage mode: the activated output is the first transposed convolution's operand and is stored
     # as such (the matrix cores round it to bf16 either way); the pre-activation stays fp32 for the backward
-    u0, h0 = dense(z, pk["Wu"], pk["bu"], Bt, L, FEAT, ACT_SWISH, want_act=True,
-                   act_dtype=ACT_DTYPE if ACT_DTYPE != torch.float32 else None)
+    c0 = P[f"hallucinate.{convs[0]}.weight"].shape[0]
+    want0 = training and planes_served(TCONV_S1P0, G, Bg, 5, c0, 8, P[f"hallucinate.{convs[0]}.weight"].shape[1])
+    # fp32x3 (round 6): with z arriving split (``z_planes``: written by the product-of-experts launch) and the packed weight's plane
+    # twin the Linear layer runs on the plane-ring kernel and hands its activated output to the first transposed convolution as
+    # plane rows of its 256 channels -- no stand-alone split launch, no fp32 copy of h0 (the backward reads u0)
+    fc_planes = (want0 and z_planes is not None and cond is None and L == L0 and ACT_DTYPE == torch.float32
+                 and FEAT % c0 == 0 and dense_planes_served(Bt, L, FEAT) and _plane_twin(pk["Wu"]) is not None)
+    if fc_planes:
+        u0, h0 = dense(z, pk["Wu"], pk["bu"], Bt, L, FEAT, ACT_SWISH, want_act=True, A_planes=z_planes, act_planes=c0)
+    else:
+        u0, h0 = dense(z, pk["Wu"], pk["bu"], Bt, L, FEAT, ACT_SWISH, want_act=True,
+                       act_dtype=ACT_DTYPE if ACT_DTYPE != torch.float32 else None)
     yield
     stages, a, H = [], h0, 5
-    if training and planes_served(TCONV_S1P0, G, Bg, 5, P[f"hallucinate.{convs[0]}.weight"].shape[0], 8,
-                                  P[f"hallucinate.{convs[0]}.weight"].shape[1]):
-        a = as_planes(h0, P[f"hallucinate.{convs[0]}.weight"].shape[0])       # (the FC kernel's fp32 output, split by its own launch)
+    if want0 and not fc_planes:
+        a = as_planes(h0, c0)       # (the FC kernel's fp32 output, split by its own launch)
     for j, i in enumerate(convs):
         cin, cout = P[f"hallucinate.{i}.weight"].shape[0], P[f"hallucinate.{i}.weight"].shape[1]
         bn = _bn_of(P, buf, f"hallucinate.{i + 1}")

@@ -306,8 +306,15 @@ class HipBackend:
             self._check_stat_tiles(stats, False, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, planes=True)
             if ws is None and splitk == 1:
                 ws = self._slabs(C, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, planes=True)
-            check(self.lib.mmdyn_igemm_nt_mx(pa, pb, _ptr(bias), _ptr(C), _ptr(C_act), _ptr(stats), _ptr(ws), None, None, None, None,
-                                             None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, 384,
+            flags, pca = 384, None
+            if isinstance(C_act, Planes):            # the activated output as a plane tensor (flag bit 10: DENSE launches)
+                if N % C_act.C or C_act.rows * C_act.C != G * Bg * Ho * Wo * N or ldc != N:
+                    raise ValueError("mmdyn_hip: igemm_nt: plane output of the wrong shape")
+                flags, pca = 384 | 1024 | ((C_act.C // 8) << 16), C_act.t.data_ptr()
+            elif C_act is not None:
+                pca = _ptr(C_act)
+            check(self.lib.mmdyn_igemm_nt_mx(pa, pb, _ptr(bias), _ptr(C), pca, _ptr(stats), _ptr(ws), None, None, None, None,
+                                             None, mode, G, Bg, Hi, Wi, Cin, Ho, Wo, N, ldc, stride, offset, act, splitk, flags,
                                              self._flags(C) if ws is not None and splitk == 1 else None, _stream()), "mmdyn_igemm_nt_mx")
             return
         (pa, a16), (pc, c16), (pca, ca16), (pb, b16) = _aptr(A), _aptr(C), _aptr(C_act), _aptr(Bp)
@@ -627,10 +634,14 @@ class HipBackend:
         check(self.lib.mmdyn_dropout_expand(_ptr(h), _ptr(masks, torch.uint8), _ptr(out), P, B, H, p_drop,
                                             _stream()), "mmdyn_dropout_expand")
 
-    def dropout_reduce(self, dout, masks, dh, P, B, H, p_drop, u=None, act=ACT_NONE):
-        """u (optional, [B][H] fp32): dh = (sum over the passes) * act'(u) -- the activation backward in the same launch."""
+    def dropout_reduce(self, dout, masks, dh, P, B, H, p_drop, u=None, act=ACT_NONE, planes=None):
+        """u (optional, [B][H] fp32): dh = (sum over the passes) * act'(u) -- the activation backward in the same launch.
+        planes (optional ops.Planes [B][H]): dh is written there as well, already split."""
+        if planes is not None and (planes.rows != B or planes.C != H):
+            raise ValueError("mmdyn_hip: dropout_reduce: plane output of the wrong shape")
         check(self.lib.mmdyn_dropout_reduce(_ptr(dout), _ptr(masks, torch.uint8), _ptr(dh), P, B, H, p_drop,
-                                            _ptr(u), int(act), _stream()), "mmdyn_dropout_reduce")
+                                            _ptr(u), int(act), None if planes is None else planes.t.data_ptr(), _stream()),
+              "mmdyn_dropout_reduce")
 
     def random_masks(self, masks, p_drop, seed, offset, offset_dev=None):
         check(self.lib.mmdyn_random_masks(_ptr(masks, torch.uint8), masks.numel(), p_drop, seed, offset,
@@ -708,6 +719,9 @@ class HipBackend:
             for k, t in enumerate(p.get("zdst", [])):      # forward: further [B][L] destinations of the pass's z
                 if t is not None:
                     arr[i].zdst[k] = _ptr(t)
+            for k, t in enumerate(p.get("zpl", [])):       # ... and plane row blocks (raw pointers into an ops.Planes)
+                if t is not None:
+                    arr[i].zpl[k] = int(t)
         return arr
 
     def poe_fwd(self, passes, eps_noise, mu, logvar, z, kl_sum, with_prior, P, B, L):

@@ -551,6 +551,7 @@ def test_split_tiles_finished_inside_the_launch_equal_the_fixup_launch(x3, arith
              ("bn", CONV, 3, 256, 16, 64, 8, 128, 2, -1), ("act", CONV, 1, 1024, 8, 128, 5, 256, 1, 0)]
     prev_split = ops.B.fp32_split
     ops.B.fp32_split = arith != "native"
+    checked = 0
     try:
         for kind, mode, G, Bg, Hi, Cin, Ho, N, stride, offset in cases:
             Bt, rows = G * Bg, G * Bg * Ho * Ho
@@ -578,7 +579,10 @@ def test_split_tiles_finished_inside_the_launch_equal_the_fixup_launch(x3, arith
             flag = 128 | (256 if arith == "planes" else 0) if arith != "native" else 0
             slab = (ops.B.lib.mmdyn_igemm_slab_floats_mx(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, flag) if flag else
                     ops.B.lib.mmdyn_igemm_slab_floats(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N))
-            assert slab > 0, (kind, arith)                         # (a stream-K launch with split tiles)
+            if slab == 0:                    # (not a stream-K launch with split tiles in this arithmetic: nothing to compare)
+                assert arith != "planes", kind
+                continue
+            checked += 1
             ops.B.use_flags = False
             try:
                 C0, s0 = run()
@@ -587,6 +591,7 @@ def test_split_tiles_finished_inside_the_launch_equal_the_fixup_launch(x3, arith
             for _ in range(3):
                 C1, s1 = run()
                 assert torch.equal(C0, C1) and torch.equal(s0, s1), (kind, arith)
+        assert checked >= 2
         # every arrival word is back at zero
         for pool in ops.B._flagpool.values():
             assert int(pool[0].abs().sum()) == 0
