@@ -343,10 +343,14 @@ __device__ __forceinline__ bool wsp_arrive_and_sum(f32x4v (&acc)[MT][NT], float*
     t = __shfl(t, 0, 64);
     if (t != (unsigned)(npieces - 1)) return false;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // NO acquire fence here: at agent scope it is `buffer_inv sc1`, which drops the XCD's L2 lines -- executed by every finishing wave
+  // it kept evicting the operands the other blocks of the XCD were streaming (measured: +27 us per stream-K launch).  The pieces are
+  // read with sc1 (agent-coherent) buffer loads instead, which do not take a stale line of an earlier launch's slab from this L2;
+  // they are issued after the arrival word's value has returned (the branch above waits for it) and loads return in order.
   asm volatile("" ::: "memory");
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slabs, 0, 0x7FFFFF00, 0x00020000);
   // pieces in K order: 0 + p0 + p1 + ...; a piece of this very wave comes from its registers when it is the first one (head_last),
-  // from its slab otherwise (one accumulator set whoever finishes).  Plain 16-byte loads behind the acquire: eight in flight per piece.
+  // from its slab otherwise (one accumulator set whoever finishes)
   if (!head_last) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -355,12 +359,19 @@ __device__ __forceinline__ bool wsp_arrive_and_sum(f32x4v (&acc)[MT][NT], float*
   }
   for (int u = head_last ? min(ue, (b0 + 1) * per) : ub; u < ue;) {
     const int b = u / per;
-    const float* sb = slabs + ((size_t)(b * 2 + (u == b * per ? 0 : 1)) * NM + mw) * SLAB;
+    const unsigned so = (unsigned)(((b * 2 + (u == b * per ? 0 : 1)) * NM + mw) * SLAB) * 4u;     // (slab workspaces are < 2 GB)
+    // (four fragments = 16 registers in flight at a time: the kernel has no 32 to spare)
+    typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+    constexpr int NF = MT * NT, HB = NF >= 4 ? 4 : NF;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int f0 = 0; f0 < NF; f0 += HB) {
+      u32x4b w[HB];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] += __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(sb + ((mt * NT + nt) * 64 + lane) * 4));
+      for (int i = 0; i < HB; ++i)
+        w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(((f0 + i) * 64 + lane) * 16), so, 16 /* sc1 */);
+#pragma unroll
+      for (int i = 0; i < HB; ++i) acc[(f0 + i) / NT][(f0 + i) % NT] += __builtin_bit_cast(f32x4v, w[i]);
+    }
     u = min(ue, (b + 1) * per);
   }
   if (lane == 0) __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
