@@ -280,9 +280,10 @@ def main():
                          "taking them already split where the plane-ring kernel serves the launch")
     ap.add_argument("--no-patch-planes", action="store_true",
                     help="A/B switch (f32x3): the 32-channel up-sampling layers (tconv_patch_kernel) keep fp32 operands")
-    ap.add_argument("--fixup-launch", action="store_true",
-                    help="A/B switch: the persistent stream-K kernels park the pieces of split tiles and a fix-up launch sums them "
-                         "(rounds 4-5) instead of finishing those tiles inside the launch")
+    ap.add_argument("--inkernel-finish", action="store_true",
+                    help="A/B switch (LAB library only: MMDYN_HIP_LIB=.../libmmdyn_hip_lab.so): the persistent stream-K kernels finish "
+                         "split tiles inside the launch instead of parking the pieces for a fix-up launch (measured slower: LAB_NOTES H.a)")
+    ap.add_argument("--ab-off", default="", help="A/B switches (comma list): fc_planes, fused_bce, copy_many -- turn a round-6 change off")
     ap.add_argument("--single-lane", action="store_true",
                     help="no visual/tactile stream overlap: per-kernel durations in a rocprofv3 trace then match "
                          "the roofline object's live HIP-event measurement")
@@ -335,9 +336,19 @@ def main():
     from mmdyn_hip.engine import MVAEStep
     from mmdyn_hip.models import setup_model, NoiseSource
     from mmdyn_hip.profiling import profile_step
-    if args.fixup_launch:
+    for sw in [x for x in args.ab_off.split(",") if x]:
+        from mmdyn_hip import layers as _lay, engine as _eng
+        if sw == "fc_planes":
+            _lay.FC_PLANES = False
+        elif sw == "fused_bce":
+            _eng.FUSED_BCE = False
+        elif sw == "copy_many":
+            _eng.COPY_MANY = False
+        else:
+            raise SystemExit(f"--ab-off: unknown switch {sw}")
+    if args.inkernel_finish:
         from mmdyn_hip import ops as _ops2
-        _ops2.B.use_flags = False
+        _ops2.B.use_flags = True
     if args.no_planes:
         from mmdyn_hip import layers as _layers
         _layers.PLANES = False

@@ -201,7 +201,7 @@ __device__ __forceinline__ void wsp_fetch_y(f32x4v (&yq)[MT][NT], const int (&oo
 }
 
 // ooff[mt]: output offset of row (l>>2) of the wave's mt-th 16-row tile (-1: no such row); tr: this wave's LDS patch
-template <int BM, int BN, int WM, int WN, int B16>
+template <int BM, int BN, int WM, int WN, int B16, bool PLOUT = false>
 __device__ __forceinline__ void wsp_epilogue(f32x4v (&acc)[WM / 16][WN / 16], const int (&ooff)[WM / 16],
                                              const f32x4v (&yq)[WM / 16][WN / 16], const TileId& id, const IgemmGeom& g,
                                              const float* __restrict__ bias, float* __restrict__ C, float* __restrict__ C_act,
@@ -259,7 +259,7 @@ __device__ __forceinline__ void wsp_epilogue(f32x4v (&acc)[WM / 16][WN / 16], co
           *reinterpret_cast<f32x4v*>(C + (size_t)oo + col) = v;
           if (g.want_act_out) {
             if (B16 && g.cact_b16) st4<st16_t>(reinterpret_cast<st16_t*>(C_act) + (size_t)oo + col, a);
-            else if (!B16 && g.cact_planes) {
+            else if (PLOUT && !B16 && g.cact_planes) {     // (PLOUT: compiled into the DENSE instance of the plane kernel only)
               // the activated output as a PLANE tensor (rows of [plane][cact_planes] bf16, the exact three-term split; ldc == N): the GEMM that
               // consumes it takes its operand already split and no stand-alone split launch is needed (round 6)
               uint32_t h0, m0, l0, h1, m1, l1;
@@ -306,7 +306,18 @@ __device__ __forceinline__ void wsp_epilogue(f32x4v (&acc)[WM / 16][WN / 16], co
   }
 }
 
-// ---- split tiles finished INSIDE the launch (round 6) ----
+// ---- split tiles finished INSIDE the launch (round 6) -- LAB build only ----
+// Built, tested bit-identical to the fix-up launch (tests/test_kernels_aten_gpu.py::test_split_tiles_finished_inside_the_launch_*)
+// and measured SLOWER on the step, same box, alternating runs (docs/LAB_NOTES.md H.a): 50.4-50.6 k samples/s against 51.2-51.7 k for the
+// fix-up launch (v1 with an agent-scope acquire per finishing wave: 49.3-50.9 against 53.8 k) -- the last arriver's round trips
+// (arrival word, pieces) sit at the END of a persistent block that holds a whole CU, where the separate launch's 13 us run beside the
+// other lane's kernels; its code also costs the main loop 6-18 VGPRs.  The product library compiles it out and always takes the
+// fix-up launch; arrival_flags is then ignored.
+#ifdef MMDYN_LAB
+#define MMDYN_INKERNEL_FINISH 1
+#else
+#define MMDYN_INKERNEL_FINISH 0
+#endif
 // A tile whose K range straddles the ranges of several blocks is finished by whichever of its pieces' owners ARRIVES LAST -- no
 // block ever waits for another one, so there is no progress assumption about dispatch order or co-residency (the lanes' persistent
 // kernels share the chip).  Per MFMA wave (the slab regions are per wave and the fragment layout is the same in every block, so
@@ -318,6 +329,7 @@ __device__ __forceinline__ void wsp_epilogue(f32x4v (&acc)[WM / 16][WN / 16], co
 // (a replay finds it zero) and runs the epilogue.  `flags`: one word per (block range, MFMA wave), indexed by the range that owns
 // the tile's FIRST piece; zero at launch (mmdyn_hip/ops.py hands out a zeroed block per launch site).
 // Returns true when this wave finished the tile (`acc` then holds the whole tile and the caller runs the epilogue).
+#ifdef MMDYN_LAB
 template <int MT, int NT, int NM>
 __device__ __forceinline__ bool wsp_arrive_and_sum(f32x4v (&acc)[MT][NT], float* slabs, unsigned* flags, const int ub, const int ue,
                                                    const int per, const int rb, const bool first_seg, const int mw, const int lane) {
@@ -377,6 +389,7 @@ __device__ __forceinline__ bool wsp_arrive_and_sum(f32x4v (&acc)[MT][NT], float*
   if (lane == 0) __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return true;
 }
+#endif
 
 // X3 (B16 = 0: fp32 operands in HBM and in the ring): the MFMA waves split their fp32 fragments in registers into three bf16
 // terms (split3_bf16, common.h) and multiply six of the nine plane pairs on v_mfma_f32_16x16x32_bf16 -- the fp32 product at 6/16 of
@@ -636,11 +649,14 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NL)) void igemm_wsp_k
     if (DIAG) { const long long c = WSP_STAMP(); d_loop += c; d_epi -= c; }
     bool finish = full;
     if (!full) {
+#ifdef MMDYN_LAB
       if (g.flags != nullptr) {
-        // a piece of a split tile, finished inside the launch by the piece that arrives last (wsp_arrive_and_sum)
+        // a piece of a split tile, finished inside the launch by the piece that arrives last (wsp_arrive_and_sum; LAB build only)
         finish = wsp_arrive_and_sum<MT, NT, NM>(acc, slabs, g.flags, sg.ub, sg.ub + sg.kt, sc.per, rb, cu == u0, mw, lane);
         if (finish && bnbwd) wsp_fetch_y<MT, NT, B16>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
-      } else {
+      } else
+#endif
+      {
         // a piece of a split tile: the accumulator fragments as they are, 16 bytes per lane (slot 0: the piece is this block's
         // first segment, slot 1: its last); igemm_wsp_fixup_kernel sums the pieces and runs the epilogue
         float* sb = slabs + ((size_t)(rb * 2 + (cu == u0 ? 0 : 1)) * NM + mw) * (MT * NT * 256);
@@ -861,11 +877,14 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NLD)) void igemm_wsp3
     }
     bool finish = full;
     if (!full) {
+#ifdef MMDYN_LAB
       if (g.flags != nullptr) {
-        // a piece of a split tile, finished inside the launch by the piece that arrives last (wsp_arrive_and_sum)
+        // a piece of a split tile, finished inside the launch by the piece that arrives last (wsp_arrive_and_sum; LAB build only)
         finish = wsp_arrive_and_sum<MT, NT, NM>(acc, slabs, g.flags, sg.ub, sg.ub + sg.kt, sc.per, rb, cu == u0, mw, lane);
         if (finish && bnbwd) wsp_fetch_y<MT, NT, 0>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
-      } else {
+      } else
+#endif
+      {
         float* sb = slabs + ((size_t)(rb * 2 + (cu == u0 ? 0 : 1)) * NM + mw) * (MT * NT * 256);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -873,7 +892,8 @@ __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NLD)) void igemm_wsp3
           for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4v*>(sb + ((mt * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
       }
     }
-    if (finish) wsp_epilogue<BM, BN, WM, WN, 0>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
+    if (finish)
+      wsp_epilogue<BM, BN, WM, WN, 0, MODE == MMDYN_DENSE>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
     cu += ke - kb;
   }
 }
@@ -920,7 +940,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_wsp_fixup_ke
                      x0, ooff[mt]);
   }
   if (g.bn_y != nullptr) wsp_fetch_y<MT, NT, B16>(yq, ooff, g, id.n0 + wn * WN + (lane & 3) * 4);
-  wsp_epilogue<BM, BN, WM, WN, B16>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane, trans + mw * 16 * TRLD);
+  wsp_epilogue<BM, BN, WM, WN, B16, MODE == MMDYN_DENSE && B16 == 0>(acc, ooff, yq, id, g, bias, C, C_act, stats, wm, wn, lane,
+                                                                   trans + mw * 16 * TRLD);
 }
 
 // ---- which launches this file serves, and how ----
@@ -1059,7 +1080,7 @@ static int wsp_launch(const float* A, const float* Bp, const float* bias, float*
       if (int e = x3_opt_in.ensure((const void*)igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, 0, false, true>, (int)smemx)) return e;
       const bool splitx = has_split_tiles(g, sc);
       if (splitx && !slabs) return MMDYN_ERR_NULL;
-      if (!splitx || nblkx * NMx > MMDYN_IGEMM_FLAG_WORDS) g.flags = nullptr;     // (flags: split tiles are finished inside the launch)
+      if (!splitx || nblkx * NMx > MMDYN_IGEMM_FLAG_WORDS || !MMDYN_INKERNEL_FINISH) g.flags = nullptr;     // (flags: split tiles are finished inside the launch)
       hipLaunchKernelGGL((igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, 0, false, true>), dim3(nblkx), dim3(64 * (NMx + NL)), smemx, st, A,
                          Bp, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes);
       if (splitx && !g.flags)
@@ -1077,7 +1098,7 @@ static int wsp_launch(const float* A, const float* Bp, const float* bias, float*
   if (int e = lds_opt_in.ensure((const void*)igemm_wsp_kernel<MODE, BM, BN, WM, WN, S, B16>, (int)smem)) return e;
   const bool split = has_split_tiles(g, sc);
   if (split && !slabs) return MMDYN_ERR_NULL;
-  if (!split || nblk * NM > MMDYN_IGEMM_FLAG_WORDS) g.flags = nullptr;
+  if (!split || nblk * NM > MMDYN_IGEMM_FLAG_WORDS || !MMDYN_INKERNEL_FINISH) g.flags = nullptr;
 #ifdef MMDYN_LAB
   if constexpr (B16 == 0 && MODE != MMDYN_DENSE) {
     const char* e = lab_env("MMDYN_WSP_DIAG");
@@ -1159,7 +1180,7 @@ static int wsp3_launch(const bf16_t* A, const bf16_t* Bp, const float* bias, flo
   if (int e = opt_in.ensure((const void*)igemm_wsp3_kernel<MODE, BM, BN, WM, WN, S, P3_NLD>, (int)smem)) return e;
   const bool split = has_split_tiles(g, sc);
   if (split && !slabs) return MMDYN_ERR_NULL;
-  if (!split || nblk * NM > MMDYN_IGEMM_FLAG_WORDS) g.flags = nullptr;      // (flags: split tiles are finished inside the launch)
+  if (!split || nblk * NM > MMDYN_IGEMM_FLAG_WORDS || !MMDYN_INKERNEL_FINISH) g.flags = nullptr;      // (flags: split tiles are finished inside the launch)
   hipLaunchKernelGGL((igemm_wsp3_kernel<MODE, BM, BN, WM, WN, S, P3_NLD>), dim3(nblk), dim3(64 * (NM + P3_NLD)), smem, st, A, Bp,
                      bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes);
   if (split && !g.flags)

@@ -24,6 +24,10 @@ import torch
 from . import layers, ops
 from .models.shapes import DROPOUT_P
 
+# A/B switches of bench.py (measurements only; the product runs with all of them on)
+FUSED_BCE = True       # the BCE term in the last decoder layer's epilogue
+COPY_MANY = True       # the batch moved into the static buffers by one launch
+
 SUBSETS_POSE = [(1, 1, 0), (1, 0, 0), (0, 1, 0), (1, 1, 1), (1, 0, 1), (0, 1, 1), (0, 0, 1)]
 SUBSETS_NOPOSE = SUBSETS_POSE[:3]
 # "fp32x3": fp32 storage and fp32 results like "fp32"; the GEMM launches that gain from it run on the bf16 matrix cores through the
@@ -591,7 +595,7 @@ class MVAEStep:
                     keep=None if self.keep_logits else plist.index(joint), mask=mk,
                     mask_channels=1 if mk is None else mk.shape[1], acc_u=None if mk is None else self.acc[3])
         lg, c["d" + m] = yield from layers.decoder_forward_steps(FP.sub(dec), self._buffers(dec), zz, len(plist),
-                                                                 packed=c["pk"].get("d" + m), cond=cond, loss=spec,
+                                                                 packed=c["pk"].get("d" + m), cond=cond, loss=spec if FUSED_BCE else None,
                                                                  z_planes=c.get("zzpl" + m))
         if c["d" + m]["loss_fused"]:
             c["lg" + m], c["dl" + m] = lg, c["d" + m]["dl"]
@@ -909,7 +913,7 @@ class MVAEStep:
             moves.append((self._static_mask, loss_mask.reshape(self._static_mask.shape)))
         if condition is not None:
             moves.append((self._static_cond, condition))
-        if all(d.dtype == s_.dtype and s_.is_cuda and s_.is_contiguous() for d, s_ in moves):
+        if COPY_MANY and all(d.dtype == s_.dtype and s_.is_cuda and s_.is_contiguous() for d, s_ in moves):
             ops.B.copy_many(moves)
         else:                        # (a batch that arrives in another type / layout / on the host: the runtime's converting copy)
             for d, s_ in moves:

@@ -51,9 +51,12 @@ def _cdiv(a, b):
 # ------------------------------------------------------------------------------------------------
 # primitive helpers
 # ------------------------------------------------------------------------------------------------
+FC_PLANES = True       # (False: A/B measurements -- the FC-level launches keep fp32 operands and the round-5 kernels)
+
+
 def dense_planes_served(rows, K, N):
     """fp32x3: does the plane-ring kernel take this Linear-level launch on operands that arrive split (host-side query)?"""
-    return planes_served(DENSE, 1, rows, 1, K, 1, N)
+    return FC_PLANES and planes_served(DENSE, 1, rows, 1, K, 1, N)
 
 
 def dense(A, Bp, bias, rows, K, N, act=ACT_NONE, want_act=False, out_dtype=torch.float32, act_dtype=None, out=None,
@@ -540,6 +543,8 @@ def wants_plane_twin(s):
     """Conv-weight packs [16][N][Cin] whose launches a plane kernel can serve (N % 64 == 0: the plane-ring kernel; N == 32: the
     patch-resident up-sampling kernel; Cin % 32 == 0) also get a Planes twin from the plan in the fp32x3 arithmetic (whether a
     given batch's launch takes it: planes_served)."""
+    if s["kind"] < K_KEEP and not FC_PLANES:
+        return False
     if s["kind"] < K_KEEP:
         # FC-level operands whose Linear launch the plane-ring kernel can serve (round 6): the decoder's Wu [6400][L] and the
         # encoder's WfT [6400][512] -- whole, unpadded 2-D packs with K % 32 == 0 and N % 128 == 0

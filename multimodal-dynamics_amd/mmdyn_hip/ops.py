@@ -101,7 +101,7 @@ class HipBackend:
         self._l, self._lib_path = None, lib_path       # lib_path: the LAB build (tests / microbenchmarks only)
         self._tickets = {}                             # device -> [zeroed int32 pool, next eager slot, next graph slot, free graph slots]
         self._drawn = None                             # (device, slot) pairs drawn by captured launches since ticket_mark()
-        self.use_flags = True
+        self.use_flags = False                         # (the product library ignores arrival words: see _flags)
         self._flagpool = {}                            # device -> [zeroed int32 pool, next eager block, next graph block, free graph blocks]
         self.force_ticket = False
         # "fp32": v_mfma_f32_32x32x2_f32 (the reference's arithmetic, the default and the BASELINE configs[1] path);
@@ -150,10 +150,12 @@ class HipBackend:
             slot = half + nxt_eager
         return pool.data_ptr() + 4 * self.TICKET_STRIDE * slot
 
-    # arrival flags of the persistent stream-K GEMMs (igemm_wsp.hip, round 6): one block of FLAG_WORDS zeroed words per launch, the
+    # arrival words of the persistent stream-K GEMMs (igemm_wsp.hip, round 6): one block of FLAG_WORDS zeroed words per launch, the
     # same ownership rules as the tickets (captured launches own theirs until ticket_release, eager launches cycle through the upper
-    # half); the kernel leaves every flag it set back at zero.  Exhausted (hundreds of live captures): None -- the launch then takes
-    # the two-launch form (slabs + fix-up kernel).
+    # half); the kernel leaves every word it set back at zero.  Exhausted (hundreds of live captures): None -- the launch then takes
+    # the two-launch form (slabs + fix-up kernel).  ``use_flags`` is False by default: finishing split tiles inside the launch is
+    # built, tested bit-identical and measured SLOWER on the step (docs/LAB_NOTES.md H.a); the product library compiles it out and
+    # only the LAB library honours the words (tests, bench.py --inkernel-finish with MMDYN_HIP_LIB pointing at the LAB build).
     FLAG_BLOCKS, FLAG_WORDS = 1024, 8192
 
     def _flags(self, like):

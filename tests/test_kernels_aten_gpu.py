@@ -541,23 +541,24 @@ def test_planes_input_gradient_with_the_epilogues(x3):
 
 @pytest.mark.parametrize("arith", ["planes", "x3", "native"])
 def test_split_tiles_finished_inside_the_launch_equal_the_fixup_launch(x3, arith):
-    """Round 6: the persistent stream-K kernels finish a tile whose K range straddles several blocks INSIDE the launch (the piece that
+    """(LAB library: the product build compiles this form out -- it measured slower on the step, docs/LAB_NOTES.md H.a.)  Round 6: the persistent stream-K kernels finish a tile whose K range straddles several blocks INSIDE the launch (the piece that
     arrives last sums the pieces in K order: igemm_wsp.hip wsp_arrive_and_sum) when they are given arrival words.  Bit-identical to
     the two-launch form (slabs + igemm_wsp_fixup_kernel) -- outputs and BatchNorm partial sums, whoever arrives last -- on the
     plain + statistics epilogue of the k4 s1 p0 layer (every tile split, up to nine pieces per tile), on the BatchNorm-backward
     epilogue and on the activation-backward epilogue; launched three times in a row on the same words (they are left zero)."""
+    from mmdyn_hip import _lib
     from mmdyn_hip.ops import TCONV_S1P0
+    LB = ops.HipBackend(lib_path=_lib.LAB_LIB_PATH)
     cases = [("s1p0", TCONV_S1P0, 4, 256, 5, 256, 8, 128, 1, 0), ("s1p0", TCONV_S1P0, 1, 256, 5, 256, 8, 128, 1, 0),
              ("bn", CONV, 3, 256, 16, 64, 8, 128, 2, -1), ("act", CONV, 1, 1024, 8, 128, 5, 256, 1, 0)]
-    prev_split = ops.B.fp32_split
-    ops.B.fp32_split = arith != "native"
+    LB.fp32_split = arith != "native"
     checked = 0
     try:
         for kind, mode, G, Bg, Hi, Cin, Ho, N, stride, offset in cases:
             Bt, rows = G * Bg, G * Bg * Ho * Ho
             A, Bp = rnd(Bt * Hi * Hi, Cin, seed=40).to(DEV), rnd(16, N, Cin, seed=41, scale=0.1).to(DEV)
             if arith == "planes":
-                assert ops.B.igemm_planes_served(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
+                assert LB.igemm_planes_served(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N)
                 a, b = _planes(A), _planes(Bp.view(-1, Cin))
             else:
                 a, b = A, Bp
@@ -566,37 +567,36 @@ def test_split_tiles_finished_inside_the_launch_equal_the_fixup_launch(x3, arith
             gamma, beta = (rnd(N, seed=45).abs() + 0.5).to(DEV), rnd(N, seed=46).to(DEV)
 
             def run():
-                T = ops.B.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, planes=arith == "planes")
+                T = LB.igemm_stat_tiles(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, planes=arith == "planes")
                 C, st = torch.zeros(rows, N, device=DEV), torch.zeros(G, max(T, 1), 2, N, device=DEV)
                 if kind == "s1p0":
-                    ops.B.igemm_nt(a, b, None, C, None, st, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1)
+                    LB.igemm_nt(a, b, None, C, None, st, None, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, N, stride, offset, 0, 1)
                 elif kind == "bn":
-                    ops.B.igemm_nt_dgrad_bn(a, b, C, st, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride, offset)
+                    LB.igemm_nt_dgrad_bn(a, b, C, st, y, mean, rstd, gamma, beta, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride, offset)
                 else:
-                    ops.B.igemm_nt_dgrad_act(a, b, C, y, ops.ACT_SWISH, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride, offset)
+                    LB.igemm_nt_dgrad_act(a, b, C, y, ops.ACT_SWISH, mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, stride, offset)
                 torch.cuda.synchronize()
                 return C, st
             flag = 128 | (256 if arith == "planes" else 0) if arith != "native" else 0
-            slab = (ops.B.lib.mmdyn_igemm_slab_floats_mx(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, flag) if flag else
-                    ops.B.lib.mmdyn_igemm_slab_floats(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N))
+            slab = (LB.lib.mmdyn_igemm_slab_floats_mx(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N, flag) if flag else
+                    LB.lib.mmdyn_igemm_slab_floats(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N))
             if slab == 0:                    # (not a stream-K launch with split tiles in this arithmetic: nothing to compare)
                 assert arith != "planes", kind
                 continue
             checked += 1
-            ops.B.use_flags = False
-            try:
-                C0, s0 = run()
-            finally:
-                ops.B.use_flags = True
+            LB.use_flags = False
+            C0, s0 = run()
+            LB.use_flags = True
             for _ in range(3):
                 C1, s1 = run()
                 assert torch.equal(C0, C1) and torch.equal(s0, s1), (kind, arith)
         assert checked >= 2
         # every arrival word is back at zero
-        for pool in ops.B._flagpool.values():
+        assert LB._flagpool
+        for pool in LB._flagpool.values():
             assert int(pool[0].abs().sum()) == 0
     finally:
-        ops.B.fp32_split = prev_split
+        LB.use_flags = False
 
 
 @pytest.mark.parametrize("G,Bg,Hi,Cin", [(4, 6, 16, 64), (2, 3, 32, 32), (1, 3, 64, 32), (2, 301, 16, 64), (1, 150, 32, 32)])
