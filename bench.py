@@ -283,7 +283,10 @@ def main():
     ap.add_argument("--inkernel-finish", action="store_true",
                     help="A/B switch (LAB library only: MMDYN_HIP_LIB=.../libmmdyn_hip_lab.so): the persistent stream-K kernels finish "
                          "split tiles inside the launch instead of parking the pieces for a fix-up launch (measured slower: LAB_NOTES H.a)")
-    ap.add_argument("--ab-off", default="", help="A/B switches (comma list): fc_planes, fused_bce, copy_many -- turn a round-6 change off")
+    ap.add_argument("--ab-off", default="", help="A/B switches (comma list): fused_bce, copy_many -- turn a round-6 change off")
+    ap.add_argument("--fc-planes", action="store_true",
+                    help="A/B switch (f32x3): the decoder's Linear forward and the encoder FC layer's input gradient on the DENSE mode of "
+                         "the plane-ring kernel (measured 0.6 %% slower on the two-lane step: layers.FC_PLANES)")
     ap.add_argument("--single-lane", action="store_true",
                     help="no visual/tactile stream overlap: per-kernel durations in a rocprofv3 trace then match "
                          "the roofline object's live HIP-event measurement")
@@ -338,14 +341,15 @@ def main():
     from mmdyn_hip.profiling import profile_step
     for sw in [x for x in args.ab_off.split(",") if x]:
         from mmdyn_hip import layers as _lay, engine as _eng
-        if sw == "fc_planes":
-            _lay.FC_PLANES = False
-        elif sw == "fused_bce":
+        if sw == "fused_bce":
             _eng.FUSED_BCE = False
         elif sw == "copy_many":
             _eng.COPY_MANY = False
         else:
             raise SystemExit(f"--ab-off: unknown switch {sw}")
+    if args.fc_planes:
+        from mmdyn_hip import layers as _lay2
+        _lay2.FC_PLANES = True
     if args.inkernel_finish:
         from mmdyn_hip import ops as _ops2
         _ops2.B.use_flags = True

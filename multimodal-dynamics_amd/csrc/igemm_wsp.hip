@@ -1250,7 +1250,15 @@ static Wsp3Cfg wsp3_pick(int mode, int G, int Bg, int Hi, int Wi, int Hr, int Wr
 
 static WspSched make_sched3(const IgemmGeom& g, const Wsp3Cfg& c) {
   WspPick p{c.bm, c.bn, c.bpc};
-  return make_sched(g, p, false);
+  WspSched sc = make_sched(g, p, false);
+  if (g.mode == MMDYN_DENSE) {
+    // FC-level launches: WHOLE tiles per block.  Their tiles are short (8-16 K-steps), so a stream-K cut splits nearly every tile
+    // and the fix-up launch (13 us) plus the slab traffic cost more than the idle CUs of an uneven cut -- which the other lane's
+    // kernels use anyway.
+    const long nblk = (long)device_cus() * c.bpc;
+    sc.per = (int)((sc.tiles + nblk - 1) / nblk) * sc.ksteps;
+  }
+  return sc;
 }
 
 // geometry of a launch as the queries below know it (shape only)

@@ -51,7 +51,13 @@ def _cdiv(a, b):
 # ------------------------------------------------------------------------------------------------
 # primitive helpers
 # ------------------------------------------------------------------------------------------------
-FC_PLANES = True       # (False: A/B measurements -- the FC-level launches keep fp32 operands and the round-5 kernels)
+# fp32x3, round 6: the decoder's Linear forward (z and its activated output as planes) and the encoder FC layer's input gradient on
+# the DENSE mode of the plane-ring kernel.  Built and tested (tests/test_kernels_aten_gpu.py::test_planes_dense_*); alone on the chip
+# the two launches run 45.5 / 27.5 us against 51.5 / 26.5 us for the fp32-operand kernels and two stand-alone split launches
+# disappear, but the two-lane step measured 0.6 % SLOWER with them, same box, alternating runs, twice (53.10 against 53.43 k, 52.9
+# against 53.3 k samples/s: docs/LAB_NOTES.md H.b) -- a one-block-per-CU persistent kernel keeps the other lane's kernels off its
+# CUs where the 64 KB blocks of the register-staged kernel shared them.  Off by default; bench.py --fc-planes turns it on.
+FC_PLANES = False
 
 
 def dense_planes_served(rows, K, N):

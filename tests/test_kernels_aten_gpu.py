@@ -599,6 +599,39 @@ def test_split_tiles_finished_inside_the_launch_equal_the_fixup_launch(x3, arith
         LB.use_flags = False
 
 
+@pytest.mark.parametrize("rows,K,N,cp", [(1024, 256, 6400, 256), (256, 512, 6400, 0), (1000, 256, 6400, 256), (130, 512, 6400, 6400)])
+def test_planes_dense_linear_with_plane_output(x3, rows, K, N, cp, monkeypatch):
+    """Round 6: the DENSE mode of the plane-ring kernel (FC-level launches whose operands arrive split): bias + Swish epilogue, the
+    pre-activation in fp32 and the activated output as a PLANE tensor of cp-channel rows (cp = 256: the decoder's Linear output read
+    as [rows * 25][256] by the transposed convolution above it; 0: a plain tensor) against fp64 ATen; the packed weight's plane twin
+    comes from a pack plan (2-D kinds 3 / 4 with dst_bf16 = 3) and equals mmdyn_split_planes of the fp32 pack bit for bit."""
+    monkeypatch.setattr(layers, "FC_PLANES", True)
+    x, W, b = rnd(rows, K, seed=50).to(DEV), rnd(N, K, seed=51, scale=0.05).to(DEV), rnd(N, seed=52).to(DEV)
+    if not layers.dense_planes_served(rows, K, N):
+        pytest.skip("the launch rule does not serve this shape")
+    plan = layers.PackPlan({"d": [layers._spec("Wu", W, 0, N, K, N, K, (N, K))]}, plane_twins=True)
+    plan.run()
+    Wp = plan.packed["d"]["Wu"]
+    twin = layers._plane_twin(Wp)
+    assert twin is not None and torch.equal(Wp, W)
+    ref_twin = _planes(Wp)
+    assert torch.equal(twin.t, ref_twin.t)
+    u, a = layers.dense(x, Wp, b, rows, K, N, ops.ACT_SWISH, want_act=True, A_planes=_planes(x), act_planes=cp)
+    ref_u = F.linear(x.double(), W.double(), b.double())
+    ref_a = ref_u * torch.sigmoid(ref_u)
+    assert relg(u, ref_u) < 2e-6
+    if cp:
+        assert isinstance(a, ops.Planes) and a.C == cp and a.rows == rows * N // cp
+        assert relg(a.float().view(rows, N), ref_a) < 2e-6
+        # ... and the planes are the exact split of the fp32 activation the kernel computed
+        u2, a2 = layers.dense(x, Wp, b, rows, K, N, ops.ACT_SWISH, want_act=True, A_planes=_planes(x))
+        assert torch.equal(u, u2) and torch.equal(a.float().view(rows, N), a2)
+    else:
+        assert relg(a, ref_a) < 2e-6
+    for ptr, pl in plan.twins:
+        layers.PLANE_TWIN.pop(ptr, None)
+
+
 @pytest.mark.parametrize("G,Bg,Hi,Cin", [(4, 6, 16, 64), (2, 3, 32, 32), (1, 3, 64, 32), (2, 301, 16, 64), (1, 150, 32, 32)])
 def test_planes_patch_resident_up_sampling_layers(x3, G, Bg, Hi, Cin):
     """ConvTranspose2d(Cin, 32, 4, 2, 1) on split operands (csrc/tconv_patch.hip, P3): the plain launch with its BatchNorm partial sums

@@ -282,6 +282,43 @@ def test_fp32x3_plane_operands_in_the_engine_variants(variant):
     assert ops.B.lib.mmdyn_igemm_planes_served(ops.CONV, 2, B, 16, 16, 64, 8, 8, 128) == 1     # (the decoders' launches took plane operands)
 
 
+def test_fc_level_launches_on_the_plane_ring_match_the_default_step(monkeypatch):
+    """layers.FC_PLANES (round 6, off by default: measured 0.6 % slower on the two-lane step): the decoders' Linear forward -- z and its
+    activated output as planes, written by the product-of-experts launch and the GEMM epilogue -- and the encoder FC layer's input
+    gradient on the DENSE mode of the plane-ring kernel, B = 256, against the default fp32x3 step on the same weights, inputs and
+    injected noise: loss within 2e-6 relative, every gradient within 2e-4 relative L2; eager and replayed from HIP graphs."""
+    from mmdyn_hip import layers
+    B, klw = 256, 0.05
+    results = []
+    for fc in (False, True):
+        monkeypatch.setattr(layers, "FC_PLANES", fc)
+        m = T.build("cnn-mvae", True, True, DEV)
+        eps, masks = seeded_noise(B, 256, 7, 8, 4321)
+        step = MVAEStep(m, noise=InjectedNoise(eps, masks))
+        inputs, targets = seeded_batch(B, 99)
+        gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+        loss = float(step.forward(gi, gt, klw))
+        if fc:
+            assert layers.dense_planes_served(4 * B, 256, layers.FEAT) and step.ctx["zzplv"] is not None
+            from mmdyn_hip import ops
+            assert isinstance(step.ctx["dv"]["h0"], ops.Planes)
+        step.backward()
+        results.append((loss, {k: v.grad.double().cpu().clone() for k, v in m.named_parameters()}))
+        step.close()
+    (l0, g0), (l1, g1) = results
+    assert l1 == pytest.approx(l0, rel=2e-6)
+    for k in g0:
+        assert float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-30)) < 2e-4, k
+    # the same path captured into HIP graphs and replayed
+    monkeypatch.setattr(layers, "FC_PLANES", True)
+    step = MVAEStep(T.build("cnn-mvae", True, True, DEV), noise=NoiseSource(5))
+    inputs, targets = seeded_batch(B, 99)
+    gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+    losses = [float(step.train_step_graphed(gi, gt, klw)) for _ in range(4)]
+    assert step._graph is not None and all(np.isfinite(l) for l in losses) and losses[-1] < losses[0]
+    step.close()
+
+
 def test_bf16_engine_vs_oracle():
     """BASELINE configs[2] arithmetic (bf16 matrix-core operands, fp32 accumulate / storage / master weights) against
     the fp32 CPU oracle, B=32, injected noise.  Stated tolerance for this mode: ELBO and each partial within 5e-3
