@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the measurement set kept under profiles/r6 (run on the GPU box through gpurun; outputs under gpurun_out/r6p).
-# usage: bash profiles/collect_r6.sh [part1|native|others|alltraffic|traffic <key> <bench args>]
+# usage: bash profiles/collect_r6.sh [part1|native|others|alltraffic|othertraffic|traffic <key> <bench args>]
 # The default arithmetic of bench.py is f32x3 (fp32 storage / results, GEMMs on the bf16 matrix cores through the exact three-term
 # split, operands arriving split where the plane kernels serve the launch); --dtype f32 = the native fp32 matrix cores.
 set -eo pipefail
@@ -42,6 +42,12 @@ elif [ "$part" = others ]; then
 elif [ "$part" = alltraffic ]; then
   bash $R/profiles/collect_r6.sh traffic s64_f32x3_b256_seq_modeling
   bash $R/profiles/collect_r6.sh traffic s64_f32_b256_seq_modeling --dtype f32
+elif [ "$part" = othertraffic ]; then
+  # whole-step PMC traffic of the other workloads of BASELINE.md (so that none of their lines says step_bound: "unknown")
+  bash $R/profiles/collect_r6.sh traffic s64_bf16s_b128_seq_modeling --dtype bf16s --batch 128
+  bash $R/profiles/collect_r6.sh traffic s128_f32x3_b128_dyn_modeling --image-size 128 --problem dyn_modeling --batch 128
+  bash $R/profiles/collect_r6.sh traffic s256_bf16s_b256_seq_modeling --image-size 256 --dtype bf16s --batch 256
+  bash $R/profiles/collect_r6.sh traffic s256_fp16s_b256_seq_modeling --image-size 256 --dtype fp16s --batch 256
 elif [ "$part" = traffic ]; then
   # whole-step HBM-side traffic of one bench.py workload: collect_r6.sh traffic <key> <bench args...>
   # separate PMC passes, --kernel-trace only (MI355X_MICROARCH.md, HBM section)

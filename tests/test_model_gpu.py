@@ -299,7 +299,7 @@ def test_fc_level_launches_on_the_plane_ring_match_the_default_step(monkeypatch)
         gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
         loss = float(step.forward(gi, gt, klw))
         if fc:
-            assert layers.dense_planes_served(4 * B, 256, layers.FEAT) and step.ctx["zzplv"] is not None
+            assert step.ctx["zzplv"] is not None and step.ctx["zzplt"] is not None       # (z arrived split at both image decoders)
             from mmdyn_hip import ops
             assert isinstance(step.ctx["dv"]["h0"], ops.Planes)
         step.backward()
