@@ -1358,6 +1358,15 @@ int mmdyn_igemm_wsp3_try(const void* A, const void* Bp, const float* bias, float
   const bf16_t* Bq = reinterpret_cast<const bf16_t*>(Bp);
 #define P3_GO(MODE_, BM_, BN_, WM_, WN_, S_) \
   return wsp3_launch<MODE_, BM_, BN_, WM_, WN_, S_>(Ap, Bq, bias, C, C_act, stats, slabs, g, sc, a_bytes, b_bytes, st)
+#ifdef MMDYN_LAB
+  // LAB, MMDYN_P3_W64=1: the 128x128 tile on FOUR MFMA waves of 64x64 (one per SIMD; 0.25 fragment reads per MFMA instead of 0.375)
+  if (const char* e = lab_env("MMDYN_P3_W64"))
+    if (e[0] == '1' && c.bn == 128 && c.bm == 128) {
+      if (g.mode == MMDYN_TCONV_S1P0) P3_GO(MMDYN_TCONV_S1P0, 128, 128, 64, 64, 3);
+      if (g.mode == MMDYN_CONV) P3_GO(MMDYN_CONV, 128, 128, 64, 64, 3);
+      if (g.mode == MMDYN_TCONV_S2P1) P3_GO(MMDYN_TCONV_S2P1, 128, 128, 64, 64, 3);
+    }
+#endif
   if (g.mode == MMDYN_TCONV_S1P0) P3_GO(MMDYN_TCONV_S1P0, 128, 128, 64, 32, 3);
   if (g.mode == MMDYN_DENSE) P3_GO(MMDYN_DENSE, 128, 128, 64, 32, 3);
   if (g.mode == MMDYN_CONV) {
