@@ -363,6 +363,122 @@ def test_last_decoder_layer_with_fused_batchnorm_swish(G, Bg, H, dtype):
         ops.B.precision = prev
 
 
+@pytest.mark.parametrize("G,Bg,H,dtype,mask_c,keep", [(4, 3, 32, torch.float32, 0, 1), (2, 2, 32, torch.float32, 1, -1), (3, 2, 32, torch.float32, 3, 0),
+                                                      (4, 5, 32, torch.bfloat16, 0, 3), (2, 1, 64, torch.float16, 1, None), (1, 2, 128, torch.float32, 0, 0)])
+def test_last_decoder_layer_with_the_loss_in_its_epilogue(G, Bg, H, dtype, mask_c, keep):
+    """Round 6, mmdyn_tconv_out3_bn_bce: BatchNorm2d(32) -> Swish -> ConvTranspose2d(32, 3, 4, 2, 1) (vae.py:275-277) with
+    F.binary_cross_entropy_with_logits(recon, target, reduction='sum') of problems.py:433-437 (with a loss mask of 1 or 3 channels:
+    torch.mul of logits and target first, problems.py:445-447, the plain sums kept beside the masked ones) in the epilogue -- loss sums
+    per group slot, dlogit = the gradient of grad_scale * sum, the logits of ONE group (keep >= 0), of all (-1) or of none (None), a
+    discarded group (slot -1: zero gradient, no loss) -- against ATen in fp64 on the same (possibly 16-bit) pre-BatchNorm tensor, and
+    against the two-kernel form (mmdyn_tconv_out3_bn_fwd + mmdyn_bce_logits_groups) it replaces."""
+    B, S = G * Bg, 2 * H
+    prec = {torch.float32: "fp32", torch.bfloat16: "bf16s", torch.float16: "fp16s"}[dtype]
+    y = (rnd(B, 32, H, H, seed=60) * 2 + 0.3).to(dtype)
+    mean, rstd = rnd(G, 32, seed=61) * 0.3, rnd(G, 32, seed=62).abs() + 0.5
+    gamma, beta = rnd(32, seed=63) + 1.2, rnd(32, seed=64)
+    W = rnd(32, 3, 4, 4, seed=65, scale=0.2)
+    g = torch.Generator().manual_seed(66)
+    target = torch.rand(Bg, 3, S, S, generator=g)
+    mask = (torch.rand(Bg, mask_c, S, S, generator=g) > 0.3).float() if mask_c else None
+    slots = [5, -1, 0, 2][:G] if G > 1 else [1]
+    scale = 0.37
+    yd = y.double()
+    xh = (yd.reshape(G, Bg, 32, H, H) - mean.double().reshape(G, 1, 32, 1, 1)) * rstd.double().reshape(G, 1, 32, 1, 1)
+    u = (xh * gamma.double().reshape(1, 1, 32, 1, 1) + beta.double().reshape(1, 1, 32, 1, 1)).reshape(B, 32, H, H)
+    logits_ref = F.conv_transpose2d(u * torch.sigmoid(u), W.double(), stride=2, padding=1).requires_grad_(True)
+    lg = logits_ref.reshape(G, Bg, 3, S, S)
+    md = None if mask is None else mask.double()
+    want = torch.zeros(8, dtype=torch.float64)
+    want_u = torch.zeros(8, dtype=torch.float64)
+    total = 0.0
+    for gi, sl in enumerate(slots):
+        if sl < 0:
+            continue
+        a, t = (lg[gi], target.double()) if md is None else (lg[gi] * md, target.double() * md)
+        li = F.binary_cross_entropy_with_logits(a, t, reduction="sum")
+        want[sl] += li.detach()
+        want_u[sl] += F.binary_cross_entropy_with_logits(lg[gi], target.double(), reduction="sum").detach()
+        total = total + li
+    (dref,) = torch.autograd.grad(scale * total, logits_ref)
+    prev = ops.B.precision
+    ops.B.precision = prec
+    try:
+        rows = nhwc_rows(y).to(DEV)
+        args = (rows, mean.to(DEV), rstd.to(DEV), gamma.to(DEV), beta.to(DEV), W.to(DEV))
+        acc, acc_u = torch.zeros(8, dtype=torch.float64, device=DEV), torch.zeros(8, dtype=torch.float64, device=DEV)
+        out = None if keep is None else torch.full((B if keep < 0 else Bg, 3, S, S), 7.0, device=DEV)
+        dl = torch.full((B, 3, S, S), 7.0, device=DEV)
+        ops.B.tconv_out3_bn_bce(*args, out, -1 if keep is None else keep, target.to(DEV), dl, acc, slots, scale, G, Bg, H, H,
+                                mask=None if mask is None else mask.to(DEV), mask_channels=max(mask_c, 1),
+                                unmasked_slots=acc_u if mask is not None else None)
+        assert rel(acc, want) < 2e-6 and (mask is None or rel(acc_u, want_u) < 2e-6)
+        assert float((dl.double().cpu() - dref).norm() / dref.norm()) < 5e-6
+        if keep is not None:
+            ref_l = logits_ref.detach() if keep < 0 else lg[keep].detach()
+            assert rel(out, ref_l) < 3e-6
+        # the two-kernel form: the same logits, the same loss sums to fp32 summation order, the same gradient bit for bit
+        out2, dl2 = torch.empty(B, 3, S, S, device=DEV), torch.empty(B, 3, S, S, device=DEV)
+        acc2, acc2_u = torch.zeros(8, dtype=torch.float64, device=DEV), torch.zeros(8, dtype=torch.float64, device=DEV)
+        ops.B.tconv_out3_bn_fwd(*args, out2, G, Bg, H, H)
+        kw = {} if mask is None else dict(mask=mask.to(DEV), chw=3 * S * S, hw=S * S, mask_channels=mask_c, unmasked_slots=acc2_u)
+        ops.B.bce_logits_groups(out2, target.to(DEV), dl2, acc2, slots, target.numel(), scale, **kw)
+        assert torch.equal(dl, dl2) and rel(acc, acc2) < 1e-7
+        if keep is not None:
+            assert torch.equal(out, out2 if keep < 0 else out2[keep * Bg:(keep + 1) * Bg])
+        # evaluation: no gradient buffer
+        acc3 = torch.zeros(8, dtype=torch.float64, device=DEV)
+        ops.B.tconv_out3_bn_bce(*args, None, -1, target.to(DEV), None, acc3, slots, scale, G, Bg, H, H,
+                                mask=None if mask is None else mask.to(DEV), mask_channels=max(mask_c, 1))
+        assert rel(acc3, want) < 2e-6
+    finally:
+        ops.B.precision = prev
+
+
+def test_round6_small_kernels_vs_torch():
+    """mmdyn_mse_groups (the pose term of several passes in one launch), mmdyn_copy_many (aligned, unaligned and odd-sized
+    segments), mmdyn_pass_experts.zdst / .zpl (z of a pass written to further destinations, plain and as the exact three-term
+    split), the plane output of mmdyn_dropout_reduce."""
+    # mse_groups
+    Gp, n = 4, 7 * 37
+    r, t = rnd(Gp, n, seed=70), rnd(n, seed=71)
+    acc = torch.zeros(8, dtype=torch.float64, device=DEV)
+    dr = torch.empty(Gp, n, device=DEV)
+    ops.B.mse_groups(r.to(DEV), t.to(DEV), dr, acc, [3, 4, 5, 6], n, 0.25)
+    d = r.double() - t.double()
+    assert rel(acc[3:7], (d * d).sum(1)) < 1e-6 and rel(dr, 2 * 0.25 * d) < 1e-6 and float(acc[:3].abs().sum()) == 0.0
+    # copy_many: nine segments (two launches), byte sizes that are no multiple of 16, a misaligned pair
+    srcs = [torch.arange(k * 1000 + 17, dtype=torch.float32, device=DEV) * 0.5 for k in range(1, 9)]
+    base_s, base_d = torch.arange(4099, dtype=torch.uint8, device=DEV), torch.zeros(4099, dtype=torch.uint8, device=DEV)
+    srcs.append(base_s[3:])
+    dsts = [torch.zeros_like(x) for x in srcs[:-1]] + [base_d[3:]]
+    ops.B.copy_many(list(zip(dsts, srcs)))
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(dsts, srcs)) and int(base_d[:3].sum()) == 0
+    # product of experts: z of pass 0 to two plain destinations and one plane destination
+    B, L = 5, 64
+    mu, lv, eps = rnd(B, L, seed=72).to(DEV), rnd(B, L, seed=73).to(DEV), rnd(1, B, L, seed=74).to(DEV)
+    out_mu, out_lv, z = (torch.empty(1, B, L, device=DEV) for _ in range(3))
+    z1, z2 = torch.zeros(B, L, device=DEV), torch.zeros(3 * B, L, device=DEV)
+    zp = ops.Planes(2 * B, L, DEV)
+    zp.t.zero_()
+    p = {"mu": [mu, None, None], "lv": [lv, None, None], "dmu": [None] * 3, "dlv": [None] * 3, "ld": [L] * 3,
+         "zdst": [z1, z2[B:2 * B], None], "zpl": [zp.t.data_ptr() + B * 3 * L * 2, None]}
+    ops.B.poe_fwd([p], eps, out_mu, out_lv, z, None, True, 1, B, L)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z[0]) and torch.equal(z2[B:2 * B], z[0]) and float(z2[:B].abs().sum() + z2[2 * B:].abs().sum()) == 0.0
+    assert torch.equal(zp.float()[B:], z[0]) and torch.equal(zp.t[B:], _planes(z[0].contiguous()).t) and float(zp.t[:B].abs().sum()) == 0.0
+    # dropout backward with a plane copy of its result
+    P, Bd, H = 3, 6, 512
+    dout, masks = rnd(P, Bd, H, seed=75).to(DEV), (torch.rand(P, Bd, H) > 0.1).to(torch.uint8).to(DEV)
+    uu = rnd(Bd, H, seed=76).to(DEV)
+    dh, dh2 = torch.empty(Bd, H, device=DEV), torch.empty(Bd, H, device=DEV)
+    dhp = ops.Planes(Bd, H, DEV)
+    ops.B.dropout_reduce(dout, masks, dh, P, Bd, H, 0.1, u=uu, act=ops.ACT_SWISH, planes=dhp)
+    ops.B.dropout_reduce(dout, masks, dh2, P, Bd, H, 0.1, u=uu, act=ops.ACT_SWISH)
+    assert torch.equal(dh, dh2) and torch.equal(dhp.float(), dh) and torch.equal(dhp.t, _planes(dh).t)
+
+
 # ---- fp32 GEMMs on the bf16 matrix cores: the exact three-term operand split (csrc/igemm_nt.hip / wgrad_tn.hip X3) --------------
 # Held to the SAME tolerances against fp64 ATen as the native fp32 kernels above, at sizes the split's launch rule serves
 # (>= 512 blocks of 64x64 or >= 384 of 128x128); "served" is checked too: the result differs in its last bits from the native one.
