@@ -75,9 +75,11 @@ int mmdyn_abi_version(void);
  *            (mmdyn_igemm_slab_floats_mx).
  *   arrival_flags (mmdyn_igemm_nt_mx, _dgrad_bn, _dgrad_act; revision 6): MMDYN_IGEMM_FLAG_WORDS uint32 words that are ZERO when the
  *            launch starts and that the launch leaves zero, owned by this launch until it has completed (a launch captured
- *            into a graph owns them for the graph's life).  With them the persistent kernel finishes a tile whose K range
- *            straddles several blocks INSIDE the launch -- the piece that arrives last on the tile's word sums the pieces in K
- *            order and runs the epilogue: same results bit for bit, no fix-up launch.  NULL: slabs + the fix-up launch.
+ *            into a graph owns them for the graph's life).  With them the LAB build of the library (make lab) finishes a tile
+ *            whose K range straddles several blocks INSIDE the launch -- the piece that arrives last on the tile's word sums the
+ *            pieces in K order and runs the epilogue: same results bit for bit, no fix-up launch.  The PRODUCT library accepts
+ *            and ignores the argument: that form measured 3-6 % slower on the train step (docs/LAB_NOTES.md H.a), so slabs + the
+ *            fix-up launch stay.  NULL: slabs + the fix-up launch in either build.
  * Requirements: Cin % 32 == 0, N % 32 == 0.  v_mfma_f32_32x32x2_f32, fp32 in / fp32 accumulate. */
 #define MMDYN_IGEMM_FLAG_WORDS 8192
 int mmdyn_igemm_nt(const float* A, const float* Bp, const float* bias, float* C, float* C_act,
