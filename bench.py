@@ -284,6 +284,9 @@ def main():
                     help="A/B switch (LAB library only: MMDYN_HIP_LIB=.../libmmdyn_hip_lab.so): the persistent stream-K kernels finish "
                          "split tiles inside the launch instead of parking the pieces for a fix-up launch (measured slower: LAB_NOTES H.a)")
     ap.add_argument("--ab-off", default="", help="A/B switches (comma list): fused_bce, copy_many -- turn a round-6 change off")
+    ap.add_argument("--ticket-max-work", type=int, default=None,
+                    help="A/B switch: BatchNorm finalize launches with at most this many (group, tile) partial-sum rows take the "
+                         "single-launch last-block-finishes form (ops.HipBackend.ticket_max_work)")
     ap.add_argument("--fc-planes", action="store_true",
                     help="A/B switch (f32x3): the decoder's Linear forward and the encoder FC layer's input gradient on the DENSE mode of "
                          "the plane-ring kernel (measured 0.6 %% slower on the two-lane step: layers.FC_PLANES)")
@@ -347,6 +350,9 @@ def main():
             _eng.COPY_MANY = False
         else:
             raise SystemExit(f"--ab-off: unknown switch {sw}")
+    if args.ticket_max_work is not None:
+        from mmdyn_hip import ops as _ops3
+        _ops3.B.ticket_max_work = args.ticket_max_work
     if args.fc_planes:
         from mmdyn_hip import layers as _lay2
         _lay2.FC_PLANES = True

@@ -87,10 +87,11 @@ class Planes:
         return (f[:, 0] + f[:, 1]) + f[:, 2]
 
 
-# The "last block finishes" single-launch forms of mmdyn_bn_finalize / mmdyn_bn_bwd_finalize / mmdyn_colsum are OFF by
-# default: measured on the two-lane step they cost 0.12 ms (fp32 bs 256: 6.78 -> 6.90 ms; bf16s bs 128: 2.165 -> 2.19 ms) --
+# The "last block finishes" single-launch forms of mmdyn_bn_finalize / mmdyn_bn_bwd_finalize / mmdyn_colsum are not taken by
+# EVERY launch: measured on the two-lane step that cost 0.12 ms (fp32 bs 256: 6.78 -> 6.90 ms; bf16s bs 128: 2.165 -> 2.19 ms) --
 # up to 1024 blocks arrive on one counter (~12 ns per arrival) and every block drains its stores before it may leave
-# (docs/LAB_NOTES.md D).  MMDYN_TICKET=1 switches them on (kernel tests, experiments).
+# (docs/LAB_NOTES.md D).  The BatchNorm finalize launches with SMALL partial tables take it (HipBackend.ticket_max_work, round 6:
+# LAB_NOTES H.g); MMDYN_TICKET=1 switches it on everywhere (kernel tests, experiments).
 _USE_TICKET = bool(os.environ.get("MMDYN_TICKET"))
 
 
@@ -104,6 +105,11 @@ class HipBackend:
         self.use_flags = False                         # (the product library ignores arrival words: see _flags)
         self._flagpool = {}                            # device -> [zeroed int32 pool, next eager block, next graph block, free graph blocks]
         self.force_ticket = False
+        # BatchNorm finalize launches whose partial-sum table has at most this many (group, tile) rows take the single-launch
+        # "last block finishes" form (0: none, rounds 3-5 -- the form lost on the whole step when EVERY finalize took it).  Same
+        # box, interleaved (profiles/r6/ab_bn_finalize_small_tables.txt, bench.py --ticket-max-work): 1024 = nothing on the
+        # power-bound configs[1] step, +1.1 % on bf16s bs 128, 18 launches fewer per step; bit-identical results either way
+        self.ticket_max_work = 1024
         # "fp32": v_mfma_f32_32x32x2_f32 (the reference's arithmetic, the default and the BASELINE configs[1] path);
         # "bf16": operands rounded to bf16 on their way into the matrix cores, fp32 accumulate (configs[2]);
         # "fp16": the same with IEEE-half operands (configs[4]); "bf16s": bf16 + bf16 activation storage;
@@ -116,7 +122,7 @@ class HipBackend:
 
     TICKET_SLOTS, TICKET_STRIDE = 4096, 16             # one 64-byte line per slot
 
-    def _ticket(self, like):
+    def _ticket(self, like, work=None):
         """Address of a zero-initialised arrival counter for ONE launch (the "last block finishes" kernels:
         mmdyn_bn_finalize, mmdyn_bn_bwd_finalize, mmdyn_colsum); the kernel that used a slot leaves it zero.
         A launch recorded into a HIP graph keeps its slot for every replay, so captured launches draw from the lower half
@@ -126,7 +132,7 @@ class HipBackend:
         launches cycle through the upper half: a slot comes up again only after 2048 eager launches of this kind -- far more
         than a train step issues -- so no two launches in flight share one, and none can meet a slot that a replaying graph
         owns."""
-        if not (_USE_TICKET or self.force_ticket):
+        if not (_USE_TICKET or self.force_ticket or (work is not None and work <= self.ticket_max_work)):
             return None
         dev = like.device
         ent = self._tickets.get(dev)
@@ -542,7 +548,7 @@ class HipBackend:
                     eps, momentum, repeat):
         check(self.lib.mmdyn_bn_finalize(_ptr(partial), _ptr(mean), _ptr(rstd), _ptr(running_mean),
                                          _ptr(running_var), _ptr(nbt, torch.int64), _ptr(scratch, torch.float64),
-                                         G, T, C, rows_per_group, eps, momentum, repeat, self._ticket(partial), _stream()),
+                                         G, T, C, rows_per_group, eps, momentum, repeat, self._ticket(partial, G * T), _stream()),
               "mmdyn_bn_finalize")
 
     def bn_swish_fwd(self, y, mean, rstd, gamma, beta, a, G, rows_per_group, C, planes=None):
@@ -577,7 +583,7 @@ class HipBackend:
 
     def bn_bwd_finalize(self, partial, sums, dgamma, dbeta, scratch, G, T, C, beta_acc):
         check(self.lib.mmdyn_bn_bwd_finalize(_ptr(partial), _ptr(sums), _ptr(dgamma), _ptr(dbeta),
-                                             _ptr(scratch, torch.float64), G, T, C, float(beta_acc), self._ticket(partial),
+                                             _ptr(scratch, torch.float64), G, T, C, float(beta_acc), self._ticket(partial, G * T),
                                              _stream()), "mmdyn_bn_bwd_finalize")
 
     def bn_eval_stats(self, running_mean, running_var, mean, rstd, G, C, eps):

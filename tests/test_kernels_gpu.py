@@ -134,14 +134,15 @@ def test_igemm_dgrad_act_epilogue(case, act):
 
 
 def test_single_launch_finalize_equals_two_launches():
-    """The "last block finishes" forms (ticket counter; off by default, see ops._USE_TICKET) of the BatchNorm finalize,
-    the BatchNorm-backward finalize and the column sum are bit-identical to the two-launch forms, also when the same
-    counter slot is used again (the last block resets it)."""
+    """The "last block finishes" forms (ticket counter; taken for small partial tables only, see ops.HipBackend.ticket_max_work) of
+    the BatchNorm finalize, the BatchNorm-backward finalize and the column sum are bit-identical to the two-launch forms, also when
+    the same counter slot is used again (the last block resets it)."""
     G, T, C, rpg = 4, 300, 64, 4096
     part = rnd(G, T, 2, C, seed=61).to(DEV)
     outs = []
+    rule = HIP.ticket_max_work
     for tick in (False, True, True):
-        HIP.force_ticket = tick
+        HIP.force_ticket, HIP.ticket_max_work = tick, 0
         try:
             mean, rstd = torch.zeros(G, C, device=DEV), torch.zeros(G, C, device=DEV)
             rm, rv, nbt = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
@@ -154,7 +155,7 @@ def test_single_launch_finalize_equals_two_launches():
             torch.cuda.synchronize()
             outs.append([t.clone() for t in (mean, rstd, rm, rv, nbt, sums, dg, db, cs)])
         finally:
-            HIP.force_ticket = False
+            HIP.force_ticket, HIP.ticket_max_work = False, rule
     for i, (a, b, c) in enumerate(zip(*outs)):
         if i == len(outs[0]) - 1:
             # column sums: without a ticket the FC-level row counts take the single-launch kernel (one block per 32 channels over all

@@ -319,6 +319,37 @@ def test_fc_level_launches_on_the_plane_ring_match_the_default_step(monkeypatch)
     step.close()
 
 
+@pytest.mark.parametrize("precision", ["fp32x3", "bf16s"])
+def test_single_launch_finalize_of_small_tables_leaves_the_step_bit_identical(precision):
+    """ops.B.ticket_max_work (round 6: BatchNorm finalize launches with at most 1024 partial-sum rows take the single-launch
+    "last block finishes" form): three replayed steps at B = 64 with the rule on (the default), off (rounds 3-5) and on for EVERY
+    finalize give the same loss step by step and the same weights, bit for bit, afterwards."""
+    from mmdyn_hip import ops
+    B, klw = 64, 0.05
+    prev = ops.B.ticket_max_work
+    assert prev == 1024
+    results = []
+    try:
+        for w in (1024, 0, 1 << 30):
+            ops.B.ticket_max_work = w
+            m = T.build("cnn-mvae", True, True, DEV)
+            step = MVAEStep(m, noise=NoiseSource(11), precision=precision)
+            inputs, targets = seeded_batch(B, 5)
+            gi, gt = [x.to(DEV) for x in inputs], [x.to(DEV) for x in targets]
+            losses = [float(step.train_step_graphed(gi, gt, klw)) for _ in range(3)]
+            assert step._graph is not None
+            torch.cuda.synchronize()
+            results.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+            step.close()
+    finally:
+        ops.B.ticket_max_work = prev
+    (l0, s0) = results[0]
+    for l1, s1 in results[1:]:
+        assert l1 == pytest.approx(l0, rel=1e-7)        # (the loss sums are fp64 atomics: their order is free)
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), k
+
+
 def test_bf16_engine_vs_oracle():
     """BASELINE configs[2] arithmetic (bf16 matrix-core operands, fp32 accumulate / storage / master weights) against
     the fp32 CPU oracle, B=32, injected noise.  Stated tolerance for this mode: ELBO and each partial within 5e-3
