@@ -1366,12 +1366,6 @@ int mmdyn_igemm_wsp3_try(const void* A, const void* Bp, const float* bias, float
       if (g.mode == MMDYN_CONV) P3_GO(MMDYN_CONV, 128, 128, 64, 64, 3);
       if (g.mode == MMDYN_TCONV_S2P1) P3_GO(MMDYN_TCONV_S2P1, 128, 128, 64, 64, 3);
     }
-  // LAB, MMDYN_P3_W32=1: the 128x64 tile on 4 x 2 MFMA waves of 32x32 (0.5 fragment reads per MFMA instead of 0.625 with 2 x 4 of 64x16)
-  if (const char* e = lab_env("MMDYN_P3_W32"))
-    if (e[0] == '1' && c.bn == 64 && c.bm == 128 && c.s == 3) {
-      if (g.mode == MMDYN_CONV) P3_GO(MMDYN_CONV, 128, 64, 32, 32, 3);
-      if (g.mode == MMDYN_TCONV_S2P1) P3_GO(MMDYN_TCONV_S2P1, 128, 64, 32, 32, 3);
-    }
 #endif
   if (g.mode == MMDYN_TCONV_S1P0) P3_GO(MMDYN_TCONV_S1P0, 128, 128, 64, 32, 3);
   if (g.mode == MMDYN_DENSE) P3_GO(MMDYN_DENSE, 128, 128, 64, 32, 3);

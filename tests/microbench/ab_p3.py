@@ -3,8 +3,7 @@
 (x3) what the product dispatch runs when the operands are fp32 -- the persistent kernel that splits its fragments in the MFMA
 waves' registers, or the register-staged split kernel -- against (p3) the plane-ring kernel on operands that ARRIVE split
 (igemm_wsp3_kernel), in the configurations named on the command line.  LAB build of the library (forces tiles / thresholds).
-usage: ab_p3.py [patch] [cfg ...]     cfg = "BM,BN,S" (forced through MMDYN_P3_TILE), "rule" (the library's own pick; default) or
-"w32" (the rule with MMDYN_P3_W32=1: N = 64 launches on 32x32 wave tiles);
+usage: ab_p3.py [patch] [cfg ...]     cfg = "BM,BN,S" (forced through MMDYN_P3_TILE) or "rule" (the library's own pick; default);
 "patch": the 32-channel up-sampling launches instead (tconv_patch_kernel on fp32 operands against its plane form)"""
 import os
 import statistics
@@ -91,16 +90,11 @@ def main():
                 if v == "x3":
                     fn = launch(A, Bp, False)
                 else:
-                    os.environ.pop("MMDYN_P3_W32", None)
                     if v == "rule":
                         os.environ.pop("MMDYN_P3_TILE", None)
-                    elif v == "w32":            # the 128x64 tile on 4 x 2 waves of 32x32 (the rule's pick otherwise)
-                        os.environ.pop("MMDYN_P3_TILE", None)
-                        os.environ["MMDYN_P3_W32"] = "1"
                     else:
                         os.environ["MMDYN_P3_TILE"] = v
-                    if not HIP.igemm_planes_served(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N) or \
-                            (v not in ("rule", "w32") and N % int(v.split(",")[1])):
+                    if not HIP.igemm_planes_served(mode, G, Bg, Hi, Hi, Cin, Ho, Ho, N) or (v != "rule" and N % int(v.split(",")[1])):
                         times[v].append(float("nan"))
                         continue
                     fn = launch(Ap, Bq, True)
