@@ -268,9 +268,15 @@ class MVAEStep:
         # backward and replayed as two more graphs during the encoder backward -- on the main stream since round 5 (_replay; rounds
         # 3-4: on two more streams).  None: the measured rule (tests/microbench/run_ab_defer_wgrad.sh, same box, alternating runs:
         # fp32 bs 256 +0.3 .. 0.9 % over three boxes, 128x128 fp32 7.0 -> 6.85 ms (+2 %), 256x256 fp32 +0.5 .. 5 %; the 16-bit
-        # storage modes 0 .. -2 %) -- on in fp32 on one GPU.
+        # storage modes 0 .. -2 %) -- on in fp32 on one GPU.  Round 6, after the launch removals, measured again (same box, alternating,
+        # profiles/r6/ab_defer_wgrad_16bit.txt): the 16-bit STORAGE modes gain 1.4-3.3 % at 64 and 128 pixels (bf16s bs 128 64.3 -> 65.8 k,
+        # fp16s bs 128 63.7 -> 65.6 k, 128 px bf16s / fp16s +2.7 / +3.0 %) and nothing at 256 pixels (+-0.2 %); bf16 / fp16 on fp32
+        # storage -0.2 ... +0.7 % at 64 pixels, fp16 at 256 pixels -1.3 % -- on for the storage modes below 256 pixels as well.
         # Data parallel: off, the decoders' gradient bucket would start its all-reduce a phase later.
-        self.defer_wgrad = (precision in ("fp32", "fp32x3") and process_group is None) if defer_wgrad is None else bool(defer_wgrad)
+        if defer_wgrad is None:
+            side = int(getattr(getattr(model, "visual_decoder", None), "image_size", 64) or 64)
+            defer_wgrad = process_group is None and (precision in ("fp32", "fp32x3") or (precision in ("bf16s", "fp16s") and side < 256))
+        self.defer_wgrad = bool(defer_wgrad)
         self.loss_scale = 1.0
         # False (default): each image decoder runs only on the passes whose reconstruction enters the loss, so its
         # BatchNorm running buffers see 4 EMA updates per step (2 without pose) where the reference applies 7 (3).

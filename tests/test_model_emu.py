@@ -318,8 +318,17 @@ def test_deferred_decoder_weight_gradients_equal_inline():
         step.backward()
         grads.append(step.params.grad.clone())
     assert torch.equal(grads[0], grads[1])
-    assert not MVAEStep(build("cnn-mvae", True, True, "cpu"), precision="bf16s").defer_wgrad
+    # the measured rule (engine.MVAEStep: profiles/r6/ab_defer_wgrad_16bit.txt): on in fp32 / fp32x3 and in the 16-bit storage modes
+    # below 256 pixels; off for 16-bit matrix-core operands on fp32 storage, at 256 pixels in the storage modes, and data parallel
     assert MVAEStep(build("cnn-mvae", True, True, "cpu")).defer_wgrad
+    assert MVAEStep(build("cnn-mvae", True, True, "cpu"), precision="fp32").defer_wgrad
+    for prec in ("bf16s", "fp16s"):
+        assert MVAEStep(build("cnn-mvae", True, True, "cpu"), precision=prec).defer_wgrad
+        assert MVAEStep(build("cnn-mvae", True, True, "cpu", size=128), precision=prec).defer_wgrad
+        assert not MVAEStep(build("cnn-mvae", True, True, "cpu", size=256), precision=prec).defer_wgrad
+    for prec in ("bf16", "fp16"):
+        assert not MVAEStep(build("cnn-mvae", True, True, "cpu"), precision=prec).defer_wgrad
+    assert not MVAEStep(build("cnn-mvae", True, True, "cpu"), precision="bf16s", defer_wgrad=False).defer_wgrad
 
 
 def test_fp32x3_precision_plumbing():
