@@ -1207,6 +1207,11 @@ class MVAEInference:
                   "td": self._P("tactile_decoder", m.tactile_decoder.param_keys())}
         self.buf = {"ve": m.visual_encoder.bn_buffers(), "te": m.tactile_encoder.bn_buffers(),
                     "vd": m.visual_decoder.bn_buffers(), "td": m.tactile_decoder.bn_buffers()}
+        if ops.B.name == "hip":
+            # the running estimates do not change between requests: their mean / rstd once, not one launch per layer and request
+            # (written into the tensors of the previous refresh, which captured graphs read)
+            prev = getattr(self, "_eval_buf", None) or {}
+            self.buf = self._eval_buf = {k: layers.precompute_eval_stats(v, prev.get(k)) for k, v in self.buf.items()}
         if self.use_pose:
             self.P["pe"] = self._P("pose_encoder", layers.POSE_ENC_KEYS + layers.HEAD_KEYS)
             self.P["pd"] = self._P("pose_decoder", layers.POSE_DEC_KEYS)
@@ -1217,7 +1222,8 @@ class MVAEInference:
             specs["ph"] = layers.heads_pack_specs(self.P["pe"])
         if getattr(self, "pk", None) is None:
             if ops.B.name == "hip":
-                self._plan = layers.PackPlan(specs, w_dtype=self._w_dtype)
+                # (fp32x3: the conv-weight packs also as plane twins -- the weights are split ONCE here, not by a launch per layer and request)
+                self._plan = layers.PackPlan(specs, w_dtype=self._w_dtype, plane_twins=self.precision == "fp32x3")
                 self.pk = self._plan.packed
             else:
                 self._plan, self._specs = None, specs
@@ -1229,6 +1235,14 @@ class MVAEInference:
                 self.pk = {k: layers.pack_now(v) for k, v in specs.items()}
             finally:
                 layers.W_DTYPE = prev_w
+
+    def close(self):
+        """Drop the captured graphs and give back the pack plan's plane twins (registered in layers.PLANE_TWIN by strong reference)."""
+        self._graphs = {}
+        for ptr, pl in getattr(self._plan, "twins", None) or ():
+            ent = layers.PLANE_TWIN.get(ptr)
+            if ent is not None and ent[1] is pl:
+                del layers.PLANE_TWIN[ptr]
 
     # ---- the forward itself (eager; captured by _graphed) -------------------------------------------------
     def _encode(self, key, x):
@@ -1304,8 +1318,11 @@ class MVAEInference:
                     out = fn(*static)
                 ent = self._graphs[key] = (g, static, out)      # (capture records, it does not execute: replay below)
             g, static, out = ent
-            for dst, src in zip(static, new_inputs):
-                if dst is not None and dst.data_ptr() != src.data_ptr():
+            moves = [(dst, src) for dst, src in zip(static, new_inputs) if dst is not None and dst.data_ptr() != src.data_ptr()]
+            if COPY_MANY and len(moves) > 1 and ops.B.name == "hip" and all(d.dtype == s_.dtype and s_.is_cuda for d, s_ in moves):
+                ops.B.copy_many(moves)                          # the request's inputs into the graph's static buffers: one launch
+            else:
+                for dst, src in moves:
                     dst.copy_(src)
             g.replay()
             return out

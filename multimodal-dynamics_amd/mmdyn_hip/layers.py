@@ -223,11 +223,43 @@ def tconv_s1p0(x, Wsp, G, Bg, Cin, N, stats=False):
 
 
 class BNState:
-    """Handles of one BatchNorm2d: affine parameters + running buffers (may be None to skip updates)."""
-    __slots__ = ("gamma", "beta", "rm", "rv", "nbt")
+    """Handles of one BatchNorm2d: affine parameters + running buffers (may be None to skip updates).
+    ``eval_stats``: (mean, rstd) [1][C] of the running estimates, computed ahead by a caller whose weights do not change between
+    calls (engine.MVAEInference.refresh) -- eval-mode passes with one group then skip the per-call mmdyn_bn_eval_stats launch."""
+    __slots__ = ("gamma", "beta", "rm", "rv", "nbt", "eval_stats")
 
-    def __init__(self, gamma, beta, rm=None, rv=None, nbt=None):
-        self.gamma, self.beta, self.rm, self.rv, self.nbt = gamma, beta, rm, rv, nbt
+    def __init__(self, gamma, beta, rm=None, rv=None, nbt=None, eval_stats=None):
+        self.gamma, self.beta, self.rm, self.rv, self.nbt, self.eval_stats = gamma, beta, rm, rv, nbt, eval_stats
+
+
+def _eval_stats(y, bn, G, C):
+    """mean / rstd [G][C] of an eval-mode BatchNorm: the running estimates (nn.BatchNorm2d, training=False)."""
+    if G == 1 and bn.eval_stats is not None:
+        return bn.eval_stats
+    mean, rstd = _new(y, G, C), _new(y, G, C)
+    ops.B.bn_eval_stats(bn.rm, bn.rv, mean, rstd, G, C, BN_EPS)
+    return mean, rstd
+
+
+def precompute_eval_stats(buf, prev=None):
+    """For every BatchNorm2d with running buffers in ``buf``: mean / rstd of the running estimates, stored in a copy of ``buf`` under
+    "<layer>.eval_stats" (picked up by _bn_of).  Valid until the buffers change: the caller recomputes -- into the SAME tensors when it
+    passes its previous result as ``prev`` (captured graphs keep reading them)."""
+    out = dict(buf)
+    for k in buf:
+        if k.endswith(".running_mean"):
+            pre = k[:-len(".running_mean")]
+            rm, rv = buf[k], buf[pre + ".running_var"]
+            C = rm.numel()
+            old = (prev or {}).get(pre + ".eval_stats")
+            if old is not None and old[0].numel() == C and old[0].device == rm.device:
+                mean, rstd = old
+            else:
+                mean = torch.empty(1, C, device=rm.device, dtype=torch.float32)
+                rstd = torch.empty(1, C, device=rm.device, dtype=torch.float32)
+            ops.B.bn_eval_stats(rm, rv, mean, rstd, 1, C, BN_EPS)
+            out[pre + ".eval_stats"] = (mean, rstd)
+    return out
 
 
 class SyncBN:
@@ -296,8 +328,7 @@ def bn_swish_from_partials(y, partial, T, bn, G, rows_per_group, C, repeat=1, pl
     """Returns (a, mean, rstd).  ``planes`` (fp32x3: the consumer GEMMs take their operand already split): the activated tensor is
     written ONLY as an ops.Planes -- the split rides on this pass, no fp32 copy exists -- and returned in place of ``a``."""
     if partial is None:             # eval mode: running estimates, no update (nn.BatchNorm2d, training=False)
-        mean, rstd = _new(y, G, C), _new(y, G, C)
-        ops.B.bn_eval_stats(bn.rm, bn.rv, mean, rstd, G, C, BN_EPS)
+        mean, rstd = _eval_stats(y, bn, G, C)
     else:
         mean, rstd = _bn_forward_stats(y, partial, T, bn, G, rows_per_group, C, repeat)
     if planes and y.dtype == torch.float32:
@@ -386,9 +417,7 @@ def run_deferred_wgrads(queue):
 def bn_stats_only(y, partial, T, bn, G, rows_per_group, C, repeat=1):
     """mean / rstd of a BatchNorm layer WITHOUT the apply pass (the consumer applies BatchNorm + Swish on its operand fetch)."""
     if partial is None:             # eval mode: running estimates
-        mean, rstd = _new(y, G, C), _new(y, G, C)
-        ops.B.bn_eval_stats(bn.rm, bn.rv, mean, rstd, G, C, BN_EPS)
-        return mean, rstd
+        return _eval_stats(y, bn, G, C)
     return _bn_forward_stats(y, partial, T, bn, G, rows_per_group, C, repeat)
 
 
@@ -699,7 +728,7 @@ ENC_KEYS = enc_keys(0)                      # the reference's 64 x 64 encoder
 def _bn_of(P, buf, pre):
     b = buf or {}
     return BNState(P[pre + ".weight"], P[pre + ".bias"], b.get(pre + ".running_mean"),
-                   b.get(pre + ".running_var"), b.get(pre + ".num_batches_tracked"))
+                   b.get(pre + ".running_var"), b.get(pre + ".num_batches_tracked"), b.get(pre + ".eval_stats"))
 
 
 def run(gen):
@@ -757,7 +786,8 @@ def encoder_trunk_forward_steps(P, buf, x, G=1, repeat=1, packed=None, training=
     # fp32x3: an activation whose consumer GEMM takes plane operands exists ONLY as ops.Planes from here on (the convolution
     # that reads it and the weight gradient that reads it as `a_in` both take it so); conv_net.0's output comes out of its kernel
     # as fp32 and is split by its own launch
-    if training and len(convs) and planes_served(CONV, G, Bg, H, 32, H // 2, P[f"conv_net.{convs[0]}.weight"].shape[0]):
+    # (eval mode too since round 6: the inference engine's launches take the same plane operands as the train step's)
+    if len(convs) and planes_served(CONV, G, Bg, H, 32, H // 2, P[f"conv_net.{convs[0]}.weight"].shape[0]):
         a = as_planes(a1, 32)
     for j, i in enumerate(convs):
         cout = P[f"conv_net.{i}.weight"].shape[0]
@@ -766,7 +796,7 @@ def encoder_trunk_forward_steps(P, buf, x, G=1, repeat=1, packed=None, training=
         bn = _bn_of(P, buf, f"conv_net.{i + 1}")
         y, st, T = conv_like(a, pk[f"W{j + 2}k"], CONV, G, Bg, H, cin, Ho, cout, stride, offset, training)
         want = False           # does the NEXT convolution take its operand already split?  Then BatchNorm + Swish writes it so.
-        if not last and training:
+        if not last:
             nlast = j + 1 == len(convs) - 1
             want = planes_served(CONV, G, Bg, Ho, cout, Ho - 3 if nlast else Ho // 2, P[f"conv_net.{convs[j + 1]}.weight"].shape[0])
         an, m, r = bn_swish_from_partials(y, st, T, bn, G, Bg * Ho * Ho, cout, repeat, planes=want)
@@ -860,7 +890,7 @@ def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, co
     # rows -> hw*256+c.  bf16 storage mode: the activated output is the first transposed convolution's operand and is stored
     # as such (the matrix cores round it to bf16 either way); the pre-activation stays fp32 for the backward
     c0 = P[f"hallucinate.{convs[0]}.weight"].shape[0]
-    want0 = training and planes_served(TCONV_S1P0, G, Bg, 5, c0, 8, P[f"hallucinate.{convs[0]}.weight"].shape[1])
+    want0 = planes_served(TCONV_S1P0, G, Bg, 5, c0, 8, P[f"hallucinate.{convs[0]}.weight"].shape[1])
     # fp32x3 (round 6): with z arriving split (``z_planes``: written by the product-of-experts launch) and the packed weight's plane
     # twin the Linear layer runs on the plane-ring kernel and hands its activated output to the first transposed convolution as
     # plane rows of its 256 channels -- no stand-alone split launch, no fp32 copy of h0 (the backward reads u0)
@@ -891,7 +921,7 @@ def decoder_forward_steps(P, buf, z, G=1, repeat=1, logits=True, packed=None, co
             an = None
         else:
             # (fp32x3: written ONLY as ops.Planes when the next transposed convolution takes plane operands)
-            want = training and j + 1 < len(convs) and planes_served(TCONV_S2P1, G, Bg, Ho, cout, 2 * Ho,
+            want = j + 1 < len(convs) and planes_served(TCONV_S2P1, G, Bg, Ho, cout, 2 * Ho,
                                                                      P[f"hallucinate.{convs[j + 1]}.weight"].shape[1])
             an, m, r = bn_swish_from_partials(y, st, T, bn, G, Bg * Ho * Ho, cout, repeat, planes=want)
         stages.append(dict(i=i, Hi=H, Ho=Ho, cin=cin, cout=cout, a_in=a, y=y, a=an, m=m, r=r, bn=bn))

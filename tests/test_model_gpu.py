@@ -704,6 +704,60 @@ def test_inference_engine_extended_size():
     assert tuple(s[0].shape) == (4, 3, size, size)
 
 
+def test_inference_engine_on_plane_operands_at_the_serving_batch():
+    """engine.MVAEInference at B = 256 in the default arithmetic (round 6: its convolution-level launches take plane operands -- the
+    weights' plane twins written once by refresh(), the activations written split by the eval-mode BatchNorm pass, whose mean / rstd
+    are precomputed): against the CPU oracle in eval mode (posterior means / log-variances of the visual expert alone and a
+    deterministic decode of z = means), and against the native-fp32 engine; then new weights + refresh(): the captured graphs stay
+    valid and give what a fresh engine gives."""
+    from mmdyn_hip.engine import MVAEInference
+    from mmdyn_hip.utils.seeded_init import seeded_running_stats
+    from mmdyn_hip import layers
+    B = 256
+    shapes = state_dict_shapes("cnn-mvae", use_pose=True)
+    sd = seeded_running_stats(seeded_state_dict(shapes, 0), 7)
+    m = T.build("cnn-mvae", True, True, DEV)
+    m.load_state_dict(sd)
+    m.eval()
+    inputs, _ = seeded_batch(B, 33)
+    gi = [x.to(DEV) for x in inputs]
+    eng = MVAEInference(m, seed=3)
+    assert eng.precision == "fp32x3" and len(eng._plan.twins) > 0                          # conv weights split once, by the pack plan
+    assert all(k.endswith(".eval_stats") is False or isinstance(v, tuple) for k, v in eng.buf["ve"].items())
+    assert any(k.endswith(".eval_stats") for k in eng.buf["ve"]) and any(k.endswith(".eval_stats") for k in eng.buf["vd"])
+    for _ in range(2):                                                                     # second call: graph replay
+        v1, t1, p1, mu1, lv1 = [None if x is None else x.clone() for x in eng([gi[0], None], pose=None)]
+    prm, buf = O.split_state(sd, requires_grad=False)
+    with O.eval_mode():
+        mo, lo = O.image_encoder(inputs[0], prm, "visual_encoder", None, buf)
+    pm, plv = O.product_of_experts(torch.stack([torch.zeros_like(mo), mo]), torch.stack([torch.zeros_like(lo), lo]))
+    torch.testing.assert_close(mu1.cpu(), pm, rtol=1e-4, atol=3e-5)
+    torch.testing.assert_close(lv1.cpu(), plv, rtol=1e-4, atol=3e-5)
+    ref = MVAEInference(m, precision="fp32", seed=3)                                       # same Philox stream: same z
+    for _ in range(2):
+        v0, t0, p0, mu0, lv0 = [None if x is None else x.clone() for x in ref([gi[0], None], pose=None)]
+    torch.testing.assert_close(mu1, mu0, rtol=1e-4, atol=3e-5)
+    assert float((v1 - v0).norm() / v0.norm()) < 1e-4 and float((t1 - t0).norm() / t0.norm()) < 1e-4
+    # new weights and running statistics, refresh(): same graphs, new results -- equal to a fresh engine's
+    sd2 = seeded_running_stats(seeded_state_dict(shapes, 5), 11)
+    ptrs = [x.data_ptr() for x in eng.buf["ve"][next(k for k in eng.buf["ve"] if k.endswith(".eval_stats"))]]
+    m.load_state_dict(sd2)
+    eng.refresh()
+    assert ptrs == [x.data_ptr() for x in eng.buf["ve"][next(k for k in eng.buf["ve"] if k.endswith(".eval_stats"))]]
+    n_graphs = len(eng._graphs)
+    a = [None if x is None else x.clone() for x in eng([gi[0], gi[1]], pose=gi[2])]
+    a = [None if x is None else x.clone() for x in eng([gi[0], None], pose=None)]
+    assert len(eng._graphs) == n_graphs + 1                                                # (the joint shape was new; the visual-only graph was reused)
+    fresh = MVAEInference(m, seed=3)
+    for _ in range(2):
+        b = [None if x is None else x.clone() for x in fresh([gi[0], None], pose=None)]
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])                             # means / log_var: no randomness
+    assert not torch.equal(a[3], mu1)
+    n_twins = len(layers.PLANE_TWIN)
+    eng.close(), ref.close(), fresh.close()
+    assert len(layers.PLANE_TWIN) < n_twins
+
+
 def test_data_parallel_schedule_two_ranks_on_one_gpu():
     """``bench.py --gpus 2`` with both ranks on this one GPU and the collectives over gloo (MMDYN_BENCH_REHEARSE_ONE_GPU=1): the real
     kernels and HIP graphs under the data-parallel schedule -- gradient buckets reduced between the graph rows, rank-0 broadcast,
