@@ -758,6 +758,38 @@ def test_inference_engine_on_plane_operands_at_the_serving_batch():
     assert len(layers.PLANE_TWIN) < n_twins
 
 
+@pytest.mark.parametrize("B", [1, 77, 130, 300])
+def test_inference_engine_ragged_batches_default_arithmetic_equals_native(B):
+    """engine.MVAEInference at batch sizes that are no multiple of a GEMM tile (and one below every plane kernel's work threshold): the
+    default arithmetic against the native-fp32 engine on the same Philox stream, every modality subset; replays included."""
+    from mmdyn_hip.engine import MVAEInference
+    from mmdyn_hip.utils.seeded_init import seeded_running_stats
+    sd = seeded_running_stats(seeded_state_dict(state_dict_shapes("cnn-mvae", use_pose=True), 0), 7)
+    m = T.build("cnn-mvae", True, True, DEV)
+    m.load_state_dict(sd)
+    m.eval()
+    inputs, _ = seeded_batch(B, 44)
+    gi = [x.to(DEV) for x in inputs]
+    engs = [MVAEInference(m, seed=9), MVAEInference(m, precision="fp32", seed=9)]
+    try:
+        for x, pose in (([gi[0], gi[1]], gi[2]), ([None, gi[1]], gi[2]), ([gi[0], None], None)):
+            outs = []
+            for e in engs:
+                for _ in range(2):                     # (eager capture pass, then a replay; both engines draw the same z each time)
+                    o = [None if t is None else t.clone() for t in e(x, pose=pose)]
+                outs.append(o)
+            a, b = outs
+            torch.testing.assert_close(a[3], b[3], rtol=1e-4, atol=3e-5)
+            torch.testing.assert_close(a[4], b[4], rtol=1e-4, atol=3e-5)
+            for i in (0, 1, 2):
+                if a[i] is not None:
+                    assert tuple(a[i].shape) == tuple(b[i].shape)
+                    assert float((a[i] - b[i]).norm() / (b[i].norm() + 1e-30)) < 2e-4, (B, i)
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_data_parallel_schedule_two_ranks_on_one_gpu():
     """``bench.py --gpus 2`` with both ranks on this one GPU and the collectives over gloo (MMDYN_BENCH_REHEARSE_ONE_GPU=1): the real
     kernels and HIP graphs under the data-parallel schedule -- gradient buckets reduced between the graph rows, rank-0 broadcast,
